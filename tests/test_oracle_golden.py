@@ -1,0 +1,150 @@
+"""Pin the CPU oracle (oracle/w2v2_oracle.py) against the golden vectors that were produced by
+running the reference itself (tools/make_goldens.py).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import w2v2_oracle as O
+from conftest import GOLDEN, rel_l2
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def test_tiny_all_stages_and_grads():
+    g = load("g1_tiny.npz")
+    cfg = O.OracleConfig.tiny()
+    sd = {k: v.clone().requires_grad_(True) for k, v in O.make_state_dict(cfg, 20211).items()}
+    wav, label, mask = T(g["wav"]), T(g["label"]), T(g["mask"])
+    out, st = O.wav2vec2_forward(wav[:, 0, :], sd, cfg, mask_time_indices=mask, return_stages=True)
+    for k in ("conv_out", "proj", "pos_conv", "enc_in", "layer0", "layer1"):
+        assert rel_l2(st[k].detach(), g["stage." + k]) < 2e-5, k
+    assert rel_l2(out.detach(), g["last_hidden"]) < 2e-5
+    emb = O.mean_std_pool(out)
+    assert rel_l2(emb.detach(), g["embedding"]) < 2e-5
+    W = O.synth_tensor("loss_fn.fc_weights", (10, 2 * cfg.hidden_size), 20211).requires_grad_(True)
+    loss, sm = O.aam_softmax(emb, W, label, 0.2, 30.0)
+    assert abs(float(loss) - float(g["loss"])) < 1e-4
+    assert rel_l2(sm.detach(), g["softmax"]) < 1e-4
+    loss.backward()
+    assert rel_l2(W.grad, g["grad.loss_fn.fc_weights"]) < 1e-4
+    for n, p in sd.items():
+        ref = g["grad." + n]
+        got = p.grad if p.grad is not None else torch.zeros_like(p)
+        # k_proj.bias (softmax shift-invariance) etc. have analytically-zero grads -> abs floor
+        err = float(np.linalg.norm(got.numpy().astype(np.float64) - ref))
+        assert err <= 2e-4 * float(np.linalg.norm(ref)) + 1e-6, n
+    ce_w = O.synth_tensor("fc_list.0.0.weight", (10, 2 * cfg.hidden_size), 20211)
+    ce_b = O.synth_tensor("fc_list.0.0.bias", (10,), 20211)
+    ce_loss, ce_sm = O.ce_head(emb.detach(), ce_w, ce_b, label)
+    assert abs(float(ce_loss) - float(g["ce.loss"])) < 1e-4
+    assert rel_l2(ce_sm, g["ce.softmax"]) < 1e-4
+
+
+def test_tiny_eval_pools_and_cls():
+    g = load("g1_tiny.npz")
+    cfg = O.OracleConfig.tiny()
+    sd = O.make_state_dict(cfg, 20211)
+    wav = T(g["wav"])
+    with torch.no_grad():
+        for pool in ("mean+std", "mean", "max", "first", "middle", "last", "quantile", "first+cls"):
+            e = O.speaker_embedding(wav, sd, cfg, pooling=pool)
+            assert rel_l2(e, g["eval." + pool]) < 2e-5, pool
+        h = O.wav2vec2_forward(wav[:, 0], sd, cfg, insert_cls_token=True)
+    assert h.shape[1] == g["eval.last_hidden"].shape[1] + 1
+    assert rel_l2(h, g["eval.cls.last_hidden"]) < 2e-5
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(GOLDEN, "g2_base.npz")), reason="no base golden")
+def test_base_config_embeddings_and_grad_norms():
+    g = load("g2_base.npz")
+    cfg = O.OracleConfig.base()
+    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    sd = {k: v.clone().requires_grad_(True) for k, v in O.make_state_dict(cfg, 20211).items()}
+    wav, label = O.synth_batch(2, 48000, 5994, seed=42133724)
+    assert np.array_equal(label.numpy(), g["label"])
+    with torch.no_grad():
+        e = O.speaker_embedding(wav, sd, cfg, "mean+std")
+        assert rel_l2(e, g["eval.mean+std"]) < 1e-4
+        e = O.speaker_embedding(wav, sd, cfg, "first+cls")
+        assert rel_l2(e, g["eval.first+cls"]) < 1e-4
+    mask = T(g["mask"])
+    emb = O.speaker_embedding(wav, sd, cfg, "mean+std", mask_time_indices=mask)
+    assert rel_l2(emb.detach(), g["train.embedding"]) < 1e-4
+    W = O.synth_tensor("loss_fn.fc_weights", (5994, 1536), 20211).requires_grad_(True)
+    loss, sm = O.aam_softmax(emb, W, label, 0.2, 30.0)
+    assert abs(float(loss) - float(g["train.loss"])) < 1e-3 * abs(float(g["train.loss"]))
+    assert rel_l2(sm.detach()[:, ::37], g["train.softmax.sample"]) < 1e-3
+    loss.backward()
+    norms = dict(zip(g["grad_names"].tolist(), g["grad_norms"].tolist()))
+    grads = dict(sd)
+    grads["loss_fn.fc_weights"] = W
+    for n, ref in norms.items():
+        got = float(grads[n].grad.double().norm()) if grads[n].grad is not None else 0.0
+        floor = 1e-6 * max(norms.values())        # analytically-zero grads (k_proj.bias) are rounding noise
+        assert abs(got - ref) <= 2e-3 * ref + floor, (n, got, ref)
+        head = grads[n].grad.flatten()[:32] if grads[n].grad is not None else torch.zeros(32)
+        assert np.allclose(head.numpy(), g["gradhead." + n], rtol=5e-3, atol=2e-3 * ref / np.sqrt(grads[n].numel()) + floor), n
+
+
+def test_aam_known_answers():
+    g = load("g4_aam.npz")
+    for margin, scale in ((0.2, 30.0), (0.3, 15.0)):
+        k = f"m{margin}_s{scale}."
+        x = T(g["x"]).requires_grad_(True)
+        W = T(g["W"]).requires_grad_(True)
+        loss, sm = O.aam_softmax(x, W, T(g["label"]), margin, scale)
+        loss.backward()
+        assert abs(float(loss) - float(g[k + "loss"])) < 1e-5
+        assert np.allclose(sm.detach().numpy(), g[k + "softmax"], atol=1e-6)
+        # row 0 has cos == -1 exactly: the reference's autograd yields NaN there (0 * inf through the
+        # unselected sqrt branch); the oracle reproduces it bit-for-bit.
+        assert np.isnan(g[k + "dx"][0]).all()
+        assert np.allclose(x.grad.numpy(), g[k + "dx"], atol=1e-5, equal_nan=True)
+        assert np.allclose(W.grad.numpy(), g[k + "dW"], atol=1e-5, equal_nan=True)
+
+
+def test_pooling_goldens_incl_edges():
+    g = load("g5_pool.npz")
+    for name in ("small", "t1", "long"):
+        x = T(g[name + ".x"]).requires_grad_(True)
+        y = O.mean_std_pool(x)
+        assert np.allclose(y.detach().numpy(), g[name + ".mean+std"], atol=1e-5, equal_nan=True), name
+        if name == "t1":
+            assert np.isnan(g["t1.mean+std"][:, :8]).all()     # unbiased std over T=1 is NaN (torch)
+        else:
+            (y * T(g[name + ".upstream"])).sum().backward()
+            assert np.allclose(x.grad.numpy(), g[name + ".dx"], atol=1e-6)
+        assert np.allclose(O.mean_pool(x).detach().numpy(), g[name + ".mean"], atol=1e-6)
+        assert np.array_equal(O.max_pool(x).detach().numpy(), g[name + ".max"])
+        assert np.array_equal(O.index_pool(x, "first").detach().numpy(), g[name + ".first"])
+        assert np.array_equal(O.index_pool(x, "middle").detach().numpy(), g[name + ".middle"])
+
+
+def test_eer_mdc_cosine_normaliser():
+    g = load("g6_eval.npz")
+    eer, thr = O.calculate_eer(g["gt"], g["scores"])
+    assert abs(eer - float(g["eer"])) < 1e-9 and abs(thr - float(g["eer_thr"])) < 1e-9
+    mdc, mthr = O.calculate_mdc(g["gt"], g["scores"])
+    assert abs(mdc - float(g["mdc"])) < 1e-12 and abs(mthr - float(g["mdc_thr"])) < 1e-12
+    s = O.cosine_scores(T(g["cos_a"]), T(g["cos_b"]))
+    assert np.allclose(s.numpy(), g["cos01"], atol=1e-6)
+    assert np.allclose(O.normalise_waveform(T(g["norm_in"])).numpy(), g["norm_out"], atol=1e-6)
+
+
+def test_one_cycle_and_adam():
+    g = load("g8_optim.npz")
+    p = T(g["p0"]).clone()
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    for i in range(100):
+        lr, b1 = O.one_cycle(i, 100, 1e-4)
+        assert abs(lr - g["lr"][i]) < 1e-12 and abs(b1 - g["beta1"][i]) < 1e-9, i
+        O.adam_step(p, T(g["grads"][i]), m, v, i + 1, lr, b1)
+        assert np.allclose(p.numpy(), g["params"][i], atol=1e-7), i

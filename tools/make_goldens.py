@@ -1,0 +1,349 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by RUNNING THE REFERENCE (authoring container only).
+
+Imports /root/reference (read-only) with the three shims of SURVEY.md App. C, builds the HF
+``Wav2Vec2Model`` through the reference's own ``Wav2Vec2WrapperModule``, overwrites every parameter
+from the name-keyed PCG64 generator in ``oracle.w2v2_oracle.synth_tensor`` and dumps small input /
+expected-output vectors.  The fixtures are data only; no reference source travels.
+
+    PYTHONDONTWRITEBYTECODE=1 python tools/make_goldens.py
+"""
+import os
+import sys
+import types
+
+os.environ.setdefault("PYTHONDONTWRITEBYTECODE", "1")
+sys.dont_write_bytecode = True
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+torch.manual_seed(0)
+torch.set_num_threads(8)
+
+# ----------------------------------------------------------------------------- shims
+REF = "/root/reference"
+sys.path.insert(0, REF)
+torch.cuda.Device = torch.device                                   # src/models/wav2vec2.py:28
+pl = types.ModuleType("pytorch_lightning")
+
+
+class LightningModule(torch.nn.Module):
+    pass
+
+
+pl.LightningModule, pl.Trainer = LightningModule, object
+sys.modules["pytorch_lightning"] = pl
+for n in ("hurry", "hurry.filesize"):
+    sys.modules[n] = types.ModuleType(n)
+sys.modules["hurry.filesize"].size = lambda *a, **k: ""
+sys.modules.setdefault("seaborn", types.ModuleType("seaborn"))     # debug plots only
+sb = "speechbrain.lobes.models.ECAPA_TDNN"
+parts = sb.split(".")
+for i in range(1, 5):
+    sys.modules.setdefault(".".join(parts[:i]), types.ModuleType(".".join(parts[:i])))
+sys.modules[sb].AttentiveStatisticsPooling = object
+
+from transformers import Wav2Vec2Config, Wav2Vec2Model  # noqa: E402
+from transformers.models.wav2vec2 import modeling_wav2vec2 as hf_mod  # noqa: E402
+
+from oracle import w2v2_oracle as O  # noqa: E402
+
+_CFG_EXTRA = {}
+
+
+def _from_config(hid, **ov):
+    ov.pop("gradient_checkpointing", None)
+    return Wav2Vec2Model(Wav2Vec2Config(attn_implementation="eager", **_CFG_EXTRA, **ov))
+
+
+Wav2Vec2Model.from_pretrained = staticmethod(_from_config)
+
+from src.models.wav2vec2 import Wav2Vec2WrapperModule, Wav2Vec2RegularisationConfig  # noqa: E402
+from src.layers.pooling import (MeanStdStatPool1D, MeanStatPool1D, IndexPool1D, MaxPool1D,  # noqa: E402
+                                QuantilePool1D)
+from src.optim.loss import AngularAdditiveMarginSoftMaxLoss, CrossEntropyLoss  # noqa: E402
+from src.eval_metrics import calculate_eer, calculate_mdc  # noqa: E402
+from src.evaluation.speaker.cosine_distance import compute_cosine_scores  # noqa: E402
+from src.data.preprocess.input_normalisation import InputNormalizer2D  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+os.makedirs(OUT, exist_ok=True)
+
+
+def hf_extra(cfg: O.OracleConfig):
+    return dict(conv_dim=list(cfg.conv_dim), hidden_size=cfg.hidden_size,
+                num_hidden_layers=cfg.num_hidden_layers,
+                num_attention_heads=cfg.num_attention_heads,
+                intermediate_size=cfg.intermediate_size,
+                num_conv_pos_embeddings=cfg.num_conv_pos_embeddings,
+                num_conv_pos_embedding_groups=cfg.num_conv_pos_embedding_groups)
+
+
+def build_reference_wrapper(cfg: O.OracleConfig, seed: int, cls_token=False):
+    """The reference's wrapper (src/models/wav2vec2.py:97-146) with dropouts/layerdrop/masking = 0."""
+    global _CFG_EXTRA
+    _CFG_EXTRA = hf_extra(cfg)
+    reg = Wav2Vec2RegularisationConfig(activation_dropout=0.0, attention_dropout=0.0,
+                                       feat_proj_dropout=0.0, hidden_dropout=0.0, layerdrop=0.0,
+                                       mask_time_prob=0.05)   # keep masked_spec_embed alive
+    w = Wav2Vec2WrapperModule("facebook/wav2vec2-base", False, reg, insert_clc_token=cls_token)
+    sd = O.make_state_dict(cfg, seed)
+    missing, unexpected = w.model.load_state_dict(sd, strict=True), None
+    return w, sd
+
+
+def to_np(d):
+    return {k: (v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v))
+            for k, v in d.items()}
+
+
+# ----------------------------------------------------------------------------- G1 tiny, all stages + grads
+def golden_tiny():
+    cfg = O.OracleConfig.tiny()
+    B, N, C = 2, 4000, 10
+    w, sd = build_reference_wrapper(cfg, seed=20211)
+    wav, label = O.synth_batch(B, N, C, seed=42133724)
+    T = cfg.num_frames(N)
+    rng = np.random.Generator(np.random.PCG64(7))
+    mask = np.zeros((B, T), dtype=bool)
+    for b in range(B):
+        s = rng.integers(0, T - 3)
+        mask[b, s:s + 3] = True
+    mask_t = torch.from_numpy(mask)
+
+    # the ~40 lines of tensor logic of Wav2vec2FCModule (wav2vec2_fc.py:414-438) restated, since the
+    # LightningModule itself needs PL/torchmetrics: squeeze -> wrapper -> transpose -> pool
+    w.train()                       # dropouts are all 0; mask injected
+    stages = {}
+    hooks = []
+
+    def grab(name):
+        def f(_m, _i, o):
+            stages[name] = (o[0] if isinstance(o, tuple) else o).detach().clone()
+        return f
+    m = w.model
+    hooks.append(m.feature_extractor.register_forward_hook(grab("conv_out_bct")))
+    hooks.append(m.feature_projection.register_forward_hook(grab("proj")))
+    hooks.append(m.encoder.pos_conv_embed.register_forward_hook(grab("pos_conv")))
+    hooks.append(m.encoder.layer_norm.register_forward_hook(grab("enc_in")))
+    for l, layer in enumerate(m.encoder.layers):
+        hooks.append(layer.register_forward_hook(grab(f"layer{l}")))
+    x = torch.squeeze(wav)                                    # wav2vec2_fc.py:418-419
+    out = m(x, mask_time_indices=mask_t).last_hidden_state.transpose(1, 2)   # models/wav2vec2.py:71-74
+    emb_in = out.transpose(2, 1)                              # wav2vec2_fc.py:428
+    emb = MeanStdStatPool1D(dim_to_reduce=1)(emb_in)
+    loss_fn = AngularAdditiveMarginSoftMaxLoss(2 * cfg.hidden_size, C, margin=0.2, scale=30)
+    aam_w = O.synth_tensor("loss_fn.fc_weights", (C, 2 * cfg.hidden_size), 20211)
+    with torch.no_grad():
+        loss_fn.fc_weights.copy_(aam_w)
+    loss, pred = loss_fn(emb, label)
+    loss.backward()
+    for h in hooks:
+        h.remove()
+    g = {"wav": wav, "label": label, "mask": mask_t, "embedding": emb, "loss": loss,
+         "softmax": pred, "last_hidden": emb_in,
+         "stage.conv_out": stages["conv_out_bct"].transpose(1, 2), "stage.proj": stages["proj"],
+         "stage.pos_conv": stages["pos_conv"], "stage.enc_in": stages["enc_in"]}
+    for l in range(cfg.num_hidden_layers):
+        g[f"stage.layer{l}"] = stages[f"layer{l}"]
+    for n, p in m.named_parameters():
+        g["grad." + n] = p.grad if p.grad is not None else torch.zeros_like(p)
+    g["grad.loss_fn.fc_weights"] = loss_fn.fc_weights.grad
+
+    # CE head (config 1): nn.Linear + CrossEntropyLoss (wav2vec2_fc.py:199-210, cross_entropy.py:27-31)
+    ce_w = O.synth_tensor("fc_list.0.0.weight", (C, 2 * cfg.hidden_size), 20211)
+    ce_b = O.synth_tensor("fc_list.0.0.bias", (C,), 20211)
+    ce_loss, ce_pred = CrossEntropyLoss()(emb.detach() @ ce_w.t() + ce_b, label)
+    g["ce.loss"], g["ce.softmax"] = ce_loss, ce_pred
+
+    # eval-mode embeddings of the other pools (f1 rows)
+    w.eval()
+    with torch.no_grad():
+        h = w(x).transpose(2, 1)
+        g["eval.last_hidden"] = h
+        g["eval.mean+std"] = MeanStdStatPool1D(1)(h)
+        g["eval.mean"] = MeanStatPool1D(1)(h)
+        g["eval.max"] = MaxPool1D(1)(h)
+        g["eval.first"] = IndexPool1D("first", 1)(h)
+        g["eval.middle"] = IndexPool1D("middle", 1)(h)
+        g["eval.last"] = IndexPool1D("last", 1)(h)
+        g["eval.quantile"] = QuantilePool1D(1)(h)
+    wc, _ = build_reference_wrapper(cfg, seed=20211, cls_token=True)
+    wc.eval()
+    # the reference hard-codes 768 for the CLS token (quirk Q5): patch the size for the tiny model only
+    import src.models.wav2vec2 as refw
+    orig_ones = refw.t.ones
+    refw.t.ones = lambda shape, **kw: orig_ones((shape[0], shape[1], cfg.hidden_size), **kw)
+    try:
+        with torch.no_grad():
+            hc = wc(x).transpose(2, 1)
+    finally:
+        refw.t.ones = orig_ones
+    g["eval.cls.last_hidden"] = hc
+    g["eval.first+cls"] = IndexPool1D("first+cls", 1)(hc)
+    np.savez_compressed(os.path.join(OUT, "g1_tiny.npz"), **to_np(g))
+    print("g1_tiny: loss", float(loss), "T", T, "keys", len(g))
+
+
+# ----------------------------------------------------------------------------- G2/G3 base config
+def golden_base():
+    cfg = O.OracleConfig.base()
+    B, N = 2, 48000
+    w, sd = build_reference_wrapper(cfg, seed=20211)
+    wav, label = O.synth_batch(B, N, 5994, seed=42133724)
+    x = torch.squeeze(wav)
+    g = {"label": label}
+    w.eval()
+    with torch.no_grad():
+        h = w(x).transpose(2, 1)
+        g["eval.mean+std"] = MeanStdStatPool1D(1)(h)
+        g["eval.last_hidden.sample"] = h[:, ::16, ::16].contiguous()
+    wc, _ = build_reference_wrapper(cfg, seed=20211, cls_token=True)
+    wc.eval()
+    with torch.no_grad():
+        hc = wc(x).transpose(2, 1)
+        g["eval.first+cls"] = IndexPool1D("first+cls", 1)(hc)
+
+    # G3: train mode, injected mask, dropouts/layerdrop 0, AAM C=5994 and CE C=1211
+    T = cfg.num_frames(N)
+    np.random.seed(7)
+    mask = hf_mod._compute_mask_indices((B, T), mask_prob=0.05, mask_length=10, min_masks=2)
+    mask_t = torch.from_numpy(mask)
+    g["mask"] = mask_t
+    w.train()
+    m = w.model
+    out = m(x, mask_time_indices=mask_t).last_hidden_state
+    emb = MeanStdStatPool1D(1)(out)
+    loss_fn = AngularAdditiveMarginSoftMaxLoss(1536, 5994, margin=0.2, scale=30)
+    with torch.no_grad():
+        loss_fn.fc_weights.copy_(O.synth_tensor("loss_fn.fc_weights", (5994, 1536), 20211))
+    loss, pred = loss_fn(emb, label)
+    loss.backward()
+    g["train.embedding"] = emb
+    g["train.loss"] = loss
+    g["train.softmax.sample"] = pred[:, ::37].contiguous()
+    g["train.softmax.label"] = pred.gather(1, label.view(-1, 1))
+    names, norms = [], []
+    for n, p in list(m.named_parameters()) + [("loss_fn.fc_weights", loss_fn.fc_weights)]:
+        gr = p.grad if p.grad is not None else torch.zeros_like(p)
+        names.append(n)
+        norms.append(float(gr.double().norm()))
+        g["gradhead." + n] = gr.flatten()[:32].clone()
+    g["grad_names"] = np.array(names)
+    g["grad_norms"] = np.array(norms)
+    lab_ce = label % 1211
+    ce_w = O.synth_tensor("fc_list.0.0.weight", (1211, 1536), 20211)
+    ce_b = O.synth_tensor("fc_list.0.0.bias", (1211,), 20211)
+    ce_loss, ce_pred = CrossEntropyLoss()(emb.detach() @ ce_w.t() + ce_b, lab_ce)
+    g["ce.loss"], g["ce.softmax.label"] = ce_loss, ce_pred.gather(1, lab_ce.view(-1, 1))
+    np.savez_compressed(os.path.join(OUT, "g2_base.npz"), **to_np(g))
+    print("g2_base: loss", float(loss), "emb norm", float(emb.norm()))
+
+
+# ----------------------------------------------------------------------------- G4 AAM known answers
+def golden_aam():
+    g = {}
+    D, C, B = 24, 7, 9
+    rng = np.random.Generator(np.random.PCG64(4))
+    W = torch.from_numpy(rng.standard_normal((C, D)).astype(np.float32))
+    x = torch.from_numpy(rng.standard_normal((B, D)).astype(np.float32))
+    label = torch.from_numpy(rng.integers(0, C, size=(B,)).astype(np.int64))
+    x[0] = -3.0 * W[label[0]]                 # cos = -1  -> (cos - th) <= 0 branch, clamp edge
+    x[1] = 2.0 * W[label[1]]                  # cos = +1  -> sine clamp edge
+    x[2] = -W[label[2]] + 0.05 * x[2]         # cos slightly above -1, still below th=-0.98
+    for margin, scale in ((0.2, 30.0), (0.3, 15.0)):
+        fn = AngularAdditiveMarginSoftMaxLoss(D, C, margin=margin, scale=scale)
+        with torch.no_grad():
+            fn.fc_weights.copy_(W)
+        xi = x.clone().requires_grad_(True)
+        loss, pred = fn(xi, label)
+        loss.backward()
+        k = f"m{margin}_s{scale}."
+        g[k + "loss"], g[k + "softmax"] = loss, pred
+        g[k + "dx"], g[k + "dW"] = xi.grad, fn.fc_weights.grad
+    g.update(x=x, W=W, label=label)
+    np.savez_compressed(os.path.join(OUT, "g4_aam.npz"), **to_np(g))
+    print("g4_aam ok")
+
+
+# ----------------------------------------------------------------------------- G5 pooling
+def golden_pool():
+    g = {}
+    rng = np.random.Generator(np.random.PCG64(5))
+    for name, shape in (("small", (3, 11, 20)), ("t1", (2, 1, 8)), ("long", (1, 7249, 16))):
+        x = torch.from_numpy((rng.standard_normal(shape) * 2 + 0.5).astype(np.float32))
+        xi = x.clone().requires_grad_(True)
+        y = MeanStdStatPool1D(1)(xi)
+        g[name + ".x"], g[name + ".mean+std"] = x, y
+        if shape[1] > 1:
+            up = torch.from_numpy(rng.standard_normal(tuple(y.shape)).astype(np.float32))
+            (y * up).sum().backward()
+            g[name + ".upstream"], g[name + ".dx"] = up, xi.grad
+        g[name + ".mean"] = MeanStatPool1D(1)(x)
+        g[name + ".max"] = MaxPool1D(1)(x)
+        g[name + ".first"] = IndexPool1D("first", 1)(x)
+        g[name + ".middle"] = IndexPool1D("middle", 1)(x)
+    np.savez_compressed(os.path.join(OUT, "g5_pool.npz"), **to_np(g))
+    print("g5_pool ok")
+
+
+# ----------------------------------------------------------------------------- G6/G7 EER, minDCF, cosine
+def golden_eval():
+    g = {}
+    rng = np.random.Generator(np.random.PCG64(6))
+    n = 1000
+    gt = rng.integers(0, 2, size=n)
+    sc = np.clip(0.5 + 0.18 * rng.standard_normal(n) + 0.15 * (gt - 0.5), 0, 1)
+    eer, thr = calculate_eer(gt.tolist(), sc.tolist())
+    mdc, mthr = calculate_mdc(gt.tolist(), sc.tolist())
+    g.update(gt=gt, scores=sc, eer=eer, eer_thr=thr, mdc=mdc, mdc_thr=mthr)
+    a = torch.from_numpy(rng.standard_normal((50, 32)).astype(np.float32))
+    b = torch.from_numpy(rng.standard_normal((50, 32)).astype(np.float32))
+    b[:5] = a[:5] * 2
+    b[5:8] = -a[5:8]
+    cos = np.array(compute_cosine_scores(a, b))
+    g.update(cos_a=a, cos_b=b, cos=cos, cos01=np.clip((cos + 1) / 2, 0, 1))   # evaluator.py:81
+    # input normaliser (input_normalisation.py:54-67)
+    wav = torch.from_numpy((rng.standard_normal((1, 4000)) * 0.1 + 0.02).astype(np.float32))
+    g["norm_in"] = wav
+    g["norm_out"] = InputNormalizer2D.normalize(wav, False)[0]   # normalize_over_channels: false
+    np.savez_compressed(os.path.join(OUT, "g6_eval.npz"), **to_np(g))
+    print("g6_eval: eer", eer, "mdc", mdc)
+
+
+# ----------------------------------------------------------------------------- G8 OneCycleLR + Adam, masks
+def golden_optim():
+    g = {}
+    p = torch.nn.Parameter(torch.linspace(-1, 1, 16))
+    opt = torch.optim.Adam([p], lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0)
+    sch = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=1e-4, total_steps=100, div_factor=25)
+    rng = np.random.Generator(np.random.PCG64(8))
+    lrs, b1s, ps, gs = [], [], [], []
+    for i in range(100):
+        lrs.append(opt.param_groups[0]["lr"])
+        b1s.append(opt.param_groups[0]["betas"][0])
+        gr = torch.from_numpy(rng.standard_normal(16).astype(np.float32))
+        p.grad = gr.clone()
+        opt.step()
+        sch.step()
+        gs.append(gr.numpy())
+        ps.append(p.detach().clone().numpy())
+    g.update(lr=np.array(lrs), beta1=np.array(b1s), grads=np.array(gs), params=np.array(ps),
+             p0=torch.linspace(-1, 1, 16).numpy())
+    # SpecAugment time masks from HF's sampler (HF:101-217) under np.random.seed
+    for seed, shape in ((7, (66, 149)), (11, (4, 249))):
+        np.random.seed(seed)
+        g[f"mask.seed{seed}"] = hf_mod._compute_mask_indices(shape, mask_prob=0.05, mask_length=10,
+                                                            min_masks=2)
+    np.savez_compressed(os.path.join(OUT, "g8_optim.npz"), **to_np(g))
+    print("g8_optim ok")
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["tiny", "base", "aam", "pool", "eval", "optim"]
+    for wname in which:
+        {"tiny": golden_tiny, "base": golden_base, "aam": golden_aam, "pool": golden_pool,
+         "eval": golden_eval, "optim": golden_optim}[wname]()
