@@ -1,0 +1,213 @@
+/*
+ * w2v2_hip.h -- C ABI of libw2v2hip.so: hand-written gfx950 (MI355X / CDNA4) kernels for the
+ * wav2vec2 speaker-recognition training path of nikvaessen/w2v2-speaker.
+ *
+ * The reference has NO native / FFI interface: its seam is a set of torch
+ * nn.Module contracts whose arithmetic lives in HuggingFace transformers / torch ATen.  Every entry
+ * point below therefore cites the reference (or HF) call site whose device arithmetic it replaces:
+ *   ref: = /root/reference/...      HF: = transformers/models/wav2vec2/modeling_wav2vec2.py (5.15.0)
+ *
+ * Conventions
+ *   - plain C: pointers + sizes only, no torch types.  All pointers are DEVICE pointers unless the
+ *     name ends in _host.  The caller owns every buffer (inputs, outputs, saved-for-backward,
+ *     workspace); the library never allocates or frees device memory and keeps no pointer past a call.
+ *   - every call only ENQUEUES work on `stream` (a hipStream_t passed as void*); no implicit sync.
+ *   - return 0 on success, negative on error; w2v2_last_error() gives the message (thread local).
+ *   - dtype codes: W2V2_F32 = 0, W2V2_BF16 = 1.  "act dtype" is the storage type of activations;
+ *     statistics, reductions, biases, LayerNorm/GroupNorm parameters and gradients are always f32.
+ *   - activations are channels-last: [B, T, C] row-major ("tokens x channels").
+ */
+#ifndef W2V2_HIP_H
+#define W2V2_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define W2V2_F32 0
+#define W2V2_BF16 1
+
+int w2v2_version(void);
+const char* w2v2_last_error(void);
+
+/* ------------------------------------------------------------------------------------------ GEMM
+ * One tiled MFMA GEMM serves every matmul-shaped op of the path (HF:520-526 q/k/v_proj, HF:544
+ * out_proj, HF:565-572 FFN, HF:429-435 projection, HF:254-272 conv layers 1-6 as implicit GEMM,
+ * HF:326-368 grouped pos-conv as implicit GEMM, attention score / context products HF:438-463,
+ * ref: src/optim/loss/aam_softmax.py:55 F.linear) and all of their backward products.
+ *
+ *   C[z][m][n] = epilogue( alpha * sum_k A[z](m,k) * B[z](n,k) )        z = 0..batch-1
+ *
+ * Operand storage: a 2-D array [outer][inner] with `inner` contiguous and outer stride `ld`
+ * (elements).  trans = 0: outer = m (or n), inner = k.   trans = 1: outer = k, inner = m (or n).
+ * The outer index may be segmented (implicit im2col of a strided conv over [B, L, C] activations):
+ *   addr(outer) = (outer / seg_len) * seg_stride + (outer % seg_len) * ld      (seg_len = 0: plain)
+ * Batch offsets are two-level: z -> (z / batch_inner, z % batch_inner) * (stride0, stride1).
+ */
+typedef struct {
+  const void* ptr;
+  int64_t ld;
+  int64_t seg_len, seg_stride;
+  int64_t stride0, stride1;
+  int32_t trans;
+  int32_t _pad;
+} w2v2_operand;
+
+enum {
+  W2V2_EPI_NONE = 0,      /* C = alpha*acc                                              */
+  W2V2_EPI_BIAS = 1,      /* C = alpha*acc + bias[n]                                    */
+  W2V2_EPI_BIAS_GELU = 2, /* pre = alpha*acc + bias[n]; aux = pre (if aux); C = gelu(pre) */
+  W2V2_EPI_GELU_BWD = 3,  /* C = alpha*acc * gelu'(aux[m][n])                           */
+  W2V2_EPI_ADD = 4,       /* C = alpha*acc + aux[m][n]   (residual / gradient join)     */
+  W2V2_EPI_SCALE_RC = 5   /* C = alpha*acc * row_scale[m] * col_scale[n]  (AAM cosine)  */
+};
+
+typedef struct {
+  int32_t M, N, K;
+  int32_t batch, batch_inner; /* batch_inner >= 1 */
+  int32_t dtype_ab;           /* dtype of A and B                                        */
+  int32_t dtype_c;            /* dtype of C and aux                                      */
+  int32_t epilogue;
+  w2v2_operand A, B;
+  void* C;
+  int64_t ldc, c_stride0, c_stride1;
+  void* aux;
+  int64_t ldaux, aux_stride0, aux_stride1;
+  const float* bias;       /* [N] f32 (EPI_BIAS*)                                         */
+  int64_t bias_stride1;    /* bias offset per (z % batch_inner)                           */
+  const float* row_scale;  /* [M] f32, const float* col_scale [N] (EPI_SCALE_RC)          */
+  const float* col_scale;
+  float alpha;
+  int32_t split_k;         /* >1: K split over grid.y, partial sums atomically ADDED into an
+                              f32 C the caller zeroed (EPI_NONE only)                     */
+  int32_t accumulate;      /* 1: C += result (f32 C, atomics; implied by split_k>1)       */
+  int32_t _pad;
+} w2v2_gemm_desc;
+
+int w2v2_gemm(const w2v2_gemm_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------ conv feature extractor
+ * Layer 0 of HF:382-419: Conv1d(1->C,k,stride,no bias) + GroupNorm(C groups == per-(b,c) over time,
+ * biased var, eps) + GELU(erf)  (HF:302-323).  wav [B,N] f32 -> y [B,L,C] act dtype, channels-last.
+ * Two passes, conv recomputed in both so the [B,L,C] pre-norm tensor never touches HBM:
+ *   stats: stats[b][c] = {sum, sumsq} (f64, caller zeroes)      apply: normalise + GELU + store. */
+int w2v2_conv0_stats(const float* wav, const float* w /*[C][k]*/, double* stats /*[B][C][2]*/,
+                     int B, int N, int C, int k, int stride, void* stream);
+int w2v2_conv0_apply(const float* wav, const float* w, const double* stats, const float* gamma,
+                     const float* beta, void* y, int dtype, int B, int N, int C, int k, int stride,
+                     float eps, void* stream);
+/* HF conv weight [Cout][Cin][k] (f32) -> implicit-GEMM operand [Cout][k][Cin] (dtype). */
+int w2v2_pack_conv_weight(const float* w, void* out, int dtype, int Cout, int Cin, int k, void* stream);
+
+/* ----------------------------------------------------------------------------- LayerNorm family
+ * y = LN(x + dropout(r)) * gamma + beta   (HF:429 feature_projection.layer_norm, HF:691-692 encoder
+ * prologue, HF:596-601 post-LN residual blocks).  r may be NULL.  When r != NULL the pre-norm sum
+ * s = x + dropout(r) is written back INTO r (saved for backward, no extra buffer).
+ * Dropout (HF nn.Dropout) keeps element i when rand(seed, i) >= p and scales by 1/(1-p). */
+int w2v2_layernorm_fwd(const void* x, void* r_inout, const float* gamma, const float* beta, void* y,
+                       float* mean, float* rstd, int M, int H, float eps, float drop_p,
+                       uint64_t seed, int dtype, void* stream);
+/* s = pre-norm input (x if r was NULL).  Outputs: ds (grad wrt s; may alias dy), d_r = ds*dropmask
+ * (only if drop_p > 0, else NULL), dgamma/dbeta ATOMICALLY ADDED (f32, caller zeroes). */
+int w2v2_layernorm_bwd(const void* dy, const void* s, const float* mean, const float* rstd,
+                       const float* gamma, void* ds, void* d_r, float* dgamma, float* dbeta, int M,
+                       int H, float drop_p, uint64_t seed, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------- elementwise */
+/* nn.Dropout fwd == bwd (same mask): y = x * keep(seed,i)/(1-p); in place allowed. */
+int w2v2_dropout(const void* x, void* y, int64_t n, float p, uint64_t seed, int dtype, void* stream);
+/* dx = dy * gelu'(pre)  (exact erf GELU, ACT2FN["gelu"]). */
+int w2v2_gelu_bwd(const void* dy, const void* pre, void* dx, int64_t n, int dtype, void* stream);
+/* y = x + a (gradient joins). */
+int w2v2_add(const void* x, const void* a, void* y, int64_t n, int dtype, void* stream);
+/* out[n] += sum_m x[m][n]   (bias gradients; f32 atomics, caller zeroes). */
+int w2v2_colsum(const void* x, int64_t ld, float* out, int M, int N, int dtype, void* stream);
+/* f32 -> act dtype cast (bf16 weight copies), and strided 2-D copy/convert. */
+int w2v2_cast(const float* x, void* y, int64_t n, int dtype, void* stream);
+/* SpecAugment time mask HF:1290-1292: h[m][:] = embed where mask[m].  Backward: d_embed += sum of
+ * masked rows of dh (atomics), masked rows of dh zeroed in place. */
+int w2v2_mask_fill(void* h, const uint8_t* mask, const float* embed, int M, int H, int dtype,
+                   void* stream);
+int w2v2_mask_fill_bwd(void* dh, const uint8_t* mask, float* d_embed, int M, int H, int dtype,
+                       void* stream);
+/* CLS token (ref: src/models/wav2vec2.py:128-140): y[b][0][:] = c, y[b][1+t][:] = x[b][t][:]. */
+int w2v2_prepend_token(const void* x, void* y, float c, int B, int T, int H, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------- pos-conv
+ * HF:326-379 grouped weight-normed Conv1d(H,H,K,pad=K/2,groups=G) as an implicit GEMM per group:
+ * regroup pads and splits channels  x [B,T,H] -> xg [B,G,T+K-1,H/G] (zero pad `pad_left` frames left).
+ * weightnorm_pack: w = g*v/||v||_(per tap) -> fwd operand wf[G][co][tap][ci] and the flipped
+ * operand wb[G][ci][K-1-tap][co] used by the data gradient; also returns inv norms.
+ * weightnorm_bwd: from dwf[G][co][tap][ci] (f32) -> dg[K], dv[H][H/G][K] (written, not added). */
+int w2v2_posconv_regroup(const void* x, void* xg, int B, int T, int H, int G, int K, int pad_left,
+                         int dtype, void* stream);
+int w2v2_weightnorm_pack(const float* g, const float* v, float* sumsq /*[K] scratch*/, void* wf,
+                         void* wb, int H, int G, int K, int dtype, void* stream);
+int w2v2_weightnorm_bwd(const float* g, const float* v, const float* sumsq, const float* dwf,
+                        float* dot /*[K] scratch*/, float* dg, float* dv, int H, int G, int K,
+                        void* stream);
+
+/* ------------------------------------------------------------------------------------ attention
+ * Unfused path (scores/context products go through w2v2_gemm): row softmax with dropout on the
+ * probabilities (HF:455-457).  s [rows][T] f32 scores (already scaled by d^-1/2 via alpha),
+ * p = softmax(s) (act dtype), p_drop = dropout(p) (only if drop_p > 0).
+ * bwd: dS = P * (dP - sum(dP*P)) with dP = dPdrop*mask/(1-p); result f32 -> act dtype ds. */
+int w2v2_softmax_fwd(const float* s, void* p, void* p_drop, int64_t rows, int T, int64_t ld,
+                     float drop_p, uint64_t seed, int dtype, void* stream);
+int w2v2_softmax_bwd(const float* dp_drop, const void* p, void* ds, int64_t rows, int T, int64_t ld,
+                     float drop_p, uint64_t seed, int dtype, void* stream);
+/* Fused multi-head self-attention over QKV [B,T,3,heads,d] (HF:438-548 minus the projections),
+ * one workgroup per (batch, head, query tile); saves row log-sum-exp for the backward.
+ * ctx [B,T,heads*d].  bwd writes dqkv [B,T,3,heads,d]. */
+int w2v2_attention_fwd(const void* qkv, void* ctx, float* lse, int B, int T, int heads, int d,
+                       float scale, float drop_p, uint64_t seed, int dtype, void* stream);
+int w2v2_attention_bwd(const void* qkv, const void* ctx, const void* dctx, const float* lse,
+                       void* dqkv, float* delta /*[B,heads,T] scratch*/, int B, int T, int heads,
+                       int d, float scale, float drop_p, uint64_t seed, int dtype, void* stream);
+
+/* -------------------------------------------------------------------------------------- pooling
+ * ref: src/layers/pooling.py:24-44,74-80,118-136.  x [B,T,H] act dtype -> out f32.
+ * mode 0: mean+std  -> [B,2H] = cat(std_unbiased, mean)  (std FIRST, quirk Q1)
+ * mode 1: mean      -> [B,H]       mode 2: max -> [B,H]
+ * mode 3: first     -> [B,H]       mode 4: last / "middle" (quirk Q2) -> [B,H] */
+int w2v2_pool_fwd(const void* x, float* out, int B, int T, int H, int mode, int dtype, void* stream);
+/* dx [B,T,H] act dtype from dout f32 and the forward output (std/mean reused; max needs x). */
+int w2v2_pool_bwd(const void* x, const float* out, const float* dout, void* dx, int B, int T, int H,
+                  int mode, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------- heads
+ * Row inverse L2 norms 1/max(||x||,1e-12) (F.normalize, ref: src/optim/loss/aam_softmax.py:55). */
+int w2v2_row_invnorm(const void* x, int64_t ld, float* inv, int rows, int cols, int dtype,
+                     void* stream);
+/* AAM margin + scale + softmax + CE (ref: aam_softmax.py:57-72) on cos [B][ldc] f32 (in: cosine).
+ * margin < 0 selects the plain CE head (ref: src/optim/loss/cross_entropy.py:27-31; `cos` holds
+ * logits, scale ignored).  Outputs: softmax [B][ldc] f32, loss_rows [B] f32 (mean is the caller's),
+ * and for the backward, with g = dLoss/dcos (loss = mean over B):
+ *   dcos_w[b][c] = g * inv_w[c]   (A operand of the embedding-gradient GEMM; inv_w NULL -> g)
+ *   dcos_x[b][c] = g * inv_x[b]   (A operand of the weight-gradient GEMM;    inv_x NULL -> g)
+ *   rowdot[b] = sum_c g*cos,  coldot[c] += sum_b g*cos (caller zeroes coldot); any may be NULL. */
+int w2v2_aam_softmax_fwd_bwd(const float* cos, const int64_t* label, float* softmax,
+                             float* loss_rows, void* dcos_w, void* dcos_x, const float* inv_x,
+                             const float* inv_w, float* rowdot, float* coldot, int B, int C,
+                             int64_t ldc, float margin, float scale, int dtype, void* stream);
+/* F.normalize backward: dx = inv[r] * (g[r] - x[r] * inv[r] * dot[r]);  g, dx f32 (dx written or
+ * added), x f32 or act dtype. */
+int w2v2_normalize_bwd(const float* g, const void* x, int64_t ldx, const float* inv,
+                       const float* dot, float* dx, int rows, int cols, int x_dtype, int add,
+                       void* stream);
+
+/* ------------------------------------------------------------------------------------ optimiser
+ * torch.optim.Adam (ref: config/optim/algo/adam.yaml, src/main.py:323-335) over one flat f32
+ * parameter arena; also refreshes the bf16 copy the GEMMs read (pb may be NULL).  grad_scale
+ * folds the 1/world_size of the data-parallel average. */
+int w2v2_adam_step(float* p, const float* g, float* m, float* v, void* pb, int64_t n, float lr,
+                   float beta1, float beta2, float eps, float bias_corr1, float bias_corr2,
+                   float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,124 @@
+"""CPU-only tests: the C-ABI library loads and exports every symbol the header declares, host logic
+(SpecAugment sampler, one-cycle schedule, flat parameter arena, bucketed all-reduce over gloo)."""
+import os
+import re
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, ROOT
+
+
+def test_library_exports_every_header_symbol():
+    from w2v2_speaker_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "w2v2_hip.h")).read()
+    declared = set(re.findall(r"\b(w2v2_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    lib = _lib.load()                      # dlopen works without a GPU
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/w2v2_hip.h but not exported"
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    assert lib.w2v2_version() >= 100
+
+
+def test_ops_refuse_cpu_tensors():
+    from w2v2_speaker_amd import ops
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.colsum(torch.zeros(4, 8), torch.zeros(8), 4, 8)
+
+
+def test_spec_augment_matches_hf_masks():
+    from w2v2_speaker_amd.spec_augment import compute_mask_indices
+    g = np.load(os.path.join(GOLDEN, "g8_optim.npz"))
+    for seed, shape in ((7, (66, 149)), (11, (4, 249))):
+        np.random.seed(seed)
+        m = compute_mask_indices(shape, 0.05, 10, min_masks=2)
+        assert np.array_equal(m, g[f"mask.seed{seed}"])
+        assert m.sum(axis=1).min() >= 10      # >= 1 span survives overlap
+
+
+def test_one_cycle_matches_torch_table():
+    from w2v2_speaker_amd.optim.schedule import OneCycle
+    g = np.load(os.path.join(GOLDEN, "g8_optim.npz"))
+    s = OneCycle(max_lr=1e-4, total_steps=100)
+    for i in range(100):
+        lr, b1 = s.at(i)
+        assert abs(lr - g["lr"][i]) < 1e-12 and abs(b1 - g["beta1"][i]) < 1e-9
+    with pytest.raises(ValueError):
+        s.at(100)
+
+
+def test_param_arena_layout_and_buckets():
+    from w2v2_speaker_amd.config import W2V2Config
+    from w2v2_speaker_amd.params import ParamStore, W2V_PREFIX
+    cfg = W2V2Config.tiny()
+    st = ParamStore(cfg, "cpu", torch.float32, head="aam", num_speakers=10)
+    # q/k/v adjacent -> fused [3H,H] view aliases the three HF parameters
+    w = st.qkv(1, "p")
+    st.mp("encoder.layers.1.attention.k_proj.weight").fill_(2.0)
+    assert float(w[cfg.hidden_size:2 * cfg.hidden_size].min()) == 2.0 and float(w[:cfg.hidden_size].max()) == 0.0
+    # frozen CNN is the tail of the arena and has no gradient
+    assert not st.is_trainable(W2V_PREFIX + "feature_extractor.conv_layers.3.conv.weight")
+    with pytest.raises(KeyError):
+        st.mg("feature_extractor.conv_layers.3.conv.weight")
+    # buckets tile the trainable range exactly, in backward order
+    b = st.grad_buckets()
+    assert b[0][0] == "head" and b[0][1] == 0 and b[-1][2] == st.n_train
+    for (n0, s0, e0), (n1, s1, e1) in zip(b, b[1:]):
+        assert e0 == s1 and e0 > s0
+    assert [n for n, _, _ in b] == ["head", "layer1", "layer0", "prologue"]
+    # state-dict round trip incl. the old weight_g / weight_v naming
+    sd = {k: torch.randn(v) for k, v in st.shapes.items()}
+    old = {k.replace("parametrizations.weight.original0", "weight_g").replace("parametrizations.weight.original1", "weight_v"): v
+           for k, v in sd.items()}
+    st.load_state_dict(old)
+    out = st.state_dict()
+    for k in sd:
+        assert torch.equal(out[k], sd[k]), k
+
+
+def test_base_param_count_matches_reference_log():
+    """ref: paper_results/auto_lr_find/wav2vec2-sv-aam/run.log:13-25 -- AAM 9.2 M + wav2vec 94.4 M."""
+    from w2v2_speaker_amd.config import W2V2Config
+    from w2v2_speaker_amd.params import ParamStore
+    st = ParamStore(W2V2Config(), "cpu", torch.float32, head="aam", num_speakers=5994)
+    n = sum(int(np.prod(s)) for s in st.shapes.values())
+    assert n == 94_371_712 + 5994 * 1536
+    trainable = sum(int(np.prod(s)) for k, s in st.shapes.items() if st.is_trainable(k))
+    assert trainable == 99_378_048                    # SURVEY 2.3 C1 (frozen feature extractor)
+
+
+def _ddp_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from w2v2_speaker_amd.config import W2V2Config
+    from w2v2_speaker_amd.params import ParamStore
+    from w2v2_speaker_amd.trainer import BucketAllReducer
+    st = ParamStore(W2V2Config.tiny(), "cpu", torch.float32, head="aam", num_speakers=10)
+    red = BucketAllReducer(st, bucket_merge=2)
+    gen = torch.Generator().manual_seed(100 + rank)
+    st.grad.copy_(torch.randn(st.n_train, generator=gen))
+    mine = st.grad.clone()
+    for name, _, _ in st.grad_buckets():          # the order backward fires them
+        red.bucket_ready(name)
+    red.wait()
+    others = [torch.randn(st.n_train, generator=torch.Generator().manual_seed(100 + r)) for r in range(world)]
+    q.put((rank, bool(torch.allclose(st.grad, sum(others), atol=1e-6)), bool(torch.equal(mine, others[rank]))))
+    dist.destroy_process_group()
+
+
+def test_bucketed_allreduce_two_ranks_gloo():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(ok and same for _, ok, same in res), res

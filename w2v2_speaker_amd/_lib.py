@@ -1,0 +1,104 @@
+"""ctypes binding of libw2v2hip.so -- the C ABI declared in include/w2v2_hip.h.
+
+There is NO CPU fallback: if the shared library is missing and cannot be built, importing the ops
+raises.  Every wrapper raises ``RuntimeError`` with ``w2v2_last_error()`` on a non-zero return code.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from . import _build
+
+F32, BF16 = 0, 1
+EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_GELU_BWD, EPI_ADD, EPI_SCALE_RC = range(6)
+
+c_i32, c_i64, c_u64, c_f32, c_vp = C.c_int32, C.c_int64, C.c_uint64, C.c_float, C.c_void_p
+
+
+class Operand(C.Structure):
+    _fields_ = [("ptr", c_vp), ("ld", c_i64), ("seg_len", c_i64), ("seg_stride", c_i64),
+                ("stride0", c_i64), ("stride1", c_i64), ("trans", c_i32), ("_pad", c_i32)]
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [("M", c_i32), ("N", c_i32), ("K", c_i32), ("batch", c_i32), ("batch_inner", c_i32),
+                ("dtype_ab", c_i32), ("dtype_c", c_i32), ("epilogue", c_i32),
+                ("A", Operand), ("B", Operand),
+                ("C", c_vp), ("ldc", c_i64), ("c_stride0", c_i64), ("c_stride1", c_i64),
+                ("aux", c_vp), ("ldaux", c_i64), ("aux_stride0", c_i64), ("aux_stride1", c_i64),
+                ("bias", c_vp), ("bias_stride1", c_i64), ("row_scale", c_vp), ("col_scale", c_vp),
+                ("alpha", c_f32), ("split_k", c_i32), ("accumulate", c_i32), ("_pad", c_i32)]
+
+
+_SIGS = {
+    "w2v2_version": (c_i32, []),
+    "w2v2_last_error": (C.c_char_p, []),
+    "w2v2_gemm": (c_i32, [C.POINTER(GemmDesc), c_vp]),
+    "w2v2_conv0_stats": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    "w2v2_conv0_apply": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32,
+                                 c_i32, c_f32, c_vp]),
+    "w2v2_pack_conv_weight": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    "w2v2_layernorm_fwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_f32, c_f32,
+                                   c_u64, c_i32, c_vp]),
+    "w2v2_layernorm_bwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32,
+                                   c_f32, c_u64, c_i32, c_vp]),
+    "w2v2_dropout": (c_i32, [c_vp, c_vp, c_i64, c_f32, c_u64, c_i32, c_vp]),
+    "w2v2_gelu_bwd": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, c_vp]),
+    "w2v2_add": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, c_vp]),
+    "w2v2_colsum": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_i32, c_i32, c_vp]),
+    "w2v2_cast": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_vp]),
+    "w2v2_mask_fill": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
+    "w2v2_mask_fill_bwd": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
+    "w2v2_prepend_token": (c_i32, [c_vp, c_vp, c_f32, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    "w2v2_posconv_regroup": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    "w2v2_weightnorm_pack": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    "w2v2_weightnorm_bwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
+    "w2v2_softmax_fwd": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, c_i64, c_f32, c_u64, c_i32, c_vp]),
+    "w2v2_softmax_bwd": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, c_i64, c_f32, c_u64, c_i32, c_vp]),
+    "w2v2_attention_fwd": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_f32, c_f32, c_u64,
+                                   c_i32, c_vp]),
+    "w2v2_attention_bwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_f32,
+                                   c_f32, c_u64, c_i32, c_vp]),
+    "w2v2_pool_fwd": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    "w2v2_pool_bwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    "w2v2_row_invnorm": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_i32, c_i32, c_vp]),
+    "w2v2_aam_softmax_fwd_bwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32,
+                                         c_i32, c_i64, c_f32, c_f32, c_i32, c_vp]),
+    "w2v2_normalize_bwd": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    "w2v2_adam_step": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32,
+                               c_f32, c_f32, c_vp]),
+}
+
+EXPORTS = tuple(_SIGS)
+_lib = None
+
+
+def library_path() -> str:
+    return _build.LIB
+
+
+def load():
+    """Load (building first if a compiler is present and sources are newer).  Raises on failure."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.LIB
+    if _build.needs_build():
+        try:
+            _build.build()
+        except Exception as e:  # no compiler on this box and no prebuilt library -> loud failure
+            if not os.path.exists(path):
+                raise RuntimeError(f"libw2v2hip.so is missing and could not be built: {e}") from e
+    lib = C.CDLL(path)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)          # AttributeError if the ABI symbol is missing
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().w2v2_last_error()
+        raise RuntimeError(f"libw2v2hip {what} failed: {msg.decode() if msg else rc}")

@@ -1,0 +1,420 @@
+// attention.hip -- fused multi-head self-attention for training-length sequences (T <= 256,
+// head dim 64): HF:438-548 minus the q/k/v/out projections.  bf16 in, f32 softmax, bf16 out.
+//
+// All three kernels share one skeleton.  A wave owns 16 "rows" (queries in fwd / dQ, keys in dK/dV)
+// whose operand fragments live in registers; the whole "column" matrix of the (batch, head) sits in
+// LDS twice: row-major [n][64] (XOR-swizzled 16-B chunks, read as ds_read_b128 MFMA fragments) for
+// the score-like products, and transposed [64][n] (read as 2 x ds_read_b64) for the product that
+// contracts over n.  Scores are computed with swapped MFMA operands (D[row=n][col=m]) so each lane
+// holds, for ONE of its 16 rows, 4 consecutive columns per 16x16 fragment: the softmax row
+// reductions are in-register + two wave shuffles (xor 16, 32), and the probabilities feed the second
+// MFMA directly from registers (never through LDS or HBM).  The MFMA k-slot <-> column mapping
+// (slot (g,e): column blk*32 + (e<4 ? g*4+e : 16+g*4+e-4)) is applied identically to the register
+// operand and the transposed-LDS operand, which is all a contraction needs.
+//
+//   fwd   : S = QK^T*scale -> P = softmax(S) (+dropout) -> O = P V            saves LSE[b,h,q]
+//   bwd_dq: recompute P; dP = dO V^T; dS = P*(dP - delta)*scale; dQ = dS K    writes delta[b,h,q]
+//   bwd_kv: (rows = keys) recompute P^T; dV = Pdrop^T dO; dK = dS^T Q
+// Backward recomputes the scores in both kernels (7 matmul units instead of 5) in exchange for
+// no [B,h,T,T] tensor in HBM at all; attention is 3 % of the step's FLOPs.
+#include "common.cuh"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+constexpr int HD = 64;  // head dim
+
+__device__ __forceinline__ int aswz(int row) { return (row ^ (row >> 3)) & 7; }
+
+__device__ __forceinline__ bf16x8 as_frag(uint4 v) {
+  union { uint4 u; bf16x8 f; } c;
+  c.u = v;
+  return c.f;
+}
+__device__ __forceinline__ bf16x8 pack_frag(const float a[4], const float b[4]) {
+  uint4 v;
+  v.x = (uint32_t)f32_to_bf16(a[0]) | ((uint32_t)f32_to_bf16(a[1]) << 16);
+  v.y = (uint32_t)f32_to_bf16(a[2]) | ((uint32_t)f32_to_bf16(a[3]) << 16);
+  v.z = (uint32_t)f32_to_bf16(b[0]) | ((uint32_t)f32_to_bf16(b[1]) << 16);
+  v.w = (uint32_t)f32_to_bf16(b[2]) | ((uint32_t)f32_to_bf16(b[3]) << 16);
+  return as_frag(v);
+}
+
+// rows [0, n_pad) x 64 bf16 from global (row stride gs elements) -> LDS [n_pad][64], chunk-swizzled
+__device__ __forceinline__ void lds_load_rows(bf16_t* lds, const bf16_t* g, int64_t gs, int n_valid, int n_pad) {
+  for (int c = threadIdx.x; c < n_pad * 8; c += 256) {
+    const int row = c >> 3, ch = c & 7;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (row < n_valid) v = *reinterpret_cast<const uint4*>(g + (int64_t)row * gs + ch * 8);
+    *reinterpret_cast<uint4*>(lds + row * 64 + ((ch ^ aswz(row)) << 3)) = v;
+  }
+}
+// same rows, transposed -> LDS [64][pitch]; 4 rows x 8 cols micro-blocks transposed in registers
+__device__ __forceinline__ void lds_load_rows_t(bf16_t* ldst, const bf16_t* g, int64_t gs, int n_valid, int n_pad,
+                                                int pitch) {
+  for (int blk = threadIdx.x; blk < (n_pad >> 2) * 8; blk += 256) {
+    const int cb = blk & 7, rb = blk >> 3;
+    uint32_t w[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = rb * 4 + i;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (row < n_valid) v = *reinterpret_cast<const uint4*>(g + (int64_t)row * gs + cb * 8);
+      w[i][0] = v.x; w[i][1] = v.y; w[i][2] = v.z; w[i][3] = v.w;
+    }
+#pragma unroll
+    for (int ci = 0; ci < 8; ++ci) {
+      const int d = ci >> 1;
+      uint2 o;
+      if (ci & 1) {
+        o.x = (w[0][d] >> 16) | (w[1][d] & 0xffff0000u);
+        o.y = (w[2][d] >> 16) | (w[3][d] & 0xffff0000u);
+      } else {
+        o.x = (w[0][d] & 0xffffu) | (w[1][d] << 16);
+        o.y = (w[2][d] & 0xffffu) | (w[3][d] << 16);
+      }
+      *reinterpret_cast<uint2*>(ldst + (cb * 8 + ci) * pitch + rb * 4) = o;
+    }
+  }
+}
+// MFMA fragment (16 rows x 32 k) from the swizzled row-major image
+__device__ __forceinline__ bf16x8 lds_frag(const bf16_t* lds, int row0, int kk, int lane) {
+  const int row = row0 + (lane & 15);
+  return as_frag(*reinterpret_cast<const uint4*>(lds + row * 64 + (((kk * 4 + (lane >> 4)) ^ aswz(row)) << 3)));
+}
+// MFMA fragment from the transposed image: row d0 + lane&15, k-slots of 32-column block `blk`
+__device__ __forceinline__ bf16x8 lds_frag_t(const bf16_t* ldst, int pitch, int d0, int blk, int lane) {
+  const bf16_t* p = ldst + (d0 + (lane & 15)) * pitch + blk * 32 + (lane >> 4) * 4;
+  const uint2 a = *reinterpret_cast<const uint2*>(p), b = *reinterpret_cast<const uint2*>(p + 16);
+  return as_frag(make_uint4(a.x, a.y, b.x, b.y));
+}
+// the wave's own 16 rows straight from global into registers (2 k-steps)
+__device__ __forceinline__ void reg_frag(bf16x8 f[2], const bf16_t* g, int64_t gs, int row, int n_valid, int lane) {
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) {
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (row < n_valid) v = *reinterpret_cast<const uint4*>(g + (int64_t)row * gs + kk * 32 + (lane >> 4) * 8);
+    f[kk] = as_frag(v);
+  }
+}
+__device__ __forceinline__ float quad_max(float v) {
+  v = fmaxf(v, __shfl_xor(v, 16, 64));
+  return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+__device__ __forceinline__ float quad_sum(float v) {
+  v += __shfl_xor(v, 16, 64);
+  return v + __shfl_xor(v, 32, 64);
+}
+
+// ------------------------------------------------------------------------------------- forward
+template <int NF>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx,
+                                                       float* __restrict__ lse, int Tn, int heads, float scale,
+                                                       float dp, float inv_keep, uint64_t seed) {
+  constexpr int TP = NF * 16, PITCH = TP + 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16_t* Ks = reinterpret_cast<bf16_t*>(smem);   // [TP][64]
+  bf16_t* Vt = Ks + TP * 64;                      // [64][PITCH]
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int H = heads * HD;
+  const int64_t gs = 3 * (int64_t)H;
+  const bf16_t* qb = qkv + (int64_t)b * Tn * gs + h * HD;
+  lds_load_rows(Ks, qb + H, gs, Tn, TP);
+  lds_load_rows_t(Vt, qb + 2 * H, gs, Tn, TP, PITCH);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
+  const int q = blockIdx.x * 64 + wave * 16 + (lane & 15);
+  bf16x8 qf[2];
+  reg_frag(qf, qb, gs, q, Tn, lane);
+  __syncthreads();
+
+  float s[NF][4];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int fj = 0; fj < NF; ++fj) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(Ks, fj * 16, kk, lane), qf[kk], acc, 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int key = fj * 16 + g * 4 + j;
+      s[fj][j] = key < Tn ? acc[j] * scale : -INFINITY;
+      mx = fmaxf(mx, s[fj][j]);
+    }
+  }
+  mx = quad_max(mx);
+  float sum = 0.f;
+#pragma unroll
+  for (int fj = 0; fj < NF; ++fj)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { s[fj][j] = __expf(s[fj][j] - mx); sum += s[fj][j]; }
+  sum = quad_sum(sum);
+  const float inv = 1.0f / sum;
+  const int64_t bh = (int64_t)b * heads + h;
+  if (g == 0 && q < Tn) lse[bh * Tn + q] = mx + __logf(sum);
+#pragma unroll
+  for (int fj = 0; fj < NF; ++fj)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float pv = s[fj][j] * inv;
+      if (dp > 0.f) pv *= drop_scale(seed, (uint64_t)((bh * Tn + q) * Tn + fj * 16 + g * 4 + j), dp, inv_keep);
+      s[fj][j] = pv;
+    }
+  f32x4 o[4];
+#pragma unroll
+  for (int df = 0; df < 4; ++df) o[df] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int kb = 0; kb < NF / 2; ++kb) {
+    const bf16x8 pf = pack_frag(s[2 * kb], s[2 * kb + 1]);
+#pragma unroll
+    for (int df = 0; df < 4; ++df)
+      o[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag_t(Vt, PITCH, df * 16, kb, lane), pf, o[df], 0, 0, 0);
+  }
+  if (q < Tn) {
+    bf16_t* dst = ctx + ((int64_t)b * Tn + q) * H + h * HD + g * 4;
+#pragma unroll
+    for (int df = 0; df < 4; ++df) {
+      uint2 w;
+      w.x = (uint32_t)f32_to_bf16(o[df][0]) | ((uint32_t)f32_to_bf16(o[df][1]) << 16);
+      w.y = (uint32_t)f32_to_bf16(o[df][2]) | ((uint32_t)f32_to_bf16(o[df][3]) << 16);
+      *reinterpret_cast<uint2*>(dst + df * 16) = w;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------- backward: dQ
+template <int NF>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv,
+                                                          const bf16_t* __restrict__ ctx,
+                                                          const bf16_t* __restrict__ dctx,
+                                                          const float* __restrict__ lse, bf16_t* __restrict__ dqkv,
+                                                          float* __restrict__ delta, int Tn, int heads, float scale,
+                                                          float dp, float inv_keep, uint64_t seed) {
+  constexpr int TP = NF * 16, PITCH = TP + 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16_t* Ks = reinterpret_cast<bf16_t*>(smem);   // [TP][64]
+  bf16_t* Vs = Ks + TP * 64;                      // [TP][64]
+  bf16_t* Kt = Vs + TP * 64;                      // [64][PITCH]
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int H = heads * HD;
+  const int64_t gs = 3 * (int64_t)H;
+  const bf16_t* qb = qkv + (int64_t)b * Tn * gs + h * HD;
+  lds_load_rows(Ks, qb + H, gs, Tn, TP);
+  lds_load_rows(Vs, qb + 2 * H, gs, Tn, TP);
+  lds_load_rows_t(Kt, qb + H, gs, Tn, TP, PITCH);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
+  const int q = blockIdx.x * 64 + wave * 16 + (lane & 15);
+  const int64_t bh = (int64_t)b * heads + h;
+  bf16x8 qf[2], dof[2], of[2];
+  reg_frag(qf, qb, gs, q, Tn, lane);
+  const bf16_t* dob = dctx + (int64_t)b * Tn * H + h * HD;
+  const bf16_t* ob = ctx + (int64_t)b * Tn * H + h * HD;
+  reg_frag(dof, dob, H, q, Tn, lane);
+  reg_frag(of, ob, H, q, Tn, lane);
+  // delta[q] = sum_d dO*O
+  float dl = 0.f;
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dl += (float)dof[kk][e] * (float)of[kk][e];
+  dl = quad_sum(dl);
+  if (g == 0 && q < Tn) delta[bh * Tn + q] = dl;
+  const float l = q < Tn ? lse[bh * Tn + q] : 0.f;
+  __syncthreads();
+
+  float ds[NF][4];
+#pragma unroll
+  for (int fj = 0; fj < NF; ++fj) {
+    f32x4 sa = {0.f, 0.f, 0.f, 0.f}, pa = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(Ks, fj * 16, kk, lane), qf[kk], sa, 0, 0, 0);
+      pa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(Vs, fj * 16, kk, lane), dof[kk], pa, 0, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int key = fj * 16 + g * 4 + j;
+      const float p = (key < Tn && q < Tn) ? __expf(sa[j] * scale - l) : 0.f;
+      float dpv = pa[j];
+      if (dp > 0.f) dpv *= drop_scale(seed, (uint64_t)((bh * Tn + q) * Tn + key), dp, inv_keep);
+      ds[fj][j] = p * (dpv - dl) * scale;
+    }
+  }
+  f32x4 o[4];
+#pragma unroll
+  for (int df = 0; df < 4; ++df) o[df] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int kb = 0; kb < NF / 2; ++kb) {
+    const bf16x8 pf = pack_frag(ds[2 * kb], ds[2 * kb + 1]);
+#pragma unroll
+    for (int df = 0; df < 4; ++df)
+      o[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag_t(Kt, PITCH, df * 16, kb, lane), pf, o[df], 0, 0, 0);
+  }
+  if (q < Tn) {
+    bf16_t* dst = dqkv + ((int64_t)b * Tn + q) * gs + h * HD + g * 4;
+#pragma unroll
+    for (int df = 0; df < 4; ++df) {
+      uint2 w;
+      w.x = (uint32_t)f32_to_bf16(o[df][0]) | ((uint32_t)f32_to_bf16(o[df][1]) << 16);
+      w.y = (uint32_t)f32_to_bf16(o[df][2]) | ((uint32_t)f32_to_bf16(o[df][3]) << 16);
+      *reinterpret_cast<uint2*>(dst + df * 16) = w;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------- backward: dK, dV
+template <int NF>
+__global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const bf16_t* __restrict__ qkv,
+                                                          const bf16_t* __restrict__ dctx,
+                                                          const float* __restrict__ lse,
+                                                          const float* __restrict__ delta, bf16_t* __restrict__ dqkv,
+                                                          int Tn, int heads, float scale, float dp, float inv_keep,
+                                                          uint64_t seed) {
+  constexpr int TP = NF * 16, PITCH = TP + 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16_t* Qs = reinterpret_cast<bf16_t*>(smem);   // [TP][64]
+  bf16_t* Os = Qs + TP * 64;                      // [TP][64]   dO
+  bf16_t* Qt = Os + TP * 64;                      // [64][PITCH]
+  bf16_t* Ot = Qt + 64 * PITCH;                   // [64][PITCH]  dO^T
+  float* lse_s = reinterpret_cast<float*>(Ot + 64 * PITCH);  // [TP]
+  float* del_s = lse_s + TP;                                 // [TP]
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int H = heads * HD;
+  const int64_t gs = 3 * (int64_t)H;
+  const bf16_t* qb = qkv + (int64_t)b * Tn * gs + h * HD;
+  const bf16_t* dob = dctx + (int64_t)b * Tn * H + h * HD;
+  const int64_t bh = (int64_t)b * heads + h;
+  lds_load_rows(Qs, qb, gs, Tn, TP);
+  lds_load_rows(Os, dob, H, Tn, TP);
+  lds_load_rows_t(Qt, qb, gs, Tn, TP, PITCH);
+  lds_load_rows_t(Ot, dob, H, Tn, TP, PITCH);
+  for (int i = threadIdx.x; i < TP; i += 256) {
+    lse_s[i] = i < Tn ? lse[bh * Tn + i] : 0.f;
+    del_s[i] = i < Tn ? delta[bh * Tn + i] : 0.f;
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
+  const int key = blockIdx.x * 64 + wave * 16 + (lane & 15);
+  bf16x8 kf[2], vf[2];
+  reg_frag(kf, qb + H, gs, key, Tn, lane);
+  reg_frag(vf, qb + 2 * H, gs, key, Tn, lane);
+  __syncthreads();
+
+  float pt[NF][4], dst_[NF][4];
+#pragma unroll
+  for (int fq = 0; fq < NF; ++fq) {
+    f32x4 sa = {0.f, 0.f, 0.f, 0.f}, pa = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(Qs, fq * 16, kk, lane), kf[kk], sa, 0, 0, 0);
+      pa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(Os, fq * 16, kk, lane), vf[kk], pa, 0, 0, 0);
+    }
+    const float4 l4 = *reinterpret_cast<const float4*>(lse_s + fq * 16 + g * 4);
+    const float4 d4 = *reinterpret_cast<const float4*>(del_s + fq * 16 + g * 4);
+    const float la[4] = {l4.x, l4.y, l4.z, l4.w}, da[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int q = fq * 16 + g * 4 + j;
+      const float p = (q < Tn && key < Tn) ? __expf(sa[j] * scale - la[j]) : 0.f;
+      float ms = 1.0f;
+      if (dp > 0.f) ms = drop_scale(seed, (uint64_t)((bh * Tn + q) * Tn + key), dp, inv_keep);
+      pt[fq][j] = p * ms;
+      dst_[fq][j] = p * (pa[j] * ms - da[j]) * scale;
+    }
+  }
+  f32x4 dv[4], dk[4];
+#pragma unroll
+  for (int df = 0; df < 4; ++df) { dv[df] = f32x4{0.f, 0.f, 0.f, 0.f}; dk[df] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+  for (int qb2 = 0; qb2 < NF / 2; ++qb2) {
+    const bf16x8 pf = pack_frag(pt[2 * qb2], pt[2 * qb2 + 1]);
+    const bf16x8 sf = pack_frag(dst_[2 * qb2], dst_[2 * qb2 + 1]);
+#pragma unroll
+    for (int df = 0; df < 4; ++df) {
+      dv[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag_t(Ot, PITCH, df * 16, qb2, lane), pf, dv[df], 0, 0, 0);
+      dk[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag_t(Qt, PITCH, df * 16, qb2, lane), sf, dk[df], 0, 0, 0);
+    }
+  }
+  if (key < Tn) {
+    bf16_t* dstk = dqkv + ((int64_t)b * Tn + key) * gs + H + h * HD + g * 4;
+    bf16_t* dstv = dstk + H;
+#pragma unroll
+    for (int df = 0; df < 4; ++df) {
+      uint2 w;
+      w.x = (uint32_t)f32_to_bf16(dk[df][0]) | ((uint32_t)f32_to_bf16(dk[df][1]) << 16);
+      w.y = (uint32_t)f32_to_bf16(dk[df][2]) | ((uint32_t)f32_to_bf16(dk[df][3]) << 16);
+      *reinterpret_cast<uint2*>(dstk + df * 16) = w;
+      w.x = (uint32_t)f32_to_bf16(dv[df][0]) | ((uint32_t)f32_to_bf16(dv[df][1]) << 16);
+      w.y = (uint32_t)f32_to_bf16(dv[df][2]) | ((uint32_t)f32_to_bf16(dv[df][3]) << 16);
+      *reinterpret_cast<uint2*>(dstv + df * 16) = w;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------- host
+template <int NF> static size_t fwd_lds() { return (size_t)(NF * 16 * 64 + 64 * (NF * 16 + 4)) * 2; }
+template <int NF> static size_t dq_lds() { return (size_t)(2 * NF * 16 * 64 + 64 * (NF * 16 + 4)) * 2; }
+template <int NF> static size_t kv_lds() { return (size_t)(2 * NF * 16 * 64 + 2 * 64 * (NF * 16 + 4)) * 2 + 2 * NF * 16 * 4; }
+
+template <typename K> static void set_lds(K kern, size_t bytes) {
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+static int attn_check(const char* nm, int B, int T, int heads, int d, int dtype, float drop_p) {
+  W2V2_REQUIRE(B > 0 && T > 0 && heads > 0, "%s: bad shape", nm);
+  W2V2_REQUIRE(d == HD, "%s: fused attention needs head dim 64 (got %d); use the unfused path", nm, d);
+  W2V2_REQUIRE(T <= 256, "%s: fused attention covers T <= 256 (got %d); use the unfused path", nm, T);
+  W2V2_REQUIRE(dtype == W2V2_BF16, "%s: fused attention is bf16 only; the f32 parity mode uses the unfused path", nm);
+  W2V2_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "%s: bad dropout p", nm);
+  return 0;
+}
+
+#define ATTN_DISPATCH(NFV, CALL)             \
+  switch (NFV) {                             \
+    case 2: { constexpr int NF = 2; CALL; } break;   \
+    case 4: { constexpr int NF = 4; CALL; } break;   \
+    case 6: { constexpr int NF = 6; CALL; } break;   \
+    case 8: { constexpr int NF = 8; CALL; } break;   \
+    case 10: { constexpr int NF = 10; CALL; } break; \
+    case 12: { constexpr int NF = 12; CALL; } break; \
+    case 14: { constexpr int NF = 14; CALL; } break; \
+    default: { constexpr int NF = 16; CALL; } break; \
+  }
+
+extern "C" int w2v2_attention_fwd(const void* qkv, void* ctx, float* lse, int B, int T, int heads, int d, float scale,
+                                  float drop_p, uint64_t seed, int dtype, void* stream) {
+  if (attn_check("attention_fwd", B, T, heads, d, dtype, drop_p)) return -1;
+  W2V2_REQUIRE(qkv && ctx && lse, "attention_fwd: null pointer");
+  const int nf = (int)cdiv(T, 32) * 2;
+  dim3 grid((unsigned)cdiv(T, 64), heads, B);
+  const float ik = 1.0f / (1.0f - drop_p);
+  hipStream_t st = as_stream(stream);
+  ATTN_DISPATCH(nf, {
+    set_lds(attn_fwd_kernel<NF>, fwd_lds<NF>());
+    hipLaunchKernelGGL(attn_fwd_kernel<NF>, grid, dim3(256), fwd_lds<NF>(), st, (const bf16_t*)qkv, (bf16_t*)ctx, lse,
+                       T, heads, scale, drop_p, ik, seed);
+  });
+  W2V2_CHECK_LAUNCH("attention_fwd");
+  return 0;
+}
+
+extern "C" int w2v2_attention_bwd(const void* qkv, const void* ctx, const void* dctx, const float* lse, void* dqkv,
+                                  float* delta, int B, int T, int heads, int d, float scale, float drop_p,
+                                  uint64_t seed, int dtype, void* stream) {
+  if (attn_check("attention_bwd", B, T, heads, d, dtype, drop_p)) return -1;
+  W2V2_REQUIRE(qkv && ctx && dctx && lse && dqkv && delta, "attention_bwd: null pointer");
+  const int nf = (int)cdiv(T, 32) * 2;
+  dim3 grid((unsigned)cdiv(T, 64), heads, B);
+  const float ik = 1.0f / (1.0f - drop_p);
+  hipStream_t st = as_stream(stream);
+  ATTN_DISPATCH(nf, {
+    set_lds(attn_bwd_dq_kernel<NF>, dq_lds<NF>());
+    set_lds(attn_bwd_kv_kernel<NF>, kv_lds<NF>());
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<NF>, grid, dim3(256), dq_lds<NF>(), st, (const bf16_t*)qkv,
+                       (const bf16_t*)ctx, (const bf16_t*)dctx, lse, (bf16_t*)dqkv, delta, T, heads, scale, drop_p, ik,
+                       seed);
+    hipLaunchKernelGGL(attn_bwd_kv_kernel<NF>, grid, dim3(256), kv_lds<NF>(), st, (const bf16_t*)qkv,
+                       (const bf16_t*)dctx, lse, (const float*)delta, (bf16_t*)dqkv, T, heads, scale, drop_p, ik, seed);
+  });
+  W2V2_CHECK_LAUNCH("attention_bwd");
+  return 0;
+}

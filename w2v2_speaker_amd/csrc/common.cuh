@@ -1,0 +1,121 @@
+// Shared device/host helpers for the gfx950 kernels of libw2v2hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <math.h>
+
+#include "../../include/w2v2_hip.h"
+
+// ---------------------------------------------------------------- error plumbing (never throw)
+extern thread_local char g_w2v2_err[512];
+#define W2V2_FAIL(...)                                   \
+  do {                                                   \
+    snprintf(g_w2v2_err, sizeof(g_w2v2_err), __VA_ARGS__); \
+    return -1;                                           \
+  } while (0)
+#define W2V2_CHECK_LAUNCH(name)                                                       \
+  do {                                                                                \
+    hipError_t e__ = hipGetLastError();                                               \
+    if (e__ != hipSuccess) W2V2_FAIL("%s: launch failed: %s", name, hipGetErrorString(e__)); \
+  } while (0)
+#define W2V2_REQUIRE(cond, ...) \
+  do {                          \
+    if (!(cond)) W2V2_FAIL(__VA_ARGS__); \
+  } while (0)
+
+static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---------------------------------------------------------------- bf16 storage type
+typedef uint16_t bf16_t;
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {  // round to nearest even, NaN kept quiet
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+
+template <typename T> __device__ __forceinline__ float to_f32(T v);
+template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ float to_f32<bf16_t>(bf16_t v) { return bf16_to_f32(v); }
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return f32_to_bf16(v); }
+
+// 8-element vector access (16 B for bf16, 32 B for f32); p must be 16-byte aligned.
+template <typename T> struct Vec8;
+template <> struct Vec8<float> {
+  float v[8];
+  __device__ __forceinline__ void load(const float* p) {
+    float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+  }
+  __device__ __forceinline__ void store(float* p) const {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+  }
+};
+template <> struct Vec8<bf16_t> {
+  float v[8];
+  __device__ __forceinline__ void load(const bf16_t* p) {
+    uint4 a = *reinterpret_cast<const uint4*>(p);
+    uint32_t w[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      v[2 * i] = __uint_as_float(w[i] << 16);
+      v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+    }
+  }
+  __device__ __forceinline__ void store(bf16_t* p) const {
+    uint32_t w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      w[i] = (uint32_t)f32_to_bf16(v[2 * i]) | ((uint32_t)f32_to_bf16(v[2 * i + 1]) << 16);
+    *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+};
+
+// ---------------------------------------------------------------- math
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad_f(float x) {
+  // d/dx [x * Phi(x)] = Phi(x) + x * phi(x)
+  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+  const float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+
+// ---------------------------------------------------------------- counter-based RNG (dropout)
+// splitmix64 finaliser over (seed, index): the same (seed, i) gives the same keep decision in the
+// forward and in the backward, so no mask is ever stored.
+__device__ __forceinline__ uint32_t rng_u32(uint64_t seed, uint64_t idx) {
+  uint64_t z = seed + 0x9E3779B97F4A7C15ull * (idx + 1);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  return (uint32_t)(z >> 32);
+}
+// returns 0 (dropped) or 1/(1-p)
+__device__ __forceinline__ float drop_scale(uint64_t seed, uint64_t idx, float p, float inv_keep) {
+  const float u = (float)(rng_u32(seed, idx) >> 8) * (1.0f / 16777216.0f);
+  return u >= p ? inv_keep : 0.0f;
+}
+
+// ---------------------------------------------------------------- wave / block reductions (wave = 64)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}

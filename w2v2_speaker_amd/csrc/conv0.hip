@@ -1,0 +1,132 @@
+// conv0.hip -- layer 0 of the wav2vec2 feature encoder (HF:302-323, HF:382-419):
+// Conv1d(1 -> C, k=10, stride=5, no bias) + GroupNorm(C groups == per-(utterance, channel) statistics
+// over time, biased variance) + GELU(erf), fused so the [B, L, C] pre-norm tensor never exists in HBM:
+//   pass 1 (stats): conv, accumulate sum / sum-of-squares per (b, c)          -> 16 B per (b, c)
+//   pass 2 (apply): conv again (10 MAC per output, cheaper than a 9.8 MB/utt round trip),
+//                   normalise, GELU, store channels-last in the activation dtype.
+// HBM-bound: algorithmic bytes/utt = 2 x 192 KB waveform reads + L*C*sizeof(T) output (9.83 MB bf16).
+// The waveform chunk of a block is staged in LDS once and read by broadcast (every thread of the
+// block needs the same 10-sample window for a given frame); threads map to adjacent channels so the
+// channels-last stores are fully coalesced (512 B per frame per block).
+#include "common.cuh"
+
+constexpr int C0_FRAMES = 128;   // frames per block
+constexpr int C0_MAXK = 16;
+
+template <typename T, bool APPLY>
+__global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ wav, const float* __restrict__ w,
+                                                    double* __restrict__ stats, const float* __restrict__ gamma,
+                                                    const float* __restrict__ beta, T* __restrict__ y, int N,
+                                                    int L, int C, int k, int stride, float eps) {
+  extern __shared__ float xs[];
+  const int b = blockIdx.y;
+  const int l0 = blockIdx.x * C0_FRAMES;
+  const int nf = min(C0_FRAMES, L - l0);
+  const int nsamp = (nf - 1) * stride + k;
+  const float* src = wav + (int64_t)b * N + (int64_t)l0 * stride;
+  for (int i = threadIdx.x; i < nsamp; i += 256) xs[i] = src[i];
+  __syncthreads();
+
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float wr[C0_MAXK];
+#pragma unroll
+    for (int j = 0; j < C0_MAXK; ++j) wr[j] = j < k ? w[c * k + j] : 0.f;
+    if constexpr (!APPLY) {
+      float s1 = 0.f, s2 = 0.f;
+      for (int f = 0; f < nf; ++f) {
+        const float* xp = xs + f * stride;
+        float acc = 0.f;
+#pragma unroll
+        for (int j = 0; j < C0_MAXK; ++j)
+          if (j < k) acc = fmaf(wr[j], xp[j], acc);
+        s1 += acc;
+        s2 = fmaf(acc, acc, s2);
+      }
+      double* st = stats + ((int64_t)b * C + c) * 2;
+      atomicAdd(st, (double)s1);
+      atomicAdd(st + 1, (double)s2);
+    } else {
+      const double* st = stats + ((int64_t)b * C + c) * 2;
+      const double mu = st[0] / (double)L;
+      const double var = st[1] / (double)L - mu * mu;
+      const float rstd = (float)(1.0 / sqrt((var > 0.0 ? var : 0.0) + (double)eps));
+      const float ga = gamma[c] * rstd;
+      const float be = beta[c] - (float)mu * ga;
+      T* dst = y + ((int64_t)b * L + l0) * C + c;
+      for (int f = 0; f < nf; ++f) {
+        const float* xp = xs + f * stride;
+        float acc = 0.f;
+#pragma unroll
+        for (int j = 0; j < C0_MAXK; ++j)
+          if (j < k) acc = fmaf(wr[j], xp[j], acc);
+        dst[(int64_t)f * C] = from_f32<T>(gelu_f(fmaf(acc, ga, be)));
+      }
+    }
+  }
+}
+
+static int conv0_check(const char* nm, int B, int N, int C, int k, int stride) {
+  W2V2_REQUIRE(B > 0 && C > 0 && k > 0 && k <= C0_MAXK && stride > 0 && N >= k,
+               "%s: bad shape B=%d N=%d C=%d k=%d stride=%d", nm, B, N, C, k, stride);
+  return 0;
+}
+
+extern "C" int w2v2_conv0_stats(const float* wav, const float* w, double* stats, int B, int N, int C, int k,
+                                int stride, void* stream) {
+  if (conv0_check("conv0_stats", B, N, C, k, stride)) return -1;
+  W2V2_REQUIRE(wav && w && stats, "conv0_stats: null pointer");
+  const int L = (N - k) / stride + 1;
+  dim3 grid((unsigned)cdiv(L, C0_FRAMES), B);
+  const size_t lds = ((size_t)(C0_FRAMES - 1) * stride + k) * sizeof(float);
+  hipLaunchKernelGGL((conv0_kernel<float, false>), grid, dim3(256), lds, as_stream(stream), wav, w, stats,
+                     (const float*)nullptr, (const float*)nullptr, (float*)nullptr, N, L, C, k, stride, 0.f);
+  W2V2_CHECK_LAUNCH("conv0_stats");
+  return 0;
+}
+
+extern "C" int w2v2_conv0_apply(const float* wav, const float* w, const double* stats, const float* gamma,
+                                const float* beta, void* y, int dtype, int B, int N, int C, int k, int stride,
+                                float eps, void* stream) {
+  if (conv0_check("conv0_apply", B, N, C, k, stride)) return -1;
+  W2V2_REQUIRE(wav && w && stats && gamma && beta && y, "conv0_apply: null pointer");
+  const int L = (N - k) / stride + 1;
+  dim3 grid((unsigned)cdiv(L, C0_FRAMES), B);
+  const size_t lds = ((size_t)(C0_FRAMES - 1) * stride + k) * sizeof(float);
+  if (dtype == W2V2_BF16)
+    hipLaunchKernelGGL((conv0_kernel<bf16_t, true>), grid, dim3(256), lds, as_stream(stream), wav, w,
+                       const_cast<double*>(stats), gamma, beta, (bf16_t*)y, N, L, C, k, stride, eps);
+  else if (dtype == W2V2_F32)
+    hipLaunchKernelGGL((conv0_kernel<float, true>), grid, dim3(256), lds, as_stream(stream), wav, w,
+                       const_cast<double*>(stats), gamma, beta, (float*)y, N, L, C, k, stride, eps);
+  else
+    W2V2_FAIL("conv0_apply: bad dtype %d", dtype);
+  W2V2_CHECK_LAUNCH("conv0_apply");
+  return 0;
+}
+
+// HF Conv1d weight [Cout][Cin][k] -> implicit-GEMM B operand [Cout][k][Cin] (K index = tap*Cin + cin,
+// matching k consecutive channels-last frames of the input).
+template <typename T>
+__global__ void pack_conv_kernel(const float* __restrict__ w, T* __restrict__ out, int Cout, int Cin, int k) {
+  const int64_t total = (int64_t)Cout * Cin * k;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int ci = (int)(i % Cin);
+    const int64_t r = i / Cin;
+    const int tap = (int)(r % k), co = (int)(r / k);
+    out[i] = from_f32<T>(w[((int64_t)co * Cin + ci) * k + tap]);
+  }
+}
+
+extern "C" int w2v2_pack_conv_weight(const float* w, void* out, int dtype, int Cout, int Cin, int k, void* stream) {
+  W2V2_REQUIRE(w && out && Cout > 0 && Cin > 0 && k > 0, "pack_conv_weight: bad arguments");
+  const int64_t total = (int64_t)Cout * Cin * k;
+  int nb = (int)(cdiv(total, 256) > 4096 ? 4096 : cdiv(total, 256));
+  if (dtype == W2V2_BF16)
+    hipLaunchKernelGGL(pack_conv_kernel<bf16_t>, dim3(nb), dim3(256), 0, as_stream(stream), w, (bf16_t*)out, Cout, Cin, k);
+  else if (dtype == W2V2_F32)
+    hipLaunchKernelGGL(pack_conv_kernel<float>, dim3(nb), dim3(256), 0, as_stream(stream), w, (float*)out, Cout, Cin, k);
+  else
+    W2V2_FAIL("pack_conv_weight: bad dtype %d", dtype);
+  W2V2_CHECK_LAUNCH("pack_conv_weight");
+  return 0;
+}

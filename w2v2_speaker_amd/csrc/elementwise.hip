@@ -1,0 +1,274 @@
+// elementwise.hip -- HBM-bound helpers: dropout, GELU', add, column sums (bias grads), casts,
+// SpecAugment mask fill, CLS-token prepend.  16-byte vector accesses, grid-stride loops.
+#include "common.cuh"
+
+static inline int ew_blocks(int64_t nvec) {
+  int64_t b = cdiv(nvec, 256);
+  if (b > 4096) b = 4096;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+// ------------------------------------------------------------------------------------- dropout
+template <typename T>
+__global__ void dropout_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t n, float p,
+                               float inv_keep, uint64_t seed) {
+  const int64_t nv = n >> 3;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nv; i += (int64_t)gridDim.x * blockDim.x) {
+    Vec8<T> v;
+    v.load(x + i * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v.v[e] *= drop_scale(seed, (uint64_t)(i * 8 + e), p, inv_keep);
+    v.store(y + i * 8);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 7)) {
+    const int64_t i = (nv << 3) + threadIdx.x;
+    y[i] = from_f32<T>(to_f32<T>(x[i]) * drop_scale(seed, (uint64_t)i, p, inv_keep));
+  }
+}
+
+extern "C" int w2v2_dropout(const void* x, void* y, int64_t n, float p, uint64_t seed, int dtype, void* stream) {
+  W2V2_REQUIRE(x && y && n >= 0 && p >= 0.f && p < 1.f, "dropout: bad arguments");
+  if (n == 0) return 0;
+  const float ik = 1.0f / (1.0f - p);
+  if (dtype == W2V2_BF16)
+    hipLaunchKernelGGL(dropout_kernel<bf16_t>, dim3(ew_blocks(n >> 3)), dim3(256), 0, as_stream(stream),
+                       (const bf16_t*)x, (bf16_t*)y, n, p, ik, seed);
+  else if (dtype == W2V2_F32)
+    hipLaunchKernelGGL(dropout_kernel<float>, dim3(ew_blocks(n >> 3)), dim3(256), 0, as_stream(stream),
+                       (const float*)x, (float*)y, n, p, ik, seed);
+  else
+    W2V2_FAIL("dropout: bad dtype %d", dtype);
+  W2V2_CHECK_LAUNCH("dropout");
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------- binary ops
+template <typename T, int OP>  // OP 0: y = a * gelu'(b)   OP 1: y = a + b
+__global__ void binary_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ y, int64_t n) {
+  const int64_t nv = n >> 3;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nv; i += (int64_t)gridDim.x * blockDim.x) {
+    Vec8<T> va, vb;
+    va.load(a + i * 8);
+    vb.load(b + i * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) va.v[e] = OP == 0 ? va.v[e] * gelu_grad_f(vb.v[e]) : va.v[e] + vb.v[e];
+    va.store(y + i * 8);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 7)) {
+    const int64_t i = (nv << 3) + threadIdx.x;
+    const float fa = to_f32<T>(a[i]), fb = to_f32<T>(b[i]);
+    y[i] = from_f32<T>(OP == 0 ? fa * gelu_grad_f(fb) : fa + fb);
+  }
+}
+
+template <int OP>
+static int launch_binary(const void* a, const void* b, void* y, int64_t n, int dtype, void* stream, const char* nm) {
+  W2V2_REQUIRE(a && b && y && n >= 0, "%s: bad arguments", nm);
+  if (n == 0) return 0;
+  if (dtype == W2V2_BF16)
+    hipLaunchKernelGGL((binary_kernel<bf16_t, OP>), dim3(ew_blocks(n >> 3)), dim3(256), 0, as_stream(stream),
+                       (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)y, n);
+  else if (dtype == W2V2_F32)
+    hipLaunchKernelGGL((binary_kernel<float, OP>), dim3(ew_blocks(n >> 3)), dim3(256), 0, as_stream(stream),
+                       (const float*)a, (const float*)b, (float*)y, n);
+  else
+    W2V2_FAIL("%s: bad dtype %d", nm, dtype);
+  W2V2_CHECK_LAUNCH(nm);
+  return 0;
+}
+
+extern "C" int w2v2_gelu_bwd(const void* dy, const void* pre, void* dx, int64_t n, int dtype, void* stream) {
+  return launch_binary<0>(dy, pre, dx, n, dtype, stream, "gelu_bwd");
+}
+extern "C" int w2v2_add(const void* x, const void* a, void* y, int64_t n, int dtype, void* stream) {
+  return launch_binary<1>(x, a, y, n, dtype, stream, "add");
+}
+
+// ------------------------------------------------------------------------------------- colsum
+// out[n] += sum_m x[m][n].  blockDim = (64 column lanes, 4 row lanes); each column lane owns VEC
+// adjacent columns; rows are strided over grid.y.
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, int64_t ld, float* __restrict__ out,
+                                                     int M, int N) {
+  __shared__ float red[4][64 * VEC];
+  const int tx = threadIdx.x, ty = threadIdx.y;
+  const int col = (blockIdx.x * 64 + tx) * VEC;
+  float acc[VEC] = {};
+  if (col < N) {
+    for (int m = blockIdx.y * 4 + ty; m < M; m += gridDim.y * 4) {
+      if constexpr (VEC == 8) {
+        Vec8<T> v;
+        v.load(x + (int64_t)m * ld + col);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += v.v[e];
+      } else {
+        acc[0] += to_f32<T>(x[(int64_t)m * ld + col]);
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) red[ty][tx * VEC + e] = acc[e];
+  __syncthreads();
+  if (ty == 0 && col < N) {
+#pragma unroll
+    for (int e = 0; e < VEC; ++e)
+      if (col + e < N)
+        unsafeAtomicAdd(out + col + e, red[0][tx * VEC + e] + red[1][tx * VEC + e] + red[2][tx * VEC + e] +
+                                           red[3][tx * VEC + e]);
+  }
+}
+
+extern "C" int w2v2_colsum(const void* x, int64_t ld, float* out, int M, int N, int dtype, void* stream) {
+  W2V2_REQUIRE(x && out && M >= 0 && N > 0 && ld >= N, "colsum: bad arguments");
+  if (M == 0) return 0;
+  const bool vec = (N % 8 == 0) && (ld % 8 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+  const int VECW = vec ? 8 : 1;
+  int gy = (int)cdiv(M, 4 * 32);
+  if (gy > 256) gy = 256;
+  if (gy < 1) gy = 1;
+  dim3 grid((unsigned)cdiv(N, 64 * VECW), gy), block(64, 4);
+  hipStream_t st = as_stream(stream);
+  if (dtype == W2V2_BF16) {
+    if (vec) hipLaunchKernelGGL((colsum_kernel<bf16_t, 8>), grid, block, 0, st, (const bf16_t*)x, ld, out, M, N);
+    else hipLaunchKernelGGL((colsum_kernel<bf16_t, 1>), grid, block, 0, st, (const bf16_t*)x, ld, out, M, N);
+  } else if (dtype == W2V2_F32) {
+    if (vec) hipLaunchKernelGGL((colsum_kernel<float, 8>), grid, block, 0, st, (const float*)x, ld, out, M, N);
+    else hipLaunchKernelGGL((colsum_kernel<float, 1>), grid, block, 0, st, (const float*)x, ld, out, M, N);
+  } else {
+    W2V2_FAIL("colsum: bad dtype %d", dtype);
+  }
+  W2V2_CHECK_LAUNCH("colsum");
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------- cast
+template <typename T>
+__global__ void cast_kernel(const float* __restrict__ x, T* __restrict__ y, int64_t n) {
+  const int64_t nv = n >> 3;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nv; i += (int64_t)gridDim.x * blockDim.x) {
+    Vec8<float> v;
+    v.load(x + i * 8);
+    Vec8<T> o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o.v[e] = v.v[e];
+    o.store(y + i * 8);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 7)) {
+    const int64_t i = (nv << 3) + threadIdx.x;
+    y[i] = from_f32<T>(x[i]);
+  }
+}
+
+extern "C" int w2v2_cast(const float* x, void* y, int64_t n, int dtype, void* stream) {
+  W2V2_REQUIRE(x && y && n >= 0, "cast: bad arguments");
+  if (n == 0) return 0;
+  if (dtype == W2V2_BF16)
+    hipLaunchKernelGGL(cast_kernel<bf16_t>, dim3(ew_blocks(n >> 3)), dim3(256), 0, as_stream(stream), x, (bf16_t*)y, n);
+  else if (dtype == W2V2_F32)
+    hipLaunchKernelGGL(cast_kernel<float>, dim3(ew_blocks(n >> 3)), dim3(256), 0, as_stream(stream), x, (float*)y, n);
+  else
+    W2V2_FAIL("cast: bad dtype %d", dtype);
+  W2V2_CHECK_LAUNCH("cast");
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------- mask fill
+template <typename T>
+__global__ void mask_fill_kernel(T* __restrict__ h, const uint8_t* __restrict__ mask,
+                                 const float* __restrict__ embed, int M, int H) {
+  const int nch = H >> 3;
+  const int64_t total = (int64_t)M * nch;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int m = (int)(i / nch), ch = (int)(i - (int64_t)m * nch);
+    if (mask[m]) {
+      Vec8<float> e;
+      e.load(embed + ch * 8);
+      Vec8<T> o;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) o.v[k] = e.v[k];
+      o.store(h + (int64_t)m * H + ch * 8);
+    }
+  }
+}
+
+template <typename T>
+__global__ void mask_fill_bwd_kernel(T* __restrict__ dh, const uint8_t* __restrict__ mask,
+                                     float* __restrict__ d_embed, int M, int H) {
+  const int nch = H >> 3;
+  const int64_t total = (int64_t)M * nch;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int m = (int)(i / nch), ch = (int)(i - (int64_t)m * nch);
+    if (mask[m]) {
+      Vec8<T> v;
+      v.load(dh + (int64_t)m * H + ch * 8);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        unsafeAtomicAdd(d_embed + ch * 8 + k, v.v[k]);
+        v.v[k] = 0.f;
+      }
+      v.store(dh + (int64_t)m * H + ch * 8);
+    }
+  }
+}
+
+extern "C" int w2v2_mask_fill(void* h, const uint8_t* mask, const float* embed, int M, int H, int dtype, void* stream) {
+  W2V2_REQUIRE(h && mask && embed && H % 8 == 0, "mask_fill: bad arguments");
+  if (M <= 0) return 0;
+  const int nb = ew_blocks((int64_t)M * (H >> 3));
+  if (dtype == W2V2_BF16)
+    hipLaunchKernelGGL(mask_fill_kernel<bf16_t>, dim3(nb), dim3(256), 0, as_stream(stream), (bf16_t*)h, mask, embed, M, H);
+  else if (dtype == W2V2_F32)
+    hipLaunchKernelGGL(mask_fill_kernel<float>, dim3(nb), dim3(256), 0, as_stream(stream), (float*)h, mask, embed, M, H);
+  else
+    W2V2_FAIL("mask_fill: bad dtype %d", dtype);
+  W2V2_CHECK_LAUNCH("mask_fill");
+  return 0;
+}
+
+extern "C" int w2v2_mask_fill_bwd(void* dh, const uint8_t* mask, float* d_embed, int M, int H, int dtype, void* stream) {
+  W2V2_REQUIRE(dh && mask && d_embed && H % 8 == 0, "mask_fill_bwd: bad arguments");
+  if (M <= 0) return 0;
+  const int nb = ew_blocks((int64_t)M * (H >> 3));
+  if (dtype == W2V2_BF16)
+    hipLaunchKernelGGL(mask_fill_bwd_kernel<bf16_t>, dim3(nb), dim3(256), 0, as_stream(stream), (bf16_t*)dh, mask, d_embed, M, H);
+  else if (dtype == W2V2_F32)
+    hipLaunchKernelGGL(mask_fill_bwd_kernel<float>, dim3(nb), dim3(256), 0, as_stream(stream), (float*)dh, mask, d_embed, M, H);
+  else
+    W2V2_FAIL("mask_fill_bwd: bad dtype %d", dtype);
+  W2V2_CHECK_LAUNCH("mask_fill_bwd");
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------- CLS token
+template <typename T>
+__global__ void prepend_kernel(const T* __restrict__ x, T* __restrict__ y, float c, int B, int Tn, int H) {
+  const int nch = H >> 3;
+  const int64_t total = (int64_t)B * (Tn + 1) * nch;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int ch = (int)(i % nch);
+    const int64_t row = i / nch;
+    const int b = (int)(row / (Tn + 1)), t = (int)(row - (int64_t)b * (Tn + 1));
+    Vec8<T> v;
+    if (t == 0) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v.v[k] = c;
+    } else {
+      v.load(x + ((int64_t)b * Tn + (t - 1)) * H + ch * 8);
+    }
+    v.store(y + row * H + ch * 8);
+  }
+}
+
+extern "C" int w2v2_prepend_token(const void* x, void* y, float c, int B, int T, int H, int dtype, void* stream) {
+  W2V2_REQUIRE(x && y && B > 0 && T > 0 && H % 8 == 0, "prepend_token: bad arguments");
+  const int nb = ew_blocks((int64_t)B * (T + 1) * (H >> 3));
+  if (dtype == W2V2_BF16)
+    hipLaunchKernelGGL(prepend_kernel<bf16_t>, dim3(nb), dim3(256), 0, as_stream(stream), (const bf16_t*)x, (bf16_t*)y, c, B, T, H);
+  else if (dtype == W2V2_F32)
+    hipLaunchKernelGGL(prepend_kernel<float>, dim3(nb), dim3(256), 0, as_stream(stream), (const float*)x, (float*)y, c, B, T, H);
+  else
+    W2V2_FAIL("prepend_token: bad dtype %d", dtype);
+  W2V2_CHECK_LAUNCH("prepend_token");
+  return 0;
+}

@@ -1,0 +1,496 @@
+// gemm.hip -- the one matmul-shaped kernel of the path (see include/w2v2_hip.h, "GEMM").
+//
+//   bf16 path : 128x128 (or 128x64) x 64 block tile, 4 waves (2x2), v_mfma_f32_16x16x32_bf16,
+//               f32 accumulate.  Operands are staged global -> VGPR -> LDS (one barrier per K tile,
+//               next tile's global loads in flight under the MFMAs).  K-major ("trans") operands
+//               are transposed in registers (4k x 8m micro-blocks) on their way to LDS, so the
+//               forward (NT), data-gradient (NN) and weight-gradient (TN) products all run on the
+//               same kernel with no transposed copies in HBM.  The segmented outer index gives
+//               zero-copy implicit im2col for the strided conv stack and the grouped pos-conv.
+//               LDS image: [row][64 k] bf16, 128-B rows, 16-B chunks XOR-swizzled by
+//               (row ^ row>>3) & 7 -> conflict-free ds_read_b128 fragment reads and ds_write_b128
+//               staging writes, <= 2-way on the transposing ds_write_b64.
+//   f32 path  : exact-f32 64x64x16 VALU tile kernel.  It exists for the parity mode only
+//               (embeddings within 1e-3 rel-L2 of the f32 reference, BASELINE.json north_star);
+//               throughput runs use bf16.
+#include "common.cuh"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+struct OpDev {
+  const void* ptr;
+  int64_t ld, seg_len, seg_stride;
+  int trans;
+  int vec_ok;  // 16-byte vector loads legal (alignment of ptr/ld/strides)
+};
+
+struct GemmArgs {
+  int M, N, K;
+  int epilogue, split_k, atomic;
+  int tiles_m, tiles_n;
+  int k_per_split;
+  OpDev A, B;
+  int64_t a_s0, a_s1, b_s0, b_s1;
+  int batch_inner;
+  void* C;
+  int64_t ldc, c_s0, c_s1;
+  void* aux;
+  int64_t ldaux, aux_s0, aux_s1;
+  const float* bias;
+  int64_t bias_s1;
+  const float* row_scale;
+  const float* col_scale;
+  float alpha;
+  int c_vec_ok;
+};
+
+__device__ __forceinline__ int64_t outer_off(const OpDev& o, int64_t idx) {
+  if (o.seg_len > 0) {
+    const int64_t q = idx / o.seg_len;
+    return q * o.seg_stride + (idx - q * o.seg_len) * o.ld;
+  }
+  return idx * o.ld;
+}
+
+__device__ __forceinline__ int swz(int row) { return (row ^ (row >> 3)) & 7; }
+
+// ------------------------------------------------------------------------------ epilogue (shared)
+template <typename TC>
+__device__ __forceinline__ void epilogue_store4(const GemmArgs& g, TC* __restrict__ C,
+                                                const TC* __restrict__ aux_in, TC* __restrict__ aux_out,
+                                                const float* __restrict__ bias, int m, int n0,
+                                                const float acc[4], bool lead) {
+  if (m >= g.M) return;
+  const float rs = (g.epilogue == W2V2_EPI_SCALE_RC) ? g.row_scale[m] : 1.0f;
+  float out[4];
+  float pre[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int n = n0 + j;
+    float v = acc[j] * g.alpha;
+    pre[j] = 0.f;
+    if (n < g.N) {
+      switch (g.epilogue) {
+        case W2V2_EPI_BIAS:
+          if (lead) v += bias[n];
+          break;
+        case W2V2_EPI_BIAS_GELU:
+          v += bias[n];
+          pre[j] = v;
+          v = gelu_f(v);
+          break;
+        case W2V2_EPI_GELU_BWD:
+          v *= gelu_grad_f(to_f32<TC>(aux_in[(int64_t)m * g.ldaux + n]));
+          break;
+        case W2V2_EPI_ADD:
+          v += to_f32<TC>(aux_in[(int64_t)m * g.ldaux + n]);
+          break;
+        case W2V2_EPI_SCALE_RC:
+          v *= rs * g.col_scale[n];
+          break;
+        default:
+          break;
+      }
+    }
+    out[j] = v;
+  }
+  TC* crow = C + (int64_t)m * g.ldc;
+  if (g.atomic) {
+    if constexpr (sizeof(TC) == 4) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (n0 + j < g.N) unsafeAtomicAdd(reinterpret_cast<float*>(crow) + n0 + j, out[j]);
+    }
+    return;
+  }
+  if (g.c_vec_ok && n0 + 4 <= g.N) {
+    if constexpr (sizeof(TC) == 4) {
+      *reinterpret_cast<float4*>(crow + n0) = make_float4(out[0], out[1], out[2], out[3]);
+    } else {
+      uint2 w;
+      w.x = (uint32_t)f32_to_bf16(out[0]) | ((uint32_t)f32_to_bf16(out[1]) << 16);
+      w.y = (uint32_t)f32_to_bf16(out[2]) | ((uint32_t)f32_to_bf16(out[3]) << 16);
+      *reinterpret_cast<uint2*>(crow + n0) = w;
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (n0 + j < g.N) crow[n0 + j] = from_f32<TC>(out[j]);
+  }
+  if (g.epilogue == W2V2_EPI_BIAS_GELU && aux_out != nullptr) {
+    TC* arow = aux_out + (int64_t)m * g.ldaux;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (n0 + j < g.N) arow[n0 + j] = from_f32<TC>(pre[j]);
+  }
+}
+
+// XCD-aware tile order: consecutive workgroup ids land on different XCDs (id % 8); remap so each
+// XCD owns a contiguous run of tiles (neighbouring tiles share the A row panel in its private L2).
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+}
+
+// ------------------------------------------------------------------------------ bf16 MFMA kernel
+// stage one operand tile (R outer rows x 64 k) global -> registers
+template <int R, bool TRANS>
+struct Stager {
+  static constexpr int NV = TRANS ? 4 : (R / 32);  // uint4 per thread
+  uint4 v[NV];
+
+  __device__ __forceinline__ void load(const OpDev& o, const bf16_t* __restrict__ base, int r0,
+                                       int rbound, int k0, int kend, int tid,
+                                       const int64_t* __restrict__ rowoff) {
+    if constexpr (!TRANS) {
+#pragma unroll
+      for (int j = 0; j < NV; ++j) {
+        const int c = tid + 256 * j;
+        const int row = c >> 3, kc = c & 7;
+        const int k = k0 + kc * 8;
+        uint4 val = make_uint4(0, 0, 0, 0);
+        if (r0 + row < rbound && k < kend) {
+          const bf16_t* p = base + rowoff[j] + k;
+          if (o.vec_ok && k + 8 <= kend) {
+            val = *reinterpret_cast<const uint4*>(p);
+          } else {
+            bf16_t t[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) t[e] = (k + e < kend) ? p[e] : (bf16_t)0;
+            val.x = t[0] | ((uint32_t)t[1] << 16); val.y = t[2] | ((uint32_t)t[3] << 16);
+            val.z = t[4] | ((uint32_t)t[5] << 16); val.w = t[6] | ((uint32_t)t[7] << 16);
+          }
+        }
+        v[j] = val;
+      }
+    } else {
+      // 4 k-rows x 8 inner per thread; block id = tid (+ nothing: R*2 blocks, R in {64,128})
+      const int nblk = R * 2;
+      const int mb = tid % (R / 8), kb = tid / (R / 8);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        uint4 val = make_uint4(0, 0, 0, 0);
+        const int k = k0 + kb * 4 + i;
+        const int in0 = r0 + mb * 8;
+        if (tid < nblk && k < kend && in0 < rbound) {
+          const bf16_t* p = base + outer_off(o, k) + in0;
+          if (o.vec_ok && in0 + 8 <= rbound) {
+            val = *reinterpret_cast<const uint4*>(p);
+          } else {
+            bf16_t t[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) t[e] = (in0 + e < rbound) ? p[e] : (bf16_t)0;
+            val.x = t[0] | ((uint32_t)t[1] << 16); val.y = t[2] | ((uint32_t)t[3] << 16);
+            val.z = t[4] | ((uint32_t)t[5] << 16); val.w = t[6] | ((uint32_t)t[7] << 16);
+          }
+        }
+        v[i] = val;
+      }
+    }
+  }
+
+  __device__ __forceinline__ void store(bf16_t* __restrict__ lds, int tid) const {
+    if constexpr (!TRANS) {
+#pragma unroll
+      for (int j = 0; j < NV; ++j) {
+        const int c = tid + 256 * j;
+        const int row = c >> 3, kc = c & 7;
+        *reinterpret_cast<uint4*>(lds + row * 64 + ((kc ^ swz(row)) << 3)) = v[j];
+      }
+    } else {
+      const int nblk = R * 2;
+      if (tid >= nblk) return;
+      const int mb = tid % (R / 8), kb = tid / (R / 8);
+      const uint32_t w[4][4] = {{v[0].x, v[0].y, v[0].z, v[0].w},
+                                {v[1].x, v[1].y, v[1].z, v[1].w},
+                                {v[2].x, v[2].y, v[2].z, v[2].w},
+                                {v[3].x, v[3].y, v[3].z, v[3].w}};
+#pragma unroll
+      for (int mi = 0; mi < 8; ++mi) {
+        const int d = mi >> 1;
+        uint2 o2;
+        if (mi & 1) {
+          o2.x = (w[0][d] >> 16) | (w[1][d] & 0xffff0000u);
+          o2.y = (w[2][d] >> 16) | (w[3][d] & 0xffff0000u);
+        } else {
+          o2.x = (w[0][d] & 0xffffu) | (w[1][d] << 16);
+          o2.y = (w[2][d] & 0xffffu) | (w[3][d] << 16);
+        }
+        const int row = mb * 8 + mi;
+        const int chunk = kb >> 1, half = kb & 1;
+        *reinterpret_cast<uint2*>(lds + row * 64 + ((chunk ^ swz(row)) << 3) + half * 4) = o2;
+      }
+    }
+  }
+};
+
+template <int FM, int FN, bool TA, bool TB, typename TC>
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmArgs g) {
+  constexpr int BM = 32 * FM, BN = 32 * FN;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  bf16_t* As = reinterpret_cast<bf16_t*>(smem_raw);           // [2][BM*64]
+  bf16_t* Bs = As + 2 * BM * 64;                              // [2][BN*64]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  const int ntile = g.tiles_m * g.tiles_n;
+  const int tile = xcd_remap(blockIdx.x, ntile);
+  const int tm = tile / g.tiles_n, tn = tile - tm * g.tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int z = blockIdx.z;
+  const int z0 = z / g.batch_inner, z1 = z - z0 * g.batch_inner;
+  const int split = blockIdx.y;
+  const int kbeg = split * g.k_per_split;
+  const int kend = min(g.K, kbeg + g.k_per_split);
+
+  const bf16_t* Ab = reinterpret_cast<const bf16_t*>(g.A.ptr) + z0 * g.a_s0 + z1 * g.a_s1;
+  const bf16_t* Bb = reinterpret_cast<const bf16_t*>(g.B.ptr) + z0 * g.b_s0 + z1 * g.b_s1;
+
+  // row offsets of the non-transposed operands are K-invariant: compute once
+  int64_t arow[TA ? 1 : (BM / 32)], brow[TB ? 1 : (BN / 32)];
+  if constexpr (!TA) {
+#pragma unroll
+    for (int j = 0; j < BM / 32; ++j) {
+      const int row = (tid + 256 * j) >> 3;
+      arow[j] = (m0 + row < g.M) ? outer_off(g.A, m0 + row) : 0;
+    }
+  }
+  if constexpr (!TB) {
+#pragma unroll
+    for (int j = 0; j < BN / 32; ++j) {
+      const int row = (tid + 256 * j) >> 3;
+      brow[j] = (n0 + row < g.N) ? outer_off(g.B, n0 + row) : 0;
+    }
+  }
+
+  f32x4 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  Stager<BM, TA> sa;
+  Stager<BN, TB> sb;
+  const int nk = (kend - kbeg + 63) / 64;
+  if (nk > 0) {
+    sa.load(g.A, Ab, m0, g.M, kbeg, kend, tid, arow);
+    sb.load(g.B, Bb, n0, g.N, kbeg, kend, tid, brow);
+    sa.store(As, tid);
+    sb.store(Bs, tid);
+  }
+  __syncthreads();
+
+  const int frow = lane & 15, fk = lane >> 4;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) {
+      const int k0 = kbeg + (kt + 1) * 64;
+      sa.load(g.A, Ab, m0, g.M, k0, kend, tid, arow);
+      sb.load(g.B, Bb, n0, g.N, k0, kend, tid, brow);
+    }
+    const bf16_t* Ac = As + cur * BM * 64;
+    const bf16_t* Bc = Bs + cur * BN * 64;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 af[FM], bfr[FN];
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
+        const int row = wm * (16 * FM) + i * 16 + frow;
+        af[i] = *reinterpret_cast<const bf16x8*>(Ac + row * 64 + (((kk * 4 + fk) ^ swz(row)) << 3));
+      }
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        const int row = wn * (16 * FN) + j * 16 + frow;
+        bfr[j] = *reinterpret_cast<const bf16x8*>(Bc + row * 64 + (((kk * 4 + fk) ^ swz(row)) << 3));
+      }
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+          // operands swapped: D[row = n][col = m] so each lane owns 4 consecutive n of one m
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nk) {
+      sa.store(As + (cur ^ 1) * BM * 64, tid);
+      sb.store(Bs + (cur ^ 1) * BN * 64, tid);
+    }
+    __syncthreads();
+  }
+
+  TC* Cz = reinterpret_cast<TC*>(g.C) + z0 * g.c_s0 + z1 * g.c_s1;
+  const TC* auxz = g.aux ? reinterpret_cast<const TC*>(g.aux) + z0 * g.aux_s0 + z1 * g.aux_s1 : nullptr;
+  TC* auxo = g.aux ? reinterpret_cast<TC*>(g.aux) + z0 * g.aux_s0 + z1 * g.aux_s1 : nullptr;
+  const float* bias = g.bias ? g.bias + z1 * g.bias_s1 : nullptr;
+#pragma unroll
+  for (int i = 0; i < FM; ++i) {
+    const int m = m0 + wm * (16 * FM) + i * 16 + frow;
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      const int n = n0 + wn * (16 * FN) + j * 16 + fk * 4;
+      const float a4[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+      epilogue_store4<TC>(g, Cz, auxz, auxo, bias, m, n, a4, split == 0);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------ exact f32 kernel
+template <typename TC>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
+  __shared__ float As[16][68];
+  __shared__ float Bs[16][68];
+  const int tid = threadIdx.x;
+  const int tx = tid & 15, ty = tid >> 4;  // 16 x 16 threads, 4x4 outputs each
+  const int tile = blockIdx.x;
+  const int tm = tile / g.tiles_n, tn = tile - tm * g.tiles_n;
+  const int m0 = tm * 64, n0 = tn * 64;
+  const int z = blockIdx.z;
+  const int z0 = z / g.batch_inner, z1 = z - z0 * g.batch_inner;
+  const int split = blockIdx.y;
+  const int kbeg = split * g.k_per_split;
+  const int kend = min(g.K, kbeg + g.k_per_split);
+  const float* Ab = reinterpret_cast<const float*>(g.A.ptr) + z0 * g.a_s0 + z1 * g.a_s1;
+  const float* Bb = reinterpret_cast<const float*>(g.B.ptr) + z0 * g.b_s0 + z1 * g.b_s1;
+
+  float acc[4][4] = {};
+  for (int k0 = kbeg; k0 < kend; k0 += 16) {
+    // each thread stages 4 elements of A and of B; index so that the contiguous (inner) dimension
+    // of the operand runs over consecutive threads
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int idx = tid + 256 * e;  // 0..1023
+      {
+        int r, k;
+        if (g.A.trans) { r = idx & 63; k = idx >> 6; } else { k = idx & 15; r = idx >> 4; }
+        float v = 0.f;
+        if (m0 + r < g.M && k0 + k < kend)
+          v = g.A.trans ? Ab[outer_off(g.A, k0 + k) + m0 + r] : Ab[outer_off(g.A, m0 + r) + k0 + k];
+        As[k][r] = v;
+      }
+      {
+        int r, k;
+        if (g.B.trans) { r = idx & 63; k = idx >> 6; } else { k = idx & 15; r = idx >> 4; }
+        float v = 0.f;
+        if (n0 + r < g.N && k0 + k < kend)
+          v = g.B.trans ? Bb[outer_off(g.B, k0 + k) + n0 + r] : Bb[outer_off(g.B, n0 + r) + k0 + k];
+        Bs[k][r] = v;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      float a[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = As[k][ty * 4 + i];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[j] = Bs[k][tx * 4 + j];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+  TC* Cz = reinterpret_cast<TC*>(g.C) + z0 * g.c_s0 + z1 * g.c_s1;
+  const TC* auxz = g.aux ? reinterpret_cast<const TC*>(g.aux) + z0 * g.aux_s0 + z1 * g.aux_s1 : nullptr;
+  TC* auxo = g.aux ? reinterpret_cast<TC*>(g.aux) + z0 * g.aux_s0 + z1 * g.aux_s1 : nullptr;
+  const float* bias = g.bias ? g.bias + z1 * g.bias_s1 : nullptr;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    epilogue_store4<TC>(g, Cz, auxz, auxo, bias, m0 + ty * 4 + i, n0 + tx * 4, acc[i], split == 0);
+}
+
+// ------------------------------------------------------------------------------ host dispatch
+static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+template <int FM, int FN, typename TC>
+static void launch_bf16(const GemmArgs& a, dim3 grid, hipStream_t st) {
+  constexpr size_t lds = (size_t)2 * (32 * FM + 32 * FN) * 64 * sizeof(bf16_t);
+  const bool ta = a.A.trans, tb = a.B.trans;
+#define W2V2_LAUNCH(TA_, TB_)                                                                   \
+  do {                                                                                          \
+    static bool attr_set = false;                                                               \
+    if (!attr_set) {                                                                            \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<FM, FN, TA_, TB_, TC>), \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);          \
+      attr_set = true;                                                                          \
+    }                                                                                           \
+    hipLaunchKernelGGL((gemm_bf16_kernel<FM, FN, TA_, TB_, TC>), grid, dim3(256), lds, st, a);  \
+  } while (0)
+  if (!ta && !tb) W2V2_LAUNCH(false, false);
+  else if (!ta && tb) W2V2_LAUNCH(false, true);
+  else if (ta && !tb) W2V2_LAUNCH(true, false);
+  else W2V2_LAUNCH(true, true);
+#undef W2V2_LAUNCH
+}
+
+extern "C" int w2v2_gemm(const w2v2_gemm_desc* d, void* stream) {
+  W2V2_REQUIRE(d != nullptr, "w2v2_gemm: null descriptor");
+  W2V2_REQUIRE(d->M > 0 && d->N > 0 && d->K >= 0 && d->batch > 0, "w2v2_gemm: bad shape M=%d N=%d K=%d batch=%d",
+               d->M, d->N, d->K, d->batch);
+  W2V2_REQUIRE(d->A.ptr && d->B.ptr && d->C, "w2v2_gemm: null operand");
+  W2V2_REQUIRE(d->dtype_ab == W2V2_F32 || d->dtype_ab == W2V2_BF16, "w2v2_gemm: bad dtype_ab %d", d->dtype_ab);
+  W2V2_REQUIRE(d->dtype_c == W2V2_F32 || d->dtype_c == W2V2_BF16, "w2v2_gemm: bad dtype_c %d", d->dtype_c);
+  W2V2_REQUIRE(d->epilogue >= 0 && d->epilogue <= W2V2_EPI_SCALE_RC, "w2v2_gemm: bad epilogue %d", d->epilogue);
+  const int split = d->split_k > 1 ? d->split_k : 1;
+  const int atomic = (split > 1 || d->accumulate) ? 1 : 0;
+  if (atomic) {
+    W2V2_REQUIRE(d->dtype_c == W2V2_F32, "w2v2_gemm: split_k/accumulate need an f32 C");
+    W2V2_REQUIRE(d->epilogue == W2V2_EPI_NONE || (split == 1) || d->epilogue == W2V2_EPI_BIAS,
+                 "w2v2_gemm: split_k supports EPI_NONE/EPI_BIAS only");
+  }
+  if (d->epilogue == W2V2_EPI_BIAS || d->epilogue == W2V2_EPI_BIAS_GELU)
+    W2V2_REQUIRE(d->bias != nullptr, "w2v2_gemm: bias epilogue without bias");
+  if (d->epilogue == W2V2_EPI_GELU_BWD || d->epilogue == W2V2_EPI_ADD)
+    W2V2_REQUIRE(d->aux != nullptr, "w2v2_gemm: epilogue %d needs aux", d->epilogue);
+  if (d->epilogue == W2V2_EPI_SCALE_RC)
+    W2V2_REQUIRE(d->row_scale && d->col_scale, "w2v2_gemm: EPI_SCALE_RC needs row/col scales");
+
+  GemmArgs a;
+  a.M = d->M; a.N = d->N; a.K = d->K;
+  a.epilogue = d->epilogue; a.split_k = split; a.atomic = atomic;
+  a.batch_inner = d->batch_inner > 0 ? d->batch_inner : 1;
+  auto cvt = [&](const w2v2_operand& o, int64_t s0, int64_t s1) {
+    OpDev r;
+    r.ptr = o.ptr; r.ld = o.ld; r.seg_len = o.seg_len; r.seg_stride = o.seg_stride; r.trans = o.trans ? 1 : 0;
+    r.vec_ok = aligned16(o.ptr) && (o.ld % 8 == 0) && (o.seg_stride % 8 == 0) && (s0 % 8 == 0) && (s1 % 8 == 0);
+    return r;
+  };
+  a.A = cvt(d->A, d->A.stride0, d->A.stride1);
+  a.B = cvt(d->B, d->B.stride0, d->B.stride1);
+  a.a_s0 = d->A.stride0; a.a_s1 = d->A.stride1; a.b_s0 = d->B.stride0; a.b_s1 = d->B.stride1;
+  a.C = d->C; a.ldc = d->ldc; a.c_s0 = d->c_stride0; a.c_s1 = d->c_stride1;
+  a.aux = d->aux; a.ldaux = d->ldaux; a.aux_s0 = d->aux_stride0; a.aux_s1 = d->aux_stride1;
+  a.bias = d->bias; a.bias_s1 = d->bias_stride1;
+  a.row_scale = d->row_scale; a.col_scale = d->col_scale;
+  a.alpha = d->alpha;
+  const int csz = d->dtype_c == W2V2_F32 ? 4 : 2;
+  a.c_vec_ok = ((reinterpret_cast<uintptr_t>(d->C) % (4 * csz)) == 0) && (d->ldc % 4 == 0) &&
+               (d->c_stride0 % 4 == 0) && (d->c_stride1 % 4 == 0);
+  hipStream_t st = as_stream(stream);
+
+  if (d->dtype_ab == W2V2_BF16) {
+    const bool narrow = d->N <= 64;
+    const int BM = 128, BN = narrow ? 64 : 128;
+    a.tiles_m = (int)cdiv(d->M, BM); a.tiles_n = (int)cdiv(d->N, BN);
+    a.k_per_split = (int)(cdiv(cdiv(d->K, split), 64) * 64);
+    if (a.k_per_split == 0) a.k_per_split = 64;
+    dim3 grid(a.tiles_m * a.tiles_n, split, d->batch);
+    if (d->dtype_c == W2V2_F32) {
+      if (narrow) launch_bf16<4, 2, float>(a, grid, st); else launch_bf16<4, 4, float>(a, grid, st);
+    } else {
+      if (narrow) launch_bf16<4, 2, bf16_t>(a, grid, st); else launch_bf16<4, 4, bf16_t>(a, grid, st);
+    }
+  } else {
+    W2V2_REQUIRE(d->dtype_c == W2V2_F32, "w2v2_gemm: f32 operands need an f32 C");
+    a.tiles_m = (int)cdiv(d->M, 64); a.tiles_n = (int)cdiv(d->N, 64);
+    a.k_per_split = (int)(cdiv(cdiv(d->K, split), 16) * 16);
+    if (a.k_per_split == 0) a.k_per_split = 16;
+    dim3 grid(a.tiles_m * a.tiles_n, split, d->batch);
+    hipLaunchKernelGGL(gemm_f32_kernel<float>, grid, dim3(256), 0, st, a);
+  }
+  W2V2_CHECK_LAUNCH("w2v2_gemm");
+  return 0;
+}

@@ -1,0 +1,160 @@
+// heads.hip -- speaker classification heads: AAM-softmax (ref: src/optim/loss/aam_softmax.py:50-74)
+// and the plain CE head (ref: src/optim/loss/cross_entropy.py:27-31).  The cosine / logit products
+// run on the GEMM (EPI_SCALE_RC folds both F.normalize calls into its epilogue); the kernels here do
+// the row norms, the margin + scale + softmax + cross-entropy row pass (forward AND the gradient
+// wrt the cosines in one sweep over [B, C]) and the F.normalize backward.
+#include "common.cuh"
+
+template <typename T>
+__global__ __launch_bounds__(256) void row_invnorm_kernel(const T* __restrict__ x, int64_t ld, float* __restrict__ inv,
+                                                          int rows, int cols) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const T* xr = x + (int64_t)row * ld;
+  float s = 0.f;
+  for (int c = lane; c < cols; c += 64) { const float v = to_f32<T>(xr[c]); s = fmaf(v, v, s); }
+  s = wave_sum(s);
+  if (lane == 0) inv[row] = 1.0f / fmaxf(sqrtf(s), 1e-12f);   // F.normalize eps
+}
+
+extern "C" int w2v2_row_invnorm(const void* x, int64_t ld, float* inv, int rows, int cols, int dtype, void* stream) {
+  W2V2_REQUIRE(x && inv && rows > 0 && cols > 0 && ld >= cols, "row_invnorm: bad arguments");
+  dim3 grid((unsigned)cdiv(rows, 4));
+  if (dtype == W2V2_BF16)
+    hipLaunchKernelGGL(row_invnorm_kernel<bf16_t>, grid, dim3(256), 0, as_stream(stream), (const bf16_t*)x, ld, inv, rows, cols);
+  else if (dtype == W2V2_F32)
+    hipLaunchKernelGGL(row_invnorm_kernel<float>, grid, dim3(256), 0, as_stream(stream), (const float*)x, ld, inv, rows, cols);
+  else
+    W2V2_FAIL("row_invnorm: bad dtype %d", dtype);
+  W2V2_CHECK_LAUNCH("row_invnorm");
+  return 0;
+}
+
+__device__ __forceinline__ float block_reduce(float v, float* sh, bool is_max) {
+  v = is_max ? wave_max(v) : wave_sum(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) sh[wave] = v;
+  __syncthreads();
+  const float a = sh[0], b = sh[1], c = sh[2], d = sh[3];
+  return is_max ? fmaxf(fmaxf(a, b), fmaxf(c, d)) : (a + b + c + d);
+}
+
+// One workgroup per utterance row.  z_c = s*cos_c (c != y), z_y = s*phi(cos_y); loss = lse(z) - z_y.
+// dLoss/dcos_c = s * (softmax_c - [c==y]) / B * (c == y ? dphi/dcos : 1).
+template <typename T>
+__global__ __launch_bounds__(256) void aam_row_kernel(const float* __restrict__ cosv, const int64_t* __restrict__ label,
+                                                      float* __restrict__ softmax, float* __restrict__ loss_rows,
+                                                      T* __restrict__ dcos_w, T* __restrict__ dcos_x,
+                                                      const float* __restrict__ inv_x,
+                                                      const float* __restrict__ inv_w, float* __restrict__ rowdot,
+                                                      float* __restrict__ coldot, int B, int C, int64_t ldc,
+                                                      float margin, float scale) {
+  __shared__ float sh[4];
+  const int b = blockIdx.x;
+  const int y = (int)label[b];
+  const float* cr = cosv + (int64_t)b * ldc;
+  const bool plain = margin < 0.f;
+  float zy, dphi = 1.0f, sc = plain ? 1.0f : scale;
+  {
+    const float cy = cr[y];
+    if (plain) {
+      zy = cy;
+    } else {
+      const float cos_m = cosf(margin), sin_m = sinf(margin);
+      const float th = cosf(3.14159265358979323846f - margin);
+      const float mm = sinf(3.14159265358979323846f - margin) * margin;
+      const float sine = sqrtf(fminf(fmaxf(1.0f - cy * cy, 0.f), 1.f));
+      float phi = cy * cos_m - sine * sin_m;
+      if (cy - th > 0.f) {
+        dphi = cos_m + sin_m * cy / fmaxf(sine, 1e-12f);
+      } else {
+        phi = cy - mm;
+        dphi = 1.0f;
+      }
+      zy = phi * scale;
+    }
+  }
+  float mx = -INFINITY;
+  for (int c = threadIdx.x; c < C; c += 256) mx = fmaxf(mx, c == y ? zy : cr[c] * sc);
+  mx = block_reduce(mx, sh, true);
+  float sum = 0.f;
+  for (int c = threadIdx.x; c < C; c += 256) sum += __expf((c == y ? zy : cr[c] * sc) - mx);
+  sum = block_reduce(sum, sh, false);
+  const float inv = 1.0f / sum;
+  if (threadIdx.x == 0) loss_rows[b] = (mx + __logf(sum)) - zy;
+  const float invB = 1.0f / (float)B;
+  float rd = 0.f;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const float cv = cr[c];
+    const float p = __expf((c == y ? zy : cv * sc) - mx) * inv;
+    softmax[(int64_t)b * ldc + c] = p;
+    if (dcos_w != nullptr) {
+      float g = (p - (c == y ? 1.0f : 0.0f)) * invB * sc;
+      if (c == y) g *= dphi;
+      // the two F.normalize scalings are folded into the operands of the two gradient GEMMs
+      dcos_w[(int64_t)b * ldc + c] = from_f32<T>(inv_w ? g * inv_w[c] : g);
+      if (dcos_x != nullptr) dcos_x[(int64_t)b * ldc + c] = from_f32<T>(inv_x ? g * inv_x[b] : g);
+      if (coldot != nullptr) {
+        rd = fmaf(g, cv, rd);
+        unsafeAtomicAdd(coldot + c, g * cv);
+      }
+    }
+  }
+  if (rowdot != nullptr) {
+    rd = block_reduce(rd, sh, false);
+    if (threadIdx.x == 0) rowdot[b] = rd;
+  }
+}
+
+extern "C" int w2v2_aam_softmax_fwd_bwd(const float* cos, const int64_t* label, float* softmax, float* loss_rows,
+                                        void* dcos_w, void* dcos_x, const float* inv_x, const float* inv_w,
+                                        float* rowdot, float* coldot, int B, int C, int64_t ldc, float margin,
+                                        float scale, int dtype, void* stream) {
+  W2V2_REQUIRE(cos && label && softmax && loss_rows && B > 0 && C > 0 && ldc >= C, "aam_softmax: bad arguments");
+  if (dtype == W2V2_BF16)
+    hipLaunchKernelGGL(aam_row_kernel<bf16_t>, dim3(B), dim3(256), 0, as_stream(stream), cos, label, softmax,
+                       loss_rows, (bf16_t*)dcos_w, (bf16_t*)dcos_x, inv_x, inv_w, rowdot, coldot, B, C, ldc, margin,
+                       scale);
+  else if (dtype == W2V2_F32)
+    hipLaunchKernelGGL(aam_row_kernel<float>, dim3(B), dim3(256), 0, as_stream(stream), cos, label, softmax,
+                       loss_rows, (float*)dcos_w, (float*)dcos_x, inv_x, inv_w, rowdot, coldot, B, C, ldc, margin,
+                       scale);
+  else
+    W2V2_FAIL("aam_softmax: bad dtype %d", dtype);
+  W2V2_CHECK_LAUNCH("aam_softmax");
+  return 0;
+}
+
+// F.normalize backward: y = x * inv, upstream g = dL/dy:  dx = inv * (g - y * <y, g>) = inv * (g - x * inv * dot)
+// where the caller supplies dot[r] = <y_r, g_r> = sum_c dcos[r,c] * cos[r,c] (DESIGN.md "AAM backward").
+template <typename TX>
+__global__ void normalize_bwd_kernel(const float* __restrict__ g, const TX* __restrict__ x, int64_t ldx,
+                                     const float* __restrict__ inv, const float* __restrict__ dot,
+                                     float* __restrict__ dx, int rows, int cols, int add) {
+  const int64_t total = (int64_t)rows * cols;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i / cols), c = (int)(i - (int64_t)r * cols);
+    const float iv = inv[r];
+    const float v = iv * (g[i] - to_f32<TX>(x[(int64_t)r * ldx + c]) * iv * dot[r]);
+    dx[i] = add ? dx[i] + v : v;
+  }
+}
+
+extern "C" int w2v2_normalize_bwd(const float* g, const void* x, int64_t ldx, const float* inv, const float* dot,
+                                  float* dx, int rows, int cols, int x_dtype, int add, void* stream) {
+  W2V2_REQUIRE(g && x && inv && dot && dx && rows > 0 && cols > 0 && ldx >= cols, "normalize_bwd: bad arguments");
+  const int64_t total = (int64_t)rows * cols;
+  int nb = (int)(cdiv(total, 256) > 4096 ? 4096 : cdiv(total, 256));
+  if (x_dtype == W2V2_BF16)
+    hipLaunchKernelGGL(normalize_bwd_kernel<bf16_t>, dim3(nb), dim3(256), 0, as_stream(stream), g, (const bf16_t*)x,
+                       ldx, inv, dot, dx, rows, cols, add);
+  else if (x_dtype == W2V2_F32)
+    hipLaunchKernelGGL(normalize_bwd_kernel<float>, dim3(nb), dim3(256), 0, as_stream(stream), g, (const float*)x,
+                       ldx, inv, dot, dx, rows, cols, add);
+  else
+    W2V2_FAIL("normalize_bwd: bad dtype %d", x_dtype);
+  W2V2_CHECK_LAUNCH("normalize_bwd");
+  return 0;
+}

@@ -1,0 +1,197 @@
+// norm.hip -- LayerNorm(+residual +dropout) forward / backward (HF:429, HF:596-601, HF:691-692).
+// One 64-lane wave per token row, 16-byte vector accesses, wave-shuffle reductions; statistics f32.
+#include "common.cuh"
+
+constexpr int LN_MAXC = 2;  // vec8 chunks per lane: H <= 1024
+
+template <typename T>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, T* __restrict__ r,
+                                                     const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, T* __restrict__ y,
+                                                     float* __restrict__ mean_o, float* __restrict__ rstd_o,
+                                                     int M, int H, float eps, float p, uint64_t seed) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row = blockIdx.x * 4 + wave;
+  if (row >= M) return;
+  const int nch = H >> 3;
+  const float inv_keep = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
+  float s[LN_MAXC][8];
+  float sum = 0.f;
+#pragma unroll
+  for (int ci = 0; ci < LN_MAXC; ++ci) {
+    const int ch = lane + 64 * ci;
+    if (ch < nch) {
+      const int64_t off = (int64_t)row * H + ch * 8;
+      Vec8<T> vx;
+      vx.load(x + off);
+      if (r != nullptr) {
+        Vec8<T> vr;
+        vr.load(r + off);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float rv = vr.v[e];
+          if (p > 0.f) rv *= drop_scale(seed, (uint64_t)(off + e), p, inv_keep);
+          vx.v[e] += rv;
+        }
+        vx.store(r + off);  // pre-norm sum saved for backward
+        // keep the stored (possibly bf16-rounded) value so fwd and bwd see the same s
+#pragma unroll
+        for (int e = 0; e < 8; ++e) vx.v[e] = to_f32<T>(from_f32<T>(vx.v[e]));
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { s[ci][e] = vx.v[e]; sum += vx.v[e]; }
+    }
+  }
+  const float mean = wave_sum(sum) / (float)H;
+  float sq = 0.f;
+#pragma unroll
+  for (int ci = 0; ci < LN_MAXC; ++ci)
+    if (lane + 64 * ci < nch)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float d = s[ci][e] - mean; sq += d * d; }
+  const float var = wave_sum(sq) / (float)H;
+  const float rstd = rsqrtf(var + eps);
+  if (lane == 0) { mean_o[row] = mean; rstd_o[row] = rstd; }
+#pragma unroll
+  for (int ci = 0; ci < LN_MAXC; ++ci) {
+    const int ch = lane + 64 * ci;
+    if (ch < nch) {
+      Vec8<float> g, b;
+      g.load(gamma + ch * 8);
+      b.load(beta + ch * 8);
+      Vec8<T> o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o.v[e] = (s[ci][e] - mean) * rstd * g.v[e] + b.v[e];
+      o.store(y + (int64_t)row * H + ch * 8);
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ s,
+                                                     const float* __restrict__ mean,
+                                                     const float* __restrict__ rstd,
+                                                     const float* __restrict__ gamma, T* __restrict__ ds,
+                                                     T* __restrict__ d_r, float* __restrict__ dgamma,
+                                                     float* __restrict__ dbeta, int M, int H, float p,
+                                                     uint64_t seed) {
+  __shared__ float red[4][LN_MAXC * 64 * 8];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nch = H >> 3;
+  const float inv_keep = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
+  float ag[LN_MAXC][8] = {}, ab[LN_MAXC][8] = {};
+  float gm[LN_MAXC][8];
+#pragma unroll
+  for (int ci = 0; ci < LN_MAXC; ++ci) {
+    const int ch = lane + 64 * ci;
+    if (ch < nch) {
+      Vec8<float> g;
+      g.load(gamma + ch * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) gm[ci][e] = g.v[e];
+    }
+  }
+  for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+    const float mu = mean[row], rs = rstd[row];
+    float xh[LN_MAXC][8], g[LN_MAXC][8];
+    float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+    for (int ci = 0; ci < LN_MAXC; ++ci) {
+      const int ch = lane + 64 * ci;
+      if (ch < nch) {
+        const int64_t off = (int64_t)row * H + ch * 8;
+        Vec8<T> vdy, vs;
+        vdy.load(dy + off);
+        vs.load(s + off);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          xh[ci][e] = (vs.v[e] - mu) * rs;
+          g[ci][e] = vdy.v[e] * gm[ci][e];
+          c1 += g[ci][e];
+          c2 += g[ci][e] * xh[ci][e];
+          ag[ci][e] += vdy.v[e] * xh[ci][e];
+          ab[ci][e] += vdy.v[e];
+        }
+      }
+    }
+    c1 = wave_sum(c1) / (float)H;
+    c2 = wave_sum(c2) / (float)H;
+#pragma unroll
+    for (int ci = 0; ci < LN_MAXC; ++ci) {
+      const int ch = lane + 64 * ci;
+      if (ch < nch) {
+        const int64_t off = (int64_t)row * H + ch * 8;
+        Vec8<T> o, o2;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          o.v[e] = rs * (g[ci][e] - c1 - xh[ci][e] * c2);
+          if (d_r != nullptr) o2.v[e] = o.v[e] * drop_scale(seed, (uint64_t)(off + e), p, inv_keep);
+        }
+        o.store(ds + off);
+        if (d_r != nullptr) o2.store(d_r + off);
+      }
+    }
+  }
+  if (dgamma == nullptr) return;
+  // cross-wave reduction of the per-lane column partials, then one atomic per column per block
+  for (int pass = 0; pass < 2; ++pass) {
+    __syncthreads();
+#pragma unroll
+    for (int ci = 0; ci < LN_MAXC; ++ci)
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        red[wave][(ci * 64 + lane) * 8 + e] = pass == 0 ? ag[ci][e] : ab[ci][e];
+    __syncthreads();
+    for (int i = threadIdx.x; i < LN_MAXC * 64 * 8; i += 256) {
+      const int ci = i / 512, rem = i - ci * 512, ln = rem >> 3, e = rem & 7;
+      const int col = (ln + 64 * ci) * 8 + e;
+      if (col < H) {
+        const float v = red[0][i] + red[1][i] + red[2][i] + red[3][i];
+        unsafeAtomicAdd((pass == 0 ? dgamma : dbeta) + col, v);
+      }
+    }
+  }
+}
+
+extern "C" int w2v2_layernorm_fwd(const void* x, void* r, const float* gamma, const float* beta, void* y,
+                                  float* mean, float* rstd, int M, int H, float eps, float drop_p,
+                                  uint64_t seed, int dtype, void* stream) {
+  W2V2_REQUIRE(x && gamma && beta && y && mean && rstd, "layernorm_fwd: null pointer");
+  W2V2_REQUIRE(H % 8 == 0 && H <= 8 * 64 * LN_MAXC, "layernorm_fwd: H=%d unsupported (need H%%8==0, H<=1024)", H);
+  W2V2_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "layernorm_fwd: bad dropout p");
+  if (M <= 0) return 0;
+  dim3 grid((unsigned)cdiv(M, 4));
+  if (dtype == W2V2_BF16)
+    hipLaunchKernelGGL(ln_fwd_kernel<bf16_t>, grid, dim3(256), 0, as_stream(stream), (const bf16_t*)x,
+                       (bf16_t*)r, gamma, beta, (bf16_t*)y, mean, rstd, M, H, eps, drop_p, seed);
+  else if (dtype == W2V2_F32)
+    hipLaunchKernelGGL(ln_fwd_kernel<float>, grid, dim3(256), 0, as_stream(stream), (const float*)x,
+                       (float*)r, gamma, beta, (float*)y, mean, rstd, M, H, eps, drop_p, seed);
+  else
+    W2V2_FAIL("layernorm_fwd: bad dtype %d", dtype);
+  W2V2_CHECK_LAUNCH("layernorm_fwd");
+  return 0;
+}
+
+extern "C" int w2v2_layernorm_bwd(const void* dy, const void* s, const float* mean, const float* rstd,
+                                  const float* gamma, void* ds, void* d_r, float* dgamma, float* dbeta,
+                                  int M, int H, float drop_p, uint64_t seed, int dtype, void* stream) {
+  W2V2_REQUIRE(dy && s && mean && rstd && gamma && ds, "layernorm_bwd: null pointer");
+  W2V2_REQUIRE(H % 8 == 0 && H <= 8 * 64 * LN_MAXC, "layernorm_bwd: H=%d unsupported", H);
+  W2V2_REQUIRE((dgamma == nullptr) == (dbeta == nullptr), "layernorm_bwd: dgamma/dbeta must come together");
+  if (M <= 0) return 0;
+  if (drop_p <= 0.f) d_r = nullptr;
+  const int nb = (int)(cdiv(M, 4) < 1024 ? cdiv(M, 4) : 1024);
+  if (dtype == W2V2_BF16)
+    hipLaunchKernelGGL(ln_bwd_kernel<bf16_t>, dim3(nb), dim3(256), 0, as_stream(stream), (const bf16_t*)dy,
+                       (const bf16_t*)s, mean, rstd, gamma, (bf16_t*)ds, (bf16_t*)d_r, dgamma, dbeta, M, H,
+                       drop_p, seed);
+  else if (dtype == W2V2_F32)
+    hipLaunchKernelGGL(ln_bwd_kernel<float>, dim3(nb), dim3(256), 0, as_stream(stream), (const float*)dy,
+                       (const float*)s, mean, rstd, gamma, (float*)ds, (float*)d_r, dgamma, dbeta, M, H,
+                       drop_p, seed);
+  else
+    W2V2_FAIL("layernorm_bwd: bad dtype %d", dtype);
+  W2V2_CHECK_LAUNCH("layernorm_bwd");
+  return 0;
+}

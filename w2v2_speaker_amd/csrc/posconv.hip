@@ -1,0 +1,139 @@
+// posconv.hip -- helpers around the grouped, weight-normed positional Conv1d (HF:326-379).
+// The convolution itself runs on the MFMA GEMM as an implicit GEMM per group; these kernels build
+// its operands: the padded group-major activation image and the weight-norm-ed packed weights, and
+// the weight-norm backward.
+#include "common.cuh"
+
+// x [B,T,H] -> xg [B,G,Tp,Cg], Tp = T+K-1, xg[b,g,tp,c] = x[b, tp-pad_left, g*Cg+c] (0 outside).
+// A row of the implicit GEMM for output frame t of group g is the contiguous K*Cg run starting at
+// xg[b,g,t,0]:  lda = Cg, seg_len = T, seg_stride = G*Tp*Cg.
+template <typename T>
+__global__ void regroup_kernel(const T* __restrict__ x, T* __restrict__ xg, int B, int Tn, int H, int G, int K,
+                               int pad_left) {
+  const int Cg = H / G, Tp = Tn + K - 1, nch = Cg >> 3;
+  const int64_t total = (int64_t)B * G * Tp * nch;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int ch = (int)(i % nch);
+    int64_t r = i / nch;
+    const int tp = (int)(r % Tp); r /= Tp;
+    const int g = (int)(r % G);
+    const int b = (int)(r / G);
+    const int t = tp - pad_left;
+    Vec8<T> v;
+    if (t >= 0 && t < Tn) {
+      v.load(x + ((int64_t)b * Tn + t) * H + g * Cg + ch * 8);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v.v[e] = 0.f;
+    }
+    v.store(xg + (((int64_t)b * G + g) * Tp + tp) * Cg + ch * 8);
+  }
+}
+
+extern "C" int w2v2_posconv_regroup(const void* x, void* xg, int B, int T, int H, int G, int K, int pad_left,
+                                    int dtype, void* stream) {
+  W2V2_REQUIRE(x && xg && B > 0 && T > 0 && G > 0 && H % G == 0 && (H / G) % 8 == 0 && K > 0,
+               "posconv_regroup: bad arguments (H/G must be a multiple of 8)");
+  const int64_t total = (int64_t)B * G * (T + K - 1) * ((H / G) >> 3);
+  int nb = (int)(cdiv(total, 256) > 8192 ? 8192 : cdiv(total, 256));
+  if (dtype == W2V2_BF16)
+    hipLaunchKernelGGL(regroup_kernel<bf16_t>, dim3(nb), dim3(256), 0, as_stream(stream), (const bf16_t*)x,
+                       (bf16_t*)xg, B, T, H, G, K, pad_left);
+  else if (dtype == W2V2_F32)
+    hipLaunchKernelGGL(regroup_kernel<float>, dim3(nb), dim3(256), 0, as_stream(stream), (const float*)x,
+                       (float*)xg, B, T, H, G, K, pad_left);
+  else
+    W2V2_FAIL("posconv_regroup: bad dtype %d", dtype);
+  W2V2_CHECK_LAUNCH("posconv_regroup");
+  return 0;
+}
+
+// per-tap reductions over v [H][Cg][K] (K fastest): out[k] += sum_{o,i} a*b
+template <bool WITH_DW>
+__global__ __launch_bounds__(256) void tap_reduce_kernel(const float* __restrict__ v, const float* __restrict__ dwf,
+                                                         float* __restrict__ out, int H, int Cg, int K) {
+  // thread -> tap (k = tid % K when K <= 256); rows (o,i) strided over blocks
+  const int rows = H * Cg;
+  const int kpt = threadIdx.x % K, rlane = threadIdx.x / K, rlanes = 256 / K;
+  if (rlane >= rlanes) return;
+  float acc = 0.f;
+  for (int r = blockIdx.x * rlanes + rlane; r < rows; r += gridDim.x * rlanes) {
+    const float vv = v[(int64_t)r * K + kpt];
+    if constexpr (WITH_DW) {
+      const int o = r / Cg, i = r - o * Cg;
+      const int g = o / Cg, co = o - g * Cg;
+      acc += vv * dwf[(((int64_t)g * Cg + co) * K + kpt) * Cg + i];
+    } else {
+      acc += vv * vv;
+    }
+  }
+  unsafeAtomicAdd(out + kpt, acc);
+}
+
+template <typename T>
+__global__ void wn_pack_kernel(const float* __restrict__ g, const float* __restrict__ v,
+                               const float* __restrict__ sumsq, T* __restrict__ wf, T* __restrict__ wb, int H,
+                               int Cg, int K) {
+  const int64_t total = (int64_t)H * Cg * K;
+  for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int tap = (int)(idx % K);
+    const int64_t r = idx / K;
+    const int i = (int)(r % Cg), o = (int)(r / Cg);
+    const int gi = o / Cg, co = o - gi * Cg;
+    const float wv = g[tap] * v[idx] * rsqrtf(sumsq[tap]);
+    wf[(((int64_t)gi * Cg + co) * K + tap) * Cg + i] = from_f32<T>(wv);
+    wb[(((int64_t)gi * Cg + i) * K + (K - 1 - tap)) * Cg + co] = from_f32<T>(wv);
+  }
+}
+
+extern "C" int w2v2_weightnorm_pack(const float* g, const float* v, float* sumsq, void* wf, void* wb, int H, int G,
+                                    int K, int dtype, void* stream) {
+  W2V2_REQUIRE(g && v && sumsq && wf && wb && G > 0 && H % G == 0 && K > 0 && K <= 256, "weightnorm_pack: bad arguments");
+  const int Cg = H / G;
+  hipStream_t st = as_stream(stream);
+  if (hipMemsetAsync(sumsq, 0, sizeof(float) * K, st) != hipSuccess) W2V2_FAIL("weightnorm_pack: memset failed");
+  hipLaunchKernelGGL((tap_reduce_kernel<false>), dim3(256), dim3(256), 0, st, v, (const float*)nullptr, sumsq, H, Cg, K);
+  const int64_t total = (int64_t)H * Cg * K;
+  int nb = (int)(cdiv(total, 256) > 4096 ? 4096 : cdiv(total, 256));
+  if (dtype == W2V2_BF16)
+    hipLaunchKernelGGL(wn_pack_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, g, v, sumsq, (bf16_t*)wf, (bf16_t*)wb, H, Cg, K);
+  else if (dtype == W2V2_F32)
+    hipLaunchKernelGGL(wn_pack_kernel<float>, dim3(nb), dim3(256), 0, st, g, v, sumsq, (float*)wf, (float*)wb, H, Cg, K);
+  else
+    W2V2_FAIL("weightnorm_pack: bad dtype %d", dtype);
+  W2V2_CHECK_LAUNCH("weightnorm_pack");
+  return 0;
+}
+
+// w = g_k v / n_k:  dg_k = dot_k / n_k,  dv = g_k/n_k * (dw - v * dot_k / n_k^2),  dot_k = sum dw*v
+__global__ void wn_bwd_kernel(const float* __restrict__ g, const float* __restrict__ v,
+                              const float* __restrict__ sumsq, const float* __restrict__ dwf,
+                              const float* __restrict__ dot, float* __restrict__ dg, float* __restrict__ dv, int H,
+                              int Cg, int K) {
+  const int64_t total = (int64_t)H * Cg * K;
+  for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int tap = (int)(idx % K);
+    const int64_t r = idx / K;
+    const int i = (int)(r % Cg), o = (int)(r / Cg);
+    const int gi = o / Cg, co = o - gi * Cg;
+    const float n2 = sumsq[tap], rn = rsqrtf(n2);
+    const float dw = dwf[(((int64_t)gi * Cg + co) * K + tap) * Cg + i];
+    dv[idx] = g[tap] * rn * (dw - v[idx] * dot[tap] / n2);
+    if (idx < K) dg[idx] = dot[idx] * rsqrtf(sumsq[idx]);
+  }
+}
+
+extern "C" int w2v2_weightnorm_bwd(const float* g, const float* v, const float* sumsq, const float* dwf, float* dot,
+                                   float* dg, float* dv, int H, int G, int K, void* stream) {
+  W2V2_REQUIRE(g && v && sumsq && dwf && dot && dg && dv && G > 0 && H % G == 0 && K > 0 && K <= 256,
+               "weightnorm_bwd: bad arguments");
+  const int Cg = H / G;
+  hipStream_t st = as_stream(stream);
+  if (hipMemsetAsync(dot, 0, sizeof(float) * K, st) != hipSuccess) W2V2_FAIL("weightnorm_bwd: memset failed");
+  hipLaunchKernelGGL((tap_reduce_kernel<true>), dim3(256), dim3(256), 0, st, v, dwf, dot, H, Cg, K);
+  const int64_t total = (int64_t)H * Cg * K;
+  int nb = (int)(cdiv(total, 256) > 4096 ? 4096 : cdiv(total, 256));
+  hipLaunchKernelGGL(wn_bwd_kernel, dim3(nb), dim3(256), 0, st, g, v, sumsq, dwf, dot, dg, dv, H, Cg, K);
+  W2V2_CHECK_LAUNCH("weightnorm_bwd");
+  return 0;
+}

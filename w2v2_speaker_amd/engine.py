@@ -1,0 +1,510 @@
+"""Static execution plans for the wav2vec2 speaker path on one MI355X.
+
+A ``Plan`` is built once per (batch, samples, mode): it allocates every activation / saved-for-backward
+buffer out of HBM up front (the whole base model at B=66 needs ~3 GB of 288 GB) and pre-builds every
+GEMM descriptor over those fixed buffers, so a training step is a flat sequence of C-ABI launches on
+one HIP stream with no allocation, no autograd graph and no host<->device sync.  Forward and the
+hand-written backward follow SURVEY.md 3.2 / 8(a) rows a2-a14 (HF:382-726 +
+ref: src/layers/pooling.py, src/optim/loss/aam_softmax.py, src/optim/loss/cross_entropy.py).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Callable, Dict, List, Optional, Sequence
+
+import torch
+
+from . import ops
+from .config import W2V2Config, Wav2Vec2RegularisationConfig
+from .ops import (EPI_ADD, EPI_BIAS, EPI_BIAS_GELU, EPI_GELU_BWD, EPI_NONE, EPI_SCALE_RC, Gemm, POOL_MODES)
+from .params import ParamStore
+
+_SITE = {"featproj": 1, "prologue": 2, "attn": 3, "post_attn": 4, "ffn": 5, "act": 6}
+
+
+def _splitk(m_tiles: int, n_tiles: int, k: int, batch: int = 1) -> int:
+    """Split K of the weight-gradient GEMMs (K = tokens) until ~2 workgroups per CU are in flight."""
+    blocks = max(1, m_tiles * n_tiles * batch)
+    s = max(1, min(16, 512 // blocks))
+    while s > 1 and k // s < 256:
+        s -= 1
+    return s
+
+
+def _tiles(n: int, t: int = 128) -> int:
+    return (n + t - 1) // t
+
+
+@dataclass
+class LayerBufs:
+    qkv: torch.Tensor
+    ctx: torch.Tensor
+    a: torch.Tensor        # out-proj output, overwritten with s1 = x + drop(a)
+    x1: torch.Tensor
+    hpre: torch.Tensor
+    h: torch.Tensor
+    f: torch.Tensor        # FFN output, overwritten with s2
+    mean1: torch.Tensor
+    rstd1: torch.Tensor
+    mean2: torch.Tensor
+    rstd2: torch.Tensor
+    lse: Optional[torch.Tensor] = None      # fused attention
+    p: Optional[torch.Tensor] = None        # unfused attention probabilities
+    pd: Optional[torch.Tensor] = None       # ... after dropout
+
+
+class Plan:
+    def __init__(self, store: ParamStore, batch: int, n_samples: int, *, train: bool,
+                 reg: Optional[Wav2Vec2RegularisationConfig] = None, pooling: str = "mean+std",
+                 insert_cls_token: bool = False, cls_token_constant: float = 1.0,
+                 aam_margin: float = 0.2, aam_scale: float = 30.0, fused_attention: Optional[bool] = None,
+                 seed: int = 7):
+        cfg = store.cfg
+        self.store, self.cfg, self.B, self.N, self.train = store, cfg, batch, n_samples, train
+        self.reg = reg if reg is not None else Wav2Vec2RegularisationConfig()
+        self.pooling, self.pool_mode = pooling, POOL_MODES[pooling]
+        self.cls, self.cls_c = insert_cls_token, cls_token_constant
+        self.margin, self.scale = aam_margin, aam_scale
+        self.seed = seed
+        self.dev, self.adt = store.device, store.act_dtype
+        self.lens = cfg.conv_lengths(n_samples)
+        self.T0 = self.lens[-1]                       # frames out of the CNN
+        self.T = self.T0 + (1 if insert_cls_token else 0)
+        self.M0, self.M = batch * self.T0, batch * self.T
+        H, d = cfg.hidden_size, cfg.head_dim
+        if fused_attention is None:
+            fused_attention = (self.adt == torch.bfloat16 and d == 64 and self.T <= 256)
+        self.fused = fused_attention
+        self.embed_dim = H * (2 if pooling == "mean+std" else 1)
+        self._pack_version = -1
+        self._cnn_version = -1
+        self._alloc()
+        self._build_gemms()
+
+    # ------------------------------------------------------------------------------------------ buffers
+    def _e(self, *shape, dtype=None) -> torch.Tensor:
+        return torch.empty(*shape, dtype=dtype or self.adt, device=self.dev)
+
+    def _alloc(self) -> None:
+        cfg, B, T, M, H, I = self.cfg, self.B, self.T, self.M, self.cfg.hidden_size, self.cfg.intermediate_size
+        f32 = torch.float32
+        C = cfg.conv_dim
+        self.stats0 = self._e(B, C[0], 2, dtype=torch.float64)
+        self.conv = [self._e(B, L, c) for L, c in zip(self.lens, C)]
+        cins = (1,) + tuple(C[:-1])
+        self.convw = [None] + [self._e(C[i], cfg.conv_kernel[i] * cins[i]) for i in range(1, len(C))]
+        self.zero_bias = torch.zeros(max(max(C), H), dtype=f32, device=self.dev)
+        self.ln_feat = self._e(self.M0, C[-1])
+        self.mean_f, self.rstd_f = self._e(self.M0, dtype=f32), self._e(self.M0, dtype=f32)
+        self.h0 = self._e(self.M0, H)                          # projection output (pre-CLS)
+        self.hx = self._e(M, H) if self.cls else self.h0       # encoder input
+        G, K = cfg.num_conv_pos_embedding_groups, cfg.num_conv_pos_embeddings
+        self.Cg, self.Tp = H // G, T + K - 1
+        self.xg = self._e(B, G, self.Tp, self.Cg)
+        self.posw_f, self.posw_b = self._e(G, self.Cg, K * self.Cg), self._e(G, self.Cg, K * self.Cg)
+        self.pos_sumsq = self._e(K, dtype=f32)
+        self.pos = self._e(M, H)                               # GELU(posconv) -> overwritten with s0
+        self.pos_pre = self._e(M, H) if self.train else None
+        self.mean0, self.rstd0 = self._e(M, dtype=f32), self._e(M, dtype=f32)
+        L = cfg.num_hidden_layers
+        nset = L if self.train else 1
+        self.X = [self._e(M, H) for _ in range(L + 1 if self.train else 2)]
+        heads = cfg.num_attention_heads
+        self.Tl = (T + 7) // 8 * 8
+        self.lb: List[LayerBufs] = []
+        for _ in range(nset):
+            lb = LayerBufs(qkv=self._e(M, 3 * H), ctx=self._e(M, H), a=self._e(M, H), x1=self._e(M, H),
+                           hpre=self._e(M, I) if self.train else None, h=self._e(M, I), f=self._e(M, H),
+                           mean1=self._e(M, dtype=f32), rstd1=self._e(M, dtype=f32),
+                           mean2=self._e(M, dtype=f32), rstd2=self._e(M, dtype=f32))
+            if self.fused:
+                lb.lse = self._e(B * heads * T, dtype=f32)
+            else:
+                lb.p = torch.zeros(B * heads * T, self.Tl, dtype=self.adt, device=self.dev)
+                lb.pd = (torch.zeros(B * heads * T, self.Tl, dtype=self.adt, device=self.dev)
+                         if (self.train and self.reg.attention_dropout > 0) else lb.p)
+            self.lb.append(lb)
+        if not self.fused:
+            self.S = torch.zeros(B * heads * T, self.Tl, dtype=f32, device=self.dev)   # scores / dP scratch
+        E = self.embed_dim
+        self.emb = self._e(B, E, dtype=f32)
+        st = self.store
+        if st.head is not None:
+            Cn = st.num_speakers
+            self.ldc = (Cn + 7) // 8 * 8
+            self.emb_lp = self._e(B, E) if self.adt != f32 else self.emb
+            self.logits = torch.zeros(B, self.ldc, dtype=f32, device=self.dev)
+            self.softmax = torch.zeros(B, self.ldc, dtype=f32, device=self.dev)
+            self.loss_rows = self._e(B, dtype=f32)
+            self.inv_x, self.inv_w = self._e(B, dtype=f32), self._e(Cn, dtype=f32)
+            if self.train:
+                self.dcos_w = torch.zeros(B, self.ldc, dtype=self.adt, device=self.dev)
+                self.dcos_x = torch.zeros(B, self.ldc, dtype=self.adt, device=self.dev) if st.head == "aam" else self.dcos_w
+                self.rowdot, self.coldot = self._e(B, dtype=f32), self._e(Cn, dtype=f32)
+                self.G1 = self._e(B, E, dtype=f32)
+                self.H1 = self._e(Cn, E, dtype=f32) if st.head == "aam" else None
+        if self.train:
+            self.demb = self._e(B, E, dtype=f32)
+            self.G = self._e(M, H)            # running activation gradient
+            self.Gd = self._e(M, H)           # ... after the dropout mask of a residual branch
+            self.DH = self._e(M, I)
+            self.DQKV = self._e(M, 3 * H)
+            self.DC = self._e(M, H)
+            self.P1 = self._e(M, H)
+            self.dyg = self._e(B, G, self.Tp, self.Cg)
+            self.dwf = self._e(G, self.Cg, K * self.Cg, dtype=f32)
+            self.pos_dot = self._e(K, dtype=f32)
+            self.dn = self._e(self.M0, C[-1])
+            self.G0 = self._e(self.M0, H) if self.cls else None
+            if self.fused:
+                self.delta = self._e(B * heads * T, dtype=f32)
+            else:
+                self.dS = torch.zeros(B * heads * T, self.Tl, dtype=self.adt, device=self.dev)
+
+    # ------------------------------------------------------------------------------------------ descriptors
+    def _build_gemms(self) -> None:
+        cfg, st, B, T, M, H, I = self.cfg, self.store, self.B, self.T, self.M, self.cfg.hidden_size, self.cfg.intermediate_size
+        C = cfg.conv_dim
+        cins = (1,) + tuple(C[:-1])
+        # conv layers 1..6: implicit GEMM over the channels-last activation of the previous layer
+        self.g_conv = []
+        for i in range(1, len(C)):
+            k, s, ci, co = cfg.conv_kernel[i], cfg.conv_stride[i], cins[i], C[i]
+            self.g_conv.append(Gemm(B * self.lens[i], co, k * ci, self.conv[i - 1], self.convw[i], self.conv[i],
+                                    lda=s * ci, ldb=k * ci, ldc=co, a_seg=(self.lens[i], self.lens[i - 1] * ci),
+                                    epilogue=EPI_BIAS_GELU, bias=self.zero_bias))
+        mw, mp = st.mw, st.mp
+        self.g_proj = Gemm(self.M0, H, C[-1], self.ln_feat, mw("feature_projection.projection.weight"), self.h0,
+                           lda=C[-1], ldb=C[-1], ldc=H, epilogue=EPI_BIAS, bias=mp("feature_projection.projection.bias"))
+        G, K, Cg, Tp = cfg.num_conv_pos_embedding_groups, cfg.num_conv_pos_embeddings, self.Cg, self.Tp
+        self.g_pos = Gemm(M, Cg, K * Cg, self.xg, self.posw_f, self.pos, lda=Cg, ldb=K * Cg, ldc=H,
+                          a_seg=(T, G * Tp * Cg), batch=G, batch_inner=G, a_strides=(0, Tp * Cg),
+                          b_strides=(0, Cg * K * Cg), c_strides=(0, Cg), epilogue=EPI_BIAS_GELU,
+                          bias=mp("encoder.pos_conv_embed.conv.bias"), bias_stride1=Cg,
+                          aux=self.pos_pre, ldaux=H, aux_strides=(0, Cg))
+        heads, d = cfg.num_attention_heads, cfg.head_dim
+        L = cfg.num_hidden_layers
+        self.g_layer: List[Dict[str, Gemm]] = []
+        for l in range(L):
+            lb = self.lb[l if self.train else 0]
+            xin = self.X[l] if self.train else self.X[l % 2]
+            pre = f"encoder.layers.{l}."
+            gl: Dict[str, Gemm] = {}
+            gl["qkv"] = Gemm(M, 3 * H, H, xin, st.qkv(l, "w"), lb.qkv, lda=H, ldb=H, ldc=3 * H, epilogue=EPI_BIAS,
+                             bias=st.qkv(l, "p", "bias"))
+            if not self.fused:
+                qkv = lb.qkv.view(-1)
+                sc = (heads * T * self.Tl, T * self.Tl)
+                gl["scores"] = Gemm(T, T, d, qkv, qkv[H:], self.S, lda=3 * H, ldb=3 * H, ldc=self.Tl,
+                                    batch=B * heads, batch_inner=heads, a_strides=(T * 3 * H, d),
+                                    b_strides=(T * 3 * H, d), c_strides=sc, alpha=d ** -0.5)
+                gl["ctx"] = Gemm(T, d, T, lb.pd, qkv[2 * H:], lb.ctx, lda=self.Tl, ldb=3 * H, ldc=H, transB=True,
+                                 batch=B * heads, batch_inner=heads, a_strides=sc, b_strides=(T * 3 * H, d),
+                                 c_strides=(T * H, d))
+            gl["out"] = Gemm(M, H, H, lb.ctx, mw(pre + "attention.out_proj.weight"), lb.a, lda=H, ldb=H, ldc=H,
+                             epilogue=EPI_BIAS, bias=mp(pre + "attention.out_proj.bias"))
+            gl["ffn1"] = Gemm(M, I, H, lb.x1, mw(pre + "feed_forward.intermediate_dense.weight"), lb.h, lda=H, ldb=H,
+                              ldc=I, epilogue=EPI_BIAS_GELU, bias=mp(pre + "feed_forward.intermediate_dense.bias"),
+                              aux=lb.hpre, ldaux=I)
+            gl["ffn2"] = Gemm(M, H, I, lb.h, mw(pre + "feed_forward.output_dense.weight"), lb.f, lda=I, ldb=I, ldc=H,
+                              epilogue=EPI_BIAS, bias=mp(pre + "feed_forward.output_dense.bias"))
+            if self.train:
+                mg = st.mg
+                sk = lambda m, n: _splitk(_tiles(m), _tiles(n), M)
+                W2, W1, Wo = (mw(pre + "feed_forward.output_dense.weight"), mw(pre + "feed_forward.intermediate_dense.weight"),
+                              mw(pre + "attention.out_proj.weight"))
+                gl["dW2"] = Gemm(H, I, M, self.Gd, lb.h, mg(pre + "feed_forward.output_dense.weight"), lda=H, ldb=I,
+                                 ldc=I, transA=True, transB=True, split_k=sk(H, I), accumulate=True)
+                gl["dh"] = Gemm(M, I, H, self.Gd, W2, self.DH, lda=H, ldb=I, ldc=I, transB=True,
+                                epilogue=EPI_GELU_BWD, aux=lb.hpre, ldaux=I)
+                gl["dW1"] = Gemm(I, H, M, self.DH, lb.x1, mg(pre + "feed_forward.intermediate_dense.weight"), lda=I,
+                                 ldb=H, ldc=H, transA=True, transB=True, split_k=sk(I, H), accumulate=True)
+                gl["dx1"] = Gemm(M, H, I, self.DH, W1, self.G, lda=I, ldb=H, ldc=H, transB=True, epilogue=EPI_ADD,
+                                 aux=self.G, ldaux=H)
+                gl["dWo"] = Gemm(H, H, M, self.Gd, lb.ctx, mg(pre + "attention.out_proj.weight"), lda=H, ldb=H, ldc=H,
+                                 transA=True, transB=True, split_k=sk(H, H), accumulate=True)
+                gl["dctx"] = Gemm(M, H, H, self.Gd, Wo, self.DC, lda=H, ldb=H, ldc=H, transB=True)
+                if not self.fused:
+                    qkv = lb.qkv.view(-1)
+                    dq = self.DQKV.view(-1)
+                    sc = (heads * T * self.Tl, T * self.Tl)
+                    hs = (T * 3 * H, d)
+                    gl["dP"] = Gemm(T, T, d, self.DC, qkv[2 * H:], self.S, lda=H, ldb=3 * H, ldc=self.Tl,
+                                    batch=B * heads, batch_inner=heads, a_strides=(T * H, d), b_strides=hs, c_strides=sc)
+                    gl["dq"] = Gemm(T, d, T, self.dS, qkv[H:], dq, lda=self.Tl, ldb=3 * H, ldc=3 * H, transB=True,
+                                    batch=B * heads, batch_inner=heads, a_strides=sc, b_strides=hs, c_strides=hs,
+                                    alpha=d ** -0.5)
+                    gl["dk"] = Gemm(T, d, T, self.dS, qkv, dq[H:], lda=self.Tl, ldb=3 * H, ldc=3 * H, transA=True,
+                                    transB=True, batch=B * heads, batch_inner=heads, a_strides=sc, b_strides=hs,
+                                    c_strides=hs, alpha=d ** -0.5)
+                    gl["dv"] = Gemm(T, d, T, lb.pd, self.DC, dq[2 * H:], lda=self.Tl, ldb=H, ldc=3 * H, transA=True,
+                                    transB=True, batch=B * heads, batch_inner=heads, a_strides=sc,
+                                    b_strides=(T * H, d), c_strides=hs)
+                gl["dWqkv"] = Gemm(3 * H, H, M, self.DQKV, xin, st.qkv(l, "g"), lda=3 * H, ldb=H, ldc=H, transA=True,
+                                   transB=True, split_k=sk(3 * H, H), accumulate=True)
+                gl["dx"] = Gemm(M, H, 3 * H, self.DQKV, st.qkv(l, "w"), self.G, lda=3 * H, ldb=H, ldc=H, transB=True,
+                                epilogue=EPI_ADD, aux=self.G, ldaux=H)
+            self.g_layer.append(gl)
+        if self.train:
+            mg = st.mg
+            # pos-conv backward: weight gradient (packed layout) and data gradient (flipped weights)
+            self.g_pos_dw = Gemm(Cg, K * Cg, M, self.P1, self.xg, self.dwf, lda=H, ldb=Cg, ldc=K * Cg, transA=True,
+                                 transB=True, b_seg=(T, G * Tp * Cg), batch=G, batch_inner=G, a_strides=(0, Cg),
+                                 b_strides=(0, Tp * Cg), c_strides=(0, Cg * K * Cg))
+            self.g_pos_dx = Gemm(M, Cg, K * Cg, self.dyg, self.posw_b, self.G, lda=Cg, ldb=K * Cg, ldc=H,
+                                 a_seg=(T, G * Tp * Cg), batch=G, batch_inner=G, a_strides=(0, Tp * Cg),
+                                 b_strides=(0, Cg * K * Cg), c_strides=(0, Cg), epilogue=EPI_ADD, aux=self.G, ldaux=H,
+                                 aux_strides=(0, Cg))
+            g0 = self.G0 if self.cls else self.G
+            self.g_proj_dw = Gemm(H, C[-1], self.M0, g0, self.ln_feat, mg("feature_projection.projection.weight"),
+                                  lda=H, ldb=C[-1], ldc=C[-1], transA=True, transB=True,
+                                  split_k=_splitk(_tiles(H), _tiles(C[-1]), self.M0), accumulate=True)
+            self.g_proj_dn = Gemm(self.M0, C[-1], H, g0, mw("feature_projection.projection.weight"), self.dn, lda=H,
+                                  ldb=C[-1], ldc=C[-1], transB=True)
+        if st.head is not None:
+            E, Cn = self.embed_dim, st.num_speakers
+            if st.head == "aam":
+                W = st.w("loss_fn.fc_weights")
+                self.g_head = Gemm(B, Cn, E, self.emb_lp, W, self.logits, lda=E, ldb=E, ldc=self.ldc,
+                                   epilogue=EPI_SCALE_RC, row_scale=self.inv_x, col_scale=self.inv_w)
+            else:
+                W = st.w("fc_list.0.0.weight")
+                self.g_head = Gemm(B, Cn, E, self.emb_lp, W, self.logits, lda=E, ldb=E, ldc=self.ldc,
+                                   epilogue=EPI_BIAS, bias=st.p("fc_list.0.0.bias"))
+            if self.train:
+                self.g_head_dx = Gemm(B, E, Cn, self.dcos_w, W, self.G1, lda=self.ldc, ldb=E, ldc=E, transB=True)
+                tgt = self.H1 if st.head == "aam" else st.g("fc_list.0.0.weight")
+                self.g_head_dw = Gemm(Cn, E, B, self.dcos_x, self.emb_lp, tgt, lda=self.ldc, ldb=E, ldc=E,
+                                      transA=True, transB=True, accumulate=(st.head == "ce"))
+
+    # ------------------------------------------------------------------------------------------ derived weights
+    def _refresh_packs(self) -> None:
+        st, cfg = self.store, self.cfg
+        if self._cnn_version != st.cnn_version:
+            for i in range(1, len(cfg.conv_dim)):
+                ops.pack_conv_weight(st.mp(f"feature_extractor.conv_layers.{i}.conv.weight"), self.convw[i])
+            self._cnn_version = st.cnn_version
+        if self._pack_version != st.version:
+            ops.weightnorm_pack(st.mp("encoder.pos_conv_embed.conv.parametrizations.weight.original0"),
+                                st.mp("encoder.pos_conv_embed.conv.parametrizations.weight.original1"),
+                                self.pos_sumsq, self.posw_f, self.posw_b, cfg.hidden_size,
+                                cfg.num_conv_pos_embedding_groups, cfg.num_conv_pos_embeddings)
+            self._pack_version = st.version
+
+    def _sd(self, site: str, layer: int, step: int) -> int:
+        """Dropout stream key for (site, layer, step)."""
+        return (self.seed * 1000003 + step) * 4096 + layer * 8 + _SITE[site]
+
+    # ------------------------------------------------------------------------------------------ forward
+    def forward(self, wav: torch.Tensor, mask: Optional[torch.Tensor] = None, skip_layers: Sequence[int] = (),
+                step: int = 0) -> torch.Tensor:
+        """wav [B,N] (or [B,1,N]) f32 on the GPU -> last_hidden_state [B,T,H] (act dtype).
+        mask: [B,T0] uint8/bool SpecAugment time mask (training only).  Dropout is active iff the plan
+        was built with train=True and the regularisation probabilities are > 0."""
+        cfg, st, reg = self.cfg, self.store, self.reg
+        B, T, M, H = self.B, self.T, self.M, cfg.hidden_size
+        if wav.dim() == 3:
+            wav = wav[:, 0, :]
+        wav = wav.contiguous()
+        assert wav.shape == (B, self.N) and wav.dtype == torch.float32 and wav.is_cuda
+        self._refresh_packs()
+        tr = self.train
+        self._step, self._skip, self._mask = step, tuple(skip_layers), None
+        mp = st.mp
+        ops.conv0_groupnorm_gelu(wav, mp("feature_extractor.conv_layers.0.conv.weight"),
+                                 mp("feature_extractor.conv_layers.0.layer_norm.weight"),
+                                 mp("feature_extractor.conv_layers.0.layer_norm.bias"), self.conv[0], self.stats0,
+                                 cfg.conv_kernel[0], cfg.conv_stride[0])
+        for g in self.g_conv:
+            g()
+        ops.layernorm_fwd(self.conv[-1].view(self.M0, -1), None, mp("feature_projection.layer_norm.weight"),
+                          mp("feature_projection.layer_norm.bias"), self.ln_feat, self.mean_f, self.rstd_f,
+                          cfg.layer_norm_eps)
+        self.g_proj()
+        if tr and reg.feat_proj_dropout > 0:
+            ops.dropout_(self.h0, reg.feat_proj_dropout, self._sd("featproj", 0, step))
+        if self.cls:
+            ops.prepend_token(self.h0.view(B, self.T0, H), self.hx.view(B, T, H), self.cls_c)
+        elif mask is not None:
+            self._mask = mask.to(torch.uint8).contiguous().view(-1)
+            ops.mask_fill(self.h0, self._mask, mp("masked_spec_embed"))
+        G, K = cfg.num_conv_pos_embedding_groups, cfg.num_conv_pos_embeddings
+        ops.posconv_regroup(self.hx, self.xg, B, T, H, G, K, K // 2)
+        self.g_pos()
+        x = self.X[0]
+        ops.layernorm_fwd(self.hx, self.pos, mp("encoder.layer_norm.weight"), mp("encoder.layer_norm.bias"), x,
+                          self.mean0, self.rstd0, cfg.layer_norm_eps)
+        if tr and reg.hidden_dropout > 0:
+            ops.dropout_(x, reg.hidden_dropout, self._sd("prologue", 0, step))
+        heads, d = cfg.num_attention_heads, cfg.head_dim
+        pa = reg.attention_dropout if tr else 0.0
+        ph = reg.hidden_dropout if tr else 0.0
+        for l in range(cfg.num_hidden_layers):
+            xin = self.X[l] if tr else self.X[l % 2]
+            xout = self.X[l + 1] if tr else self.X[(l + 1) % 2]
+            if l in self._skip:                 # LayerDrop (HF:698-709): the layer is the identity
+                xout.copy_(xin)
+                continue
+            lb, gl = self.lb[l if tr else 0], self.g_layer[l]
+            pre = f"encoder.layers.{l}."
+            gl["qkv"]()
+            if self.fused:
+                ops.attention_fwd(lb.qkv, lb.ctx, lb.lse, B, T, heads, d, d ** -0.5, pa, self._sd("attn", l, step))
+            else:
+                gl["scores"]()
+                ops.softmax_fwd(self.S, lb.p, lb.pd if pa > 0 else None, B * heads * T, T, self.Tl, pa,
+                                self._sd("attn", l, step))
+                gl["ctx"]()
+            gl["out"]()
+            ops.layernorm_fwd(xin, lb.a, mp(pre + "layer_norm.weight"), mp(pre + "layer_norm.bias"), lb.x1, lb.mean1,
+                              lb.rstd1, cfg.layer_norm_eps, ph, self._sd("post_attn", l, step))
+            gl["ffn1"]()
+            if tr and reg.activation_dropout > 0:
+                ops.dropout_(lb.h, reg.activation_dropout, self._sd("act", l, step))
+            gl["ffn2"]()
+            ops.layernorm_fwd(lb.x1, lb.f, mp(pre + "final_layer_norm.weight"), mp(pre + "final_layer_norm.bias"),
+                              xout, lb.mean2, lb.rstd2, cfg.layer_norm_eps, ph, self._sd("ffn", l, step))
+        self.out = (self.X[cfg.num_hidden_layers] if tr else self.X[cfg.num_hidden_layers % 2]).view(B, T, H)
+        return self.out
+
+    def embed(self, wav, mask=None, skip_layers=(), step: int = 0) -> torch.Tensor:
+        """ref: src/lightning_modules/speaker/wav2vec2_fc.py:414-431 -> pooled embedding [B,E] f32."""
+        out = self.forward(wav, mask, skip_layers, step)
+        ops.pool_fwd(out, self.emb, self.pool_mode)
+        return self.emb
+
+    # ------------------------------------------------------------------------------------------ head
+    def head_forward_backward(self, label: torch.Tensor):
+        """Loss head on self.emb: AAM-softmax (ref: aam_softmax.py:50-74) or Linear+CE
+        (ref: wav2vec2_fc.py:199-210, cross_entropy.py:27-31).  Returns (loss scalar tensor, softmax [B,C]);
+        when the plan is a training plan also leaves d(loss)/d(emb) in self.demb and the head gradients in
+        the flat gradient buffer."""
+        st, B, E, Cn = self.store, self.B, self.embed_dim, self.store.num_speakers
+        assert label.dtype == torch.int64 and label.is_cuda and label.shape == (B,)
+        if self.emb_lp is not self.emb:
+            ops.cast(self.emb, self.emb_lp)
+        aam = st.head == "aam"
+        if aam:
+            ops.row_invnorm(self.emb, self.inv_x, B, E)
+            ops.row_invnorm(st.p("loss_fn.fc_weights"), self.inv_w, Cn, E)
+        self.g_head()
+        tr = self.train
+        if tr and aam:
+            self.coldot.zero_()
+        ops.aam_softmax_fwd_bwd(self.logits, label, self.softmax, self.loss_rows,
+                                self.dcos_w if tr else None, (self.dcos_x if aam else None) if tr else None,
+                                self.inv_x if aam else None, self.inv_w if aam else None,
+                                self.rowdot if (tr and aam) else None, self.coldot if (tr and aam) else None,
+                                B, Cn, self.ldc, self.margin if aam else -1.0, self.scale)
+        loss = self.loss_rows.mean()
+        if tr:
+            self.g_head_dx()
+            if aam:
+                ops.normalize_bwd(self.G1, self.emb, self.inv_x, self.rowdot, self.demb, B, E)
+                self.g_head_dw()
+                ops.normalize_bwd(self.H1, st.p("loss_fn.fc_weights"), self.inv_w, self.coldot,
+                                  st.g("loss_fn.fc_weights"), Cn, E)
+            else:
+                self.demb.copy_(self.G1)
+                self.g_head_dw()
+                ops.colsum(self.dcos_w, st.g("fc_list.0.0.bias"), B, Cn, self.ldc)
+        return loss, self.softmax[:, :Cn]
+
+    # ------------------------------------------------------------------------------------------ backward
+    def backward(self, demb: Optional[torch.Tensor] = None,
+                 on_bucket_ready: Optional[Callable[[str], None]] = None) -> None:
+        """Backward of embed(): demb [B,E] f32 (default self.demb from the head) -> parameter gradients
+        accumulated into store.grad.  on_bucket_ready(name) fires as soon as a gradient bucket
+        ('head', 'layer11', ..., 'layer0', 'prologue') is final, for the overlapped all-reduce."""
+        assert self.train, "backward needs a training plan"
+        cfg, st, reg = self.cfg, self.store, self.reg
+        B, T, M, H = self.B, self.T, self.M, cfg.hidden_size
+        mp, mg = st.mp, st.mg
+        step = self._step
+        notify = on_bucket_ready or (lambda name: None)
+        if demb is None:
+            demb = self.demb
+        notify("head")
+        ops.pool_bwd(self.out, self.emb, demb, self.G.view(B, T, H), self.pool_mode)
+        heads, d = cfg.num_attention_heads, cfg.head_dim
+        pa, ph = reg.attention_dropout, reg.hidden_dropout
+        for l in reversed(range(cfg.num_hidden_layers)):
+            if l in self._skip:
+                notify(f"layer{l}")
+                continue
+            lb, gl = self.lb[l], self.g_layer[l]
+            pre = f"encoder.layers.{l}."
+            gd = self.Gd if ph > 0 else self.G
+            # x2 = LN2(x1 + drop(f))
+            ops.layernorm_bwd(self.G, lb.f, lb.mean2, lb.rstd2, mp(pre + "final_layer_norm.weight"), self.G,
+                              self.Gd if ph > 0 else None, mg(pre + "final_layer_norm.weight"),
+                              mg(pre + "final_layer_norm.bias"), ph, self._sd("ffn", l, step))
+            self._run_with_A(gl["dW2"], gd)
+            ops.colsum(gd, mg(pre + "feed_forward.output_dense.bias"), M, H)
+            self._run_with_A(gl["dh"], gd)                      # DH = (gd @ W2) * gelu'(hpre)
+            if reg.activation_dropout > 0:
+                raise NotImplementedError("activation_dropout > 0 (reference default is 0.0)")
+            gl["dW1"]()
+            ops.colsum(self.DH, mg(pre + "feed_forward.intermediate_dense.bias"), M, cfg.intermediate_size)
+            gl["dx1"]()                                         # G = DH @ W1 + G
+            # x1 = LN1(x + drop(a))
+            ops.layernorm_bwd(self.G, lb.a, lb.mean1, lb.rstd1, mp(pre + "layer_norm.weight"), self.G,
+                              self.Gd if ph > 0 else None, mg(pre + "layer_norm.weight"), mg(pre + "layer_norm.bias"),
+                              ph, self._sd("post_attn", l, step))
+            self._run_with_A(gl["dWo"], gd)
+            ops.colsum(gd, mg(pre + "attention.out_proj.bias"), M, H)
+            self._run_with_A(gl["dctx"], gd)
+            if self.fused:
+                ops.attention_bwd(lb.qkv, lb.ctx, self.DC, lb.lse, self.DQKV, self.delta, B, T, heads, d, d ** -0.5,
+                                  pa, self._sd("attn", l, step))
+            else:
+                gl["dP"]()
+                ops.softmax_bwd(self.S, lb.p, self.dS, B * heads * T, T, self.Tl, pa, self._sd("attn", l, step))
+                gl["dq"]()
+                gl["dk"]()
+                gl["dv"]()
+            gl["dWqkv"]()
+            ops.colsum(self.DQKV, st.qkv(l, "g", "bias"), M, 3 * H)
+            gl["dx"]()                                          # G = DQKV @ Wqkv + G
+            notify(f"layer{l}")
+        # encoder prologue: x0 = drop(LN(hx + pos)), pos = GELU(posconv(hx) + b)
+        if ph > 0:
+            ops.dropout_(self.G, ph, self._sd("prologue", 0, step))
+        ops.layernorm_bwd(self.G, self.pos, self.mean0, self.rstd0, mp("encoder.layer_norm.weight"), self.G, None,
+                          mg("encoder.layer_norm.weight"), mg("encoder.layer_norm.bias"))
+        ops.gelu_bwd(self.G, self.pos_pre, self.P1)
+        ops.colsum(self.P1, mg("encoder.pos_conv_embed.conv.bias"), M, H)
+        G_, K = cfg.num_conv_pos_embedding_groups, cfg.num_conv_pos_embeddings
+        self.g_pos_dw()
+        ops.weightnorm_bwd(mp("encoder.pos_conv_embed.conv.parametrizations.weight.original0"),
+                           mp("encoder.pos_conv_embed.conv.parametrizations.weight.original1"), self.pos_sumsq,
+                           self.dwf, self.pos_dot, mg("encoder.pos_conv_embed.conv.parametrizations.weight.original0"),
+                           mg("encoder.pos_conv_embed.conv.parametrizations.weight.original1"), H, G_, K)
+        ops.posconv_regroup(self.P1, self.dyg, B, T, H, G_, K, K - 1 - K // 2)
+        self.g_pos_dx()                                         # G = conv^T(P1) + G
+        if self.cls:
+            self.G0.view(B, self.T0, H).copy_(self.G.view(B, T, H)[:, 1:, :])    # the CLS row has no input
+            g0 = self.G0
+        else:
+            g0 = self.G
+            if self._mask is not None:
+                ops.mask_fill_bwd(g0, self._mask, mg("masked_spec_embed"))
+        if reg.feat_proj_dropout > 0:
+            ops.dropout_(g0, reg.feat_proj_dropout, self._sd("featproj", 0, step))
+        self.g_proj_dw()
+        ops.colsum(g0, mg("feature_projection.projection.bias"), self.M0, H)
+        self.g_proj_dn()
+        if not st.freeze_cnn:
+            raise NotImplementedError("CNN feature-extractor backward (completely_freeze_feature_extractor=False)")
+        ops.layernorm_bwd(self.dn, self.conv[-1].view(self.M0, -1), self.mean_f, self.rstd_f,
+                          mp("feature_projection.layer_norm.weight"), self.dn, None,
+                          mg("feature_projection.layer_norm.weight"), mg("feature_projection.layer_norm.bias"))
+        notify("prologue")
+
+    @staticmethod
+    def _run_with_A(g: Gemm, a: torch.Tensor) -> None:
+        """The post-dropout gradient lives in Gd when hidden_dropout > 0 and in G otherwise; the
+        descriptor was built for Gd, so patch the A pointer (one int store) before launching."""
+        g.desc.A.ptr = a.data_ptr()
+        g()

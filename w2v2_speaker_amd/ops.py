@@ -1,0 +1,281 @@
+"""Thin tensor-level wrappers over the C ABI (include/w2v2_hip.h).
+
+PyTorch is plumbing here: device memory, streams.  Every op enqueues hand-written HIP kernels on the
+current torch stream; nothing falls back to torch / CPU arithmetic.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import (BF16, EPI_ADD, EPI_BIAS, EPI_BIAS_GELU, EPI_GELU_BWD, EPI_NONE, EPI_SCALE_RC, F32,
+                   GemmDesc)
+
+POOL_MODES = {"mean+std": 0, "mean": 1, "max": 2, "first": 3, "first+cls": 3, "last": 4, "middle": 4}
+
+
+def lib():
+    return _lib.load()
+
+
+def dt(t: torch.Tensor) -> int:
+    if t.dtype == torch.bfloat16:
+        return BF16
+    if t.dtype == torch.float32:
+        return F32
+    raise TypeError(f"unsupported dtype {t.dtype}")
+
+
+def stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _dev(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("w2v2_speaker_amd ops need tensors on the GPU (no CPU fallback exists)")
+
+
+class Gemm:
+    """A prebuilt GEMM descriptor over fixed buffers: build once, launch every step."""
+
+    def __init__(self, M: int, N: int, K: int, A: torch.Tensor, B: torch.Tensor, Cmat: torch.Tensor, *,
+                 lda: int, ldb: int, ldc: int, transA: bool = False, transB: bool = False,
+                 batch: int = 1, batch_inner: int = 1,
+                 a_strides: Tuple[int, int] = (0, 0), b_strides: Tuple[int, int] = (0, 0),
+                 c_strides: Tuple[int, int] = (0, 0),
+                 a_seg: Tuple[int, int] = (0, 0), b_seg: Tuple[int, int] = (0, 0),
+                 epilogue: int = EPI_NONE, bias: Optional[torch.Tensor] = None, bias_stride1: int = 0,
+                 aux: Optional[torch.Tensor] = None, ldaux: int = 0, aux_strides: Tuple[int, int] = (0, 0),
+                 row_scale: Optional[torch.Tensor] = None, col_scale: Optional[torch.Tensor] = None,
+                 alpha: float = 1.0, split_k: int = 1, accumulate: bool = False):
+        _dev(A, B, Cmat, bias, aux, row_scale, col_scale)
+        if dt(A) != dt(B):
+            raise TypeError("GEMM operands must share a dtype")
+        if aux is not None and aux.dtype != Cmat.dtype:
+            raise TypeError("aux must have the dtype of C")
+        for t in (bias, row_scale, col_scale):
+            if t is not None and t.dtype != torch.float32:
+                raise TypeError("bias / scales are f32")
+        d = GemmDesc()
+        d.M, d.N, d.K = M, N, K
+        d.batch, d.batch_inner = batch, max(1, batch_inner)
+        d.dtype_ab, d.dtype_c, d.epilogue = dt(A), dt(Cmat), epilogue
+        d.A.ptr, d.A.ld, d.A.trans = A.data_ptr(), lda, int(transA)
+        d.A.seg_len, d.A.seg_stride = a_seg
+        d.A.stride0, d.A.stride1 = a_strides
+        d.B.ptr, d.B.ld, d.B.trans = B.data_ptr(), ldb, int(transB)
+        d.B.seg_len, d.B.seg_stride = b_seg
+        d.B.stride0, d.B.stride1 = b_strides
+        d.C, d.ldc = Cmat.data_ptr(), ldc
+        d.c_stride0, d.c_stride1 = c_strides
+        d.aux, d.ldaux = _p(aux), ldaux
+        d.aux_stride0, d.aux_stride1 = aux_strides
+        d.bias, d.bias_stride1 = _p(bias), bias_stride1
+        d.row_scale, d.col_scale = _p(row_scale), _p(col_scale)
+        d.alpha, d.split_k, d.accumulate = alpha, split_k, int(accumulate)
+        self.desc = d
+        self._ref = C.byref(d)
+        self._keep = (A, B, Cmat, bias, aux, row_scale, col_scale)   # keep buffers alive
+        self._fn = lib().w2v2_gemm
+        self.flops = 2.0 * M * N * K * batch
+
+    def __call__(self) -> None:
+        rc = self._fn(self._ref, stream())
+        if rc:
+            _lib.check(rc, "gemm")
+
+
+def gemm(*args, **kw) -> None:
+    Gemm(*args, **kw)()
+
+
+# ------------------------------------------------------------------------------------------------ conv0
+def conv0_groupnorm_gelu(wav: torch.Tensor, w: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor,
+                         out: torch.Tensor, stats: torch.Tensor, k: int, stride: int, eps: float = 1e-5) -> None:
+    """HF:302-323 layer 0.  wav [B,N] f32, w [C,1,k] f32, out [B,L,C], stats [B,C,2] f64 scratch."""
+    _dev(wav, w, gamma, beta, out, stats)
+    B, N = wav.shape
+    Cc = w.shape[0]
+    stats.zero_()
+    L = lib()
+    _lib.check(L.w2v2_conv0_stats(wav.data_ptr(), w.data_ptr(), stats.data_ptr(), B, N, Cc, k, stride, stream()),
+               "conv0_stats")
+    _lib.check(L.w2v2_conv0_apply(wav.data_ptr(), w.data_ptr(), stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                  out.data_ptr(), dt(out), B, N, Cc, k, stride, eps, stream()), "conv0_apply")
+
+
+def pack_conv_weight(w: torch.Tensor, out: torch.Tensor) -> None:
+    _dev(w, out)
+    co, ci, k = w.shape
+    _lib.check(lib().w2v2_pack_conv_weight(w.data_ptr(), out.data_ptr(), dt(out), co, ci, k, stream()), "pack_conv")
+
+
+# ------------------------------------------------------------------------------------------------ norm
+def layernorm_fwd(x, r, gamma, beta, y, mean, rstd, eps: float, drop_p: float = 0.0, seed: int = 0) -> None:
+    _dev(x, r, gamma, beta, y, mean, rstd)
+    H = x.shape[-1]
+    M = x.numel() // H
+    _lib.check(lib().w2v2_layernorm_fwd(x.data_ptr(), _p(r), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(),
+                                        mean.data_ptr(), rstd.data_ptr(), M, H, eps, drop_p, seed, dt(x), stream()),
+               "layernorm_fwd")
+
+
+def layernorm_bwd(dy, s, mean, rstd, gamma, ds, d_r, dgamma, dbeta, drop_p: float = 0.0, seed: int = 0) -> None:
+    _dev(dy, s, mean, rstd, gamma, ds, d_r, dgamma, dbeta)
+    H = dy.shape[-1]
+    M = dy.numel() // H
+    _lib.check(lib().w2v2_layernorm_bwd(dy.data_ptr(), s.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                        gamma.data_ptr(), ds.data_ptr(), _p(d_r), _p(dgamma), _p(dbeta), M, H,
+                                        drop_p, seed, dt(dy), stream()), "layernorm_bwd")
+
+
+# ------------------------------------------------------------------------------------------------ elementwise
+def dropout_(x: torch.Tensor, p: float, seed: int) -> None:
+    _dev(x)
+    _lib.check(lib().w2v2_dropout(x.data_ptr(), x.data_ptr(), x.numel(), p, seed, dt(x), stream()), "dropout")
+
+
+def gelu_bwd(dy, pre, dx) -> None:
+    _dev(dy, pre, dx)
+    _lib.check(lib().w2v2_gelu_bwd(dy.data_ptr(), pre.data_ptr(), dx.data_ptr(), dy.numel(), dt(dy), stream()),
+               "gelu_bwd")
+
+
+def add(x, a, y) -> None:
+    _dev(x, a, y)
+    _lib.check(lib().w2v2_add(x.data_ptr(), a.data_ptr(), y.data_ptr(), x.numel(), dt(x), stream()), "add")
+
+
+def colsum(x: torch.Tensor, out: torch.Tensor, M: int, N: int, ld: Optional[int] = None) -> None:
+    """out[n] += sum_m x[m][n] (f32 atomics)."""
+    _dev(x, out)
+    _lib.check(lib().w2v2_colsum(x.data_ptr(), ld if ld is not None else N, out.data_ptr(), M, N, dt(x), stream()),
+               "colsum")
+
+
+def cast(x: torch.Tensor, y: torch.Tensor) -> None:
+    _dev(x, y)
+    _lib.check(lib().w2v2_cast(x.data_ptr(), y.data_ptr(), x.numel(), dt(y), stream()), "cast")
+
+
+def mask_fill(h, mask_u8, embed) -> None:
+    _dev(h, mask_u8, embed)
+    H = h.shape[-1]
+    _lib.check(lib().w2v2_mask_fill(h.data_ptr(), mask_u8.data_ptr(), embed.data_ptr(), h.numel() // H, H, dt(h),
+                                    stream()), "mask_fill")
+
+
+def mask_fill_bwd(dh, mask_u8, d_embed) -> None:
+    _dev(dh, mask_u8, d_embed)
+    H = dh.shape[-1]
+    _lib.check(lib().w2v2_mask_fill_bwd(dh.data_ptr(), mask_u8.data_ptr(), d_embed.data_ptr(), dh.numel() // H, H,
+                                        dt(dh), stream()), "mask_fill_bwd")
+
+
+def prepend_token(x, y, c: float) -> None:
+    _dev(x, y)
+    B, T, H = x.shape
+    _lib.check(lib().w2v2_prepend_token(x.data_ptr(), y.data_ptr(), c, B, T, H, dt(x), stream()), "prepend_token")
+
+
+# ------------------------------------------------------------------------------------------------ pos-conv
+def posconv_regroup(x, xg, B: int, T: int, H: int, G: int, K: int, pad_left: int) -> None:
+    _dev(x, xg)
+    _lib.check(lib().w2v2_posconv_regroup(x.data_ptr(), xg.data_ptr(), B, T, H, G, K, pad_left, dt(x), stream()),
+               "posconv_regroup")
+
+
+def weightnorm_pack(g, v, sumsq, wf, wb, H: int, G: int, K: int) -> None:
+    _dev(g, v, sumsq, wf, wb)
+    _lib.check(lib().w2v2_weightnorm_pack(g.data_ptr(), v.data_ptr(), sumsq.data_ptr(), wf.data_ptr(),
+                                          wb.data_ptr(), H, G, K, dt(wf), stream()), "weightnorm_pack")
+
+
+def weightnorm_bwd(g, v, sumsq, dwf, dot, dg, dv, H: int, G: int, K: int) -> None:
+    _dev(g, v, sumsq, dwf, dot, dg, dv)
+    _lib.check(lib().w2v2_weightnorm_bwd(g.data_ptr(), v.data_ptr(), sumsq.data_ptr(), dwf.data_ptr(),
+                                         dot.data_ptr(), dg.data_ptr(), dv.data_ptr(), H, G, K, stream()),
+               "weightnorm_bwd")
+
+
+# ------------------------------------------------------------------------------------------------ attention
+def softmax_fwd(s, p, p_drop, rows: int, T: int, ld: int, drop_p: float, seed: int) -> None:
+    _dev(s, p, p_drop)
+    _lib.check(lib().w2v2_softmax_fwd(s.data_ptr(), p.data_ptr(), _p(p_drop), rows, T, ld, drop_p, seed, dt(p),
+                                      stream()), "softmax_fwd")
+
+
+def softmax_bwd(dp_drop, p, ds, rows: int, T: int, ld: int, drop_p: float, seed: int) -> None:
+    _dev(dp_drop, p, ds)
+    _lib.check(lib().w2v2_softmax_bwd(dp_drop.data_ptr(), p.data_ptr(), ds.data_ptr(), rows, T, ld, drop_p, seed,
+                                      dt(p), stream()), "softmax_bwd")
+
+
+def attention_fwd(qkv, ctx, lse, B: int, T: int, heads: int, d: int, scale: float, drop_p: float, seed: int) -> None:
+    _dev(qkv, ctx, lse)
+    _lib.check(lib().w2v2_attention_fwd(qkv.data_ptr(), ctx.data_ptr(), lse.data_ptr(), B, T, heads, d, scale,
+                                        drop_p, seed, dt(qkv), stream()), "attention_fwd")
+
+
+def attention_bwd(qkv, ctx, dctx, lse, dqkv, delta, B: int, T: int, heads: int, d: int, scale: float,
+                  drop_p: float, seed: int) -> None:
+    _dev(qkv, ctx, dctx, lse, dqkv, delta)
+    _lib.check(lib().w2v2_attention_bwd(qkv.data_ptr(), ctx.data_ptr(), dctx.data_ptr(), lse.data_ptr(),
+                                        dqkv.data_ptr(), delta.data_ptr(), B, T, heads, d, scale, drop_p, seed,
+                                        dt(qkv), stream()), "attention_bwd")
+
+
+# ------------------------------------------------------------------------------------------------ pooling
+def pool_fwd(x, out, mode: int) -> None:
+    _dev(x, out)
+    B, T, H = x.shape
+    _lib.check(lib().w2v2_pool_fwd(x.data_ptr(), out.data_ptr(), B, T, H, mode, dt(x), stream()), "pool_fwd")
+
+
+def pool_bwd(x, out, dout, dx, mode: int) -> None:
+    _dev(x, out, dout, dx)
+    B, T, H = x.shape
+    _lib.check(lib().w2v2_pool_bwd(x.data_ptr(), out.data_ptr(), dout.data_ptr(), dx.data_ptr(), B, T, H, mode,
+                                   dt(x), stream()), "pool_bwd")
+
+
+# ------------------------------------------------------------------------------------------------ heads
+def row_invnorm(x, inv, rows: int, cols: int, ld: Optional[int] = None) -> None:
+    _dev(x, inv)
+    _lib.check(lib().w2v2_row_invnorm(x.data_ptr(), ld if ld is not None else cols, inv.data_ptr(), rows, cols,
+                                      dt(x), stream()), "row_invnorm")
+
+
+def aam_softmax_fwd_bwd(cos, label, softmax, loss_rows, dcos_w, dcos_x, inv_x, inv_w, rowdot, coldot, B: int,
+                        Cn: int, ldc: int, margin: float, scale: float) -> None:
+    _dev(cos, label, softmax, loss_rows, dcos_w, dcos_x, inv_x, inv_w, rowdot, coldot)
+    dty = dt(dcos_w) if dcos_w is not None else F32
+    _lib.check(lib().w2v2_aam_softmax_fwd_bwd(cos.data_ptr(), label.data_ptr(), softmax.data_ptr(),
+                                              loss_rows.data_ptr(), _p(dcos_w), _p(dcos_x), _p(inv_x), _p(inv_w),
+                                              _p(rowdot), _p(coldot), B, Cn, ldc, margin, scale, dty, stream()),
+               "aam_softmax")
+
+
+def normalize_bwd(g, x, inv, dot, dx, rows: int, cols: int, ldx: Optional[int] = None, add_to: bool = False) -> None:
+    _dev(g, x, inv, dot, dx)
+    _lib.check(lib().w2v2_normalize_bwd(g.data_ptr(), x.data_ptr(), ldx if ldx is not None else cols, inv.data_ptr(),
+                                        dot.data_ptr(), dx.data_ptr(), rows, cols, dt(x), int(add_to), stream()),
+               "normalize_bwd")
+
+
+# ------------------------------------------------------------------------------------------------ optimiser
+def adam_step(p, g, m, v, pb, n: int, lr: float, beta1: float, beta2: float, eps: float, step: int,
+              grad_scale: float = 1.0) -> None:
+    _dev(p, g, m, v, pb)
+    bc1 = 1.0 - beta1 ** step
+    bc2 = 1.0 - beta2 ** step
+    _lib.check(lib().w2v2_adam_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), _p(pb), n, lr, beta1,
+                                    beta2, eps, bc1, bc2, grad_scale, stream()), "adam_step")

@@ -1,0 +1,255 @@
+"""Flat parameter arena for the wav2vec2 speaker model.
+
+All parameters live in ONE f32 device buffer, laid out in *backward order* (classification head,
+encoder layers L-1..0, encoder prologue, feature projection, then the frozen CNN), so that
+  * the fused Adam kernel updates every trainable parameter in one launch,
+  * each data-parallel gradient bucket is a contiguous slice of the flat gradient buffer that becomes
+    final exactly when backward has passed that point -> RCCL all-reduce straight on the slice, no
+    copies, overlapped with the rest of backward,
+  * q/k/v projection weights are adjacent, i.e. already the fused [3H, H] QKV GEMM operand.
+Names are the reference's state-dict keys (``wav2vec.model.<HF name>``, ``loss_fn.fc_weights``,
+``fc_list.0.0.{weight,bias}``; SURVEY 5 "Checkpoint / resume").
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import ops
+from .config import W2V2Config
+
+ALIGN = 64  # elements
+
+
+def hf_param_shapes(cfg: W2V2Config) -> "OrderedDict[str, Tuple[int, ...]]":
+    """HF state-dict names/shapes, in the arena (= backward) order."""
+    H, I, C = cfg.hidden_size, cfg.intermediate_size, cfg.conv_dim[-1]
+    K, G = cfg.num_conv_pos_embeddings, cfg.num_conv_pos_embedding_groups
+    shp: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()
+    for l in reversed(range(cfg.num_hidden_layers)):
+        p = f"encoder.layers.{l}."
+        shp[p + "final_layer_norm.weight"] = (H,)
+        shp[p + "final_layer_norm.bias"] = (H,)
+        shp[p + "feed_forward.output_dense.weight"] = (H, I)
+        shp[p + "feed_forward.output_dense.bias"] = (H,)
+        shp[p + "feed_forward.intermediate_dense.weight"] = (I, H)
+        shp[p + "feed_forward.intermediate_dense.bias"] = (I,)
+        shp[p + "layer_norm.weight"] = (H,)
+        shp[p + "layer_norm.bias"] = (H,)
+        shp[p + "attention.out_proj.weight"] = (H, H)
+        shp[p + "attention.out_proj.bias"] = (H,)
+        for n in ("q_proj", "k_proj", "v_proj"):           # adjacent: fused QKV operand
+            shp[p + f"attention.{n}.weight"] = (H, H)
+        for n in ("q_proj", "k_proj", "v_proj"):
+            shp[p + f"attention.{n}.bias"] = (H,)
+    shp["encoder.layer_norm.weight"] = (H,)
+    shp["encoder.layer_norm.bias"] = (H,)
+    shp["encoder.pos_conv_embed.conv.bias"] = (H,)
+    shp["encoder.pos_conv_embed.conv.parametrizations.weight.original0"] = (1, 1, K)
+    shp["encoder.pos_conv_embed.conv.parametrizations.weight.original1"] = (H, H // G, K)
+    shp["masked_spec_embed"] = (H,)
+    shp["feature_projection.projection.weight"] = (H, C)
+    shp["feature_projection.projection.bias"] = (H,)
+    shp["feature_projection.layer_norm.weight"] = (C,)
+    shp["feature_projection.layer_norm.bias"] = (C,)
+    cins = (1,) + tuple(cfg.conv_dim[:-1])
+    for i in reversed(range(len(cfg.conv_dim))):
+        shp[f"feature_extractor.conv_layers.{i}.conv.weight"] = (cfg.conv_dim[i], cins[i], cfg.conv_kernel[i])
+    shp["feature_extractor.conv_layers.0.layer_norm.weight"] = (cfg.conv_dim[0],)
+    shp["feature_extractor.conv_layers.0.layer_norm.bias"] = (cfg.conv_dim[0],)
+    return shp
+
+
+W2V_PREFIX = "wav2vec.model."
+# HF < 4.3x naming of the weight-norm parameters (the reference pins transformers ^4.8.2)
+_WN_OLD = {"encoder.pos_conv_embed.conv.weight_g": "encoder.pos_conv_embed.conv.parametrizations.weight.original0",
+           "encoder.pos_conv_embed.conv.weight_v": "encoder.pos_conv_embed.conv.parametrizations.weight.original1"}
+
+
+class ParamStore:
+    def __init__(self, cfg: W2V2Config, device, act_dtype: torch.dtype = torch.bfloat16,
+                 head: Optional[str] = "aam", num_speakers: int = 5994, embed_dim: Optional[int] = None,
+                 freeze_cnn: bool = True):
+        assert act_dtype in (torch.bfloat16, torch.float32)
+        assert head in (None, "aam", "ce")
+        self.cfg, self.device, self.act_dtype = cfg, torch.device(device), act_dtype
+        self.head, self.num_speakers, self.freeze_cnn = head, num_speakers, freeze_cnn
+        self.embed_dim = embed_dim if embed_dim is not None else 2 * cfg.hidden_size
+        shapes: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()
+        if head == "aam":
+            shapes["loss_fn.fc_weights"] = (num_speakers, self.embed_dim)
+        elif head == "ce":
+            shapes["fc_list.0.0.weight"] = (num_speakers, self.embed_dim)
+            shapes["fc_list.0.0.bias"] = (num_speakers,)
+        for n, s in hf_param_shapes(cfg).items():
+            shapes[W2V_PREFIX + n] = s
+        self.shapes = shapes
+        self.offsets: Dict[str, int] = {}
+        off = 0
+        self.n_train = None
+        for n, s in shapes.items():
+            if self.n_train is None and freeze_cnn and n.startswith(W2V_PREFIX + "feature_extractor."):
+                self.n_train = off
+            self.offsets[n] = off
+            off += (int(np.prod(s)) + ALIGN - 1) // ALIGN * ALIGN
+        self.n_total = off
+        if self.n_train is None:
+            self.n_train = off
+        dev = self.device
+        self.flat = torch.zeros(self.n_total, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(self.n_train, dtype=torch.float32, device=dev)
+        self.exp_avg: Optional[torch.Tensor] = None
+        self.exp_avg_sq: Optional[torch.Tensor] = None
+        self.flat_lp = (torch.zeros(self.n_total, dtype=torch.bfloat16, device=dev)
+                        if act_dtype == torch.bfloat16 else None)
+        self.version = 0          # bumped whenever weights change (derived packs are re-made lazily)
+        self.cnn_version = 0      # bumped whenever the CNN weights change
+        self.step_count = 0
+
+    # ------------------------------------------------------------------ views
+    def _view(self, buf: torch.Tensor, name: str) -> torch.Tensor:
+        s = self.shapes[name]
+        o = self.offsets[name]
+        return buf[o:o + int(np.prod(s))].view(*s)
+
+    def p(self, name: str) -> torch.Tensor:
+        """f32 master view."""
+        return self._view(self.flat, name)
+
+    def g(self, name: str) -> torch.Tensor:
+        """f32 gradient view (trainable parameters only)."""
+        if self.offsets[name] >= self.n_train:
+            raise KeyError(f"{name} is frozen: no gradient")
+        return self._view(self.grad, name)
+
+    def w(self, name: str) -> torch.Tensor:
+        """GEMM-operand view in the activation dtype."""
+        return self._view(self.flat_lp if self.flat_lp is not None else self.flat, name)
+
+    def is_trainable(self, name: str) -> bool:
+        return self.offsets[name] < self.n_train
+
+    def mp(self, name: str) -> torch.Tensor:
+        return self.p(W2V_PREFIX + name)
+
+    def mg(self, name: str) -> torch.Tensor:
+        return self.g(W2V_PREFIX + name)
+
+    def mw(self, name: str) -> torch.Tensor:
+        return self.w(W2V_PREFIX + name)
+
+    def qkv(self, layer: int, kind: str, which: str = "weight") -> torch.Tensor:
+        """Fused [3H, H] weight (or [3H] bias) view: kind in {'p','g','w'}."""
+        H = self.cfg.hidden_size
+        name = W2V_PREFIX + f"encoder.layers.{layer}.attention.q_proj.{which}"
+        buf = {"p": self.flat, "g": self.grad, "w": self.flat_lp if self.flat_lp is not None else self.flat}[kind]
+        o = self.offsets[name]
+        n = 3 * H * H if which == "weight" else 3 * H
+        step = H * H if which == "weight" else H
+        assert self.offsets[name.replace("q_proj", "k_proj")] == o + step, "q/k/v must be adjacent"
+        assert self.offsets[name.replace("q_proj", "v_proj")] == o + 2 * step, "q/k/v must be adjacent"
+        t = buf[o:o + n]
+        return t.view(3 * H, H) if which == "weight" else t
+
+    # ------------------------------------------------------------------ buckets (backward order)
+    def grad_buckets(self) -> List[Tuple[str, int, int]]:
+        """Contiguous gradient slices in the order backward finishes them."""
+        names = list(self.shapes)
+        marks: List[Tuple[str, int]] = []
+        if self.head is not None:
+            marks.append(("head", 0))
+        L = self.cfg.num_hidden_layers
+        for l in reversed(range(L)):
+            marks.append((f"layer{l}", self.offsets[W2V_PREFIX + f"encoder.layers.{l}.final_layer_norm.weight"]))
+        marks.append(("prologue", self.offsets[W2V_PREFIX + "encoder.layer_norm.weight"]))
+        if not self.freeze_cnn:
+            marks.append(("cnn", self.offsets[W2V_PREFIX + f"feature_extractor.conv_layers.{len(self.cfg.conv_dim) - 1}.conv.weight"]))
+        out = []
+        for i, (n, s) in enumerate(marks):
+            e = marks[i + 1][1] if i + 1 < len(marks) else self.n_train
+            out.append((n, s, e))
+        del names
+        return out
+
+    # ------------------------------------------------------------------ state
+    def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = True, prefix_model: bool = True) -> None:
+        """Accepts reference-style keys (``wav2vec.model.*``) or bare HF keys (prefix_model adds the prefix),
+        and both weight-norm namings."""
+        seen = set()
+        for k, v in sd.items():
+            k = _WN_OLD.get(k, k)
+            for old, new in _WN_OLD.items():
+                if k.endswith(old):
+                    k = k[: -len(old)] + new
+            name = k if k in self.shapes else (W2V_PREFIX + k if prefix_model and W2V_PREFIX + k in self.shapes else None)
+            if name is None:
+                if strict:
+                    raise KeyError(f"unexpected key {k}")
+                continue
+            t = torch.as_tensor(v).to(torch.float32)
+            if tuple(t.shape) != tuple(self.shapes[name]):
+                raise ValueError(f"{name}: shape {tuple(t.shape)} != {self.shapes[name]}")
+            self.p(name).copy_(t.to(self.device))
+            seen.add(name)
+        if strict and len(seen) != len(self.shapes):
+            missing = [n for n in self.shapes if n not in seen]
+            raise KeyError(f"missing keys: {missing[:5]}{'...' if len(missing) > 5 else ''}")
+        self.sync_lowp()
+
+    def state_dict(self) -> "OrderedDict[str, torch.Tensor]":
+        return OrderedDict((n, self.p(n).detach().clone().cpu()) for n in self.shapes)
+
+    def init_weights(self, seed: int = 20211) -> None:
+        """Random initialisation in the spirit of HF ``_init_weights`` (HF:1100-1140) and
+        ``xavier_normal_`` for the AAM weight (ref: src/optim/loss/aam_softmax.py:38)."""
+        g = torch.Generator(device="cpu").manual_seed(seed)
+        for n, s in self.shapes.items():
+            leaf = n.rsplit(".", 1)[-1]
+            if n.endswith("masked_spec_embed"):
+                t = torch.rand(s, generator=g)
+            elif n.endswith("weight.original0"):
+                t = torch.ones(s)
+            elif "layer_norm" in n:
+                t = torch.ones(s) if leaf == "weight" else torch.zeros(s)
+            elif leaf == "bias":
+                t = torch.zeros(s)
+            elif n == "loss_fn.fc_weights":
+                t = torch.randn(s, generator=g) * math.sqrt(2.0 / (s[0] + s[1]))
+            elif n.endswith("original1"):
+                t = torch.randn(s, generator=g) * (2.0 * math.sqrt(1.0 / (s[2] * s[1] * self.cfg.num_conv_pos_embedding_groups)))
+            elif "feature_extractor" in n:
+                t = torch.randn(s, generator=g) * math.sqrt(2.0 / (s[1] * s[2]))
+            else:
+                t = torch.randn(s, generator=g) * 0.02
+            self.p(n).copy_(t.to(self.device))
+        # weight-norm: g initialised to ||v|| so that w == v (torch weight_norm semantics)
+        v = self.mp("encoder.pos_conv_embed.conv.parametrizations.weight.original1")
+        self.mp("encoder.pos_conv_embed.conv.parametrizations.weight.original0").copy_(
+            v.pow(2).sum(dim=(0, 1), keepdim=True).sqrt())
+        self.sync_lowp()
+
+    def sync_lowp(self) -> None:
+        if self.flat_lp is not None:
+            ops.cast(self.flat, self.flat_lp)
+        self.version += 1
+        self.cnn_version += 1
+
+    # ------------------------------------------------------------------ optimiser
+    def zero_grad(self) -> None:
+        self.grad.zero_()
+
+    def adam_step(self, lr: float, beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8,
+                  grad_scale: float = 1.0) -> None:
+        if self.exp_avg is None:
+            self.exp_avg = torch.zeros_like(self.grad)
+            self.exp_avg_sq = torch.zeros_like(self.grad)
+        self.step_count += 1
+        ops.adam_step(self.flat, self.grad, self.exp_avg, self.exp_avg_sq, self.flat_lp, self.n_train, lr, beta1,
+                      beta2, eps, self.step_count, grad_scale)
+        self.version += 1
+        if not self.freeze_cnn:
+            self.cnn_version += 1

@@ -1,0 +1,124 @@
+"""One training step of the reference's hot loop on one GPU of a data-parallel job.
+
+  forward (conv stack -> projection -> SpecAugment mask -> encoder -> pooling -> AAM/CE head)
+  -> hand-written backward -> [RCCL all-reduce of gradient buckets on a side HIP stream, overlapped
+  with the rest of backward] -> fused Adam with the one-cycle lr / beta1 of this step.
+
+Data parallelism is one process per GPU (``torch.distributed``, backend "nccl" == RCCL over xGMI):
+every rank holds a full replica, draws its own minibatch, and the only collective is the SUM
+all-reduce of the flat gradient buffer, issued bucket by bucket in the order backward finishes them
+(ref: PL ``accelerator: ddp``, config/trainer/trainer.yaml:6-12).  The 1/world of the
+gradient mean is folded into the Adam kernel.  LayerDrop-skipped layers contribute zero gradients, so
+every rank issues identical collectives regardless of its own LayerDrop draws.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from .engine import Plan
+from .params import ParamStore
+from .spec_augment import compute_mask_indices
+
+
+class BucketAllReducer:
+    """All-reduce contiguous slices of the flat gradient buffer on a side stream as they become final."""
+
+    def __init__(self, store: ParamStore, process_group=None, bucket_merge: int = 2):
+        import torch.distributed as dist
+        self.dist = dist
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.store = store
+        raw = store.grad_buckets()
+        # merge neighbouring layer buckets so each collective carries >= ~2 layers (xGMI rings are
+        # per-link bound: fewer, larger messages; SURVEY 5 "Distributed comm backend")
+        self.ranges = {}
+        merged: List[Tuple[str, int, int]] = []
+        i = 0
+        while i < len(raw):
+            n, s, e = raw[i]
+            j = i
+            if n.startswith("layer"):
+                while j + 1 < len(raw) and raw[j + 1][0].startswith("layer") and (j - i + 1) < bucket_merge:
+                    j += 1
+                e = raw[j][2]
+            merged.append((raw[j][0], s, e))      # fires when the LAST member is final
+            i = j + 1
+        for n, s, e in merged:
+            self.ranges[n] = (s, e)
+        self.comm_stream = torch.cuda.Stream() if store.device.type == "cuda" else None
+        self.works = []
+
+    def bucket_ready(self, name: str) -> None:
+        if self.world == 1 or name not in self.ranges:
+            return
+        s, e = self.ranges[name]
+        if e <= s:
+            return
+        view = self.store.grad[s:e]
+        if self.comm_stream is None:       # CPU / gloo test path
+            self.works.append(self.dist.all_reduce(view, op=self.dist.ReduceOp.SUM, group=self.pg, async_op=True))
+            return
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        self.comm_stream.wait_event(ev)
+        with torch.cuda.stream(self.comm_stream):
+            self.works.append(self.dist.all_reduce(view, op=self.dist.ReduceOp.SUM, group=self.pg, async_op=True))
+
+    def wait(self) -> None:
+        for w in self.works:
+            w.wait()                      # makes the current (compute) stream wait for the collective
+        self.works = []
+        if self.comm_stream is not None and self.world > 1:
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
+
+
+class SpeakerTrainer:
+    def __init__(self, store: ParamStore, plan: Plan, schedule, process_group=None, beta2: float = 0.999,
+                 eps: float = 1e-8, layerdrop_seed: int = 1234, mask_seed: int = 7):
+        assert plan.train
+        self.store, self.plan, self.schedule = store, plan, schedule
+        self.beta2, self.eps = beta2, eps
+        self.step = 0
+        self.reducer = BucketAllReducer(store, process_group)
+        self.world = self.reducer.world
+        self._ld_rng = np.random.RandomState(layerdrop_seed)
+        self._mask_rng = np.random.RandomState(mask_seed)
+
+    def sample_layerdrop(self) -> Tuple[int, ...]:
+        """HF:698-709: each layer is skipped with probability ``layerdrop`` (host RNG)."""
+        p = self.plan.reg.layerdrop
+        if p <= 0:
+            return ()
+        u = self._ld_rng.rand(self.plan.cfg.num_hidden_layers)
+        return tuple(int(i) for i in np.nonzero(u < p)[0])
+
+    def sample_time_mask(self) -> Optional[torch.Tensor]:
+        reg, plan = self.plan.reg, self.plan
+        if reg.mask_time_prob <= 0 or plan.cls:
+            return None
+        m = compute_mask_indices((plan.B, plan.T0), reg.mask_time_prob, reg.mask_time_length,
+                                 plan.cfg.mask_time_min_masks, rng=self._mask_rng)
+        return torch.from_numpy(m.astype(np.uint8)).to(plan.dev, non_blocking=True)
+
+    def train_step(self, wav: torch.Tensor, label: torch.Tensor, mask: Optional[torch.Tensor] = None,
+                   skip_layers: Optional[Sequence[int]] = None):
+        """ref: speaker_recognition_module.py:207-220 (_train_step_ce_loss) + PL backward/optimizer step.
+        Returns (loss, softmax) as device tensors; no host sync."""
+        plan, store = self.plan, self.store
+        if skip_layers is None:
+            skip_layers = self.sample_layerdrop()
+        if mask is None:
+            mask = self.sample_time_mask()
+        store.zero_grad()
+        plan.embed(wav, mask, skip_layers, self.step)
+        loss, softmax = plan.head_forward_backward(label)
+        plan.backward(on_bucket_ready=self.reducer.bucket_ready)
+        self.reducer.wait()
+        lr, beta1 = self.schedule.at(self.step)
+        store.adam_step(lr, beta1, self.beta2, self.eps, grad_scale=1.0 / self.world)
+        self.step += 1
+        return loss, softmax
