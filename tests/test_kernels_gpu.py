@@ -1,0 +1,531 @@
+"""GPU unit tests: every C-ABI kernel against a plain torch f32/f64 reference of the same op
+(floating-point kernels -> torch reference; tolerances stated per test).  Run with -m gpu."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def ops():
+    from w2v2_speaker_amd import ops as o
+    return o
+
+
+def rnd(*shape, seed=0, scale=1.0, dtype=torch.float32):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dtype)
+
+
+def bf(t):
+    return t.to(torch.bfloat16)
+
+
+def gelu(x):
+    return 0.5 * x * (1 + torch.erf(x / math.sqrt(2)))
+
+
+# ----------------------------------------------------------------------------------------------- GEMM
+def _gemm_case(o, M, N, K, ta, tb, dtype, cdtype, epi="none", split=1, seed=0):
+    A = rnd(M, K, seed=seed + 1, scale=0.5)
+    Bm = rnd(N, K, seed=seed + 2, scale=0.5)
+    if dtype == torch.bfloat16:
+        A, Bm = bf(A).float(), bf(Bm).float()
+    ref = A.double() @ Bm.double().t()
+    Ad = (A.t().contiguous() if ta else A).to(dtype).to(DEV)
+    Bd = (Bm.t().contiguous() if tb else Bm).to(dtype).to(DEV)
+    lda = M if ta else K
+    ldb = N if tb else K
+    ldc = (N + 3) // 4 * 4
+    C = torch.zeros(M, ldc, dtype=cdtype, device=DEV)
+    kw = {}
+    bias = rnd(N, seed=seed + 3)
+    aux_host = rnd(M, ldc, seed=seed + 4)
+    if cdtype == torch.bfloat16:
+        aux_host = bf(aux_host).float()
+    aux = None
+    if epi == "bias":
+        kw.update(epilogue=o.EPI_BIAS, bias=bias.to(DEV))
+        ref = ref + bias.double()
+    elif epi == "bias_gelu":
+        aux = torch.zeros(M, ldc, dtype=cdtype, device=DEV)
+        kw.update(epilogue=o.EPI_BIAS_GELU, bias=bias.to(DEV), aux=aux, ldaux=ldc)
+        pre = ref + bias.double()
+        ref = gelu(pre)
+    elif epi == "gelu_bwd":
+        aux = aux_host.to(cdtype).to(DEV)
+        kw.update(epilogue=o.EPI_GELU_BWD, aux=aux, ldaux=ldc)
+        a = aux_host[:, :N].double()
+        ref = ref * (0.5 * (1 + torch.erf(a / math.sqrt(2))) + a * torch.exp(-0.5 * a * a) / math.sqrt(2 * math.pi))
+    elif epi == "add":
+        aux = aux_host.to(cdtype).to(DEV)
+        kw.update(epilogue=o.EPI_ADD, aux=aux, ldaux=ldc)
+        ref = ref + aux_host[:, :N].double()
+    elif epi == "scale_rc":
+        rs, cs = rnd(M, seed=seed + 5).abs() + 0.5, rnd(N, seed=seed + 6).abs() + 0.5
+        kw.update(epilogue=o.EPI_SCALE_RC, row_scale=rs.to(DEV), col_scale=cs.to(DEV))
+        ref = ref * rs.double()[:, None] * cs.double()[None, :]
+    o.gemm(M, N, K, Ad, Bd, C, lda=lda, ldb=ldb, ldc=ldc, transA=ta, transB=tb, alpha=1.0, split_k=split, **kw)
+    torch.cuda.synchronize()
+    got = C[:, :N].float().cpu().double()
+    tol = 2e-5 if dtype == torch.float32 else (1.2e-2 if cdtype == torch.bfloat16 else 2e-3)
+    err = rel_l2(got, ref)
+    assert err < tol, (M, N, K, ta, tb, dtype, cdtype, epi, split, err)
+    if epi == "bias_gelu":
+        assert rel_l2(aux[:, :N].float().cpu().double(), pre) < tol
+    assert float(C[:, N:].abs().max()) == 0.0 if ldc > N else True     # no out-of-bounds columns written
+
+
+@pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, False), (True, True)])
+def test_gemm_bf16_layouts_and_ragged_shapes(ta, tb):
+    o = ops()
+    for (M, N, K) in [(256, 256, 128), (149, 48, 96), (300, 130, 200), (66, 5994, 72), (1000, 64, 6144 // 8)]:
+        _gemm_case(o, M, N, K, ta, tb, torch.bfloat16, torch.float32)
+    _gemm_case(o, 298, 768, 256, ta, tb, torch.bfloat16, torch.bfloat16)
+
+
+def test_gemm_bf16_identity_asymmetric():
+    """A = I with an asymmetric B: catches a transposed C write (guide rule 16)."""
+    o = ops()
+    n = 128
+    Bm = torch.arange(n * n, dtype=torch.float32).view(n, n) % 251
+    A = torch.eye(n)
+    C = torch.zeros(n, n, dtype=torch.float32, device=DEV)
+    o.gemm(n, n, n, bf(A).to(DEV), bf(Bm).to(DEV), C, lda=n, ldb=n, ldc=n)
+    torch.cuda.synchronize()
+    assert torch.equal(C.cpu(), bf(Bm).float().t())
+
+
+@pytest.mark.parametrize("epi", ["bias", "bias_gelu", "gelu_bwd", "add", "scale_rc"])
+def test_gemm_epilogues(epi):
+    o = ops()
+    _gemm_case(o, 200, 136, 160, False, False, torch.bfloat16, torch.bfloat16, epi)
+    _gemm_case(o, 200, 136, 160, False, True, torch.bfloat16, torch.float32, epi)
+    _gemm_case(o, 70, 52, 40, True, False, torch.float32, torch.float32, epi)
+
+
+def test_gemm_split_k_and_accumulate():
+    o = ops()
+    for dtype in (torch.bfloat16, torch.float32):
+        _gemm_case(o, 192, 160, 2000, True, True, dtype, torch.float32, "none", split=5)
+        _gemm_case(o, 192, 160, 2000, False, False, dtype, torch.float32, "bias", split=3)
+
+
+@pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, False), (True, True)])
+def test_gemm_f32_exact(ta, tb):
+    o = ops()
+    for (M, N, K) in [(64, 64, 16), (149, 48, 100), (70, 130, 33)]:
+        _gemm_case(o, M, N, K, ta, tb, torch.float32, torch.float32)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gemm_batched_heads_and_implicit_conv(dtype):
+    o = ops()
+    # attention-style batch: q,k from a fused [B,T,3,heads,d] buffer
+    B, T, heads, d = 2, 21, 3, 16
+    H = heads * d
+    qkv = rnd(B, T, 3 * H, seed=3, scale=0.5)
+    if dtype == torch.bfloat16:
+        qkv = bf(qkv).float()
+    q = qkv[:, :, :H].view(B, T, heads, d).transpose(1, 2)
+    k = qkv[:, :, H:2 * H].view(B, T, heads, d).transpose(1, 2)
+    ref = (q.double() @ k.double().transpose(2, 3)) * 0.25
+    Tl = 24
+    S = torch.zeros(B * heads * T, Tl, dtype=torch.float32, device=DEV)
+    qd = qkv.to(dtype).to(DEV).view(-1)
+    o.gemm(T, T, d, qd, qd[H:], S, lda=3 * H, ldb=3 * H, ldc=Tl, batch=B * heads, batch_inner=heads,
+           a_strides=(T * 3 * H, d), b_strides=(T * 3 * H, d), c_strides=(heads * T * Tl, T * Tl), alpha=0.25)
+    torch.cuda.synchronize()
+    got = S.view(B, heads, T, Tl)[..., :T].cpu().double()
+    assert rel_l2(got, ref) < (1e-5 if dtype == torch.float32 else 3e-3)
+    # implicit im2col: Conv1d(Cin->Cout, k=3, stride=2) over channels-last [B, L, Cin]
+    Bn, L, Cin, Cout, kk, st = 3, 41, 32, 40, 3, 2
+    x = rnd(Bn, L, Cin, seed=5)
+    w = rnd(Cout, Cin, kk, seed=6, scale=0.2)
+    if dtype == torch.bfloat16:
+        x, w = bf(x).float(), bf(w).float()
+    ref = torch.nn.functional.conv1d(x.transpose(1, 2).double(), w.double(), stride=st).transpose(1, 2)
+    Lo = (L - kk) // st + 1
+    wp = torch.zeros(Cout, kk * Cin, dtype=dtype, device=DEV)
+    o.pack_conv_weight(w.to(DEV), wp)
+    y = torch.zeros(Bn * Lo, Cout, dtype=dtype, device=DEV)
+    o.gemm(Bn * Lo, Cout, kk * Cin, x.to(dtype).to(DEV), wp, y, lda=st * Cin, ldb=kk * Cin, ldc=Cout,
+           a_seg=(Lo, L * Cin))
+    torch.cuda.synchronize()
+    assert rel_l2(y.float().cpu().view(Bn, Lo, Cout), ref) < (1e-5 if dtype == torch.float32 else 1e-2)
+
+
+# ----------------------------------------------------------------------------------------------- conv0
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_conv0_groupnorm_gelu(dtype):
+    o = ops()
+    B, N, C, k, s = 3, 4000, 96, 10, 5
+    wav = rnd(B, N, seed=1)
+    w = rnd(C, 1, k, seed=2, scale=0.4)
+    gamma, beta = 1 + 0.1 * rnd(C, seed=3), 0.1 * rnd(C, seed=4)
+    y = torch.nn.functional.conv1d(wav[:, None].double(), w.double(), stride=s)
+    y = torch.nn.functional.group_norm(y, C, gamma.double(), beta.double(), eps=1e-5)
+    ref = gelu(y).transpose(1, 2)
+    L = ref.shape[1]
+    out = torch.zeros(B, L, C, dtype=dtype, device=DEV)
+    stats = torch.zeros(B, C, 2, dtype=torch.float64, device=DEV)
+    o.conv0_groupnorm_gelu(wav.to(DEV), w.to(DEV), gamma.to(DEV), beta.to(DEV), out, stats, k, s)
+    torch.cuda.synchronize()
+    assert rel_l2(out.float().cpu(), ref) < (2e-6 if dtype == torch.float32 else 4e-3)
+
+
+# ----------------------------------------------------------------------------------------------- LayerNorm
+@pytest.mark.parametrize("dtype,H", [(torch.float32, 768), (torch.bfloat16, 768), (torch.float32, 64),
+                                     (torch.bfloat16, 1024), (torch.float32, 512)])
+def test_layernorm_fwd_bwd(dtype, H):
+    o = ops()
+    M = 37
+    x, r = rnd(M, H, seed=1), rnd(M, H, seed=2)
+    if dtype == torch.bfloat16:
+        x, r = bf(x).float(), bf(r).float()
+    gamma, beta = 1 + 0.1 * rnd(H, seed=3), 0.1 * rnd(H, seed=4)
+    dy = rnd(M, H, seed=5)
+    if dtype == torch.bfloat16:
+        dy = bf(dy).float()
+    xs = (x + r).double().requires_grad_(True)
+    if dtype == torch.bfloat16:
+        xs = bf(x + r).double().requires_grad_(True)       # the kernel saves s in bf16 and normalises that
+    gd = gamma.double().requires_grad_(True)
+    bd = beta.double().requires_grad_(True)
+    yref = torch.nn.functional.layer_norm(xs, (H,), gd, bd, 1e-5)
+    yref.backward(dy.double())
+    xd, rd = x.to(dtype).to(DEV), r.to(dtype).to(DEV)
+    y = torch.zeros(M, H, dtype=dtype, device=DEV)
+    mean, rstd = torch.zeros(M, device=DEV), torch.zeros(M, device=DEV)
+    o.layernorm_fwd(xd, rd, gamma.to(DEV), beta.to(DEV), y, mean, rstd, 1e-5)
+    torch.cuda.synchronize()
+    tol = 2e-6 if dtype == torch.float32 else 4e-3
+    assert rel_l2(y.float().cpu(), yref.detach()) < tol
+    assert rel_l2(rd.float().cpu(), xs.detach()) < tol           # r now holds s = x + r
+    ds = torch.zeros(M, H, dtype=dtype, device=DEV)
+    dg, db = torch.zeros(H, device=DEV), torch.zeros(H, device=DEV)
+    o.layernorm_bwd(dy.to(dtype).to(DEV), rd, mean, rstd, gamma.to(DEV), ds, None, dg, db)
+    torch.cuda.synchronize()
+    assert rel_l2(ds.float().cpu(), xs.grad) < (1e-5 if dtype == torch.float32 else 6e-3)
+    assert rel_l2(dg.cpu(), gd.grad) < (1e-5 if dtype == torch.float32 else 3e-3)
+    assert rel_l2(db.cpu(), bd.grad) < 1e-5
+    # no-residual form
+    y2 = torch.zeros_like(y)
+    o.layernorm_fwd(xd, None, gamma.to(DEV), beta.to(DEV), y2, mean, rstd, 1e-5)
+    torch.cuda.synchronize()
+    ref2 = torch.nn.functional.layer_norm(x.double(), (H,), gamma.double(), beta.double(), 1e-5)
+    assert rel_l2(y2.float().cpu(), ref2) < tol
+
+
+def test_layernorm_dropout_mask_consistent_fwd_bwd():
+    o = ops()
+    M, H, p, seed = 64, 768, 0.1, 12345
+    x, r = rnd(M, H, seed=1), rnd(M, H, seed=2)
+    ones = torch.ones(M, H, device=DEV)
+    o.dropout_(ones, p, seed)                 # the same (seed, index) stream as the LN kernels
+    torch.cuda.synchronize()
+    mask = ones.cpu()
+    keep = float((mask > 0).float().mean())
+    assert abs(keep - (1 - p)) < 0.01 and abs(float(mask.max()) - 1 / (1 - p)) < 1e-6
+    gamma, beta = torch.ones(H), torch.zeros(H)
+    rd = r.to(DEV)
+    y = torch.zeros(M, H, device=DEV)
+    mean, rstd = torch.zeros(M, device=DEV), torch.zeros(M, device=DEV)
+    o.layernorm_fwd(x.to(DEV), rd, gamma.to(DEV), beta.to(DEV), y, mean, rstd, 1e-5, p, seed)
+    torch.cuda.synchronize()
+    s_ref = x + r * mask
+    assert rel_l2(rd.cpu(), s_ref) < 1e-6
+    assert rel_l2(y.cpu(), torch.nn.functional.layer_norm(s_ref, (H,))) < 1e-5
+    dy = rnd(M, H, seed=3)
+    ds, dr = torch.zeros(M, H, device=DEV), torch.zeros(M, H, device=DEV)
+    dg, db = torch.zeros(H, device=DEV), torch.zeros(H, device=DEV)
+    o.layernorm_bwd(dy.to(DEV), rd, mean, rstd, gamma.to(DEV), ds, dr, dg, db, p, seed)
+    torch.cuda.synchronize()
+    assert rel_l2(dr.cpu(), ds.cpu() * mask) < 1e-6
+
+
+# ----------------------------------------------------------------------------------------------- elementwise
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_elementwise_family(dtype):
+    o = ops()
+    n = 8 * 1000 + 5
+    a, b = rnd(n, seed=1), rnd(n, seed=2)
+    if dtype == torch.bfloat16:
+        a, b = bf(a).float(), bf(b).float()
+    ad, bd = a.to(dtype).to(DEV), b.to(dtype).to(DEV)
+    out = torch.zeros(n, dtype=dtype, device=DEV)
+    o.add(ad, bd, out)
+    torch.cuda.synchronize()
+    tol = 1e-6 if dtype == torch.float32 else 4e-3
+    assert rel_l2(out.float().cpu(), a + b) < tol
+    o.gelu_bwd(ad, bd, out)
+    torch.cuda.synchronize()
+    bb = b.double().requires_grad_(True)
+    gelu(bb).backward(a.double())
+    assert rel_l2(out.float().cpu(), bb.grad) < (2e-6 if dtype == torch.float32 else 4e-3)
+    # colsum (vector path and ragged scalar path)
+    for (M, N, ld) in [(333, 768, 768), (50, 30, 34)]:
+        x = rnd(M, ld, seed=3)
+        if dtype == torch.bfloat16:
+            x = bf(x).float()
+        acc = torch.ones(N, device=DEV)
+        o.colsum(x.to(dtype).to(DEV), acc, M, N, ld)
+        torch.cuda.synchronize()
+        assert rel_l2(acc.cpu(), 1 + x[:, :N].double().sum(0)) < 1e-5
+    # cast
+    src = rnd(n, seed=4)
+    dst = torch.zeros(n, dtype=dtype, device=DEV)
+    o.cast(src.to(DEV), dst)
+    torch.cuda.synchronize()
+    assert torch.equal(dst.cpu(), src.to(dtype))
+    # mask fill fwd / bwd
+    M, H = 40, 64
+    h = rnd(M, H, seed=5)
+    if dtype == torch.bfloat16:
+        h = bf(h).float()
+    mask = (torch.arange(M) % 7 == 0)
+    emb = rnd(H, seed=6)
+    hd = h.to(dtype).to(DEV)
+    o.mask_fill(hd, mask.to(torch.uint8).to(DEV), emb.to(DEV))
+    torch.cuda.synchronize()
+    ref = torch.where(mask[:, None], emb.to(dtype).float()[None], h)
+    assert torch.equal(hd.float().cpu(), ref)
+    dh = h.to(dtype).to(DEV)
+    de = torch.zeros(H, device=DEV)
+    o.mask_fill_bwd(dh, mask.to(torch.uint8).to(DEV), de)
+    torch.cuda.synchronize()
+    assert rel_l2(de.cpu(), h[mask].double().sum(0)) < 1e-5
+    assert float(dh.float().cpu()[mask].abs().max()) == 0.0 and torch.equal(dh.float().cpu()[~mask], h[~mask])
+    # CLS prepend
+    x = rnd(2, 5, 16, seed=7)
+    y = torch.zeros(2, 6, 16, dtype=dtype, device=DEV)
+    o.prepend_token(x.to(dtype).to(DEV), y, 1.0)
+    torch.cuda.synchronize()
+    assert torch.equal(y[:, 1:].cpu(), x.to(dtype)) and float((y[:, 0].float() - 1).abs().max()) == 0.0
+
+
+# ----------------------------------------------------------------------------------------------- pos-conv
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_posconv_forward_backward(dtype):
+    """Grouped weight-normed conv (HF:326-379) through regroup + weightnorm_pack + implicit GEMM."""
+    o = ops()
+    B, T, H, G, K = 2, 19, 64, 4, 16
+    Cg, Tp = H // G, T + K - 1
+    x = rnd(B, T, H, seed=1)
+    g = 1 + 0.2 * rnd(1, 1, K, seed=2)
+    v = rnd(H, Cg, K, seed=3, scale=0.1)
+    bias = 0.1 * rnd(H, seed=4)
+    up = rnd(B, T, H, seed=5)
+    if dtype == torch.bfloat16:
+        x, up = bf(x).float(), bf(up).float()
+    xr = x.double().requires_grad_(True)
+    gr, vr = g.double().requires_grad_(True), v.double().requires_grad_(True)
+    w = gr * vr / torch.sqrt((vr * vr).sum(dim=(0, 1), keepdim=True))
+    pre = torch.nn.functional.conv1d(xr.transpose(1, 2), w, bias.double(), padding=K // 2, groups=G)[:, :, :-1]
+    yref = gelu(pre).transpose(1, 2)
+    yref.backward(up.double())
+    xd = x.to(dtype).to(DEV)
+    xg = torch.zeros(B, G, Tp, Cg, dtype=dtype, device=DEV)
+    o.posconv_regroup(xd, xg, B, T, H, G, K, K // 2)
+    wf, wb = torch.zeros(G, Cg, K * Cg, dtype=dtype, device=DEV), torch.zeros(G, Cg, K * Cg, dtype=dtype, device=DEV)
+    sumsq = torch.zeros(K, device=DEV)
+    o.weightnorm_pack(g.to(DEV), v.to(DEV), sumsq, wf, wb, H, G, K)
+    y = torch.zeros(B * T, H, dtype=dtype, device=DEV)
+    ypre = torch.zeros(B * T, H, dtype=dtype, device=DEV)
+    M = B * T
+    o.gemm(M, Cg, K * Cg, xg, wf, y, lda=Cg, ldb=K * Cg, ldc=H, a_seg=(T, G * Tp * Cg), batch=G, batch_inner=G,
+           a_strides=(0, Tp * Cg), b_strides=(0, Cg * K * Cg), c_strides=(0, Cg), epilogue=o.EPI_BIAS_GELU,
+           bias=bias.to(DEV), bias_stride1=Cg, aux=ypre, ldaux=H, aux_strides=(0, Cg))
+    torch.cuda.synchronize()
+    tol = 1e-5 if dtype == torch.float32 else 1.5e-2
+    assert rel_l2(y.float().cpu().view(B, T, H), yref.detach()) < tol
+    # backward
+    P1 = torch.zeros(M, H, dtype=dtype, device=DEV)
+    o.gelu_bwd(up.to(dtype).to(DEV).view(M, H), ypre, P1)
+    dwf = torch.zeros(G, Cg, K * Cg, device=DEV)
+    o.gemm(Cg, K * Cg, M, P1, xg, dwf, lda=H, ldb=Cg, ldc=K * Cg, transA=True, transB=True,
+           b_seg=(T, G * Tp * Cg), batch=G, batch_inner=G, a_strides=(0, Cg), b_strides=(0, Tp * Cg),
+           c_strides=(0, Cg * K * Cg))
+    dot, dg, dv = torch.zeros(K, device=DEV), torch.zeros(K, device=DEV), torch.zeros(H, Cg, K, device=DEV)
+    o.weightnorm_bwd(g.to(DEV), v.to(DEV), sumsq, dwf, dot, dg, dv, H, G, K)
+    dyg = torch.zeros(B, G, Tp, Cg, dtype=dtype, device=DEV)
+    o.posconv_regroup(P1, dyg, B, T, H, G, K, K - 1 - K // 2)
+    dx = torch.zeros(M, H, dtype=dtype, device=DEV)
+    o.gemm(M, Cg, K * Cg, dyg, wb, dx, lda=Cg, ldb=K * Cg, ldc=H, a_seg=(T, G * Tp * Cg), batch=G, batch_inner=G,
+           a_strides=(0, Tp * Cg), b_strides=(0, Cg * K * Cg), c_strides=(0, Cg))
+    torch.cuda.synchronize()
+    tolb = 2e-5 if dtype == torch.float32 else 2.5e-2
+    assert rel_l2(dx.float().cpu().view(B, T, H), xr.grad) < tolb
+    assert rel_l2(dv.cpu(), vr.grad) < tolb
+    assert rel_l2(dg.cpu(), gr.grad.view(-1)) < tolb
+
+
+# ----------------------------------------------------------------------------------------------- attention
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_softmax_fwd_bwd_unfused(dtype):
+    o = ops()
+    rows, T, ld = 50, 149, 152
+    s = torch.zeros(rows, ld)
+    s[:, :T] = rnd(rows, T, seed=1, scale=2.0)
+    p = torch.zeros(rows, ld, dtype=dtype, device=DEV)
+    o.softmax_fwd(s.to(DEV), p, None, rows, T, ld, 0.0, 0)
+    torch.cuda.synchronize()
+    sr = s[:, :T].double().requires_grad_(True)
+    pref = torch.softmax(sr, dim=-1)
+    tol = 1e-6 if dtype == torch.float32 else 4e-3
+    assert rel_l2(p[:, :T].float().cpu(), pref.detach()) < tol
+    dp = torch.zeros(rows, ld)
+    dp[:, :T] = rnd(rows, T, seed=2)
+    ds = torch.zeros(rows, ld, dtype=dtype, device=DEV)
+    o.softmax_bwd(dp.to(DEV), p, ds, rows, T, ld, 0.0, 0)
+    torch.cuda.synchronize()
+    pref.backward(dp[:, :T].double())
+    assert rel_l2(ds[:, :T].float().cpu(), sr.grad) < (1e-5 if dtype == torch.float32 else 1e-2)
+
+
+def _attn_ref(qkv, B, T, heads, d, mask=None, keep=1.0):
+    H = heads * d
+    q, k, v = [qkv[:, :, i * H:(i + 1) * H].reshape(B, T, heads, d).transpose(1, 2) for i in range(3)]
+    p = torch.softmax(q @ k.transpose(2, 3) * d ** -0.5, dim=-1)
+    if mask is not None:
+        p = p * mask / keep
+    return (p @ v).transpose(1, 2).reshape(B, T, H)
+
+
+@pytest.mark.parametrize("T", [149, 150, 249, 64, 12, 256])
+def test_fused_attention_fwd_bwd(T):
+    o = ops()
+    B, heads, d = 2, 3, 64
+    H = heads * d
+    qkv = bf(rnd(B, T, 3 * H, seed=T, scale=1.0)).float()
+    qkv[..., :2 * H] *= 1.5                         # non-trivial softmax
+    dctx = bf(rnd(B, T, H, seed=T + 1)).float()
+    qr = qkv.double().requires_grad_(True)
+    ref = _attn_ref(qr, B, T, heads, d)
+    ref.backward(dctx.double())
+    qd = qkv.to(torch.bfloat16).to(DEV)
+    ctx = torch.zeros(B, T, H, dtype=torch.bfloat16, device=DEV)
+    lse = torch.zeros(B * heads * T, device=DEV)
+    o.attention_fwd(qd, ctx, lse, B, T, heads, d, d ** -0.5, 0.0, 0)
+    torch.cuda.synchronize()
+    assert rel_l2(ctx.float().cpu(), ref.detach()) < 8e-3, T
+    q_, k_ = [qkv[:, :, i * H:(i + 1) * H].reshape(B, T, heads, d).transpose(1, 2).double() for i in range(2)]
+    lref = torch.logsumexp(q_ @ k_.transpose(2, 3) * d ** -0.5, dim=-1)
+    assert float((lse.cpu().view(B, heads, T) - lref).abs().max()) < 2e-2
+    dqkv = torch.zeros(B, T, 3 * H, dtype=torch.bfloat16, device=DEV)
+    delta = torch.zeros(B * heads * T, device=DEV)
+    o.attention_bwd(qd, ctx, dctx.to(torch.bfloat16).to(DEV), lse, dqkv, delta, B, T, heads, d, d ** -0.5, 0.0, 0)
+    torch.cuda.synchronize()
+    g = dqkv.float().cpu()
+    for i, nm in enumerate("qkv"):
+        assert rel_l2(g[..., i * H:(i + 1) * H], qr.grad[..., i * H:(i + 1) * H]) < 2e-2, (T, nm)
+
+
+def test_fused_attention_dropout_mask_recovered_and_consistent():
+    """T = 64: with q = k = 0 (uniform P) and V = identity the output IS the dropout mask; then the
+    forward/backward with that exact mask must match the torch reference."""
+    o = ops()
+    B, heads, d, T, p, seed = 2, 2, 64, 64, 0.1, 991
+    H = heads * d
+    probe = torch.zeros(B, T, 3 * H)
+    probe[..., 2 * H:] = torch.eye(T).repeat(1, heads)[None]
+    ctx = torch.zeros(B, T, H, dtype=torch.bfloat16, device=DEV)
+    lse = torch.zeros(B * heads * T, device=DEV)
+    o.attention_fwd(probe.to(torch.bfloat16).to(DEV), ctx, lse, B, T, heads, d, d ** -0.5, p, seed)
+    torch.cuda.synchronize()
+    m = (ctx.float().cpu().view(B, T, heads, d).transpose(1, 2) > 0).double()       # [B,h,q,key]
+    keep = float(m.mean())
+    assert abs(keep - (1 - p)) < 0.02
+    qkv = bf(rnd(B, T, 3 * H, seed=5)).float()
+    dctx = bf(rnd(B, T, H, seed=6)).float()
+    qr = qkv.double().requires_grad_(True)
+    ref = _attn_ref(qr, B, T, heads, d, mask=m, keep=1 - p)
+    ref.backward(dctx.double())
+    qd = qkv.to(torch.bfloat16).to(DEV)
+    o.attention_fwd(qd, ctx, lse, B, T, heads, d, d ** -0.5, p, seed)
+    dqkv = torch.zeros(B, T, 3 * H, dtype=torch.bfloat16, device=DEV)
+    delta = torch.zeros(B * heads * T, device=DEV)
+    o.attention_bwd(qd, ctx, dctx.to(torch.bfloat16).to(DEV), lse, dqkv, delta, B, T, heads, d, d ** -0.5, p, seed)
+    torch.cuda.synchronize()
+    assert rel_l2(ctx.float().cpu(), ref.detach()) < 1e-2
+    assert rel_l2(dqkv.float().cpu(), qr.grad) < 2.5e-2
+
+
+# ----------------------------------------------------------------------------------------------- pooling
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_pooling_all_modes(dtype):
+    o = ops()
+    B, T, H = 3, 149, 768
+    x = rnd(B, T, H, seed=1, scale=2.0) + 0.5
+    if dtype == torch.bfloat16:
+        x = bf(x).float()
+    xd = x.to(dtype).to(DEV)
+    refs = {"mean+std": lambda t: torch.cat(torch.std_mean(t, dim=1), 1), "mean": lambda t: t.mean(1),
+            "max": lambda t: t.max(1).values, "first": lambda t: t[:, 0], "last": lambda t: t[:, -1],
+            "middle": lambda t: t[:, -1]}
+    for name, fn in refs.items():
+        xr = x.double().requires_grad_(True)
+        ref = fn(xr)
+        up = rnd(*ref.shape, seed=9)
+        ref.backward(up.double())
+        out = torch.zeros(*ref.shape, device=DEV)
+        o.pool_fwd(xd, out, o.POOL_MODES[name])
+        torch.cuda.synchronize()
+        assert rel_l2(out.cpu(), ref.detach()) < 1e-5, name
+        dx = torch.zeros(B, T, H, dtype=dtype, device=DEV)
+        o.pool_bwd(xd, out, up.to(DEV), dx, o.POOL_MODES[name])
+        torch.cuda.synchronize()
+        assert rel_l2(dx.float().cpu(), xr.grad) < (1e-5 if dtype == torch.float32 else 4e-3), name
+
+
+def test_pooling_golden_edges():
+    """Reference-generated vectors incl. T = 1 (unbiased std -> NaN, like torch) and T = 7249."""
+    o = ops()
+    g = np.load(os.path.join(GOLDEN, "g5_pool.npz"))
+    for name in ("t1", "long"):
+        x = torch.from_numpy(g[name + ".x"])
+        B, T, H = x.shape
+        out = torch.zeros(B, 2 * H, device=DEV)
+        o.pool_fwd(x.to(DEV), out, 0)
+        torch.cuda.synchronize()
+        assert np.allclose(out.cpu().numpy(), g[name + ".mean+std"], atol=2e-5, equal_nan=True), name
+        if name == "long":
+            dx = torch.zeros(B, T, H, device=DEV)
+            o.pool_bwd(x.to(DEV), out, torch.from_numpy(g["long.upstream"]).to(DEV), dx, 0)
+            torch.cuda.synchronize()
+            assert np.allclose(dx.cpu().numpy(), g["long.dx"], atol=1e-7)
+
+
+# ----------------------------------------------------------------------------------------------- Adam
+def test_fused_adam_matches_torch_and_golden():
+    o = ops()
+    g = np.load(os.path.join(GOLDEN, "g8_optim.npz"))
+    p = torch.from_numpy(g["p0"]).clone().to(DEV)
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    pb = torch.zeros(16, dtype=torch.bfloat16, device=DEV)
+    for i in range(100):
+        gr = torch.from_numpy(g["grads"][i]).to(DEV)
+        o.adam_step(p, gr, m, v, pb, 16, float(g["lr"][i]), float(g["beta1"][i]), 0.999, 1e-8, i + 1)
+    torch.cuda.synchronize()
+    assert np.allclose(p.cpu().numpy(), g["params"][99], atol=2e-7)
+    assert torch.equal(pb.cpu(), p.cpu().to(torch.bfloat16))
+    n = 4 * 1000 + 3
+    pp = rnd(n, seed=1)
+    ref = torch.nn.Parameter(pp.clone())
+    opt = torch.optim.Adam([ref], lr=1e-3)
+    pd = pp.clone().to(DEV)
+    md, vd = torch.zeros_like(pd), torch.zeros_like(pd)
+    for i in range(3):
+        gr = rnd(n, seed=10 + i)
+        ref.grad = gr.clone() * 0.5
+        opt.step()
+        o.adam_step(pd, gr.to(DEV), md, vd, None, n, 1e-3, 0.9, 0.999, 1e-8, i + 1, grad_scale=0.5)
+    torch.cuda.synchronize()
+    assert np.allclose(pd.cpu().numpy(), ref.detach().numpy(), atol=1e-6)

@@ -86,9 +86,37 @@ class Gemm:
         self._keep = (A, B, Cmat, bias, aux, row_scale, col_scale)   # keep buffers alive
         self._fn = lib().w2v2_gemm
         self.flops = 2.0 * M * N * K * batch
+        # which template instantiation of csrc/gemm.hip this descriptor launches (for profiling)
+        self.kernel_class = ("bf16" if dt(A) == BF16 else "f32") + "_" + ("t" if transA else "n") + ("n" if transB else "t")
+        self.narrow = N <= 64
+        self.out_is_act = Cmat.dtype == torch.bfloat16
+
+    _prof = None
+
+    @classmethod
+    def profile_begin(cls, select) -> None:
+        """Time every launch for which select(gemm) is true with HIP events on the launch stream."""
+        cls._prof = {"select": select, "events": []}
+
+    @classmethod
+    def profile_end(cls) -> dict:
+        prof, cls._prof = cls._prof, None
+        if not prof or not prof["events"]:
+            return {"launches": 0, "ms": 0.0, "flops": 0.0}
+        torch.cuda.synchronize()
+        ms = sum(a.elapsed_time(b) for a, b, _ in prof["events"])
+        return {"launches": len(prof["events"]), "ms": ms, "flops": sum(f for _, _, f in prof["events"])}
 
     def __call__(self) -> None:
-        rc = self._fn(self._ref, stream())
+        prof = Gemm._prof
+        if prof is not None and not self.narrow and prof["select"](self):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            rc = self._fn(self._ref, stream())
+            e1.record()
+            prof["events"].append((e0, e1, self.flops))
+        else:
+            rc = self._fn(self._ref, stream())
         if rc:
             _lib.check(rc, "gemm")
 
