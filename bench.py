@@ -43,7 +43,9 @@ def cpu_baseline(batch=2, n_samples=48000, num_speakers=5994):
     """The CPU oracle on a bounded sample of the same workload: `batch` utterances of 3 s through
     w2v2-base + mean+std + AAM, forward + backward (CNN frozen) + Adam, f32, all host cores."""
     from oracle import w2v2_oracle as O
-    torch.set_num_threads(os.cpu_count() or 1)
+    # torch's CPU kernels stop scaling (and then collapse) beyond a few dozen threads at these sizes:
+    # use up to 32 host cores and report that number
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
     cores = torch.get_num_threads()
     cfg = O.OracleConfig.base()
     sd = O.make_state_dict(cfg, 20211)
@@ -66,14 +68,16 @@ def cpu_baseline(batch=2, n_samples=48000, num_speakers=5994):
                     O.adam_step(p, p.grad, m, v, i + 1, 1e-5, 0.9)
         return float(loss)
 
-    step(0)                                   # warm-up (thread pools, allocator)
     t0 = time.perf_counter()
-    n = 2
+    step(0)                                   # warm-up (thread pools, allocator)
+    warm = time.perf_counter() - t0
+    n = 2 if warm < 12 else 1                 # bound the sample to ~10-30 s of CPU work
+    t0 = time.perf_counter()
     for i in range(n):
         step(i + 1)
     dt = (time.perf_counter() - t0) / n
     return {"value": round(batch / dt, 4), "unit": "utterances/sec", "cores": cores, "kind": "port",
-            "sample": f"{n} timed steps of {batch} x 3 s utterances, w2v2-base + mean+std + AAM(5994), "
+            "sample": f"{n} timed step(s) of {batch} x 3 s utterances, w2v2-base + mean+std + AAM(5994), "
                       f"fwd+bwd (CNN frozen) + Adam, f32 torch CPU oracle ({dt:.2f} s/step)"}
 
 

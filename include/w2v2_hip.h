@@ -93,12 +93,16 @@ int w2v2_gemm(const w2v2_gemm_desc* d, void* stream);
  * Layer 0 of HF:382-419: Conv1d(1->C,k,stride,no bias) + GroupNorm(C groups == per-(b,c) over time,
  * biased var, eps) + GELU(erf)  (HF:302-323).  wav [B,N] f32 -> y [B,L,C] act dtype, channels-last.
  * Two passes, conv recomputed in both so the [B,L,C] pre-norm tensor never touches HBM:
- *   stats: stats[b][c] = {sum, sumsq} (f64, caller zeroes)      apply: normalise + GELU + store. */
-int w2v2_conv0_stats(const float* wav, const float* w /*[C][k]*/, double* stats /*[B][C][2]*/,
-                     int B, int N, int C, int k, int stride, void* stream);
-int w2v2_conv0_apply(const float* wav, const float* w, const double* stats, const float* gamma,
+ *   stats: per-block partial {sum, sumsq} -> partial[B][nchunk][C][2] (f32 workspace of
+ *          B * w2v2_conv0_workspace_floats() floats), folded in a fixed order (f64) into
+ *          mean_rstd[B][C][2] = {mean, 1/sqrt(var+eps)}: deterministic and batch-invariant.
+ *   apply: normalise + GELU + store. */
+int w2v2_conv0_workspace_floats(int N, int C, int k, int stride);
+int w2v2_conv0_stats(const float* wav, const float* w /*[C][k]*/, float* partial, float* mean_rstd,
+                     int B, int N, int C, int k, int stride, float eps, void* stream);
+int w2v2_conv0_apply(const float* wav, const float* w, const float* mean_rstd, const float* gamma,
                      const float* beta, void* y, int dtype, int B, int N, int C, int k, int stride,
-                     float eps, void* stream);
+                     void* stream);
 /* HF conv weight [Cout][Cin][k] (f32) -> implicit-GEMM operand [Cout][k][Cin] (dtype). */
 int w2v2_pack_conv_weight(const float* w, void* out, int dtype, int Cout, int Cin, int k, void* stream);
 

@@ -175,7 +175,7 @@ def test_conv0_groupnorm_gelu(dtype):
     ref = gelu(y).transpose(1, 2)
     L = ref.shape[1]
     out = torch.zeros(B, L, C, dtype=dtype, device=DEV)
-    stats = torch.zeros(B, C, 2, dtype=torch.float64, device=DEV)
+    stats = o.conv0_workspace(B, N, C, k, s, DEV)
     o.conv0_groupnorm_gelu(wav.to(DEV), w.to(DEV), gamma.to(DEV), beta.to(DEV), out, stats, k, s)
     torch.cuda.synchronize()
     assert rel_l2(out.float().cpu(), ref) < (2e-6 if dtype == torch.float32 else 4e-3)
@@ -404,8 +404,9 @@ def test_fused_attention_fwd_bwd(T):
     o = ops()
     B, heads, d = 2, 3, 64
     H = heads * d
-    qkv = bf(rnd(B, T, 3 * H, seed=T, scale=1.0)).float()
+    qkv = rnd(B, T, 3 * H, seed=T, scale=1.0)
     qkv[..., :2 * H] *= 1.5                         # non-trivial softmax
+    qkv = bf(qkv).float()
     dctx = bf(rnd(B, T, H, seed=T + 1)).float()
     qr = qkv.double().requires_grad_(True)
     ref = _attn_ref(qr, B, T, heads, d)

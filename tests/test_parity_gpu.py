@@ -226,7 +226,8 @@ def test_full_batch_no_cross_utterance_mixing_and_determinism():
     for i in (0, 17, 65):
         ei = one.embed(wav[i:i + 1]).clone()
         torch.cuda.synchronize()
-        assert rel_l2(ei.cpu(), e1[i:i + 1].cpu()) < 2e-3, i       # same bf16 path, different tile schedule only
+        # every kernel reduces in a batch-independent order (no atomics on the forward path)
+        assert torch.equal(ei, e1[i:i + 1]), (i, rel_l2(ei.cpu(), e1[i:i + 1].cpu()))
     assert torch.isfinite(e1).all()
 
 

@@ -1,7 +1,9 @@
 // conv0.hip -- layer 0 of the wav2vec2 feature encoder (HF:302-323, HF:382-419):
 // Conv1d(1 -> C, k=10, stride=5, no bias) + GroupNorm(C groups == per-(utterance, channel) statistics
 // over time, biased variance) + GELU(erf), fused so the [B, L, C] pre-norm tensor never exists in HBM:
-//   pass 1 (stats): conv, accumulate sum / sum-of-squares per (b, c)          -> 16 B per (b, c)
+//   pass 1 (stats): conv, per-block partial sum / sum-of-squares per (b, chunk, c), then a tiny
+//                   finalize kernel folds the partials in a FIXED order (f64) -> {mean, rstd}:
+//                   bitwise deterministic and independent of the batch an utterance sits in.
 //   pass 2 (apply): conv again (10 MAC per output, cheaper than a 9.8 MB/utt round trip),
 //                   normalise, GELU, store channels-last in the activation dtype.
 // HBM-bound: algorithmic bytes/utt = 2 x 192 KB waveform reads + L*C*sizeof(T) output (9.83 MB bf16).
@@ -15,7 +17,8 @@ constexpr int C0_MAXK = 16;
 
 template <typename T, bool APPLY>
 __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ wav, const float* __restrict__ w,
-                                                    double* __restrict__ stats, const float* __restrict__ gamma,
+                                                    float* __restrict__ partial, const float* __restrict__ mr,
+                                                    const float* __restrict__ gamma,
                                                     const float* __restrict__ beta, T* __restrict__ y, int N,
                                                     int L, int C, int k, int stride, float eps) {
   extern __shared__ float xs[];
@@ -42,16 +45,13 @@ __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ wa
         s1 += acc;
         s2 = fmaf(acc, acc, s2);
       }
-      double* st = stats + ((int64_t)b * C + c) * 2;
-      atomicAdd(st, (double)s1);
-      atomicAdd(st + 1, (double)s2);
+      float* pt = partial + (((int64_t)b * gridDim.x + blockIdx.x) * C + c) * 2;
+      pt[0] = s1;
+      pt[1] = s2;
     } else {
-      const double* st = stats + ((int64_t)b * C + c) * 2;
-      const double mu = st[0] / (double)L;
-      const double var = st[1] / (double)L - mu * mu;
-      const float rstd = (float)(1.0 / sqrt((var > 0.0 ? var : 0.0) + (double)eps));
-      const float ga = gamma[c] * rstd;
-      const float be = beta[c] - (float)mu * ga;
+      const float* st = mr + ((int64_t)b * C + c) * 2;
+      const float ga = gamma[c] * st[1];
+      const float be = beta[c] - st[0] * ga;
       T* dst = y + ((int64_t)b * L + l0) * C + c;
       for (int f = 0; f < nf; ++f) {
         const float* xp = xs + f * stride;
@@ -65,39 +65,66 @@ __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ wa
   }
 }
 
+// fold the per-chunk partials of one (b, c) in chunk order (f64) -> {mean, rstd}
+__global__ void conv0_finalize_kernel(const float* __restrict__ partial, float* __restrict__ mr, int B, int C,
+                                      int nchunk, int L, float eps) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * C) return;
+  const int b = i / C, c = i - b * C;
+  double s1 = 0.0, s2 = 0.0;
+  for (int j = 0; j < nchunk; ++j) {
+    const float* pt = partial + (((int64_t)b * nchunk + j) * C + c) * 2;
+    s1 += (double)pt[0];
+    s2 += (double)pt[1];
+  }
+  const double mu = s1 / (double)L;
+  const double var = s2 / (double)L - mu * mu;
+  mr[(int64_t)i * 2] = (float)mu;
+  mr[(int64_t)i * 2 + 1] = (float)(1.0 / sqrt((var > 0.0 ? var : 0.0) + (double)eps));
+}
+
 static int conv0_check(const char* nm, int B, int N, int C, int k, int stride) {
   W2V2_REQUIRE(B > 0 && C > 0 && k > 0 && k <= C0_MAXK && stride > 0 && N >= k,
                "%s: bad shape B=%d N=%d C=%d k=%d stride=%d", nm, B, N, C, k, stride);
   return 0;
 }
 
-extern "C" int w2v2_conv0_stats(const float* wav, const float* w, double* stats, int B, int N, int C, int k,
-                                int stride, void* stream) {
+extern "C" int w2v2_conv0_stats(const float* wav, const float* w, float* partial, float* mean_rstd, int B, int N,
+                                int C, int k, int stride, float eps, void* stream) {
   if (conv0_check("conv0_stats", B, N, C, k, stride)) return -1;
-  W2V2_REQUIRE(wav && w && stats, "conv0_stats: null pointer");
+  W2V2_REQUIRE(wav && w && partial && mean_rstd, "conv0_stats: null pointer");
   const int L = (N - k) / stride + 1;
-  dim3 grid((unsigned)cdiv(L, C0_FRAMES), B);
+  const int nchunk = (int)cdiv(L, C0_FRAMES);
+  dim3 grid((unsigned)nchunk, B);
   const size_t lds = ((size_t)(C0_FRAMES - 1) * stride + k) * sizeof(float);
-  hipLaunchKernelGGL((conv0_kernel<float, false>), grid, dim3(256), lds, as_stream(stream), wav, w, stats,
-                     (const float*)nullptr, (const float*)nullptr, (float*)nullptr, N, L, C, k, stride, 0.f);
+  hipLaunchKernelGGL((conv0_kernel<float, false>), grid, dim3(256), lds, as_stream(stream), wav, w, partial,
+                     (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, N, L, C, k,
+                     stride, 0.f);
+  hipLaunchKernelGGL(conv0_finalize_kernel, dim3((unsigned)cdiv((int64_t)B * C, 256)), dim3(256), 0,
+                     as_stream(stream), partial, mean_rstd, B, C, nchunk, L, eps);
   W2V2_CHECK_LAUNCH("conv0_stats");
   return 0;
 }
 
-extern "C" int w2v2_conv0_apply(const float* wav, const float* w, const double* stats, const float* gamma,
+extern "C" int w2v2_conv0_workspace_floats(int N, int C, int k, int stride) {
+  const int L = (N - k) / stride + 1;
+  return (int)cdiv(L, C0_FRAMES) * C * 2;   // per utterance
+}
+
+extern "C" int w2v2_conv0_apply(const float* wav, const float* w, const float* mean_rstd, const float* gamma,
                                 const float* beta, void* y, int dtype, int B, int N, int C, int k, int stride,
-                                float eps, void* stream) {
+                                void* stream) {
   if (conv0_check("conv0_apply", B, N, C, k, stride)) return -1;
-  W2V2_REQUIRE(wav && w && stats && gamma && beta && y, "conv0_apply: null pointer");
+  W2V2_REQUIRE(wav && w && mean_rstd && gamma && beta && y, "conv0_apply: null pointer");
   const int L = (N - k) / stride + 1;
   dim3 grid((unsigned)cdiv(L, C0_FRAMES), B);
   const size_t lds = ((size_t)(C0_FRAMES - 1) * stride + k) * sizeof(float);
   if (dtype == W2V2_BF16)
     hipLaunchKernelGGL((conv0_kernel<bf16_t, true>), grid, dim3(256), lds, as_stream(stream), wav, w,
-                       const_cast<double*>(stats), gamma, beta, (bf16_t*)y, N, L, C, k, stride, eps);
+                       (float*)nullptr, mean_rstd, gamma, beta, (bf16_t*)y, N, L, C, k, stride, 0.f);
   else if (dtype == W2V2_F32)
     hipLaunchKernelGGL((conv0_kernel<float, true>), grid, dim3(256), lds, as_stream(stream), wav, w,
-                       const_cast<double*>(stats), gamma, beta, (float*)y, N, L, C, k, stride, eps);
+                       (float*)nullptr, mean_rstd, gamma, beta, (float*)y, N, L, C, k, stride, 0.f);
   else
     W2V2_FAIL("conv0_apply: bad dtype %d", dtype);
   W2V2_CHECK_LAUNCH("conv0_apply");

@@ -90,7 +90,7 @@ class Plan:
         cfg, B, T, M, H, I = self.cfg, self.B, self.T, self.M, self.cfg.hidden_size, self.cfg.intermediate_size
         f32 = torch.float32
         C = cfg.conv_dim
-        self.stats0 = self._e(B, C[0], 2, dtype=torch.float64)
+        self.stats0 = ops.conv0_workspace(B, self.N, C[0], cfg.conv_kernel[0], cfg.conv_stride[0], self.dev)
         self.conv = [self._e(B, L, c) for L, c in zip(self.lens, C)]
         cins = (1,) + tuple(C[:-1])
         self.convw = [None] + [self._e(C[i], cfg.conv_kernel[i] * cins[i]) for i in range(1, len(C))]

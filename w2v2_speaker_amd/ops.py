@@ -126,18 +126,24 @@ def gemm(*args, **kw) -> None:
 
 
 # ------------------------------------------------------------------------------------------------ conv0
+def conv0_workspace(B: int, N: int, C: int, k: int, stride: int, device) -> torch.Tensor:
+    """f32 scratch for conv0_groupnorm_gelu: per-chunk partial sums + {mean, rstd}."""
+    n = lib().w2v2_conv0_workspace_floats(N, C, k, stride)
+    return torch.empty(B * n + B * C * 2, dtype=torch.float32, device=device)
+
+
 def conv0_groupnorm_gelu(wav: torch.Tensor, w: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor,
-                         out: torch.Tensor, stats: torch.Tensor, k: int, stride: int, eps: float = 1e-5) -> None:
-    """HF:302-323 layer 0.  wav [B,N] f32, w [C,1,k] f32, out [B,L,C], stats [B,C,2] f64 scratch."""
-    _dev(wav, w, gamma, beta, out, stats)
+                         out: torch.Tensor, work: torch.Tensor, k: int, stride: int, eps: float = 1e-5) -> None:
+    """HF:302-323 layer 0.  wav [B,N] f32, w [C,1,k] f32, out [B,L,C], work from conv0_workspace()."""
+    _dev(wav, w, gamma, beta, out, work)
     B, N = wav.shape
     Cc = w.shape[0]
-    stats.zero_()
+    mr = work[work.numel() - B * Cc * 2:]
     L = lib()
-    _lib.check(L.w2v2_conv0_stats(wav.data_ptr(), w.data_ptr(), stats.data_ptr(), B, N, Cc, k, stride, stream()),
-               "conv0_stats")
-    _lib.check(L.w2v2_conv0_apply(wav.data_ptr(), w.data_ptr(), stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
-                                  out.data_ptr(), dt(out), B, N, Cc, k, stride, eps, stream()), "conv0_apply")
+    _lib.check(L.w2v2_conv0_stats(wav.data_ptr(), w.data_ptr(), work.data_ptr(), mr.data_ptr(), B, N, Cc, k, stride,
+                                  eps, stream()), "conv0_stats")
+    _lib.check(L.w2v2_conv0_apply(wav.data_ptr(), w.data_ptr(), mr.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                  out.data_ptr(), dt(out), B, N, Cc, k, stride, stream()), "conv0_apply")
 
 
 def pack_conv_weight(w: torch.Tensor, out: torch.Tensor) -> None:
