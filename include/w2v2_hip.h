@@ -89,6 +89,22 @@ typedef struct {
 
 int w2v2_gemm(const w2v2_gemm_desc* d, void* stream);
 
+/* Grouped weight-gradient GEMM (the backward of HF:520-526,544,565-572 nn.Linear weights/biases):
+ *   dW_p[o][i] = sum_t dY_p[t][o] * X_p[t][i]      dbias_p[o] = sum_t dY_p[t][o]   (dbias may be NULL)
+ * for 1..8 (dY, X) pairs in ONE launch, bf16 operands [tokens][features] (K-major), f32 results
+ * WRITTEN (not accumulated), no split-K, no atomics -> bitwise reproducible.
+ * Contract: rows [tokens, tokens_padded) of every dY / X are readable and zero
+ * (tokens_padded = tokens rounded up to 64); n_out, n_in multiples of 8; 16-byte aligned rows. */
+typedef struct {
+  const void* dY; int64_t ld_dy;
+  const void* X;  int64_t ld_x;
+  float* dW;      int64_t ld_dw;
+  float* dbias;
+  int32_t n_out, n_in;
+} w2v2_wgrad_problem;
+int w2v2_wgrad_grouped(const w2v2_wgrad_problem* problems, int n, int tokens, int tokens_padded,
+                       void* stream);
+
 /* ------------------------------------------------------------------------ conv feature extractor
  * Layer 0 of HF:382-419: Conv1d(1->C,k,stride,no bias) + GroupNorm(C groups == per-(b,c) over time,
  * biased var, eps) + GELU(erf)  (HF:302-323).  wav [B,N] f32 -> y [B,L,C] act dtype, channels-last.
@@ -115,7 +131,7 @@ int w2v2_layernorm_fwd(const void* x, void* r_inout, const float* gamma, const f
                        float* mean, float* rstd, int M, int H, float eps, float drop_p,
                        uint64_t seed, int dtype, void* stream);
 /* s = pre-norm input (x if r was NULL).  Outputs: ds (grad wrt s; may alias dy), d_r = ds*dropmask
- * (only if drop_p > 0, else NULL), dgamma/dbeta ATOMICALLY ADDED (f32, caller zeroes). */
+ * (optional; a plain copy of ds when drop_p == 0), dgamma/dbeta ATOMICALLY ADDED (f32, caller zeroes). */
 int w2v2_layernorm_bwd(const void* dy, const void* s, const float* mean, const float* rstd,
                        const float* gamma, void* ds, void* d_r, float* dgamma, float* dbeta, int M,
                        int H, float drop_p, uint64_t seed, int dtype, void* stream);
@@ -131,6 +147,11 @@ int w2v2_add(const void* x, const void* a, void* y, int64_t n, int dtype, void* 
 int w2v2_colsum(const void* x, int64_t ld, float* out, int M, int N, int dtype, void* stream);
 /* f32 -> act dtype cast (bf16 weight copies), and strided 2-D copy/convert. */
 int w2v2_cast(const float* x, void* y, int64_t n, int dtype, void* stream);
+/* dst_i[C][R] = transpose(src_i[R][C]) for n matrices of one arena; table (device) holds per matrix
+ * {src element offset, dst element offset, R, C}.  Refreshes the pre-transposed bf16 weight copies the
+ * data-gradient GEMMs read (so dX = dY W runs K-contiguous like the forward products). */
+int w2v2_transpose_many(const void* src, void* dst, const int64_t* table, int n, int blocks_per_matrix,
+                        int dtype, void* stream);
 /* SpecAugment time mask HF:1290-1292: h[m][:] = embed where mask[m].  Backward: d_embed += sum of
  * masked rows of dh (atomics), masked rows of dh zeroed in place. */
 int w2v2_mask_fill(void* h, const uint8_t* mask, const float* embed, int M, int H, int dtype,
@@ -145,13 +166,15 @@ int w2v2_prepend_token(const void* x, void* y, float c, int B, int T, int H, int
  * regroup pads and splits channels  x [B,T,H] -> xg [B,G,T+K-1,H/G] (zero pad `pad_left` frames left).
  * weightnorm_pack: w = g*v/||v||_(per tap) -> fwd operand wf[G][co][tap][ci] and the flipped
  * operand wb[G][ci][K-1-tap][co] used by the data gradient; also returns inv norms.
- * weightnorm_bwd: from dwf[G][co][tap][ci] (f32) -> dg[K], dv[H][H/G][K] (written, not added). */
+ * weightnorm_bwd: from dwf[G][co][tap][ci] (f32) -> dg[K], dv[H][H/G][K] (written, not added).
+ * `sumsq` / `dot` are f32 scratch of 129*K floats: [0,K) the per-tap result, the rest per-block
+ * partials that are folded in a fixed order (bitwise reproducible packed weights). */
 int w2v2_posconv_regroup(const void* x, void* xg, int B, int T, int H, int G, int K, int pad_left,
                          int dtype, void* stream);
-int w2v2_weightnorm_pack(const float* g, const float* v, float* sumsq /*[K] scratch*/, void* wf,
+int w2v2_weightnorm_pack(const float* g, const float* v, float* sumsq /*[129*K]*/, void* wf,
                          void* wb, int H, int G, int K, int dtype, void* stream);
 int w2v2_weightnorm_bwd(const float* g, const float* v, const float* sumsq, const float* dwf,
-                        float* dot /*[K] scratch*/, float* dg, float* dv, int H, int G, int K,
+                        float* dot /*[129*K]*/, float* dg, float* dv, int H, int G, int K,
                         void* stream);
 
 /* ------------------------------------------------------------------------------------ attention

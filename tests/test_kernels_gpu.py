@@ -335,7 +335,7 @@ def test_posconv_forward_backward(dtype):
     xg = torch.zeros(B, G, Tp, Cg, dtype=dtype, device=DEV)
     o.posconv_regroup(xd, xg, B, T, H, G, K, K // 2)
     wf, wb = torch.zeros(G, Cg, K * Cg, dtype=dtype, device=DEV), torch.zeros(G, Cg, K * Cg, dtype=dtype, device=DEV)
-    sumsq = torch.zeros(K, device=DEV)
+    sumsq = torch.zeros(129 * K, device=DEV)
     o.weightnorm_pack(g.to(DEV), v.to(DEV), sumsq, wf, wb, H, G, K)
     y = torch.zeros(B * T, H, dtype=dtype, device=DEV)
     ypre = torch.zeros(B * T, H, dtype=dtype, device=DEV)
@@ -353,7 +353,7 @@ def test_posconv_forward_backward(dtype):
     o.gemm(Cg, K * Cg, M, P1, xg, dwf, lda=H, ldb=Cg, ldc=K * Cg, transA=True, transB=True,
            b_seg=(T, G * Tp * Cg), batch=G, batch_inner=G, a_strides=(0, Cg), b_strides=(0, Tp * Cg),
            c_strides=(0, Cg * K * Cg))
-    dot, dg, dv = torch.zeros(K, device=DEV), torch.zeros(K, device=DEV), torch.zeros(H, Cg, K, device=DEV)
+    dot, dg, dv = torch.zeros(129 * K, device=DEV), torch.zeros(K, device=DEV), torch.zeros(H, Cg, K, device=DEV)
     o.weightnorm_bwd(g.to(DEV), v.to(DEV), sumsq, dwf, dot, dg, dv, H, G, K)
     dyg = torch.zeros(B, G, Tp, Cg, dtype=dtype, device=DEV)
     o.posconv_regroup(P1, dyg, B, T, H, G, K, K - 1 - K // 2)
@@ -530,3 +530,33 @@ def test_fused_adam_matches_torch_and_golden():
         o.adam_step(pd, gr.to(DEV), md, vd, None, n, 1e-3, 0.9, 0.999, 1e-8, i + 1, grad_scale=0.5)
     torch.cuda.synchronize()
     assert np.allclose(pd.cpu().numpy(), ref.detach().numpy(), atol=1e-6)
+
+
+# ----------------------------------------------------------------------------------------------- grouped wgrad
+def test_grouped_weight_gradient_gemm():
+    """dW = dY^T X and dbias = colsum(dY) for several Linear layers in one launch (LDS-DMA staging +
+    ds_read_b64_tr_b16 transposing fragment reads); ragged feature sizes, token tail zero-padded."""
+    o = ops()
+    tokens = 2 * 149
+    tp = (tokens + 63) // 64 * 64
+    shapes = [(768, 3072), (3072, 768), (768, 768), (2304, 768), (64, 128), (136, 72)]
+    probs, refs = [], []
+    for i, (no, ni) in enumerate(shapes):
+        dY = torch.zeros(tp, no)
+        X = torch.zeros(tp, ni)
+        dY[:tokens] = bf(rnd(tokens, no, seed=2 * i + 1, scale=0.5)).float()
+        X[:tokens] = bf(rnd(tokens, ni, seed=2 * i + 2, scale=0.5)).float()
+        dW = torch.full((no, ni), 7.0, device=DEV)           # must be overwritten, not accumulated
+        db = torch.full((no,), 7.0, device=DEV)
+        probs.append((dY.to(torch.bfloat16).to(DEV), X.to(torch.bfloat16).to(DEV), dW, db))
+        refs.append((dY.double().t() @ X.double(), dY.double().sum(0)))
+    o.WgradGroup(probs, tokens, tp)()
+    torch.cuda.synchronize()
+    for (dY, X, dW, db), (rw, rb), shp in zip(probs, refs, shapes):
+        assert rel_l2(dW.cpu(), rw) < 1e-5, shp
+        assert rel_l2(db.cpu(), rb) < 1e-5, shp
+    # bitwise reproducible (no atomics)
+    first = [p[2].clone() for p in probs]
+    o.WgradGroup(probs, tokens, tp)()
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, p[2]) for a, p in zip(first, probs))

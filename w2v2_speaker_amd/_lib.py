@@ -31,10 +31,16 @@ class GemmDesc(C.Structure):
                 ("alpha", c_f32), ("split_k", c_i32), ("accumulate", c_i32), ("_pad", c_i32)]
 
 
+class WgradProblem(C.Structure):
+    _fields_ = [("dY", c_vp), ("ld_dy", c_i64), ("X", c_vp), ("ld_x", c_i64), ("dW", c_vp), ("ld_dw", c_i64),
+                ("dbias", c_vp), ("n_out", c_i32), ("n_in", c_i32)]
+
+
 _SIGS = {
     "w2v2_version": (c_i32, []),
     "w2v2_last_error": (C.c_char_p, []),
     "w2v2_gemm": (c_i32, [C.POINTER(GemmDesc), c_vp]),
+    "w2v2_wgrad_grouped": (c_i32, [C.POINTER(WgradProblem), c_i32, c_i32, c_i32, c_vp]),
     "w2v2_conv0_workspace_floats": (c_i32, [c_i32, c_i32, c_i32, c_i32]),
     "w2v2_conv0_stats": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp]),
     "w2v2_conv0_apply": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32,
@@ -49,6 +55,7 @@ _SIGS = {
     "w2v2_add": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, c_vp]),
     "w2v2_colsum": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_i32, c_i32, c_vp]),
     "w2v2_cast": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_vp]),
+    "w2v2_transpose_many": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
     "w2v2_mask_fill": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
     "w2v2_mask_fill_bwd": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
     "w2v2_prepend_token": (c_i32, [c_vp, c_vp, c_f32, c_i32, c_i32, c_i32, c_i32, c_vp]),

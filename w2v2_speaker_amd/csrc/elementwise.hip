@@ -272,3 +272,47 @@ extern "C" int w2v2_prepend_token(const void* x, void* y, float c, int B, int T,
   W2V2_CHECK_LAUNCH("prepend_token");
   return 0;
 }
+
+// ------------------------------------------------------------------------------------- batched transpose
+// dst_i[C][R] = src_i[R][C]^T for a table of matrices inside one arena (the bf16 weight copies): one launch
+// refreshes every pre-transposed weight after the optimiser step, so that the data-gradient GEMMs
+// (dX = dY W) run on the same K-contiguous LDS-DMA kernel as the forward products.
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_many_kernel(const T* __restrict__ src, T* __restrict__ dst,
+                                                             const int64_t* __restrict__ table) {
+  __shared__ T tile[64][66];
+  const int64_t* e = table + (int64_t)blockIdx.y * 4;
+  const int64_t so = e[0], dof = e[1];
+  const int R = (int)e[2], Cc = (int)e[3];
+  const int tc = (Cc + 63) / 64, tr = (R + 63) / 64;
+  for (int t = blockIdx.x; t < tc * tr; t += gridDim.x) {
+    const int r0 = (t / tc) * 64, c0 = (t % tc) * 64;
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+      const int r = i >> 6, c = i & 63;
+      if (r0 + r < R && c0 + c < Cc) tile[r][c] = src[so + (int64_t)(r0 + r) * Cc + c0 + c];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+      const int c = i >> 6, r = i & 63;
+      if (r0 + r < R && c0 + c < Cc) dst[dof + (int64_t)(c0 + c) * R + r0 + r] = tile[r][c];
+    }
+  }
+}
+
+extern "C" int w2v2_transpose_many(const void* src, void* dst, const int64_t* table, int n, int blocks_per_matrix,
+                                   int dtype, void* stream) {
+  W2V2_REQUIRE(src && dst && table && n >= 0 && blocks_per_matrix > 0, "transpose_many: bad arguments");
+  if (n == 0) return 0;
+  dim3 grid(blocks_per_matrix, n);
+  if (dtype == W2V2_BF16)
+    hipLaunchKernelGGL(transpose_many_kernel<bf16_t>, grid, dim3(256), 0, as_stream(stream), (const bf16_t*)src,
+                       (bf16_t*)dst, table);
+  else if (dtype == W2V2_F32)
+    hipLaunchKernelGGL(transpose_many_kernel<float>, grid, dim3(256), 0, as_stream(stream), (const float*)src,
+                       (float*)dst, table);
+  else
+    W2V2_FAIL("transpose_many: bad dtype %d", dtype);
+  W2V2_CHECK_LAUNCH("transpose_many");
+  return 0;
+}

@@ -14,6 +14,7 @@
 //               (embeddings within 1e-3 rel-L2 of the f32 reference, BASELINE.json north_star);
 //               throughput runs use bf16.
 #include "common.cuh"
+#include <stdlib.h>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
@@ -42,7 +43,9 @@ struct GemmArgs {
   const float* row_scale;
   const float* col_scale;
   float alpha;
-  int c_vec_ok;
+  int c_vec_ok;    // 8-element vector stores to C legal
+  int aux_vec_ok;  // 8-element vector access to aux legal
+  int dbg;
 };
 
 __device__ __forceinline__ int64_t outer_off(const OpDev& o, int64_t idx) {
@@ -124,6 +127,148 @@ __device__ __forceinline__ void epilogue_store4(const GemmArgs& g, TC* __restric
     for (int j = 0; j < 4; ++j)
       if (n0 + j < g.N) arow[n0 + j] = from_f32<TC>(pre[j]);
   }
+}
+
+// ------------------------------------------------------------------------------ coalesced tile epilogue
+// The MFMA accumulator layout gives each lane 4 consecutive columns of 16 different rows: storing
+// that directly issues 32-byte row fragments (measured: ~1.1 TB/s, 40 % of a K=768 GEMM's time).
+// Instead the tile goes through LDS (the operand tiles are dead by now): the two row-halves of the
+// block tile are written as f32 [64][BN+4], then all 256 threads read back whole rows, apply the
+// epilogue on 8 consecutive columns and issue 16-byte stores, 16 lanes per 256-B row segment.
+template <typename TC, int FM, int FN, int EPI, bool ATOMIC>
+__device__ __forceinline__ void tile_epilogue_impl(const GemmArgs& g, f32x4 (&acc)[FM][FN],
+                                                   float* __restrict__ stage, int m0, int n0, int wm, int wn, int z0,
+                                                   int z1, int split) {
+  constexpr int BN = 32 * FN, ROWS = 16 * FM, PITCH = BN + 4, CPR = BN / 8;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int frow = lane & 15, fk = lane >> 4;
+  TC* Cz = reinterpret_cast<TC*>(g.C) + z0 * g.c_s0 + z1 * g.c_s1;
+  TC* auxz = g.aux ? reinterpret_cast<TC*>(g.aux) + z0 * g.aux_s0 + z1 * g.aux_s1 : nullptr;
+  const float* bias = g.bias ? g.bias + z1 * g.bias_s1 : nullptr;
+  const bool lead = split == 0;
+#pragma unroll 1
+  for (int pass = 0; pass < 2; ++pass) {
+    __syncthreads();
+    if (wm == pass) {
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+          *reinterpret_cast<float4*>(stage + (i * 16 + frow) * PITCH + wn * (16 * FN) + j * 16 + fk * 4) =
+              make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < (ROWS * CPR) / 256; ++it) {
+      const int c = tid + 256 * it;
+      const int r = c / CPR, ch = c - r * CPR;
+      const int m = m0 + pass * ROWS + r, n = n0 + ch * 8;
+      if (m >= g.M || n >= g.N) continue;
+      const float4 lo = *reinterpret_cast<const float4*>(stage + r * PITCH + ch * 8);
+      const float4 hi = *reinterpret_cast<const float4*>(stage + r * PITCH + ch * 8 + 4);
+      float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+      float pre[8];
+      const bool full = n + 8 <= g.N;
+      float ax[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      if constexpr (EPI == W2V2_EPI_GELU_BWD || EPI == W2V2_EPI_ADD) {
+        const TC* ap = auxz + (int64_t)m * g.ldaux + n;
+        if (full && g.aux_vec_ok) {
+          Vec8<TC> t;
+          t.load(ap);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) ax[e] = t.v[e];
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) if (n + e < g.N) ax[e] = to_f32<TC>(ap[e]);
+        }
+      }
+      float bs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      if constexpr (EPI == W2V2_EPI_BIAS || EPI == W2V2_EPI_BIAS_GELU) {
+        if (EPI == W2V2_EPI_BIAS_GELU || lead) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) if (n + e < g.N) bs[e] = bias[n + e];
+        }
+      }
+      float cs[8] = {1, 1, 1, 1, 1, 1, 1, 1};
+      if constexpr (EPI == W2V2_EPI_SCALE_RC) {
+        const float rs = g.row_scale[m];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) if (n + e < g.N) cs[e] = rs * g.col_scale[n + e];
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float x = v[e] * g.alpha;
+        if constexpr (EPI == W2V2_EPI_BIAS) x += bs[e];
+        if constexpr (EPI == W2V2_EPI_BIAS_GELU) { x += bs[e]; pre[e] = x; x = gelu_f(x); }
+        if constexpr (EPI == W2V2_EPI_GELU_BWD) x *= gelu_grad_f(ax[e]);
+        if constexpr (EPI == W2V2_EPI_ADD) x += ax[e];
+        if constexpr (EPI == W2V2_EPI_SCALE_RC) x *= cs[e];
+        v[e] = x;
+      }
+      TC* cp = Cz + (int64_t)m * g.ldc + n;
+      if constexpr (ATOMIC) {
+        if constexpr (sizeof(TC) == 4) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) if (n + e < g.N) unsafeAtomicAdd(reinterpret_cast<float*>(cp) + e, v[e]);
+        }
+      } else {
+        if (full && g.c_vec_ok) {
+          Vec8<TC> t;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) t.v[e] = v[e];
+          t.store(cp);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) if (n + e < g.N) cp[e] = from_f32<TC>(v[e]);
+        }
+      }
+      if constexpr (EPI == W2V2_EPI_BIAS_GELU) {
+        if (auxz != nullptr) {
+          TC* ap = auxz + (int64_t)m * g.ldaux + n;
+          if (full && g.aux_vec_ok) {
+            Vec8<TC> t;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) t.v[e] = pre[e];
+            t.store(ap);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) if (n + e < g.N) ap[e] = from_f32<TC>(pre[e]);
+          }
+        }
+      }
+    }
+  }
+}
+
+// the epilogue kind is wave-uniform: branch ONCE to a specialised body (a per-element switch gets
+// if-converted and evaluates erff/expf for every element of every GEMM)
+template <typename TC, int FM, int FN>
+__device__ __forceinline__ void tile_epilogue(const GemmArgs& g, f32x4 (&acc)[FM][FN], float* __restrict__ stage,
+                                              int m0, int n0, int wm, int wn, int z0, int z1, int split) {
+#define W2V2_EPI_CASE(E)                                                                              \
+  case E:                                                                                             \
+    tile_epilogue_impl<TC, FM, FN, E, false>(g, acc, stage, m0, n0, wm, wn, z0, z1, split);           \
+    break;
+  if (g.atomic) {
+    if constexpr (sizeof(TC) == 4) {
+      if (g.epilogue == W2V2_EPI_BIAS)
+        tile_epilogue_impl<TC, FM, FN, W2V2_EPI_BIAS, true>(g, acc, stage, m0, n0, wm, wn, z0, z1, split);
+      else
+        tile_epilogue_impl<TC, FM, FN, W2V2_EPI_NONE, true>(g, acc, stage, m0, n0, wm, wn, z0, z1, split);
+    }
+    return;
+  }
+  switch (g.epilogue) {
+    W2V2_EPI_CASE(W2V2_EPI_BIAS)
+    W2V2_EPI_CASE(W2V2_EPI_BIAS_GELU)
+    W2V2_EPI_CASE(W2V2_EPI_GELU_BWD)
+    W2V2_EPI_CASE(W2V2_EPI_ADD)
+    W2V2_EPI_CASE(W2V2_EPI_SCALE_RC)
+    default:
+      tile_epilogue_impl<TC, FM, FN, W2V2_EPI_NONE, false>(g, acc, stage, m0, n0, wm, wn, z0, z1, split);
+      break;
+  }
+#undef W2V2_EPI_CASE
 }
 
 // XCD-aware tile order: consecutive workgroup ids land on different XCDs (id % 8); remap so each
@@ -320,20 +465,135 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmArgs g) {
     __syncthreads();
   }
 
+  tile_epilogue<TC, FM, FN>(g, acc, reinterpret_cast<float*>(smem_raw), m0, n0, wm, wn, z0, z1, split);
+}
+
+// ------------------------------------------------------------------------------ bf16 MFMA kernel, LDS-DMA staging
+// Fast path for K-contiguous operands (forward products and, with the pre-transposed weight copies,
+// the data-gradient products): tiles go HBM -> LDS directly with global_load_lds_dwordx4 (no VGPR
+// round trip, no ds_write pass -- the staging writes were the LDS bottleneck of the register-staged
+// kernel).  An LDS-DMA wave-instruction writes 1 KiB lane-linearly (8 rows x 128 B), so the XOR
+// swizzle is applied on the per-lane SOURCE address (physical chunk c' of row r loads logical chunk
+// c' ^ swz(r)) and again on the fragment read.  Out-of-range rows are clamped to the last valid row
+// (their results are never stored); K must be a multiple of 64.
+typedef __attribute__((address_space(1))) const void gvoid_t;
+typedef __attribute__((address_space(3))) void lvoid_t;
+
+template <int FM, int FN, typename TC>
+__global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(const GemmArgs g) {
+  constexpr int BM = 32 * FM, BN = 32 * FN;
+  constexpr int NA = BM / 32, NB = BN / 32;      // 1 KiB pieces per wave per operand tile
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  bf16_t* As = reinterpret_cast<bf16_t*>(smem_raw);           // [2][BM*64]
+  bf16_t* Bs = As + 2 * BM * 64;                              // [2][BN*64]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+
+  const int ntile = g.tiles_m * g.tiles_n;
+  const int tile = xcd_remap(blockIdx.x, ntile);
+  const int tm = tile / g.tiles_n, tn = tile - tm * g.tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int z = blockIdx.z;
+  const int z0 = z / g.batch_inner, z1 = z - z0 * g.batch_inner;
+  const int split = blockIdx.y;
+  const int kbeg = split * g.k_per_split;
+  const int kend = min(g.K, kbeg + g.k_per_split);
+  const int nk = (kend - kbeg) >> 6;
+
+  const bf16_t* Ab = reinterpret_cast<const bf16_t*>(g.A.ptr) + z0 * g.a_s0 + z1 * g.a_s1;
+  const bf16_t* Bb = reinterpret_cast<const bf16_t*>(g.B.ptr) + z0 * g.b_s0 + z1 * g.b_s1;
+
+  const int c8 = lane & 7, r8 = lane >> 3;
+  const bf16_t* ap[NA];
+  const bf16_t* bp[NB];
+#pragma unroll
+  for (int j = 0; j < NA; ++j) {
+    const int row = (wave * NA + j) * 8 + r8;
+    const int grow = min(m0 + row, g.M - 1);
+    ap[j] = Ab + outer_off(g.A, grow) + kbeg + ((c8 ^ swz(row)) << 3);
+  }
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    const int row = (wave * NB + j) * 8 + r8;
+    const int grow = min(n0 + row, g.N - 1);
+    bp[j] = Bb + outer_off(g.B, grow) + kbeg + ((c8 ^ swz(row)) << 3);
+  }
+
+  f32x4 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  auto stage = [&](int buf, int kt) {
+    bf16_t* ad = As + buf * BM * 64 + wave * NA * 8 * 64;
+    bf16_t* bd = Bs + buf * BN * 64 + wave * NB * 8 * 64;
+#pragma unroll
+    for (int j = 0; j < NA; ++j)
+      __builtin_amdgcn_global_load_lds((gvoid_t*)(ap[j] + kt * 64), (lvoid_t*)(ad + j * 8 * 64), 16, 0, 0);
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+      __builtin_amdgcn_global_load_lds((gvoid_t*)(bp[j] + kt * 64), (lvoid_t*)(bd + j * 8 * 64), 16, 0, 0);
+  };
+  const int frow = lane & 15, fk = lane >> 4;
+  auto compute = [&](int buf) {
+    const bf16_t* Ac = As + buf * BM * 64;
+    const bf16_t* Bc = Bs + buf * BN * 64;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 af[FM], bfr[FN];
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
+        const int row = wm * (16 * FM) + i * 16 + frow;
+        af[i] = *reinterpret_cast<const bf16x8*>(Ac + row * 64 + (((kk * 4 + fk) ^ swz(row)) << 3));
+      }
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        const int row = wn * (16 * FN) + j * 16 + frow;
+        bfr[j] = *reinterpret_cast<const bf16x8*>(Bc + row * 64 + (((kk * 4 + fk) ^ swz(row)) << 3));
+      }
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  if (nk > 0) stage(0, 0);
+  __syncthreads();
+  for (int kt = 0; kt < ((g.dbg & 1) ? 0 : nk); kt += 2) {
+    if (kt + 1 < nk) stage(1, kt + 1);
+    compute(0);
+    __syncthreads();
+    if (kt + 1 < nk) {
+      if (kt + 2 < nk) stage(0, kt + 2);
+      compute(1);
+      __syncthreads();
+    }
+  }
+
   TC* Cz = reinterpret_cast<TC*>(g.C) + z0 * g.c_s0 + z1 * g.c_s1;
   const TC* auxz = g.aux ? reinterpret_cast<const TC*>(g.aux) + z0 * g.aux_s0 + z1 * g.aux_s1 : nullptr;
   TC* auxo = g.aux ? reinterpret_cast<TC*>(g.aux) + z0 * g.aux_s0 + z1 * g.aux_s1 : nullptr;
   const float* bias = g.bias ? g.bias + z1 * g.bias_s1 : nullptr;
-#pragma unroll
-  for (int i = 0; i < FM; ++i) {
-    const int m = m0 + wm * (16 * FM) + i * 16 + frow;
-#pragma unroll
-    for (int j = 0; j < FN; ++j) {
-      const int n = n0 + wn * (16 * FN) + j * 16 + fk * 4;
-      const float a4[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-      epilogue_store4<TC>(g, Cz, auxz, auxo, bias, m, n, a4, split == 0);
-    }
+  if ((g.dbg & 2) && acc[0][0][0] != 12345.f) return;
+  tile_epilogue<TC, FM, FN>(g, acc, reinterpret_cast<float*>(smem_raw), m0, n0, wm, wn, z0, z1, split);
+}
+
+template <int FM, int FN, typename TC>
+static void launch_glds(const GemmArgs& a, dim3 grid, hipStream_t st) {
+  constexpr size_t lds = (size_t)2 * (32 * FM + 32 * FN) * 64 * sizeof(bf16_t);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_glds_kernel<FM, FN, TC>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
   }
+  hipLaunchKernelGGL((gemm_bf16_glds_kernel<FM, FN, TC>), grid, dim3(256), lds, st, a);
 }
 
 // ------------------------------------------------------------------------------ exact f32 kernel
@@ -403,6 +663,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
 }
 
 // ------------------------------------------------------------------------------ host dispatch
+static const bool g_w2v2_no_glds = getenv("W2V2_NO_GLDS") != nullptr;   // A/B switch for benchmarking
+
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 template <int FM, int FN, typename TC>
@@ -466,9 +728,11 @@ extern "C" int w2v2_gemm(const w2v2_gemm_desc* d, void* stream) {
   a.bias = d->bias; a.bias_s1 = d->bias_stride1;
   a.row_scale = d->row_scale; a.col_scale = d->col_scale;
   a.alpha = d->alpha;
-  const int csz = d->dtype_c == W2V2_F32 ? 4 : 2;
-  a.c_vec_ok = ((reinterpret_cast<uintptr_t>(d->C) % (4 * csz)) == 0) && (d->ldc % 4 == 0) &&
-               (d->c_stride0 % 4 == 0) && (d->c_stride1 % 4 == 0);
+  a.dbg = getenv("W2V2_GEMM_DBG") ? atoi(getenv("W2V2_GEMM_DBG")) : 0;
+  const int cal = d->dtype_c == W2V2_F32 ? 4 : 8;     // elements per 16 bytes
+  a.c_vec_ok = aligned16(d->C) && (d->ldc % cal == 0) && (d->c_stride0 % cal == 0) && (d->c_stride1 % cal == 0);
+  a.aux_vec_ok = d->aux && aligned16(d->aux) && (d->ldaux % cal == 0) && (d->aux_stride0 % cal == 0) &&
+                 (d->aux_stride1 % cal == 0);
   hipStream_t st = as_stream(stream);
 
   if (d->dtype_ab == W2V2_BF16) {
@@ -478,7 +742,15 @@ extern "C" int w2v2_gemm(const w2v2_gemm_desc* d, void* stream) {
     a.k_per_split = (int)(cdiv(cdiv(d->K, split), 64) * 64);
     if (a.k_per_split == 0) a.k_per_split = 64;
     dim3 grid(a.tiles_m * a.tiles_n, split, d->batch);
-    if (d->dtype_c == W2V2_F32) {
+    const bool glds = !a.A.trans && !a.B.trans && a.A.vec_ok && a.B.vec_ok && (d->K % 64 == 0) && d->K >= 64 &&
+                      !g_w2v2_no_glds;
+    if (glds) {
+      if (d->dtype_c == W2V2_F32) {
+        if (narrow) launch_glds<4, 2, float>(a, grid, st); else launch_glds<4, 4, float>(a, grid, st);
+      } else {
+        if (narrow) launch_glds<4, 2, bf16_t>(a, grid, st); else launch_glds<4, 4, bf16_t>(a, grid, st);
+      }
+    } else if (d->dtype_c == W2V2_F32) {
       if (narrow) launch_bf16<4, 2, float>(a, grid, st); else launch_bf16<4, 4, float>(a, grid, st);
     } else {
       if (narrow) launch_bf16<4, 2, bf16_t>(a, grid, st); else launch_bf16<4, 4, bf16_t>(a, grid, st);

@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           o.v[e] = rs * (g[ci][e] - c1 - xh[ci][e] * c2);
-          if (d_r != nullptr) o2.v[e] = o.v[e] * drop_scale(seed, (uint64_t)(off + e), p, inv_keep);
+          if (d_r != nullptr) o2.v[e] = p > 0.f ? o.v[e] * drop_scale(seed, (uint64_t)(off + e), p, inv_keep) : o.v[e];
         }
         o.store(ds + off);
         if (d_r != nullptr) o2.store(d_r + off);
@@ -180,7 +180,6 @@ extern "C" int w2v2_layernorm_bwd(const void* dy, const void* s, const float* me
   W2V2_REQUIRE(H % 8 == 0 && H <= 8 * 64 * LN_MAXC, "layernorm_bwd: H=%d unsupported", H);
   W2V2_REQUIRE((dgamma == nullptr) == (dbeta == nullptr), "layernorm_bwd: dgamma/dbeta must come together");
   if (M <= 0) return 0;
-  if (drop_p <= 0.f) d_r = nullptr;
   const int nb = (int)(cdiv(M, 4) < 1024 ? cdiv(M, 4) : 1024);
   if (dtype == W2V2_BF16)
     hipLaunchKernelGGL(ln_bwd_kernel<bf16_t>, dim3(nb), dim3(256), 0, as_stream(stream), (const bf16_t*)dy,

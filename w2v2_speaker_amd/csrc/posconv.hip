@@ -48,26 +48,45 @@ extern "C" int w2v2_posconv_regroup(const void* x, void* xg, int B, int T, int H
   return 0;
 }
 
-// per-tap reductions over v [H][Cg][K] (K fastest): out[k] += sum_{o,i} a*b
+// per-tap reductions over v [H][Cg][K] (K fastest): out[k] = sum_{o,i} a*b, in a FIXED order
+// (per-block partials folded by a second kernel) so the packed weights are bitwise reproducible.
+constexpr int TAP_BLOCKS = 128;
+
 template <bool WITH_DW>
 __global__ __launch_bounds__(256) void tap_reduce_kernel(const float* __restrict__ v, const float* __restrict__ dwf,
-                                                         float* __restrict__ out, int H, int Cg, int K) {
-  // thread -> tap (k = tid % K when K <= 256); rows (o,i) strided over blocks
+                                                         float* __restrict__ partial, int H, int Cg, int K) {
+  __shared__ float red[256];
+  // thread -> tap (k = tid % K); rows (o,i) strided over (block, row lane)
   const int rows = H * Cg;
   const int kpt = threadIdx.x % K, rlane = threadIdx.x / K, rlanes = 256 / K;
-  if (rlane >= rlanes) return;
   float acc = 0.f;
-  for (int r = blockIdx.x * rlanes + rlane; r < rows; r += gridDim.x * rlanes) {
-    const float vv = v[(int64_t)r * K + kpt];
-    if constexpr (WITH_DW) {
-      const int o = r / Cg, i = r - o * Cg;
-      const int g = o / Cg, co = o - g * Cg;
-      acc += vv * dwf[(((int64_t)g * Cg + co) * K + kpt) * Cg + i];
-    } else {
-      acc += vv * vv;
+  if (rlane < rlanes) {
+    for (int r = blockIdx.x * rlanes + rlane; r < rows; r += gridDim.x * rlanes) {
+      const float vv = v[(int64_t)r * K + kpt];
+      if constexpr (WITH_DW) {
+        const int o = r / Cg, i = r - o * Cg;
+        const int g = o / Cg, co = o - g * Cg;
+        acc += vv * dwf[(((int64_t)g * Cg + co) * K + kpt) * Cg + i];
+      } else {
+        acc += vv * vv;
+      }
     }
   }
-  unsafeAtomicAdd(out + kpt, acc);
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  if (threadIdx.x < K) {
+    float s = 0.f;
+    for (int j = 0; j < rlanes; ++j) s += red[j * K + threadIdx.x];
+    partial[(int64_t)blockIdx.x * K + threadIdx.x] = s;
+  }
+}
+
+__global__ void tap_finalize_kernel(const float* __restrict__ partial, float* __restrict__ out, int K) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= K) return;
+  float s = 0.f;
+  for (int b = 0; b < TAP_BLOCKS; ++b) s += partial[(int64_t)b * K + k];
+  out[k] = s;
 }
 
 template <typename T>
@@ -91,8 +110,9 @@ extern "C" int w2v2_weightnorm_pack(const float* g, const float* v, float* sumsq
   W2V2_REQUIRE(g && v && sumsq && wf && wb && G > 0 && H % G == 0 && K > 0 && K <= 256, "weightnorm_pack: bad arguments");
   const int Cg = H / G;
   hipStream_t st = as_stream(stream);
-  if (hipMemsetAsync(sumsq, 0, sizeof(float) * K, st) != hipSuccess) W2V2_FAIL("weightnorm_pack: memset failed");
-  hipLaunchKernelGGL((tap_reduce_kernel<false>), dim3(256), dim3(256), 0, st, v, (const float*)nullptr, sumsq, H, Cg, K);
+  hipLaunchKernelGGL((tap_reduce_kernel<false>), dim3(TAP_BLOCKS), dim3(256), 0, st, v, (const float*)nullptr,
+                     sumsq + K, H, Cg, K);
+  hipLaunchKernelGGL(tap_finalize_kernel, dim3((unsigned)cdiv(K, 128)), dim3(128), 0, st, sumsq + K, sumsq, K);
   const int64_t total = (int64_t)H * Cg * K;
   int nb = (int)(cdiv(total, 256) > 4096 ? 4096 : cdiv(total, 256));
   if (dtype == W2V2_BF16)
@@ -129,8 +149,8 @@ extern "C" int w2v2_weightnorm_bwd(const float* g, const float* v, const float* 
                "weightnorm_bwd: bad arguments");
   const int Cg = H / G;
   hipStream_t st = as_stream(stream);
-  if (hipMemsetAsync(dot, 0, sizeof(float) * K, st) != hipSuccess) W2V2_FAIL("weightnorm_bwd: memset failed");
-  hipLaunchKernelGGL((tap_reduce_kernel<true>), dim3(256), dim3(256), 0, st, v, dwf, dot, H, Cg, K);
+  hipLaunchKernelGGL((tap_reduce_kernel<true>), dim3(TAP_BLOCKS), dim3(256), 0, st, v, dwf, dot + K, H, Cg, K);
+  hipLaunchKernelGGL(tap_finalize_kernel, dim3((unsigned)cdiv(K, 128)), dim3(128), 0, st, dot + K, dot, K);
   const int64_t total = (int64_t)H * Cg * K;
   int nb = (int)(cdiv(total, 256) > 4096 ? 4096 : cdiv(total, 256));
   hipLaunchKernelGGL(wn_bwd_kernel, dim3(nb), dim3(256), 0, st, g, v, sumsq, dwf, dot, dg, dv, H, Cg, K);

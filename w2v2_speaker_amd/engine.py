@@ -17,7 +17,8 @@ import torch
 
 from . import ops
 from .config import W2V2Config, Wav2Vec2RegularisationConfig
-from .ops import (EPI_ADD, EPI_BIAS, EPI_BIAS_GELU, EPI_GELU_BWD, EPI_NONE, EPI_SCALE_RC, Gemm, POOL_MODES)
+from .ops import (EPI_ADD, EPI_BIAS, EPI_BIAS_GELU, EPI_GELU_BWD, EPI_NONE, EPI_SCALE_RC, Gemm, POOL_MODES,
+                  WgradGroup)
 from .params import ParamStore
 
 _SITE = {"featproj": 1, "prologue": 2, "attn": 3, "post_attn": 4, "ffn": 5, "act": 6}
@@ -86,6 +87,15 @@ class Plan:
     def _e(self, *shape, dtype=None) -> torch.Tensor:
         return torch.empty(*shape, dtype=dtype or self.adt, device=self.dev)
 
+    def _ep(self, rows: int, cols: int) -> torch.Tensor:
+        """[rows, cols] activation whose storage is padded with ZERO rows up to a multiple of 64: it can
+        be the K-major operand of the grouped weight-gradient GEMM (csrc/wgrad.hip contract)."""
+        rp = (rows + 63) // 64 * 64
+        full = torch.zeros(rp, cols, dtype=self.adt, device=self.dev)
+        v = full[:rows]
+        v._w2v2_padded = full
+        return v
+
     def _alloc(self) -> None:
         cfg, B, T, M, H, I = self.cfg, self.B, self.T, self.M, self.cfg.hidden_size, self.cfg.intermediate_size
         f32 = torch.float32
@@ -95,7 +105,7 @@ class Plan:
         cins = (1,) + tuple(C[:-1])
         self.convw = [None] + [self._e(C[i], cfg.conv_kernel[i] * cins[i]) for i in range(1, len(C))]
         self.zero_bias = torch.zeros(max(max(C), H), dtype=f32, device=self.dev)
-        self.ln_feat = self._e(self.M0, C[-1])
+        self.ln_feat = self._ep(self.M0, C[-1])
         self.mean_f, self.rstd_f = self._e(self.M0, dtype=f32), self._e(self.M0, dtype=f32)
         self.h0 = self._e(self.M0, H)                          # projection output (pre-CLS)
         self.hx = self._e(M, H) if self.cls else self.h0       # encoder input
@@ -103,19 +113,19 @@ class Plan:
         self.Cg, self.Tp = H // G, T + K - 1
         self.xg = self._e(B, G, self.Tp, self.Cg)
         self.posw_f, self.posw_b = self._e(G, self.Cg, K * self.Cg), self._e(G, self.Cg, K * self.Cg)
-        self.pos_sumsq = self._e(K, dtype=f32)
+        self.pos_sumsq = self._e(129 * K, dtype=f32)
         self.pos = self._e(M, H)                               # GELU(posconv) -> overwritten with s0
         self.pos_pre = self._e(M, H) if self.train else None
         self.mean0, self.rstd0 = self._e(M, dtype=f32), self._e(M, dtype=f32)
         L = cfg.num_hidden_layers
         nset = L if self.train else 1
-        self.X = [self._e(M, H) for _ in range(L + 1 if self.train else 2)]
+        self.X = [self._ep(M, H) for _ in range(L + 1 if self.train else 2)]
         heads = cfg.num_attention_heads
         self.Tl = (T + 7) // 8 * 8
         self.lb: List[LayerBufs] = []
         for _ in range(nset):
-            lb = LayerBufs(qkv=self._e(M, 3 * H), ctx=self._e(M, H), a=self._e(M, H), x1=self._e(M, H),
-                           hpre=self._e(M, I) if self.train else None, h=self._e(M, I), f=self._e(M, H),
+            lb = LayerBufs(qkv=self._e(M, 3 * H), ctx=self._ep(M, H), a=self._e(M, H), x1=self._ep(M, H),
+                           hpre=self._e(M, I) if self.train else None, h=self._ep(M, I), f=self._e(M, H),
                            mean1=self._e(M, dtype=f32), rstd1=self._e(M, dtype=f32),
                            mean2=self._e(M, dtype=f32), rstd2=self._e(M, dtype=f32))
             if self.fused:
@@ -146,17 +156,18 @@ class Plan:
                 self.H1 = self._e(Cn, E, dtype=f32) if st.head == "aam" else None
         if self.train:
             self.demb = self._e(B, E, dtype=f32)
-            self.G = self._e(M, H)            # running activation gradient
-            self.Gd = self._e(M, H)           # ... after the dropout mask of a residual branch
-            self.DH = self._e(M, I)
-            self.DQKV = self._e(M, 3 * H)
+            self.G = self._ep(M, H)           # running activation gradient
+            self.Gd = self._ep(M, H)          # ... after the dropout mask of the FFN residual branch (df)
+            self.Gd1 = self._ep(M, H)         # ... of the attention residual branch (da)
+            self.DH = self._ep(M, I)
+            self.DQKV = self._ep(M, 3 * H)
             self.DC = self._e(M, H)
             self.P1 = self._e(M, H)
             self.dyg = self._e(B, G, self.Tp, self.Cg)
             self.dwf = self._e(G, self.Cg, K * self.Cg, dtype=f32)
-            self.pos_dot = self._e(K, dtype=f32)
+            self.pos_dot = self._e(129 * K, dtype=f32)
             self.dn = self._e(self.M0, C[-1])
-            self.G0 = self._e(self.M0, H) if self.cls else None
+            self.G0 = self._ep(self.M0, H) if self.cls else None
             if self.fused:
                 self.delta = self._e(B * heads * T, dtype=f32)
             else:
@@ -214,17 +225,38 @@ class Plan:
                 sk = lambda m, n: _splitk(_tiles(m), _tiles(n), M)
                 W2, W1, Wo = (mw(pre + "feed_forward.output_dense.weight"), mw(pre + "feed_forward.intermediate_dense.weight"),
                               mw(pre + "attention.out_proj.weight"))
+                Wqkv = st.qkv(l, "w")
+                # data-gradient products: with the pre-transposed bf16 weight copies they are plain
+                # K-contiguous GEMMs (LDS-DMA kernel); the f32 parity mode reads W as a K-major operand
+                tb = st.flat_lp_t is None
+                if not tb:
+                    W2, W1, Wo = (st.wt("wav2vec.model." + pre + "feed_forward.output_dense.weight"),
+                                  st.wt("wav2vec.model." + pre + "feed_forward.intermediate_dense.weight"),
+                                  st.wt("wav2vec.model." + pre + "attention.out_proj.weight"))
+                    Wqkv = st.qkv_t(l)
+                self.grouped = st.flat_lp_t is not None      # bf16 mode: one grouped, atomic-free wgrad launch
+                if self.grouped:
+                    pad = lambda t: t._w2v2_padded
+                    Mp = pad(self.G).shape[0]
+                    gl["wgrad"] = WgradGroup([
+                        (pad(self.Gd), pad(lb.h), mg(pre + "feed_forward.output_dense.weight"),
+                         mg(pre + "feed_forward.output_dense.bias")),
+                        (pad(self.DH), pad(lb.x1), mg(pre + "feed_forward.intermediate_dense.weight"),
+                         mg(pre + "feed_forward.intermediate_dense.bias")),
+                        (pad(self.Gd1), pad(lb.ctx), mg(pre + "attention.out_proj.weight"),
+                         mg(pre + "attention.out_proj.bias")),
+                        (pad(self.DQKV), pad(xin), st.qkv(l, "g"), st.qkv(l, "g", "bias"))], M, Mp)
                 gl["dW2"] = Gemm(H, I, M, self.Gd, lb.h, mg(pre + "feed_forward.output_dense.weight"), lda=H, ldb=I,
                                  ldc=I, transA=True, transB=True, split_k=sk(H, I), accumulate=True)
-                gl["dh"] = Gemm(M, I, H, self.Gd, W2, self.DH, lda=H, ldb=I, ldc=I, transB=True,
+                gl["dh"] = Gemm(M, I, H, self.Gd, W2, self.DH, lda=H, ldb=I if tb else H, ldc=I, transB=tb,
                                 epilogue=EPI_GELU_BWD, aux=lb.hpre, ldaux=I)
                 gl["dW1"] = Gemm(I, H, M, self.DH, lb.x1, mg(pre + "feed_forward.intermediate_dense.weight"), lda=I,
                                  ldb=H, ldc=H, transA=True, transB=True, split_k=sk(I, H), accumulate=True)
-                gl["dx1"] = Gemm(M, H, I, self.DH, W1, self.G, lda=I, ldb=H, ldc=H, transB=True, epilogue=EPI_ADD,
-                                 aux=self.G, ldaux=H)
-                gl["dWo"] = Gemm(H, H, M, self.Gd, lb.ctx, mg(pre + "attention.out_proj.weight"), lda=H, ldb=H, ldc=H,
+                gl["dx1"] = Gemm(M, H, I, self.DH, W1, self.G, lda=I, ldb=H if tb else I, ldc=H, transB=tb,
+                                 epilogue=EPI_ADD, aux=self.G, ldaux=H)
+                gl["dWo"] = Gemm(H, H, M, self.Gd1, lb.ctx, mg(pre + "attention.out_proj.weight"), lda=H, ldb=H, ldc=H,
                                  transA=True, transB=True, split_k=sk(H, H), accumulate=True)
-                gl["dctx"] = Gemm(M, H, H, self.Gd, Wo, self.DC, lda=H, ldb=H, ldc=H, transB=True)
+                gl["dctx"] = Gemm(M, H, H, self.Gd1, Wo, self.DC, lda=H, ldb=H, ldc=H, transB=tb)
                 if not self.fused:
                     qkv = lb.qkv.view(-1)
                     dq = self.DQKV.view(-1)
@@ -243,8 +275,8 @@ class Plan:
                                     b_strides=(T * H, d), c_strides=hs)
                 gl["dWqkv"] = Gemm(3 * H, H, M, self.DQKV, xin, st.qkv(l, "g"), lda=3 * H, ldb=H, ldc=H, transA=True,
                                    transB=True, split_k=sk(3 * H, H), accumulate=True)
-                gl["dx"] = Gemm(M, H, 3 * H, self.DQKV, st.qkv(l, "w"), self.G, lda=3 * H, ldb=H, ldc=H, transB=True,
-                                epilogue=EPI_ADD, aux=self.G, ldaux=H)
+                gl["dx"] = Gemm(M, H, 3 * H, self.DQKV, Wqkv, self.G, lda=3 * H, ldb=H if tb else 3 * H, ldc=H,
+                                transB=tb, epilogue=EPI_ADD, aux=self.G, ldaux=H)
             self.g_layer.append(gl)
         if self.train:
             mg = st.mg
@@ -257,11 +289,20 @@ class Plan:
                                  b_strides=(0, Cg * K * Cg), c_strides=(0, Cg), epilogue=EPI_ADD, aux=self.G, ldaux=H,
                                  aux_strides=(0, Cg))
             g0 = self.G0 if self.cls else self.G
-            self.g_proj_dw = Gemm(H, C[-1], self.M0, g0, self.ln_feat, mg("feature_projection.projection.weight"),
-                                  lda=H, ldb=C[-1], ldc=C[-1], transA=True, transB=True,
-                                  split_k=_splitk(_tiles(H), _tiles(C[-1]), self.M0), accumulate=True)
-            self.g_proj_dn = Gemm(self.M0, C[-1], H, g0, mw("feature_projection.projection.weight"), self.dn, lda=H,
-                                  ldb=C[-1], ldc=C[-1], transB=True)
+            if st.flat_lp_t is not None:
+                self.g_proj_dw = WgradGroup([(g0._w2v2_padded, self.ln_feat._w2v2_padded,
+                                              mg("feature_projection.projection.weight"),
+                                              mg("feature_projection.projection.bias"))], self.M0,
+                                            g0._w2v2_padded.shape[0])
+            else:
+                self.g_proj_dw = Gemm(H, C[-1], self.M0, g0, self.ln_feat, mg("feature_projection.projection.weight"),
+                                      lda=H, ldb=C[-1], ldc=C[-1], transA=True, transB=True,
+                                      split_k=_splitk(_tiles(H), _tiles(C[-1]), self.M0), accumulate=True)
+            tbp = st.flat_lp_t is None
+            Wp = (mw("feature_projection.projection.weight") if tbp
+                  else st.wt("wav2vec.model.feature_projection.projection.weight"))
+            self.g_proj_dn = Gemm(self.M0, C[-1], H, g0, Wp, self.dn, lda=H, ldb=C[-1] if tbp else H, ldc=C[-1],
+                                  transB=tbp)
         if st.head is not None:
             E, Cn = self.embed_dim, st.num_speakers
             if st.head == "aam":
@@ -435,26 +476,29 @@ class Plan:
                 continue
             lb, gl = self.lb[l], self.g_layer[l]
             pre = f"encoder.layers.{l}."
-            gd = self.Gd if ph > 0 else self.G
-            # x2 = LN2(x1 + drop(f))
-            ops.layernorm_bwd(self.G, lb.f, lb.mean2, lb.rstd2, mp(pre + "final_layer_norm.weight"), self.G,
-                              self.Gd if ph > 0 else None, mg(pre + "final_layer_norm.weight"),
-                              mg(pre + "final_layer_norm.bias"), ph, self._sd("ffn", l, step))
-            self._run_with_A(gl["dW2"], gd)
-            ops.colsum(gd, mg(pre + "feed_forward.output_dense.bias"), M, H)
-            self._run_with_A(gl["dh"], gd)                      # DH = (gd @ W2) * gelu'(hpre)
+            grouped = self.grouped
+            # x2 = LN2(x1 + drop(f)):  G <- ds2 (residual path), Gd <- df = ds2 * dropmask
+            ops.layernorm_bwd(self.G, lb.f, lb.mean2, lb.rstd2, mp(pre + "final_layer_norm.weight"), self.G, self.Gd,
+                              mg(pre + "final_layer_norm.weight"), mg(pre + "final_layer_norm.bias"), ph,
+                              self._sd("ffn", l, step))
+            if not grouped:
+                gl["dW2"]()
+                ops.colsum(self.Gd, mg(pre + "feed_forward.output_dense.bias"), M, H)
+            gl["dh"]()                                          # DH = (df @ W2) * gelu'(hpre)
             if reg.activation_dropout > 0:
                 raise NotImplementedError("activation_dropout > 0 (reference default is 0.0)")
-            gl["dW1"]()
-            ops.colsum(self.DH, mg(pre + "feed_forward.intermediate_dense.bias"), M, cfg.intermediate_size)
+            if not grouped:
+                gl["dW1"]()
+                ops.colsum(self.DH, mg(pre + "feed_forward.intermediate_dense.bias"), M, cfg.intermediate_size)
             gl["dx1"]()                                         # G = DH @ W1 + G
-            # x1 = LN1(x + drop(a))
-            ops.layernorm_bwd(self.G, lb.a, lb.mean1, lb.rstd1, mp(pre + "layer_norm.weight"), self.G,
-                              self.Gd if ph > 0 else None, mg(pre + "layer_norm.weight"), mg(pre + "layer_norm.bias"),
-                              ph, self._sd("post_attn", l, step))
-            self._run_with_A(gl["dWo"], gd)
-            ops.colsum(gd, mg(pre + "attention.out_proj.bias"), M, H)
-            self._run_with_A(gl["dctx"], gd)
+            # x1 = LN1(x + drop(a)):  G <- ds1, Gd1 <- da
+            ops.layernorm_bwd(self.G, lb.a, lb.mean1, lb.rstd1, mp(pre + "layer_norm.weight"), self.G, self.Gd1,
+                              mg(pre + "layer_norm.weight"), mg(pre + "layer_norm.bias"), ph,
+                              self._sd("post_attn", l, step))
+            if not grouped:
+                gl["dWo"]()
+                ops.colsum(self.Gd1, mg(pre + "attention.out_proj.bias"), M, H)
+            gl["dctx"]()
             if self.fused:
                 ops.attention_bwd(lb.qkv, lb.ctx, self.DC, lb.lse, self.DQKV, self.delta, B, T, heads, d, d ** -0.5,
                                   pa, self._sd("attn", l, step))
@@ -464,8 +508,11 @@ class Plan:
                 gl["dq"]()
                 gl["dk"]()
                 gl["dv"]()
-            gl["dWqkv"]()
-            ops.colsum(self.DQKV, st.qkv(l, "g", "bias"), M, 3 * H)
+            if grouped:
+                gl["wgrad"]()       # dW2,db2 | dW1,db1 | dWo,dbo | dWqkv,dbqkv in one atomic-free launch
+            else:
+                gl["dWqkv"]()
+                ops.colsum(self.DQKV, st.qkv(l, "g", "bias"), M, 3 * H)
             gl["dx"]()                                          # G = DQKV @ Wqkv + G
             notify(f"layer{l}")
         # encoder prologue: x0 = drop(LN(hx + pos)), pos = GELU(posconv(hx) + b)
@@ -493,7 +540,8 @@ class Plan:
         if reg.feat_proj_dropout > 0:
             ops.dropout_(g0, reg.feat_proj_dropout, self._sd("featproj", 0, step))
         self.g_proj_dw()
-        ops.colsum(g0, mg("feature_projection.projection.bias"), self.M0, H)
+        if st.flat_lp_t is None:
+            ops.colsum(g0, mg("feature_projection.projection.bias"), self.M0, H)
         self.g_proj_dn()
         if not st.freeze_cnn:
             raise NotImplementedError("CNN feature-extractor backward (completely_freeze_feature_extractor=False)")
@@ -502,9 +550,3 @@ class Plan:
                           mg("feature_projection.layer_norm.weight"), mg("feature_projection.layer_norm.bias"))
         notify("prologue")
 
-    @staticmethod
-    def _run_with_A(g: Gemm, a: torch.Tensor) -> None:
-        """The post-dropout gradient lives in Gd when hidden_dropout > 0 and in G otherwise; the
-        descriptor was built for Gd, so patch the A pointer (one int store) before launching."""
-        g.desc.A.ptr = a.data_ptr()
-        g()

@@ -125,6 +125,37 @@ def gemm(*args, **kw) -> None:
     Gemm(*args, **kw)()
 
 
+class WgradGroup:
+    """Prebuilt grouped weight-gradient launch: problems = [(dY, X, dW, dbias or None), ...] with
+    dY [Tpad, n_out] / X [Tpad, n_in] bf16 (rows >= tokens zero) and dW [n_out, n_in] f32."""
+
+    def __init__(self, problems, tokens: int, tokens_padded: int):
+        n = len(problems)
+        arr = (_lib.WgradProblem * n)()
+        keep = []
+        self.flops = 0.0
+        for i, (dY, X, dW, db) in enumerate(problems):
+            _dev(dY, X, dW, db)
+            assert dY.dtype == torch.bfloat16 and X.dtype == torch.bfloat16 and dW.dtype == torch.float32
+            assert dY.shape[0] >= tokens_padded and X.shape[0] >= tokens_padded
+            q = arr[i]
+            q.dY, q.ld_dy = dY.data_ptr(), dY.stride(0)
+            q.X, q.ld_x = X.data_ptr(), X.stride(0)
+            q.dW, q.ld_dw = dW.data_ptr(), dW.stride(0)
+            q.dbias = _p(db)
+            q.n_out, q.n_in = dW.shape
+            keep.append((dY, X, dW, db))
+            self.flops += 2.0 * tokens * dW.shape[0] * dW.shape[1]
+        self._arr, self._keep, self._n = arr, keep, n
+        self._tokens, self._tpad = tokens, tokens_padded
+        self._fn = lib().w2v2_wgrad_grouped
+
+    def __call__(self) -> None:
+        rc = self._fn(self._arr, self._n, self._tokens, self._tpad, stream())
+        if rc:
+            _lib.check(rc, "wgrad_grouped")
+
+
 # ------------------------------------------------------------------------------------------------ conv0
 def conv0_workspace(B: int, N: int, C: int, k: int, stride: int, device) -> torch.Tensor:
     """f32 scratch for conv0_groupnorm_gelu: per-chunk partial sums + {mean, rstd}."""
@@ -198,6 +229,12 @@ def colsum(x: torch.Tensor, out: torch.Tensor, M: int, N: int, ld: Optional[int]
 def cast(x: torch.Tensor, y: torch.Tensor) -> None:
     _dev(x, y)
     _lib.check(lib().w2v2_cast(x.data_ptr(), y.data_ptr(), x.numel(), dt(y), stream()), "cast")
+
+
+def transpose_many(src, dst, table, n: int, blocks_per_matrix: int = 64) -> None:
+    _dev(src, dst, table)
+    _lib.check(lib().w2v2_transpose_many(src.data_ptr(), dst.data_ptr(), table.data_ptr(), n, blocks_per_matrix,
+                                         dt(src), stream()), "transpose_many")
 
 
 def mask_fill(h, mask_u8, embed) -> None:

@@ -106,6 +106,25 @@ class ParamStore:
         self.exp_avg_sq: Optional[torch.Tensor] = None
         self.flat_lp = (torch.zeros(self.n_total, dtype=torch.bfloat16, device=dev)
                         if act_dtype == torch.bfloat16 else None)
+        # pre-transposed bf16 copies of the 2-D weights whose data-gradient product dX = dY W is on the
+        # training path (refreshed by one batched-transpose launch after every optimiser step)
+        self.flat_lp_t = None
+        self._t_table = None
+        if self.flat_lp is not None:
+            ent = []
+            H = cfg.hidden_size
+            for l in range(cfg.num_hidden_layers):
+                pre = W2V_PREFIX + f"encoder.layers.{l}."
+                o = self.offsets[pre + "attention.q_proj.weight"]
+                ent.append((o, o, 3 * H, H))                     # fused QKV [3H,H] -> [H,3H]
+                for n in ("attention.out_proj.weight", "feed_forward.intermediate_dense.weight",
+                          "feed_forward.output_dense.weight"):
+                    r, c = shapes[pre + n]
+                    ent.append((self.offsets[pre + n], self.offsets[pre + n], r, c))
+            n = W2V_PREFIX + "feature_projection.projection.weight"
+            ent.append((self.offsets[n], self.offsets[n], shapes[n][0], shapes[n][1]))
+            self.flat_lp_t = torch.zeros(self.n_total, dtype=torch.bfloat16, device=dev)
+            self._t_table = torch.tensor(ent, dtype=torch.int64, device=dev)
         self.version = 0          # bumped whenever weights change (derived packs are re-made lazily)
         self.cnn_version = 0      # bumped whenever the CNN weights change
         self.step_count = 0
@@ -129,6 +148,21 @@ class ParamStore:
     def w(self, name: str) -> torch.Tensor:
         """GEMM-operand view in the activation dtype."""
         return self._view(self.flat_lp if self.flat_lp is not None else self.flat, name)
+
+    def wt(self, name: str) -> torch.Tensor:
+        """Pre-transposed bf16 operand view [in, out] of a 2-D weight [out, in] (bf16 mode only)."""
+        r, c = self.shapes[name]
+        o = self.offsets[name]
+        return self.flat_lp_t[o:o + r * c].view(c, r)
+
+    def qkv_t(self, layer: int) -> torch.Tensor:
+        H = self.cfg.hidden_size
+        o = self.offsets[W2V_PREFIX + f"encoder.layers.{layer}.attention.q_proj.weight"]
+        return self.flat_lp_t[o:o + 3 * H * H].view(H, 3 * H)
+
+    def sync_transposed(self) -> None:
+        if self.flat_lp_t is not None:
+            ops.transpose_many(self.flat_lp, self.flat_lp_t, self._t_table, self._t_table.shape[0])
 
     def is_trainable(self, name: str) -> bool:
         return self.offsets[name] < self.n_train
@@ -235,6 +269,7 @@ class ParamStore:
     def sync_lowp(self) -> None:
         if self.flat_lp is not None:
             ops.cast(self.flat, self.flat_lp)
+            self.sync_transposed()
         self.version += 1
         self.cnn_version += 1
 
@@ -250,6 +285,7 @@ class ParamStore:
         self.step_count += 1
         ops.adam_step(self.flat, self.grad, self.exp_avg, self.exp_avg_sq, self.flat_lp, self.n_train, lr, beta1,
                       beta2, eps, self.step_count, grad_scale)
+        self.sync_transposed()
         self.version += 1
         if not self.freeze_cnn:
             self.cnn_version += 1
