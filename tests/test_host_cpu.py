@@ -122,3 +122,26 @@ def test_bucketed_allreduce_two_ranks_gloo():
     for p in procs:
         p.join(timeout=60)
     assert all(ok and same for _, ok, same in res), res
+
+
+def test_eval_metrics_and_evaluator_match_reference_golden():
+    from w2v2_speaker_amd.eval_metrics import calculate_eer, calculate_mdc
+    from w2v2_speaker_amd.evaluation.speaker.cosine_distance import (CosineDistanceEvaluator, EmbeddingSample,
+                                                                     EvaluationPair, compute_cosine_scores)
+    g = np.load(os.path.join(GOLDEN, "g6_eval.npz"))
+    eer, thr = calculate_eer(g["gt"].tolist(), g["scores"].tolist())
+    assert abs(eer - float(g["eer"])) < 1e-12 and abs(thr - float(g["eer_thr"])) < 1e-12
+    mdc, mthr = calculate_mdc(g["gt"].tolist(), g["scores"].tolist())
+    assert abs(mdc - float(g["mdc"])) < 1e-12 and abs(mthr - float(g["mdc_thr"])) < 1e-12
+    a, b = torch.from_numpy(g["cos_a"]), torch.from_numpy(g["cos_b"])
+    assert np.allclose(compute_cosine_scores(a, b), g["cos"], atol=1e-6)
+    # evaluator end to end: (s+1)/2 clip, EER/minDCF of the same trials
+    samples = [EmbeddingSample(f"a{i}", a[i]) for i in range(50)] + [EmbeddingSample(f"b{i}", b[i]) for i in range(50)]
+    pairs = [EvaluationPair(bool(i % 2), f"a{i}", f"b{i}") for i in range(50)]
+    res = CosineDistanceEvaluator(False, False, 0).evaluate(pairs, samples)
+    ref_eer, _ = calculate_eer([i % 2 for i in range(50)], g["cos01"].tolist())
+    assert abs(res["eer"] - ref_eer) < 1e-9
+    with pytest.raises(ValueError):
+        calculate_eer([0, 2], [0.1, 0.2])
+    missing = CosineDistanceEvaluator().evaluate([EvaluationPair(True, "zz", "a0")], samples)
+    assert missing["eer"] == -1

@@ -140,22 +140,19 @@ class Plan:
         E = self.embed_dim
         self.emb = self._e(B, E, dtype=f32)
         st = self.store
+        self.head = None
         if st.head is not None:
-            Cn = st.num_speakers
-            self.ldc = (Cn + 7) // 8 * 8
-            self.emb_lp = self._e(B, E) if self.adt != f32 else self.emb
-            self.logits = torch.zeros(B, self.ldc, dtype=f32, device=self.dev)
-            self.softmax = torch.zeros(B, self.ldc, dtype=f32, device=self.dev)
-            self.loss_rows = self._e(B, dtype=f32)
-            self.inv_x, self.inv_w = self._e(B, dtype=f32), self._e(Cn, dtype=f32)
-            if self.train:
-                self.dcos_w = torch.zeros(B, self.ldc, dtype=self.adt, device=self.dev)
-                self.dcos_x = torch.zeros(B, self.ldc, dtype=self.adt, device=self.dev) if st.head == "aam" else self.dcos_w
-                self.rowdot, self.coldot = self._e(B, dtype=f32), self._e(Cn, dtype=f32)
-                self.G1 = self._e(B, E, dtype=f32)
-                self.H1 = self._e(Cn, E, dtype=f32) if st.head == "aam" else None
+            from .heads import ClassifierHead
+            aam = st.head == "aam"
+            wname = "loss_fn.fc_weights" if aam else "fc_list.0.0.weight"
+            self.head = ClassifierHead(st.head, B, E, st.num_speakers, w_master=st.p(wname), w_operand=st.w(wname),
+                                       w_grad=st.g(wname) if self.train else None,
+                                       bias=None if aam else st.p("fc_list.0.0.bias"),
+                                       bias_grad=None if (aam or not self.train) else st.g("fc_list.0.0.bias"),
+                                       emb=self.emb, act_dtype=self.adt, train=self.train, margin=self.margin,
+                                       scale=self.scale)
         if self.train:
-            self.demb = self._e(B, E, dtype=f32)
+            self.demb = self.head.demb if self.head is not None else self._e(B, E, dtype=f32)
             self.G = self._ep(M, H)           # running activation gradient
             self.Gd = self._ep(M, H)          # ... after the dropout mask of the FFN residual branch (df)
             self.Gd1 = self._ep(M, H)         # ... of the attention residual branch (da)
@@ -303,21 +300,6 @@ class Plan:
                   else st.wt("wav2vec.model.feature_projection.projection.weight"))
             self.g_proj_dn = Gemm(self.M0, C[-1], H, g0, Wp, self.dn, lda=H, ldb=C[-1] if tbp else H, ldc=C[-1],
                                   transB=tbp)
-        if st.head is not None:
-            E, Cn = self.embed_dim, st.num_speakers
-            if st.head == "aam":
-                W = st.w("loss_fn.fc_weights")
-                self.g_head = Gemm(B, Cn, E, self.emb_lp, W, self.logits, lda=E, ldb=E, ldc=self.ldc,
-                                   epilogue=EPI_SCALE_RC, row_scale=self.inv_x, col_scale=self.inv_w)
-            else:
-                W = st.w("fc_list.0.0.weight")
-                self.g_head = Gemm(B, Cn, E, self.emb_lp, W, self.logits, lda=E, ldb=E, ldc=self.ldc,
-                                   epilogue=EPI_BIAS, bias=st.p("fc_list.0.0.bias"))
-            if self.train:
-                self.g_head_dx = Gemm(B, E, Cn, self.dcos_w, W, self.G1, lda=self.ldc, ldb=E, ldc=E, transB=True)
-                tgt = self.H1 if st.head == "aam" else st.g("fc_list.0.0.weight")
-                self.g_head_dw = Gemm(Cn, E, B, self.dcos_x, self.emb_lp, tgt, lda=self.ldc, ldb=E, ldc=E,
-                                      transA=True, transB=True, accumulate=(st.head == "ce"))
 
     # ------------------------------------------------------------------------------------------ derived weights
     def _refresh_packs(self) -> None:
@@ -417,44 +399,14 @@ class Plan:
 
     # ------------------------------------------------------------------------------------------ head
     def head_forward_backward(self, label: torch.Tensor):
-        """Loss head on self.emb: AAM-softmax (ref: aam_softmax.py:50-74) or Linear+CE
-        (ref: wav2vec2_fc.py:199-210, cross_entropy.py:27-31).  Returns (loss scalar tensor, softmax [B,C]);
-        when the plan is a training plan also leaves d(loss)/d(emb) in self.demb and the head gradients in
-        the flat gradient buffer."""
-        st, B, E, Cn = self.store, self.B, self.embed_dim, self.store.num_speakers
-        assert label.dtype == torch.int64 and label.is_cuda and label.shape == (B,)
-        if self.emb_lp is not self.emb:
-            ops.cast(self.emb, self.emb_lp)
-        aam = st.head == "aam"
-        if aam:
-            ops.row_invnorm(self.emb, self.inv_x, B, E)
-            ops.row_invnorm(st.p("loss_fn.fc_weights"), self.inv_w, Cn, E)
-        self.g_head()
-        tr = self.train
-        if tr and aam:
-            self.coldot.zero_()
-        ops.aam_softmax_fwd_bwd(self.logits, label, self.softmax, self.loss_rows,
-                                self.dcos_w if tr else None, (self.dcos_x if aam else None) if tr else None,
-                                self.inv_x if aam else None, self.inv_w if aam else None,
-                                self.rowdot if (tr and aam) else None, self.coldot if (tr and aam) else None,
-                                B, Cn, self.ldc, self.margin if aam else -1.0, self.scale)
-        loss = self.loss_rows.mean()
-        if tr:
-            self.g_head_dx()
-            if aam:
-                ops.normalize_bwd(self.G1, self.emb, self.inv_x, self.rowdot, self.demb, B, E)
-                self.g_head_dw()
-                ops.normalize_bwd(self.H1, st.p("loss_fn.fc_weights"), self.inv_w, self.coldot,
-                                  st.g("loss_fn.fc_weights"), Cn, E)
-            else:
-                self.demb.copy_(self.G1)
-                self.g_head_dw()
-                ops.colsum(self.dcos_w, st.g("fc_list.0.0.bias"), B, Cn, self.ldc)
-        return loss, self.softmax[:, :Cn]
+        """Loss head on self.emb (heads.ClassifierHead): returns (loss scalar tensor, softmax [B,C]); a
+        training plan also leaves d(loss)/d(emb) in self.demb and the head gradients in the flat buffer."""
+        return self.head.forward_backward(label)
 
     # ------------------------------------------------------------------------------------------ backward
     def backward(self, demb: Optional[torch.Tensor] = None,
-                 on_bucket_ready: Optional[Callable[[str], None]] = None) -> None:
+                 on_bucket_ready: Optional[Callable[[str], None]] = None,
+                 dhidden: Optional[torch.Tensor] = None) -> None:
         """Backward of embed(): demb [B,E] f32 (default self.demb from the head) -> parameter gradients
         accumulated into store.grad.  on_bucket_ready(name) fires as soon as a gradient bucket
         ('head', 'layer11', ..., 'layer0', 'prologue') is final, for the overlapped all-reduce."""
@@ -464,10 +416,13 @@ class Plan:
         mp, mg = st.mp, st.mg
         step = self._step
         notify = on_bucket_ready or (lambda name: None)
-        if demb is None:
-            demb = self.demb
         notify("head")
-        ops.pool_bwd(self.out, self.emb, demb, self.G.view(B, T, H), self.pool_mode)
+        if dhidden is not None:           # gradient wrt last_hidden_state given directly (module surface)
+            self.G.view(B, T, H).copy_(dhidden)
+        else:
+            if demb is None:
+                demb = self.demb
+            ops.pool_bwd(self.out, self.emb, demb, self.G.view(B, T, H), self.pool_mode)
         heads, d = cfg.num_attention_heads, cfg.head_dim
         pa, ph = reg.attention_dropout, reg.hidden_dropout
         for l in reversed(range(cfg.num_hidden_layers)):

@@ -1,0 +1,85 @@
+"""Speaker classification heads on the HIP kernels: AAM-softmax (ref: src/optim/loss/aam_softmax.py:21-74)
+and Linear + cross-entropy (ref: src/lightning_modules/speaker/wav2vec2_fc.py:199-210,
+src/optim/loss/cross_entropy.py:15-33).  One object = fixed buffers + prebuilt GEMM descriptors for a
+given (batch, embedding dim, classes); used by engine.Plan and by the nn.Module surface."""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import ops
+from .ops import EPI_BIAS, EPI_SCALE_RC, Gemm
+
+
+class ClassifierHead:
+    def __init__(self, kind: str, batch: int, embed_dim: int, classes: int, *, w_master: torch.Tensor,
+                 w_operand: torch.Tensor, w_grad: Optional[torch.Tensor], bias: Optional[torch.Tensor] = None,
+                 bias_grad: Optional[torch.Tensor] = None, emb: torch.Tensor, act_dtype: torch.dtype,
+                 train: bool, margin: float = 0.2, scale: float = 30.0):
+        assert kind in ("aam", "ce")
+        self.kind, self.B, self.E, self.C, self.train = kind, batch, embed_dim, classes, train
+        self.margin, self.scale = margin, scale
+        self.w_master, self.w_grad, self.bias, self.bias_grad, self.emb = w_master, w_grad, bias, bias_grad, emb
+        dev, f32 = emb.device, torch.float32
+        B, E, Cn = batch, embed_dim, classes
+        self.ldc = (Cn + 7) // 8 * 8
+        self.emb_lp = torch.empty(B, E, dtype=act_dtype, device=dev) if act_dtype != f32 else emb
+        self.logits = torch.zeros(B, self.ldc, dtype=f32, device=dev)
+        self.softmax = torch.zeros(B, self.ldc, dtype=f32, device=dev)
+        self.loss_rows = torch.empty(B, dtype=f32, device=dev)
+        aam = kind == "aam"
+        if aam:
+            self.inv_x, self.inv_w = torch.empty(B, dtype=f32, device=dev), torch.empty(Cn, dtype=f32, device=dev)
+            self.g_fwd = Gemm(B, Cn, E, self.emb_lp, w_operand, self.logits, lda=E, ldb=E, ldc=self.ldc,
+                              epilogue=EPI_SCALE_RC, row_scale=self.inv_x, col_scale=self.inv_w)
+        else:
+            self.g_fwd = Gemm(B, Cn, E, self.emb_lp, w_operand, self.logits, lda=E, ldb=E, ldc=self.ldc,
+                              epilogue=EPI_BIAS, bias=bias)
+        if train:
+            self.dcos_w = torch.zeros(B, self.ldc, dtype=act_dtype, device=dev)
+            self.dcos_x = torch.zeros(B, self.ldc, dtype=act_dtype, device=dev) if aam else self.dcos_w
+            self.rowdot = torch.empty(B, dtype=f32, device=dev)
+            self.coldot = torch.empty(Cn, dtype=f32, device=dev)
+            self.G1 = torch.empty(B, E, dtype=f32, device=dev)
+            self.demb = torch.empty(B, E, dtype=f32, device=dev)
+            self.g_dx = Gemm(B, E, Cn, self.dcos_w, w_operand, self.G1, lda=self.ldc, ldb=E, ldc=E, transB=True)
+            if aam:
+                self.H1 = torch.empty(Cn, E, dtype=f32, device=dev)
+                self.g_dw = Gemm(Cn, E, B, self.dcos_x, self.emb_lp, self.H1, lda=self.ldc, ldb=E, ldc=E,
+                                 transA=True, transB=True)
+            else:
+                self.g_dw = Gemm(Cn, E, B, self.dcos_x, self.emb_lp, w_grad, lda=self.ldc, ldb=E, ldc=E,
+                                 transA=True, transB=True, accumulate=True)
+
+    def forward_backward(self, label: torch.Tensor):
+        """(loss, softmax[B,C]); in training also d(loss)/d(emb) -> self.demb and the head gradients
+        (dW written for AAM, accumulated for CE; dbias accumulated) into the tensors given at build."""
+        B, E, Cn = self.B, self.E, self.C
+        assert label.dtype == torch.int64 and label.is_cuda and label.shape == (B,)
+        aam, tr = self.kind == "aam", self.train
+        if self.emb_lp is not self.emb:
+            ops.cast(self.emb, self.emb_lp)
+        if aam:
+            ops.row_invnorm(self.emb, self.inv_x, B, E)
+            ops.row_invnorm(self.w_master, self.inv_w, Cn, E)
+        self.g_fwd()
+        if tr and aam:
+            self.coldot.zero_()
+        ops.aam_softmax_fwd_bwd(self.logits, label, self.softmax, self.loss_rows,
+                                self.dcos_w if tr else None, (self.dcos_x if aam else None) if tr else None,
+                                self.inv_x if aam else None, self.inv_w if aam else None,
+                                self.rowdot if (tr and aam) else None, self.coldot if (tr and aam) else None,
+                                B, Cn, self.ldc, self.margin if aam else -1.0, self.scale)
+        loss = self.loss_rows.mean()
+        if tr:
+            self.g_dx()
+            if aam:
+                ops.normalize_bwd(self.G1, self.emb, self.inv_x, self.rowdot, self.demb, B, E)
+                self.g_dw()
+                ops.normalize_bwd(self.H1, self.w_master, self.inv_w, self.coldot, self.w_grad, Cn, E)
+            else:
+                self.demb.copy_(self.G1)
+                self.g_dw()
+                ops.colsum(self.dcos_w, self.bias_grad, B, Cn, self.ldc)
+        return loss, self.softmax[:, :Cn]

@@ -1,0 +1,2 @@
+from .aam_softmax import AngularAdditiveMarginSoftMaxLoss  # noqa: F401
+from .cross_entropy import CrossEntropyLoss  # noqa: F401
