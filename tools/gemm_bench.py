@@ -40,7 +40,7 @@ for name, m, n, k, ta, tb, cdt, split in shapes:
         g()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    reps = 20
+    reps = int(os.environ.get('REPS', '20'))
     for _ in range(3):
         blocker()
     e0.record()

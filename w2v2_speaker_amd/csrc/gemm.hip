@@ -56,7 +56,9 @@ __device__ __forceinline__ int64_t outer_off(const OpDev& o, int64_t idx) {
   return idx * o.ld;
 }
 
-__device__ __forceinline__ int swz(int row) { return (row ^ (row >> 3)) & 7; }
+// depends on (row & 15) only: every 16-row MFMA fragment of a tile shares one per-lane swizzle, so the
+// fragment addresses of a wave differ by compile-time constants (ds_read offset immediates)
+__device__ __forceinline__ int swz(int row) { return (row & 7) ^ ((row >> 3) & 1); }
 
 // ------------------------------------------------------------------------------ epilogue (shared)
 template <typename TC>
@@ -131,21 +133,147 @@ __device__ __forceinline__ void epilogue_store4(const GemmArgs& g, TC* __restric
 
 // ------------------------------------------------------------------------------ coalesced tile epilogue
 // The MFMA accumulator layout gives each lane 4 consecutive columns of 16 different rows: storing
-// that directly issues 32-byte row fragments (measured: ~1.1 TB/s, 40 % of a K=768 GEMM's time).
-// Instead the tile goes through LDS (the operand tiles are dead by now): the two row-halves of the
-// block tile are written as f32 [64][BN+4], then all 256 threads read back whole rows, apply the
-// epilogue on 8 consecutive columns and issue 16-byte stores, 16 lanes per 256-B row segment.
-template <typename TC, int FM, int FN, int EPI, bool ATOMIC>
-__device__ __forceinline__ void tile_epilogue_impl(const GemmArgs& g, f32x4 (&acc)[FM][FN],
-                                                   float* __restrict__ stage, int m0, int n0, int wm, int wn, int z0,
-                                                   int z1, int split) {
+// that directly issues 32-byte row fragments.  Instead the tile goes through LDS (the operand tiles
+// are dead by now): row-halves of the block tile are written as f32 [rows][BN+4], then all threads
+// read back whole rows, apply the epilogue on 8 consecutive columns and issue 16-byte stores,
+// 16 lanes per 256-B row segment.
+// Epilogue of 8 consecutive columns of one row.  Per-column operands (bias / column scale) are loaded
+// ONCE per thread (a thread keeps the same 8 columns for every row it stores) and the aux rows of a
+// whole pass are fetched up front with 16-byte loads, so no global-load latency sits between the LDS
+// read-back and the store.  The kind is wave-uniform: one scalar branch selects a specialised body.
+template <typename TC, int EPI>
+__device__ __forceinline__ void epilogue_row8_impl(const GemmArgs& g, TC* __restrict__ Cz, TC* __restrict__ auxz,
+                                                   int m, int n, float (&v)[8], const float (&cv)[8],
+                                                   const float (&ax)[8], bool lead) {
+  const bool full = n + 8 <= g.N;
+  float pre[8];
+  float rs = 1.0f;
+  if constexpr (EPI == W2V2_EPI_SCALE_RC) rs = g.row_scale[m];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    float x = v[e] * g.alpha;
+    if constexpr (EPI == W2V2_EPI_BIAS) { if (lead) x += cv[e]; }
+    if constexpr (EPI == W2V2_EPI_BIAS_GELU) { x += cv[e]; pre[e] = x; x = gelu_f(x); }
+    if constexpr (EPI == W2V2_EPI_GELU_BWD) x *= gelu_grad_f(ax[e]);
+    if constexpr (EPI == W2V2_EPI_ADD) x += ax[e];
+    if constexpr (EPI == W2V2_EPI_SCALE_RC) x *= rs * cv[e];
+    v[e] = x;
+  }
+  TC* cp = Cz + (int64_t)m * g.ldc + n;
+  if (g.atomic) {
+    if constexpr (sizeof(TC) == 4) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) if (n + e < g.N) unsafeAtomicAdd(reinterpret_cast<float*>(cp) + e, v[e]);
+    }
+  } else if (full && g.c_vec_ok) {
+    Vec8<TC> t;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) t.v[e] = v[e];
+    t.store(cp);
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) if (n + e < g.N) cp[e] = from_f32<TC>(v[e]);
+  }
+  if constexpr (EPI == W2V2_EPI_BIAS_GELU) {
+    if (auxz != nullptr) {
+      TC* ap = auxz + (int64_t)m * g.ldaux + n;
+      if (full && g.aux_vec_ok) {
+        Vec8<TC> t;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) t.v[e] = pre[e];
+        t.store(ap);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) if (n + e < g.N) ap[e] = from_f32<TC>(pre[e]);
+      }
+    }
+  }
+}
+
+// read back NIT row-chunks of the staged f32 tile (ROWS x BN, pitch BN+4) and store them
+template <typename TC, int EPI, int NIT, int NTHREADS, int BN>
+__device__ __forceinline__ void epilogue_pass(const GemmArgs& g, const float* __restrict__ stage,
+                                              TC* __restrict__ Cz, TC* __restrict__ auxz, int mbase, int n0,
+                                              const float (&cv)[8], bool lead) {
+  constexpr int PITCH = BN + 4, CPR = BN / 8;
+  const int tid = threadIdx.x;
+  const int ch = tid % CPR;                       // the same 8 columns for every iteration
+  const int n = n0 + ch * 8;
+  if (n >= g.N) return;
+  float ax[NIT][8];
+  if constexpr (EPI == W2V2_EPI_GELU_BWD || EPI == W2V2_EPI_ADD) {
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int r = (tid + NTHREADS * it) / CPR;
+      const int m = mbase + r;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) ax[it][e] = 0.f;
+      if (m < g.M) {
+        const TC* ap = auxz + (int64_t)m * g.ldaux + n;
+        if (n + 8 <= g.N && g.aux_vec_ok) {
+          Vec8<TC> t;
+          t.load(ap);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) ax[it][e] = t.v[e];
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) if (n + e < g.N) ax[it][e] = to_f32<TC>(ap[e]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int r = (tid + NTHREADS * it) / CPR;
+    const int m = mbase + r;
+    if (m >= g.M) continue;
+    const float4 lo = *reinterpret_cast<const float4*>(stage + r * PITCH + ch * 8);
+    const float4 hi = *reinterpret_cast<const float4*>(stage + r * PITCH + ch * 8 + 4);
+    float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    if constexpr (EPI == W2V2_EPI_GELU_BWD || EPI == W2V2_EPI_ADD)
+      epilogue_row8_impl<TC, EPI>(g, Cz, auxz, m, n, v, cv, ax[it], lead);
+    else
+      epilogue_row8_impl<TC, EPI>(g, Cz, auxz, m, n, v, cv, cv, lead);
+  }
+}
+
+// per-thread column operands: bias[n..n+7] or col_scale[n..n+7]
+__device__ __forceinline__ void load_col8(const GemmArgs& g, const float* __restrict__ bias, int n, float (&cv)[8]) {
+  const float* src = (g.epilogue == W2V2_EPI_SCALE_RC) ? g.col_scale : bias;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) cv[e] = 0.f;
+  if (src == nullptr || n >= g.N) return;
+  if (n + 8 <= g.N && ((reinterpret_cast<uintptr_t>(src + n) & 15) == 0)) {
+    const float4 a = *reinterpret_cast<const float4*>(src + n), b = *reinterpret_cast<const float4*>(src + n + 4);
+    cv[0] = a.x; cv[1] = a.y; cv[2] = a.z; cv[3] = a.w; cv[4] = b.x; cv[5] = b.y; cv[6] = b.z; cv[7] = b.w;
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) if (n + e < g.N) cv[e] = src[n + e];
+  }
+}
+
+#define W2V2_EPI_DISPATCH(CALL)                                              \
+  switch (g.epilogue) {                                                      \
+    case W2V2_EPI_BIAS: { constexpr int EPI = W2V2_EPI_BIAS; CALL; } break;  \
+    case W2V2_EPI_BIAS_GELU: { constexpr int EPI = W2V2_EPI_BIAS_GELU; CALL; } break; \
+    case W2V2_EPI_GELU_BWD: { constexpr int EPI = W2V2_EPI_GELU_BWD; CALL; } break;   \
+    case W2V2_EPI_ADD: { constexpr int EPI = W2V2_EPI_ADD; CALL; } break;    \
+    case W2V2_EPI_SCALE_RC: { constexpr int EPI = W2V2_EPI_SCALE_RC; CALL; } break;   \
+    default: { constexpr int EPI = W2V2_EPI_NONE; CALL; } break;             \
+  }
+
+// ------------------------------------------------------------------------------ coalesced tile epilogue (128-row tiles)
+template <typename TC, int FM, int FN>
+__device__ __forceinline__ void tile_epilogue(const GemmArgs& g, f32x4 (&acc)[FM][FN], float* __restrict__ stage,
+                                              int m0, int n0, int wm, int wn, int z0, int z1, int split) {
   constexpr int BN = 32 * FN, ROWS = 16 * FM, PITCH = BN + 4, CPR = BN / 8;
   const int tid = threadIdx.x, lane = tid & 63;
   const int frow = lane & 15, fk = lane >> 4;
   TC* Cz = reinterpret_cast<TC*>(g.C) + z0 * g.c_s0 + z1 * g.c_s1;
   TC* auxz = g.aux ? reinterpret_cast<TC*>(g.aux) + z0 * g.aux_s0 + z1 * g.aux_s1 : nullptr;
   const float* bias = g.bias ? g.bias + z1 * g.bias_s1 : nullptr;
-  const bool lead = split == 0;
+  float cv[8];
+  load_col8(g, bias, n0 + (tid % CPR) * 8, cv);
 #pragma unroll 1
   for (int pass = 0; pass < 2; ++pass) {
     __syncthreads();
@@ -158,117 +286,9 @@ __device__ __forceinline__ void tile_epilogue_impl(const GemmArgs& g, f32x4 (&ac
               make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
     }
     __syncthreads();
-#pragma unroll
-    for (int it = 0; it < (ROWS * CPR) / 256; ++it) {
-      const int c = tid + 256 * it;
-      const int r = c / CPR, ch = c - r * CPR;
-      const int m = m0 + pass * ROWS + r, n = n0 + ch * 8;
-      if (m >= g.M || n >= g.N) continue;
-      const float4 lo = *reinterpret_cast<const float4*>(stage + r * PITCH + ch * 8);
-      const float4 hi = *reinterpret_cast<const float4*>(stage + r * PITCH + ch * 8 + 4);
-      float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-      float pre[8];
-      const bool full = n + 8 <= g.N;
-      float ax[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-      if constexpr (EPI == W2V2_EPI_GELU_BWD || EPI == W2V2_EPI_ADD) {
-        const TC* ap = auxz + (int64_t)m * g.ldaux + n;
-        if (full && g.aux_vec_ok) {
-          Vec8<TC> t;
-          t.load(ap);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) ax[e] = t.v[e];
-        } else {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) if (n + e < g.N) ax[e] = to_f32<TC>(ap[e]);
-        }
-      }
-      float bs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-      if constexpr (EPI == W2V2_EPI_BIAS || EPI == W2V2_EPI_BIAS_GELU) {
-        if (EPI == W2V2_EPI_BIAS_GELU || lead) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) if (n + e < g.N) bs[e] = bias[n + e];
-        }
-      }
-      float cs[8] = {1, 1, 1, 1, 1, 1, 1, 1};
-      if constexpr (EPI == W2V2_EPI_SCALE_RC) {
-        const float rs = g.row_scale[m];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) if (n + e < g.N) cs[e] = rs * g.col_scale[n + e];
-      }
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        float x = v[e] * g.alpha;
-        if constexpr (EPI == W2V2_EPI_BIAS) x += bs[e];
-        if constexpr (EPI == W2V2_EPI_BIAS_GELU) { x += bs[e]; pre[e] = x; x = gelu_f(x); }
-        if constexpr (EPI == W2V2_EPI_GELU_BWD) x *= gelu_grad_f(ax[e]);
-        if constexpr (EPI == W2V2_EPI_ADD) x += ax[e];
-        if constexpr (EPI == W2V2_EPI_SCALE_RC) x *= cs[e];
-        v[e] = x;
-      }
-      TC* cp = Cz + (int64_t)m * g.ldc + n;
-      if constexpr (ATOMIC) {
-        if constexpr (sizeof(TC) == 4) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) if (n + e < g.N) unsafeAtomicAdd(reinterpret_cast<float*>(cp) + e, v[e]);
-        }
-      } else {
-        if (full && g.c_vec_ok) {
-          Vec8<TC> t;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) t.v[e] = v[e];
-          t.store(cp);
-        } else {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) if (n + e < g.N) cp[e] = from_f32<TC>(v[e]);
-        }
-      }
-      if constexpr (EPI == W2V2_EPI_BIAS_GELU) {
-        if (auxz != nullptr) {
-          TC* ap = auxz + (int64_t)m * g.ldaux + n;
-          if (full && g.aux_vec_ok) {
-            Vec8<TC> t;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) t.v[e] = pre[e];
-            t.store(ap);
-          } else {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) if (n + e < g.N) ap[e] = from_f32<TC>(pre[e]);
-          }
-        }
-      }
-    }
+    W2V2_EPI_DISPATCH((epilogue_pass<TC, EPI, (ROWS * CPR) / 256, 256, BN>(g, stage, Cz, auxz, m0 + pass * ROWS, n0, cv,
+                                                                        split == 0)));
   }
-}
-
-// the epilogue kind is wave-uniform: branch ONCE to a specialised body (a per-element switch gets
-// if-converted and evaluates erff/expf for every element of every GEMM)
-template <typename TC, int FM, int FN>
-__device__ __forceinline__ void tile_epilogue(const GemmArgs& g, f32x4 (&acc)[FM][FN], float* __restrict__ stage,
-                                              int m0, int n0, int wm, int wn, int z0, int z1, int split) {
-#define W2V2_EPI_CASE(E)                                                                              \
-  case E:                                                                                             \
-    tile_epilogue_impl<TC, FM, FN, E, false>(g, acc, stage, m0, n0, wm, wn, z0, z1, split);           \
-    break;
-  if (g.atomic) {
-    if constexpr (sizeof(TC) == 4) {
-      if (g.epilogue == W2V2_EPI_BIAS)
-        tile_epilogue_impl<TC, FM, FN, W2V2_EPI_BIAS, true>(g, acc, stage, m0, n0, wm, wn, z0, z1, split);
-      else
-        tile_epilogue_impl<TC, FM, FN, W2V2_EPI_NONE, true>(g, acc, stage, m0, n0, wm, wn, z0, z1, split);
-    }
-    return;
-  }
-  switch (g.epilogue) {
-    W2V2_EPI_CASE(W2V2_EPI_BIAS)
-    W2V2_EPI_CASE(W2V2_EPI_BIAS_GELU)
-    W2V2_EPI_CASE(W2V2_EPI_GELU_BWD)
-    W2V2_EPI_CASE(W2V2_EPI_ADD)
-    W2V2_EPI_CASE(W2V2_EPI_SCALE_RC)
-    default:
-      tile_epilogue_impl<TC, FM, FN, W2V2_EPI_NONE, false>(g, acc, stage, m0, n0, wm, wn, z0, z1, split);
-      break;
-  }
-#undef W2V2_EPI_CASE
 }
 
 // XCD-aware tile order: consecutive workgroup ids land on different XCDs (id % 8); remap so each
@@ -584,6 +604,162 @@ __global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(const GemmArgs g) {
   tile_epilogue<TC, FM, FN>(g, acc, reinterpret_cast<float*>(smem_raw), m0, n0, wm, wn, z0, z1, split);
 }
 
+// ------------------------------------------------------------------------------ 256x128x64, 3-stage LDS-DMA ring
+// The 128x128 kernel moves 32 KiB from L2 per 2.1 MFLOP (64 FLOP/B): at 2 workgroups per CU that is a
+// large fraction of the aggregate L2 bandwidth, and its 1-tile prefetch distance (vmcnt(0) before every
+// barrier) exposes the L2/HBM latency once per K tile.  This variant uses a 256x128 block tile (8 waves
+// as 4x2, 64x64 per wave, 87 FLOP/B) and a 3-stage LDS ring (144 KiB) with a COUNTED wait: while tile t
+// is multiplied, tiles t+1 and t+2 are in flight; per K tile one raw s_barrier and `s_waitcnt vmcnt(G)`
+// (G = this wave's DMA pieces per stage), never vmcnt(0) in the loop.
+template <int S> __device__ __forceinline__ void wait_vmcnt() {
+  if constexpr (S == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if constexpr (S == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else static_assert(S == 0 || S == 6, "unsupported count");
+}
+
+template <typename TC>
+__global__ __launch_bounds__(512) void gemm_bf16_glds3_kernel(const GemmArgs g) {
+  constexpr int BM = 256, BN = 128, FM = 4, FN = 4;
+  constexpr int STAGE = (BM + BN) * 64;           // elements per stage (A then B)
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // 0..7
+  const int wm = wave >> 1, wn = wave & 1;
+
+  const int ntile = g.tiles_m * g.tiles_n;
+  const int tile = xcd_remap(blockIdx.x, ntile);
+  const int tm = tile / g.tiles_n, tn = tile - tm * g.tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int z = blockIdx.z;
+  const int z0 = z / g.batch_inner, z1 = z - z0 * g.batch_inner;
+  const int nk = g.K >> 6;
+
+  const bf16_t* Ab = reinterpret_cast<const bf16_t*>(g.A.ptr) + z0 * g.a_s0 + z1 * g.a_s1;
+  const bf16_t* Bb = reinterpret_cast<const bf16_t*>(g.B.ptr) + z0 * g.b_s0 + z1 * g.b_s1;
+
+  const int c8 = lane & 7, r8 = lane >> 3;
+  const bf16_t* ap[4];
+  const bf16_t* bp[2];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int row = (wave * 4 + j) * 8 + r8;
+    const int grow = min(m0 + row, g.M - 1);
+    ap[j] = Ab + outer_off(g.A, grow) + ((c8 ^ swz(row)) << 3);
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int row = (wave * 2 + j) * 8 + r8;
+    const int grow = min(n0 + row, g.N - 1);
+    bp[j] = Bb + outer_off(g.B, grow) + ((c8 ^ swz(row)) << 3);
+  }
+
+  f32x4 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  auto stage = [&](bf16_t* base, int kt) {
+    bf16_t* ad = base + wave * 4 * 8 * 64;
+    bf16_t* bd = base + BM * 64 + wave * 2 * 8 * 64;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      __builtin_amdgcn_global_load_lds((gvoid_t*)(ap[j] + kt * 64), (lvoid_t*)(ad + j * 8 * 64), 16, 0, 0);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      __builtin_amdgcn_global_load_lds((gvoid_t*)(bp[j] + kt * 64), (lvoid_t*)(bd + j * 8 * 64), 16, 0, 0);
+  };
+  const int frow = lane & 15, fk = lane >> 4;
+  // per-lane fragment offsets (elements) for k-step 0 / 1; everything else is a compile-time constant
+  const int lo0 = frow * 64 + ((fk ^ swz(frow)) << 3);
+  const int lo1 = frow * 64 + (((4 + fk) ^ swz(frow)) << 3);
+  const int aoff = wm * 64 * 64, boff = BM * 64 + wn * 64 * 64;
+  auto compute = [&](const bf16_t* base) {
+    const bf16_t* a0 = base + aoff + lo0;
+    const bf16_t* a1 = base + aoff + lo1;
+    const bf16_t* b0 = base + boff + lo0;
+    const bf16_t* b1 = base + boff + lo1;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 af[FM], bfr[FN];
+#pragma unroll
+      for (int i = 0; i < FM; ++i) af[i] = *reinterpret_cast<const bf16x8*>((kk ? a1 : a0) + i * 16 * 64);
+#pragma unroll
+      for (int j = 0; j < FN; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>((kk ? b1 : b0) + j * 16 * 64);
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+    }
+  };
+  bf16_t* s0 = smem;
+  bf16_t* s1 = smem + STAGE;
+  bf16_t* s2 = smem + 2 * STAGE;
+
+  // one ring step: tile kt is in `cur`; tile kt+2 goes to `nxt` (which held tile kt-1)
+#define W2V2_RING_STEP(cur, nxt)                                   \
+  {                                                                \
+    if (kt + 1 < nk) wait_vmcnt<6>(); else wait_vmcnt<0>();        \
+    __builtin_amdgcn_s_barrier();                                  \
+    if (kt + 2 < nk) stage(nxt, kt + 2);                           \
+    compute(cur);                                                  \
+    ++kt;                                                          \
+  }
+  if (nk > 0) stage(s0, 0);
+  if (nk > 1) stage(s1, 1);
+  int kt = 0;
+  while (kt < nk) {
+    W2V2_RING_STEP(s0, s2)
+    if (kt >= nk) break;
+    W2V2_RING_STEP(s1, s0)
+    if (kt >= nk) break;
+    W2V2_RING_STEP(s2, s1)
+  }
+#undef W2V2_RING_STEP
+
+  // epilogue: two passes of 128 rows through LDS (all DMA has landed: the last wait was vmcnt(0))
+  float* stagef = reinterpret_cast<float*>(smem_raw);
+  constexpr int PITCH = BN + 4;
+  TC* Cz = reinterpret_cast<TC*>(g.C) + z0 * g.c_s0 + z1 * g.c_s1;
+  TC* auxz = g.aux ? reinterpret_cast<TC*>(g.aux) + z0 * g.aux_s0 + z1 * g.aux_s1 : nullptr;
+  const float* bias = g.bias ? g.bias + z1 * g.bias_s1 : nullptr;
+  float cv[8];
+  load_col8(g, bias, n0 + (tid & 15) * 8, cv);
+#pragma unroll 1
+  for (int pass = 0; pass < 2; ++pass) {
+    __syncthreads();
+    if ((wm >> 1) == pass) {
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+          *reinterpret_cast<float4*>(stagef + ((wm & 1) * 64 + i * 16 + frow) * PITCH + wn * 64 + j * 16 + fk * 4) =
+              make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+    }
+    __syncthreads();
+    W2V2_EPI_DISPATCH((epilogue_pass<TC, EPI, 4, 512, BN>(g, stagef, Cz, auxz, m0 + pass * 128, n0, cv, true)));
+  }
+}
+
+template <typename TC>
+static void launch_glds3(GemmArgs a, int M, int N, int batch, hipStream_t st) {
+  constexpr size_t lds = (size_t)3 * (256 + 128) * 64 * sizeof(bf16_t);   // 144 KiB
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_glds3_kernel<TC>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  a.tiles_m = (int)cdiv(M, 256);
+  a.tiles_n = (int)cdiv(N, 128);
+  dim3 grid(a.tiles_m * a.tiles_n, 1, batch);
+  hipLaunchKernelGGL((gemm_bf16_glds3_kernel<TC>), grid, dim3(512), lds, st, a);
+}
+
 template <int FM, int FN, typename TC>
 static void launch_glds(const GemmArgs& a, dim3 grid, hipStream_t st) {
   constexpr size_t lds = (size_t)2 * (32 * FM + 32 * FN) * 64 * sizeof(bf16_t);
@@ -663,7 +839,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
 }
 
 // ------------------------------------------------------------------------------ host dispatch
-static const bool g_w2v2_no_glds = getenv("W2V2_NO_GLDS") != nullptr;   // A/B switch for benchmarking
+static const bool g_w2v2_no_glds = getenv("W2V2_NO_GLDS") != nullptr;   // A/B switches for benchmarking
+static const bool g_w2v2_glds3 = getenv("W2V2_NO_GLDS3") == nullptr;
 
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
@@ -744,7 +921,13 @@ extern "C" int w2v2_gemm(const w2v2_gemm_desc* d, void* stream) {
     dim3 grid(a.tiles_m * a.tiles_n, split, d->batch);
     const bool glds = !a.A.trans && !a.B.trans && a.A.vec_ok && a.B.vec_ok && (d->K % 64 == 0) && d->K >= 64 &&
                       !g_w2v2_no_glds;
-    if (glds) {
+    // 256x128 3-stage kernel for the encoder shapes; the conv stack (N = 512, M ~ 3e5) measures
+    // slightly faster on the 128x128 kernel at 2 workgroups per CU
+    const bool big = glds && d->N >= 768 && split == 1 && !atomic && d->M >= 1024 && g_w2v2_glds3;
+    if (big) {
+      if (d->dtype_c == W2V2_F32) launch_glds3<float>(a, d->M, d->N, d->batch, st);
+      else launch_glds3<bf16_t>(a, d->M, d->N, d->batch, st);
+    } else if (glds) {
       if (d->dtype_c == W2V2_F32) {
         if (narrow) launch_glds<4, 2, float>(a, grid, st); else launch_glds<4, 4, float>(a, grid, st);
       } else {
