@@ -166,7 +166,9 @@ int w2v2_prepend_token(const void* x, void* y, float c, int B, int T, int H, int
  * regroup pads and splits channels  x [B,T,H] -> xg [B,G,T+K-1,H/G] (zero pad `pad_left` frames left).
  * weightnorm_pack: w = g*v/||v||_(per tap) -> fwd operand wf[G][co][tap][ci] and the flipped
  * operand wb[G][ci][K-1-tap][co] used by the data gradient; also returns inv norms.
- * weightnorm_bwd: from dwf[G][co][tap][ci] (f32) -> dg[K], dv[H][H/G][K] (written, not added).
+ * weightnorm_bwd: from the packed weight gradient dwf[G][tap][ci][co] (f32; = the GEMM
+ *   dwf_g[(tap,ci)][co] = sum_t xg_g[t][(tap,ci)] * dy_g[t][co], large dimension as M) -> dg[K],
+ *   dv[H][H/G][K] (written, not added).
  * `sumsq` / `dot` are f32 scratch of 129*K floats: [0,K) the per-tap result, the rest per-block
  * partials that are folded in a fixed order (bitwise reproducible packed weights). */
 int w2v2_posconv_regroup(const void* x, void* xg, int B, int T, int H, int G, int K, int pad_left,

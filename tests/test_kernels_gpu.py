@@ -349,10 +349,10 @@ def test_posconv_forward_backward(dtype):
     # backward
     P1 = torch.zeros(M, H, dtype=dtype, device=DEV)
     o.gelu_bwd(up.to(dtype).to(DEV).view(M, H), ypre, P1)
-    dwf = torch.zeros(G, Cg, K * Cg, device=DEV)
-    o.gemm(Cg, K * Cg, M, P1, xg, dwf, lda=H, ldb=Cg, ldc=K * Cg, transA=True, transB=True,
-           b_seg=(T, G * Tp * Cg), batch=G, batch_inner=G, a_strides=(0, Cg), b_strides=(0, Tp * Cg),
-           c_strides=(0, Cg * K * Cg))
+    dwf = torch.zeros(G, K * Cg, Cg, device=DEV)
+    o.gemm(K * Cg, Cg, M, xg, P1, dwf, lda=Cg, ldb=H, ldc=Cg, transA=True, transB=True,
+           a_seg=(T, G * Tp * Cg), batch=G, batch_inner=G, a_strides=(0, Tp * Cg), b_strides=(0, Cg),
+           c_strides=(0, K * Cg * Cg))
     dot, dg, dv = torch.zeros(129 * K, device=DEV), torch.zeros(K, device=DEV), torch.zeros(H, Cg, K, device=DEV)
     o.weightnorm_bwd(g.to(DEV), v.to(DEV), sumsq, dwf, dot, dg, dv, H, G, K)
     dyg = torch.zeros(B, G, Tp, Cg, dtype=dtype, device=DEV)

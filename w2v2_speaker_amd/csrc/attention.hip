@@ -18,13 +18,16 @@
 // Backward recomputes the scores in both kernels (7 matmul units instead of 5) in exchange for
 // no [B,h,T,T] tensor in HBM at all; attention is 3 % of the step's FLOPs.
 #include "common.cuh"
+#include <stdlib.h>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 constexpr int HD = 64;  // head dim
 
-__device__ __forceinline__ int aswz(int row) { return (row ^ (row >> 3)) & 7; }
+// 16-row periodic: all fragments of an image share one per-lane swizzle, so fragment addresses are
+// lane base + compile-time constant (ds_read offset immediates instead of one address VGPR each)
+__device__ __forceinline__ int aswz(int row) { return (row & 7) ^ ((row >> 3) & 1); }
 
 __device__ __forceinline__ bf16x8 as_frag(uint4 v) {
   union { uint4 u; bf16x8 f; } c;
@@ -79,8 +82,9 @@ __device__ __forceinline__ void lds_load_rows_t(bf16_t* ldst, const bf16_t* g, i
 }
 // MFMA fragment (16 rows x 32 k) from the swizzled row-major image
 __device__ __forceinline__ bf16x8 lds_frag(const bf16_t* lds, int row0, int kk, int lane) {
-  const int row = row0 + (lane & 15);
-  return as_frag(*reinterpret_cast<const uint4*>(lds + row * 64 + (((kk * 4 + (lane >> 4)) ^ aswz(row)) << 3)));
+  const int fr = lane & 15;                         // row0 is a multiple of 16: swizzle depends on fr only
+  const int lane_off = fr * 64 + (((kk * 4 + (lane >> 4)) ^ aswz(fr)) << 3);
+  return as_frag(*reinterpret_cast<const uint4*>(lds + lane_off + row0 * 64));
 }
 // MFMA fragment from the transposed image: row d0 + lane&15, k-slots of 32-column block `blk`
 __device__ __forceinline__ bf16x8 lds_frag_t(const bf16_t* ldst, int pitch, int d0, int blk, int lane) {
@@ -350,6 +354,305 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const bf16_t* __restri
   }
 }
 
+// ===================================================================================== v2: one workgroup per (b, h)
+// For T <= 160 (the 3 s training clips: T = 149 / 150) a single workgroup owns a whole (batch, head):
+// K/V/Q/dO are fetched ONCE, with all global loads of a thread issued before the first LDS store (the
+// v1 fill loops were a chain of dependent load->store round trips, ~18 us per workgroup), and both the
+// row-major and the transposed LDS images are produced from the same registers.  The backward is one
+// kernel: phase A (waves own query fragments) produces dQ and delta, phase B (waves own key fragments)
+// produces dK and dV from the same LDS images.
+template <int NF> struct BlkRegs {
+  static constexpr int NIT = (NF * 16 / 4 * 8 + 255) / 256;   // 4-row x 8-col micro-blocks per thread
+  uint4 v[NIT][4];
+};
+
+template <int NF>
+__device__ __forceinline__ void blk_load(BlkRegs<NF>& r, const bf16_t* g, int64_t gs, int n_valid) {
+  constexpr int NB = NF * 16 / 4 * 8;
+#pragma unroll
+  for (int it = 0; it < BlkRegs<NF>::NIT; ++it) {
+    const int blk = threadIdx.x + 256 * it;
+    const int cb = blk & 7, rb = blk >> 3;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = rb * 4 + i;
+      r.v[it][i] = make_uint4(0, 0, 0, 0);
+      if (blk < NB && row < n_valid) r.v[it][i] = *reinterpret_cast<const uint4*>(g + (int64_t)row * gs + cb * 8);
+    }
+  }
+}
+template <int NF>
+__device__ __forceinline__ void blk_store_rows(const BlkRegs<NF>& r, bf16_t* lds) {
+  constexpr int NB = NF * 16 / 4 * 8;
+#pragma unroll
+  for (int it = 0; it < BlkRegs<NF>::NIT; ++it) {
+    const int blk = threadIdx.x + 256 * it;
+    if (blk >= NB) continue;
+    const int cb = blk & 7, rb = blk >> 3;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = rb * 4 + i;
+      *reinterpret_cast<uint4*>(lds + row * 64 + ((cb ^ aswz(row)) << 3)) = r.v[it][i];
+    }
+  }
+}
+template <int NF>
+__device__ __forceinline__ void blk_store_t(const BlkRegs<NF>& r, bf16_t* ldst, int pitch) {
+  constexpr int NB = NF * 16 / 4 * 8;
+#pragma unroll
+  for (int it = 0; it < BlkRegs<NF>::NIT; ++it) {
+    const int blk = threadIdx.x + 256 * it;
+    if (blk >= NB) continue;
+    const int cb = blk & 7, rb = blk >> 3;
+    const uint32_t w[4][4] = {{r.v[it][0].x, r.v[it][0].y, r.v[it][0].z, r.v[it][0].w},
+                              {r.v[it][1].x, r.v[it][1].y, r.v[it][1].z, r.v[it][1].w},
+                              {r.v[it][2].x, r.v[it][2].y, r.v[it][2].z, r.v[it][2].w},
+                              {r.v[it][3].x, r.v[it][3].y, r.v[it][3].z, r.v[it][3].w}};
+#pragma unroll
+    for (int ci = 0; ci < 8; ++ci) {
+      const int d = ci >> 1;
+      uint2 o;
+      if (ci & 1) {
+        o.x = (w[0][d] >> 16) | (w[1][d] & 0xffff0000u);
+        o.y = (w[2][d] >> 16) | (w[3][d] & 0xffff0000u);
+      } else {
+        o.x = (w[0][d] & 0xffffu) | (w[1][d] << 16);
+        o.y = (w[2][d] & 0xffffu) | (w[3][d] << 16);
+      }
+      *reinterpret_cast<uint2*>(ldst + (cb * 8 + ci) * pitch + rb * 4) = o;
+    }
+  }
+}
+__device__ __forceinline__ void store_row4x4(bf16_t* dst, const f32x4 (&o)[4]) {
+#pragma unroll
+  for (int df = 0; df < 4; ++df) {
+    uint2 w;
+    w.x = (uint32_t)f32_to_bf16(o[df][0]) | ((uint32_t)f32_to_bf16(o[df][1]) << 16);
+    w.y = (uint32_t)f32_to_bf16(o[df][2]) | ((uint32_t)f32_to_bf16(o[df][3]) << 16);
+    *reinterpret_cast<uint2*>(dst + df * 16) = w;
+  }
+}
+
+template <int NF>
+__global__ __launch_bounds__(256) void attn_fwd2_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx,
+                                                        float* __restrict__ lse, int Tn, int heads, float scale,
+                                                        float dp, float inv_keep, uint64_t seed) {
+  constexpr int TP = NF * 16, PITCH = TP + 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16_t* Ks = reinterpret_cast<bf16_t*>(smem);   // [TP][64]
+  bf16_t* Qs = Ks + TP * 64;                      // [TP][64]
+  bf16_t* Vt = Qs + TP * 64;                      // [64][PITCH]
+  const int b = blockIdx.y, h = blockIdx.x;
+  const int H = heads * HD;
+  const int64_t gs = 3 * (int64_t)H;
+  const bf16_t* qb = qkv + (int64_t)b * Tn * gs + h * HD;
+  {
+    BlkRegs<NF> rq, rk, rv;
+    blk_load<NF>(rq, qb, gs, Tn);
+    blk_load<NF>(rk, qb + H, gs, Tn);
+    blk_load<NF>(rv, qb + 2 * H, gs, Tn);
+    blk_store_rows<NF>(rq, Qs);
+    blk_store_rows<NF>(rk, Ks);
+    blk_store_t<NF>(rv, Vt, PITCH);
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
+  const int64_t bh = (int64_t)b * heads + h;
+#pragma unroll 1
+  for (int qf = wave; qf < NF; qf += 4) {
+    asm volatile("" ::: "memory");   // keep the K / V^T fragment loads inside the loop (LICM would hoist 240 VGPRs)
+    const int q = qf * 16 + (lane & 15);
+    bf16x8 qfr[2] = {lds_frag(Qs, qf * 16, 0, lane), lds_frag(Qs, qf * 16, 1, lane)};
+    float s[NF][4];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int fj = 0; fj < NF; ++fj) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(Ks, fj * 16, kk, lane), qfr[kk], acc, 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int key = fj * 16 + g * 4 + j;
+        s[fj][j] = key < Tn ? acc[j] * scale : -INFINITY;
+        mx = fmaxf(mx, s[fj][j]);
+      }
+    }
+    mx = quad_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int fj = 0; fj < NF; ++fj)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { s[fj][j] = __expf(s[fj][j] - mx); sum += s[fj][j]; }
+    sum = quad_sum(sum);
+    const float inv = 1.0f / sum;
+    if (g == 0 && q < Tn) lse[bh * Tn + q] = mx + __logf(sum);
+#pragma unroll
+    for (int fj = 0; fj < NF; ++fj)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float pv = s[fj][j] * inv;
+        if (dp > 0.f) pv *= drop_scale(seed, (uint64_t)((bh * Tn + q) * Tn + fj * 16 + g * 4 + j), dp, inv_keep);
+        s[fj][j] = pv;
+      }
+    f32x4 o[4];
+#pragma unroll
+    for (int df = 0; df < 4; ++df) o[df] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < NF / 2; ++kb) {
+      const bf16x8 pf = pack_frag(s[2 * kb], s[2 * kb + 1]);
+#pragma unroll
+      for (int df = 0; df < 4; ++df)
+        o[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag_t(Vt, PITCH, df * 16, kb, lane), pf, o[df], 0, 0, 0);
+    }
+    if (q < Tn) store_row4x4(ctx + ((int64_t)b * Tn + q) * H + h * HD + g * 4, o);
+  }
+}
+
+template <int NF>
+__global__ __launch_bounds__(256) void attn_bwd2_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ ctx,
+                                                        const bf16_t* __restrict__ dctx,
+                                                        const float* __restrict__ lse, bf16_t* __restrict__ dqkv,
+                                                        int Tn, int heads, float scale, float dp, float inv_keep,
+                                                        uint64_t seed) {
+  constexpr int TP = NF * 16, PITCH = TP + 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16_t* Ks = reinterpret_cast<bf16_t*>(smem);   // row-major images [TP][64]
+  bf16_t* Vs = Ks + TP * 64;
+  bf16_t* Qs = Vs + TP * 64;
+  bf16_t* Os = Qs + TP * 64;                      // dO
+  bf16_t* Kt = Os + TP * 64;                      // transposed images [64][PITCH]
+  bf16_t* Qt = Kt + 64 * PITCH;
+  bf16_t* Ot = Qt + 64 * PITCH;                   // dO^T
+  float* lse_s = reinterpret_cast<float*>(Ot + 64 * PITCH);   // [TP]
+  float* del_s = lse_s + TP;                                  // [TP]
+  const int b = blockIdx.y, h = blockIdx.x;
+  const int H = heads * HD;
+  const int64_t gs = 3 * (int64_t)H;
+  const bf16_t* qb = qkv + (int64_t)b * Tn * gs + h * HD;
+  const bf16_t* dob = dctx + (int64_t)b * Tn * H + h * HD;
+  const bf16_t* ob = ctx + (int64_t)b * Tn * H + h * HD;
+  const int64_t bh = (int64_t)b * heads + h;
+  {   // two rounds of batched loads (64 staging VGPRs each) instead of one of 128
+    BlkRegs<NF> ra, rb;
+    blk_load<NF>(ra, qb, gs, Tn);
+    blk_load<NF>(rb, qb + H, gs, Tn);
+    blk_store_rows<NF>(ra, Qs);
+    blk_store_t<NF>(ra, Qt, PITCH);
+    blk_store_rows<NF>(rb, Ks);
+    blk_store_t<NF>(rb, Kt, PITCH);
+    blk_load<NF>(ra, qb + 2 * H, gs, Tn);
+    blk_load<NF>(rb, dob, H, Tn);
+    blk_store_rows<NF>(ra, Vs);
+    blk_store_rows<NF>(rb, Os);
+    blk_store_t<NF>(rb, Ot, PITCH);
+  }
+  for (int i = threadIdx.x; i < TP; i += 256) lse_s[i] = i < Tn ? lse[bh * Tn + i] : 0.f;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
+  __syncthreads();
+
+  // ---- phase A: waves own query fragments -> dQ, delta
+#pragma unroll 1
+  for (int qf = wave; qf < NF; qf += 4) {
+    asm volatile("" ::: "memory");   // no LICM of the loop-invariant LDS fragment loads
+    const int q = qf * 16 + (lane & 15);
+    bf16x8 qfr[2] = {lds_frag(Qs, qf * 16, 0, lane), lds_frag(Qs, qf * 16, 1, lane)};
+    bf16x8 dof[2] = {lds_frag(Os, qf * 16, 0, lane), lds_frag(Os, qf * 16, 1, lane)};
+    bf16x8 of[2];
+    reg_frag(of, ob, H, q, Tn, lane);
+    float dl = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dl += (float)dof[kk][e] * (float)of[kk][e];
+    dl = quad_sum(dl);
+    if (g == 0) del_s[q] = q < Tn ? dl : 0.f;
+    const float l = lse_s[q];
+    float ds[NF][4];
+#pragma unroll
+    for (int fj = 0; fj < NF; ++fj) {
+      f32x4 sa = {0.f, 0.f, 0.f, 0.f}, pa = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(Ks, fj * 16, kk, lane), qfr[kk], sa, 0, 0, 0);
+        pa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(Vs, fj * 16, kk, lane), dof[kk], pa, 0, 0, 0);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int key = fj * 16 + g * 4 + j;
+        const float p = (key < Tn && q < Tn) ? __expf(sa[j] * scale - l) : 0.f;
+        float dpv = pa[j];
+        if (dp > 0.f) dpv *= drop_scale(seed, (uint64_t)((bh * Tn + q) * Tn + key), dp, inv_keep);
+        ds[fj][j] = p * (dpv - dl) * scale;
+      }
+    }
+    f32x4 o[4];
+#pragma unroll
+    for (int df = 0; df < 4; ++df) o[df] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < NF / 2; ++kb) {
+      const bf16x8 pf = pack_frag(ds[2 * kb], ds[2 * kb + 1]);
+#pragma unroll
+      for (int df = 0; df < 4; ++df)
+        o[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag_t(Kt, PITCH, df * 16, kb, lane), pf, o[df], 0, 0, 0);
+    }
+    if (q < Tn) store_row4x4(dqkv + ((int64_t)b * Tn + q) * gs + h * HD + g * 4, o);
+  }
+  __syncthreads();          // delta complete
+
+  // ---- phase B: waves own key fragments -> dK, dV
+#pragma unroll 1
+  for (int kf = wave; kf < NF; kf += 4) {
+    asm volatile("" ::: "memory");
+    const int key = kf * 16 + (lane & 15);
+    bf16x8 kfr[2] = {lds_frag(Ks, kf * 16, 0, lane), lds_frag(Ks, kf * 16, 1, lane)};
+    bf16x8 vfr[2] = {lds_frag(Vs, kf * 16, 0, lane), lds_frag(Vs, kf * 16, 1, lane)};
+    float pt[NF][4], dst_[NF][4];
+#pragma unroll
+    for (int fq = 0; fq < NF; ++fq) {
+      f32x4 sa = {0.f, 0.f, 0.f, 0.f}, pa = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(Qs, fq * 16, kk, lane), kfr[kk], sa, 0, 0, 0);
+        pa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(Os, fq * 16, kk, lane), vfr[kk], pa, 0, 0, 0);
+      }
+      const float4 l4 = *reinterpret_cast<const float4*>(lse_s + fq * 16 + g * 4);
+      const float4 d4 = *reinterpret_cast<const float4*>(del_s + fq * 16 + g * 4);
+      const float la[4] = {l4.x, l4.y, l4.z, l4.w}, da[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int q = fq * 16 + g * 4 + j;
+        const float p = (q < Tn && key < Tn) ? __expf(sa[j] * scale - la[j]) : 0.f;
+        float ms = 1.0f;
+        if (dp > 0.f) ms = drop_scale(seed, (uint64_t)((bh * Tn + q) * Tn + key), dp, inv_keep);
+        pt[fq][j] = p * ms;
+        dst_[fq][j] = p * (pa[j] * ms - da[j]) * scale;
+      }
+    }
+    f32x4 dv[4], dk[4];
+#pragma unroll
+    for (int df = 0; df < 4; ++df) { dv[df] = f32x4{0.f, 0.f, 0.f, 0.f}; dk[df] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int qb2 = 0; qb2 < NF / 2; ++qb2) {
+      const bf16x8 pf = pack_frag(pt[2 * qb2], pt[2 * qb2 + 1]);
+      const bf16x8 sf = pack_frag(dst_[2 * qb2], dst_[2 * qb2 + 1]);
+#pragma unroll
+      for (int df = 0; df < 4; ++df) {
+        dv[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag_t(Ot, PITCH, df * 16, qb2, lane), pf, dv[df], 0, 0, 0);
+        dk[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag_t(Qt, PITCH, df * 16, qb2, lane), sf, dk[df], 0, 0, 0);
+      }
+    }
+    if (key < Tn) {
+      bf16_t* dstk = dqkv + ((int64_t)b * Tn + key) * gs + H + h * HD + g * 4;
+      store_row4x4(dstk, dk);
+      store_row4x4(dstk + H, dv);
+    }
+  }
+}
+
+template <int NF> static size_t fwd2_lds() { return (size_t)(2 * NF * 16 * 64 + 64 * (NF * 16 + 4)) * 2; }
+template <int NF> static size_t bwd2_lds() { return (size_t)(4 * NF * 16 * 64 + 3 * 64 * (NF * 16 + 4)) * 2 + 2 * NF * 16 * 4; }
+
 // ------------------------------------------------------------------------------------- host
 template <int NF> static size_t fwd_lds() { return (size_t)(NF * 16 * 64 + 64 * (NF * 16 + 4)) * 2; }
 template <int NF> static size_t dq_lds() { return (size_t)(2 * NF * 16 * 64 + 64 * (NF * 16 + 4)) * 2; }
@@ -367,6 +670,17 @@ static int attn_check(const char* nm, int B, int T, int heads, int d, int dtype,
   W2V2_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "%s: bad dropout p", nm);
   return 0;
 }
+
+static const bool g_attn_v1 = getenv("W2V2_ATTN_V1") != nullptr;   // A/B switch
+
+#define ATTN_DISPATCH_SMALL(NFV, CALL)       \
+  switch (NFV) {                             \
+    case 2: { constexpr int NF = 2; CALL; } break;   \
+    case 4: { constexpr int NF = 4; CALL; } break;   \
+    case 6: { constexpr int NF = 6; CALL; } break;   \
+    case 8: { constexpr int NF = 8; CALL; } break;   \
+    default: { constexpr int NF = 10; CALL; } break; \
+  }
 
 #define ATTN_DISPATCH(NFV, CALL)             \
   switch (NFV) {                             \
@@ -388,6 +702,16 @@ extern "C" int w2v2_attention_fwd(const void* qkv, void* ctx, float* lse, int B,
   dim3 grid((unsigned)cdiv(T, 64), heads, B);
   const float ik = 1.0f / (1.0f - drop_p);
   hipStream_t st = as_stream(stream);
+  if (nf <= 10 && !g_attn_v1) {
+    dim3 grid2(heads, B);
+    ATTN_DISPATCH_SMALL(nf, {
+      set_lds(attn_fwd2_kernel<NF>, fwd2_lds<NF>());
+      hipLaunchKernelGGL(attn_fwd2_kernel<NF>, grid2, dim3(256), fwd2_lds<NF>(), st, (const bf16_t*)qkv, (bf16_t*)ctx,
+                         lse, T, heads, scale, drop_p, ik, seed);
+    });
+    W2V2_CHECK_LAUNCH("attention_fwd");
+    return 0;
+  }
   ATTN_DISPATCH(nf, {
     set_lds(attn_fwd_kernel<NF>, fwd_lds<NF>());
     hipLaunchKernelGGL(attn_fwd_kernel<NF>, grid, dim3(256), fwd_lds<NF>(), st, (const bf16_t*)qkv, (bf16_t*)ctx, lse,
@@ -406,6 +730,16 @@ extern "C" int w2v2_attention_bwd(const void* qkv, const void* ctx, const void* 
   dim3 grid((unsigned)cdiv(T, 64), heads, B);
   const float ik = 1.0f / (1.0f - drop_p);
   hipStream_t st = as_stream(stream);
+  if (nf <= 10 && !g_attn_v1) {
+    dim3 grid2(heads, B);
+    ATTN_DISPATCH_SMALL(nf, {
+      set_lds(attn_bwd2_kernel<NF>, bwd2_lds<NF>());
+      hipLaunchKernelGGL(attn_bwd2_kernel<NF>, grid2, dim3(256), bwd2_lds<NF>(), st, (const bf16_t*)qkv,
+                         (const bf16_t*)ctx, (const bf16_t*)dctx, lse, (bf16_t*)dqkv, T, heads, scale, drop_p, ik, seed);
+    });
+    W2V2_CHECK_LAUNCH("attention_bwd");
+    return 0;
+  }
   ATTN_DISPATCH(nf, {
     set_lds(attn_bwd_dq_kernel<NF>, dq_lds<NF>());
     set_lds(attn_bwd_kv_kernel<NF>, kv_lds<NF>());

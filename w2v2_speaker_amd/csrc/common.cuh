@@ -88,19 +88,26 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
 }
 
 // ---------------------------------------------------------------- counter-based RNG (dropout)
-// splitmix64 finaliser over (seed, index): the same (seed, i) gives the same keep decision in the
-// forward and in the backward, so no mask is ever stored.
+// keep(seed, i) must be recomputable in the backward, so no mask is ever stored.  It also sits in the
+// inner loops of the attention kernels (T^2 decisions per head, three times per step), so it is a
+// 32-bit integer hash (murmur3 finaliser over the element index, keyed by a seed mix that is
+// wave-uniform and therefore scalar-unit work): ~10 VALU ops per decision.  (A 64-bit splitmix cost
+// ~80 and made dropout 90 % of the fused attention kernels' time.)
 __device__ __forceinline__ uint32_t rng_u32(uint64_t seed, uint64_t idx) {
-  uint64_t z = seed + 0x9E3779B97F4A7C15ull * (idx + 1);
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  z = z ^ (z >> 31);
-  return (uint32_t)(z >> 32);
+  const uint32_t key = (uint32_t)seed * 0x9E3779B1u ^ (uint32_t)(seed >> 32) * 0x85EBCA77u ^ 0x27D4EB2Fu;
+  uint32_t x = (uint32_t)idx ^ ((uint32_t)(idx >> 32) * 0xC2B2AE3Du) ^ key;
+  x ^= x >> 16; x *= 0x85EBCA6Bu;
+  x ^= x >> 13; x *= 0xC2B2AE35u;
+  x ^= x >> 16;
+  x += key;                      // second keyed round: decorrelates streams of nearby seeds
+  x ^= x >> 15; x *= 0x2C1B3C6Du;
+  x ^= x >> 12;
+  return x;
 }
-// returns 0 (dropped) or 1/(1-p)
+// returns 0 (dropped, probability p) or 1/(1-p)
 __device__ __forceinline__ float drop_scale(uint64_t seed, uint64_t idx, float p, float inv_keep) {
-  const float u = (float)(rng_u32(seed, idx) >> 8) * (1.0f / 16777216.0f);
-  return u >= p ? inv_keep : 0.0f;
+  const uint32_t thr = (uint32_t)fminf(p * 4294967296.0f, 4294967040.0f);
+  return rng_u32(seed, idx) >= thr ? inv_keep : 0.0f;
 }
 
 // ---------------------------------------------------------------- wave / block reductions (wave = 64)

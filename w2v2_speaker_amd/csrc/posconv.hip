@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void tap_reduce_kernel(const float* __restrict
       if constexpr (WITH_DW) {
         const int o = r / Cg, i = r - o * Cg;
         const int g = o / Cg, co = o - g * Cg;
-        acc += vv * dwf[(((int64_t)g * Cg + co) * K + kpt) * Cg + i];
+        acc += vv * dwf[(((int64_t)g * K + kpt) * Cg + i) * Cg + co];
       } else {
         acc += vv * vv;
       }
@@ -137,7 +137,7 @@ __global__ void wn_bwd_kernel(const float* __restrict__ g, const float* __restri
     const int i = (int)(r % Cg), o = (int)(r / Cg);
     const int gi = o / Cg, co = o - gi * Cg;
     const float n2 = sumsq[tap], rn = rsqrtf(n2);
-    const float dw = dwf[(((int64_t)gi * Cg + co) * K + tap) * Cg + i];
+    const float dw = dwf[(((int64_t)gi * K + tap) * Cg + i) * Cg + co];
     dv[idx] = g[tap] * rn * (dw - v[idx] * dot[tap] / n2);
     if (idx < K) dg[idx] = dot[idx] * rsqrtf(sumsq[idx]);
   }

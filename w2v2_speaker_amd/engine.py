@@ -161,7 +161,7 @@ class Plan:
             self.DC = self._e(M, H)
             self.P1 = self._e(M, H)
             self.dyg = self._e(B, G, self.Tp, self.Cg)
-            self.dwf = self._e(G, self.Cg, K * self.Cg, dtype=f32)
+            self.dwf = self._e(G, K * self.Cg, self.Cg, dtype=f32)
             self.pos_dot = self._e(129 * K, dtype=f32)
             self.dn = self._e(self.M0, C[-1])
             self.G0 = self._ep(self.M0, H) if self.cls else None
@@ -278,9 +278,11 @@ class Plan:
         if self.train:
             mg = st.mg
             # pos-conv backward: weight gradient (packed layout) and data gradient (flipped weights)
-            self.g_pos_dw = Gemm(Cg, K * Cg, M, self.P1, self.xg, self.dwf, lda=H, ldb=Cg, ldc=K * Cg, transA=True,
-                                 transB=True, b_seg=(T, G * Tp * Cg), batch=G, batch_inner=G, a_strides=(0, Cg),
-                                 b_strides=(0, Tp * Cg), c_strides=(0, Cg * K * Cg))
+            # weight gradient with the LARGE dimension (tap, ci) = 6144 as M and the 48 output channels of the
+            # group as N (narrow 128x64 tiles, 75 % full) instead of M = 48 on 128-row tiles (37 % full)
+            self.g_pos_dw = Gemm(K * Cg, Cg, M, self.xg, self.P1, self.dwf, lda=Cg, ldb=H, ldc=Cg, transA=True,
+                                 transB=True, a_seg=(T, G * Tp * Cg), batch=G, batch_inner=G, a_strides=(0, Tp * Cg),
+                                 b_strides=(0, Cg), c_strides=(0, K * Cg * Cg))
             self.g_pos_dx = Gemm(M, Cg, K * Cg, self.dyg, self.posw_b, self.G, lda=Cg, ldb=K * Cg, ldc=H,
                                  a_seg=(T, G * Tp * Cg), batch=G, batch_inner=G, a_strides=(0, Tp * Cg),
                                  b_strides=(0, Cg * K * Cg), c_strides=(0, Cg), epilogue=EPI_ADD, aux=self.G, ldaux=H,
