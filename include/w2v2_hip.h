@@ -131,10 +131,14 @@ int w2v2_layernorm_fwd(const void* x, void* r_inout, const float* gamma, const f
                        float* mean, float* rstd, int M, int H, float eps, float drop_p,
                        uint64_t seed, int dtype, void* stream);
 /* s = pre-norm input (x if r was NULL).  Outputs: ds (grad wrt s; may alias dy), d_r = ds*dropmask
- * (optional; a plain copy of ds when drop_p == 0), dgamma/dbeta ATOMICALLY ADDED (f32, caller zeroes). */
+ * (optional; a plain copy of ds when drop_p == 0), dgamma/dbeta ADDED to (f32, caller zeroes): with a
+ * workspace of w2v2_layernorm_bwd_workspace_floats(H) floats the column sums are folded in a fixed
+ * order by a second tiny kernel (deterministic, no atomics); workspace NULL falls back to f32 atomics. */
+int w2v2_layernorm_bwd_workspace_floats(int H);
 int w2v2_layernorm_bwd(const void* dy, const void* s, const float* mean, const float* rstd,
-                       const float* gamma, void* ds, void* d_r, float* dgamma, float* dbeta, int M,
-                       int H, float drop_p, uint64_t seed, int dtype, void* stream);
+                       const float* gamma, void* ds, void* d_r, float* dgamma, float* dbeta,
+                       float* workspace, int M, int H, float drop_p, uint64_t seed, int dtype,
+                       void* stream);
 
 /* ---------------------------------------------------------------------------------- elementwise */
 /* nn.Dropout fwd == bwd (same mask): y = x * keep(seed,i)/(1-p); in place allowed. */

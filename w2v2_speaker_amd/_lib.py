@@ -48,7 +48,8 @@ _SIGS = {
     "w2v2_pack_conv_weight": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "w2v2_layernorm_fwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_f32, c_f32,
                                    c_u64, c_i32, c_vp]),
-    "w2v2_layernorm_bwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32,
+    "w2v2_layernorm_bwd_workspace_floats": (c_i32, [c_i32]),
+    "w2v2_layernorm_bwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32,
                                    c_f32, c_u64, c_i32, c_vp]),
     "w2v2_dropout": (c_i32, [c_vp, c_vp, c_i64, c_f32, c_u64, c_i32, c_vp]),
     "w2v2_gelu_bwd": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, c_vp]),

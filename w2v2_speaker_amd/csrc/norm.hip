@@ -73,8 +73,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
                                                      const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, T* __restrict__ ds,
                                                      T* __restrict__ d_r, float* __restrict__ dgamma,
-                                                     float* __restrict__ dbeta, int M, int H, float p,
-                                                     uint64_t seed) {
+                                                     float* __restrict__ dbeta, float* __restrict__ partial,
+                                                     int M, int H, float p, uint64_t seed) {
   __shared__ float red[4][LN_MAXC * 64 * 8];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nch = H >> 3;
@@ -147,9 +147,37 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
       const int col = (ln + 64 * ci) * 8 + e;
       if (col < H) {
         const float v = red[0][i] + red[1][i] + red[2][i] + red[3][i];
-        unsafeAtomicAdd((pass == 0 ? dgamma : dbeta) + col, v);
+        if (partial != nullptr) partial[((int64_t)blockIdx.x * 2 + pass) * H + col] = v;   // folded by ln_bwd_finalize
+        else unsafeAtomicAdd((pass == 0 ? dgamma : dbeta) + col, v);
       }
     }
+  }
+}
+
+// fold the per-block column partials in a fixed order (deterministic) and add them to dgamma / dbeta:
+// 32 columns x 8 block lanes per workgroup, each lane sums every 8th block (independent loads, unrolled),
+// then a fixed-order LDS fold over the 8 lanes
+__global__ __launch_bounds__(256) void ln_bwd_finalize_kernel(const float* __restrict__ partial,
+                                                              float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                              int nblk, int H) {
+  __shared__ float red[8][32];
+  const int cl = threadIdx.x & 31, bl = threadIdx.x >> 5;
+  const int i = blockIdx.x * 32 + cl;                 // index into [2][H]
+  float s = 0.f;
+  if (i < 2 * H) {
+    const int pass = i / H, col = i - pass * H;
+#pragma unroll 8
+    for (int b = bl; b < nblk; b += 8) s += partial[((int64_t)b * 2 + pass) * H + col];
+  }
+  red[bl][cl] = s;
+  __syncthreads();
+  if (bl == 0 && i < 2 * H) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += red[k][cl];
+    const int pass = i / H, col = i - pass * H;
+    float* dst = (pass == 0 ? dgamma : dbeta) + col;
+    *dst += t;
   }
 }
 
@@ -173,24 +201,31 @@ extern "C" int w2v2_layernorm_fwd(const void* x, void* r, const float* gamma, co
   return 0;
 }
 
+extern "C" int w2v2_layernorm_bwd_workspace_floats(int H) { return 512 * 2 * H; }
+
 extern "C" int w2v2_layernorm_bwd(const void* dy, const void* s, const float* mean, const float* rstd,
                                   const float* gamma, void* ds, void* d_r, float* dgamma, float* dbeta,
-                                  int M, int H, float drop_p, uint64_t seed, int dtype, void* stream) {
+                                  float* workspace, int M, int H, float drop_p, uint64_t seed, int dtype,
+                                  void* stream) {
   W2V2_REQUIRE(dy && s && mean && rstd && gamma && ds, "layernorm_bwd: null pointer");
   W2V2_REQUIRE(H % 8 == 0 && H <= 8 * 64 * LN_MAXC, "layernorm_bwd: H=%d unsupported", H);
   W2V2_REQUIRE((dgamma == nullptr) == (dbeta == nullptr), "layernorm_bwd: dgamma/dbeta must come together");
   if (M <= 0) return 0;
-  const int nb = (int)(cdiv(M, 4) < 1024 ? cdiv(M, 4) : 1024);
+  const int nb = (int)(cdiv(M, 4) < 512 ? cdiv(M, 4) : 512);
+  float* partial = dgamma ? workspace : nullptr;
   if (dtype == W2V2_BF16)
     hipLaunchKernelGGL(ln_bwd_kernel<bf16_t>, dim3(nb), dim3(256), 0, as_stream(stream), (const bf16_t*)dy,
-                       (const bf16_t*)s, mean, rstd, gamma, (bf16_t*)ds, (bf16_t*)d_r, dgamma, dbeta, M, H,
+                       (const bf16_t*)s, mean, rstd, gamma, (bf16_t*)ds, (bf16_t*)d_r, dgamma, dbeta, partial, M, H,
                        drop_p, seed);
   else if (dtype == W2V2_F32)
     hipLaunchKernelGGL(ln_bwd_kernel<float>, dim3(nb), dim3(256), 0, as_stream(stream), (const float*)dy,
-                       (const float*)s, mean, rstd, gamma, (float*)ds, (float*)d_r, dgamma, dbeta, M, H,
+                       (const float*)s, mean, rstd, gamma, (float*)ds, (float*)d_r, dgamma, dbeta, partial, M, H,
                        drop_p, seed);
   else
     W2V2_FAIL("layernorm_bwd: bad dtype %d", dtype);
+  if (partial != nullptr)
+    hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3((unsigned)cdiv(2 * H, 32)), dim3(256), 0, as_stream(stream),
+                       partial, dgamma, dbeta, nb, H);
   W2V2_CHECK_LAUNCH("layernorm_bwd");
   return 0;
 }

@@ -193,12 +193,23 @@ def layernorm_fwd(x, r, gamma, beta, y, mean, rstd, eps: float, drop_p: float = 
                "layernorm_fwd")
 
 
+_LN_WS = {}
+
+
+def _ln_workspace(H: int, device) -> torch.Tensor:
+    key = (H, str(device))
+    if key not in _LN_WS:
+        _LN_WS[key] = torch.empty(lib().w2v2_layernorm_bwd_workspace_floats(H), dtype=torch.float32, device=device)
+    return _LN_WS[key]
+
+
 def layernorm_bwd(dy, s, mean, rstd, gamma, ds, d_r, dgamma, dbeta, drop_p: float = 0.0, seed: int = 0) -> None:
     _dev(dy, s, mean, rstd, gamma, ds, d_r, dgamma, dbeta)
     H = dy.shape[-1]
     M = dy.numel() // H
+    ws = _ln_workspace(H, dy.device) if dgamma is not None else None
     _lib.check(lib().w2v2_layernorm_bwd(dy.data_ptr(), s.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
-                                        gamma.data_ptr(), ds.data_ptr(), _p(d_r), _p(dgamma), _p(dbeta), M, H,
+                                        gamma.data_ptr(), ds.data_ptr(), _p(d_r), _p(dgamma), _p(dbeta), _p(ws), M, H,
                                         drop_p, seed, dt(dy), stream()), "layernorm_bwd")
 
 
