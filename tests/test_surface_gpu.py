@@ -153,3 +153,37 @@ def test_fc_module_training_and_eer_parity_on_synthetic_trials():
     assert np.isfinite(losses).all() and losses[-1] < losses[0], losses
     emb, pred = mod(batch.network_input[:3])
     assert emb.shape == (3, 2 * cfg.hidden_size) and pred.shape == emb.shape
+
+
+def test_initially_frozen_network_trains_head_only_then_unfreezes():
+    """ref: wav2vec2_fc.py:339-361 -- while frozen only loss_fn.fc_weights moves; after num_frozen_steps the
+    encoder trains too (the CNN stays frozen throughout)."""
+    from w2v2_speaker_amd.config import W2V2Config
+    from w2v2_speaker_amd.lightning_modules.speaker.wav2vec2_fc import (SpeakerClassificationDataBatch,
+                                                                         Wav2vec2FCModule, Wav2vec2FCModuleConfig)
+    cfg = W2V2Config.tiny()
+    orig = W2V2Config.from_huggingface_id
+    W2V2Config.from_huggingface_id = staticmethod(lambda _id: cfg)
+    try:
+        mod = Wav2vec2FCModule(Wav2vec2FCModuleConfig(wav2vec_initially_frozen=True, num_frozen_steps=2),
+                               num_speakers=5, device=DEV, act_dtype=torch.float32, max_lr=1e-2, max_steps=20)
+    finally:
+        W2V2Config.from_huggingface_id = orig
+    wav, label = O.synth_batch(4, 4000, 5, seed=9)
+    batch = SpeakerClassificationDataBatch(4, ["a", "b", "c", "d"], wav, label).to(DEV)
+    mod.train()
+    mod.on_train_start()
+    st = mod.store
+    h = st.head_size()
+    before = st.flat.clone()
+    mod.training_step(batch, 0)
+    torch.cuda.synchronize()
+    assert not torch.equal(st.flat[:h], before[:h])            # head moved
+    assert torch.equal(st.flat[h:], before[h:])                # everything else frozen
+    mod.training_step(batch, 1)
+    assert mod._is_wav2vec_frozen is False                      # 2 backward calls -> unfrozen
+    mid = st.flat.clone()
+    mod.training_step(batch, 2)
+    torch.cuda.synchronize()
+    assert not torch.equal(st.flat[h:st.n_train], mid[h:st.n_train])
+    assert torch.equal(st.flat[st.n_train:], before[st.n_train:])   # CNN never updated

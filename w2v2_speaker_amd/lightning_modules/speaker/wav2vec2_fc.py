@@ -124,12 +124,17 @@ class Wav2vec2FCModule:
         return self.train(False)
 
     def on_train_start(self) -> None:
+        # ref: wav2vec2_fc.py:339-347
         self.steps = 0
         if self.cfg.wav2vec_initially_frozen:
-            raise NotImplementedError("wav2vec_initially_frozen (reference default False) -- SURVEY 8a row a16")
+            self._is_wav2vec_frozen = True
 
     def on_after_backward(self) -> None:
+        # ref: wav2vec2_fc.py:349-361 -- num_frozen_steps counts backward calls
         self.steps += 1
+        if (self._is_wav2vec_frozen and self.cfg.num_frozen_steps is not None
+                and self.steps >= self.cfg.num_frozen_steps):
+            self._is_wav2vec_frozen = False
 
     # ------------------------------------------------------------------ plans
     def _plan(self, batch: int, n: int, train: bool) -> Plan:
@@ -192,7 +197,20 @@ class Wav2vec2FCModule:
             self._trainers[key] = tr
         tr = self._trainers[key]
         tr.step = self.steps
-        loss, pred = tr.train_step(x, label)
+        if self._is_wav2vec_frozen:
+            # frozen network = eval-mode forward (PL freeze()), head-only backward + Adam
+            fkey = (x.shape[0], x.shape[1], "frozen")
+            if fkey not in self._plans:
+                noreg = Wav2Vec2RegularisationConfig(activation_dropout=0.0, attention_dropout=0.0,
+                                                     feat_proj_dropout=0.0, hidden_dropout=0.0, layerdrop=0.0,
+                                                     mask_time_prob=0.0)
+                self._plans[fkey] = Plan(self.store, x.shape[0], x.shape[1], train=True, reg=noreg,
+                                         pooling=self.cfg.stat_pooling_type,
+                                         insert_cls_token=(self.cfg.stat_pooling_type == "first+cls"),
+                                         aam_margin=self.margin, aam_scale=self.scale)
+            loss, pred = tr.train_step_frozen_encoder(self._plans[fkey], x, label)
+        else:
+            loss, pred = tr.train_step(x, label)
         self.on_after_backward()
         return {"loss": loss, "prediction": pred}
 

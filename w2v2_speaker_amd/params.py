@@ -128,6 +128,8 @@ class ParamStore:
         self.version = 0          # bumped whenever weights change (derived packs are re-made lazily)
         self.cnn_version = 0      # bumped whenever the CNN weights change
         self.step_count = 0
+        self.step_head = 0
+        self.step_body = 0
 
     # ------------------------------------------------------------------ views
     def _view(self, buf: torch.Tensor, name: str) -> torch.Tensor:
@@ -277,14 +279,36 @@ class ParamStore:
     def zero_grad(self) -> None:
         self.grad.zero_()
 
+    def head_size(self) -> int:
+        """Number of leading arena elements that belong to the classification head."""
+        return self.grad_buckets()[0][2] if self.head is not None else 0
+
     def adam_step(self, lr: float, beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8,
-                  grad_scale: float = 1.0) -> None:
+                  grad_scale: float = 1.0, head_only: bool = False) -> None:
+        """head_only: the wav2vec2 network is frozen (ref: wav2vec2_fc.py:339-361 ``wav2vec_initially_frozen``),
+        only the head slice of the arena is updated.
+
+        torch.optim.Adam keeps a step count PER PARAMETER that only advances when the parameter has a
+        gradient: parameters frozen for the first steps start their bias correction at 1 when they
+        unfreeze.  Two counters (head / rest of the arena) reproduce that."""
         if self.exp_avg is None:
             self.exp_avg = torch.zeros_like(self.grad)
             self.exp_avg_sq = torch.zeros_like(self.grad)
-        self.step_count += 1
-        ops.adam_step(self.flat, self.grad, self.exp_avg, self.exp_avg_sq, self.flat_lp, self.n_train, lr, beta1,
-                      beta2, eps, self.step_count, grad_scale)
+        h = self.head_size()
+        self.step_head += 1
+        if not head_only:
+            self.step_body += 1
+        self.step_count = max(self.step_head, self.step_body)
+        a = (self.flat, self.grad, self.exp_avg, self.exp_avg_sq)
+        lp = self.flat_lp
+        if head_only:
+            ops.adam_step(*a, lp, h, lr, beta1, beta2, eps, self.step_head, grad_scale)
+        elif self.step_head == self.step_body or h == 0:
+            ops.adam_step(*a, lp, self.n_train, lr, beta1, beta2, eps, self.step_body, grad_scale)
+        else:
+            ops.adam_step(*a, lp, h, lr, beta1, beta2, eps, self.step_head, grad_scale)
+            ops.adam_step(*(t[h:] for t in a), lp[h:] if lp is not None else None, self.n_train - h, lr, beta1,
+                          beta2, eps, self.step_body, grad_scale)
         self.sync_transposed()
         self.version += 1
         if not self.freeze_cnn:

@@ -104,6 +104,20 @@ class SpeakerTrainer:
                                  plan.cfg.mask_time_min_masks, rng=self._mask_rng)
         return torch.from_numpy(m.astype(np.uint8)).to(plan.dev, non_blocking=True)
 
+    def train_step_frozen_encoder(self, frozen_plan: Plan, wav: torch.Tensor, label: torch.Tensor):
+        """Step while the whole wav2vec2 network is frozen (ref: wav2vec2_fc.py:339-347 + PL ``freeze()`` =
+        requires_grad False AND eval mode): eval-mode forward, head forward/backward, Adam on the head only."""
+        store = self.store
+        store.zero_grad()
+        frozen_plan.embed(wav, None, (), self.step)
+        loss, softmax = frozen_plan.head_forward_backward(label)
+        self.reducer.bucket_ready("head")
+        self.reducer.wait()
+        lr, beta1 = self.schedule.at(self.step)
+        store.adam_step(lr, beta1, self.beta2, self.eps, grad_scale=1.0 / self.world, head_only=True)
+        self.step += 1
+        return loss, softmax
+
     def train_step(self, wav: torch.Tensor, label: torch.Tensor, mask: Optional[torch.Tensor] = None,
                    skip_layers: Optional[Sequence[int]] = None):
         """ref: speaker_recognition_module.py:207-220 (_train_step_ce_loss) + PL backward/optimizer step.
