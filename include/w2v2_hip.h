@@ -119,6 +119,17 @@ int w2v2_conv0_stats(const float* wav, const float* w /*[C][k]*/, float* partial
 int w2v2_conv0_apply(const float* wav, const float* w, const float* mean_rstd, const float* gamma,
                      const float* beta, void* y, int dtype, int B, int N, int C, int k, int stride,
                      void* stream);
+/* Backward of layer 0 (unfrozen feature extractor): from dz = dL/d(layer-0 output) [B,L,C] compute dw [C][k],
+ * dgamma [C], dbeta [C] (f32 atomics, caller zeroes); conv / GroupNorm are recomputed from the waveform and the
+ * forward's mean_rstd.  sums [B][C][2] is f32 scratch. */
+int w2v2_conv0_bwd(const float* wav, const float* w, const float* mean_rstd, const float* gamma,
+                   const float* beta, const void* dz, float* sums, float* dw, float* dgamma, float* dbeta,
+                   int dtype, int B, int N, int C, int k, int stride, void* stream);
+/* col2im of a strided Conv1d data gradient: col [B*Lout][k*Cin] (= dpre @ packed weight) -> dx [B][Lin][Cin]. */
+int w2v2_col2im(const void* col, void* dx, int B, int Lin, int Lout, int Cin, int k, int stride, int dtype,
+                void* stream);
+/* packed weight gradient [Cout][k][Cin] (f32) ADDED into the HF-layout gradient [Cout][Cin][k]. */
+int w2v2_unpack_conv_grad(const float* gp, float* g, int Cout, int Cin, int k, void* stream);
 /* HF conv weight [Cout][Cin][k] (f32) -> implicit-GEMM operand [Cout][k][Cin] (dtype). */
 int w2v2_pack_conv_weight(const float* w, void* out, int dtype, int Cout, int Cin, int k, void* stream);
 

@@ -277,3 +277,37 @@ def test_regularised_training_step_runs_layerdrop_masks_dropout():
         assert float(st.mg("encoder.layers.0.feed_forward.output_dense.weight").abs().max()) > 0.0
         assert float(st.mg("masked_spec_embed").abs().max()) > 0.0
         assert torch.isfinite(st.flat).all()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_unfrozen_cnn_every_gradient_vs_reference_golden(dtype):
+    """completely_freeze_feature_extractor=False: gradients of ALL parameters, incl. the 7 conv layers and the
+    layer-0 GroupNorm, against the reference golden (which kept the CNN trainable)."""
+    from w2v2_speaker_amd.engine import Plan
+    from w2v2_speaker_amd.params import ParamStore
+    g = load("g1_tiny.npz")
+    cfg, ocfg = _cfgs("tiny")
+    st = ParamStore(cfg, DEV, dtype, head="aam", num_speakers=10, freeze_cnn=False)
+    sd = O.make_state_dict(ocfg, 20211)
+    sd["loss_fn.fc_weights"] = O.synth_tensor("loss_fn.fc_weights", (10, 2 * cfg.hidden_size), 20211)
+    st.load_state_dict(sd)
+    assert st.n_train == st.n_total and [b[0] for b in st.grad_buckets()][-1] == "cnn"
+    wav, label, mask = T(g["wav"]).to(DEV), T(g["label"]).to(DEV), T(g["mask"]).to(DEV)
+    plan = Plan(st, 2, wav.shape[-1], train=True, reg=_no_reg())
+    st.zero_grad()
+    plan.embed(wav, mask)
+    loss, _ = plan.head_forward_backward(label)
+    plan.backward()
+    torch.cuda.synchronize()
+    f32 = dtype == torch.float32
+    assert abs(float(loss) - float(g["loss"])) < (1e-4 if f32 else 5e-2) * abs(float(g["loss"]))
+    gtol, floor = (2e-3, 1e-6) if f32 else (0.15, 3e-3)
+    for name in st.shapes:
+        key = "grad." + (name[len("wav2vec.model."):] if name.startswith("wav2vec.model.") else name)
+        ref = g[key]
+        err = np.linalg.norm(st.g(name).cpu().numpy().astype(np.float64) - ref)
+        assert err <= gtol * np.linalg.norm(ref) + floor, (name, err, np.linalg.norm(ref))
+    # one optimiser step moves the CNN weights too
+    before = st.mp("feature_extractor.conv_layers.3.conv.weight").clone()
+    st.adam_step(1e-3)
+    assert not torch.equal(before, st.mp("feature_extractor.conv_layers.3.conv.weight"))

@@ -157,3 +157,164 @@ extern "C" int w2v2_pack_conv_weight(const float* w, void* out, int dtype, int C
   W2V2_CHECK_LAUNCH("pack_conv_weight");
   return 0;
 }
+
+// =============================================================================== backward (unfrozen CNN)
+// z = gelu(y), y = gamma * yhat + beta, yhat = (u - mu) * rstd, u = conv(x, w)   per (utterance b, channel c)
+// Given dz [B,L,C]:  dy = dz * gelu'(y);  dgamma_c = sum dy*yhat;  dbeta_c = sum dy;
+//   du = rstd*gamma * (dy - mean_l(dy) - yhat * mean_l(dy*yhat));   dw[c][k] = sum_{b,l} du * x[b, stride*l + k].
+// u / yhat / y are RECOMPUTED from the waveform (10 MAC), so nothing of layer 0 is saved by the forward.
+//   pass 1: per-(b,c) sums {sum dy, sum dy*yhat}            (f32 atomics into sums[B][C][2], caller zeroes)
+//   pass 2: du, accumulate dw (+ dgamma, dbeta once per (b,c)) (f32 atomics, caller zeroes)
+template <typename T, int PASS>
+__global__ __launch_bounds__(256) void conv0_bwd_kernel(const float* __restrict__ wav, const float* __restrict__ w,
+                                                        const float* __restrict__ mr, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, const T* __restrict__ dz,
+                                                        float* __restrict__ sums, float* __restrict__ dw,
+                                                        float* __restrict__ dgamma, float* __restrict__ dbeta, int N,
+                                                        int L, int C, int k, int stride) {
+  extern __shared__ float xs[];
+  const int b = blockIdx.y;
+  const int l0 = blockIdx.x * C0_FRAMES;
+  const int nf = min(C0_FRAMES, L - l0);
+  const int nsamp = (nf - 1) * stride + k;
+  const float* src = wav + (int64_t)b * N + (int64_t)l0 * stride;
+  for (int i = threadIdx.x; i < nsamp; i += 256) xs[i] = src[i];
+  __syncthreads();
+  const float invL = 1.0f / (float)L;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float wr[C0_MAXK];
+#pragma unroll
+    for (int j = 0; j < C0_MAXK; ++j) wr[j] = j < k ? w[c * k + j] : 0.f;
+    const float* st = mr + ((int64_t)b * C + c) * 2;
+    const float mu = st[0], rstd = st[1], ga = gamma[c], be = beta[c];
+    const T* dzp = dz + ((int64_t)b * L + l0) * C + c;
+    if constexpr (PASS == 1) {
+      float s1 = 0.f, s2 = 0.f;
+      for (int f = 0; f < nf; ++f) {
+        const float* xp = xs + f * stride;
+        float u = 0.f;
+#pragma unroll
+        for (int j = 0; j < C0_MAXK; ++j)
+          if (j < k) u = fmaf(wr[j], xp[j], u);
+        const float yh = (u - mu) * rstd;
+        const float dy = to_f32<T>(dzp[(int64_t)f * C]) * gelu_grad_f(fmaf(yh, ga, be));
+        s1 += dy;
+        s2 = fmaf(dy, yh, s2);
+      }
+      float* sp = sums + ((int64_t)b * C + c) * 2;
+      unsafeAtomicAdd(sp, s1);
+      unsafeAtomicAdd(sp + 1, s2);
+    } else {
+      const float* sp = sums + ((int64_t)b * C + c) * 2;
+      const float m1 = sp[0] * invL, m2 = sp[1] * invL;
+      float acc[C0_MAXK];
+#pragma unroll
+      for (int j = 0; j < C0_MAXK; ++j) acc[j] = 0.f;
+      for (int f = 0; f < nf; ++f) {
+        const float* xp = xs + f * stride;
+        float u = 0.f;
+#pragma unroll
+        for (int j = 0; j < C0_MAXK; ++j)
+          if (j < k) u = fmaf(wr[j], xp[j], u);
+        const float yh = (u - mu) * rstd;
+        const float dy = to_f32<T>(dzp[(int64_t)f * C]) * gelu_grad_f(fmaf(yh, ga, be));
+        const float du = rstd * ga * (dy - m1 - yh * m2);
+#pragma unroll
+        for (int j = 0; j < C0_MAXK; ++j)
+          if (j < k) acc[j] = fmaf(du, xp[j], acc[j]);
+      }
+#pragma unroll
+      for (int j = 0; j < C0_MAXK; ++j)
+        if (j < k) unsafeAtomicAdd(dw + c * k + j, acc[j]);
+      if (blockIdx.x == 0) {             // once per (b, c)
+        unsafeAtomicAdd(dgamma + c, sp[1]);
+        unsafeAtomicAdd(dbeta + c, sp[0]);
+      }
+    }
+  }
+}
+
+extern "C" int w2v2_conv0_bwd(const float* wav, const float* w, const float* mean_rstd, const float* gamma,
+                              const float* beta, const void* dz, float* sums, float* dw, float* dgamma, float* dbeta,
+                              int dtype, int B, int N, int C, int k, int stride, void* stream) {
+  if (conv0_check("conv0_bwd", B, N, C, k, stride)) return -1;
+  W2V2_REQUIRE(wav && w && mean_rstd && gamma && beta && dz && sums && dw && dgamma && dbeta, "conv0_bwd: null pointer");
+  const int L = (N - k) / stride + 1;
+  dim3 grid((unsigned)cdiv(L, C0_FRAMES), B);
+  const size_t lds = ((size_t)(C0_FRAMES - 1) * stride + k) * sizeof(float);
+  hipStream_t st = as_stream(stream);
+  if (hipMemsetAsync(sums, 0, sizeof(float) * 2 * (size_t)B * C, st) != hipSuccess) W2V2_FAIL("conv0_bwd: memset failed");
+#define W2V2_C0B(T_, P_)                                                                                       \
+  hipLaunchKernelGGL((conv0_bwd_kernel<T_, P_>), grid, dim3(256), lds, st, wav, w, mean_rstd, gamma, beta,     \
+                     (const T_*)dz, sums, dw, dgamma, dbeta, N, L, C, k, stride)
+  if (dtype == W2V2_BF16) { W2V2_C0B(bf16_t, 1); W2V2_C0B(bf16_t, 2); }
+  else if (dtype == W2V2_F32) { W2V2_C0B(float, 1); W2V2_C0B(float, 2); }
+  else W2V2_FAIL("conv0_bwd: bad dtype %d", dtype);
+#undef W2V2_C0B
+  W2V2_CHECK_LAUNCH("conv0_bwd");
+  return 0;
+}
+
+// col2im of a strided Conv1d data gradient: col [B*Lout][k*Cin] (rows = output frames, K index = tap*Cin+ci)
+// -> dx [B][Lin][Cin], dx[b][r][ci] = sum over (l, tap) with stride*l + tap == r.  Every dx element written.
+template <typename T>
+__global__ void col2im_kernel(const T* __restrict__ col, T* __restrict__ dx, int B, int Lin, int Lout, int Cin,
+                              int k, int stride) {
+  const int nch = Cin >> 3;
+  const int64_t total = (int64_t)B * Lin * nch;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int ch = (int)(i % nch);
+    const int64_t row = i / nch;
+    const int b = (int)(row / Lin), r = (int)(row - (int64_t)b * Lin);
+    float acc[8] = {};
+    for (int tap = 0; tap < k; ++tap) {
+      const int t = r - tap;
+      if (t < 0 || t % stride != 0) continue;
+      const int l = t / stride;
+      if (l >= Lout) continue;
+      Vec8<T> v;
+      v.load(col + ((int64_t)b * Lout + l) * ((int64_t)k * Cin) + (int64_t)tap * Cin + ch * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += v.v[e];
+    }
+    Vec8<T> o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o.v[e] = acc[e];
+    o.store(dx + row * Cin + ch * 8);
+  }
+}
+
+extern "C" int w2v2_col2im(const void* col, void* dx, int B, int Lin, int Lout, int Cin, int k, int stride, int dtype,
+                           void* stream) {
+  W2V2_REQUIRE(col && dx && B > 0 && Lin > 0 && Lout > 0 && Cin % 8 == 0 && k > 0 && stride > 0, "col2im: bad arguments");
+  const int64_t total = (int64_t)B * Lin * (Cin >> 3);
+  int nb = (int)(cdiv(total, 256) > 16384 ? 16384 : cdiv(total, 256));
+  if (dtype == W2V2_BF16)
+    hipLaunchKernelGGL(col2im_kernel<bf16_t>, dim3(nb), dim3(256), 0, as_stream(stream), (const bf16_t*)col, (bf16_t*)dx, B, Lin, Lout, Cin, k, stride);
+  else if (dtype == W2V2_F32)
+    hipLaunchKernelGGL(col2im_kernel<float>, dim3(nb), dim3(256), 0, as_stream(stream), (const float*)col, (float*)dx, B, Lin, Lout, Cin, k, stride);
+  else
+    W2V2_FAIL("col2im: bad dtype %d", dtype);
+  W2V2_CHECK_LAUNCH("col2im");
+  return 0;
+}
+
+// gradient of the packed conv weight [Cout][k][Cin] (f32, from the dW GEMM) -> HF layout [Cout][Cin][k], ADDED
+__global__ void unpack_conv_grad_kernel(const float* __restrict__ gp, float* __restrict__ g, int Cout, int Cin, int k) {
+  const int64_t total = (int64_t)Cout * Cin * k;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int ci = (int)(i % Cin);
+    const int64_t r = i / Cin;
+    const int tap = (int)(r % k), co = (int)(r / k);
+    g[((int64_t)co * Cin + ci) * k + tap] += gp[i];
+  }
+}
+
+extern "C" int w2v2_unpack_conv_grad(const float* gp, float* g, int Cout, int Cin, int k, void* stream) {
+  W2V2_REQUIRE(gp && g && Cout > 0 && Cin > 0 && k > 0, "unpack_conv_grad: bad arguments");
+  const int64_t total = (int64_t)Cout * Cin * k;
+  int nb = (int)(cdiv(total, 256) > 4096 ? 4096 : cdiv(total, 256));
+  hipLaunchKernelGGL(unpack_conv_grad_kernel, dim3(nb), dim3(256), 0, as_stream(stream), gp, g, Cout, Cin, k);
+  W2V2_CHECK_LAUNCH("unpack_conv_grad");
+  return 0;
+}

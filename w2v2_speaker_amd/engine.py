@@ -105,6 +105,14 @@ class Plan:
         cins = (1,) + tuple(C[:-1])
         self.convw = [None] + [self._e(C[i], cfg.conv_kernel[i] * cins[i]) for i in range(1, len(C))]
         self.zero_bias = torch.zeros(max(max(C), H), dtype=f32, device=self.dev)
+        self.cnn_train = self.train and not self.store.freeze_cnn
+        if self.cnn_train:      # unfrozen feature extractor: pre-activations saved, gradient + im2col scratch
+            self.conv_pre = [None] + [self._e(B, L, c) for L, c in zip(self.lens[1:], C[1:])]
+            self.dconv = [self._e(B, L, c) for L, c in zip(self.lens[:-1], C[:-1])]      # d(conv[i] output), i < last
+            self.col = self._e(max(B * self.lens[i] * cfg.conv_kernel[i] * cins[i] for i in range(1, len(C))))
+            self.dwp = torch.zeros(max(C[i] * cfg.conv_kernel[i] * cins[i] for i in range(1, len(C))), dtype=f32,
+                                   device=self.dev)
+            self.sums0 = self._e(B, C[0], 2, dtype=f32)
         self.ln_feat = self._ep(self.M0, C[-1])
         self.mean_f, self.rstd_f = self._e(self.M0, dtype=f32), self._e(self.M0, dtype=f32)
         self.h0 = self._e(self.M0, H)                          # projection output (pre-CLS)
@@ -181,7 +189,21 @@ class Plan:
             k, s, ci, co = cfg.conv_kernel[i], cfg.conv_stride[i], cins[i], C[i]
             self.g_conv.append(Gemm(B * self.lens[i], co, k * ci, self.conv[i - 1], self.convw[i], self.conv[i],
                                     lda=s * ci, ldb=k * ci, ldc=co, a_seg=(self.lens[i], self.lens[i - 1] * ci),
-                                    epilogue=EPI_BIAS_GELU, bias=self.zero_bias))
+                                    epilogue=EPI_BIAS_GELU, bias=self.zero_bias,
+                                    aux=self.conv_pre[i] if self.cnn_train else None, ldaux=co))
+        if self.cnn_train:
+            # conv layer i backward: dW (packed layout, f32 scratch) and the im2col-space data gradient
+            self.g_conv_dw, self.g_conv_dx = [None], [None]
+            for i in range(1, len(C)):
+                k, sd, ci, co = cfg.conv_kernel[i], cfg.conv_stride[i], cins[i], C[i]
+                Mi = B * self.lens[i]
+                gout = self.dn if i == len(C) - 1 else self.dconv[i]          # d(conv[i] output) -> dpre in place
+                self.g_conv_dw.append(Gemm(co, k * ci, Mi, gout, self.conv[i - 1], self.dwp, lda=co, ldb=sd * ci,
+                                           ldc=k * ci, transA=True, transB=True,
+                                           b_seg=(self.lens[i], self.lens[i - 1] * ci),
+                                           split_k=_splitk(_tiles(co), _tiles(k * ci), Mi), accumulate=True))
+                self.g_conv_dx.append(Gemm(Mi, k * ci, co, gout, self.convw[i], self.col, lda=co, ldb=k * ci,
+                                           ldc=k * ci, transB=True))
         mw, mp = st.mw, st.mp
         self.g_proj = Gemm(self.M0, H, C[-1], self.ln_feat, mw("feature_projection.projection.weight"), self.h0,
                            lda=C[-1], ldb=C[-1], ldc=H, epilogue=EPI_BIAS, bias=mp("feature_projection.projection.bias"))
@@ -334,6 +356,7 @@ class Plan:
         wav = wav.contiguous()
         assert wav.shape == (B, self.N) and wav.dtype == torch.float32 and wav.is_cuda
         self._refresh_packs()
+        self._wav = wav
         tr = self.train
         self._step, self._skip, self._mask = step, tuple(skip_layers), None
         mp = st.mp
@@ -500,10 +523,35 @@ class Plan:
         if st.flat_lp_t is None:
             ops.colsum(g0, mg("feature_projection.projection.bias"), self.M0, H)
         self.g_proj_dn()
-        if not st.freeze_cnn:
-            raise NotImplementedError("CNN feature-extractor backward (completely_freeze_feature_extractor=False)")
         ops.layernorm_bwd(self.dn, self.conv[-1].view(self.M0, -1), self.mean_f, self.rstd_f,
                           mp("feature_projection.layer_norm.weight"), self.dn, None,
                           mg("feature_projection.layer_norm.weight"), mg("feature_projection.layer_norm.bias"))
         notify("prologue")
+        if not st.freeze_cnn:
+            self._backward_cnn()
+            notify("cnn")
+
+    def _backward_cnn(self) -> None:
+        """Backward of the 7-layer conv feature extractor (HF:382-419) -- the reference's
+        ``completely_freeze_feature_extractor: false`` ablation.  self.dn holds d(conv[6] output)."""
+        cfg, st, B = self.cfg, self.store, self.B
+        C = cfg.conv_dim
+        cins = (1,) + tuple(C[:-1])
+        mg = st.mg
+        for i in reversed(range(1, len(C))):
+            k, sd, ci, co = cfg.conv_kernel[i], cfg.conv_stride[i], cins[i], C[i]
+            gout = self.dn if i == len(C) - 1 else self.dconv[i]
+            gv = gout.view(-1, co)
+            ops.gelu_bwd(gv, self.conv_pre[i].view(-1, co), gv)            # d(pre-activation), in place
+            self.dwp.zero_()
+            self.g_conv_dw[i]()
+            ops.unpack_conv_grad(self.dwp, mg(f"feature_extractor.conv_layers.{i}.conv.weight"))
+            self.g_conv_dx[i]()
+            ops.col2im(self.col, self.dconv[i - 1], B, self.lens[i - 1], self.lens[i], ci, k, sd)
+        ops.conv0_bwd(self._wav, st.mp("feature_extractor.conv_layers.0.conv.weight"), self.stats0,
+                      st.mp("feature_extractor.conv_layers.0.layer_norm.weight"),
+                      st.mp("feature_extractor.conv_layers.0.layer_norm.bias"), self.dconv[0], self.sums0,
+                      mg("feature_extractor.conv_layers.0.conv.weight"),
+                      mg("feature_extractor.conv_layers.0.layer_norm.weight"),
+                      mg("feature_extractor.conv_layers.0.layer_norm.bias"), cfg.conv_kernel[0], cfg.conv_stride[0])
 

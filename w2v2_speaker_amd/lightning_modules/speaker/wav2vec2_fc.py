@@ -86,8 +86,6 @@ class Wav2vec2FCModule:
             raise NotImplementedError("hidden FC layers are not on the reference's default path")
         if cfg.mask_feature_prob > 0 or cfg.final_channel_mask_prob > 0 and False:
             raise NotImplementedError("feature-axis SpecAugment (reference default mask_feature_prob=0.0)")
-        if not cfg.completely_freeze_feature_extractor:
-            raise NotImplementedError("CNN backward (completely_freeze_feature_extractor=False) -- see DESIGN.md")
         assert loss in ("aam", "ce")
         self.cfg = cfg
         self.model_cfg = W2V2Config.from_huggingface_id(cfg.wav2vec_hunggingface_id)
@@ -101,7 +99,8 @@ class Wav2vec2FCModule:
         self.stat_pool_dimension = cfg.explicit_stat_pool_embedding_size or (
             2 * H if cfg.stat_pooling_type == "mean+std" else H)
         self.store = ParamStore(self.model_cfg, device, act_dtype, head=loss, num_speakers=self.num_speakers,
-                                embed_dim=self.stat_pool_dimension, freeze_cnn=True)
+                                embed_dim=self.stat_pool_dimension,
+                                freeze_cnn=cfg.completely_freeze_feature_extractor)
         self.store.init_weights(init_seed)
         self.loss, self.margin, self.scale = loss, aam_margin, aam_scale
         self.validation_pairs, self.test_pairs = validation_pairs or [], test_pairs or []

@@ -177,6 +177,29 @@ def conv0_groupnorm_gelu(wav: torch.Tensor, w: torch.Tensor, gamma: torch.Tensor
                                   out.data_ptr(), dt(out), B, N, Cc, k, stride, stream()), "conv0_apply")
 
 
+def conv0_bwd(wav, w, work, gamma, beta, dz, sums, dw, dgamma, dbeta, k: int, stride: int) -> None:
+    """Backward of layer 0 (see w2v2_conv0_bwd); `work` is the forward's conv0 workspace (holds mean/rstd)."""
+    _dev(wav, w, work, gamma, beta, dz, sums, dw, dgamma, dbeta)
+    B, N = wav.shape
+    Cc = w.shape[0]
+    mr = work[work.numel() - B * Cc * 2:]
+    _lib.check(lib().w2v2_conv0_bwd(wav.data_ptr(), w.data_ptr(), mr.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                    dz.data_ptr(), sums.data_ptr(), dw.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
+                                    dt(dz), B, N, Cc, k, stride, stream()), "conv0_bwd")
+
+
+def col2im(col, dx, B: int, Lin: int, Lout: int, Cin: int, k: int, stride: int) -> None:
+    _dev(col, dx)
+    _lib.check(lib().w2v2_col2im(col.data_ptr(), dx.data_ptr(), B, Lin, Lout, Cin, k, stride, dt(col), stream()),
+               "col2im")
+
+
+def unpack_conv_grad(gp, g) -> None:
+    _dev(gp, g)
+    co, ci, k = g.shape
+    _lib.check(lib().w2v2_unpack_conv_grad(gp.data_ptr(), g.data_ptr(), co, ci, k, stream()), "unpack_conv_grad")
+
+
 def pack_conv_weight(w: torch.Tensor, out: torch.Tensor) -> None:
     _dev(w, out)
     co, ci, k = w.shape
