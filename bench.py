@@ -8,7 +8,7 @@ SpecAugment time masks).
     python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
 
 Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel (the forward-layout MFMA GEMM
-instantiation `gemm_bf16_kernel<4,4,false,false,bf16>`): algorithmic FLOPs of its launches divided
+`gemm_bf16_glds3_kernel<bf16>`): algorithmic FLOPs of its launches divided
 by their HIP-event-measured durations inside the timed region.  `cpu_baseline` times the CPU oracle
 (oracle/w2v2_oracle.py, kind "port") on a bounded sample of the same workload on the host cores.
 """
@@ -92,6 +92,8 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-regularisation", action="store_true", help="dropout/LayerDrop/mask off")
+    ap.add_argument("--unfreeze-cnn", action="store_true",
+                    help="completely_freeze_feature_extractor=False ablation (127.2 GFLOP/utt)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -119,7 +121,7 @@ def main():
     cfg = W2V2Config()
     n_samples = int(round(args.seconds * 16000))
     adt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
-    store = ParamStore(cfg, dev, adt, head="aam", num_speakers=args.speakers)
+    store = ParamStore(cfg, dev, adt, head="aam", num_speakers=args.speakers, freeze_cnn=not args.unfreeze_cnn)
     store.init_weights(seed=20211)            # identical replicas on every rank (DDP broadcast equivalent)
     reg = Wav2Vec2RegularisationConfig()
     if args.no_regularisation:
@@ -140,7 +142,8 @@ def main():
     for _ in range(args.warmup):
         trainer.train_step(wav, label)
     sync()
-    ops.Gemm.profile_begin(lambda g: g.kernel_class == "bf16_nt" and g.out_is_act)
+    # dominant kernel = the 256x128 3-stage LDS-DMA GEMM (encoder forward products + all data gradients)
+    ops.Gemm.profile_begin(lambda g: g.kernel_name == "gemm_bf16_glds3_kernel")
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss, _ = trainer.train_step(wav, label)
@@ -161,19 +164,27 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16" if adt == torch.bfloat16 else "f32", "data": "synthetic",
             "config": {"workload": "wav2vec2-base + AAM-softmax(5994), mean+std pooling, 3 s synthetic audio, "
-                                   "bs=66 per GPU, CNN frozen, fwd+bwd+all-reduce+Adam (BASELINE configs[1])",
+                                   f"bs={args.batch} per GPU, CNN {'trainable' if args.unfreeze_cnn else 'frozen'}, "
+                                   "fwd+bwd+all-reduce+Adam (BASELINE configs[1])",
                        "global_batch": args.batch * world, "samples_per_utt": n_samples,
                        "parallelism": f"dp{world}", "regularisation": not args.no_regularisation,
                        "final_loss": round(float(loss), 4)},
             "utt_per_sec_per_gpu": round(utt / elapsed / world, 2),
-            "model_tflops_per_gpu": round(fl["train_frozen_cnn"] * utt / elapsed / world / 1e12, 2),
+            "model_tflops_per_gpu": round(fl["train_full" if args.unfreeze_cnn else "train_frozen_cnn"] * utt / elapsed
+                                          / world / 1e12, 2),
         }
         if prof["launches"]:
             ach = prof["flops"] / (prof["ms"] * 1e-3) / 1e12
+            traffic = None       # HBM bytes per launch from the PMC passes (profiles/r01_pmc_hbm_traffic.json)
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")))
+                traffic = pmc["kernels"]["gemm_bf16_glds3_kernel<unsigned short>"]["hbm_bytes_per_launch"]
+            except Exception:
+                pass
             out["roofline"] = {"bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
-                               "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
-                               "kernel": "gemm_bf16_kernel<4,4,false,false,bf16> (forward-layout GEMMs: conv1-6, "
-                                         "projection, QKV, out-proj, FFN1, FFN2)",
+                               "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic,
+                               "kernel": "gemm_bf16_glds3_kernel<bf16> (256x128x64 3-stage LDS-DMA MFMA GEMM: QKV, "
+                                         "out-proj, FFN1, FFN2 forward + every data-gradient product)",
                                "launches": prof["launches"], "avg_us": round(1e3 * prof["ms"] / prof["launches"], 2),
                                "avg_gflop_per_launch": round(prof["flops"] / prof["launches"] / 1e9, 3)}
         if not args.no_cpu_baseline:

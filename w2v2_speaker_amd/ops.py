@@ -90,6 +90,14 @@ class Gemm:
         self.kernel_class = ("bf16" if dt(A) == BF16 else "f32") + "_" + ("t" if transA else "n") + ("n" if transB else "t")
         self.narrow = N <= 64
         self.out_is_act = Cmat.dtype == torch.bfloat16
+        # mirrors the host dispatch of csrc/gemm.hip (w2v2_gemm): which kernel this descriptor launches
+        fast = (dt(A) == BF16 and not transA and not transB and K % 64 == 0 and K >= 64 and lda % 8 == 0 and ldb % 8 == 0)
+        if fast and N >= 768 and M >= 1024 and split_k <= 1 and not accumulate:
+            self.kernel_name = "gemm_bf16_glds3_kernel"
+        elif fast:
+            self.kernel_name = "gemm_bf16_glds_kernel"
+        else:
+            self.kernel_name = "gemm_bf16_kernel" if dt(A) == BF16 else "gemm_f32_kernel"
 
     _prof = None
 
@@ -109,7 +117,7 @@ class Gemm:
 
     def __call__(self) -> None:
         prof = Gemm._prof
-        if prof is not None and not self.narrow and prof["select"](self):
+        if prof is not None and prof["select"](self):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             rc = self._fn(self._ref, stream())
