@@ -462,6 +462,9 @@ __global__ __launch_bounds__(256) void attn_fwd2_kernel(const bf16_t* __restrict
   for (int qf = wave; qf < NF; qf += 4) {
     asm volatile("" ::: "memory");   // keep the K / V^T fragment loads inside the loop (LICM would hoist 240 VGPRs)
     const int q = qf * 16 + (lane & 15);
+    int g4 = g * 4;
+    asm volatile("" : "+v"(g4));          // opaque: no hoisting of the 40 per-column index / RNG-counter values
+    const uint64_t qbase = (uint64_t)(bh * Tn + q) * (uint64_t)Tn;
     bf16x8 qfr[2] = {lds_frag(Qs, qf * 16, 0, lane), lds_frag(Qs, qf * 16, 1, lane)};
     float s[NF][4];
     float mx = -INFINITY;
@@ -473,7 +476,7 @@ __global__ __launch_bounds__(256) void attn_fwd2_kernel(const bf16_t* __restrict
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(Ks, fj * 16, kk, lane), qfr[kk], acc, 0, 0, 0);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const int key = fj * 16 + g * 4 + j;
+        const int key = fj * 16 + g4 + j;
         s[fj][j] = key < Tn ? acc[j] * scale : -INFINITY;
         mx = fmaxf(mx, s[fj][j]);
       }
@@ -492,7 +495,7 @@ __global__ __launch_bounds__(256) void attn_fwd2_kernel(const bf16_t* __restrict
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         float pv = s[fj][j] * inv;
-        if (dp > 0.f) pv *= drop_scale(seed, (uint64_t)((bh * Tn + q) * Tn + fj * 16 + g * 4 + j), dp, inv_keep);
+        if (dp > 0.f) pv *= drop_scale(seed, qbase + (uint64_t)(fj * 16 + g4 + j), dp, inv_keep);
         s[fj][j] = pv;
       }
     f32x4 o[4];
@@ -650,6 +653,204 @@ __global__ __launch_bounds__(256) void attn_bwd2_kernel(const bf16_t* __restrict
   }
 }
 
+// ===================================================================================== v3 backward: tr-read, 2 workgroups / CU
+// The merged backward above keeps 4 row-major and 3 transposed LDS images (144 KiB): ONE workgroup of 4 waves
+// per CU, i.e. one wave per SIMD and every LDS / MFMA / exp latency exposed.  Here the contraction-side
+// operands (K for dQ, dO and Q for dV / dK) are read straight from the ROW-MAJOR images with the hardware
+// transpose read ds_read_b64_tr_b16 (16 lanes x 8 B = a 4(row) x 16(col) block, lane i receives column i), so
+// only K, V, Q, dO row-major remain: exactly 80 KiB -> two workgroups per CU (8 waves, 2 per SIMD).  dS / P are
+// consumed per 32-column block as soon as they exist (no [T] x 4 register arrays), delta goes through a
+// global scratch row (written in phase A, read in phase B of the same workgroup).
+typedef __attribute__((ext_vector_type(4))) short short4v_t;
+typedef __attribute__((address_space(3))) short4v_t lds_s4v_t;
+
+// MFMA operand fragment "columns d0..d0+15 x k-slots of 32-row block blk" from a row-major swizzled image.
+// The swizzle of the rows a lane touches depends on the lane only (16-row periodic, blocks of 32 rows), so the
+// address is  lane_off[d0/16] + blk * 2048 (+ 1024 for the second transposing read): four per-lane offsets
+// computed once, everything else a ds_read immediate.
+struct TrOff { int o[4]; };
+__device__ __forceinline__ TrOff tr_offsets(int lane) {
+  const int i = lane & 15, g = lane >> 4;
+  const int r = g * 4 + (i >> 2);                    // row within the 32-row block (first read; second = +16)
+  const int sw = (r & 7) ^ ((r >> 3) & 1);
+  TrOff t;
+#pragma unroll
+  for (int df = 0; df < 4; ++df) t.o[df] = r * 64 + (((2 * df + ((i & 3) >> 1)) ^ sw) << 3) + ((i & 1) << 2);
+  return t;
+}
+__device__ __forceinline__ bf16x8 lds_frag_tr(const bf16_t* img, const TrOff& t, int df, int blk) {
+  const bf16_t* p0 = img + t.o[df] + blk * 2048;
+  const short4v_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v_t*)p0);
+  const short4v_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v_t*)(p0 + 1024));
+  union { struct { short4v_t a, b; } s; bf16x8 v; } u;
+  u.s.a = lo;
+  u.s.b = hi;
+  return u.v;
+}
+
+template <int NF>
+__global__ __launch_bounds__(256, 2) void attn_bwd3_kernel(const bf16_t* __restrict__ qkv,
+                                                           const bf16_t* __restrict__ ctx,
+                                                           const bf16_t* __restrict__ dctx,
+                                                           const float* __restrict__ lse, bf16_t* __restrict__ dqkv,
+                                                           float* __restrict__ delta, int Tn, int heads, float scale,
+                                                           float dp, float inv_keep, uint64_t seed) {
+  constexpr int TP = NF * 16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16_t* Ks = reinterpret_cast<bf16_t*>(smem);   // row-major swizzled images [TP][64]
+  bf16_t* Vs = Ks + TP * 64;
+  bf16_t* Qs = Vs + TP * 64;
+  bf16_t* Os = Qs + TP * 64;                      // dO
+  const int b = blockIdx.y, h = blockIdx.x;
+  const int H = heads * HD;
+  const int64_t gs = 3 * (int64_t)H;
+  const bf16_t* qb = qkv + (int64_t)b * Tn * gs + h * HD;
+  const bf16_t* dob = dctx + (int64_t)b * Tn * H + h * HD;
+  const bf16_t* ob = ctx + (int64_t)b * Tn * H + h * HD;
+  const int64_t bh = (int64_t)b * heads + h;
+  {
+    BlkRegs<NF> ra, rb;
+    blk_load<NF>(ra, qb, gs, Tn);
+    blk_load<NF>(rb, qb + H, gs, Tn);
+    blk_store_rows<NF>(ra, Qs);
+    blk_store_rows<NF>(rb, Ks);
+    blk_load<NF>(ra, qb + 2 * H, gs, Tn);
+    blk_load<NF>(rb, dob, H, Tn);
+    blk_store_rows<NF>(ra, Vs);
+    blk_store_rows<NF>(rb, Os);
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
+  const float* lse_b = lse + bh * Tn;
+  float* del_b = delta + bh * Tn;
+  const TrOff troff = tr_offsets(lane);
+  __syncthreads();
+
+  // ---- phase A: waves own query fragments -> dQ, delta
+#pragma unroll 1
+  for (int qf = wave; qf < NF; qf += 4) {
+    asm volatile("" ::: "memory");
+    const int q = qf * 16 + (lane & 15);
+    bf16x8 qfr[2] = {lds_frag(Qs, qf * 16, 0, lane), lds_frag(Qs, qf * 16, 1, lane)};
+    bf16x8 dof[2] = {lds_frag(Os, qf * 16, 0, lane), lds_frag(Os, qf * 16, 1, lane)};
+    bf16x8 of[2];
+    reg_frag(of, ob, H, q, Tn, lane);
+    float dl = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dl += (float)dof[kk][e] * (float)of[kk][e];
+    dl = quad_sum(dl);
+    if (g == 0 && q < Tn) del_b[q] = dl;
+    const float l = q < Tn ? lse_b[q] : 0.f;
+    const uint64_t qbase = (uint64_t)(bh * Tn + q) * (uint64_t)Tn;
+    f32x4 o[4];
+#pragma unroll
+    for (int df = 0; df < 4; ++df) o[df] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < NF / 2; ++kb) {
+      asm volatile("" ::: "memory");      // bound the scheduler's load hoisting to one 32-key block
+      int g4 = g * 4;
+      asm volatile("" : "+v"(g4));        // opaque: keeps the per-column index / predicate / RNG-counter math of
+                                          // all 40 columns from being hoisted out of the fragment loop (and spilled)
+      float ds2[2][4];
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        const int fj = 2 * kb + hf;
+        f32x4 sa = {0.f, 0.f, 0.f, 0.f}, pa = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(Ks, fj * 16, kk, lane), qfr[kk], sa, 0, 0, 0);
+          pa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(Vs, fj * 16, kk, lane), dof[kk], pa, 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int key = fj * 16 + g4 + j;
+          const float p = (key < Tn && q < Tn) ? __expf(sa[j] * scale - l) : 0.f;
+          float dpv = pa[j];
+          if (dp > 0.f) dpv *= drop_scale(seed, qbase + (uint64_t)key, dp, inv_keep);
+          ds2[hf][j] = p * (dpv - dl) * scale;
+        }
+      }
+      const bf16x8 pf = pack_frag(ds2[0], ds2[1]);
+#pragma unroll
+      for (int df = 0; df < 4; ++df)
+        o[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag_tr(Ks, troff, df, kb), pf, o[df], 0, 0, 0);
+    }
+    if (q < Tn) store_row4x4(dqkv + ((int64_t)b * Tn + q) * gs + h * HD + g * 4, o);
+  }
+  __threadfence_block();
+  __syncthreads();          // delta of every query row of this (b, h) is visible to the workgroup
+
+  // ---- phase B: waves own key fragments -> dK, dV
+  // every wave keeps the (b, h)'s LSE and delta rows distributed over its lanes (3 VGPRs each: row r lives in
+  // lane r & 63, register r >> 6) and fetches the 4 values a fragment needs with cross-lane reads
+  constexpr int NR = (TP + 63) / 64;
+  float lse_r[NR], del_r[NR];
+#pragma unroll
+  for (int k2 = 0; k2 < NR; ++k2) {
+    const int r = k2 * 64 + lane;
+    lse_r[k2] = r < Tn ? lse_b[r] : 0.f;
+    del_r[k2] = r < Tn ? del_b[r] : 0.f;
+  }
+#pragma unroll 1
+  for (int kf = wave; kf < NF; kf += 4) {
+    asm volatile("" ::: "memory");
+    const int key = kf * 16 + (lane & 15);
+    bf16x8 kfr[2] = {lds_frag(Ks, kf * 16, 0, lane), lds_frag(Ks, kf * 16, 1, lane)};
+    bf16x8 vfr[2] = {lds_frag(Vs, kf * 16, 0, lane), lds_frag(Vs, kf * 16, 1, lane)};
+    f32x4 dv[4], dk[4];
+#pragma unroll
+    for (int df = 0; df < 4; ++df) { dv[df] = f32x4{0.f, 0.f, 0.f, 0.f}; dk[df] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int qb2 = 0; qb2 < NF / 2; ++qb2) {
+      asm volatile("" ::: "memory");
+      // opaque redefinition: the cross-lane reads below are loop-invariant in kf and would otherwise be hoisted
+      // out of the key-fragment loop as 80 live VGPRs
+#pragma unroll
+      for (int k2 = 0; k2 < NR; ++k2) asm volatile("" : "+v"(lse_r[k2]), "+v"(del_r[k2]));
+      int g4 = g * 4;
+      asm volatile("" : "+v"(g4));
+      float pt2[2][4], ds2[2][4];
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        const int fq = 2 * qb2 + hf;
+        f32x4 sa = {0.f, 0.f, 0.f, 0.f}, pa = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(Qs, fq * 16, kk, lane), kfr[kk], sa, 0, 0, 0);
+          pa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(Os, fq * 16, kk, lane), vfr[kk], pa, 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int q = fq * 16 + g4 + j;
+          const bool ok = q < Tn && key < Tn;
+          const float la = __shfl(lse_r[(fq * 16) >> 6], q & 63, 64);
+          const float da = __shfl(del_r[(fq * 16) >> 6], q & 63, 64);
+          const float p = ok ? __expf(sa[j] * scale - la) : 0.f;
+          float ms = 1.0f;
+          if (dp > 0.f) ms = drop_scale(seed, (uint64_t)(bh * Tn + q) * (uint64_t)Tn + (uint64_t)key, dp, inv_keep);
+          pt2[hf][j] = p * ms;
+          ds2[hf][j] = p * (pa[j] * ms - da) * scale;
+        }
+      }
+      const bf16x8 pf = pack_frag(pt2[0], pt2[1]);
+      const bf16x8 sf = pack_frag(ds2[0], ds2[1]);
+#pragma unroll
+      for (int df = 0; df < 4; ++df) {
+        dv[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag_tr(Os, troff, df, qb2), pf, dv[df], 0, 0, 0);
+        dk[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag_tr(Qs, troff, df, qb2), sf, dk[df], 0, 0, 0);
+      }
+    }
+    if (key < Tn) {
+      bf16_t* dstk = dqkv + ((int64_t)b * Tn + key) * gs + H + h * HD + g * 4;
+      store_row4x4(dstk, dk);
+      store_row4x4(dstk + H, dv);
+    }
+  }
+}
+
+template <int NF> static size_t bwd3_lds() { return (size_t)(4 * NF * 16 * 64) * 2; }
+
 template <int NF> static size_t fwd2_lds() { return (size_t)(2 * NF * 16 * 64 + 64 * (NF * 16 + 4)) * 2; }
 template <int NF> static size_t bwd2_lds() { return (size_t)(4 * NF * 16 * 64 + 3 * 64 * (NF * 16 + 4)) * 2 + 2 * NF * 16 * 4; }
 
@@ -671,7 +872,8 @@ static int attn_check(const char* nm, int B, int T, int heads, int d, int dtype,
   return 0;
 }
 
-static const bool g_attn_v1 = getenv("W2V2_ATTN_V1") != nullptr;   // A/B switch
+static const bool g_attn_v1 = getenv("W2V2_ATTN_V1") != nullptr;   // A/B switches
+static const bool g_attn_v2 = getenv("W2V2_ATTN_V2") != nullptr;
 
 #define ATTN_DISPATCH_SMALL(NFV, CALL)       \
   switch (NFV) {                             \
@@ -732,11 +934,21 @@ extern "C" int w2v2_attention_bwd(const void* qkv, const void* ctx, const void* 
   hipStream_t st = as_stream(stream);
   if (nf <= 10 && !g_attn_v1) {
     dim3 grid2(heads, B);
-    ATTN_DISPATCH_SMALL(nf, {
-      set_lds(attn_bwd2_kernel<NF>, bwd2_lds<NF>());
-      hipLaunchKernelGGL(attn_bwd2_kernel<NF>, grid2, dim3(256), bwd2_lds<NF>(), st, (const bf16_t*)qkv,
-                         (const bf16_t*)ctx, (const bf16_t*)dctx, lse, (bf16_t*)dqkv, T, heads, scale, drop_p, ik, seed);
-    });
+    if (g_attn_v2) {
+      ATTN_DISPATCH_SMALL(nf, {
+        set_lds(attn_bwd2_kernel<NF>, bwd2_lds<NF>());
+        hipLaunchKernelGGL(attn_bwd2_kernel<NF>, grid2, dim3(256), bwd2_lds<NF>(), st, (const bf16_t*)qkv,
+                           (const bf16_t*)ctx, (const bf16_t*)dctx, lse, (bf16_t*)dqkv, T, heads, scale, drop_p, ik,
+                           seed);
+      });
+    } else {
+      ATTN_DISPATCH_SMALL(nf, {
+        set_lds(attn_bwd3_kernel<NF>, bwd3_lds<NF>());
+        hipLaunchKernelGGL(attn_bwd3_kernel<NF>, grid2, dim3(256), bwd3_lds<NF>(), st, (const bf16_t*)qkv,
+                           (const bf16_t*)ctx, (const bf16_t*)dctx, lse, (bf16_t*)dqkv, delta, T, heads, scale, drop_p,
+                           ik, seed);
+      });
+    }
     W2V2_CHECK_LAUNCH("attention_bwd");
     return 0;
   }
