@@ -63,6 +63,8 @@ if not only or "wgrad" in only:
              (mk(I), mk(H), torch.zeros(I, H, device=dev), torch.zeros(I, device=dev)),
              (mk(H), mk(H), torch.zeros(H, H, device=dev), torch.zeros(H, device=dev)),
              (mk(3 * H), mk(H), torch.zeros(3 * H, H, device=dev), torch.zeros(3 * H, device=dev))]
+    if os.environ.get('W2V2_NO_DBIAS'):
+        probs = [(a, b, c, None) for a, b, c, _ in probs]
     wg = ops.WgradGroup(probs, M, Mp)
     for _ in range(3):
         wg()

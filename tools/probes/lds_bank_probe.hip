@@ -1,0 +1,115 @@
+// Which per-row XOR swizzles make the MFMA-fragment ds_read_b128 pattern (16 rows x 4 k-chunks of a
+// [row][64 bf16] tile, 128-B rows) conflict-free on gfx950?  Times every GF(2)-linear swizzle
+// s(row) : 4 bits -> 3 bits (4096 candidates) with one wave per candidate, plus reference patterns.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdint.h>
+#include <vector>
+#include <algorithm>
+__global__ void probe(const int* offs, unsigned long long* cycles, int iters) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int l = threadIdx.x & 63;
+  for (int i = threadIdx.x; i < 16384; i += 512) reinterpret_cast<int*>(lds)[i] = i;
+  __syncthreads();
+  const uint32_t addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds + offs[blockIdx.x * 64 + l];
+  uint4 v0, v1, v2, v3;
+  unsigned acc = 0;
+  const unsigned long long t0 = __builtin_readcyclecounter();
+  for (int it = 0; it < iters; ++it) {
+    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:2048\n\tds_read_b128 %2, %4 offset:4096\n\t"
+                 "ds_read_b128 %3, %4 offset:6144\n\t"
+                 "ds_read_b128 %0, %4 offset:8192\n\tds_read_b128 %1, %4 offset:10240\n\tds_read_b128 %2, %4 offset:12288\n\t"
+                 "ds_read_b128 %3, %4 offset:14336\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3) : "v"(addr) : "memory");
+    acc += v0.x + v1.y + v2.z + v3.w;
+  }
+  const unsigned long long t1 = __builtin_readcyclecounter();
+  if (threadIdx.x == 0) cycles[blockIdx.x] = t1 - t0 + (acc == 0x12345u);
+}
+__global__ void probe_tr(const int* offs, unsigned long long* cycles, int iters) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int l = threadIdx.x & 63;
+  for (int i = threadIdx.x; i < 16384; i += 512) reinterpret_cast<int*>(lds)[i] = i;
+  __syncthreads();
+  const uint32_t addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds + offs[blockIdx.x * 64 + l];
+  uint2 v0, v1, v2, v3;
+  unsigned acc = 0;
+  const unsigned long long t0 = __builtin_readcyclecounter();
+  for (int it = 0; it < iters; ++it) {
+    asm volatile("ds_read_b64_tr_b16 %0, %4\n\tds_read_b64_tr_b16 %1, %4 offset:2048\n\tds_read_b64_tr_b16 %2, %4 offset:4096\n\t"
+                 "ds_read_b64_tr_b16 %3, %4 offset:6144\n\t"
+                 "ds_read_b64_tr_b16 %0, %4 offset:8192\n\tds_read_b64_tr_b16 %1, %4 offset:10240\n\tds_read_b64_tr_b16 %2, %4 offset:12288\n\t"
+                 "ds_read_b64_tr_b16 %3, %4 offset:14336\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3) : "v"(addr) : "memory");
+    acc += v0.x + v1.y + v2.x + v3.y;
+  }
+  const unsigned long long t1 = __builtin_readcyclecounter();
+  if (threadIdx.x == 0) cycles[blockIdx.x] = t1 - t0 + (acc == 0x12345u);
+}
+static int parity(int x) { return __builtin_popcount(x) & 1; }
+int main() {
+  std::vector<int> offs;
+  std::vector<int> id;
+  auto add = [&](auto f, int tag) { for (int l = 0; l < 64; ++l) offs.push_back(f(l)); id.push_back(tag); };
+  add([](int l) { return l * 16; }, -1);                                                            // linear
+  add([](int l) { int r = l & 15, k = l >> 4; return r * 128 + k * 16; }, -2);                      // no swizzle
+  add([](int l) { int r = l & 15, k = l >> 4; return r * 128 + ((k ^ ((r & 7) ^ ((r >> 3) & 1))) << 4); }, -3);  // current
+  add([](int l) { int r = l & 15, k = l >> 4; int s = ((r >> 1) & 1) | (((r >> 2) & 1) << 2); return r * 128 + ((k ^ s) << 4); }, -4);
+  for (int m = 0; m < 4096; ++m)   // rows of the 3x4 matrix: bit b of s = parity(mask_b & row)
+    add([m](int l) { int r = l & 15, k = l >> 4;
+                     int s = parity((m & 15) & r) | (parity(((m >> 4) & 15) & r) << 1) | (parity(((m >> 8) & 15) & r) << 2);
+                     return r * 128 + ((k ^ s) << 4); }, m);
+  const int n = (int)id.size();
+  int* d; unsigned long long* c;
+  hipMalloc(&d, offs.size() * 4); hipMalloc(&c, n * 8);
+  hipMemcpy(d, offs.data(), offs.size() * 4, hipMemcpyHostToDevice);
+  const int iters = 2000;
+  for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL(probe, dim3(n), dim3(512), 65536, 0, d, c, iters);
+  std::vector<unsigned long long> h(n);
+  hipMemcpy(h.data(), c, n * 8, hipMemcpyDeviceToHost);
+  auto per = [&](int i) { return (double)h[i] / (iters * 64.0); };
+  printf("linear %.2f  none %.2f  current %.2f  h2-design %.2f  (counter ticks per ds_read_b128, 8 waves x 8 reads in flight)\n", per(0), per(1), per(2), per(3));
+  std::vector<std::pair<double, int>> r;
+  for (int i = 4; i < n; ++i) r.push_back({per(i), id[i]});
+  std::sort(r.begin(), r.end());
+  printf("best linear swizzles (ticks, masks b0 b1 b2):\n");
+  for (int i = 0; i < 4; ++i) printf("  %.2f  %x %x %x\n", r[i].first, r[i].second & 15, (r[i].second >> 4) & 15, (r[i].second >> 8) & 15);
+  printf("simplest conflict-free maps (total mask popcount <= 4):\n");
+  for (auto& p : r) {
+    const int pc = __builtin_popcount(p.second);
+    if (p.first < r[0].first * 1.05 && pc <= 4)
+      printf("  %.2f  b0=%x b1=%x b2=%x\n", p.first, p.second & 15, (p.second >> 4) & 15, (p.second >> 8) & 15);
+  }
+  // second pattern on the same image: transposing 8-byte reads (attention backward): lane (i, g) -> row g*4 + i/4,
+  // 16-byte chunk (i%4)/2, 8-byte half i%2
+  {
+    std::vector<int> o2;
+    for (int m = 0; m < 4096; ++m)
+      for (int l = 0; l < 64; ++l) {
+        const int i = l & 15, g = l >> 4, rr = g * 4 + (i >> 2);
+        const int sv = parity((m & 15) & rr) | (parity(((m >> 4) & 15) & rr) << 1) | (parity(((m >> 8) & 15) & rr) << 2);
+        o2.push_back(rr * 128 + ((((i & 3) >> 1) ^ sv) << 4) + ((i & 1) << 3));
+      }
+    int* d2; unsigned long long* c2;
+    hipMalloc(&d2, o2.size() * 4); hipMalloc(&c2, 4096 * 8);
+    hipMemcpy(d2, o2.data(), o2.size() * 4, hipMemcpyHostToDevice);
+    for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL(probe_tr, dim3(4096), dim3(512), 65536, 0, d2, c2, iters);
+    std::vector<unsigned long long> h2(4096);
+    hipMemcpy(h2.data(), c2, 4096 * 8, hipMemcpyDeviceToHost);
+    double best2 = 1e30, cur2 = 0;
+    for (int m = 0; m < 4096; ++m) best2 = std::min(best2, (double)h2[m] / (iters * 64.0));
+    cur2 = (double)h2[9 | (2 << 4) | (4 << 8)] / (iters * 64.0);
+    printf("tr-read pattern: best %.2f ticks, textbook map %.2f, map(0,2,8) %.2f\n", best2, cur2, (double)h2[0 | (2 << 4) | (8 << 8)] / (iters * 64.0));
+    printf("maps conflict-free for BOTH patterns (popcount <= 5):\n");
+    for (auto& p : r) {
+      const double t2 = (double)h2[p.second] / (iters * 64.0);
+      if (p.first < r[0].first * 1.05 && t2 < best2 * 1.05 && __builtin_popcount(p.second) <= 5)
+        printf("  b128 %.2f tr %.2f  b0=%x b1=%x b2=%x\n", p.first, t2, p.second & 15, (p.second >> 4) & 15, (p.second >> 8) & 15);
+    }
+  }
+  int nbest = 0; for (auto& p : r) if (p.first < r[0].first * 1.05) nbest++;
+  printf("%d of 4096 within 5%% of the best; worst %.2f\n", nbest, r.back().first);
+  // is the current swizzle family member? s = (r&7)^((r>>3)&1): b0 = r0^r3 (mask 9), b1 = r1 (2), b2 = r2 (4)
+  for (auto& p : r) if (p.second == (9 | (2 << 4) | (4 << 8))) printf("current as linear map: %.2f\n", p.first);
+  return 0;
+}

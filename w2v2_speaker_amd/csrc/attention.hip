@@ -27,7 +27,7 @@ constexpr int HD = 64;  // head dim
 
 // 16-row periodic: all fragments of an image share one per-lane swizzle, so fragment addresses are
 // lane base + compile-time constant (ds_read offset immediates instead of one address VGPR each)
-__device__ __forceinline__ int aswz(int row) { return (row & 7) ^ ((row >> 3) & 1); }
+__device__ __forceinline__ int aswz(int row) { return ((row ^ (row >> 1)) & 3) | (row & 4); }   // measured map, see gemm.hip swz()
 
 __device__ __forceinline__ bf16x8 as_frag(uint4 v) {
   union { uint4 u; bf16x8 f; } c;
@@ -672,7 +672,7 @@ struct TrOff { int o[4]; };
 __device__ __forceinline__ TrOff tr_offsets(int lane) {
   const int i = lane & 15, g = lane >> 4;
   const int r = g * 4 + (i >> 2);                    // row within the 32-row block (first read; second = +16)
-  const int sw = (r & 7) ^ ((r >> 3) & 1);
+  const int sw = aswz(r);
   TrOff t;
 #pragma unroll
   for (int df = 0; df < 4; ++df) t.o[df] = r * 64 + (((2 * df + ((i & 3) >> 1)) ^ sw) << 3) + ((i & 1) << 2);

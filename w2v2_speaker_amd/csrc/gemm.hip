@@ -58,7 +58,15 @@ __device__ __forceinline__ int64_t outer_off(const OpDev& o, int64_t idx) {
 
 // depends on (row & 15) only: every 16-row MFMA fragment of a tile shares one per-lane swizzle, so the
 // fragment addresses of a wave differ by compile-time constants (ds_read offset immediates)
-__device__ __forceinline__ int swz(int row) { return (row & 7) ^ ((row >> 3) & 1); }
+// Measured on gfx950 (tools/probes/lds_bank_probe.hip times all 4096 GF(2)-linear row->chunk maps): with this
+// map the fragment ds_read_b128 pattern (16 rows x 4 k-chunks, 128-B rows) issues at the conflict-free
+// 4 clk/instruction AND the transposing ds_read_b64_tr_b16 pattern of the attention backward at 2.4 clk (best
+// found 2.3).  The textbook (row & 7) XOR costs 7 clk resp. 4 clk: the 64 x 4-B banks serve 16-byte accesses
+// in lane groups that are not 16 consecutive lanes, so "8 rows -> 8 chunks" is not enough.
+__device__ __forceinline__ int swz(int row) { return ((row ^ (row >> 1)) & 3) | (row & 4); }
+// The register-staged kernel also WRITES its image with transposing 8-byte stores (K-major operands), whose
+// conflicts the map above doubles (TT weight-gradient products 332 -> 389 us); it keeps the textbook map.
+__device__ __forceinline__ int swz_rs(int row) { return (row & 7) ^ ((row >> 3) & 1); }
 
 // ------------------------------------------------------------------------------ epilogue (shared)
 template <typename TC>
@@ -361,7 +369,7 @@ struct Stager {
       for (int j = 0; j < NV; ++j) {
         const int c = tid + 256 * j;
         const int row = c >> 3, kc = c & 7;
-        *reinterpret_cast<uint4*>(lds + row * 64 + ((kc ^ swz(row)) << 3)) = v[j];
+        *reinterpret_cast<uint4*>(lds + row * 64 + ((kc ^ swz_rs(row)) << 3)) = v[j];
       }
     } else {
       const int nblk = R * 2;
@@ -384,7 +392,7 @@ struct Stager {
         }
         const int row = mb * 8 + mi;
         const int chunk = kb >> 1, half = kb & 1;
-        *reinterpret_cast<uint2*>(lds + row * 64 + ((chunk ^ swz(row)) << 3) + half * 4) = o2;
+        *reinterpret_cast<uint2*>(lds + row * 64 + ((chunk ^ swz_rs(row)) << 3) + half * 4) = o2;
       }
     }
   }
@@ -464,12 +472,12 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmArgs g) {
 #pragma unroll
       for (int i = 0; i < FM; ++i) {
         const int row = wm * (16 * FM) + i * 16 + frow;
-        af[i] = *reinterpret_cast<const bf16x8*>(Ac + row * 64 + (((kk * 4 + fk) ^ swz(row)) << 3));
+        af[i] = *reinterpret_cast<const bf16x8*>(Ac + row * 64 + (((kk * 4 + fk) ^ swz_rs(row)) << 3));
       }
 #pragma unroll
       for (int j = 0; j < FN; ++j) {
         const int row = wn * (16 * FN) + j * 16 + frow;
-        bfr[j] = *reinterpret_cast<const bf16x8*>(Bc + row * 64 + (((kk * 4 + fk) ^ swz(row)) << 3));
+        bfr[j] = *reinterpret_cast<const bf16x8*>(Bc + row * 64 + (((kk * 4 + fk) ^ swz_rs(row)) << 3));
       }
 #pragma unroll
       for (int i = 0; i < FM; ++i)

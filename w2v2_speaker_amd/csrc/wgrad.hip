@@ -13,8 +13,11 @@
 // Contract: token rows [tokens, tokens_padded) of every operand are readable and ZERO
 // (tokens_padded = tokens rounded up to 64); n_out, n_in multiples of 8; 16-byte aligned rows.
 #include "common.cuh"
+#include <stdlib.h>
+#include <type_traits>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 typedef __attribute__((ext_vector_type(4))) short short4v;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((address_space(1))) const void gvoid_t;
@@ -186,12 +189,225 @@ __global__ __launch_bounds__(256) void wgrad_grouped_kernel(const WgArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------ 256 x 128 ring kernel
+// Same data path (LDS-DMA in natural [k][m] layout + ds_read_b64_tr_b16 fragments), but a 256(n_out) x
+// 128(n_in) x 64(tokens) block tile for 8 waves (4 x 2, 64 x 64 per wave) on the 3-stage LDS ring of
+// gemm_bf16_glds3_kernel: while tile t is multiplied, tiles t+1 and t+2 are in flight; per K tile one raw
+// s_barrier and `s_waitcnt vmcnt(6)` (6 = this wave's DMA pieces per stage: 4 x [2 rows x 512 B] of dY,
+// 2 x [4 rows x 256 B] of X).  The four Linear layers of a w2v2-base block are 216 tiles = one round on 256 CUs.
+template <int S> __device__ __forceinline__ void wg_wait_vmcnt() {
+  if constexpr (S == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+}
+
+__global__ __launch_bounds__(512) void wgrad_grouped_ring_kernel(const WgArgs a) {
+  constexpr int BM = 256, BN = 128;
+  constexpr int STAGE = 64 * (BM + BN);             // elements per stage: A [64][256] then B [64][128]
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // 0..7
+  const int wm = wave >> 1, wn = wave & 1;
+
+  int tile;
+  {
+    const int nwg = a.total_tiles, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  }
+  int pi = 0;
+#pragma unroll
+  for (int i = 1; i < WG_MAXP; ++i)
+    if (i < a.n_problems && tile >= a.p[i].tile_begin) pi = i;
+  const WgProblem& P = a.p[pi];
+  const int t = tile - P.tile_begin;
+  const int tm = t / P.tiles_n, tn = t - tm * P.tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  // DMA sources.  A: piece j of a wave = token rows (wave*4 + j)*2 + {0,1}, 32 chunks of 16 B per row;
+  //              B: piece j of a wave = token rows (wave*2 + j)*4 + {0..3}, 16 chunks per row.
+  const bf16_t* ap[4];
+  const bf16_t* bp[2];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int r = (wave * 4 + j) * 2 + (lane >> 5);
+    const int c = (lane & 31) ^ (wg_f(r) << 1);
+    const int mc = min(m0 + c * 8, P.n_out - 8);
+    ap[j] = P.dY + (int64_t)r * P.ld_dy + mc;
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int r = (wave * 2 + j) * 4 + (lane >> 4);
+    const int c = (lane & 15) ^ (wg_f(r) << 1);
+    const int nc = min(n0 + c * 8, P.n_in - 8);
+    bp[j] = P.X + (int64_t)r * P.ld_x + nc;
+  }
+  const int64_t astep = 64 * P.ld_dy, bstep = 64 * P.ld_x;
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // dbias[m] = sum_t dY[t][m]: the waves of n-tile 0 / wn 0 add up the dY fragments they hold anyway, two bf16 per
+  // v_dot2c_f32_bf16 against (1, 1) -- 4 VALU ops per fragment instead of 16 converts+adds
+  float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+  const bool do_bias = (P.dbias != nullptr) && tn == 0 && wn == 0;
+  bf16x2 one2;
+  one2[0] = (__bf16)1.0f;
+  one2[1] = (__bf16)1.0f;
+
+  auto stage = [&](bf16_t* base, int kt) {
+    bf16_t* ad = base + wave * 8 * BM;
+    bf16_t* bd = base + 64 * BM + wave * 8 * BN;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      __builtin_amdgcn_global_load_lds((gvoid_t*)(ap[j] + kt * astep), (lvoid_t*)(ad + j * 2 * BM), 16, 0, 0);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      __builtin_amdgcn_global_load_lds((gvoid_t*)(bp[j] + kt * bstep), (lvoid_t*)(bd + j * 4 * BN), 16, 0, 0);
+  };
+  // per-lane fragment byte offsets: row (g*8 + i/4), 8-byte piece (i%4), physical segment (seg ^ f) with
+  // seg = w*4 + x (x = 0..3 compile time) and f = (i/4) | ((g&1) << 2)  ->  ((w ^ f>>2) << 2) | (x ^ (f&3)).
+  // The transposing reads are issued as inline asm: the compiler treats the ds_read_tr builtin as possibly
+  // aliasing the LDS-DMA writes in flight and would put `s_waitcnt vmcnt(0)` in front of every group of
+  // reads, draining the ring.  Which stage is being read vs written is guaranteed by the ring protocol.
+  const int li = lane & 15, lg = lane >> 4;
+  const int fr = lg * 8 + (li >> 2);
+  const int flo = (li >> 2), fhi = lg & 1;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem_raw;
+  uint32_t aoff[4], boff[4];
+#pragma unroll
+  for (int x = 0; x < 4; ++x) {
+    aoff[x] = lds0 + 2u * (fr * BM + (((((wm ^ fhi) & 3) << 2) | (x ^ flo)) << 4) + ((li & 3) << 2));
+    boff[x] = lds0 + 2u * (64 * BM + fr * BN + (((((wn ^ fhi) & 1) << 2) | (x ^ flo)) << 4) + ((li & 3) << 2));
+  }
+  union Frag { struct { short4v a, b; } s; bf16x8 v; };
+#define W2V2_TR_READ(dst, addr, OFF) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:" #OFF : "=v"(dst) : "v"(addr) : "memory")
+#define W2V2_FRAG_A(f, addr, KK)                                   \
+  if (KK == 0) { W2V2_TR_READ(f.s.a, addr, 0);     W2V2_TR_READ(f.s.b, addr, 2048); }  \
+  else         { W2V2_TR_READ(f.s.a, addr, 16384); W2V2_TR_READ(f.s.b, addr, 18432); }
+#define W2V2_FRAG_B(f, addr, KK)                                   \
+  if (KK == 0) { W2V2_TR_READ(f.s.a, addr, 0);    W2V2_TR_READ(f.s.b, addr, 1024); }   \
+  else         { W2V2_TR_READ(f.s.a, addr, 8192); W2V2_TR_READ(f.s.b, addr, 9216); }
+  static_assert(4 * BM * 2 == 2048 && 32 * BM * 2 == 16384 && 4 * BN * 2 == 1024 && 32 * BN * 2 == 8192, "offsets");
+  auto landed = [&](Frag (&f)[4]) {   // LDS returns in order: all reads issued so far have landed after this
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[i].s.a), "+v"(f[i].s.b));
+  };
+  auto mma = [&](Frag (&af)[4], Frag (&bfr)[4]) {
+    if (do_bias) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        union { bf16x8 v; bf16x2 p[4]; } u;
+        u.v = af[i].v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bsum[i] = __builtin_amdgcn_fdot2_f32_bf16(u.p[e], one2, bsum[i], false);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j].v, af[i].v, acc[i][j], 0, 0, 0);
+  };
+  auto compute = [&](uint32_t sbytes) {
+    uint32_t aa[4], ba[4];
+#pragma unroll
+    for (int x = 0; x < 4; ++x) { aa[x] = aoff[x] + sbytes; ba[x] = boff[x] + sbytes; }
+    Frag a0[4], b0[4], a1[4], b1[4];
+#pragma unroll
+    for (int x = 0; x < 4; ++x) { W2V2_FRAG_A(a0[x], aa[x], 0) }
+#pragma unroll
+    for (int x = 0; x < 4; ++x) { W2V2_FRAG_B(b0[x], ba[x], 0) }
+    landed(a0);
+    landed(b0);
+#pragma unroll
+    for (int x = 0; x < 4; ++x) { W2V2_FRAG_A(a1[x], aa[x], 1) }
+#pragma unroll
+    for (int x = 0; x < 4; ++x) { W2V2_FRAG_B(b1[x], ba[x], 1) }
+    __builtin_amdgcn_sched_barrier(0);   // k-step 1 reads are in flight under the MFMAs of k-step 0 ...
+    mma(a0, b0);
+    __builtin_amdgcn_sched_barrier(0);   // ... and their wait comes after those MFMAs
+    landed(a1);
+    landed(b1);
+    mma(a1, b1);
+  };
+  const int nk = a.ktiles;
+#define W2V2_WG_RING_STEP(cur, nxt)                                      \
+  {                                                                      \
+    if (kt + 1 < nk) wg_wait_vmcnt<6>(); else wg_wait_vmcnt<0>();        \
+    __builtin_amdgcn_s_barrier();                                        \
+    if (kt + 2 < nk) stage(smem + (nxt) * STAGE, kt + 2);                \
+    compute((cur) * STAGE * 2u);                                         \
+    ++kt;                                                                \
+  }
+  if (nk > 0) stage(smem, 0);
+  if (nk > 1) stage(smem + STAGE, 1);
+  int kt = 0;
+  while (kt < nk) {
+    W2V2_WG_RING_STEP(0, 2)
+    if (kt >= nk) break;
+    W2V2_WG_RING_STEP(1, 0)
+    if (kt >= nk) break;
+    W2V2_WG_RING_STEP(2, 1)
+  }
+#undef W2V2_WG_RING_STEP
+#undef W2V2_FRAG_A
+#undef W2V2_FRAG_B
+#undef W2V2_TR_READ
+
+  if (do_bias) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float s = bsum[i];
+      s += __shfl_xor(s, 16, 64);
+      s += __shfl_xor(s, 32, 64);
+      const int m = m0 + wm * 64 + i * 16 + (lane & 15);
+      if ((lane >> 4) == 0 && m < P.n_out) P.dbias[m] = s;
+    }
+  }
+  // coalesced f32 tile store through LDS: two passes of 128 rows
+  float* stagef = reinterpret_cast<float*>(smem_raw);
+  constexpr int PITCH = BN + 4;
+  const int frow = lane & 15, fk = lane >> 4;
+#pragma unroll 1
+  for (int pass = 0; pass < 2; ++pass) {
+    __syncthreads();
+    if ((wm >> 1) == pass) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          *reinterpret_cast<float4*>(stagef + ((wm & 1) * 64 + i * 16 + frow) * PITCH + wn * 64 + j * 16 + fk * 4) =
+              make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int c = tid + 512 * it;                 // 128 rows x 32 float4 chunks
+      const int r = c >> 5, ch = c & 31;
+      const int m = m0 + pass * 128 + r, n = n0 + ch * 4;
+      if (m < P.n_out && n + 4 <= P.n_in)
+        *reinterpret_cast<float4*>(P.dW + (int64_t)m * P.ld_dw + n) =
+            *reinterpret_cast<const float4*>(stagef + r * PITCH + ch * 4);
+    }
+  }
+}
+
+
 extern "C" int w2v2_wgrad_grouped(const w2v2_wgrad_problem* probs, int n, int tokens, int tokens_padded, void* stream) {
   W2V2_REQUIRE(probs && n > 0 && n <= WG_MAXP, "wgrad_grouped: need 1..%d problems", WG_MAXP);
   W2V2_REQUIRE(tokens > 0 && tokens_padded >= tokens && tokens_padded % 64 == 0,
                "wgrad_grouped: tokens_padded must be tokens rounded up to a multiple of 64");
   WgArgs a;
   int tiles = 0;
+  // 256-row ring kernel unless every problem is narrower than one 256-row tile (or W2V2_WGRAD_V1 is set)
+  int max_out = 0;
+  for (int i = 0; i < n; ++i) max_out = probs[i].n_out > max_out ? probs[i].n_out : max_out;
+  const bool ring = max_out > 128 && getenv("W2V2_WGRAD_V1") == nullptr;
+  const int bm = ring ? 256 : 128;
   for (int i = 0; i < n; ++i) {
     const w2v2_wgrad_problem& q = probs[i];
     W2V2_REQUIRE(q.dY && q.X && q.dW, "wgrad_grouped: null operand in problem %d", i);
@@ -207,20 +423,31 @@ extern "C" int w2v2_wgrad_grouped(const w2v2_wgrad_problem* probs, int n, int to
     P.n_out = q.n_out; P.n_in = q.n_in;
     P.tiles_n = (int)cdiv(q.n_in, 128);
     P.tile_begin = tiles;
-    tiles += (int)cdiv(q.n_out, 128) * P.tiles_n;
+    tiles += (int)cdiv(q.n_out, bm) * P.tiles_n;
   }
   for (int i = n; i < WG_MAXP; ++i) a.p[i] = a.p[0];
   a.n_problems = n;
   a.total_tiles = tiles;
   a.ktiles = tokens_padded / 64;
-  constexpr size_t lds = (size_t)2 * 2 * 64 * 128 * sizeof(bf16_t);   // 64 KiB
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_grouped_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
+  if (ring) {
+    constexpr size_t lds = (size_t)3 * 64 * (256 + 128) * sizeof(bf16_t);   // 144 KiB
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_grouped_ring_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(wgrad_grouped_ring_kernel, dim3(tiles), dim3(512), lds, as_stream(stream), a);
+  } else {
+    constexpr size_t lds = (size_t)2 * 2 * 64 * 128 * sizeof(bf16_t);   // 64 KiB
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_grouped_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(wgrad_grouped_kernel, dim3(tiles), dim3(256), lds, as_stream(stream), a);
   }
-  hipLaunchKernelGGL(wgrad_grouped_kernel, dim3(tiles), dim3(256), lds, as_stream(stream), a);
   W2V2_CHECK_LAUNCH("wgrad_grouped");
   return 0;
 }
