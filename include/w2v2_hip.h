@@ -116,6 +116,11 @@ int w2v2_wgrad_grouped(const w2v2_wgrad_problem* problems, int n, int tokens, in
 int w2v2_conv0_workspace_floats(int N, int C, int k, int stride);
 int w2v2_conv0_stats(const float* wav, const float* w /*[C][k]*/, float* partial, float* mean_rstd,
                      int B, int N, int C, int k, int stride, float eps, void* stream);
+/* Statistics of the matrix-core convolution that w2v2_conv0_apply uses for bf16 outputs (x and w split into
+ * bf16 hi+lo pairs, xh.wh + xh.wl + xl.wh in one K=32 MFMA, relative error ~2^-16); same arguments and
+ * workspace as w2v2_conv0_stats, which it calls for shapes outside C % 128 == 0, 3k <= 32. */
+int w2v2_conv0_stats_mfma(const float* wav, const float* w, float* partial, float* mean_rstd,
+                          int B, int N, int C, int k, int stride, float eps, void* stream);
 int w2v2_conv0_apply(const float* wav, const float* w, const float* mean_rstd, const float* gamma,
                      const float* beta, void* y, int dtype, int B, int N, int C, int k, int stride,
                      void* stream);

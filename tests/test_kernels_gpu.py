@@ -181,6 +181,36 @@ def test_conv0_groupnorm_gelu(dtype):
     assert rel_l2(out.float().cpu(), ref) < (2e-6 if dtype == torch.float32 else 4e-3)
 
 
+@pytest.mark.parametrize("C,N", [(128, 4000), (512, 3333), (640, 1291)])
+def test_conv0_matrix_core_path(C, N):
+    """bf16 outputs with C % 128 == 0 take the split-bf16 MFMA convolution (conv0.hip): f32-class statistics
+    (mean / rstd within 1e-5 of the f64 reference), ragged tail chunk, several channel groups per wave."""
+    o = ops()
+    B, k, s = 2, 10, 5
+    wav = rnd(B, N, seed=11)
+    w = rnd(C, 1, k, seed=12, scale=0.4)
+    gamma, beta = 1 + 0.1 * rnd(C, seed=13), 0.1 * rnd(C, seed=14)
+    u = torch.nn.functional.conv1d(wav[:, None].double(), w.double(), stride=s)          # [B, C, L]
+    ref = gelu(torch.nn.functional.group_norm(u, C, gamma.double(), beta.double(), eps=1e-5)).transpose(1, 2)
+    L = ref.shape[1]
+    out = torch.zeros(B, L, C, dtype=torch.bfloat16, device=DEV)
+    work = o.conv0_workspace(B, N, C, k, s, DEV)
+    o.conv0_groupnorm_gelu(wav.to(DEV), w.to(DEV), gamma.to(DEV), beta.to(DEV), out, work, k, s)
+    torch.cuda.synchronize()
+    mr = work[work.numel() - B * C * 2:].view(B, C, 2).cpu().double()
+    mean_ref, var_ref = u.mean(dim=2), u.var(dim=2, unbiased=False)
+    # split-bf16 products carry ~2^-16 relative error per output: the mean over L frames sees its random walk
+    assert (mr[..., 0] - mean_ref).abs().max() < 4 * 2.0 ** -16 * u.abs().max() / L ** 0.5
+    assert ((mr[..., 1] - (var_ref + 1e-5).rsqrt()) / (var_ref + 1e-5).rsqrt()).abs().max() < 2e-5
+    assert rel_l2(out.float().cpu(), ref) < 4e-3
+    # against the exact-f32 VALU kernel rounded to bf16: at most an occasional one-ulp flip
+    out32 = torch.zeros(B, L, C, dtype=torch.float32, device=DEV)
+    o.conv0_groupnorm_gelu(wav.to(DEV), w.to(DEV), gamma.to(DEV), beta.to(DEV), out32, work, k, s)
+    torch.cuda.synchronize()
+    d = (out.float() - out32.to(torch.bfloat16).float()).abs().cpu()
+    assert (d > 0).float().mean() < 0.02 and rel_l2(out.float().cpu(), out32.cpu().double()) < 3e-3
+
+
 # ----------------------------------------------------------------------------------------------- LayerNorm
 @pytest.mark.parametrize("dtype,H", [(torch.float32, 768), (torch.bfloat16, 768), (torch.float32, 64),
                                      (torch.bfloat16, 1024), (torch.float32, 512)])

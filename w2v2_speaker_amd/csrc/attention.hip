@@ -36,10 +36,10 @@ __device__ __forceinline__ bf16x8 as_frag(uint4 v) {
 }
 __device__ __forceinline__ bf16x8 pack_frag(const float a[4], const float b[4]) {
   uint4 v;
-  v.x = (uint32_t)f32_to_bf16(a[0]) | ((uint32_t)f32_to_bf16(a[1]) << 16);
-  v.y = (uint32_t)f32_to_bf16(a[2]) | ((uint32_t)f32_to_bf16(a[3]) << 16);
-  v.z = (uint32_t)f32_to_bf16(b[0]) | ((uint32_t)f32_to_bf16(b[1]) << 16);
-  v.w = (uint32_t)f32_to_bf16(b[2]) | ((uint32_t)f32_to_bf16(b[3]) << 16);
+  v.x = f32x2_to_bf16x2(a[0], a[1]);
+  v.y = f32x2_to_bf16x2(a[2], a[3]);
+  v.z = f32x2_to_bf16x2(b[0], b[1]);
+  v.w = f32x2_to_bf16x2(b[2], b[3]);
   return as_frag(v);
 }
 
@@ -179,8 +179,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
 #pragma unroll
     for (int df = 0; df < 4; ++df) {
       uint2 w;
-      w.x = (uint32_t)f32_to_bf16(o[df][0]) | ((uint32_t)f32_to_bf16(o[df][1]) << 16);
-      w.y = (uint32_t)f32_to_bf16(o[df][2]) | ((uint32_t)f32_to_bf16(o[df][3]) << 16);
+      w.x = f32x2_to_bf16x2(o[df][0], o[df][1]);
+      w.y = f32x2_to_bf16x2(o[df][2], o[df][3]);
       *reinterpret_cast<uint2*>(dst + df * 16) = w;
     }
   }
@@ -259,8 +259,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
 #pragma unroll
     for (int df = 0; df < 4; ++df) {
       uint2 w;
-      w.x = (uint32_t)f32_to_bf16(o[df][0]) | ((uint32_t)f32_to_bf16(o[df][1]) << 16);
-      w.y = (uint32_t)f32_to_bf16(o[df][2]) | ((uint32_t)f32_to_bf16(o[df][3]) << 16);
+      w.x = f32x2_to_bf16x2(o[df][0], o[df][1]);
+      w.y = f32x2_to_bf16x2(o[df][2], o[df][3]);
       *reinterpret_cast<uint2*>(dst + df * 16) = w;
     }
   }
@@ -344,11 +344,11 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const bf16_t* __restri
 #pragma unroll
     for (int df = 0; df < 4; ++df) {
       uint2 w;
-      w.x = (uint32_t)f32_to_bf16(dk[df][0]) | ((uint32_t)f32_to_bf16(dk[df][1]) << 16);
-      w.y = (uint32_t)f32_to_bf16(dk[df][2]) | ((uint32_t)f32_to_bf16(dk[df][3]) << 16);
+      w.x = f32x2_to_bf16x2(dk[df][0], dk[df][1]);
+      w.y = f32x2_to_bf16x2(dk[df][2], dk[df][3]);
       *reinterpret_cast<uint2*>(dstk + df * 16) = w;
-      w.x = (uint32_t)f32_to_bf16(dv[df][0]) | ((uint32_t)f32_to_bf16(dv[df][1]) << 16);
-      w.y = (uint32_t)f32_to_bf16(dv[df][2]) | ((uint32_t)f32_to_bf16(dv[df][3]) << 16);
+      w.x = f32x2_to_bf16x2(dv[df][0], dv[df][1]);
+      w.y = f32x2_to_bf16x2(dv[df][2], dv[df][3]);
       *reinterpret_cast<uint2*>(dstv + df * 16) = w;
     }
   }
@@ -427,8 +427,8 @@ __device__ __forceinline__ void store_row4x4(bf16_t* dst, const f32x4 (&o)[4]) {
 #pragma unroll
   for (int df = 0; df < 4; ++df) {
     uint2 w;
-    w.x = (uint32_t)f32_to_bf16(o[df][0]) | ((uint32_t)f32_to_bf16(o[df][1]) << 16);
-    w.y = (uint32_t)f32_to_bf16(o[df][2]) | ((uint32_t)f32_to_bf16(o[df][3]) << 16);
+    w.x = f32x2_to_bf16x2(o[df][0], o[df][1]);
+    w.y = f32x2_to_bf16x2(o[df][2], o[df][3]);
     *reinterpret_cast<uint2*>(dst + df * 16) = w;
   }
 }

@@ -31,11 +31,15 @@ static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 typedef uint16_t bf16_t;
 
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
-__device__ __forceinline__ bf16_t f32_to_bf16(float f) {  // round to nearest even, NaN kept quiet
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
+// round to nearest even on the gfx950 converter (v_cvt_pk_bf16_f32: one instruction per TWO values; the integer
+// add/shift formulation cost ~6 VALU ops per value in every epilogue that stores bf16)
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_hw;
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
+__device__ __forceinline__ uint32_t f32x2_to_bf16x2(float lo, float hi) {
+  bf16x2_hw v;
+  v[0] = (__bf16)lo;
+  v[1] = (__bf16)hi;
+  return __builtin_bit_cast(uint32_t, v);
 }
 
 template <typename T> __device__ __forceinline__ float to_f32(T v);
@@ -72,8 +76,7 @@ template <> struct Vec8<bf16_t> {
   __device__ __forceinline__ void store(bf16_t* p) const {
     uint32_t w[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-      w[i] = (uint32_t)f32_to_bf16(v[2 * i]) | ((uint32_t)f32_to_bf16(v[2 * i + 1]) << 16);
+    for (int i = 0; i < 4; ++i) w[i] = f32x2_to_bf16x2(v[2 * i], v[2 * i + 1]);
     *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
   }
 };

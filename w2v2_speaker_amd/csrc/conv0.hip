@@ -11,6 +11,7 @@
 // block needs the same 10-sample window for a given frame); threads map to adjacent channels so the
 // channels-last stores are fully coalesced (512 B per frame per block).
 #include "common.cuh"
+#include <stdlib.h>
 
 constexpr int C0_FRAMES = 128;   // frames per block
 constexpr int C0_MAXK = 16;
@@ -83,6 +84,159 @@ __global__ void conv0_finalize_kernel(const float* __restrict__ partial, float* 
   mr[(int64_t)i * 2 + 1] = (float)(1.0 / sqrt((var > 0.0 ? var : 0.0) + (double)eps));
 }
 
+// ------------------------------------------------------------------------------ matrix-core variant (bf16 activations)
+// The VALU kernel above spends 10 FMA + 10 LDS broadcasts per output on the convolution and stores 2 bytes per
+// lane.  Here the convolution of 16 frames x 16 channels is ONE v_mfma_f32_16x16x32_bf16 with f32-class accuracy:
+// x = xh + xl and w = wh + wl are split into bf16 pairs and the K = 32 slots carry
+//     [ xh(k taps) | xh(k taps) | xl(k taps) | 0 ] . [ wh | wl | wh | 0 ]  =  xh.wh + xh.wl + xl.wh      (3k <= 32)
+// (relative error ~2^-16: only the xl.wl term is dropped).  The weight fragments' rows are permuted so that a lane
+// ends up with 32 CONSECUTIVE channels of one frame (8 fragments x 4 accumulator registers): the normalise + GELU
+// epilogue runs on registers and stores 4 x 16 B per lane, 256 B contiguous per 4 lanes.  What remains is the
+// ~25 VALU ops of GELU per output.  The statistics pass is the same MFMA with a sum / sum-of-squares epilogue.
+typedef __attribute__((ext_vector_type(8))) __bf16 c0_bf16x8;
+typedef __attribute__((ext_vector_type(4))) float c0_f32x4;
+
+__device__ __forceinline__ bf16_t c0_hi(float x) { return f32_to_bf16(x); }
+__device__ __forceinline__ bf16_t c0_lo(float x) { return f32_to_bf16(x - bf16_to_f32(f32_to_bf16(x))); }
+
+constexpr int C0_CPB = 5;        // 128-frame chunks per workgroup: amortises the weight / scale fragments
+
+template <bool APPLY>
+__global__ __launch_bounds__(256) void conv0_mfma_kernel(const float* __restrict__ wav, const float* __restrict__ w,
+                                                         float* __restrict__ partial, const float* __restrict__ mr,
+                                                         const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, bf16_t* __restrict__ y,
+                                                         int N, int L, int C, int k, int stride) {
+  extern __shared__ bf16_t c0_lds[];                 // xh[nmax] | xl[nmax] | one zero slot
+  const int nmax = (C0_FRAMES - 1) * stride + k;
+  const int b = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 15, kq = lane >> 4;           // operand row / 8-wide k slot; as output: frame row r, channel quad kq
+  // LDS offsets of this lane's 8 k slots relative to the first sample of its frame (zero slot for the padding)
+  int xoff[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int ki = kq * 8 + e;
+    xoff[e] = ki < k ? ki : ki < 2 * k ? ki - k : ki < 3 * k ? nmax + ki - 2 * k : -1;
+  }
+  const int chunk0 = blockIdx.x * C0_CPB;
+  const int nchunk = (L + C0_FRAMES - 1) / C0_FRAMES;
+  const int chunk1 = min(chunk0 + C0_CPB, nchunk);
+
+  for (int cw0 = 0; cw0 < C; cw0 += 512) {           // uniform trip count: every wave takes part in the staging
+    const int cw = cw0 + wave * 128;                 // this wave's 128 channels
+    const bool active = cw < C;
+    // weight fragments: fragment j row rho <-> channel cw + (rho >> 2) * 32 + j * 4 + (rho & 3)
+    c0_bf16x8 wf[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int ch = active ? cw + (r >> 2) * 32 + j * 4 + (r & 3) : 0;
+      const float* wp = w + (int64_t)ch * k;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int ki = kq * 8 + e;
+        bf16_t v = 0;
+        if (ki < k) v = c0_hi(wp[ki]);
+        else if (ki < 2 * k) v = c0_lo(wp[ki - k]);
+        else if (ki < 3 * k) v = c0_hi(wp[ki - 2 * k]);
+        wf[j][e] = __builtin_bit_cast(__bf16, v);
+      }
+    }
+    const int cl = active ? cw + kq * 32 : 0;        // this lane's 32 output channels
+    float ga[32], be[32];
+    if constexpr (APPLY) {
+#pragma unroll
+      for (int q = 0; q < 32; ++q) {
+        const float* st = mr + ((int64_t)b * C + cl + q) * 2;
+        ga[q] = gamma[cl + q] * st[1];
+        be[q] = beta[cl + q] - st[0] * ga[q];
+      }
+    }
+    float s1[32], s2[32];
+    if constexpr (!APPLY) {
+#pragma unroll
+      for (int q = 0; q < 32; ++q) { s1[q] = 0.f; s2[q] = 0.f; }
+    }
+#pragma unroll 1
+    for (int chunk = chunk0; chunk < chunk1; ++chunk) {
+      const int l0 = chunk * C0_FRAMES;
+      const int nf = min(C0_FRAMES, L - l0);
+      const int nsamp = (nf - 1) * stride + k;
+      const float* src = wav + (int64_t)b * N + (int64_t)l0 * stride;
+      __syncthreads();                               // previous chunk fully consumed
+      for (int i = threadIdx.x; i <= nmax; i += 256) {
+        const float v = i < nsamp ? src[i] : 0.f;
+        if (i < nmax) {
+          c0_lds[i] = c0_hi(v);
+          c0_lds[nmax + i] = c0_lo(v);
+        } else {
+          c0_lds[2 * nmax] = 0;                      // the zero slot
+        }
+      }
+      __syncthreads();
+#pragma unroll 1
+      for (int f0 = 0; f0 < (active ? nf : 0); f0 += 16) {
+        // activation fragment: frame f0 + r, k slots kq*8 .. +7; rows past the last frame are exact zeros
+        const int sbase = (f0 + r) * stride;
+        const bool live = f0 + r < nf;
+        c0_bf16x8 xf;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const bf16_t v = c0_lds[(live && xoff[e] >= 0) ? sbase + xoff[e] : 2 * nmax];
+          xf[e] = __builtin_bit_cast(__bf16, v);
+        }
+        c0_f32x4 acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf, c0_f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        if constexpr (APPLY) {
+          if (live) {
+            bf16_t* dst = y + ((int64_t)b * L + l0 + f0 + r) * C + cl;
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {             // 8 channels = fragments 2h, 2h+1
+              Vec8<bf16_t> o;
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                const int q = h * 8 + e;
+                o.v[e] = gelu_f(fmaf(acc[q >> 2][q & 3], ga[q], be[q]));
+              }
+              o.store(dst + h * 8);
+            }
+          }
+        } else {
+#pragma unroll
+          for (int q = 0; q < 32; ++q) {
+            const float u = acc[q >> 2][q & 3];
+            s1[q] += u;
+            s2[q] = fmaf(u, u, s2[q]);
+          }
+        }
+      }
+    }
+    if constexpr (!APPLY) {
+      // fold the 16 frame rows (lanes with equal kq) in a fixed butterfly order, then one lane per quad writes
+#pragma unroll
+      for (int q = 0; q < 32; ++q) {
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+          s1[q] += __shfl_xor(s1[q], o, 64);
+          s2[q] += __shfl_xor(s2[q], o, 64);
+        }
+      }
+      if (r == 0 && active) {
+        float* pt = partial + (((int64_t)b * gridDim.x + blockIdx.x) * C + cl) * 2;
+#pragma unroll
+        for (int q = 0; q < 32; ++q) {
+          pt[2 * q] = s1[q];
+          pt[2 * q + 1] = s2[q];
+        }
+      }
+    }
+  }
+}
+
+static bool conv0_mfma_ok(int C, int k) { return C % 128 == 0 && 3 * k <= 32 && getenv("W2V2_CONV0_VALU") == nullptr; }
+
 static int conv0_check(const char* nm, int B, int N, int C, int k, int stride) {
   W2V2_REQUIRE(B > 0 && C > 0 && k > 0 && k <= C0_MAXK && stride > 0 && N >= k,
                "%s: bad shape B=%d N=%d C=%d k=%d stride=%d", nm, B, N, C, k, stride);
@@ -106,6 +260,26 @@ extern "C" int w2v2_conv0_stats(const float* wav, const float* w, float* partial
   return 0;
 }
 
+// Same contract as w2v2_conv0_stats, statistics of the split-bf16 matrix-core convolution (what
+// w2v2_conv0_apply computes for bf16 outputs); falls back to the exact kernel for shapes the MFMA path does not take.
+extern "C" int w2v2_conv0_stats_mfma(const float* wav, const float* w, float* partial, float* mean_rstd, int B, int N,
+                                     int C, int k, int stride, float eps, void* stream) {
+  if (!conv0_mfma_ok(C, k)) return w2v2_conv0_stats(wav, w, partial, mean_rstd, B, N, C, k, stride, eps, stream);
+  if (conv0_check("conv0_stats_mfma", B, N, C, k, stride)) return -1;
+  W2V2_REQUIRE(wav && w && partial && mean_rstd, "conv0_stats_mfma: null pointer");
+  const int L = (N - k) / stride + 1;
+  const int nchunk = (int)cdiv(cdiv(L, C0_FRAMES), C0_CPB);      // one partial per workgroup (C0_CPB chunks)
+  dim3 grid((unsigned)nchunk, B);
+  const size_t lds2 = (2 * ((size_t)(C0_FRAMES - 1) * stride + k) + 8) * sizeof(bf16_t);
+  hipLaunchKernelGGL((conv0_mfma_kernel<false>), grid, dim3(256), lds2, as_stream(stream), wav, w, partial,
+                     (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (bf16_t*)nullptr, N, L, C, k,
+                     stride);
+  hipLaunchKernelGGL(conv0_finalize_kernel, dim3((unsigned)cdiv((int64_t)B * C, 256)), dim3(256), 0,
+                     as_stream(stream), partial, mean_rstd, B, C, nchunk, L, eps);
+  W2V2_CHECK_LAUNCH("conv0_stats_mfma");
+  return 0;
+}
+
 extern "C" int w2v2_conv0_workspace_floats(int N, int C, int k, int stride) {
   const int L = (N - k) / stride + 1;
   return (int)cdiv(L, C0_FRAMES) * C * 2;   // per utterance
@@ -119,7 +293,12 @@ extern "C" int w2v2_conv0_apply(const float* wav, const float* w, const float* m
   const int L = (N - k) / stride + 1;
   dim3 grid((unsigned)cdiv(L, C0_FRAMES), B);
   const size_t lds = ((size_t)(C0_FRAMES - 1) * stride + k) * sizeof(float);
-  if (dtype == W2V2_BF16)
+  if (dtype == W2V2_BF16 && conv0_mfma_ok(C, k)) {
+    const size_t lds2 = (2 * ((size_t)(C0_FRAMES - 1) * stride + k) + 8) * sizeof(bf16_t);
+    dim3 grid2((unsigned)cdiv(cdiv(L, C0_FRAMES), C0_CPB), B);
+    hipLaunchKernelGGL((conv0_mfma_kernel<true>), grid2, dim3(256), lds2, as_stream(stream), wav, w, (float*)nullptr,
+                       mean_rstd, gamma, beta, (bf16_t*)y, N, L, C, k, stride);
+  } else if (dtype == W2V2_BF16)
     hipLaunchKernelGGL((conv0_kernel<bf16_t, true>), grid, dim3(256), lds, as_stream(stream), wav, w,
                        (float*)nullptr, mean_rstd, gamma, beta, (bf16_t*)y, N, L, C, k, stride, 0.f);
   else if (dtype == W2V2_F32)

@@ -122,8 +122,8 @@ __device__ __forceinline__ void epilogue_store4(const GemmArgs& g, TC* __restric
       *reinterpret_cast<float4*>(crow + n0) = make_float4(out[0], out[1], out[2], out[3]);
     } else {
       uint2 w;
-      w.x = (uint32_t)f32_to_bf16(out[0]) | ((uint32_t)f32_to_bf16(out[1]) << 16);
-      w.y = (uint32_t)f32_to_bf16(out[2]) | ((uint32_t)f32_to_bf16(out[3]) << 16);
+      w.x = f32x2_to_bf16x2(out[0], out[1]);
+      w.y = f32x2_to_bf16x2(out[2], out[3]);
       *reinterpret_cast<uint2*>(crow + n0) = w;
     }
   } else {

@@ -28,8 +28,8 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     reinterpret_cast<float4*>(v)[i] = vv;
     if (pb != nullptr) {
       uint2 w;
-      w.x = (uint32_t)f32_to_bf16(pp.x) | ((uint32_t)f32_to_bf16(pp.y) << 16);
-      w.y = (uint32_t)f32_to_bf16(pp.z) | ((uint32_t)f32_to_bf16(pp.w) << 16);
+      w.x = f32x2_to_bf16x2(pp.x, pp.y);
+      w.y = f32x2_to_bf16x2(pp.z, pp.w);
       reinterpret_cast<uint2*>(pb)[i] = w;
     }
   }

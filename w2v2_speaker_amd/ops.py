@@ -179,8 +179,10 @@ def conv0_groupnorm_gelu(wav: torch.Tensor, w: torch.Tensor, gamma: torch.Tensor
     Cc = w.shape[0]
     mr = work[work.numel() - B * Cc * 2:]
     L = lib()
-    _lib.check(L.w2v2_conv0_stats(wav.data_ptr(), w.data_ptr(), work.data_ptr(), mr.data_ptr(), B, N, Cc, k, stride,
-                                  eps, stream()), "conv0_stats")
+    # bf16 activations: conv on the matrix cores (split-bf16, ~2^-16), statistics from the same arithmetic
+    stats = L.w2v2_conv0_stats_mfma if out.dtype == torch.bfloat16 else L.w2v2_conv0_stats
+    _lib.check(stats(wav.data_ptr(), w.data_ptr(), work.data_ptr(), mr.data_ptr(), B, N, Cc, k, stride,
+                     eps, stream()), "conv0_stats")
     _lib.check(L.w2v2_conv0_apply(wav.data_ptr(), w.data_ptr(), mr.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
                                   out.data_ptr(), dt(out), B, N, Cc, k, stride, stream()), "conv0_apply")
 
