@@ -64,6 +64,9 @@ __device__ __forceinline__ int64_t outer_off(const OpDev& o, int64_t idx) {
 // found 2.3).  The textbook (row & 7) XOR costs 7 clk resp. 4 clk: the 64 x 4-B banks serve 16-byte accesses
 // in lane groups that are not 16 consecutive lanes, so "8 rows -> 8 chunks" is not enough.
 __device__ __forceinline__ int swz(int row) { return ((row ^ (row >> 1)) & 3) | (row & 4); }
+// B image of the 256x128 ring kernel: its fragments take tile rows (rho >> 2) * 16 + j * 4 + (rho & 3), so the map
+// is applied to the fragment-local row index rho = ((row >> 4) & 3) * 4 + (row & 3) (same lane pattern as above)
+__device__ __forceinline__ int swz_b(int row) { return swz((((row >> 4) & 3) << 2) | (row & 3)); }
 // The register-staged kernel also WRITES its image with transposing 8-byte stores (K-major operands), whose
 // conflicts the map above doubles (TT weight-gradient products 332 -> 389 us); it keeps the textbook map.
 __device__ __forceinline__ int swz_rs(int row) { return (row & 7) ^ ((row >> 3) & 1); }
@@ -257,6 +260,54 @@ __device__ __forceinline__ void load_col8(const GemmArgs& g, const float* __rest
   } else {
 #pragma unroll
     for (int e = 0; e < 8; ++e) if (n + e < g.N) cv[e] = src[n + e];
+  }
+}
+
+// epilogue straight from the accumulators of a wave whose lane owns columns n .. n+15 of rows m + 16 i
+template <typename TC, int EPI>
+__device__ __forceinline__ void epilogue_direct(const GemmArgs& g, TC* __restrict__ Cz, TC* __restrict__ auxz,
+                                                f32x4 (&acc)[4][4], int m, int n, const float (&cv0)[8],
+                                                const float (&cv1)[8]) {
+  if (n >= g.N) return;
+  float ax[4][16];
+  if constexpr (EPI == W2V2_EPI_GELU_BWD || EPI == W2V2_EPI_ADD) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int mi = m + 16 * i;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) ax[i][e] = 0.f;
+      if (mi < g.M) {
+        const TC* ap = auxz + (int64_t)mi * g.ldaux + n;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          if (n + 8 * h + 8 <= g.N && g.aux_vec_ok) {
+            Vec8<TC> t;
+            t.load(ap + 8 * h);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ax[i][8 * h + e] = t.v[e];
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) if (n + 8 * h + e < g.N) ax[i][8 * h + e] = to_f32<TC>(ap[8 * h + e]);
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int mi = m + 16 * i;
+    if (mi >= g.M) continue;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      if (n + 8 * h >= g.N) continue;
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = acc[i][2 * h + (e >> 2)][e & 3];
+      float a8[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) a8[e] = (EPI == W2V2_EPI_GELU_BWD || EPI == W2V2_EPI_ADD) ? ax[i][8 * h + e] : 0.f;
+      epilogue_row8_impl<TC, EPI>(g, Cz, auxz, mi, n + 8 * h, v, h ? cv1 : cv0, a8, true);
+    }
   }
 }
 
@@ -661,7 +712,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_glds3_kernel(const GemmArgs g) 
   for (int j = 0; j < 2; ++j) {
     const int row = (wave * 2 + j) * 8 + r8;
     const int grow = min(n0 + row, g.N - 1);
-    bp[j] = Bb + outer_off(g.B, grow) + ((c8 ^ swz(row)) << 3);
+    bp[j] = Bb + outer_off(g.B, grow) + ((c8 ^ swz_b(row)) << 3);
   }
 
   f32x4 acc[FM][FN];
@@ -684,19 +735,24 @@ __global__ __launch_bounds__(512) void gemm_bf16_glds3_kernel(const GemmArgs g) 
   // per-lane fragment offsets (elements) for k-step 0 / 1; everything else is a compile-time constant
   const int lo0 = frow * 64 + ((fk ^ swz(frow)) << 3);
   const int lo1 = frow * 64 + (((4 + fk) ^ swz(frow)) << 3);
+  // B fragment j, operand row rho = frow  <->  tile row (rho >> 2) * 16 + j * 4 + (rho & 3): after the MFMA a lane
+  // owns the 16 CONSECUTIVE columns fk * 16 + j * 4 + e of its row (register epilogue below)
+  const int brow = (frow >> 2) * 16 + (frow & 3);
+  const int lb0 = brow * 64 + ((fk ^ swz(frow)) << 3);
+  const int lb1 = brow * 64 + (((4 + fk) ^ swz(frow)) << 3);
   const int aoff = wm * 64 * 64, boff = BM * 64 + wn * 64 * 64;
   auto compute = [&](const bf16_t* base) {
     const bf16_t* a0 = base + aoff + lo0;
     const bf16_t* a1 = base + aoff + lo1;
-    const bf16_t* b0 = base + boff + lo0;
-    const bf16_t* b1 = base + boff + lo1;
+    const bf16_t* b0 = base + boff + lb0;
+    const bf16_t* b1 = base + boff + lb1;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       bf16x8 af[FM], bfr[FN];
 #pragma unroll
       for (int i = 0; i < FM; ++i) af[i] = *reinterpret_cast<const bf16x8*>((kk ? a1 : a0) + i * 16 * 64);
 #pragma unroll
-      for (int j = 0; j < FN; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>((kk ? b1 : b0) + j * 16 * 64);
+      for (int j = 0; j < FN; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>((kk ? b1 : b0) + j * 4 * 64);
 #pragma unroll
       for (int i = 0; i < FM; ++i)
 #pragma unroll
@@ -729,28 +785,17 @@ __global__ __launch_bounds__(512) void gemm_bf16_glds3_kernel(const GemmArgs g) 
   }
 #undef W2V2_RING_STEP
 
-  // epilogue: two passes of 128 rows through LDS (all DMA has landed: the last wait was vmcnt(0))
-  float* stagef = reinterpret_cast<float*>(smem_raw);
-  constexpr int PITCH = BN + 4;
+  // Register epilogue: thanks to the permuted B rows a lane holds, for each of its four rows, 16 consecutive
+  // output columns (32 B of bf16): bias / GELU / residual are applied in registers and stored as 2 x 16 B per lane,
+  // four lanes covering 128 contiguous bytes of a row -- no LDS round trip and no barrier after the main loop.
   TC* Cz = reinterpret_cast<TC*>(g.C) + z0 * g.c_s0 + z1 * g.c_s1;
   TC* auxz = g.aux ? reinterpret_cast<TC*>(g.aux) + z0 * g.aux_s0 + z1 * g.aux_s1 : nullptr;
   const float* bias = g.bias ? g.bias + z1 * g.bias_s1 : nullptr;
-  float cv[8];
-  load_col8(g, bias, n0 + (tid & 15) * 8, cv);
-#pragma unroll 1
-  for (int pass = 0; pass < 2; ++pass) {
-    __syncthreads();
-    if ((wm >> 1) == pass) {
-#pragma unroll
-      for (int i = 0; i < FM; ++i)
-#pragma unroll
-        for (int j = 0; j < FN; ++j)
-          *reinterpret_cast<float4*>(stagef + ((wm & 1) * 64 + i * 16 + frow) * PITCH + wn * 64 + j * 16 + fk * 4) =
-              make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
-    }
-    __syncthreads();
-    W2V2_EPI_DISPATCH((epilogue_pass<TC, EPI, 4, 512, BN>(g, stagef, Cz, auxz, m0 + pass * 128, n0, cv, true)));
-  }
+  const int nc = n0 + wn * 64 + fk * 16;
+  float cv0[8], cv1[8];
+  load_col8(g, bias, nc, cv0);
+  load_col8(g, bias, nc + 8, cv1);
+  W2V2_EPI_DISPATCH((epilogue_direct<TC, EPI>(g, Cz, auxz, acc, m0 + wm * 64 + frow, nc, cv0, cv1)));
 }
 
 template <typename TC>
