@@ -976,7 +976,7 @@ extern "C" int w2v2_gemm(const w2v2_gemm_desc* d, void* stream) {
                       !g_w2v2_no_glds;
     // 256x128 3-stage kernel for the encoder shapes; the conv stack (N = 512, M ~ 3e5) measures
     // slightly faster on the 128x128 kernel at 2 workgroups per CU
-    const bool big = glds && d->N >= 768 && split == 1 && !atomic && d->M >= 1024 && g_w2v2_glds3;
+    const bool big = glds && d->N >= (getenv("W2V2_G3N") ? atoi(getenv("W2V2_G3N")) : 512) && split == 1 && !atomic && d->M >= 1024 && g_w2v2_glds3;
     if (big) {
       if (d->dtype_c == W2V2_F32) launch_glds3<float>(a, d->M, d->N, d->batch, st);
       else launch_glds3<bf16_t>(a, d->M, d->N, d->batch, st);
