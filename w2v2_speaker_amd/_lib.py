@@ -97,7 +97,10 @@ def load():
     if _lib is not None:
         return _lib
     path = _build.LIB
-    if _build.needs_build():
+    alt = os.environ.get("W2V2_LIB_AB")        # A/B timing of two builds in one process tree (tools only)
+    if alt and os.path.exists(alt):
+        path = alt
+    elif _build.needs_build():
         try:
             _build.build()
         except Exception as e:  # no compiler on this box and no prebuilt library -> loud failure
