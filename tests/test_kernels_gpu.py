@@ -489,6 +489,33 @@ def test_fused_attention_dropout_mask_recovered_and_consistent():
     assert rel_l2(dqkv.float().cpu(), qr.grad) < 2.5e-2
 
 
+def test_dropout_stream_statistics():
+    """Counter-based dropout (common.cuh rng_pair): keep rate, independence of the two elements that share one
+    32-bit hash, independence of neighbouring hashes, and decorrelation of consecutive seeds."""
+    o = ops()
+    n, p = 1 << 22, 0.1
+    masks = []
+    for seed in (1234, 1235):
+        x = torch.ones(n, dtype=torch.float32, device=DEV)
+        o.dropout_(x, p, seed)
+        torch.cuda.synchronize()
+        xc = x.cpu()
+        vals = xc.unique().tolist()
+        assert len(vals) == 2 and vals[0] == 0.0 and abs(vals[1] - 1 / (1 - p)) < 1e-6
+        masks.append((xc > 0).double())
+    m = masks[0]
+    se = (p * (1 - p) / n) ** 0.5
+    assert abs(m.mean().item() - (1 - p)) < 5 * se
+
+    def corr(a, b):
+        a, b = a - a.mean(), b - b.mean()
+        return float((a * b).mean() / (a.std() * b.std()))
+    assert abs(corr(m[0::2], m[1::2])) < 5 / (n / 2) ** 0.5          # halves of one hash
+    assert abs(corr(m[1:-1:2], m[2::2])) < 5 / (n / 2) ** 0.5        # neighbouring hashes
+    assert abs(corr(m[:-64], m[64:])) < 5 / n ** 0.5                 # one wave apart
+    assert abs(corr(masks[0], masks[1])) < 5 / n ** 0.5              # consecutive seeds
+
+
 # ----------------------------------------------------------------------------------------------- pooling
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_pooling_all_modes(dtype):

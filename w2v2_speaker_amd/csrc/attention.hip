@@ -27,6 +27,38 @@ constexpr int HD = 64;  // head dim
 
 // 16-row periodic: all fragments of an image share one per-lane swizzle, so fragment addresses are
 // lane base + compile-time constant (ds_read offset immediates instead of one address VGPR each)
+// dropout counter of attention probability (bh, q, key): rows are padded to an even length so that keys 2j, 2j+1
+// of a row always share one hash (common.cuh rng_pair); every fused kernel (forward, all backward variants) uses it
+__device__ __forceinline__ uint64_t attn_drop_idx(int64_t bh, int q, int key, int Tn) {
+  return (uint64_t)(bh * Tn + q) * (uint64_t)((Tn + 1) & ~1) + (uint64_t)key;
+}
+// keep-scales of 4 consecutive keys key0 .. key0+3 (key0 % 4 == 0) of query row q: two hashes
+__device__ __forceinline__ void attn_drop4_keys(uint64_t seed, int64_t bh, int q, int key0, int Tn, float dp,
+                                                float inv_keep, float (&ms)[4]) {
+  const uint32_t k = rng_key(seed), thr = drop_thr16(dp);
+  const uint64_t pi = attn_drop_idx(bh, q, key0, Tn) >> 1;
+  const uint32_t h0 = rng_pair(k, pi), h1 = rng_pair(k, pi + 1);
+  ms[0] = (h0 & 0xffffu) >= thr ? inv_keep : 0.f;
+  ms[1] = (h0 >> 16) >= thr ? inv_keep : 0.f;
+  ms[2] = (h1 & 0xffffu) >= thr ? inv_keep : 0.f;
+  ms[3] = (h1 >> 16) >= thr ? inv_keep : 0.f;
+}
+// keep-scales of key column `key` (parity == lane parity) for 4 consecutive query rows q0 .. q0+3: the two lanes
+// of a key pair hash two rows each and swap (one hash serves keys 2j and 2j+1 of a row)
+__device__ __forceinline__ void attn_drop4_rows(uint64_t seed, int64_t bh, int q0, int key, int Tn, float dp,
+                                                float inv_keep, float (&ms)[4]) {
+  const uint32_t k = rng_key(seed), thr = drop_thr16(dp);
+  const int odd = key & 1;
+  const uint32_t h0 = rng_pair(k, attn_drop_idx(bh, q0 + 2 * odd, key, Tn) >> 1);
+  const uint32_t h1 = rng_pair(k, attn_drop_idx(bh, q0 + 2 * odd + 1, key, Tn) >> 1);
+  const uint32_t p0 = __shfl_xor(h0, 1, 64), p1 = __shfl_xor(h1, 1, 64);
+  const uint32_t r0 = odd ? p0 : h0, r1 = odd ? p1 : h1, r2 = odd ? h0 : p0, r3 = odd ? h1 : p1;
+  const int sh = odd * 16;
+  ms[0] = ((r0 >> sh) & 0xffffu) >= thr ? inv_keep : 0.f;
+  ms[1] = ((r1 >> sh) & 0xffffu) >= thr ? inv_keep : 0.f;
+  ms[2] = ((r2 >> sh) & 0xffffu) >= thr ? inv_keep : 0.f;
+  ms[3] = ((r3 >> sh) & 0xffffu) >= thr ? inv_keep : 0.f;
+}
 __device__ __forceinline__ int aswz(int row) { return ((row ^ (row >> 1)) & 3) | (row & 4); }   // measured map, see gemm.hip swz()
 
 __device__ __forceinline__ bf16x8 as_frag(uint4 v) {
@@ -161,7 +193,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       float pv = s[fj][j] * inv;
-      if (dp > 0.f) pv *= drop_scale(seed, (uint64_t)((bh * Tn + q) * Tn + fj * 16 + g * 4 + j), dp, inv_keep);
+      if (dp > 0.f) pv *= drop_scale(seed, attn_drop_idx(bh, q, fj * 16 + g * 4 + j, Tn), dp, inv_keep);
       s[fj][j] = pv;
     }
   f32x4 o[4];
@@ -240,7 +272,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
       const int key = fj * 16 + g * 4 + j;
       const float p = (key < Tn && q < Tn) ? __expf(sa[j] * scale - l) : 0.f;
       float dpv = pa[j];
-      if (dp > 0.f) dpv *= drop_scale(seed, (uint64_t)((bh * Tn + q) * Tn + key), dp, inv_keep);
+      if (dp > 0.f) dpv *= drop_scale(seed, attn_drop_idx(bh, q, key, Tn), dp, inv_keep);
       ds[fj][j] = p * (dpv - dl) * scale;
     }
   }
@@ -320,7 +352,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const bf16_t* __restri
       const int q = fq * 16 + g * 4 + j;
       const float p = (q < Tn && key < Tn) ? __expf(sa[j] * scale - la[j]) : 0.f;
       float ms = 1.0f;
-      if (dp > 0.f) ms = drop_scale(seed, (uint64_t)((bh * Tn + q) * Tn + key), dp, inv_keep);
+      if (dp > 0.f) ms = drop_scale(seed, attn_drop_idx(bh, q, key, Tn), dp, inv_keep);
       pt[fq][j] = p * ms;
       dst_[fq][j] = p * (pa[j] * ms - da[j]) * scale;
     }
@@ -464,7 +496,6 @@ __global__ __launch_bounds__(256) void attn_fwd2_kernel(const bf16_t* __restrict
     const int q = qf * 16 + (lane & 15);
     int g4 = g * 4;
     asm volatile("" : "+v"(g4));          // opaque: no hoisting of the 40 per-column index / RNG-counter values
-    const uint64_t qbase = (uint64_t)(bh * Tn + q) * (uint64_t)Tn;
     bf16x8 qfr[2] = {lds_frag(Qs, qf * 16, 0, lane), lds_frag(Qs, qf * 16, 1, lane)};
     float s[NF][4];
     float mx = -INFINITY;
@@ -491,13 +522,12 @@ __global__ __launch_bounds__(256) void attn_fwd2_kernel(const bf16_t* __restrict
     const float inv = 1.0f / sum;
     if (g == 0 && q < Tn) lse[bh * Tn + q] = mx + __logf(sum);
 #pragma unroll
-    for (int fj = 0; fj < NF; ++fj)
+    for (int fj = 0; fj < NF; ++fj) {
+      float ms[4] = {1.f, 1.f, 1.f, 1.f};
+      if (dp > 0.f) attn_drop4_keys(seed, bh, q, fj * 16 + g4, Tn, dp, inv_keep, ms);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        float pv = s[fj][j] * inv;
-        if (dp > 0.f) pv *= drop_scale(seed, qbase + (uint64_t)(fj * 16 + g4 + j), dp, inv_keep);
-        s[fj][j] = pv;
-      }
+      for (int j = 0; j < 4; ++j) s[fj][j] = s[fj][j] * inv * ms[j];
+    }
     f32x4 o[4];
 #pragma unroll
     for (int df = 0; df < 4; ++df) o[df] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -585,7 +615,7 @@ __global__ __launch_bounds__(256) void attn_bwd2_kernel(const bf16_t* __restrict
         const int key = fj * 16 + g * 4 + j;
         const float p = (key < Tn && q < Tn) ? __expf(sa[j] * scale - l) : 0.f;
         float dpv = pa[j];
-        if (dp > 0.f) dpv *= drop_scale(seed, (uint64_t)((bh * Tn + q) * Tn + key), dp, inv_keep);
+        if (dp > 0.f) dpv *= drop_scale(seed, attn_drop_idx(bh, q, key, Tn), dp, inv_keep);
         ds[fj][j] = p * (dpv - dl) * scale;
       }
     }
@@ -627,7 +657,7 @@ __global__ __launch_bounds__(256) void attn_bwd2_kernel(const bf16_t* __restrict
         const int q = fq * 16 + g * 4 + j;
         const float p = (q < Tn && key < Tn) ? __expf(sa[j] * scale - la[j]) : 0.f;
         float ms = 1.0f;
-        if (dp > 0.f) ms = drop_scale(seed, (uint64_t)((bh * Tn + q) * Tn + key), dp, inv_keep);
+        if (dp > 0.f) ms = drop_scale(seed, attn_drop_idx(bh, q, key, Tn), dp, inv_keep);
         pt[fq][j] = p * ms;
         dst_[fq][j] = p * (pa[j] * ms - da[j]) * scale;
       }
@@ -742,7 +772,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd3_kernel(const bf16_t* __restr
     dl = quad_sum(dl);
     if (g == 0 && q < Tn) del_b[q] = dl;
     const float l = q < Tn ? lse_b[q] : 0.f;
-    const uint64_t qbase = (uint64_t)(bh * Tn + q) * (uint64_t)Tn;
     f32x4 o[4];
 #pragma unroll
     for (int df = 0; df < 4; ++df) o[df] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -762,13 +791,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd3_kernel(const bf16_t* __restr
           sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(Ks, fj * 16, kk, lane), qfr[kk], sa, 0, 0, 0);
           pa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(Vs, fj * 16, kk, lane), dof[kk], pa, 0, 0, 0);
         }
+        float ms[4] = {1.f, 1.f, 1.f, 1.f};
+        if (dp > 0.f) attn_drop4_keys(seed, bh, q, fj * 16 + g4, Tn, dp, inv_keep, ms);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int key = fj * 16 + g4 + j;
           const float p = (key < Tn && q < Tn) ? __expf(sa[j] * scale - l) : 0.f;
-          float dpv = pa[j];
-          if (dp > 0.f) dpv *= drop_scale(seed, qbase + (uint64_t)key, dp, inv_keep);
-          ds2[hf][j] = p * (dpv - dl) * scale;
+          ds2[hf][j] = p * (pa[j] * ms[j] - dl) * scale;
         }
       }
       const bf16x8 pf = pack_frag(ds2[0], ds2[1]);
@@ -820,6 +849,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd3_kernel(const bf16_t* __restr
           sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(Qs, fq * 16, kk, lane), kfr[kk], sa, 0, 0, 0);
           pa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(Os, fq * 16, kk, lane), vfr[kk], pa, 0, 0, 0);
         }
+        float ms[4] = {1.f, 1.f, 1.f, 1.f};
+        if (dp > 0.f) attn_drop4_rows(seed, bh, fq * 16 + g4, key, Tn, dp, inv_keep, ms);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int q = fq * 16 + g4 + j;
@@ -827,10 +858,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd3_kernel(const bf16_t* __restr
           const float la = __shfl(lse_r[(fq * 16) >> 6], q & 63, 64);
           const float da = __shfl(del_r[(fq * 16) >> 6], q & 63, 64);
           const float p = ok ? __expf(sa[j] * scale - la) : 0.f;
-          float ms = 1.0f;
-          if (dp > 0.f) ms = drop_scale(seed, (uint64_t)(bh * Tn + q) * (uint64_t)Tn + (uint64_t)key, dp, inv_keep);
-          pt2[hf][j] = p * ms;
-          ds2[hf][j] = p * (pa[j] * ms - da) * scale;
+          pt2[hf][j] = p * ms[j];
+          ds2[hf][j] = p * (pa[j] * ms[j] - da) * scale;
         }
       }
       const bf16x8 pf = pack_frag(pt2[0], pt2[1]);

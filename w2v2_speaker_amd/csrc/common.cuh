@@ -104,26 +104,39 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
 }
 
 // ---------------------------------------------------------------- counter-based RNG (dropout)
-// keep(seed, i) must be recomputable in the backward, so no mask is ever stored.  It also sits in the
-// inner loops of the attention kernels (T^2 decisions per head, three times per step), so it is a
-// 32-bit integer hash (murmur3 finaliser over the element index, keyed by a seed mix that is
-// wave-uniform and therefore scalar-unit work): ~10 VALU ops per decision.  (A 64-bit splitmix cost
-// ~80 and made dropout 90 % of the fused attention kernels' time.)
-__device__ __forceinline__ uint32_t rng_u32(uint64_t seed, uint64_t idx) {
-  const uint32_t key = (uint32_t)seed * 0x9E3779B1u ^ (uint32_t)(seed >> 32) * 0x85EBCA77u ^ 0x27D4EB2Fu;
-  uint32_t x = (uint32_t)idx ^ ((uint32_t)(idx >> 32) * 0xC2B2AE3Du) ^ key;
+// keep(seed, i) must be recomputable in the backward, so no mask is ever stored.  It sits in the inner loops of
+// the attention kernels (T^2 decisions per head, three times per step) where it used to be the single largest
+// cost: 32-bit integer multiplies run at quarter rate on CDNA (16 clk per wave instruction).  One murmur3
+// finaliser (2 multiplies) over the PAIR index i >> 1 yields 32 bits = two 16-bit uniforms, for elements 2j and
+// 2j + 1; the seed is mixed into a key on the scalar unit (wave-uniform).  p is quantised to 1/65536.
+__device__ __forceinline__ uint32_t rng_key(uint64_t seed) {
+  uint32_t k = (uint32_t)seed * 0x9E3779B1u ^ (uint32_t)(seed >> 32) * 0x85EBCA77u ^ 0x27D4EB2Fu;
+  k ^= k >> 15; k *= 0x2C1B3C6Du;
+  k ^= k >> 12; k *= 0x297A2D39u;
+  k ^= k >> 15;
+  return k;
+}
+__device__ __forceinline__ uint32_t rng_pair(uint32_t key, uint64_t pair_idx) {
+  uint32_t x = (uint32_t)pair_idx ^ key ^ __umul24((uint32_t)(pair_idx >> 32), 0x9E3779u);
   x ^= x >> 16; x *= 0x85EBCA6Bu;
   x ^= x >> 13; x *= 0xC2B2AE35u;
   x ^= x >> 16;
-  x += key;                      // second keyed round: decorrelates streams of nearby seeds
-  x ^= x >> 15; x *= 0x2C1B3C6Du;
-  x ^= x >> 12;
   return x;
 }
+__device__ __forceinline__ uint32_t drop_thr16(float p) { return (uint32_t)fminf(p * 65536.0f + 0.5f, 65535.0f); }
 // returns 0 (dropped, probability p) or 1/(1-p)
 __device__ __forceinline__ float drop_scale(uint64_t seed, uint64_t idx, float p, float inv_keep) {
-  const uint32_t thr = (uint32_t)fminf(p * 4294967296.0f, 4294967040.0f);
-  return rng_u32(seed, idx) >= thr ? inv_keep : 0.0f;
+  const uint32_t h = rng_pair(rng_key(seed), idx >> 1);
+  const uint32_t r = (idx & 1) ? (h >> 16) : (h & 0xffffu);
+  return r >= drop_thr16(p) ? inv_keep : 0.0f;
+}
+// elements idx_even and idx_even + 1 from one hash (idx_even must be even)
+__device__ __forceinline__ void drop_scale2(uint64_t seed, uint64_t idx_even, float p, float inv_keep, float& s0,
+                                            float& s1) {
+  const uint32_t h = rng_pair(rng_key(seed), idx_even >> 1);
+  const uint32_t thr = drop_thr16(p);
+  s0 = (h & 0xffffu) >= thr ? inv_keep : 0.0f;
+  s1 = (h >> 16) >= thr ? inv_keep : 0.0f;
 }
 
 // ---------------------------------------------------------------- wave / block reductions (wave = 64)

@@ -18,7 +18,12 @@ __global__ void dropout_kernel(const T* __restrict__ x, T* __restrict__ y, int64
     Vec8<T> v;
     v.load(x + i * 8);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v.v[e] *= drop_scale(seed, (uint64_t)(i * 8 + e), p, inv_keep);
+    for (int e = 0; e < 8; e += 2) {
+      float s0, s1;
+      drop_scale2(seed, (uint64_t)(i * 8 + e), p, inv_keep, s0, s1);
+      v.v[e] *= s0;
+      v.v[e + 1] *= s1;
+    }
     v.store(y + i * 8);
   }
   if (blockIdx.x == 0 && threadIdx.x < (n & 7)) {

@@ -28,10 +28,11 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, T*
         Vec8<T> vr;
         vr.load(r + off);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          float rv = vr.v[e];
-          if (p > 0.f) rv *= drop_scale(seed, (uint64_t)(off + e), p, inv_keep);
-          vx.v[e] += rv;
+        for (int e = 0; e < 8; e += 2) {
+          float s0 = 1.f, s1 = 1.f;
+          if (p > 0.f) drop_scale2(seed, (uint64_t)(off + e), p, inv_keep, s0, s1);   // off is a multiple of 8
+          vx.v[e] += vr.v[e] * s0;
+          vx.v[e + 1] += vr.v[e + 1] * s1;
         }
         vx.store(r + off);  // pre-norm sum saved for backward
         // keep the stored (possibly bf16-rounded) value so fwd and bwd see the same s
@@ -123,9 +124,15 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
         const int64_t off = (int64_t)row * H + ch * 8;
         Vec8<T> o, o2;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          o.v[e] = rs * (g[ci][e] - c1 - xh[ci][e] * c2);
-          if (d_r != nullptr) o2.v[e] = p > 0.f ? o.v[e] * drop_scale(seed, (uint64_t)(off + e), p, inv_keep) : o.v[e];
+        for (int e = 0; e < 8; ++e) o.v[e] = rs * (g[ci][e] - c1 - xh[ci][e] * c2);
+        if (d_r != nullptr) {
+#pragma unroll
+          for (int e = 0; e < 8; e += 2) {
+            float s0 = 1.f, s1 = 1.f;
+            if (p > 0.f) drop_scale2(seed, (uint64_t)(off + e), p, inv_keep, s0, s1);
+            o2.v[e] = o.v[e] * s0;
+            o2.v[e + 1] = o.v[e + 1] * s1;
+          }
         }
         o.store(ds + off);
         if (d_r != nullptr) o2.store(d_r + off);
