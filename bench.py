@@ -90,6 +90,9 @@ def main():
     ap.add_argument("--seconds", type=float, default=3.0)
     ap.add_argument("--speakers", type=int, default=5994)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--model", default="base", choices=["base", "large"],
+                    help="base = BASELINE configs[1] (the metric's workload); large = configs[3] geometry "
+                         "(24 layers, H=1024; use --seconds 5 --batch 32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-regularisation", action="store_true", help="dropout/LayerDrop/mask off")
     ap.add_argument("--unfreeze-cnn", action="store_true",
@@ -118,7 +121,7 @@ def main():
     from w2v2_speaker_amd.params import ParamStore
     from w2v2_speaker_amd.trainer import SpeakerTrainer
 
-    cfg = W2V2Config()
+    cfg = W2V2Config.from_huggingface_id("facebook/wav2vec2-" + args.model)
     n_samples = int(round(args.seconds * 16000))
     adt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     store = ParamStore(cfg, dev, adt, head="aam", num_speakers=args.speakers, freeze_cnn=not args.unfreeze_cnn)
@@ -158,14 +161,17 @@ def main():
         utt = args.batch * world * args.steps
         fl = cfg.flops_per_utt(n_samples, args.speakers)
         out = {
-            "metric": "utterances/sec (w2v2-base + mean+std + AAM-softmax training step, 3 s clips)",
+            "metric": (f"utterances/sec (w2v2-{args.model} + mean+std + AAM-softmax training step, "
+                       f"{args.seconds:g} s clips)"),
             "value": round(utt / elapsed, 2), "unit": "utterances/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16" if adt == torch.bfloat16 else "f32", "data": "synthetic",
-            "config": {"workload": "wav2vec2-base + AAM-softmax(5994), mean+std pooling, 3 s synthetic audio, "
+            "config": {"workload": f"wav2vec2-{args.model} + AAM-softmax({args.speakers}), mean+std pooling, "
+                                   f"{args.seconds:g} s synthetic audio, "
                                    f"bs={args.batch} per GPU, CNN {'trainable' if args.unfreeze_cnn else 'frozen'}, "
-                                   "fwd+bwd+all-reduce+Adam (BASELINE configs[1])",
+                                   "fwd+bwd+all-reduce+Adam (BASELINE "
+                                   + ("configs[1])" if args.model == "base" else "configs[3] geometry)"),
                        "global_batch": args.batch * world, "samples_per_utt": n_samples,
                        "parallelism": f"dp{world}", "regularisation": not args.no_regularisation,
                        "final_loss": round(float(loss), 4)},
@@ -183,8 +189,8 @@ def main():
                 pass
             out["roofline"] = {"bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
                                "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic,
-                               "kernel": "gemm_bf16_glds3_kernel<bf16> (256x128x64 3-stage LDS-DMA MFMA GEMM: QKV, "
-                                         "out-proj, FFN1, FFN2 forward + every data-gradient product)",
+                               "kernel": "gemm_bf16_glds3_kernel<bf16> (256x128x64 3-stage LDS-DMA MFMA GEMM: conv1-6, "
+                                         "projection, QKV, out-proj, FFN1, FFN2 forward + every data-gradient product)",
                                "launches": prof["launches"], "avg_us": round(1e3 * prof["ms"] / prof["launches"], 2),
                                "avg_gflop_per_launch": round(prof["flops"] / prof["launches"] / 1e9, 3)}
         if not args.no_cpu_baseline:

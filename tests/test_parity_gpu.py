@@ -208,6 +208,56 @@ def test_base_bf16_fused_attention_vs_reference_and_vs_f32_mode():
     assert not bad, bad[:10]
 
 
+def test_large_shape_5s_clips_vs_oracle():
+    """BASELINE configs[3] geometry (wav2vec2-large: H=1024, 16 heads, FFN 4096; 5 s clips -> T=249, which takes
+    the T > 160 attention kernels), cut to 2 encoder layers so the CPU oracle finishes in seconds: eval embedding,
+    loss and every trainable gradient norm in the exact-f32 mode; embedding in the bf16 mode."""
+    import dataclasses
+    from w2v2_speaker_amd.config import W2V2Config
+    from w2v2_speaker_amd.engine import Plan
+    cfg = dataclasses.replace(W2V2Config.from_huggingface_id("facebook/wav2vec2-large"), num_hidden_layers=2)
+    ocfg = dataclasses.replace(O.OracleConfig.large(), num_hidden_layers=2)
+    B, N, C = 2, 80000, 211
+    assert cfg.num_frames(N) == 249
+    wav, label = O.synth_batch(B, N, C, seed=77)
+    st, sd = _store(cfg, ocfg, torch.float32, "aam", C)
+    sdg = {k: v.clone().requires_grad_(k.startswith("encoder") or k.startswith("feature_projection")
+                                       or k in ("masked_spec_embed", "loss_fn.fc_weights")) for k, v in sd.items()}
+    torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))
+    emb_ref = O.speaker_embedding(wav, sdg, ocfg)
+    loss_ref, _ = O.aam_softmax(emb_ref, sdg["loss_fn.fc_weights"], label)
+    loss_ref.backward()
+    ev = Plan(st, B, N, train=False)
+    e = ev.embed(wav.to(DEV))
+    torch.cuda.synchronize()
+    assert rel_l2(e.cpu(), emb_ref.detach()) < 1e-4
+    del ev
+    tr = Plan(st, B, N, train=True, reg=_no_reg())
+    st.zero_grad()
+    emb = tr.embed(wav.to(DEV))
+    loss, _ = tr.head_forward_backward(label.to(DEV))
+    tr.backward()
+    torch.cuda.synchronize()
+    assert rel_l2(emb.cpu(), emb_ref.detach()) < 1e-4
+    assert abs(float(loss) - float(loss_ref)) < 1e-4 * abs(float(loss_ref))
+    gmax = max(float(v.grad.norm()) for v in sdg.values() if v.grad is not None)
+    for n, v in sdg.items():
+        if v.grad is None:
+            continue
+        name = n if n.startswith("loss_fn") else "wav2vec.model." + n
+        if not st.is_trainable(name):
+            continue
+        ref = float(v.grad.double().norm())
+        got = float(st.g(name).double().norm())
+        assert abs(got - ref) <= 2e-3 * ref + 1e-6 * gmax, (n, got, ref)
+    del tr
+    stb, _ = _store(cfg, ocfg, torch.bfloat16, "aam", C)
+    evb = Plan(stb, B, N, train=False)
+    eb = evb.embed(wav.to(DEV))
+    torch.cuda.synchronize()
+    assert rel_l2(eb.cpu(), emb_ref.detach()) < 3e-2
+
+
 def test_full_batch_no_cross_utterance_mixing_and_determinism():
     """Size-independent property at the BASELINE size (B = 66, 3 s): an utterance's embedding does not
     depend on its batch neighbours (the reference's own BatchGradientVerification check,
