@@ -90,6 +90,8 @@ def main():
     ap.add_argument("--seconds", type=float, default=3.0)
     ap.add_argument("--speakers", type=int, default=5994)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--pooling", default="mean+std", choices=["mean+std", "attentive", "first+cls"],
+                    help="mean+std = the metric's workload; attentive = BASELINE configs[2]")
     ap.add_argument("--model", default="base", choices=["base", "large"],
                     help="base = BASELINE configs[1] (the metric's workload); large = configs[3] geometry "
                          "(24 layers, H=1024; use --seconds 5 --batch 32)")
@@ -124,13 +126,16 @@ def main():
     cfg = W2V2Config.from_huggingface_id("facebook/wav2vec2-" + args.model)
     n_samples = int(round(args.seconds * 16000))
     adt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
-    store = ParamStore(cfg, dev, adt, head="aam", num_speakers=args.speakers, freeze_cnn=not args.unfreeze_cnn)
+    store = ParamStore(cfg, dev, adt, head="aam", num_speakers=args.speakers, freeze_cnn=not args.unfreeze_cnn,
+                       attentive_pool=args.pooling == "attentive",
+                       embed_dim=cfg.hidden_size * (1 if args.pooling == "first+cls" else 2))
     store.init_weights(seed=20211)            # identical replicas on every rank (DDP broadcast equivalent)
     reg = Wav2Vec2RegularisationConfig()
     if args.no_regularisation:
         reg = Wav2Vec2RegularisationConfig(attention_dropout=0.0, feat_proj_dropout=0.0, hidden_dropout=0.0,
                                            layerdrop=0.0, mask_time_prob=0.0)
-    plan = Plan(store, args.batch, n_samples, train=True, reg=reg, seed=7 + rank)
+    plan = Plan(store, args.batch, n_samples, train=True, reg=reg, seed=7 + rank, pooling=args.pooling,
+                insert_cls_token=args.pooling == "first+cls")
     total = args.steps + args.warmup + 1
     trainer = SpeakerTrainer(store, plan, OneCycle(max_lr=5e-5, total_steps=max(total, 10)),
                              layerdrop_seed=1234 + rank, mask_seed=7 + rank)
@@ -161,13 +166,13 @@ def main():
         utt = args.batch * world * args.steps
         fl = cfg.flops_per_utt(n_samples, args.speakers)
         out = {
-            "metric": (f"utterances/sec (w2v2-{args.model} + mean+std + AAM-softmax training step, "
+            "metric": (f"utterances/sec (w2v2-{args.model} + {args.pooling} + AAM-softmax training step, "
                        f"{args.seconds:g} s clips)"),
             "value": round(utt / elapsed, 2), "unit": "utterances/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16" if adt == torch.bfloat16 else "f32", "data": "synthetic",
-            "config": {"workload": f"wav2vec2-{args.model} + AAM-softmax({args.speakers}), mean+std pooling, "
+            "config": {"workload": f"wav2vec2-{args.model} + AAM-softmax({args.speakers}), {args.pooling} pooling, "
                                    f"{args.seconds:g} s synthetic audio, "
                                    f"bs={args.batch} per GPU, CNN {'trainable' if args.unfreeze_cnn else 'frozen'}, "
                                    "fwd+bwd+all-reduce+Adam (BASELINE "

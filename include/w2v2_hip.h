@@ -227,6 +227,41 @@ int w2v2_pool_fwd(const void* x, float* out, int B, int T, int H, int mode, int 
 int w2v2_pool_bwd(const void* x, const float* out, const float* dout, void* dx, int B, int T, int H,
                   int mode, int dtype, void* stream);
 
+/* ------------------------------------------------------------------- attentive statistics pooling
+ * ref call site: src/layers/pooling.py:87-106 (AttentiveStatPool1D) -> speechbrain 0.5.x
+ * AttentiveStatisticsPooling(C, attention_channels A = 128, global_context=True); speechbrain is not part of the
+ * reference tree: the arithmetic follows its published definition (oracle.attentive_stat_pool).
+ *   ctx [B][2C] = {mean_t x, std_t x} (biased, clamp 1e-12);  a = Wx x_t + (W1[:, C:] ctx + b1) (GEMM + cb);
+ *   h = tanh(BatchNorm(relu(a))) with batch statistics over all B*T rows;  s = W2 h + b2 (GEMM);
+ *   w = softmax_t s;  out [B][2C] = {sum_t w x, sqrt(clamp(sum_t w (x - mean)^2, 1e-12))}  (mean first).
+ * x, a, h, s and their gradients are [B*T][.] act dtype; parameters / statistics f32.  The Wx / W2 products and
+ * their data / weight gradients are w2v2_gemm / w2v2_wgrad_grouped calls made by the host. */
+int w2v2_asp_context(const void* x, float* ctx, int B, int T, int C, int dtype, void* stream);
+int w2v2_asp_context_bias(const float* ctx, const float* w1 /*[A][3C]*/, const float* b1, float* cb /*[B][A]*/,
+                          int B, int A, int C, void* stream);
+int w2v2_asp_bn_workspace_floats(int M, int A);
+/* batch statistics of relu(a_pre) -> mean_rstd[A][2]; running = {mean[A], var[A]} updated like torch
+ * BatchNorm1d (momentum, unbiased variance) or NULL */
+int w2v2_asp_bn_stats(const void* a_pre, float* workspace, float* mean_rstd, float* running, int M, int A,
+                      float eps, float momentum, int dtype, void* stream);
+int w2v2_asp_bn_eval_stats(const float* running, float* mean_rstd, int A, float eps, void* stream);
+int w2v2_asp_bn_tanh(const void* a_pre, const float* mean_rstd, const float* gamma, const float* beta, void* h,
+                     int M, int A, int dtype, void* stream);
+/* dh -> da_pre through tanh, BatchNorm (batch statistics) and relu; writes dgamma[A], dbeta[A].  tanh is
+ * recomputed from a_pre (1 - h^2 from a stored bf16 h has no precision for saturated units). */
+int w2v2_asp_bn_bwd(const void* dh, const void* a_pre, const float* mean_rstd, const float* gamma,
+                    const float* beta, float* workspace, float* dgamma, float* dbeta, void* da, int M, int A,
+                    int dtype, void* stream);
+/* stats [B][C][2] = {max_t s, sum_t exp(s - max)} saved for the backward */
+int w2v2_asp_pool_fwd(const void* x, const void* s, float* out, float* stats, int B, int T, int C, int dtype,
+                      void* stream);
+/* dout [B][2C] -> ds (through the softmax) and the direct part of dx (both written) */
+int w2v2_asp_pool_bwd(const void* x, const void* s, const float* out, const float* stats, const float* dout,
+                      void* ds, void* dx, int B, int T, int C, int dtype, void* stream);
+/* context path: dW1[:, C:] (written), dx += d(mean, std) terms; scratch = B*A + B*2C floats */
+int w2v2_asp_context_bwd(const void* x, const float* ctx, const void* da, const float* w1, float* dw1, void* dx,
+                         float* scratch, int B, int T, int C, int A, int dtype, void* stream);
+
 /* ---------------------------------------------------------------------------------------- heads
  * Row inverse L2 norms 1/max(||x||,1e-12) (F.normalize, ref: src/optim/loss/aam_softmax.py:55). */
 int w2v2_row_invnorm(const void* x, int64_t ld, float* inv, int rows, int cols, int dtype,

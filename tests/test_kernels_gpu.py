@@ -516,6 +516,98 @@ def test_dropout_stream_statistics():
     assert abs(corr(masks[0], masks[1])) < 5 / n ** 0.5              # consecutive seeds
 
 
+# ----------------------------------------------------------------------------------------------- attentive pooling
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_attentive_pooling_stages_at_base_size(dtype):
+    """Every stage of csrc/asp.hip (+ its GEMMs) at the BASELINE configs[2] size (T=149, C=768, A=128) against an
+    f64 torch evaluation of the SAME stage on the stage's own inputs as stored by the HIP path -- so bf16 is tested
+    per stage, free of the noise amplification of the chained BatchNorm backward."""
+    from w2v2_speaker_amd.asp import ASP_PREFIX, AttentivePool
+    from w2v2_speaker_amd.config import W2V2Config
+    from w2v2_speaker_amd.params import ParamStore
+    B, T, C, A = 4, 149, 768, 128
+    st = ParamStore(W2V2Config(num_hidden_layers=1), DEV, dtype, head=None, attentive_pool=True)
+    g = torch.Generator().manual_seed(3)
+    for n, shp in st.shapes.items():
+        if n.startswith(ASP_PREFIX):
+            t = torch.randn(shp, generator=g)
+            t = 1 + 0.1 * t if n.endswith("norm.norm.weight") else (t / shp[1] ** 0.5 if t.dim() == 3 else 0.1 * t)
+            st.p(n).copy_(t.to(DEV))
+    st.sync_lowp()
+    rows = (B * T + 63) // 64 * 64
+    full = torch.zeros(rows, C, dtype=dtype, device=DEV)
+    x = full[:B * T]
+    x.copy_((rnd(B * T, C, seed=8) * 2 + 0.3).to(dtype))
+    x._w2v2_padded = full
+    emb = torch.zeros(B, 2 * C, device=DEV)
+    dx = torch.zeros(rows, C, dtype=dtype, device=DEV)[:B * T]
+    ap = AttentivePool(st, x, emb, dx, B, T, train=True)
+    st.zero_grad()
+    ap.forward()
+    demb = rnd(B, 2 * C, seed=9).to(DEV)
+    ap.backward(demb)
+    torch.cuda.synchronize()
+    tol = 1e-5 if dtype == torch.float32 else 1.5e-2
+    D = lambda t: t.detach().double().cpu()
+    P = lambda n: D(st.p(ASP_PREFIX + n))
+    G = lambda n: D(st.g(ASP_PREFIX + n))
+    xd = D(x).view(B, T, C)
+    W1, b1 = P("tdnn.conv.conv.weight").view(A, 3 * C), P("tdnn.conv.conv.bias")
+    W1q = D(st.w(ASP_PREFIX + "tdnn.conv.conv.weight")).view(A, 3 * C)          # operand copy the GEMMs read
+    W2q, b2 = D(st.w(ASP_PREFIX + "conv.conv.weight")).view(C, A), P("conv.conv.bias")
+    gam, bet = P("tdnn.norm.norm.weight"), P("tdnn.norm.norm.bias")
+    # forward stages
+    mean = xd.mean(1)
+    std = ((xd - mean[:, None]) ** 2).mean(1).clamp_min(1e-12).sqrt()
+    ctx = torch.cat([mean, std], 1)
+    assert rel_l2(D(ap.ctx), ctx) < 1e-5
+    cb = D(ap.ctx) @ W1[:, C:].t() + b1
+    assert rel_l2(D(ap.cb), cb) < 1e-5
+    a_pre = (xd @ W1q[:, :C].t() + D(ap.cb)[:, None]).view(B * T, A)
+    assert rel_l2(D(ap.a_pre), a_pre) < tol
+    r = D(ap.a_pre).clamp_min(0)
+    mu, var = r.mean(0), r.var(0, unbiased=False)
+    rstd = (var + 1e-5).rsqrt()
+    assert rel_l2(D(ap.mean_rstd)[:, 0], mu) < 1e-5 and rel_l2(D(ap.mean_rstd)[:, 1], rstd) < 1e-5
+    rh = (r - mu) * rstd
+    h = torch.tanh(rh * gam + bet)
+    assert rel_l2(D(ap.h), h) < tol
+    s_ref = D(ap.h) @ W2q.t() + b2
+    assert rel_l2(D(ap.s), s_ref) < tol
+    sd_ = D(ap.s).view(B, T, C)
+    w = torch.softmax(sd_, 1)
+    wm = (w * xd).sum(1)
+    wvar = (w * (xd - wm[:, None]) ** 2).sum(1)
+    out = torch.cat([wm, wvar.clamp_min(1e-12).sqrt()], 1)
+    assert rel_l2(D(emb), out) < 1e-5
+    # backward stages (each from the HIP path's own stored inputs)
+    dm, dsd = D(demb)[:, :C], D(demb)[:, C:]
+    dvar = dsd / (2 * out[:, C:])
+    dwt = xd * dm[:, None] + dvar[:, None] * (xd - wm[:, None]) ** 2
+    ds_ref = w * (dwt - (w * dwt).sum(1, keepdim=True))
+    dx_direct = w * (dm[:, None] + 2 * dvar[:, None] * (xd - wm[:, None]))
+    assert rel_l2(D(ap.ds).view(B, T, C), ds_ref) < tol
+    dh_ref = D(ap.ds) @ W2q
+    assert rel_l2(D(ap.dh), dh_ref) < tol
+    dz = D(ap.dh) * (1 - h * h)
+    da_ref = (gam * rstd * (dz - dz.mean(0) - rh * (dz * rh).mean(0))) * (D(ap.a_pre) > 0)
+    assert rel_l2(D(ap.da), da_ref) < tol
+    assert rel_l2(G("tdnn.norm.norm.weight"), (dz * rh).sum(0)) < tol and rel_l2(G("tdnn.norm.norm.bias"), dz.sum(0)) < tol
+    assert rel_l2(G("conv.conv.weight").view(C, A), D(ap.ds).t() @ D(ap.h)) < tol
+    # sum_t ds == 0 exactly (softmax backward): only rounding noise is left, compare on the scale of the summands
+    assert (G("conv.conv.bias") - D(ap.ds).sum(0)).abs().max() < tol * D(ap.ds).abs().sum(0).max()
+    dW1 = G("tdnn.conv.conv.weight").view(A, 3 * C)
+    dad = D(ap.da)
+    assert rel_l2(dW1[:, :C], dad.t() @ xd.view(B * T, C)) < tol
+    dsum = dad.view(B, T, A).sum(1)
+    assert rel_l2(dW1[:, C:], dsum.t() @ D(ap.ctx)) < tol
+    assert rel_l2(G("tdnn.conv.conv.bias"), dad.sum(0)) < tol
+    dctx = dsum @ W1[:, C:]
+    dx_ref = dx_direct + (dad @ W1q[:, :C]).view(B, T, C) + dctx[:, None, :C] / T \
+        + dctx[:, None, C:] * (xd - mean[:, None]) / (T * std[:, None])
+    assert rel_l2(D(dx).view(B, T, C), dx_ref) < tol
+
+
 # ----------------------------------------------------------------------------------------------- pooling
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_pooling_all_modes(dtype):

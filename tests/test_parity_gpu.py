@@ -208,6 +208,90 @@ def test_base_bf16_fused_attention_vs_reference_and_vs_f32_mode():
     assert not bad, bad[:10]
 
 
+def _asp_weights(store, seed=5):
+    """Seeded attentive-pooling weights under the speechbrain state-dict names, and as the oracle's dict."""
+    from w2v2_speaker_amd.asp import ASP_PREFIX
+    sd, od = {}, {}
+    for n, shp in store.shapes.items():
+        if not n.startswith(ASP_PREFIX):
+            continue
+        t = O.synth_tensor(n, shp, seed)
+        if n.endswith("norm.norm.weight"):
+            t = 1.0 + 0.1 * t
+        elif n.endswith("conv.conv.weight"):
+            t = t * (1.0 / shp[1] ** 0.5)
+        sd[n] = t
+    od["tdnn.conv.weight"] = sd[ASP_PREFIX + "tdnn.conv.conv.weight"]
+    od["tdnn.conv.bias"] = sd[ASP_PREFIX + "tdnn.conv.conv.bias"]
+    od["tdnn.norm.weight"] = sd[ASP_PREFIX + "tdnn.norm.norm.weight"]
+    od["tdnn.norm.bias"] = sd[ASP_PREFIX + "tdnn.norm.norm.bias"]
+    od["conv.weight"] = sd[ASP_PREFIX + "conv.conv.weight"]
+    od["conv.bias"] = sd[ASP_PREFIX + "conv.conv.bias"]
+    return sd, od
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_attentive_statistics_pooling_step_vs_oracle(dtype):
+    """SURVEY 8a row a10 / BASELINE configs[2]: wav2vec2 -> attentive statistics pooling (global context, BatchNorm
+    with batch statistics) -> AAM.  Embedding, loss and EVERY gradient (encoder + the six pooling tensors) against
+    the oracle's autograd.  The oracle restates speechbrain's published definition (speechbrain is not available
+    here): parity for this row is unpinned, see oracle.attentive_stat_pool."""
+    from w2v2_speaker_amd.engine import Plan
+    from w2v2_speaker_amd.params import ParamStore
+    cfg, ocfg = _cfgs("tiny")
+    B, N, C = 8, 4000, 10
+    st = ParamStore(cfg, DEV, dtype, head="aam", num_speakers=C, attentive_pool=True)
+    sd = O.make_state_dict(ocfg, 20211)
+    sd["loss_fn.fc_weights"] = O.synth_tensor("loss_fn.fc_weights", (C, st.embed_dim), 20211)
+    asd, aod = _asp_weights(st)
+    sd.update(asd)
+    st.load_state_dict(sd)
+    wav, label = O.synth_batch(B, N, C, seed=11)
+    sdg = {k: v.clone().requires_grad_(True) for k, v in sd.items() if not k.startswith("stat_pooling")}
+    aog = {k: v.clone().requires_grad_(True) for k, v in aod.items()}
+    hid = O.wav2vec2_forward(wav[:, 0] if wav.dim() == 3 else wav, sdg, ocfg)
+    emb_ref = O.attentive_stat_pool(hid, aog)
+    loss_ref, _ = O.aam_softmax(emb_ref, sdg["loss_fn.fc_weights"], label)
+    loss_ref.backward()
+    tr = Plan(st, B, N, train=True, reg=_no_reg(), pooling="attentive")
+    st.zero_grad()
+    emb = tr.embed(wav.to(DEV))
+    loss, _ = tr.head_forward_backward(label.to(DEV))
+    tr.backward()
+    torch.cuda.synchronize()
+    f32 = dtype == torch.float32
+    assert rel_l2(emb.cpu(), emb_ref.detach()) < (2e-5 if f32 else 3e-2)
+    assert abs(float(loss.detach()) - float(loss_ref.detach())) < (1e-4 if f32 else 3e-2) * abs(float(loss_ref.detach()))
+    from w2v2_speaker_amd.asp import ASP_PREFIX
+    names = {ASP_PREFIX + "tdnn.conv.conv.weight": aog["tdnn.conv.weight"], ASP_PREFIX + "tdnn.conv.conv.bias": aog["tdnn.conv.bias"],
+             ASP_PREFIX + "tdnn.norm.norm.weight": aog["tdnn.norm.weight"], ASP_PREFIX + "tdnn.norm.norm.bias": aog["tdnn.norm.bias"],
+             ASP_PREFIX + "conv.conv.weight": aog["conv.weight"], ASP_PREFIX + "conv.conv.bias": aog["conv.bias"]}
+    for n, v in sdg.items():
+        name = n if n.startswith("loss_fn") else "wav2vec.model." + n
+        if v.grad is not None and st.is_trainable(name):
+            names[name] = v
+    gmax = max(float(v.grad.norm()) for v in names.values())
+    tol = 2e-3 if f32 else 0.12
+    bad = []
+    for name, v in names.items():
+        got, ref = st.g(name).double().cpu().reshape(v.grad.shape), v.grad.double()
+        assert torch.isfinite(got).all(), name
+        if not f32 and not (name.startswith("loss_fn") or ".conv.conv." in name and "tdnn" not in name):
+            # bf16: everything upstream of the BatchNorm backward (a projection orthogonal to {1, rhat} that leaves
+            # a small residual of dz here) amplifies rounding noise ~10x in this random tiny model; those stages are
+            # checked one by one against f64 on their own bf16 inputs in test_kernels_gpu (attentive pooling stages)
+            continue
+        err = float((got - ref).norm())
+        if err > tol * float(ref.norm()) + (1e-6 if f32 else 2e-3) * gmax:
+            bad.append((name, round(err, 4), round(float(ref.norm()), 4)))
+    assert not bad, bad
+    # eval mode uses the running statistics the training step just updated (BatchNorm1d semantics)
+    ev = Plan(st, B, N, train=False, pooling="attentive")
+    e2 = ev.embed(wav.to(DEV))
+    torch.cuda.synchronize()
+    assert torch.isfinite(e2).all()
+
+
 def test_large_shape_5s_clips_vs_oracle():
     """BASELINE configs[3] geometry (wav2vec2-large: H=1024, 16 heads, FFN 4096; 5 s clips -> T=249, which takes
     the T > 160 attention kernels), cut to 2 encoder layers so the CPU oracle finishes in seconds: eval embedding,

@@ -75,6 +75,16 @@ _SIGS = {
                                    c_f32, c_u64, c_i32, c_vp]),
     "w2v2_pool_fwd": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "w2v2_pool_bwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    "w2v2_asp_context": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    "w2v2_asp_context_bias": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
+    "w2v2_asp_bn_workspace_floats": (c_i32, [c_i32, c_i32]),
+    "w2v2_asp_bn_stats": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_f32, c_f32, c_i32, c_vp]),
+    "w2v2_asp_bn_eval_stats": (c_i32, [c_vp, c_vp, c_i32, c_f32, c_vp]),
+    "w2v2_asp_bn_tanh": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
+    "w2v2_asp_bn_bwd": (c_i32, [c_vp] * 9 + [c_i32, c_i32, c_i32, c_vp]),
+    "w2v2_asp_pool_fwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    "w2v2_asp_pool_bwd": (c_i32, [c_vp] * 7 + [c_i32, c_i32, c_i32, c_i32, c_vp]),
+    "w2v2_asp_context_bwd": (c_i32, [c_vp] * 7 + [c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "w2v2_row_invnorm": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_i32, c_i32, c_vp]),
     "w2v2_aam_softmax_fwd_bwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32,
                                          c_i32, c_i64, c_f32, c_f32, c_i32, c_vp]),

@@ -1,0 +1,410 @@
+// asp.hip -- attentive statistics pooling (ref call site: src/layers/pooling.py:87-106 ->
+// speechbrain 0.5.x AttentiveStatisticsPooling(C, attention_channels=A=128, global_context=True);
+// speechbrain is NOT under /root/reference: restated from the published definition, see oracle.attentive_stat_pool).
+//
+//   ctx   = [mean_t x, std_t x]                                  (biased var, clamp 1e-12)        [B, 2C]
+//   a     = W1 . [x_t, ctx] + b1 = Wx x_t + (Wm mean + Ws std + b1)                               [B*T, A]
+//   h     = tanh(BatchNorm_{batch stats over (B,T)}(relu(a)))                                     [B*T, A]
+//   s     = W2 h + b2 ;  w = softmax_t(s)                                                         [B*T, C]
+//   out   = [sum_t w x, sqrt(clamp(sum_t w (x - mean_w)^2, 1e-12))]   (mean FIRST, quirk Q1)      [B, 2C]
+//
+// The two matmuls (Wx x, W2 h) and their data / weight gradients run on the GEMM kernels (gemm.hip, wgrad.hip);
+// this file holds the column / row statistics around them.  Everything here is HBM-bound and small (0.12 GFLOP/utt):
+// one thread per (utterance, channel) walks the time axis, adjacent threads = adjacent channels (coalesced rows).
+// Reductions over (B, T) are two-stage with a fixed order (deterministic, no atomics).
+#include "common.cuh"
+
+constexpr float ASP_EPS = 1e-12f;
+constexpr int ASP_ROWS = 64;       // rows per partial-sum block of the BatchNorm reductions
+
+// ------------------------------------------------------------------------------------------ global context
+template <typename T>
+__global__ void asp_context_kernel(const T* __restrict__ x, float* __restrict__ ctx, int Tn, int C) {
+  const int b = blockIdx.y, c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const T* xp = x + (int64_t)b * Tn * C + c;
+  float s = 0.f;
+  for (int t = 0; t < Tn; ++t) s += to_f32<T>(xp[(int64_t)t * C]);
+  const float mu = s / (float)Tn;
+  float q = 0.f;
+  for (int t = 0; t < Tn; ++t) {
+    const float d = to_f32<T>(xp[(int64_t)t * C]) - mu;
+    q = fmaf(d, d, q);
+  }
+  ctx[(int64_t)b * 2 * C + c] = mu;
+  ctx[(int64_t)b * 2 * C + C + c] = sqrtf(fmaxf(q / (float)Tn, ASP_EPS));
+}
+
+// cb[b][a] = b1[a] + sum_j ctx[b][j] * W1[a][C + j]        (one wave per output)
+__global__ __launch_bounds__(64) void asp_ctx_bias_kernel(const float* __restrict__ ctx, const float* __restrict__ w1,
+                                                          const float* __restrict__ b1, float* __restrict__ cb, int A,
+                                                          int C) {
+  const int a = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+  const float* cp = ctx + (int64_t)b * 2 * C;
+  const float* wp = w1 + (int64_t)a * 3 * C + C;
+  float s = 0.f;
+  for (int j = lane; j < 2 * C; j += 64) s = fmaf(cp[j], wp[j], s);
+  s = wave_sum(s);
+  if (lane == 0) cb[(int64_t)b * A + a] = s + b1[a];
+}
+
+// ------------------------------------------------------------------------------------------ BatchNorm over (B,T)
+// partial[blk][a][2] = {sum r, sum r^2} over ASP_ROWS rows, r = relu(a_pre)
+template <typename T>
+__global__ void asp_bn_partial_kernel(const T* __restrict__ a_pre, float* __restrict__ partial, int M, int A) {
+  const int a = blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= A) return;
+  const int m0 = blockIdx.y * ASP_ROWS, m1 = min(M, m0 + ASP_ROWS);
+  float s1 = 0.f, s2 = 0.f;
+  for (int m = m0; m < m1; ++m) {
+    const float r = fmaxf(to_f32<T>(a_pre[(int64_t)m * A + a]), 0.f);
+    s1 += r;
+    s2 = fmaf(r, r, s2);
+  }
+  float* pt = partial + ((int64_t)blockIdx.y * A + a) * 2;
+  pt[0] = s1;
+  pt[1] = s2;
+}
+// fixed-order fold -> {mean, rstd} (biased variance); running stats as torch BatchNorm1d (unbiased var, momentum)
+__global__ void asp_bn_finalize_kernel(const float* __restrict__ partial, float* __restrict__ mean_rstd,
+                                       float* __restrict__ running, int nblk, int M, int A, float eps,
+                                       float momentum) {
+  const int a = blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= A) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int j = 0; j < nblk; ++j) {
+    s1 += (double)partial[((int64_t)j * A + a) * 2];
+    s2 += (double)partial[((int64_t)j * A + a) * 2 + 1];
+  }
+  const double mu = s1 / M;
+  double var = s2 / M - mu * mu;
+  var = var > 0.0 ? var : 0.0;
+  mean_rstd[2 * a] = (float)mu;
+  mean_rstd[2 * a + 1] = (float)(1.0 / sqrt(var + (double)eps));
+  if (running != nullptr) {
+    const double unb = M > 1 ? var * M / (M - 1) : var;
+    running[a] = (1.f - momentum) * running[a] + momentum * (float)mu;
+    running[A + a] = (1.f - momentum) * running[A + a] + momentum * (float)unb;
+  }
+}
+__global__ void asp_bn_eval_kernel(const float* __restrict__ running, float* __restrict__ mean_rstd, int A, float eps) {
+  const int a = blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= A) return;
+  mean_rstd[2 * a] = running[a];
+  mean_rstd[2 * a + 1] = rsqrtf(running[A + a] + eps);
+}
+
+template <typename T>
+__global__ void asp_bn_tanh_kernel(const T* __restrict__ a_pre, const float* __restrict__ mean_rstd,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   T* __restrict__ h, int64_t n, int A) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int a = (int)(i % A);
+    const float r = fmaxf(to_f32<T>(a_pre[i]), 0.f);
+    const float z = (r - mean_rstd[2 * a]) * mean_rstd[2 * a + 1] * gamma[a] + beta[a];
+    h[i] = from_f32<T>(tanhf(z));
+  }
+}
+
+// backward of h = tanh(BN(relu(a_pre))): partial sums of dz and dz * rhat, then the apply pass.  tanh(z) is
+// RECOMPUTED from a_pre: 1 - h^2 from the stored bf16 h loses all precision for saturated units (h ~ 0.99 +- 0.004).
+template <typename T>
+__global__ void asp_bn_bwd_partial_kernel(const T* __restrict__ dh, const T* __restrict__ a_pre,
+                                          const float* __restrict__ mean_rstd, const float* __restrict__ gamma,
+                                          const float* __restrict__ beta, float* __restrict__ partial, int M, int A) {
+  const int a = blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= A) return;
+  const int m0 = blockIdx.y * ASP_ROWS, m1 = min(M, m0 + ASP_ROWS);
+  const float mu = mean_rstd[2 * a], rs = mean_rstd[2 * a + 1], ga = gamma[a], be = beta[a];
+  float s1 = 0.f, s2 = 0.f;
+  for (int m = m0; m < m1; ++m) {
+    const int64_t i = (int64_t)m * A + a;
+    const float rh = (fmaxf(to_f32<T>(a_pre[i]), 0.f) - mu) * rs;
+    const float y = tanhf(fmaf(rh, ga, be));
+    const float dz = to_f32<T>(dh[i]) * (1.f - y * y);
+    s1 += dz;
+    s2 = fmaf(dz, rh, s2);
+  }
+  float* pt = partial + ((int64_t)blockIdx.y * A + a) * 2;
+  pt[0] = s1;
+  pt[1] = s2;
+}
+// sums[a] = {sum dz, sum dz*rhat}; dbeta = sum dz, dgamma = sum dz*rhat (written, not accumulated)
+__global__ void asp_bn_bwd_finalize_kernel(const float* __restrict__ partial, float* __restrict__ sums,
+                                           float* __restrict__ dgamma, float* __restrict__ dbeta, int nblk, int A) {
+  const int a = blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= A) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int j = 0; j < nblk; ++j) {
+    s1 += (double)partial[((int64_t)j * A + a) * 2];
+    s2 += (double)partial[((int64_t)j * A + a) * 2 + 1];
+  }
+  sums[2 * a] = (float)s1;
+  sums[2 * a + 1] = (float)s2;
+  dbeta[a] = (float)s1;
+  dgamma[a] = (float)s2;
+}
+template <typename T>
+__global__ void asp_bn_bwd_apply_kernel(const T* __restrict__ dh, const T* __restrict__ a_pre,
+                                        const float* __restrict__ mean_rstd, const float* __restrict__ gamma,
+                                        const float* __restrict__ beta, const float* __restrict__ sums,
+                                        T* __restrict__ da, int64_t n, int A, float invM) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int a = (int)(i % A);
+    const float ap = to_f32<T>(a_pre[i]);
+    const float mu = mean_rstd[2 * a], rstd = mean_rstd[2 * a + 1];
+    const float rh = (fmaxf(ap, 0.f) - mu) * rstd;
+    const float y = tanhf(fmaf(rh, gamma[a], beta[a]));
+    const float dz = to_f32<T>(dh[i]) * (1.f - y * y);
+    const float dr = gamma[a] * rstd * (dz - sums[2 * a] * invM - rh * sums[2 * a + 1] * invM);
+    da[i] = from_f32<T>(ap > 0.f ? dr : 0.f);
+  }
+}
+
+// ------------------------------------------------------------------------------------------ weighted statistics
+// per (b, c): w = softmax_t(s);  out = [sum w x, sqrt(clamp(sum w (x - mean)^2))];  stats = {max_t s, sum_t exp(s - max)}
+template <typename T>
+__global__ void asp_pool_fwd_kernel(const T* __restrict__ x, const T* __restrict__ s, float* __restrict__ out,
+                                    float* __restrict__ stats, int Tn, int C) {
+  const int b = blockIdx.y, c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const int64_t base = (int64_t)b * Tn * C + c;
+  float mx = -INFINITY;
+  for (int t = 0; t < Tn; ++t) mx = fmaxf(mx, to_f32<T>(s[base + (int64_t)t * C]));
+  float z = 0.f, m1 = 0.f;
+  for (int t = 0; t < Tn; ++t) {
+    const float e = __expf(to_f32<T>(s[base + (int64_t)t * C]) - mx);
+    z += e;
+    m1 = fmaf(e, to_f32<T>(x[base + (int64_t)t * C]), m1);
+  }
+  const float inv = 1.0f / z, mean = m1 * inv;
+  float v = 0.f;
+  for (int t = 0; t < Tn; ++t) {
+    const float e = __expf(to_f32<T>(s[base + (int64_t)t * C]) - mx);
+    const float d = to_f32<T>(x[base + (int64_t)t * C]) - mean;
+    v = fmaf(e * d, d, v);
+  }
+  out[(int64_t)b * 2 * C + c] = mean;
+  out[(int64_t)b * 2 * C + C + c] = sqrtf(fmaxf(v * inv, ASP_EPS));
+  stats[((int64_t)b * C + c) * 2] = mx;
+  stats[((int64_t)b * C + c) * 2 + 1] = z;
+}
+
+// dout [B][2C] = {dmean, dstd}.  With var = sum w (x - mean)^2 (d var / d mean = 0 because sum w = 1):
+//   dvar = dstd / (2 std) if var > eps;  dx_t = w_t (dmean + 2 dvar (x_t - mean));  dw_t = x_t dmean + dvar (x_t - mean)^2
+//   ds_t = w_t (dw_t - sum_u w_u dw_u)
+template <typename T>
+__global__ void asp_pool_bwd_kernel(const T* __restrict__ x, const T* __restrict__ s, const float* __restrict__ out,
+                                    const float* __restrict__ stats, const float* __restrict__ dout,
+                                    T* __restrict__ ds, T* __restrict__ dx, int Tn, int C) {
+  const int b = blockIdx.y, c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const int64_t base = (int64_t)b * Tn * C + c;
+  const float mean = out[(int64_t)b * 2 * C + c], sd = out[(int64_t)b * 2 * C + C + c];
+  const float dmean = dout[(int64_t)b * 2 * C + c], dstd = dout[(int64_t)b * 2 * C + C + c];
+  const float mx = stats[((int64_t)b * C + c) * 2], inv = 1.0f / stats[((int64_t)b * C + c) * 2 + 1];
+  const float dvar = (sd * sd > ASP_EPS) ? dstd / (2.f * sd) : 0.f;
+  float dot = 0.f;
+  for (int t = 0; t < Tn; ++t) {
+    const float w = __expf(to_f32<T>(s[base + (int64_t)t * C]) - mx) * inv;
+    const float xv = to_f32<T>(x[base + (int64_t)t * C]), d = xv - mean;
+    dot = fmaf(w, xv * dmean + dvar * d * d, dot);
+  }
+  for (int t = 0; t < Tn; ++t) {
+    const float w = __expf(to_f32<T>(s[base + (int64_t)t * C]) - mx) * inv;
+    const float xv = to_f32<T>(x[base + (int64_t)t * C]), d = xv - mean;
+    const float dw = xv * dmean + dvar * d * d;
+    ds[base + (int64_t)t * C] = from_f32<T>(w * (dw - dot));
+    dx[base + (int64_t)t * C] = from_f32<T>(w * (dmean + 2.f * dvar * d));
+  }
+}
+
+// ------------------------------------------------------------------------------------------ context backward
+// dsum[b][a] = sum_t da[b,t,a]
+template <typename T>
+__global__ void asp_dsum_kernel(const T* __restrict__ da, float* __restrict__ dsum, int Tn, int A) {
+  const int b = blockIdx.y, a = blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= A) return;
+  float s = 0.f;
+  for (int t = 0; t < Tn; ++t) s += to_f32<T>(da[((int64_t)b * Tn + t) * A + a]);
+  dsum[(int64_t)b * A + a] = s;
+}
+// dW1[a][C + j] = sum_b dsum[b][a] ctx[b][j]  (j < 2C; written, not accumulated)
+__global__ void asp_dw_ctx_kernel(const float* __restrict__ dsum, const float* __restrict__ ctx,
+                                  float* __restrict__ dw1, int B, int A, int C) {
+  const int a = blockIdx.y, j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= 2 * C) return;
+  float s = 0.f;
+  for (int b = 0; b < B; ++b) s = fmaf(dsum[(int64_t)b * A + a], ctx[(int64_t)b * 2 * C + j], s);
+  dw1[(int64_t)a * 3 * C + C + j] = s;
+}
+// dctx[b][j] = sum_a dsum[b][a] W1[a][C + j]
+__global__ void asp_dctx_kernel(const float* __restrict__ dsum, const float* __restrict__ w1,
+                                float* __restrict__ dctx, int A, int C) {
+  const int b = blockIdx.y, j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= 2 * C) return;
+  float s = 0.f;
+  for (int a = 0; a < A; ++a) s = fmaf(dsum[(int64_t)b * A + a], w1[(int64_t)a * 3 * C + C + j], s);
+  dctx[(int64_t)b * 2 * C + j] = s;
+}
+// dx_t += dmean_ctx / T + dstd_ctx (x_t - mean) / (T std)    (std clamped: zero gradient below the clamp)
+template <typename T>
+__global__ void asp_context_bwd_kernel(const T* __restrict__ x, const float* __restrict__ ctx,
+                                       const float* __restrict__ dctx, T* __restrict__ dx, int Tn, int C) {
+  const int b = blockIdx.y, c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const int64_t base = (int64_t)b * Tn * C + c;
+  const float mu = ctx[(int64_t)b * 2 * C + c], sd = ctx[(int64_t)b * 2 * C + C + c];
+  const float dm = dctx[(int64_t)b * 2 * C + c] / (float)Tn;
+  const float dsd = (sd * sd > ASP_EPS) ? dctx[(int64_t)b * 2 * C + C + c] / ((float)Tn * sd) : 0.f;
+  for (int t = 0; t < Tn; ++t) {
+    const int64_t i = base + (int64_t)t * C;
+    const float xv = to_f32<T>(x[i]);
+    dx[i] = from_f32<T>(to_f32<T>(dx[i]) + dm + dsd * (xv - mu));
+  }
+}
+
+// ------------------------------------------------------------------------------------------ C ABI
+#define ASP_DT(CALL_BF16, CALL_F32, NAME)                \
+  if (dtype == W2V2_BF16) { CALL_BF16; }                 \
+  else if (dtype == W2V2_F32) { CALL_F32; }              \
+  else W2V2_FAIL(NAME ": bad dtype %d", dtype);          \
+  W2V2_CHECK_LAUNCH(NAME);                               \
+  return 0
+
+extern "C" int w2v2_asp_context(const void* x, float* ctx, int B, int T, int C, int dtype, void* stream) {
+  W2V2_REQUIRE(x && ctx && B > 0 && T > 0 && C > 0, "asp_context: bad arguments");
+  dim3 grid((unsigned)cdiv(C, 256), B);
+  hipStream_t st = as_stream(stream);
+  ASP_DT(hipLaunchKernelGGL(asp_context_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, ctx, T, C),
+         hipLaunchKernelGGL(asp_context_kernel<float>, grid, dim3(256), 0, st, (const float*)x, ctx, T, C),
+         "asp_context");
+}
+
+extern "C" int w2v2_asp_context_bias(const float* ctx, const float* w1, const float* b1, float* cb, int B, int A,
+                                     int C, void* stream) {
+  W2V2_REQUIRE(ctx && w1 && b1 && cb && B > 0 && A > 0 && C > 0, "asp_context_bias: bad arguments");
+  hipLaunchKernelGGL(asp_ctx_bias_kernel, dim3(A, B), dim3(64), 0, as_stream(stream), ctx, w1, b1, cb, A, C);
+  W2V2_CHECK_LAUNCH("asp_context_bias");
+  return 0;
+}
+
+extern "C" int w2v2_asp_bn_workspace_floats(int M, int A) { return (int)cdiv(M, ASP_ROWS) * A * 2 + 2 * A; }
+
+extern "C" int w2v2_asp_bn_stats(const void* a_pre, float* workspace, float* mean_rstd, float* running, int M, int A,
+                                 float eps, float momentum, int dtype, void* stream) {
+  W2V2_REQUIRE(a_pre && workspace && mean_rstd && M > 0 && A > 0, "asp_bn_stats: bad arguments");
+  const int nblk = (int)cdiv(M, ASP_ROWS);
+  dim3 grid((unsigned)cdiv(A, 128), nblk);
+  hipStream_t st = as_stream(stream);
+  if (dtype == W2V2_BF16)
+    hipLaunchKernelGGL(asp_bn_partial_kernel<bf16_t>, grid, dim3(128), 0, st, (const bf16_t*)a_pre, workspace, M, A);
+  else if (dtype == W2V2_F32)
+    hipLaunchKernelGGL(asp_bn_partial_kernel<float>, grid, dim3(128), 0, st, (const float*)a_pre, workspace, M, A);
+  else
+    W2V2_FAIL("asp_bn_stats: bad dtype %d", dtype);
+  hipLaunchKernelGGL(asp_bn_finalize_kernel, dim3((unsigned)cdiv(A, 128)), dim3(128), 0, st, workspace, mean_rstd,
+                     running, nblk, M, A, eps, momentum);
+  W2V2_CHECK_LAUNCH("asp_bn_stats");
+  return 0;
+}
+
+extern "C" int w2v2_asp_bn_eval_stats(const float* running, float* mean_rstd, int A, float eps, void* stream) {
+  W2V2_REQUIRE(running && mean_rstd && A > 0, "asp_bn_eval_stats: bad arguments");
+  hipLaunchKernelGGL(asp_bn_eval_kernel, dim3((unsigned)cdiv(A, 128)), dim3(128), 0, as_stream(stream), running,
+                     mean_rstd, A, eps);
+  W2V2_CHECK_LAUNCH("asp_bn_eval_stats");
+  return 0;
+}
+
+extern "C" int w2v2_asp_bn_tanh(const void* a_pre, const float* mean_rstd, const float* gamma, const float* beta,
+                                void* h, int M, int A, int dtype, void* stream) {
+  W2V2_REQUIRE(a_pre && mean_rstd && gamma && beta && h && M > 0 && A > 0, "asp_bn_tanh: bad arguments");
+  const int64_t n = (int64_t)M * A;
+  const int nb = (int)(cdiv(n, 256) > 4096 ? 4096 : cdiv(n, 256));
+  hipStream_t st = as_stream(stream);
+  ASP_DT(hipLaunchKernelGGL(asp_bn_tanh_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, (const bf16_t*)a_pre, mean_rstd,
+                            gamma, beta, (bf16_t*)h, n, A),
+         hipLaunchKernelGGL(asp_bn_tanh_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)a_pre, mean_rstd,
+                            gamma, beta, (float*)h, n, A),
+         "asp_bn_tanh");
+}
+
+extern "C" int w2v2_asp_bn_bwd(const void* dh, const void* a_pre, const float* mean_rstd, const float* gamma,
+                               const float* beta, float* workspace, float* dgamma, float* dbeta, void* da, int M, int A,
+                               int dtype, void* stream) {
+  W2V2_REQUIRE(dh && a_pre && mean_rstd && gamma && beta && workspace && dgamma && dbeta && da && M > 0 && A > 0,
+               "asp_bn_bwd: bad arguments");
+  const int nblk = (int)cdiv(M, ASP_ROWS);
+  float* sums = workspace + (int64_t)nblk * A * 2;
+  dim3 grid((unsigned)cdiv(A, 128), nblk);
+  const int64_t n = (int64_t)M * A;
+  const int nb = (int)(cdiv(n, 256) > 4096 ? 4096 : cdiv(n, 256));
+  hipStream_t st = as_stream(stream);
+#define ASP_BNB(T_)                                                                                                  \
+  hipLaunchKernelGGL(asp_bn_bwd_partial_kernel<T_>, grid, dim3(128), 0, st, (const T_*)dh, (const T_*)a_pre,         \
+                     mean_rstd, gamma, beta, workspace, M, A);                                                       \
+  hipLaunchKernelGGL(asp_bn_bwd_finalize_kernel, dim3((unsigned)cdiv(A, 128)), dim3(128), 0, st, workspace, sums,    \
+                     dgamma, dbeta, nblk, A);                                                                        \
+  hipLaunchKernelGGL(asp_bn_bwd_apply_kernel<T_>, dim3(nb), dim3(256), 0, st, (const T_*)dh, (const T_*)a_pre,       \
+                     mean_rstd, gamma, beta, sums, (T_*)da, n, A, 1.0f / (float)M)
+  if (dtype == W2V2_BF16) { ASP_BNB(bf16_t); }
+  else if (dtype == W2V2_F32) { ASP_BNB(float); }
+  else W2V2_FAIL("asp_bn_bwd: bad dtype %d", dtype);
+#undef ASP_BNB
+  W2V2_CHECK_LAUNCH("asp_bn_bwd");
+  return 0;
+}
+
+extern "C" int w2v2_asp_pool_fwd(const void* x, const void* s, float* out, float* stats, int B, int T, int C, int dtype,
+                                 void* stream) {
+  W2V2_REQUIRE(x && s && out && stats && B > 0 && T > 0 && C > 0, "asp_pool_fwd: bad arguments");
+  dim3 grid((unsigned)cdiv(C, 128), B);
+  hipStream_t st = as_stream(stream);
+  ASP_DT(hipLaunchKernelGGL(asp_pool_fwd_kernel<bf16_t>, grid, dim3(128), 0, st, (const bf16_t*)x, (const bf16_t*)s,
+                            out, stats, T, C),
+         hipLaunchKernelGGL(asp_pool_fwd_kernel<float>, grid, dim3(128), 0, st, (const float*)x, (const float*)s, out,
+                            stats, T, C),
+         "asp_pool_fwd");
+}
+
+extern "C" int w2v2_asp_pool_bwd(const void* x, const void* s, const float* out, const float* stats, const float* dout,
+                                 void* ds, void* dx, int B, int T, int C, int dtype, void* stream) {
+  W2V2_REQUIRE(x && s && out && stats && dout && ds && dx && B > 0 && T > 0 && C > 0, "asp_pool_bwd: bad arguments");
+  dim3 grid((unsigned)cdiv(C, 128), B);
+  hipStream_t st = as_stream(stream);
+  ASP_DT(hipLaunchKernelGGL(asp_pool_bwd_kernel<bf16_t>, grid, dim3(128), 0, st, (const bf16_t*)x, (const bf16_t*)s,
+                            out, stats, dout, (bf16_t*)ds, (bf16_t*)dx, T, C),
+         hipLaunchKernelGGL(asp_pool_bwd_kernel<float>, grid, dim3(128), 0, st, (const float*)x, (const float*)s, out,
+                            stats, dout, (float*)ds, (float*)dx, T, C),
+         "asp_pool_bwd");
+}
+
+// scratch: B*A (dsum) + B*2C (dctx) floats
+extern "C" int w2v2_asp_context_bwd(const void* x, const float* ctx, const void* da, const float* w1, float* dw1,
+                                    void* dx, float* scratch, int B, int T, int C, int A, int dtype, void* stream) {
+  W2V2_REQUIRE(x && ctx && da && w1 && dw1 && dx && scratch && B > 0 && T > 0 && C > 0 && A > 0,
+               "asp_context_bwd: bad arguments");
+  float* dsum = scratch;
+  float* dctx = scratch + (int64_t)B * A;
+  hipStream_t st = as_stream(stream);
+  if (dtype == W2V2_BF16)
+    hipLaunchKernelGGL(asp_dsum_kernel<bf16_t>, dim3((unsigned)cdiv(A, 128), B), dim3(128), 0, st, (const bf16_t*)da,
+                       dsum, T, A);
+  else if (dtype == W2V2_F32)
+    hipLaunchKernelGGL(asp_dsum_kernel<float>, dim3((unsigned)cdiv(A, 128), B), dim3(128), 0, st, (const float*)da,
+                       dsum, T, A);
+  else
+    W2V2_FAIL("asp_context_bwd: bad dtype %d", dtype);
+  hipLaunchKernelGGL(asp_dw_ctx_kernel, dim3((unsigned)cdiv(2 * C, 256), A), dim3(256), 0, st, dsum, ctx, dw1, B, A, C);
+  hipLaunchKernelGGL(asp_dctx_kernel, dim3((unsigned)cdiv(2 * C, 256), B), dim3(256), 0, st, dsum, w1, dctx, A, C);
+  dim3 grid((unsigned)cdiv(C, 256), B);
+  if (dtype == W2V2_BF16)
+    hipLaunchKernelGGL(asp_context_bwd_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, ctx, dctx,
+                       (bf16_t*)dx, T, C);
+  else
+    hipLaunchKernelGGL(asp_context_bwd_kernel<float>, grid, dim3(256), 0, st, (const float*)x, ctx, dctx, (float*)dx,
+                       T, C);
+  W2V2_CHECK_LAUNCH("asp_context_bwd");
+  return 0;
+}

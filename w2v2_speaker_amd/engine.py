@@ -64,7 +64,8 @@ class Plan:
         cfg = store.cfg
         self.store, self.cfg, self.B, self.N, self.train = store, cfg, batch, n_samples, train
         self.reg = reg if reg is not None else Wav2Vec2RegularisationConfig()
-        self.pooling, self.pool_mode = pooling, POOL_MODES[pooling]
+        self.pooling, self.pool_mode = pooling, POOL_MODES.get(pooling, -1)
+        assert pooling == "attentive" or pooling in POOL_MODES, pooling
         self.cls, self.cls_c = insert_cls_token, cls_token_constant
         self.margin, self.scale = aam_margin, aam_scale
         self.seed = seed
@@ -77,9 +78,10 @@ class Plan:
         if fused_attention is None:
             fused_attention = (self.adt == torch.bfloat16 and d == 64 and self.T <= 256)
         self.fused = fused_attention
-        self.embed_dim = H * (2 if pooling == "mean+std" else 1)
+        self.embed_dim = H * (2 if pooling in ("mean+std", "attentive") else 1)
         self._pack_version = -1
         self._cnn_version = -1
+        self._asp = {}
         self._alloc()
         self._build_gemms()
 
@@ -419,8 +421,24 @@ class Plan:
     def embed(self, wav, mask=None, skip_layers=(), step: int = 0) -> torch.Tensor:
         """ref: src/lightning_modules/speaker/wav2vec2_fc.py:414-431 -> pooled embedding [B,E] f32."""
         out = self.forward(wav, mask, skip_layers, step)
+        if self.pooling == "attentive":
+            return self._asp_for(out).forward()
         ops.pool_fwd(out, self.emb, self.pool_mode)
         return self.emb
+
+    def _asp_for(self, out: torch.Tensor):
+        """Attentive statistics pooling over the buffer the encoder just wrote (built once per buffer)."""
+        from .asp import AttentivePool
+        key = out.data_ptr()
+        if key not in self._asp:
+            B, T, H = out.shape
+            x2 = out.view(B * T, H)
+            src = next((x for x in self.X if x.data_ptr() == key), None)
+            if src is not None and hasattr(src, "_w2v2_padded"):
+                x2._w2v2_padded = src._w2v2_padded
+            self._asp[key] = AttentivePool(self.store, x2, self.emb, self.G if self.train else None, B, T, self.train)
+        self._asp_cur = self._asp[key]
+        return self._asp_cur
 
     # ------------------------------------------------------------------------------------------ head
     def head_forward_backward(self, label: torch.Tensor):
@@ -441,13 +459,16 @@ class Plan:
         mp, mg = st.mp, st.mg
         step = self._step
         notify = on_bucket_ready or (lambda name: None)
-        notify("head")
         if dhidden is not None:           # gradient wrt last_hidden_state given directly (module surface)
             self.G.view(B, T, H).copy_(dhidden)
         else:
             if demb is None:
                 demb = self.demb
-            ops.pool_bwd(self.out, self.emb, demb, self.G.view(B, T, H), self.pool_mode)
+            if self.pooling == "attentive":   # its parameters share the head's gradient bucket
+                self._asp_cur.backward(demb)
+            else:
+                ops.pool_bwd(self.out, self.emb, demb, self.G.view(B, T, H), self.pool_mode)
+        notify("head")
         heads, d = cfg.num_attention_heads, cfg.head_dim
         pa, ph = reg.attention_dropout, reg.hidden_dropout
         for l in reversed(range(cfg.num_hidden_layers)):

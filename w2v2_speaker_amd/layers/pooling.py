@@ -101,4 +101,6 @@ class AttentiveStatPool1D(torch.nn.Module):
     def __init__(self, embedding_size: int, dim_to_reduce: int = 2):
         super().__init__()
         raise NotImplementedError("attentive statistics pooling (speechbrain; ref: src/layers/pooling.py:87-106) "
-                                  "has no HIP kernel yet (SURVEY 8a row a10)")
+                                  "runs inside the engine (its parameters live in the ParamStore arena): use "
+                                  "Wav2vec2FCModule(stat_pooling_type='attentive') or engine.Plan(pooling='attentive')"
+                                  " -- w2v2_speaker_amd/asp.py")

@@ -97,10 +97,11 @@ class Wav2vec2FCModule:
             mask_time_length=cfg.mask_time_length, mask_time_prob=cfg.mask_time_prob)
         H = self.model_cfg.hidden_size
         self.stat_pool_dimension = cfg.explicit_stat_pool_embedding_size or (
-            2 * H if cfg.stat_pooling_type == "mean+std" else H)
+            2 * H if cfg.stat_pooling_type in ("mean+std", "attentive") else H)
         self.store = ParamStore(self.model_cfg, device, act_dtype, head=loss, num_speakers=self.num_speakers,
                                 embed_dim=self.stat_pool_dimension,
-                                freeze_cnn=cfg.completely_freeze_feature_extractor)
+                                freeze_cnn=cfg.completely_freeze_feature_extractor,
+                                attentive_pool="attentive" in (cfg.stat_pooling_type, cfg.test_stat_pooling_type))
         self.store.init_weights(init_seed)
         self.loss, self.margin, self.scale = loss, aam_margin, aam_scale
         self.validation_pairs, self.test_pairs = validation_pairs or [], test_pairs or []

@@ -92,7 +92,7 @@ class Gemm:
         self.out_is_act = Cmat.dtype == torch.bfloat16
         # mirrors the host dispatch of csrc/gemm.hip (w2v2_gemm): which kernel this descriptor launches
         fast = (dt(A) == BF16 and not transA and not transB and K % 64 == 0 and K >= 64 and lda % 8 == 0 and ldb % 8 == 0)
-        if fast and N >= 768 and M >= 1024 and split_k <= 1 and not accumulate:
+        if fast and N >= 512 and M >= 1024 and split_k <= 1 and not accumulate:
             self.kernel_name = "gemm_bf16_glds3_kernel"
         elif fast:
             self.kernel_name = "gemm_bf16_glds_kernel"
@@ -394,3 +394,63 @@ def adam_step(p, g, m, v, pb, n: int, lr: float, beta1: float, beta2: float, eps
     bc2 = 1.0 - beta2 ** step
     _lib.check(lib().w2v2_adam_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), _p(pb), n, lr, beta1,
                                     beta2, eps, bc1, bc2, grad_scale, stream()), "adam_step")
+
+
+# ------------------------------------------------------------------------------------------------ attentive pooling
+def asp_context(x, ctx, B: int, T: int, C: int) -> None:
+    _dev(x, ctx)
+    _lib.check(lib().w2v2_asp_context(x.data_ptr(), ctx.data_ptr(), B, T, C, dt(x), stream()), "asp_context")
+
+
+def asp_context_bias(ctx, w1, b1, cb, B: int, A: int, C: int) -> None:
+    _dev(ctx, w1, b1, cb)
+    _lib.check(lib().w2v2_asp_context_bias(ctx.data_ptr(), w1.data_ptr(), b1.data_ptr(), cb.data_ptr(), B, A, C,
+                                           stream()), "asp_context_bias")
+
+
+def asp_bn_workspace(M: int, A: int, device) -> torch.Tensor:
+    return torch.empty(lib().w2v2_asp_bn_workspace_floats(M, A), dtype=torch.float32, device=device)
+
+
+def asp_bn_stats(a_pre, work, mean_rstd, running, M: int, A: int, eps: float, momentum: float) -> None:
+    _dev(a_pre, work, mean_rstd, running)
+    _lib.check(lib().w2v2_asp_bn_stats(a_pre.data_ptr(), work.data_ptr(), mean_rstd.data_ptr(), _p(running), M, A, eps,
+                                       momentum, dt(a_pre), stream()), "asp_bn_stats")
+
+
+def asp_bn_eval_stats(running, mean_rstd, A: int, eps: float) -> None:
+    _dev(running, mean_rstd)
+    _lib.check(lib().w2v2_asp_bn_eval_stats(running.data_ptr(), mean_rstd.data_ptr(), A, eps, stream()),
+               "asp_bn_eval_stats")
+
+
+def asp_bn_tanh(a_pre, mean_rstd, gamma, beta, h, M: int, A: int) -> None:
+    _dev(a_pre, mean_rstd, gamma, beta, h)
+    _lib.check(lib().w2v2_asp_bn_tanh(a_pre.data_ptr(), mean_rstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                      h.data_ptr(), M, A, dt(a_pre), stream()), "asp_bn_tanh")
+
+
+def asp_bn_bwd(dh, a_pre, mean_rstd, gamma, beta, work, dgamma, dbeta, da, M: int, A: int) -> None:
+    _dev(dh, a_pre, mean_rstd, gamma, beta, work, dgamma, dbeta, da)
+    _lib.check(lib().w2v2_asp_bn_bwd(dh.data_ptr(), a_pre.data_ptr(), mean_rstd.data_ptr(),
+                                     gamma.data_ptr(), beta.data_ptr(), work.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
+                                     da.data_ptr(), M, A, dt(dh), stream()), "asp_bn_bwd")
+
+
+def asp_pool_fwd(x, s, out, stats, B: int, T: int, C: int) -> None:
+    _dev(x, s, out, stats)
+    _lib.check(lib().w2v2_asp_pool_fwd(x.data_ptr(), s.data_ptr(), out.data_ptr(), stats.data_ptr(), B, T, C, dt(x),
+                                       stream()), "asp_pool_fwd")
+
+
+def asp_pool_bwd(x, s, out, stats, dout, ds, dx, B: int, T: int, C: int) -> None:
+    _dev(x, s, out, stats, dout, ds, dx)
+    _lib.check(lib().w2v2_asp_pool_bwd(x.data_ptr(), s.data_ptr(), out.data_ptr(), stats.data_ptr(), dout.data_ptr(),
+                                       ds.data_ptr(), dx.data_ptr(), B, T, C, dt(x), stream()), "asp_pool_bwd")
+
+
+def asp_context_bwd(x, ctx, da, w1, dw1, dx, scratch, B: int, T: int, C: int, A: int) -> None:
+    _dev(x, ctx, da, w1, dw1, dx, scratch)
+    _lib.check(lib().w2v2_asp_context_bwd(x.data_ptr(), ctx.data_ptr(), da.data_ptr(), w1.data_ptr(), dw1.data_ptr(),
+                                          dx.data_ptr(), scratch.data_ptr(), B, T, C, A, dt(x), stream()),
+               "asp_context_bwd")

@@ -73,7 +73,7 @@ _WN_OLD = {"encoder.pos_conv_embed.conv.weight_g": "encoder.pos_conv_embed.conv.
 class ParamStore:
     def __init__(self, cfg: W2V2Config, device, act_dtype: torch.dtype = torch.bfloat16,
                  head: Optional[str] = "aam", num_speakers: int = 5994, embed_dim: Optional[int] = None,
-                 freeze_cnn: bool = True):
+                 freeze_cnn: bool = True, attentive_pool: bool = False, attention_channels: int = 128):
         assert act_dtype in (torch.bfloat16, torch.float32)
         assert head in (None, "aam", "ce")
         self.cfg, self.device, self.act_dtype = cfg, torch.device(device), act_dtype
@@ -85,6 +85,13 @@ class ParamStore:
         elif head == "ce":
             shapes["fc_list.0.0.weight"] = (num_speakers, self.embed_dim)
             shapes["fc_list.0.0.bias"] = (num_speakers,)
+        self.attentive_pool = attentive_pool
+        # BatchNorm1d buffers {running_mean[A], running_var[A]} of the attentive pooling, shared by every plan
+        self.asp_running = (torch.cat([torch.zeros(attention_channels), torch.ones(attention_channels)]).to(device)
+                            if attentive_pool else None)
+        if attentive_pool:      # pooling parameters sit with the classifier: same gradient bucket and Adam slice
+            from .asp import asp_param_shapes
+            shapes.update(asp_param_shapes(cfg.hidden_size, attention_channels))
         for n, s in hf_param_shapes(cfg).items():
             shapes[W2V_PREFIX + n] = s
         self.shapes = shapes
@@ -196,7 +203,7 @@ class ParamStore:
         """Contiguous gradient slices in the order backward finishes them."""
         names = list(self.shapes)
         marks: List[Tuple[str, int]] = []
-        if self.head is not None:
+        if self.head is not None or self.attentive_pool:
             marks.append(("head", 0))
         L = self.cfg.num_hidden_layers
         for l in reversed(range(L)):
@@ -249,7 +256,7 @@ class ParamStore:
                 t = torch.rand(s, generator=g)
             elif n.endswith("weight.original0"):
                 t = torch.ones(s)
-            elif "layer_norm" in n:
+            elif "layer_norm" in n or ".norm.norm." in n:
                 t = torch.ones(s) if leaf == "weight" else torch.zeros(s)
             elif leaf == "bias":
                 t = torch.zeros(s)
@@ -281,7 +288,7 @@ class ParamStore:
 
     def head_size(self) -> int:
         """Number of leading arena elements that belong to the classification head."""
-        return self.grad_buckets()[0][2] if self.head is not None else 0
+        return self.grad_buckets()[0][2] if (self.head is not None or self.attentive_pool) else 0
 
     def adam_step(self, lr: float, beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8,
                   grad_scale: float = 1.0, head_only: bool = False) -> None:
