@@ -17,22 +17,50 @@
 constexpr float ASP_EPS = 1e-12f;
 constexpr int ASP_ROWS = 64;       // rows per partial-sum block of the BatchNorm reductions
 
+// Per-(utterance, channel) walks over time use blockDim = (64 channels, ASP_TL time lanes): lane ty takes frames
+// ty, ty + ASP_TL, ...; partial results meet in LDS and every thread folds them in the same fixed order.
+constexpr int ASP_TL = 8;
+__device__ __forceinline__ float asp_block_sum(float v, float (*red)[64]) {
+  __syncthreads();
+  red[threadIdx.y][threadIdx.x] = v;
+  __syncthreads();
+  float s = 0.f;
+#pragma unroll
+  for (int y = 0; y < ASP_TL; ++y) s += red[y][threadIdx.x];
+  return s;
+}
+__device__ __forceinline__ float asp_block_max(float v, float (*red)[64]) {
+  __syncthreads();
+  red[threadIdx.y][threadIdx.x] = v;
+  __syncthreads();
+  float s = -INFINITY;
+#pragma unroll
+  for (int y = 0; y < ASP_TL; ++y) s = fmaxf(s, red[y][threadIdx.x]);
+  return s;
+}
+
 // ------------------------------------------------------------------------------------------ global context
 template <typename T>
 __global__ void asp_context_kernel(const T* __restrict__ x, float* __restrict__ ctx, int Tn, int C) {
-  const int b = blockIdx.y, c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  const T* xp = x + (int64_t)b * Tn * C + c;
+  __shared__ float red[ASP_TL][64];
+  const int b = blockIdx.y, c = blockIdx.x * 64 + threadIdx.x;
+  const bool ok = c < C;
+  const T* xp = x + (int64_t)b * Tn * C + (ok ? c : 0);
   float s = 0.f;
-  for (int t = 0; t < Tn; ++t) s += to_f32<T>(xp[(int64_t)t * C]);
-  const float mu = s / (float)Tn;
+  if (ok)
+    for (int t = threadIdx.y; t < Tn; t += ASP_TL) s += to_f32<T>(xp[(int64_t)t * C]);
+  const float mu = asp_block_sum(s, red) / (float)Tn;
   float q = 0.f;
-  for (int t = 0; t < Tn; ++t) {
-    const float d = to_f32<T>(xp[(int64_t)t * C]) - mu;
-    q = fmaf(d, d, q);
+  if (ok)
+    for (int t = threadIdx.y; t < Tn; t += ASP_TL) {
+      const float d = to_f32<T>(xp[(int64_t)t * C]) - mu;
+      q = fmaf(d, d, q);
+    }
+  q = asp_block_sum(q, red);
+  if (ok && threadIdx.y == 0) {
+    ctx[(int64_t)b * 2 * C + c] = mu;
+    ctx[(int64_t)b * 2 * C + C + c] = sqrtf(fmaxf(q / (float)Tn, ASP_EPS));
   }
-  ctx[(int64_t)b * 2 * C + c] = mu;
-  ctx[(int64_t)b * 2 * C + C + c] = sqrtf(fmaxf(q / (float)Tn, ASP_EPS));
 }
 
 // cb[b][a] = b1[a] + sum_j ctx[b][j] * W1[a][C + j]        (one wave per output)
@@ -65,17 +93,34 @@ __global__ void asp_bn_partial_kernel(const T* __restrict__ a_pre, float* __rest
   pt[0] = s1;
   pt[1] = s2;
 }
-// fixed-order fold -> {mean, rstd} (biased variance); running stats as torch BatchNorm1d (unbiased var, momentum)
-__global__ void asp_bn_finalize_kernel(const float* __restrict__ partial, float* __restrict__ mean_rstd,
-                                       float* __restrict__ running, int nblk, int M, int A, float eps,
-                                       float momentum) {
-  const int a = blockIdx.x * blockDim.x + threadIdx.x;
-  if (a >= A) return;
-  double s1 = 0.0, s2 = 0.0;
-  for (int j = 0; j < nblk; ++j) {
-    s1 += (double)partial[((int64_t)j * A + a) * 2];
-    s2 += (double)partial[((int64_t)j * A + a) * 2 + 1];
-  }
+// fixed-order fold -> {mean, rstd} (biased variance); running stats as torch BatchNorm1d (unbiased var, momentum).
+// blockDim = (128 channels, 8 partial-block groups): group y folds blocks y, y+8, ... in order, then thread y == 0
+// folds the 8 group sums in order (deterministic, 8x shorter serial chain than one thread per channel).
+__device__ __forceinline__ void asp_fold(const float* __restrict__ partial, int nblk, int A, int a, double& s1,
+                                         double& s2, double (*red)[128][2]) {
+  double p1 = 0.0, p2 = 0.0;
+  if (a < A)
+    for (int j = threadIdx.y; j < nblk; j += 8) {
+      p1 += (double)partial[((int64_t)j * A + a) * 2];
+      p2 += (double)partial[((int64_t)j * A + a) * 2 + 1];
+    }
+  red[threadIdx.y][threadIdx.x][0] = p1;
+  red[threadIdx.y][threadIdx.x][1] = p2;
+  __syncthreads();
+  s1 = 0.0;
+  s2 = 0.0;
+  if (threadIdx.y == 0)
+    for (int y = 0; y < 8; ++y) { s1 += red[y][threadIdx.x][0]; s2 += red[y][threadIdx.x][1]; }
+}
+__global__ __launch_bounds__(1024) void asp_bn_finalize_kernel(const float* __restrict__ partial,
+                                                               float* __restrict__ mean_rstd,
+                                                               float* __restrict__ running, int nblk, int M, int A,
+                                                               float eps, float momentum) {
+  __shared__ double red[8][128][2];
+  const int a = blockIdx.x * 128 + threadIdx.x;
+  double s1, s2;
+  asp_fold(partial, nblk, A, a, s1, s2, red);
+  if (threadIdx.y != 0 || a >= A) return;
   const double mu = s1 / M;
   double var = s2 / M - mu * mu;
   var = var > 0.0 ? var : 0.0;
@@ -130,15 +175,14 @@ __global__ void asp_bn_bwd_partial_kernel(const T* __restrict__ dh, const T* __r
   pt[1] = s2;
 }
 // sums[a] = {sum dz, sum dz*rhat}; dbeta = sum dz, dgamma = sum dz*rhat (written, not accumulated)
-__global__ void asp_bn_bwd_finalize_kernel(const float* __restrict__ partial, float* __restrict__ sums,
-                                           float* __restrict__ dgamma, float* __restrict__ dbeta, int nblk, int A) {
-  const int a = blockIdx.x * blockDim.x + threadIdx.x;
-  if (a >= A) return;
-  double s1 = 0.0, s2 = 0.0;
-  for (int j = 0; j < nblk; ++j) {
-    s1 += (double)partial[((int64_t)j * A + a) * 2];
-    s2 += (double)partial[((int64_t)j * A + a) * 2 + 1];
-  }
+__global__ __launch_bounds__(1024) void asp_bn_bwd_finalize_kernel(const float* __restrict__ partial,
+                                                                   float* __restrict__ sums, float* __restrict__ dgamma,
+                                                                   float* __restrict__ dbeta, int nblk, int A) {
+  __shared__ double red[8][128][2];
+  const int a = blockIdx.x * 128 + threadIdx.x;
+  double s1, s2;
+  asp_fold(partial, nblk, A, a, s1, s2, red);
+  if (threadIdx.y != 0 || a >= A) return;
   sums[2 * a] = (float)s1;
   sums[2 * a + 1] = (float)s2;
   dbeta[a] = (float)s1;
@@ -166,28 +210,38 @@ __global__ void asp_bn_bwd_apply_kernel(const T* __restrict__ dh, const T* __res
 template <typename T>
 __global__ void asp_pool_fwd_kernel(const T* __restrict__ x, const T* __restrict__ s, float* __restrict__ out,
                                     float* __restrict__ stats, int Tn, int C) {
-  const int b = blockIdx.y, c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  const int64_t base = (int64_t)b * Tn * C + c;
+  __shared__ float red[ASP_TL][64];
+  const int b = blockIdx.y, c = blockIdx.x * 64 + threadIdx.x;
+  const bool ok = c < C;
+  const int64_t base = (int64_t)b * Tn * C + (ok ? c : 0);
   float mx = -INFINITY;
-  for (int t = 0; t < Tn; ++t) mx = fmaxf(mx, to_f32<T>(s[base + (int64_t)t * C]));
+  if (ok)
+    for (int t = threadIdx.y; t < Tn; t += ASP_TL) mx = fmaxf(mx, to_f32<T>(s[base + (int64_t)t * C]));
+  mx = asp_block_max(mx, red);
   float z = 0.f, m1 = 0.f;
-  for (int t = 0; t < Tn; ++t) {
-    const float e = __expf(to_f32<T>(s[base + (int64_t)t * C]) - mx);
-    z += e;
-    m1 = fmaf(e, to_f32<T>(x[base + (int64_t)t * C]), m1);
-  }
+  if (ok)
+    for (int t = threadIdx.y; t < Tn; t += ASP_TL) {
+      const float e = __expf(to_f32<T>(s[base + (int64_t)t * C]) - mx);
+      z += e;
+      m1 = fmaf(e, to_f32<T>(x[base + (int64_t)t * C]), m1);
+    }
+  z = asp_block_sum(z, red);
+  m1 = asp_block_sum(m1, red);
   const float inv = 1.0f / z, mean = m1 * inv;
   float v = 0.f;
-  for (int t = 0; t < Tn; ++t) {
-    const float e = __expf(to_f32<T>(s[base + (int64_t)t * C]) - mx);
-    const float d = to_f32<T>(x[base + (int64_t)t * C]) - mean;
-    v = fmaf(e * d, d, v);
+  if (ok)
+    for (int t = threadIdx.y; t < Tn; t += ASP_TL) {
+      const float e = __expf(to_f32<T>(s[base + (int64_t)t * C]) - mx);
+      const float d = to_f32<T>(x[base + (int64_t)t * C]) - mean;
+      v = fmaf(e * d, d, v);
+    }
+  v = asp_block_sum(v, red);
+  if (ok && threadIdx.y == 0) {
+    out[(int64_t)b * 2 * C + c] = mean;
+    out[(int64_t)b * 2 * C + C + c] = sqrtf(fmaxf(v * inv, ASP_EPS));
+    stats[((int64_t)b * C + c) * 2] = mx;
+    stats[((int64_t)b * C + c) * 2 + 1] = z;
   }
-  out[(int64_t)b * 2 * C + c] = mean;
-  out[(int64_t)b * 2 * C + C + c] = sqrtf(fmaxf(v * inv, ASP_EPS));
-  stats[((int64_t)b * C + c) * 2] = mx;
-  stats[((int64_t)b * C + c) * 2 + 1] = z;
 }
 
 // dout [B][2C] = {dmean, dstd}.  With var = sum w (x - mean)^2 (d var / d mean = 0 because sum w = 1):
@@ -197,20 +251,25 @@ template <typename T>
 __global__ void asp_pool_bwd_kernel(const T* __restrict__ x, const T* __restrict__ s, const float* __restrict__ out,
                                     const float* __restrict__ stats, const float* __restrict__ dout,
                                     T* __restrict__ ds, T* __restrict__ dx, int Tn, int C) {
-  const int b = blockIdx.y, c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  const int64_t base = (int64_t)b * Tn * C + c;
-  const float mean = out[(int64_t)b * 2 * C + c], sd = out[(int64_t)b * 2 * C + C + c];
-  const float dmean = dout[(int64_t)b * 2 * C + c], dstd = dout[(int64_t)b * 2 * C + C + c];
-  const float mx = stats[((int64_t)b * C + c) * 2], inv = 1.0f / stats[((int64_t)b * C + c) * 2 + 1];
+  __shared__ float red[ASP_TL][64];
+  const int b = blockIdx.y, c = blockIdx.x * 64 + threadIdx.x;
+  const bool ok = c < C;
+  const int cc = ok ? c : 0;
+  const int64_t base = (int64_t)b * Tn * C + cc;
+  const float mean = out[(int64_t)b * 2 * C + cc], sd = out[(int64_t)b * 2 * C + C + cc];
+  const float dmean = dout[(int64_t)b * 2 * C + cc], dstd = dout[(int64_t)b * 2 * C + C + cc];
+  const float mx = stats[((int64_t)b * C + cc) * 2], inv = 1.0f / stats[((int64_t)b * C + cc) * 2 + 1];
   const float dvar = (sd * sd > ASP_EPS) ? dstd / (2.f * sd) : 0.f;
   float dot = 0.f;
-  for (int t = 0; t < Tn; ++t) {
-    const float w = __expf(to_f32<T>(s[base + (int64_t)t * C]) - mx) * inv;
-    const float xv = to_f32<T>(x[base + (int64_t)t * C]), d = xv - mean;
-    dot = fmaf(w, xv * dmean + dvar * d * d, dot);
-  }
-  for (int t = 0; t < Tn; ++t) {
+  if (ok)
+    for (int t = threadIdx.y; t < Tn; t += ASP_TL) {
+      const float w = __expf(to_f32<T>(s[base + (int64_t)t * C]) - mx) * inv;
+      const float xv = to_f32<T>(x[base + (int64_t)t * C]), d = xv - mean;
+      dot = fmaf(w, xv * dmean + dvar * d * d, dot);
+    }
+  dot = asp_block_sum(dot, red);
+  if (!ok) return;
+  for (int t = threadIdx.y; t < Tn; t += ASP_TL) {
     const float w = __expf(to_f32<T>(s[base + (int64_t)t * C]) - mx) * inv;
     const float xv = to_f32<T>(x[base + (int64_t)t * C]), d = xv - mean;
     const float dw = xv * dmean + dvar * d * d;
@@ -223,11 +282,14 @@ __global__ void asp_pool_bwd_kernel(const T* __restrict__ x, const T* __restrict
 // dsum[b][a] = sum_t da[b,t,a]
 template <typename T>
 __global__ void asp_dsum_kernel(const T* __restrict__ da, float* __restrict__ dsum, int Tn, int A) {
-  const int b = blockIdx.y, a = blockIdx.x * blockDim.x + threadIdx.x;
-  if (a >= A) return;
+  __shared__ float red[ASP_TL][64];
+  const int b = blockIdx.y, a = blockIdx.x * 64 + threadIdx.x;
+  const bool ok = a < A;
   float s = 0.f;
-  for (int t = 0; t < Tn; ++t) s += to_f32<T>(da[((int64_t)b * Tn + t) * A + a]);
-  dsum[(int64_t)b * A + a] = s;
+  if (ok)
+    for (int t = threadIdx.y; t < Tn; t += ASP_TL) s += to_f32<T>(da[((int64_t)b * Tn + t) * A + a]);
+  s = asp_block_sum(s, red);
+  if (ok && threadIdx.y == 0) dsum[(int64_t)b * A + a] = s;
 }
 // dW1[a][C + j] = sum_b dsum[b][a] ctx[b][j]  (j < 2C; written, not accumulated)
 __global__ void asp_dw_ctx_kernel(const float* __restrict__ dsum, const float* __restrict__ ctx,
@@ -251,13 +313,13 @@ __global__ void asp_dctx_kernel(const float* __restrict__ dsum, const float* __r
 template <typename T>
 __global__ void asp_context_bwd_kernel(const T* __restrict__ x, const float* __restrict__ ctx,
                                        const float* __restrict__ dctx, T* __restrict__ dx, int Tn, int C) {
-  const int b = blockIdx.y, c = blockIdx.x * blockDim.x + threadIdx.x;
+  const int b = blockIdx.y, c = blockIdx.x * 64 + threadIdx.x;
   if (c >= C) return;
   const int64_t base = (int64_t)b * Tn * C + c;
   const float mu = ctx[(int64_t)b * 2 * C + c], sd = ctx[(int64_t)b * 2 * C + C + c];
   const float dm = dctx[(int64_t)b * 2 * C + c] / (float)Tn;
   const float dsd = (sd * sd > ASP_EPS) ? dctx[(int64_t)b * 2 * C + C + c] / ((float)Tn * sd) : 0.f;
-  for (int t = 0; t < Tn; ++t) {
+  for (int t = threadIdx.y; t < Tn; t += ASP_TL) {
     const int64_t i = base + (int64_t)t * C;
     const float xv = to_f32<T>(x[i]);
     dx[i] = from_f32<T>(to_f32<T>(dx[i]) + dm + dsd * (xv - mu));
@@ -274,10 +336,10 @@ __global__ void asp_context_bwd_kernel(const T* __restrict__ x, const float* __r
 
 extern "C" int w2v2_asp_context(const void* x, float* ctx, int B, int T, int C, int dtype, void* stream) {
   W2V2_REQUIRE(x && ctx && B > 0 && T > 0 && C > 0, "asp_context: bad arguments");
-  dim3 grid((unsigned)cdiv(C, 256), B);
+  dim3 grid((unsigned)cdiv(C, 64), B), blk(64, ASP_TL);
   hipStream_t st = as_stream(stream);
-  ASP_DT(hipLaunchKernelGGL(asp_context_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, ctx, T, C),
-         hipLaunchKernelGGL(asp_context_kernel<float>, grid, dim3(256), 0, st, (const float*)x, ctx, T, C),
+  ASP_DT(hipLaunchKernelGGL(asp_context_kernel<bf16_t>, grid, blk, 0, st, (const bf16_t*)x, ctx, T, C),
+         hipLaunchKernelGGL(asp_context_kernel<float>, grid, blk, 0, st, (const float*)x, ctx, T, C),
          "asp_context");
 }
 
@@ -303,7 +365,7 @@ extern "C" int w2v2_asp_bn_stats(const void* a_pre, float* workspace, float* mea
     hipLaunchKernelGGL(asp_bn_partial_kernel<float>, grid, dim3(128), 0, st, (const float*)a_pre, workspace, M, A);
   else
     W2V2_FAIL("asp_bn_stats: bad dtype %d", dtype);
-  hipLaunchKernelGGL(asp_bn_finalize_kernel, dim3((unsigned)cdiv(A, 128)), dim3(128), 0, st, workspace, mean_rstd,
+  hipLaunchKernelGGL(asp_bn_finalize_kernel, dim3((unsigned)cdiv(A, 128)), dim3(128, 8), 0, st, workspace, mean_rstd,
                      running, nblk, M, A, eps, momentum);
   W2V2_CHECK_LAUNCH("asp_bn_stats");
   return 0;
@@ -344,7 +406,7 @@ extern "C" int w2v2_asp_bn_bwd(const void* dh, const void* a_pre, const float* m
 #define ASP_BNB(T_)                                                                                                  \
   hipLaunchKernelGGL(asp_bn_bwd_partial_kernel<T_>, grid, dim3(128), 0, st, (const T_*)dh, (const T_*)a_pre,         \
                      mean_rstd, gamma, beta, workspace, M, A);                                                       \
-  hipLaunchKernelGGL(asp_bn_bwd_finalize_kernel, dim3((unsigned)cdiv(A, 128)), dim3(128), 0, st, workspace, sums,    \
+  hipLaunchKernelGGL(asp_bn_bwd_finalize_kernel, dim3((unsigned)cdiv(A, 128)), dim3(128, 8), 0, st, workspace, sums,    \
                      dgamma, dbeta, nblk, A);                                                                        \
   hipLaunchKernelGGL(asp_bn_bwd_apply_kernel<T_>, dim3(nb), dim3(256), 0, st, (const T_*)dh, (const T_*)a_pre,       \
                      mean_rstd, gamma, beta, sums, (T_*)da, n, A, 1.0f / (float)M)
@@ -359,11 +421,11 @@ extern "C" int w2v2_asp_bn_bwd(const void* dh, const void* a_pre, const float* m
 extern "C" int w2v2_asp_pool_fwd(const void* x, const void* s, float* out, float* stats, int B, int T, int C, int dtype,
                                  void* stream) {
   W2V2_REQUIRE(x && s && out && stats && B > 0 && T > 0 && C > 0, "asp_pool_fwd: bad arguments");
-  dim3 grid((unsigned)cdiv(C, 128), B);
+  dim3 grid((unsigned)cdiv(C, 64), B), blk(64, ASP_TL);
   hipStream_t st = as_stream(stream);
-  ASP_DT(hipLaunchKernelGGL(asp_pool_fwd_kernel<bf16_t>, grid, dim3(128), 0, st, (const bf16_t*)x, (const bf16_t*)s,
+  ASP_DT(hipLaunchKernelGGL(asp_pool_fwd_kernel<bf16_t>, grid, blk, 0, st, (const bf16_t*)x, (const bf16_t*)s,
                             out, stats, T, C),
-         hipLaunchKernelGGL(asp_pool_fwd_kernel<float>, grid, dim3(128), 0, st, (const float*)x, (const float*)s, out,
+         hipLaunchKernelGGL(asp_pool_fwd_kernel<float>, grid, blk, 0, st, (const float*)x, (const float*)s, out,
                             stats, T, C),
          "asp_pool_fwd");
 }
@@ -371,11 +433,11 @@ extern "C" int w2v2_asp_pool_fwd(const void* x, const void* s, float* out, float
 extern "C" int w2v2_asp_pool_bwd(const void* x, const void* s, const float* out, const float* stats, const float* dout,
                                  void* ds, void* dx, int B, int T, int C, int dtype, void* stream) {
   W2V2_REQUIRE(x && s && out && stats && dout && ds && dx && B > 0 && T > 0 && C > 0, "asp_pool_bwd: bad arguments");
-  dim3 grid((unsigned)cdiv(C, 128), B);
+  dim3 grid((unsigned)cdiv(C, 64), B), blk(64, ASP_TL);
   hipStream_t st = as_stream(stream);
-  ASP_DT(hipLaunchKernelGGL(asp_pool_bwd_kernel<bf16_t>, grid, dim3(128), 0, st, (const bf16_t*)x, (const bf16_t*)s,
+  ASP_DT(hipLaunchKernelGGL(asp_pool_bwd_kernel<bf16_t>, grid, blk, 0, st, (const bf16_t*)x, (const bf16_t*)s,
                             out, stats, dout, (bf16_t*)ds, (bf16_t*)dx, T, C),
-         hipLaunchKernelGGL(asp_pool_bwd_kernel<float>, grid, dim3(128), 0, st, (const float*)x, (const float*)s, out,
+         hipLaunchKernelGGL(asp_pool_bwd_kernel<float>, grid, blk, 0, st, (const float*)x, (const float*)s, out,
                             stats, dout, (float*)ds, (float*)dx, T, C),
          "asp_pool_bwd");
 }
@@ -389,21 +451,21 @@ extern "C" int w2v2_asp_context_bwd(const void* x, const float* ctx, const void*
   float* dctx = scratch + (int64_t)B * A;
   hipStream_t st = as_stream(stream);
   if (dtype == W2V2_BF16)
-    hipLaunchKernelGGL(asp_dsum_kernel<bf16_t>, dim3((unsigned)cdiv(A, 128), B), dim3(128), 0, st, (const bf16_t*)da,
-                       dsum, T, A);
+    hipLaunchKernelGGL(asp_dsum_kernel<bf16_t>, dim3((unsigned)cdiv(A, 64), B), dim3(64, ASP_TL), 0, st,
+                       (const bf16_t*)da, dsum, T, A);
   else if (dtype == W2V2_F32)
-    hipLaunchKernelGGL(asp_dsum_kernel<float>, dim3((unsigned)cdiv(A, 128), B), dim3(128), 0, st, (const float*)da,
-                       dsum, T, A);
+    hipLaunchKernelGGL(asp_dsum_kernel<float>, dim3((unsigned)cdiv(A, 64), B), dim3(64, ASP_TL), 0, st,
+                       (const float*)da, dsum, T, A);
   else
     W2V2_FAIL("asp_context_bwd: bad dtype %d", dtype);
   hipLaunchKernelGGL(asp_dw_ctx_kernel, dim3((unsigned)cdiv(2 * C, 256), A), dim3(256), 0, st, dsum, ctx, dw1, B, A, C);
   hipLaunchKernelGGL(asp_dctx_kernel, dim3((unsigned)cdiv(2 * C, 256), B), dim3(256), 0, st, dsum, w1, dctx, A, C);
-  dim3 grid((unsigned)cdiv(C, 256), B);
+  dim3 grid((unsigned)cdiv(C, 64), B), blk(64, ASP_TL);
   if (dtype == W2V2_BF16)
-    hipLaunchKernelGGL(asp_context_bwd_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, ctx, dctx,
+    hipLaunchKernelGGL(asp_context_bwd_kernel<bf16_t>, grid, blk, 0, st, (const bf16_t*)x, ctx, dctx,
                        (bf16_t*)dx, T, C);
   else
-    hipLaunchKernelGGL(asp_context_bwd_kernel<float>, grid, dim3(256), 0, st, (const float*)x, ctx, dctx, (float*)dx,
+    hipLaunchKernelGGL(asp_context_bwd_kernel<float>, grid, blk, 0, st, (const float*)x, ctx, dctx, (float*)dx,
                        T, C);
   W2V2_CHECK_LAUNCH("asp_context_bwd");
   return 0;
