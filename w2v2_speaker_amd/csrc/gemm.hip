@@ -688,11 +688,19 @@ __global__ __launch_bounds__(512) void gemm_bf16_glds3_kernel(const GemmArgs g) 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // 0..7
   const int wm = wave >> 1, wn = wave & 1;
 
+  // Persistent over tiles: gridDim.x = min(tiles, CUs) workgroups, each takes tiles t, t + G, ...  (one 144 KiB
+  // workgroup per CU anyway).  The next tile's first two DMA stages are issued right behind the epilogue's stores,
+  // so their latency -- and a workgroup launch -- hides under the store drain instead of following it.
   const int ntile = g.tiles_m * g.tiles_n;
-  const int tile = xcd_remap(blockIdx.x, ntile);
+  const int G = gridDim.x;
+  const int z = blockIdx.z;
+#pragma unroll 1
+  for (int t0 = 0; t0 < ntile; t0 += G) {
+  const int nchunk = min(G, ntile - t0);
+  if ((int)blockIdx.x >= nchunk) break;
+  const int tile = t0 + xcd_remap(blockIdx.x, nchunk);
   const int tm = tile / g.tiles_n, tn = tile - tm * g.tiles_n;
   const int m0 = tm * BM, n0 = tn * BN;
-  const int z = blockIdx.z;
   const int z0 = z / g.batch_inner, z1 = z - z0 * g.batch_inner;
   const int nk = g.K >> 6;
 
@@ -773,6 +781,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_glds3_kernel(const GemmArgs g) 
     compute(cur);                                                  \
     ++kt;                                                          \
   }
+  __builtin_amdgcn_s_barrier();          // every wave has finished reading the previous tile's stages
   if (nk > 0) stage(s0, 0);
   if (nk > 1) stage(s1, 1);
   int kt = 0;
@@ -796,6 +805,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_glds3_kernel(const GemmArgs g) 
   load_col8(g, bias, nc, cv0);
   load_col8(g, bias, nc + 8, cv1);
   W2V2_EPI_DISPATCH((epilogue_direct<TC, EPI>(g, Cz, auxz, acc, m0 + wm * 64 + frow, nc, cv0, cv1)));
+  }   // tile loop
 }
 
 template <typename TC>
@@ -809,7 +819,15 @@ static void launch_glds3(GemmArgs a, int M, int N, int batch, hipStream_t st) {
   }
   a.tiles_m = (int)cdiv(M, 256);
   a.tiles_n = (int)cdiv(N, 128);
-  dim3 grid(a.tiles_m * a.tiles_n, 1, batch);
+  static int ncu = 0;
+  if (ncu == 0) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
+    if (getenv("W2V2_G3_NONPERSISTENT")) ncu = 1 << 30;
+  }
+  const int tiles = a.tiles_m * a.tiles_n;
+  dim3 grid(tiles < ncu ? tiles : ncu, 1, batch);
   hipLaunchKernelGGL((gemm_bf16_glds3_kernel<TC>), grid, dim3(512), lds, st, a);
 }
 
