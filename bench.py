@@ -197,7 +197,8 @@ def main():
                                "kernel": "gemm_bf16_glds3_kernel<bf16> (256x128x64 3-stage LDS-DMA MFMA GEMM: conv1-6, "
                                          "projection, QKV, out-proj, FFN1, FFN2 forward + every data-gradient product)",
                                "launches": prof["launches"], "avg_us": round(1e3 * prof["ms"] / prof["launches"], 2),
-                               "avg_gflop_per_launch": round(prof["flops"] / prof["launches"] / 1e9, 3)}
+                               "avg_gflop_per_launch": round(prof["flops"] / prof["launches"] / 1e9, 3),
+                               "avg_algorithmic_mb_per_launch": round(prof["bytes"] / prof["launches"] / 1e6, 1)}
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

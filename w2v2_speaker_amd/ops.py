@@ -86,6 +86,9 @@ class Gemm:
         self._keep = (A, B, Cmat, bias, aux, row_scale, col_scale)   # keep buffers alive
         self._fn = lib().w2v2_gemm
         self.flops = 2.0 * M * N * K * batch
+        # algorithmic HBM bytes: each operand read once, C written once (+ the aux tensor read or written once)
+        esz = A.element_size()
+        self.bytes = float(batch) * ((M * K + N * K) * esz + M * N * Cmat.element_size() * (2 if aux is not None else 1))
         # which template instantiation of csrc/gemm.hip this descriptor launches (for profiling)
         self.kernel_class = ("bf16" if dt(A) == BF16 else "f32") + "_" + ("t" if transA else "n") + ("n" if transB else "t")
         self.narrow = N <= 64
@@ -110,10 +113,11 @@ class Gemm:
     def profile_end(cls) -> dict:
         prof, cls._prof = cls._prof, None
         if not prof or not prof["events"]:
-            return {"launches": 0, "ms": 0.0, "flops": 0.0}
+            return {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0}
         torch.cuda.synchronize()
-        ms = sum(a.elapsed_time(b) for a, b, _ in prof["events"])
-        return {"launches": len(prof["events"]), "ms": ms, "flops": sum(f for _, _, f in prof["events"])}
+        ms = sum(a.elapsed_time(b) for a, b, _, _ in prof["events"])
+        return {"launches": len(prof["events"]), "ms": ms, "flops": sum(f for _, _, f, _ in prof["events"]),
+                "bytes": sum(b for _, _, _, b in prof["events"])}
 
     def __call__(self) -> None:
         prof = Gemm._prof
@@ -122,7 +126,7 @@ class Gemm:
             e0.record()
             rc = self._fn(self._ref, stream())
             e1.record()
-            prof["events"].append((e0, e1, self.flops))
+            prof["events"].append((e0, e1, self.flops, self.bytes))
         else:
             rc = self._fn(self._ref, stream())
         if rc:
