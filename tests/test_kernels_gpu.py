@@ -111,6 +111,46 @@ def test_gemm_epilogues(epi):
     _gemm_case(o, 70, 52, 40, True, False, torch.float32, torch.float32, epi)
 
 
+@pytest.mark.parametrize("M,N,K", [(9834, 3072, 768), (32768, 2048, 64), (16384, 2004, 192), (2100, 768, 256),
+                                   (9834, 768, 3072)])
+@pytest.mark.parametrize("epi", ["none", "bias_gelu", "gelu_bwd", "add"])
+def test_gemm_ring_kernels_at_full_size(M, N, K, epi):
+    """The persistent LDS-DMA ring kernels only take products that fill the chip: 256x256 tiles (4-stage ring) for
+    the first three shapes, 256x128 (3-stage) for the last two.  Ragged M, ragged N (2004: scalar tail path), K of
+    only two ring steps, every fused epilogue; reference = f32 matmul of the same bf16-rounded operands."""
+    o = ops()
+    g = torch.Generator(device="cpu").manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g).to(torch.bfloat16).to(DEV)
+    Bm = (torch.randn(N, K, generator=g) / K ** 0.5).to(torch.bfloat16).to(DEV)
+    ldc = (N + 7) // 8 * 8
+    C = torch.zeros(M, ldc, dtype=torch.bfloat16, device=DEV)
+    ref = A.float() @ Bm.float().t()
+    kw = {}
+    if epi == "bias_gelu":
+        bias = torch.randn(N, generator=g).to(DEV)
+        aux = torch.zeros(M, ldc, dtype=torch.bfloat16, device=DEV)
+        kw.update(epilogue=o.EPI_BIAS_GELU, bias=bias, aux=aux, ldaux=ldc)
+        pre = ref + bias
+        ref = torch.nn.functional.gelu(pre)
+    elif epi in ("gelu_bwd", "add"):
+        aux = torch.randn(M, ldc, generator=g).to(torch.bfloat16).to(DEV)
+        a = aux[:, :N].float()
+        if epi == "add":
+            kw.update(epilogue=o.EPI_ADD, aux=aux, ldaux=ldc)
+            ref = ref + a
+        else:
+            kw.update(epilogue=o.EPI_GELU_BWD, aux=aux, ldaux=ldc)
+            ref = ref * (0.5 * (1 + torch.erf(a / math.sqrt(2))) + a * torch.exp(-0.5 * a * a) / math.sqrt(2 * math.pi))
+    o.gemm(M, N, K, A, Bm, C, lda=K, ldb=K, ldc=ldc, **kw)
+    torch.cuda.synchronize()
+    err = float((C[:, :N].float() - ref).norm() / ref.norm())
+    assert err < 4e-3, (M, N, K, epi, err)
+    if epi == "bias_gelu":
+        assert float((aux[:, :N].float() - pre).norm() / pre.norm()) < 4e-3
+    if ldc > N:
+        assert float(C[:, N:].abs().max()) == 0.0
+
+
 def test_gemm_split_k_and_accumulate():
     o = ops()
     for dtype in (torch.bfloat16, torch.float32):

@@ -107,6 +107,29 @@ int main() {
         printf("  b128 %.2f tr %.2f  b0=%x b1=%x b2=%x\n", p.first, t2, p.second & 15, (p.second >> 4) & 15, (p.second >> 8) & 15);
     }
   }
+  // third geometry: 64-byte rows (BK = 32 bf16): lane (r, kq) reads chunk kq ^ s(r) of row r, s: 4 bits -> 2 bits
+  {
+    std::vector<int> o3;
+    for (int m = 0; m < 256; ++m)
+      for (int l = 0; l < 64; ++l) {
+        const int rr = l & 15, kq = l >> 4;
+        const int sv = parity((m & 15) & rr) | (parity(((m >> 4) & 15) & rr) << 1);
+        o3.push_back(rr * 64 + ((kq ^ sv) << 4));
+      }
+    int* d3; unsigned long long* c3;
+    hipMalloc(&d3, o3.size() * 4); hipMalloc(&c3, 256 * 8);
+    hipMemcpy(d3, o3.data(), o3.size() * 4, hipMemcpyHostToDevice);
+    for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL(probe, dim3(256), dim3(512), 65536, 0, d3, c3, iters);
+    std::vector<unsigned long long> h3(256);
+    hipMemcpy(h3.data(), c3, 256 * 8, hipMemcpyDeviceToHost);
+    printf("64-byte rows: no swizzle %.2f ticks; conflict-free maps (b0 b1):", (double)h3[0] / (iters * 64.0));
+    double best3 = 1e30;
+    for (int m = 0; m < 256; ++m) best3 = std::min(best3, (double)h3[m] / (iters * 64.0));
+    int shown = 0;
+    for (int m = 0; m < 256 && shown < 12; ++m)
+      if ((double)h3[m] / (iters * 64.0) < best3 * 1.03 && __builtin_popcount(m) <= 3) { printf(" (%x,%x)", m & 15, m >> 4); shown++; }
+    printf("  best %.2f\n", best3);
+  }
   int nbest = 0; for (auto& p : r) if (p.first < r[0].first * 1.05) nbest++;
   printf("%d of 4096 within 5%% of the best; worst %.2f\n", nbest, r.back().first);
   // is the current swizzle family member? s = (r&7)^((r>>3)&1): b0 = r0^r3 (mask 9), b1 = r1 (2), b2 = r2 (4)

@@ -263,17 +263,16 @@ __device__ __forceinline__ void load_col8(const GemmArgs& g, const float* __rest
   }
 }
 
-// epilogue straight from the accumulators of a wave whose lane owns columns n .. n+15 of rows m + 16 i
-template <typename TC, int EPI>
-__device__ __forceinline__ void epilogue_direct(const GemmArgs& g, TC* __restrict__ Cz, TC* __restrict__ auxz,
-                                                f32x4 (&acc)[4][4], int m, int n, const float (&cv0)[8],
-                                                const float (&cv1)[8]) {
-  if (n >= g.N) return;
+template <typename TC, int EPI, int FM, int I0>
+__device__ __forceinline__ void epilogue_direct4(const GemmArgs& g, TC* __restrict__ Cz, TC* __restrict__ auxz,
+                                                 f32x4 (&acc)[FM][4], int m, int n, const float (&cv0)[8],
+                                                 const float (&cv1)[8]) {
+  // row fragments I0 .. I0+3 of the wave tile (rows m + 16 i); four at a time bounds the aux staging registers
   float ax[4][16];
   if constexpr (EPI == W2V2_EPI_GELU_BWD || EPI == W2V2_EPI_ADD) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int mi = m + 16 * i;
+      const int mi = m + 16 * (I0 + i);
 #pragma unroll
       for (int e = 0; e < 16; ++e) ax[i][e] = 0.f;
       if (mi < g.M) {
@@ -295,20 +294,29 @@ __device__ __forceinline__ void epilogue_direct(const GemmArgs& g, TC* __restric
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int mi = m + 16 * i;
+    const int mi = m + 16 * (I0 + i);
     if (mi >= g.M) continue;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       if (n + 8 * h >= g.N) continue;
       float v[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = acc[i][2 * h + (e >> 2)][e & 3];
+      for (int e = 0; e < 8; ++e) v[e] = acc[I0 + i][2 * h + (e >> 2)][e & 3];
       float a8[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) a8[e] = (EPI == W2V2_EPI_GELU_BWD || EPI == W2V2_EPI_ADD) ? ax[i][8 * h + e] : 0.f;
       epilogue_row8_impl<TC, EPI>(g, Cz, auxz, mi, n + 8 * h, v, h ? cv1 : cv0, a8, true);
     }
   }
+}
+// epilogue straight from the accumulators of a wave whose lane owns columns n .. n+15 of rows m + 16 i, i < FM
+template <typename TC, int EPI, int FM>
+__device__ __forceinline__ void epilogue_direct(const GemmArgs& g, TC* __restrict__ Cz, TC* __restrict__ auxz,
+                                                f32x4 (&acc)[FM][4], int m, int n, const float (&cv0)[8],
+                                                const float (&cv1)[8]) {
+  if (n >= g.N) return;
+  epilogue_direct4<TC, EPI, FM, 0>(g, Cz, auxz, acc, m, n, cv0, cv1);
+  if constexpr (FM > 4) epilogue_direct4<TC, EPI, FM, 4>(g, Cz, auxz, acc, m, n, cv0, cv1);
 }
 
 #define W2V2_EPI_DISPATCH(CALL)                                              \
@@ -672,8 +680,10 @@ __global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(const GemmArgs g) {
 // (G = this wave's DMA pieces per stage), never vmcnt(0) in the loop.
 template <int S> __device__ __forceinline__ void wait_vmcnt() {
   if constexpr (S == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if constexpr (S == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
   else if constexpr (S == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-  else static_assert(S == 0 || S == 6, "unsupported count");
+  else if constexpr (S == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else static_assert(S == 0 || S == 4 || S == 6 || S == 8, "unsupported count");
 }
 
 template <typename TC>
@@ -804,8 +814,141 @@ __global__ __launch_bounds__(512) void gemm_bf16_glds3_kernel(const GemmArgs g) 
   float cv0[8], cv1[8];
   load_col8(g, bias, nc, cv0);
   load_col8(g, bias, nc + 8, cv1);
-  W2V2_EPI_DISPATCH((epilogue_direct<TC, EPI>(g, Cz, auxz, acc, m0 + wm * 64 + frow, nc, cv0, cv1)));
+  W2V2_EPI_DISPATCH((epilogue_direct<TC, EPI, 4>(g, Cz, auxz, acc, m0 + wm * 64 + frow, nc, cv0, cv1)));
   }   // tile loop
+}
+
+// ------------------------------------------------------------------------------ 256 x 256 x 32, 4-stage ring
+// The 256x128 kernel above is bound by the L2 -> LDS feed (48 KiB per 4.2 MFLOP tile step; all 256 CUs together draw
+// ~22 TB/s, tools/probes/load_path_probe).  A 256x256 tile halves the bytes per flop (32 KiB per 4.2 MFLOP step at
+// BK = 32).  8 waves as 2 (m) x 4 (n), 128 x 64 per wave (128 accumulator VGPRs); LDS holds FOUR 32 KiB stages
+// [256 + 256 rows][32 k] with 64-byte rows: three K steps in flight, `s_waitcnt vmcnt(8)` (4 DMA pieces per wave and
+// stage) and one s_barrier per step of 32 MFMAs.  64-byte rows: chunk map s(row) = ((row >> 2) & 1) << 1 is the
+// conflict-free one for the fragment ds_read_b128 (lds_bank_probe: 4.0 vs 6.0 clk unswizzled).  Used for products
+// whose 256x256 tiling fills the chip (FFN1, dH, the conv stack); B rows permuted for the register epilogue as above.
+__device__ __forceinline__ int swz64(int row) { return ((row >> 2) & 1) << 1; }
+__device__ __forceinline__ int swz64_b(int row) { return ((row >> 4) & 1) << 1; }   // fragment-local row (row>>4&3)*4+(row&3)
+
+template <typename TC>
+__global__ __launch_bounds__(512) void gemm_bf16_glds4_kernel(const GemmArgs g) {
+  constexpr int BM = 256, BN = 256, FM = 8, FN = 4, BK = 32;
+  constexpr int STAGE = (BM + BN) * BK;           // elements per stage (A then B): 32 KiB
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // 0..7
+  const int wm = wave >> 2, wn = wave & 3;
+  const int ntile = g.tiles_m * g.tiles_n;
+  const int G = gridDim.x;
+  const int z = blockIdx.z;
+  const int z0 = z / g.batch_inner, z1 = z - z0 * g.batch_inner;
+  const int nk = g.K >> 5;
+  const bf16_t* Ab = reinterpret_cast<const bf16_t*>(g.A.ptr) + z0 * g.a_s0 + z1 * g.a_s1;
+  const bf16_t* Bb = reinterpret_cast<const bf16_t*>(g.B.ptr) + z0 * g.b_s0 + z1 * g.b_s1;
+  const int c4 = lane & 3, r16 = lane >> 2;        // DMA piece = 16 rows x 4 chunks of 16 B
+  const int frow = lane & 15, fk = lane >> 4;
+  const int la = frow * BK + ((fk ^ swz64(frow)) << 3);
+  const int lb = ((frow >> 2) * 16 + (frow & 3)) * BK + ((fk ^ swz64(frow)) << 3);
+  const int aoff = wm * 128 * BK, boff = BM * BK + wn * 64 * BK;
+
+#pragma unroll 1
+  for (int t0 = 0; t0 < ntile; t0 += G) {
+    const int nchunk = min(G, ntile - t0);
+    if ((int)blockIdx.x >= nchunk) break;
+    const int tile = t0 + xcd_remap(blockIdx.x, nchunk);
+    const int tm = tile / g.tiles_n, tn = tile - tm * g.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const bf16_t* ap[2];
+    const bf16_t* bp[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int row = (wave * 2 + j) * 16 + r16;
+      ap[j] = Ab + outer_off(g.A, min(m0 + row, g.M - 1)) + ((c4 ^ swz64(row)) << 3);
+      bp[j] = Bb + outer_off(g.B, min(n0 + row, g.N - 1)) + ((c4 ^ swz64_b(row)) << 3);
+    }
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    auto stage = [&](bf16_t* base, int kt) {
+      bf16_t* ad = base + wave * 2 * 16 * BK;
+      bf16_t* bd = base + BM * BK + wave * 2 * 16 * BK;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        __builtin_amdgcn_global_load_lds((gvoid_t*)(ap[j] + kt * BK), (lvoid_t*)(ad + j * 16 * BK), 16, 0, 0);
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        __builtin_amdgcn_global_load_lds((gvoid_t*)(bp[j] + kt * BK), (lvoid_t*)(bd + j * 16 * BK), 16, 0, 0);
+    };
+    auto compute = [&](const bf16_t* base) {
+      const bf16_t* pa = base + aoff + la;
+      const bf16_t* pb = base + boff + lb;
+      bf16x8 af[FM], bfr[FN];
+#pragma unroll
+      for (int j = 0; j < FN; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(pb + j * 4 * BK);
+#pragma unroll
+      for (int i = 0; i < FM; ++i) af[i] = *reinterpret_cast<const bf16x8*>(pa + i * 16 * BK);
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+    };
+    // ring: K step kt sits in stage kt & 3; step kt+3 goes to the stage that held step kt-1.  The loop stays ROLLED
+    // (stage offset computed per step): unrolled by four the compiler materialises every stage's fragment addresses
+    // and spills ~400 registers of the 128-accumulator tile.
+    __builtin_amdgcn_s_barrier();          // every wave has finished reading the previous tile's stages
+    if (nk > 0) stage(smem, 0);
+    if (nk > 1) stage(smem + STAGE, 1);
+    if (nk > 2) stage(smem + 2 * STAGE, 2);
+#pragma unroll 1
+    for (int kt = 0; kt < nk; ++kt) {
+      if (kt + 2 < nk) wait_vmcnt<8>(); else if (kt + 1 < nk) wait_vmcnt<4>(); else wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+      if (kt + 3 < nk) stage(smem + ((kt + 3) & 3) * STAGE, kt + 3);
+      compute(smem + (kt & 3) * STAGE);
+    }
+
+    TC* Cz = reinterpret_cast<TC*>(g.C) + z0 * g.c_s0 + z1 * g.c_s1;
+    TC* auxz = g.aux ? reinterpret_cast<TC*>(g.aux) + z0 * g.aux_s0 + z1 * g.aux_s1 : nullptr;
+    const float* bias = g.bias ? g.bias + z1 * g.bias_s1 : nullptr;
+    const int nc = n0 + wn * 64 + fk * 16;
+    float cv0[8], cv1[8];
+    load_col8(g, bias, nc, cv0);
+    load_col8(g, bias, nc + 8, cv1);
+    W2V2_EPI_DISPATCH((epilogue_direct<TC, EPI, FM>(g, Cz, auxz, acc, m0 + wm * 128 + frow, nc, cv0, cv1)));
+  }   // tile loop
+}
+
+static int g_w2v2_ncu = 0;
+static int device_cus() {
+  if (g_w2v2_ncu == 0) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (hipDeviceGetAttribute(&g_w2v2_ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || g_w2v2_ncu <= 0)
+      g_w2v2_ncu = 256;
+  }
+  return g_w2v2_ncu;
+}
+
+template <typename TC>
+static void launch_glds4(GemmArgs a, int M, int N, int batch, hipStream_t st) {
+  constexpr size_t lds = (size_t)4 * (256 + 256) * 32 * sizeof(bf16_t);   // 128 KiB
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_glds4_kernel<TC>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  a.tiles_m = (int)cdiv(M, 256);
+  a.tiles_n = (int)cdiv(N, 256);
+  const int tiles = a.tiles_m * a.tiles_n, ncu = device_cus();
+  dim3 grid(tiles < ncu ? tiles : ncu, 1, batch);
+  hipLaunchKernelGGL((gemm_bf16_glds4_kernel<TC>), grid, dim3(512), lds, st, a);
 }
 
 template <typename TC>
@@ -819,13 +962,7 @@ static void launch_glds3(GemmArgs a, int M, int N, int batch, hipStream_t st) {
   }
   a.tiles_m = (int)cdiv(M, 256);
   a.tiles_n = (int)cdiv(N, 128);
-  static int ncu = 0;
-  if (ncu == 0) {
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
-    if (getenv("W2V2_G3_NONPERSISTENT")) ncu = 1 << 30;
-  }
+  const int ncu = getenv("W2V2_G3_NONPERSISTENT") ? (1 << 30) : device_cus();
   const int tiles = a.tiles_m * a.tiles_n;
   dim3 grid(tiles < ncu ? tiles : ncu, 1, batch);
   hipLaunchKernelGGL((gemm_bf16_glds3_kernel<TC>), grid, dim3(512), lds, st, a);
@@ -995,7 +1132,17 @@ extern "C" int w2v2_gemm(const w2v2_gemm_desc* d, void* stream) {
     // 256x128 3-stage kernel for the encoder shapes; the conv stack (N = 512, M ~ 3e5) measures
     // slightly faster on the 128x128 kernel at 2 workgroups per CU
     const bool big = glds && d->N >= (getenv("W2V2_G3N") ? atoi(getenv("W2V2_G3N")) : 512) && split == 1 && !atomic && d->M >= 1024 && g_w2v2_glds3;
-    if (big) {
+    // 256x256 tiles when they fill the chip: >= 85 % of the CU slots of the last round busy (FFN1, dH, conv stack)
+    bool huge = false;
+    if (big && d->N >= 512 && d->batch == 1 && !getenv("W2V2_NO_GLDS4")) {
+      const int64_t t4 = cdiv(d->M, 256) * cdiv(d->N, 256), ncu = device_cus();
+      huge = t4 >= ncu && (double)t4 / (double)(cdiv(t4, ncu) * ncu) >= 0.85 &&
+             (double)d->N / (double)(cdiv(d->N, 256) * 256) >= 0.9;
+    }
+    if (huge) {
+      if (d->dtype_c == W2V2_F32) launch_glds4<float>(a, d->M, d->N, d->batch, st);
+      else launch_glds4<bf16_t>(a, d->M, d->N, d->batch, st);
+    } else if (big) {
       if (d->dtype_c == W2V2_F32) launch_glds3<float>(a, d->M, d->N, d->batch, st);
       else launch_glds3<bf16_t>(a, d->M, d->N, d->batch, st);
     } else if (glds) {
