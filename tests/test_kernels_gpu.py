@@ -722,13 +722,17 @@ def test_fused_adam_matches_torch_and_golden():
 
 
 # ----------------------------------------------------------------------------------------------- grouped wgrad
-def test_grouped_weight_gradient_gemm():
+@pytest.mark.parametrize("shapes", [
+    [(768, 3072), (3072, 768), (768, 768), (2304, 768), (64, 128), (136, 72)],            # 256x128 ring kernel
+    [(768, 3072), (3072, 768), (768, 776), (2304, 768), (768, 3072), (3072, 768), (520, 768), (2304, 768)],  # 256x256
+    [(64, 128), (136, 72)]])                                                               # 128x128 kernel
+def test_grouped_weight_gradient_gemm(shapes):
     """dW = dY^T X and dbias = colsum(dY) for several Linear layers in one launch (LDS-DMA staging +
-    ds_read_b64_tr_b16 transposing fragment reads); ragged feature sizes, token tail zero-padded."""
+    ds_read_b64_tr_b16 transposing fragment reads); ragged feature sizes, token tail zero-padded.  The second
+    set is two transformer blocks' worth of problems: 219 tiles of 256x256 -> the four-stage ring kernel."""
     o = ops()
     tokens = 2 * 149
     tp = (tokens + 63) // 64 * 64
-    shapes = [(768, 3072), (3072, 768), (768, 768), (2304, 768), (64, 128), (136, 72)]
     probs, refs = [], []
     for i, (no, ni) in enumerate(shapes):
         dY = torch.zeros(tp, no)

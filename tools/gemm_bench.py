@@ -79,3 +79,27 @@ if not only or "wgrad" in only:
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e2
     print(f"wgrad grouped (dW2,dW1,dWo,dWqkv + biases)  {us:9.1f} us  {wg.flops / us / 1e6:8.1f} TFLOP/s")
+
+# two transformer blocks' weight gradients in one launch (8 problems -> 216 tiles of 256x256, wgrad_grouped_ring4)
+if not only or "wgrad" in only:
+    probs2 = probs + [(mk(H), mk(I), torch.zeros(H, I, device=dev), torch.zeros(H, device=dev)),
+                      (mk(I), mk(H), torch.zeros(I, H, device=dev), torch.zeros(I, device=dev)),
+                      (mk(H), mk(H), torch.zeros(H, H, device=dev), torch.zeros(H, device=dev)),
+                      (mk(3 * H), mk(H), torch.zeros(3 * H, H, device=dev), torch.zeros(3 * H, device=dev))]
+    if os.environ.get('W2V2_NO_DBIAS'):
+        probs2 = [(a, b, c, None) for a, b, c, _ in probs2]
+    wg2 = ops.WgradGroup(probs2, M, Mp)
+    for _ in range(3):
+        wg2()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for _ in range(3):
+        blocker()
+    e0.record()
+    for _ in range(10):
+        wg2()
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e2
+    print(f"wgrad grouped, two blocks in one launch        {us:9.1f} us  {wg2.flops / us / 1e6:8.1f} TFLOP/s")
+

@@ -397,6 +397,186 @@ __global__ __launch_bounds__(512) void wgrad_grouped_ring_kernel(const WgArgs a)
 }
 
 
+// ------------------------------------------------------------------------------ 256 x 256 x 32, 4-stage ring
+// Same idea as gemm_bf16_glds4_kernel: half the L2 -> LDS bytes per flop of the 256x128 tile.  A block of w2v2-base
+// has only 108 such tiles, so the host groups the four Linear layers of TWO transformer blocks (8 problems = 216
+// tiles, one round on 256 CUs): still no split-K, no atomics, bitwise reproducible.  8 waves as 2 (n_out) x 4 (n_in),
+// 128 x 64 per wave; four 32 KiB stages [32 tokens][256 + 256] in natural K-major layout, three in flight
+// (`s_waitcnt vmcnt(8)`, 4 DMA pieces per wave and stage); rolled ring loop (see gemm.hip on why).
+__global__ __launch_bounds__(512) void wgrad_grouped_ring4_kernel(const WgArgs a) {
+  constexpr int BM = 256, BN = 256, BK = 32;
+  constexpr int STAGE = BK * (BM + BN);             // elements per stage: A [32][256] then B [32][256]
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // 0..7
+  const int wm = wave >> 2, wn = wave & 3;
+
+  int tile;
+  {
+    const int nwg = a.total_tiles, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  }
+  int pi = 0;
+#pragma unroll
+  for (int i = 1; i < WG_MAXP; ++i)
+    if (i < a.n_problems && tile >= a.p[i].tile_begin) pi = i;
+  const WgProblem& P = a.p[pi];
+  const int t = tile - P.tile_begin;
+  const int tm = t / P.tiles_n, tn = t - tm * P.tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  // DMA pieces: piece j of a wave = token rows (wave*2 + j)*2 + {0,1} of the 32-row stage, 32 chunks of 16 B per row
+  const bf16_t* ap[2];
+  const bf16_t* bp[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int r = (wave * 2 + j) * 2 + (lane >> 5);
+    const int c = (lane & 31) ^ (wg_f(r) << 1);
+    ap[j] = P.dY + (int64_t)r * P.ld_dy + min(m0 + c * 8, P.n_out - 8);
+    bp[j] = P.X + (int64_t)r * P.ld_x + min(n0 + c * 8, P.n_in - 8);
+  }
+  const int64_t astep = (int64_t)BK * P.ld_dy, bstep = (int64_t)BK * P.ld_x;
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const bool do_bias = (P.dbias != nullptr) && tn == 0 && wn == 0;
+  bf16x2 one2;
+  one2[0] = (__bf16)1.0f;
+  one2[1] = (__bf16)1.0f;
+
+  auto stage = [&](int sidx, int kt) {
+    bf16_t* ad = smem + sidx * STAGE + wave * 4 * BM;
+    bf16_t* bd = smem + sidx * STAGE + BK * BM + wave * 4 * BN;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      __builtin_amdgcn_global_load_lds((gvoid_t*)(ap[j] + kt * astep), (lvoid_t*)(ad + j * 2 * BM), 16, 0, 0);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      __builtin_amdgcn_global_load_lds((gvoid_t*)(bp[j] + kt * bstep), (lvoid_t*)(bd + j * 2 * BN), 16, 0, 0);
+  };
+  // fragment byte offsets (see wgrad_grouped_ring_kernel): row g*8 + i/4 (+4 for the second read), 8-byte piece
+  // i%4, physical 32-byte segment (seg ^ f), f = (i/4) | ((g&1) << 2); seg = wm*8 + x (A), wn*4 + x (B)
+  const int li = lane & 15, lg = lane >> 4;
+  const int fr = lg * 8 + (li >> 2);
+  const int ff = (li >> 2) | ((lg & 1) << 2);
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem_raw;
+  uint32_t aoff[8], boff[4];
+#pragma unroll
+  for (int x = 0; x < 8; ++x) aoff[x] = lds0 + 2u * (fr * BM + (((wm * 8 + x) ^ ff) << 4) + ((li & 3) << 2));
+#pragma unroll
+  for (int x = 0; x < 4; ++x) boff[x] = lds0 + 2u * (BK * BM + fr * BN + (((wn * 4 + x) ^ ff) << 4) + ((li & 3) << 2));
+  union Frag { struct { short4v a, b; } s; bf16x8 v; };
+#define W2V2_TR4(f, addr)                                                                              \
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f.s.a) : "v"(addr) : "memory");                      \
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "=v"(f.s.b) : "v"(addr) : "memory")
+  static_assert(4 * BM * 2 == 2048 && 4 * BN * 2 == 2048, "second transposing read = +4 token rows");
+
+  const int nk = a.ktiles * 2;                       // stages of 32 tokens
+  __builtin_amdgcn_s_barrier();
+  if (nk > 0) stage(0, 0);
+  if (nk > 1) stage(1, 1);
+  if (nk > 2) stage(2, 2);
+#pragma unroll 1
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (kt + 3 < nk) stage((kt + 3) & 3, kt + 3);
+    const uint32_t sb = (uint32_t)(kt & 3) * (STAGE * 2u);
+    Frag bf_[4], af[8];
+#pragma unroll
+    for (int x = 0; x < 4; ++x) { const uint32_t ad = boff[x] + sb; W2V2_TR4(bf_[x], ad); }
+#pragma unroll
+    for (int x = 0; x < 4; ++x) { const uint32_t ad = aoff[x] + sb; W2V2_TR4(af[x], ad); }
+#pragma unroll
+    for (int x = 0; x < 4; ++x) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bf_[x].s.a), "+v"(bf_[x].s.b));
+#pragma unroll
+    for (int x = 0; x < 4; ++x) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[x].s.a), "+v"(af[x].s.b));
+#pragma unroll
+    for (int x = 4; x < 8; ++x) { const uint32_t ad = aoff[x] + sb; W2V2_TR4(af[x], ad); }
+    __builtin_amdgcn_sched_barrier(0);     // the second half of the dY fragments lands under the first 16 MFMAs
+    if (do_bias) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        union { bf16x8 v; bf16x2 p[4]; } u;
+        u.v = af[i].v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bsum[i] = __builtin_amdgcn_fdot2_f32_bf16(u.p[e], one2, bsum[i], false);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf_[j].v, af[i].v, acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int x = 4; x < 8; ++x) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[x].s.a), "+v"(af[x].s.b));
+    if (do_bias) {
+#pragma unroll
+      for (int i = 4; i < 8; ++i) {
+        union { bf16x8 v; bf16x2 p[4]; } u;
+        u.v = af[i].v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bsum[i] = __builtin_amdgcn_fdot2_f32_bf16(u.p[e], one2, bsum[i], false);
+      }
+    }
+#pragma unroll
+    for (int i = 4; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf_[j].v, af[i].v, acc[i][j], 0, 0, 0);
+  }
+#undef W2V2_TR4
+
+  if (do_bias) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      float s = bsum[i];
+      s += __shfl_xor(s, 16, 64);
+      s += __shfl_xor(s, 32, 64);
+      const int m = m0 + wm * 128 + i * 16 + (lane & 15);
+      if ((lane >> 4) == 0 && m < P.n_out) P.dbias[m] = s;
+    }
+  }
+  // coalesced f32 tile store through LDS: four passes of 64 rows (fragments (p & 1) * 4 .. +3 of the waves wm == p >> 1)
+  float* stagef = reinterpret_cast<float*>(smem_raw);
+  constexpr int PITCH = BN + 4;
+  const int frow = lane & 15, fk = lane >> 4;
+#pragma unroll
+  for (int pass = 0; pass < 4; ++pass) {             // fully unrolled: the accumulator indices must stay static
+    __syncthreads();
+    if (wm == (pass >> 1)) {
+#pragma unroll
+      for (int i4 = 0; i4 < 4; ++i4) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const f32x4 v = acc[(pass & 1) * 4 + i4][j];
+          *reinterpret_cast<float4*>(stagef + (i4 * 16 + frow) * PITCH + wn * 64 + j * 16 + fk * 4) =
+              make_float4(v[0], v[1], v[2], v[3]);
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int c = tid + 512 * it;                 // 64 rows x 64 float4 chunks
+      const int r = c >> 6, ch = c & 63;
+      const int m = m0 + pass * 64 + r, n = n0 + ch * 4;
+      if (m < P.n_out && n + 4 <= P.n_in)
+        *reinterpret_cast<float4*>(P.dW + (int64_t)m * P.ld_dw + n) =
+            *reinterpret_cast<const float4*>(stagef + r * PITCH + ch * 4);
+    }
+  }
+}
+
 extern "C" int w2v2_wgrad_grouped(const w2v2_wgrad_problem* probs, int n, int tokens, int tokens_padded, void* stream) {
   W2V2_REQUIRE(probs && n > 0 && n <= WG_MAXP, "wgrad_grouped: need 1..%d problems", WG_MAXP);
   W2V2_REQUIRE(tokens > 0 && tokens_padded >= tokens && tokens_padded % 64 == 0,
@@ -407,7 +587,18 @@ extern "C" int w2v2_wgrad_grouped(const w2v2_wgrad_problem* probs, int n, int to
   int max_out = 0;
   for (int i = 0; i < n; ++i) max_out = probs[i].n_out > max_out ? probs[i].n_out : max_out;
   const bool ring = max_out > 128 && getenv("W2V2_WGRAD_V1") == nullptr;
+  // 256x256 tiles when they alone fill >= 80 % of the CUs (e.g. the 8 problems of two w2v2-base blocks: 216 tiles)
+  int64_t t4 = 0;
+  for (int i = 0; i < n; ++i) t4 += cdiv(probs[i].n_out, 256) * cdiv(probs[i].n_in, 256);
+  int ncu = 256;
+  {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
+  }
+  const bool ring4 = ring && t4 * 10 >= (int64_t)ncu * 8 && getenv("W2V2_NO_WGRAD4") == nullptr;
   const int bm = ring ? 256 : 128;
+  const int bn = ring4 ? 256 : 128;
   for (int i = 0; i < n; ++i) {
     const w2v2_wgrad_problem& q = probs[i];
     W2V2_REQUIRE(q.dY && q.X && q.dW, "wgrad_grouped: null operand in problem %d", i);
@@ -421,7 +612,7 @@ extern "C" int w2v2_wgrad_grouped(const w2v2_wgrad_problem* probs, int n, int to
     P.dY = (const bf16_t*)q.dY; P.X = (const bf16_t*)q.X; P.dW = q.dW; P.dbias = q.dbias;
     P.ld_dy = q.ld_dy; P.ld_x = q.ld_x; P.ld_dw = q.ld_dw;
     P.n_out = q.n_out; P.n_in = q.n_in;
-    P.tiles_n = (int)cdiv(q.n_in, 128);
+    P.tiles_n = (int)cdiv(q.n_in, bn);
     P.tile_begin = tiles;
     tiles += (int)cdiv(q.n_out, bm) * P.tiles_n;
   }
@@ -429,7 +620,16 @@ extern "C" int w2v2_wgrad_grouped(const w2v2_wgrad_problem* probs, int n, int to
   a.n_problems = n;
   a.total_tiles = tiles;
   a.ktiles = tokens_padded / 64;
-  if (ring) {
+  if (ring4) {
+    constexpr size_t lds = (size_t)4 * 32 * (256 + 256) * sizeof(bf16_t);   // 128 KiB
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_grouped_ring4_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(wgrad_grouped_ring4_kernel, dim3(tiles), dim3(512), lds, as_stream(stream), a);
+  } else if (ring) {
     constexpr size_t lds = (size_t)3 * 64 * (256 + 128) * sizeof(bf16_t);   // 144 KiB
     static bool attr_set = false;
     if (!attr_set) {

@@ -9,6 +9,8 @@ ref: src/layers/pooling.py, src/optim/loss/aam_softmax.py, src/optim/loss/cross_
 """
 from __future__ import annotations
 
+import os
+
 import math
 from dataclasses import dataclass
 from typing import Callable, Dict, List, Optional, Sequence
@@ -164,10 +166,12 @@ class Plan:
         if self.train:
             self.demb = self.head.demb if self.head is not None else self._e(B, E, dtype=f32)
             self.G = self._ep(M, H)           # running activation gradient
-            self.Gd = self._ep(M, H)          # ... after the dropout mask of the FFN residual branch (df)
-            self.Gd1 = self._ep(M, H)         # ... of the attention residual branch (da)
-            self.DH = self._ep(M, I)
-            self.DQKV = self._ep(M, 3 * H)
+            # Gradient scratch of one layer's backward: Gd = df (after the dropout mask of the FFN residual branch),
+            # Gd1 = da (attention residual branch), DH, DQKV.  TWO sets, used by alternating layers: the grouped
+            # weight-gradient launch then covers a PAIR of layers (8 problems = 216 tiles of 256x256, one full round
+            # of the chip instead of two 216-tile rounds of 256x128), see _build_gemms / backward.
+            self._gsets = [dict(Gd=self._ep(M, H), Gd1=self._ep(M, H), DH=self._ep(M, I), DQKV=self._ep(M, 3 * H))
+                           for _ in range(2)]
             self.DC = self._e(M, H)
             self.P1 = self._e(M, H)
             self.dyg = self._e(B, G, self.Tp, self.Cg)
@@ -249,6 +253,7 @@ class Plan:
                 Wqkv = st.qkv(l, "w")
                 # data-gradient products: with the pre-transposed bf16 weight copies they are plain
                 # K-contiguous GEMMs (LDS-DMA kernel); the f32 parity mode reads W as a K-major operand
+                gs = self._gsets[l % 2]
                 tb = st.flat_lp_t is None
                 if not tb:
                     W2, W1, Wo = (st.wt("wav2vec.model." + pre + "feed_forward.output_dense.weight"),
@@ -259,28 +264,29 @@ class Plan:
                 if self.grouped:
                     pad = lambda t: t._w2v2_padded
                     Mp = pad(self.G).shape[0]
-                    gl["wgrad"] = WgradGroup([
-                        (pad(self.Gd), pad(lb.h), mg(pre + "feed_forward.output_dense.weight"),
+                    gl["wgrad_problems"] = [
+                        (pad(gs["Gd"]), pad(lb.h), mg(pre + "feed_forward.output_dense.weight"),
                          mg(pre + "feed_forward.output_dense.bias")),
-                        (pad(self.DH), pad(lb.x1), mg(pre + "feed_forward.intermediate_dense.weight"),
+                        (pad(gs["DH"]), pad(lb.x1), mg(pre + "feed_forward.intermediate_dense.weight"),
                          mg(pre + "feed_forward.intermediate_dense.bias")),
-                        (pad(self.Gd1), pad(lb.ctx), mg(pre + "attention.out_proj.weight"),
+                        (pad(gs["Gd1"]), pad(lb.ctx), mg(pre + "attention.out_proj.weight"),
                          mg(pre + "attention.out_proj.bias")),
-                        (pad(self.DQKV), pad(xin), st.qkv(l, "g"), st.qkv(l, "g", "bias"))], M, Mp)
-                gl["dW2"] = Gemm(H, I, M, self.Gd, lb.h, mg(pre + "feed_forward.output_dense.weight"), lda=H, ldb=I,
+                        (pad(gs["DQKV"]), pad(xin), st.qkv(l, "g"), st.qkv(l, "g", "bias"))]
+                    gl["wgrad"] = WgradGroup(gl["wgrad_problems"], M, Mp)
+                gl["dW2"] = Gemm(H, I, M, gs["Gd"], lb.h, mg(pre + "feed_forward.output_dense.weight"), lda=H, ldb=I,
                                  ldc=I, transA=True, transB=True, split_k=sk(H, I), accumulate=True)
-                gl["dh"] = Gemm(M, I, H, self.Gd, W2, self.DH, lda=H, ldb=I if tb else H, ldc=I, transB=tb,
+                gl["dh"] = Gemm(M, I, H, gs["Gd"], W2, gs["DH"], lda=H, ldb=I if tb else H, ldc=I, transB=tb,
                                 epilogue=EPI_GELU_BWD, aux=lb.hpre, ldaux=I)
-                gl["dW1"] = Gemm(I, H, M, self.DH, lb.x1, mg(pre + "feed_forward.intermediate_dense.weight"), lda=I,
+                gl["dW1"] = Gemm(I, H, M, gs["DH"], lb.x1, mg(pre + "feed_forward.intermediate_dense.weight"), lda=I,
                                  ldb=H, ldc=H, transA=True, transB=True, split_k=sk(I, H), accumulate=True)
-                gl["dx1"] = Gemm(M, H, I, self.DH, W1, self.G, lda=I, ldb=H if tb else I, ldc=H, transB=tb,
+                gl["dx1"] = Gemm(M, H, I, gs["DH"], W1, self.G, lda=I, ldb=H if tb else I, ldc=H, transB=tb,
                                  epilogue=EPI_ADD, aux=self.G, ldaux=H)
-                gl["dWo"] = Gemm(H, H, M, self.Gd1, lb.ctx, mg(pre + "attention.out_proj.weight"), lda=H, ldb=H, ldc=H,
+                gl["dWo"] = Gemm(H, H, M, gs["Gd1"], lb.ctx, mg(pre + "attention.out_proj.weight"), lda=H, ldb=H, ldc=H,
                                  transA=True, transB=True, split_k=sk(H, H), accumulate=True)
-                gl["dctx"] = Gemm(M, H, H, self.Gd1, Wo, self.DC, lda=H, ldb=H, ldc=H, transB=tb)
+                gl["dctx"] = Gemm(M, H, H, gs["Gd1"], Wo, self.DC, lda=H, ldb=H, ldc=H, transB=tb)
                 if not self.fused:
                     qkv = lb.qkv.view(-1)
-                    dq = self.DQKV.view(-1)
+                    dq = gs["DQKV"].view(-1)
                     sc = (heads * T * self.Tl, T * self.Tl)
                     hs = (T * 3 * H, d)
                     gl["dP"] = Gemm(T, T, d, self.DC, qkv[2 * H:], self.S, lda=H, ldb=3 * H, ldc=self.Tl,
@@ -294,11 +300,18 @@ class Plan:
                     gl["dv"] = Gemm(T, d, T, lb.pd, self.DC, dq[2 * H:], lda=self.Tl, ldb=H, ldc=3 * H, transA=True,
                                     transB=True, batch=B * heads, batch_inner=heads, a_strides=sc,
                                     b_strides=(T * H, d), c_strides=hs)
-                gl["dWqkv"] = Gemm(3 * H, H, M, self.DQKV, xin, st.qkv(l, "g"), lda=3 * H, ldb=H, ldc=H, transA=True,
+                gl["dWqkv"] = Gemm(3 * H, H, M, gs["DQKV"], xin, st.qkv(l, "g"), lda=3 * H, ldb=H, ldc=H, transA=True,
                                    transB=True, split_k=sk(3 * H, H), accumulate=True)
-                gl["dx"] = Gemm(M, H, 3 * H, self.DQKV, Wqkv, self.G, lda=3 * H, ldb=H if tb else 3 * H, ldc=H,
+                gl["dx"] = Gemm(M, H, 3 * H, gs["DQKV"], Wqkv, self.G, lda=3 * H, ldb=H if tb else 3 * H, ldc=H,
                                 transB=tb, epilogue=EPI_ADD, aux=self.G, ldaux=H)
             self.g_layer.append(gl)
+        # weight gradients of two consecutive layers (l, l-1; l counted down from the top) in one launch
+        self.g_wgrad_pair = {}
+        if self.train and getattr(self, "grouped", False) and not os.environ.get("W2V2_NO_WGRAD_PAIRS"):
+            Mp = self.G._w2v2_padded.shape[0]
+            for l in range(L - 1, 0, -2):
+                self.g_wgrad_pair[l] = WgradGroup(self.g_layer[l]["wgrad_problems"] +
+                                                  self.g_layer[l - 1]["wgrad_problems"], M, Mp)
         if self.train:
             mg = st.mg
             # pos-conv backward: weight gradient (packed layout) and data gradient (flipped weights)
@@ -471,37 +484,45 @@ class Plan:
         notify("head")
         heads, d = cfg.num_attention_heads, cfg.head_dim
         pa, ph = reg.attention_dropout, reg.hidden_dropout
+        Ltop = cfg.num_hidden_layers - 1
+        held = None            # upper layer of a pair whose weight-gradient launch waits for its partner
         for l in reversed(range(cfg.num_hidden_layers)):
+            upper = (Ltop - l) % 2 == 0 and l > 0 and l in self.g_wgrad_pair     # l pairs with l-1
             if l in self._skip:
+                if held is not None:                  # partner skipped by LayerDrop: the held layer goes alone
+                    self.g_layer[held]["wgrad"]()
+                    notify(f"layer{held}")
+                    held = None
                 notify(f"layer{l}")
                 continue
             lb, gl = self.lb[l], self.g_layer[l]
+            gs = self._gsets[l % 2]
             pre = f"encoder.layers.{l}."
             grouped = self.grouped
             # x2 = LN2(x1 + drop(f)):  G <- ds2 (residual path), Gd <- df = ds2 * dropmask
-            ops.layernorm_bwd(self.G, lb.f, lb.mean2, lb.rstd2, mp(pre + "final_layer_norm.weight"), self.G, self.Gd,
+            ops.layernorm_bwd(self.G, lb.f, lb.mean2, lb.rstd2, mp(pre + "final_layer_norm.weight"), self.G, gs["Gd"],
                               mg(pre + "final_layer_norm.weight"), mg(pre + "final_layer_norm.bias"), ph,
                               self._sd("ffn", l, step))
             if not grouped:
                 gl["dW2"]()
-                ops.colsum(self.Gd, mg(pre + "feed_forward.output_dense.bias"), M, H)
+                ops.colsum(gs["Gd"], mg(pre + "feed_forward.output_dense.bias"), M, H)
             gl["dh"]()                                          # DH = (df @ W2) * gelu'(hpre)
             if reg.activation_dropout > 0:
                 raise NotImplementedError("activation_dropout > 0 (reference default is 0.0)")
             if not grouped:
                 gl["dW1"]()
-                ops.colsum(self.DH, mg(pre + "feed_forward.intermediate_dense.bias"), M, cfg.intermediate_size)
+                ops.colsum(gs["DH"], mg(pre + "feed_forward.intermediate_dense.bias"), M, cfg.intermediate_size)
             gl["dx1"]()                                         # G = DH @ W1 + G
             # x1 = LN1(x + drop(a)):  G <- ds1, Gd1 <- da
-            ops.layernorm_bwd(self.G, lb.a, lb.mean1, lb.rstd1, mp(pre + "layer_norm.weight"), self.G, self.Gd1,
+            ops.layernorm_bwd(self.G, lb.a, lb.mean1, lb.rstd1, mp(pre + "layer_norm.weight"), self.G, gs["Gd1"],
                               mg(pre + "layer_norm.weight"), mg(pre + "layer_norm.bias"), ph,
                               self._sd("post_attn", l, step))
             if not grouped:
                 gl["dWo"]()
-                ops.colsum(self.Gd1, mg(pre + "attention.out_proj.bias"), M, H)
+                ops.colsum(gs["Gd1"], mg(pre + "attention.out_proj.bias"), M, H)
             gl["dctx"]()
             if self.fused:
-                ops.attention_bwd(lb.qkv, lb.ctx, self.DC, lb.lse, self.DQKV, self.delta, B, T, heads, d, d ** -0.5,
+                ops.attention_bwd(lb.qkv, lb.ctx, self.DC, lb.lse, gs["DQKV"], self.delta, B, T, heads, d, d ** -0.5,
                                   pa, self._sd("attn", l, step))
             else:
                 gl["dP"]()
@@ -509,12 +530,24 @@ class Plan:
                 gl["dq"]()
                 gl["dk"]()
                 gl["dv"]()
-            if grouped:
-                gl["wgrad"]()       # dW2,db2 | dW1,db1 | dWo,dbo | dWqkv,dbqkv in one atomic-free launch
+            defer = False
+            if grouped:         # dW2,db2 | dW1,db1 | dWo,dbo | dWqkv,dbqkv: one atomic-free launch per layer PAIR
+                if held is not None:
+                    self.g_wgrad_pair[held]()
+                elif upper:
+                    defer = True                      # wait for layer l-1 (its dY's live in the other buffer set)
+                else:
+                    gl["wgrad"]()
             else:
                 gl["dWqkv"]()
-                ops.colsum(self.DQKV, st.qkv(l, "g", "bias"), M, 3 * H)
+                ops.colsum(gs["DQKV"], st.qkv(l, "g", "bias"), M, 3 * H)
             gl["dx"]()                                          # G = DQKV @ Wqkv + G
+            if defer:
+                held = l
+                continue
+            if held is not None:
+                notify(f"layer{held}")
+                held = None
             notify(f"layer{l}")
         # encoder prologue: x0 = drop(LN(hx + pos)), pos = GELU(posconv(hx) + b)
         if ph > 0:

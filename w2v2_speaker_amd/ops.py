@@ -6,6 +6,7 @@ current torch stream; nothing falls back to torch / CPU arithmetic.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -97,6 +98,10 @@ class Gemm:
         fast = (dt(A) == BF16 and not transA and not transB and K % 64 == 0 and K >= 64 and lda % 8 == 0 and ldb % 8 == 0)
         if fast and N >= 512 and M >= 1024 and split_k <= 1 and not accumulate:
             self.kernel_name = "gemm_bf16_glds3_kernel"
+            t4 = -(-M // 256) * -(-N // 256)          # 256x256 tiling fills >= 85 % of the last round of 256 CUs
+            if (batch == 1 and t4 >= 256 and t4 / (-(-t4 // 256) * 256) >= 0.85 and N / (-(-N // 256) * 256) >= 0.9
+                    and not os.environ.get("W2V2_NO_GLDS4")):
+                self.kernel_name = "gemm_bf16_glds4_kernel"
         elif fast:
             self.kernel_name = "gemm_bf16_glds_kernel"
         else:
@@ -113,11 +118,18 @@ class Gemm:
     def profile_end(cls) -> dict:
         prof, cls._prof = cls._prof, None
         if not prof or not prof["events"]:
-            return {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0}
+            return {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0, "by_kernel": {}}
         torch.cuda.synchronize()
-        ms = sum(a.elapsed_time(b) for a, b, _, _ in prof["events"])
-        return {"launches": len(prof["events"]), "ms": ms, "flops": sum(f for _, _, f, _ in prof["events"]),
-                "bytes": sum(b for _, _, _, b in prof["events"])}
+        out = {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0, "by_kernel": {}}
+        for a, b, f, nb, name in prof["events"]:
+            ms = a.elapsed_time(b)
+            k = out["by_kernel"].setdefault(name, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+            for d in (out, k):
+                d["launches"] += 1
+                d["ms"] += ms
+                d["flops"] += f
+                d["bytes"] += nb
+        return out
 
     def __call__(self) -> None:
         prof = Gemm._prof
@@ -126,7 +138,7 @@ class Gemm:
             e0.record()
             rc = self._fn(self._ref, stream())
             e1.record()
-            prof["events"].append((e0, e1, self.flops, self.bytes))
+            prof["events"].append((e0, e1, self.flops, self.bytes, self.kernel_name))
         else:
             rc = self._fn(self._ref, stream())
         if rc:
