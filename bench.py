@@ -186,9 +186,9 @@ def main():
         }
         if prof["launches"]:
             # the two persistent LDS-DMA ring GEMM kernels; the roofline entry is the one with the larger total time
-            desc = {"gemm_bf16_glds3_kernel": "256x128x64 3-stage LDS-DMA ring MFMA GEMM: projection, QKV, out-proj, "
-                                              "FFN2 forward + the N<=2304 data-gradient products",
-                    "gemm_bf16_glds4_kernel": "256x256x32 4-stage LDS-DMA ring MFMA GEMM: conv1-6, FFN1 forward, dH"}
+            desc = {"gemm_bf16_glds3_kernel": "256x128x64 3-stage LDS-DMA ring MFMA GEMM: conv4-6, projection, QKV, "
+                                              "out-proj, FFN2 forward + the N<=2304 data-gradient products",
+                    "gemm_bf16_glds4_kernel": "256x256x32 4-stage LDS-DMA ring MFMA GEMM: conv1-3, FFN1 forward, dH"}
             pmc = {}
             try:     # HBM bytes per launch from the PMC passes (tools/pmc_traffic.py)
                 pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")))["kernels"]
