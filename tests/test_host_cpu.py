@@ -145,3 +145,26 @@ def test_eval_metrics_and_evaluator_match_reference_golden():
         calculate_eer([0, 2], [0.1, 0.2])
     missing = CosineDistanceEvaluator().evaluate([EvaluationPair(True, "zz", "a0")], samples)
     assert missing["eer"] == -1
+
+
+def test_ensemble_of_layers_scoring_is_mean_of_member_scores():
+    """ref: src/evaluation/speaker/cosine_distance.py:134-185."""
+    import torch
+    from w2v2_speaker_amd.evaluation.speaker.cosine_distance import CosineDistanceEvaluator, EmbeddingSample
+    g = torch.Generator().manual_seed(0)
+    n, d = 3, 16
+    samples = {k: [torch.randn(d, generator=g) for _ in range(n)] for k in "abcd"}
+    pairs = [(EmbeddingSample("a", samples["a"]), EmbeddingSample("b", samples["b"])),
+             (EmbeddingSample("c", samples["c"]), EmbeddingSample("d", samples["d"]))]
+    ev = CosineDistanceEvaluator(False, False, 0)
+    got = ev._compute_prediction_scores(pairs)
+    for (l, r), s in zip((("a", "b"), ("c", "d")), got):
+        ref = sum(float(torch.nn.functional.cosine_similarity(samples[l][i], samples[r][i], dim=0)) for i in range(n)) / n
+        assert abs(s - ref) < 1e-6
+    bad = [(EmbeddingSample("a", samples["a"]), EmbeddingSample("b", samples["b"][:2]))]
+    try:
+        ev._compute_prediction_scores(bad)
+        assert False
+    except ValueError:
+        pass
+

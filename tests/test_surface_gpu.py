@@ -187,3 +187,26 @@ def test_initially_frozen_network_trains_head_only_then_unfreezes():
     torch.cuda.synchronize()
     assert not torch.equal(st.flat[h:st.n_train], mid[h:st.n_train])
     assert torch.equal(st.flat[st.n_train:], before[st.n_train:])   # CNN never updated
+
+
+def test_ensemble_of_layers_embeddings_vs_oracle():
+    """ref: wav2vec2_fc.py:440-463: pooled embedding of each of the last n hidden states (HF output_hidden_states)."""
+    from w2v2_speaker_amd.config import W2V2Config
+    from w2v2_speaker_amd.engine import Plan
+    from w2v2_speaker_amd.params import ParamStore
+    cfg, ocfg = W2V2Config.tiny(), O.OracleConfig.tiny()
+    st = ParamStore(cfg, DEV, torch.float32, head=None)
+    sd = O.make_state_dict(ocfg, 20211)
+    st.load_state_dict(sd)
+    wav, _ = O.synth_batch(3, 4000, 10, seed=4)
+    plan = Plan(st, 3, 4000, train=False, keep_hidden_states=True)
+    embs = plan.ensemble_embeddings(wav.to(DEV), 2)
+    torch.cuda.synchronize()
+    _, stages = O.wav2vec2_forward(wav[:, 0], sd, ocfg, return_stages=True)
+    refs = [O.mean_std_pool(stages["layer0"]), O.mean_std_pool(stages["layer1"])]
+    assert len(embs) == 2
+    for e, r in zip(embs, refs):
+        assert rel_l2(e.cpu(), r) < 2e-5
+    hs = plan.hidden_states()
+    assert len(hs) == cfg.num_hidden_layers + 1 and rel_l2(hs[-1].cpu(), stages["layer1"]) < 2e-5
+

@@ -62,7 +62,7 @@ class Plan:
                  reg: Optional[Wav2Vec2RegularisationConfig] = None, pooling: str = "mean+std",
                  insert_cls_token: bool = False, cls_token_constant: float = 1.0,
                  aam_margin: float = 0.2, aam_scale: float = 30.0, fused_attention: Optional[bool] = None,
-                 seed: int = 7):
+                 seed: int = 7, keep_hidden_states: bool = False):
         cfg = store.cfg
         self.store, self.cfg, self.B, self.N, self.train = store, cfg, batch, n_samples, train
         self.reg = reg if reg is not None else Wav2Vec2RegularisationConfig()
@@ -71,6 +71,9 @@ class Plan:
         self.cls, self.cls_c = insert_cls_token, cls_token_constant
         self.margin, self.scale = aam_margin, aam_scale
         self.seed = seed
+        # eval plans normally ping-pong two activation buffers; keeping all L+1 of them gives HF's
+        # ``output_hidden_states`` (ref: wav2vec2_fc.py:440-463 ensemble of layers)
+        self.all_x = train or keep_hidden_states
         self.dev, self.adt = store.device, store.act_dtype
         self.lens = cfg.conv_lengths(n_samples)
         self.T0 = self.lens[-1]                       # frames out of the CNN
@@ -131,7 +134,7 @@ class Plan:
         self.mean0, self.rstd0 = self._e(M, dtype=f32), self._e(M, dtype=f32)
         L = cfg.num_hidden_layers
         nset = L if self.train else 1
-        self.X = [self._ep(M, H) for _ in range(L + 1 if self.train else 2)]
+        self.X = [self._ep(M, H) for _ in range(L + 1 if self.all_x else 2)]
         heads = cfg.num_attention_heads
         self.Tl = (T + 7) // 8 * 8
         self.lb: List[LayerBufs] = []
@@ -224,7 +227,7 @@ class Plan:
         self.g_layer: List[Dict[str, Gemm]] = []
         for l in range(L):
             lb = self.lb[l if self.train else 0]
-            xin = self.X[l] if self.train else self.X[l % 2]
+            xin = self.X[l] if self.all_x else self.X[l % 2]
             pre = f"encoder.layers.{l}."
             gl: Dict[str, Gemm] = {}
             gl["qkv"] = Gemm(M, 3 * H, H, xin, st.qkv(l, "w"), lb.qkv, lda=H, ldb=H, ldc=3 * H, epilogue=EPI_BIAS,
@@ -404,8 +407,8 @@ class Plan:
         pa = reg.attention_dropout if tr else 0.0
         ph = reg.hidden_dropout if tr else 0.0
         for l in range(cfg.num_hidden_layers):
-            xin = self.X[l] if tr else self.X[l % 2]
-            xout = self.X[l + 1] if tr else self.X[(l + 1) % 2]
+            xin = self.X[l] if self.all_x else self.X[l % 2]
+            xout = self.X[l + 1] if self.all_x else self.X[(l + 1) % 2]
             if l in self._skip:                 # LayerDrop (HF:698-709): the layer is the identity
                 xout.copy_(xin)
                 continue
@@ -428,7 +431,7 @@ class Plan:
             gl["ffn2"]()
             ops.layernorm_fwd(lb.x1, lb.f, mp(pre + "final_layer_norm.weight"), mp(pre + "final_layer_norm.bias"),
                               xout, lb.mean2, lb.rstd2, cfg.layer_norm_eps, ph, self._sd("ffn", l, step))
-        self.out = (self.X[cfg.num_hidden_layers] if tr else self.X[cfg.num_hidden_layers % 2]).view(B, T, H)
+        self.out = (self.X[cfg.num_hidden_layers] if self.all_x else self.X[cfg.num_hidden_layers % 2]).view(B, T, H)
         return self.out
 
     def embed(self, wav, mask=None, skip_layers=(), step: int = 0) -> torch.Tensor:
@@ -438,6 +441,24 @@ class Plan:
             return self._asp_for(out).forward()
         ops.pool_fwd(out, self.emb, self.pool_mode)
         return self.emb
+
+    def hidden_states(self) -> List[torch.Tensor]:
+        """HF ``output_hidden_states`` of the last forward: [prologue output, layer 1, ..., layer L], each [B,T,H]."""
+        assert self.all_x, "build the plan with keep_hidden_states=True"
+        return [x.view(self.B, self.T, self.cfg.hidden_size) for x in self.X]
+
+    def ensemble_embeddings(self, wav, num_ensembles: int) -> List[torch.Tensor]:
+        """ref: src/lightning_modules/speaker/wav2vec2_fc.py:440-463 (compute_ensemble_embedding): the pooled
+        embedding of each of the last ``num_ensembles`` hidden states (hidden_states[L+1-n : L+1])."""
+        assert self.pooling != "attentive", "ensemble pooling shares one stat-pooling layer: use a stateless pool"
+        self.forward(wav, None, (), 0)
+        hs = self.hidden_states()
+        out = []
+        for h in hs[len(hs) - num_ensembles:]:
+            e = torch.empty_like(self.emb)
+            ops.pool_fwd(h, e, self.pool_mode)
+            out.append(e)
+        return out
 
     def _asp_for(self, out: torch.Tensor):
         """Attentive statistics pooling over the buffer the encoder just wrote (built once per buffer)."""

@@ -58,9 +58,31 @@ class CosineDistanceEvaluator:
         return t
 
     def _compute_prediction_scores(self, pairs: List[Tuple[EmbeddingSample, EmbeddingSample]]) -> List[float]:
+        if isinstance(pairs[0][0].embedding, list):     # ref: cosine_distance.py:110-112 (ensemble of layers)
+            return self._compute_ensemble_prediction_scores(pairs)
         left = self._prep(torch.stack([torch.as_tensor(a.embedding).flatten().float().cpu() for a, _ in pairs]))
         right = self._prep(torch.stack([torch.as_tensor(b.embedding).flatten().float().cpu() for _, b in pairs]))
         return compute_cosine_scores(left, right)
+
+    def _compute_ensemble_prediction_scores(self, pairs: List[Tuple[EmbeddingSample, EmbeddingSample]]) -> List[float]:
+        """ref: cosine_distance.py:134-185 -- every sample carries a LIST of embeddings (one per hidden state,
+        Wav2vec2FCModule.compute_ensemble_embedding); the score of a pair is the mean of the per-member scores."""
+        n = len(pairs[0][0].embedding)
+        for s1, s2 in pairs:
+            if not isinstance(s1.embedding, list) or not isinstance(s2.embedding, list):
+                raise ValueError("not every embedding sample is an ensemble")
+            if len(s1.embedding) != n or len(s2.embedding) != n:
+                raise ValueError(f"expected each list to have len num_ensembles={n}")
+        member_scores = [self._compute_prediction_scores(
+            [(EmbeddingSample(sample_id=a.sample_id, embedding=a.embedding[i]),
+              EmbeddingSample(sample_id=b.sample_id, embedding=b.embedding[i])) for a, b in pairs]) for i in range(n)]
+        combined = []
+        for idx in range(len(pairs)):
+            score = 0
+            for i in range(n):                       # same accumulation order as the reference
+                score += member_scores[i][idx] * (1 / n)
+            combined.append(score)
+        return combined
 
     def evaluate(self, pairs: List[EvaluationPair], samples: List[EmbeddingSample]):
         sample_map = {}

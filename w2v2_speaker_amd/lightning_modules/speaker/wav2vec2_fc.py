@@ -237,6 +237,24 @@ class Wav2vec2FCModule:
         return self._evaluate_embeddings(outputs, self.test_pairs)
 
     # ------------------------------------------------------------------ checkpoints (reference key names)
+    def compute_ensemble_embedding(self, input_tensor: torch.Tensor):
+        """ref: wav2vec2_fc.py:440-463 -- list of ``num_ensembles`` pooled embeddings, one per hidden state of the
+        last transformer layers (``use_transformers_as_ensembles``); scored by CosineDistanceEvaluator as the mean
+        of the per-layer cosine scores."""
+        x = input_tensor
+        if x.dim() == 3 and x.shape[1] == 1:
+            x = x[:, 0, :]
+        if x.dim() == 1:
+            x = x[None]
+        key = ("ensemble", x.shape[0], x.shape[1])
+        if key not in self._plans:
+            self._plans[key] = Plan(self.store, x.shape[0], x.shape[1], train=False, reg=self.reg,
+                                    pooling=self.cfg.stat_pooling_type, keep_hidden_states=True,
+                                    insert_cls_token=(self.cfg.stat_pooling_type == "first+cls"),
+                                    cls_token_constant=self.cfg.cls_token_constant
+                                    if hasattr(self.cfg, "cls_token_constant") else 1.0)
+        return self._plans[key].ensemble_embeddings(x.to(self.device), self.cfg.num_ensembles)
+
     def state_dict(self):
         return self.store.state_dict()
 
