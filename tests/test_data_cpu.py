@@ -1,0 +1,76 @@
+"""Data feed in the reference's shard format: round trip, preprocessors, shuffle-queue batcher."""
+import os
+import random
+
+import pytest
+import torch
+
+from oracle import w2v2_oracle as O
+from w2v2_speaker_amd.data import (AudioChunkSelector, BatchProcessor, DeviceFeeder, InputNormalizer2D, ShardDataset,
+                                   SpeakerClassificationDataSample, find_shards, iter_shard, read_meta, write_shards)
+
+
+def _synthetic(n=23, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    out = []
+    for i in range(n):
+        frames = 48000 + int(torch.randint(0, 32000, (1,), generator=g))
+        out.append((f"id{10000 + i % 5}/yt{i:03d}/{i:05d}", i % 5, 0.1 * torch.randn(1, frames, generator=g) + 0.02))
+    return out
+
+
+@pytest.mark.parametrize("compress", [False, True])
+def test_shard_round_trip_and_folder_meta(tmp_path, compress):
+    data = _synthetic()
+    paths = write_shards(data, str(tmp_path), samples_per_shard=10, compress=compress)
+    assert len(paths) == 3 and paths == find_shards(str(tmp_path), "train_shard_*.tar*")
+    assert read_meta(str(tmp_path)) == {"num_samples": 23, "num_speakers": 5, "num_shards": 3}
+    got = [x for p in paths for x in iter_shard(p)]
+    assert [x["__key__"] for x in got] == [k for k, _, _ in data]
+    for x, (k, spk, wav) in zip(got, data):
+        assert torch.equal(x["wav.pyd"], wav) and x["meta.json"]["speaker_id_idx"] == spk
+        assert x["meta.json"]["num_frames"] == wav.shape[-1] and x["meta.json"]["speaker_id"] == k.split("/")[0]
+
+
+def test_normaliser_matches_oracle_and_selector_lengths():
+    wav = 0.3 * torch.randn(1, 70000) + 0.1
+    x, mean, std = InputNormalizer2D.normalize(wav, channel_wise=False)
+    assert torch.allclose(x[0], O.normalise_waveform(wav[0]), atol=1e-6)
+    s = SpeakerClassificationDataSample("k", 3, wav)
+    random.seed(5)
+    out = AudioChunkSelector("random", 3.0).process(s)
+    assert out.network_input.shape == (1, 48000)
+    random.seed(5)
+    start = random.randint(0, 70000 - 48000 - 1)                       # the reference's own draw
+    assert torch.equal(out.network_input, wav[..., start:start + 48000])
+    many = AudioChunkSelector("contiguous", 1.0).process(SpeakerClassificationDataSample("k", 3, wav))
+    assert len(many) == 4 and many[2].key == "k/chunk2" and all(m.network_input.shape[-1] == 16000 for m in many)
+    short = AudioChunkSelector("random", 3.0).process(SpeakerClassificationDataSample("k", 3, wav[..., :1000]))
+    assert short.network_input.shape[-1] == 1000
+
+
+def test_batch_processor_sees_every_sample_once_and_is_seed_deterministic():
+    samples = [SpeakerClassificationDataSample(f"k{i}", i % 7, torch.full((1, 8), float(i))) for i in range(50)]
+    with pytest.raises(ValueError):
+        BatchProcessor(8, 4)
+    random.seed(1)
+    a = list(BatchProcessor(8, 16)(iter(samples)))
+    random.seed(1)
+    b = list(BatchProcessor(8, 16)(iter(samples)))
+    assert [x.keys for x in a] == [x.keys for x in b]
+    keys = [k for x in a for k in x.keys]
+    assert sorted(keys) == sorted(s.key for s in samples)
+    assert all(x.batch_size == 8 for x in a[:-1]) and a[0].network_input.shape == (8, 1, 8)
+    assert a[0].ground_truth.dtype == torch.int64
+    assert keys != [s.key for s in samples]                             # shuffled
+
+
+def test_shard_dataset_end_to_end_and_feeder_on_cpu(tmp_path):
+    paths = write_shards(_synthetic(30), str(tmp_path), samples_per_shard=16)
+    random.seed(3)
+    ds = ShardDataset(paths, batch_size=6, queue_size=12)
+    batches = list(DeviceFeeder(ds, "cpu", depth=2))
+    assert sum(b.batch_size for b in batches) == 30
+    b0 = batches[0]
+    assert b0.network_input.shape == (6, 1, 48000) and b0.ground_truth.shape == (6,)
+    assert abs(float(b0.network_input.mean())) < 0.05          # chunk of a normalised utterance
