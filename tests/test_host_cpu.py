@@ -168,3 +168,34 @@ def test_ensemble_of_layers_scoring_is_mean_of_member_scores():
     except ValueError:
         pass
 
+
+def test_pl_format_checkpoint_round_trip_and_reheading(tmp_path):
+    """state_dict under the reference's key names in a PL-style file; non-strict reload into a
+    module with a different number of speakers keeps the network and re-initialises only the head."""
+    import torch
+    from w2v2_speaker_amd.lightning_modules.speaker.wav2vec2_fc import Wav2vec2FCModule, Wav2vec2FCModuleConfig
+    import dataclasses
+    from w2v2_speaker_amd import config as C
+    tiny = C.W2V2Config.tiny()
+    orig = C.W2V2Config.from_huggingface_id
+    C.W2V2Config.from_huggingface_id = staticmethod(lambda _id: tiny)       # keep the CPU test small
+    try:
+        kw = dict(device="cpu", act_dtype=torch.float32)
+        a = Wav2vec2FCModule(Wav2vec2FCModuleConfig(), num_speakers=7, init_seed=1, **kw)
+        path = str(tmp_path / "last.ckpt")
+        a.steps = 123
+        a.save_checkpoint(path)
+        ck = torch.load(path, weights_only=False)
+        assert {"state_dict", "global_step", "pytorch-lightning_version"} <= set(ck)
+        assert "loss_fn.fc_weights" in ck["state_dict"]
+        assert "wav2vec.model.encoder.layers.0.attention.q_proj.weight" in ck["state_dict"]
+        b = Wav2vec2FCModule.load_from_checkpoint(path, cfg=Wav2vec2FCModuleConfig(), num_speakers=7, init_seed=2, **kw)
+        assert b.steps == 123 and all(torch.equal(v, b.state_dict()[k]) for k, v in a.state_dict().items())
+        c = Wav2vec2FCModule.load_from_checkpoint(path, cfg=Wav2vec2FCModuleConfig(explicit_num_speakers=11),
+                                                  num_speakers=7, init_seed=3, **kw)
+        sc, sa = c.state_dict(), a.state_dict()
+        assert sc["loss_fn.fc_weights"].shape[0] == 11
+        assert all(torch.equal(sa[k], sc[k]) for k in sa if k != "loss_fn.fc_weights")
+    finally:
+        C.W2V2Config.from_huggingface_id = orig
+

@@ -260,3 +260,28 @@ class Wav2vec2FCModule:
 
     def load_state_dict(self, sd, strict: bool = True):
         self.store.load_state_dict(sd, strict=strict, prefix_model=False)
+
+    # ------------------------------------------------------------------ PL-format checkpoints
+    def save_checkpoint(self, path: str) -> None:
+        """A file ``Trainer.save_checkpoint`` / ``load_from_checkpoint`` of the reference can exchange: a pickled
+        dict whose ``state_dict`` uses the reference's parameter names (``wav2vec.model.<HF name>``,
+        ``loss_fn.fc_weights`` / ``fc_list.0.0.*``, ``stat_pooling.pooling_layer.*``)."""
+        torch.save({"state_dict": self.state_dict(), "global_step": self.steps, "epoch": 0,
+                    "pytorch-lightning_version": "1.3.8",
+                    "hyper_parameters": {"num_speakers": self.num_speakers, "loss": self.loss}}, path)
+
+    @classmethod
+    def load_from_checkpoint(cls, checkpoint_path: str, strict: bool = False, **kwargs) -> "Wav2vec2FCModule":
+        """ref: src/main.py:272-283 (``network_class.load_from_checkpoint(path, strict=False, **kwargs)``): construct
+        from kwargs, then load ``checkpoint["state_dict"]``.  Non-strict: unknown keys (e.g. BatchNorm buffers,
+        ``num_batches_tracked``) are skipped, tensors whose shape differs from this module's (a head re-sized through
+        ``explicit_num_speakers``) and missing ones keep their fresh initialisation."""
+        module = cls(**kwargs)
+        ckpt = torch.load(checkpoint_path, map_location="cpu", weights_only=False)
+        sd = ckpt["state_dict"] if "state_dict" in ckpt else ckpt
+        if not strict:
+            shapes = module.store.shapes
+            sd = {k: v for k, v in sd.items() if k not in shapes or tuple(v.shape) == tuple(shapes[k])}
+        module.load_state_dict(sd, strict=strict)
+        module.steps = int(ckpt.get("global_step", 0)) if isinstance(ckpt, dict) else 0
+        return module
