@@ -262,6 +262,38 @@ int w2v2_asp_pool_bwd(const void* x, const void* s, const float* out, const floa
 int w2v2_asp_context_bwd(const void* x, const float* ctx, const void* da, const float* w1, float* dw1, void* dx,
                          float* scratch, int B, int T, int C, int A, int dtype, void* stream);
 
+/* ------------------------------------------------------------------------------ ECAPA-TDNN pieces
+ * ref: src/lightning_modules/speaker/ecapa_tdnn.py:75-85 -> speechbrain 0.5.x ECAPA_TDNN (not part of the reference
+ * tree; restated in oracle/ecapa_oracle.py).  Channels-last [B*T][C] activations; `ld*` = row stride in elements so
+ * Res2Net channel slices and the MFA concatenation are views of their parent tensors.
+ * BatchNorm1d with batch statistics over the M rows (biased variance), optionally on relu(a) (TDNNBlock = conv ->
+ * ReLU -> BatchNorm): stats -> mean_rstd[C][2]; running = {mean[C], var[C]} updated like torch or NULL. */
+int w2v2_bn_workspace_floats(int M, int C);
+int w2v2_bn_stats(const void* a, int64_t lda, float* workspace, float* mean_rstd, float* running, int M, int C,
+                  float eps, float momentum, int relu, int dtype, void* stream);
+int w2v2_bn_apply(const void* a, int64_t lda, const float* mean_rstd, const float* gamma, const float* beta, void* y,
+                  int64_t ldy, int M, int C, int relu, int dtype, void* stream);
+/* dy -> da (through BatchNorm and the optional relu); writes dgamma[C], dbeta[C] */
+int w2v2_bn_bwd(const void* dy, int64_t lddy, const void* a, int64_t lda, const float* mean_rstd, const float* gamma,
+                float* workspace, float* dgamma, float* dbeta, void* da, int64_t ldda, int M, int C, int relu,
+                int dtype, void* stream);
+/* Conv1d(padding="same", padding_mode="reflect", dilation d, odd k) as im2col + GEMM:
+ * col[(b,t)][j*Cin + c] = x[b][reflect(t + (j - (k-1)/2) d)][c]; col2im is its exact adjoint (gather, deterministic) */
+int w2v2_im2col_reflect(const void* x, int64_t ldx, void* col, int B, int T, int Cin, int k, int dilation, int dtype,
+                        void* stream);
+int w2v2_col2im_reflect(const void* dcol, void* dx, int64_t lddx, int B, int T, int Cin, int k, int dilation,
+                        int accumulate, int dtype, void* stream);
+int w2v2_add_strided(const void* a, int64_t lda, const void* b, int64_t ldb, void* y, int64_t ldy, int M, int C,
+                     int dtype, void* stream);
+/* squeeze-excitation gate g [B][C] f32: y = x * g;  dg = sum_t dout * x;  dx = dout * g + ds / T */
+int w2v2_se_scale(const void* x, const float* g, void* y, int B, int T, int C, int dtype, void* stream);
+int w2v2_se_bwd_gate(const void* dout, const void* x, float* dg, int B, int T, int C, int dtype, void* stream);
+int w2v2_se_bwd_x(const void* dout, const float* g, const float* ds, void* dx, int B, int T, int C, int dtype,
+                  void* stream);
+/* f32 vectors; mode 0 relu, 1 sigmoid; the backward takes the forward output */
+int w2v2_act_fwd(const float* x, float* y, int64_t n, int mode, void* stream);
+int w2v2_act_bwd(const float* dy, const float* y, float* dx, int64_t n, int mode, void* stream);
+
 /* ---------------------------------------------------------------------------------------- heads
  * Row inverse L2 norms 1/max(||x||,1e-12) (F.normalize, ref: src/optim/loss/aam_softmax.py:55). */
 int w2v2_row_invnorm(const void* x, int64_t ld, float* inv, int rows, int cols, int dtype,

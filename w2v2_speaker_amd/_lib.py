@@ -75,6 +75,19 @@ _SIGS = {
                                    c_f32, c_u64, c_i32, c_vp]),
     "w2v2_pool_fwd": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "w2v2_pool_bwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    "w2v2_bn_workspace_floats": (c_i32, [c_i32, c_i32]),
+    "w2v2_bn_stats": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_i32, c_i32, c_f32, c_f32, c_i32, c_i32, c_vp]),
+    "w2v2_bn_apply": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    "w2v2_bn_bwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32,
+                            c_i32, c_vp]),
+    "w2v2_im2col_reflect": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    "w2v2_col2im_reflect": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    "w2v2_add_strided": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp]),
+    "w2v2_se_scale": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    "w2v2_se_bwd_gate": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    "w2v2_se_bwd_x": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    "w2v2_act_fwd": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_vp]),
+    "w2v2_act_bwd": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, c_vp]),
     "w2v2_asp_context": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "w2v2_asp_context_bias": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
     "w2v2_asp_bn_workspace_floats": (c_i32, [c_i32, c_i32]),

@@ -30,8 +30,11 @@ class AttentivePool:
     """x [B*T, C] (the last hidden state, padded storage) -> emb [B, 2C] = [mean_w, std_w]; backward adds the
     gradient of x into ``dx`` and writes the six parameter gradients."""
 
-    def __init__(self, store, x: torch.Tensor, emb: torch.Tensor, dx: torch.Tensor, B: int, T: int, train: bool):
+    def __init__(self, store, x: torch.Tensor, emb: torch.Tensor, dx: torch.Tensor, B: int, T: int, train: bool,
+                 prefix: str = ASP_PREFIX):
         self.store, self.B, self.T, self.train = store, B, T, train
+        ASP_PREFIX = prefix          # parameter names of this instance (the ECAPA model keeps them under ``asp.``)
+        self.prefix = prefix
         C = x.shape[1]
         A = store.shapes[ASP_PREFIX + "tdnn.conv.conv.bias"][0]
         self.C, self.A = C, A
@@ -88,15 +91,15 @@ class AttentivePool:
         st, B, T, C, A = self.store, self.B, self.T, self.C, self.A
         p = st.p
         ops.asp_context(self.x, self.ctx, B, T, C)
-        ops.asp_context_bias(self.ctx, p(ASP_PREFIX + "tdnn.conv.conv.weight"), p(ASP_PREFIX + "tdnn.conv.conv.bias"),
+        ops.asp_context_bias(self.ctx, p(self.prefix + "tdnn.conv.conv.weight"), p(self.prefix + "tdnn.conv.conv.bias"),
                              self.cb, B, A, C)
         self.g_a()
         if self.train:      # batch statistics (and running-stat update) like BatchNorm1d.train()
             ops.asp_bn_stats(self.a_pre, self.work, self.mean_rstd, self.running, B * T, A, BN_EPS, BN_MOMENTUM)
         else:
             ops.asp_bn_eval_stats(self.running, self.mean_rstd, A, BN_EPS)
-        ops.asp_bn_tanh(self.a_pre, self.mean_rstd, p(ASP_PREFIX + "tdnn.norm.norm.weight"),
-                        p(ASP_PREFIX + "tdnn.norm.norm.bias"), self.h, B * T, A)
+        ops.asp_bn_tanh(self.a_pre, self.mean_rstd, p(self.prefix + "tdnn.norm.norm.weight"),
+                        p(self.prefix + "tdnn.norm.norm.bias"), self.h, B * T, A)
         self.g_s()
         ops.asp_pool_fwd(self.x, self.s, self.emb, self.stats, B, T, C)
         return self.emb
@@ -108,16 +111,16 @@ class AttentivePool:
         M = B * T
         ops.asp_pool_bwd(self.x, self.s, self.emb, self.stats, demb, self.ds, self.dx, B, T, C)
         self.g_dh()
-        ops.asp_bn_bwd(self.dh, self.a_pre, self.mean_rstd, p(ASP_PREFIX + "tdnn.norm.norm.weight"),
-                       p(ASP_PREFIX + "tdnn.norm.norm.bias"), self.work,
-                       g(ASP_PREFIX + "tdnn.norm.norm.weight"), g(ASP_PREFIX + "tdnn.norm.norm.bias"), self.da, M, A)
+        ops.asp_bn_bwd(self.dh, self.a_pre, self.mean_rstd, p(self.prefix + "tdnn.norm.norm.weight"),
+                       p(self.prefix + "tdnn.norm.norm.bias"), self.work,
+                       g(self.prefix + "tdnn.norm.norm.weight"), g(self.prefix + "tdnn.norm.norm.bias"), self.da, M, A)
         if self.grouped:
             self.g_w()
         else:
             self.g_w2()
-            ops.colsum(self.ds, g(ASP_PREFIX + "conv.conv.bias"), M, C)
+            ops.colsum(self.ds, g(self.prefix + "conv.conv.bias"), M, C)
             self.g_w1()
-            ops.colsum(self.da, g(ASP_PREFIX + "tdnn.conv.conv.bias"), M, A)
+            ops.colsum(self.da, g(self.prefix + "tdnn.conv.conv.bias"), M, A)
         self.g_dx()                                                  # dx += da Wx
-        ops.asp_context_bwd(self.x, self.ctx, self.da, p(ASP_PREFIX + "tdnn.conv.conv.weight"),
-                            g(ASP_PREFIX + "tdnn.conv.conv.weight"), self.dx, self.scratch, B, T, C, A)
+        ops.asp_context_bwd(self.x, self.ctx, self.da, p(self.prefix + "tdnn.conv.conv.weight"),
+                            g(self.prefix + "tdnn.conv.conv.weight"), self.dx, self.scratch, B, T, C, A)

@@ -1,0 +1,492 @@
+"""ECAPA-TDNN training step on the HIP path (BASELINE configs[4]).
+
+ref: src/lightning_modules/speaker/ecapa_tdnn.py:51-137 (``EcapaTdnnModule`` -> speechbrain 0.5.x
+``ECAPA_TDNN(input_size=40, channels=[1024]*4+[3072], kernel_sizes=[5,3,3,3,1], dilations=[1,2,3,4,1],
+attention_channels=128, res2net_scale=8, se_channels=128, lin_neurons=192)``, config/network/ecapa_tdnn.yaml) with
+the AAM-softmax head on the 192-d embedding (the ``Classifier`` is skipped under AAM, :98-100,129-137).
+speechbrain is not part of the reference tree: the arithmetic is the published definition restated in
+``oracle/ecapa_oracle.py`` -- parity for this row is against that restatement only ("parity unpinned").
+
+Same design as the wav2vec2 engine: channels-last activations [B*T, C], a flat f32 parameter arena (+ bf16 operand
+copy) with fused Adam, static buffers and prebuilt GEMM descriptors, hand-written backward.  Dilated "same"
+convolutions are reflect-im2col + GEMM (csrc/tdnn.hip); Res2Net slices and the MFA concatenation are row-strided
+views of their parent tensors; BatchNorm uses deterministic two-stage batch statistics.
+"""
+from __future__ import annotations
+
+import dataclasses
+import math
+from collections import OrderedDict
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import ops
+from .asp import AttentivePool
+from .heads import ClassifierHead
+from .ops import EPI_ADD, EPI_BIAS, EPI_NONE, Gemm
+
+FE = "feature_extractor."          # reference attribute name of the ECAPA_TDNN module (ecapa_tdnn.py:75)
+BN_EPS, BN_MOMENTUM = 1e-5, 0.1
+ALIGN = 64
+
+
+@dataclasses.dataclass
+class EcapaConfig:
+    """ref: config/network/ecapa_tdnn.yaml:4-30 (EcapaTDNNModuleConfig)."""
+    input_mel_coefficients: int = 40
+    lin_neurons: int = 192
+    channels: Tuple[int, ...] = (1024, 1024, 1024, 1024, 3072)
+    kernel_sizes: Tuple[int, ...] = (5, 3, 3, 3, 1)
+    dilations: Tuple[int, ...] = (1, 2, 3, 4, 1)
+    attention_channels: int = 128
+    res2net_scale: int = 8
+    se_channels: int = 128
+
+    @staticmethod
+    def tiny() -> "EcapaConfig":
+        return EcapaConfig(input_mel_coefficients=16, lin_neurons=24, channels=(64, 64, 64, 64, 192),
+                           attention_channels=16, res2net_scale=4, se_channels=16)
+
+
+def ecapa_param_shapes(cfg: EcapaConfig) -> "OrderedDict[str, Tuple[int, ...]]":
+    """speechbrain state-dict names under ``feature_extractor.`` (Conv1d wrapper -> .conv, BatchNorm1d -> .norm)."""
+    s: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()
+
+    def tdnn(p, cin, cout, k):
+        s[FE + p + "conv.conv.weight"] = (cout, cin, k)
+        s[FE + p + "conv.conv.bias"] = (cout,)
+        s[FE + p + "norm.norm.weight"] = (cout,)
+        s[FE + p + "norm.norm.bias"] = (cout,)
+    C = cfg.channels
+    tdnn("blocks.0.", cfg.input_mel_coefficients, C[0], cfg.kernel_sizes[0])
+    for i in range(1, len(C) - 1):
+        p = f"blocks.{i}."
+        assert C[i - 1] == C[i], "SERes2NetBlock shortcut conv (in != out channels) is not used by the reference config"
+        tdnn(p + "tdnn1.", C[i - 1], C[i], 1)
+        w = C[i] // cfg.res2net_scale
+        for j in range(cfg.res2net_scale - 1):
+            tdnn(p + f"res2net_block.blocks.{j}.", w, w, cfg.kernel_sizes[i])
+        tdnn(p + "tdnn2.", C[i], C[i], 1)
+        s[FE + p + "se_block.conv1.conv.weight"] = (cfg.se_channels, C[i], 1)
+        s[FE + p + "se_block.conv1.conv.bias"] = (cfg.se_channels,)
+        s[FE + p + "se_block.conv2.conv.weight"] = (C[i], cfg.se_channels, 1)
+        s[FE + p + "se_block.conv2.conv.bias"] = (C[i],)
+    tdnn("mfa.", C[-1], C[-1], cfg.kernel_sizes[-1])
+    A = cfg.attention_channels
+    s[FE + "asp.tdnn.conv.conv.weight"] = (A, 3 * C[-1], 1)
+    s[FE + "asp.tdnn.conv.conv.bias"] = (A,)
+    s[FE + "asp.tdnn.norm.norm.weight"] = (A,)
+    s[FE + "asp.tdnn.norm.norm.bias"] = (A,)
+    s[FE + "asp.conv.conv.weight"] = (C[-1], A, 1)
+    s[FE + "asp.conv.conv.bias"] = (C[-1],)
+    s[FE + "asp_bn.norm.weight"] = (2 * C[-1],)
+    s[FE + "asp_bn.norm.bias"] = (2 * C[-1],)
+    s[FE + "fc.conv.weight"] = (cfg.lin_neurons, 2 * C[-1], 1)
+    s[FE + "fc.conv.bias"] = (cfg.lin_neurons,)
+    return s
+
+
+class EcapaStore:
+    """Flat parameter arena (f32 master, gradient, Adam moments, bf16 operand copy) of the ECAPA model + AAM head;
+    the subset of ParamStore's interface that AttentivePool / ClassifierHead / the plan below use."""
+
+    def __init__(self, cfg: EcapaConfig, device, act_dtype: torch.dtype = torch.bfloat16, num_speakers: int = 5994):
+        assert act_dtype in (torch.bfloat16, torch.float32)
+        self.cfg, self.device, self.act_dtype, self.num_speakers = cfg, torch.device(device), act_dtype, num_speakers
+        self.embed_dim = cfg.lin_neurons
+        shapes: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()
+        shapes["loss_fn.fc_weights"] = (num_speakers, cfg.lin_neurons)
+        shapes.update(ecapa_param_shapes(cfg))
+        self.shapes, self.offsets = shapes, {}
+        off = 0
+        for n, s in shapes.items():
+            self.offsets[n] = off
+            off += (int(np.prod(s)) + ALIGN - 1) // ALIGN * ALIGN
+        self.n_total = self.n_train = off
+        dev = self.device
+        self.flat = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.exp_avg = self.exp_avg_sq = None
+        self.flat_lp = torch.zeros(off, dtype=torch.bfloat16, device=dev) if act_dtype == torch.bfloat16 else None
+        self.asp_running = torch.cat([torch.zeros(cfg.attention_channels), torch.ones(cfg.attention_channels)]).to(dev)
+        self.version, self.step_count = 0, 0
+
+    def _view(self, buf, name):
+        s, o = self.shapes[name], self.offsets[name]
+        return buf[o:o + int(np.prod(s))].view(*s)
+
+    def p(self, name): return self._view(self.flat, name)
+    def g(self, name): return self._view(self.grad, name)
+    def w(self, name): return self._view(self.flat_lp if self.flat_lp is not None else self.flat, name)
+
+    def sync_lowp(self) -> None:
+        if self.flat_lp is not None:
+            ops.cast(self.flat, self.flat_lp)
+        self.version += 1
+
+    def zero_grad(self) -> None:
+        self.grad.zero_()
+
+    def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = True) -> None:
+        seen = set()
+        for k, v in sd.items():
+            name = k if k in self.shapes else (FE + k if FE + k in self.shapes else None)
+            if name is None:
+                if strict:
+                    raise KeyError(f"unexpected key {k}")
+                continue
+            t = torch.as_tensor(v).to(torch.float32)
+            if tuple(t.shape) != tuple(self.shapes[name]):
+                raise ValueError(f"{name}: shape {tuple(t.shape)} != {self.shapes[name]}")
+            self.p(name).copy_(t.to(self.device))
+            seen.add(name)
+        if strict and len(seen) != len(self.shapes):
+            raise KeyError(f"missing keys: {[n for n in self.shapes if n not in seen][:5]}")
+        self.sync_lowp()
+
+    def state_dict(self):
+        return OrderedDict((n, self.p(n).detach().clone().cpu()) for n in self.shapes)
+
+    def init_weights(self, seed: int = 20211) -> None:
+        g = torch.Generator(device="cpu").manual_seed(seed)
+        for n, s in self.shapes.items():
+            if n.endswith("norm.weight"):
+                t = torch.ones(s)
+            elif n.endswith("bias"):
+                t = torch.zeros(s)
+            elif n == "loss_fn.fc_weights":
+                t = torch.randn(s, generator=g) * math.sqrt(2.0 / (s[0] + s[1]))
+            else:                                    # torch Conv1d default: kaiming-uniform, bound 1/sqrt(fan_in)
+                t = (torch.rand(s, generator=g) * 2 - 1) / math.sqrt(s[1] * s[2])
+            self.p(n).copy_(t.to(self.device))
+        self.sync_lowp()
+
+    def adam_step(self, lr: float, beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8,
+                  grad_scale: float = 1.0) -> None:
+        if self.exp_avg is None:
+            self.exp_avg, self.exp_avg_sq = torch.zeros_like(self.grad), torch.zeros_like(self.grad)
+        self.step_count += 1
+        ops.adam_step(self.flat, self.grad, self.exp_avg, self.exp_avg_sq, self.flat_lp, self.n_total, lr, beta1, beta2,
+                      eps, self.step_count, grad_scale)
+        self.version += 1
+
+
+class _Tdnn:
+    """TDNNBlock = Conv1d("same", reflect, dilation) -> ReLU -> BatchNorm1d over one [M, Cin] view -> [M, Cout] view."""
+
+    def __init__(self, plan: "EcapaPlan", prefix: str, x: torch.Tensor, ldx: int, cin: int, cout: int, k: int, dil: int,
+                 y: torch.Tensor, ldy: int):
+        st, B, T, dev, adt, f32 = plan.store, plan.B, plan.T, plan.dev, plan.adt, torch.float32
+        self.plan, self.pre, self.x, self.ldx, self.y, self.ldy = plan, FE + prefix, x, ldx, y, ldy
+        self.cin, self.cout, self.k, self.dil = cin, cout, k, dil
+        M, K = B * T, k * cin
+        self.M, self.K = M, K
+        self.wp = torch.empty(cout, K, dtype=adt, device=dev)                  # packed [cout][tap][cin] operand
+        self.col = torch.empty(M, K, dtype=adt, device=dev) if k > 1 else None
+        self.a = torch.empty(M, cout, dtype=adt, device=dev)                   # pre-activation (saved)
+        self.mean_rstd = torch.empty(cout, 2, dtype=f32, device=dev)
+        self.running = torch.cat([torch.zeros(cout), torch.ones(cout)]).to(dev)
+        self.work = ops.bn_workspace(M, cout, dev)
+        A, lda = (self.col, K) if k > 1 else (x, ldx)
+        self.g_fwd = Gemm(M, cout, K, A, self.wp, self.a, lda=lda, ldb=K, ldc=cout, epilogue=EPI_BIAS,
+                          bias=st.p(self.pre + "conv.conv.bias"))
+        if plan.train:
+            self.da = torch.empty(M, cout, dtype=adt, device=dev)
+            self.dwp = torch.zeros(cout, K, dtype=f32, device=dev) if k > 1 else None
+            dW = self.dwp if k > 1 else st.g(self.pre + "conv.conv.weight").view(cout, cin)
+            self.g_dw = Gemm(cout, K, M, self.da, A, dW, lda=cout, ldb=lda, ldc=K, transA=True, transB=True,
+                             accumulate=(k == 1))
+            self.dcol = torch.empty(M, K, dtype=adt, device=dev) if k > 1 else None
+            self._dx_gemm = {}
+
+    def refresh(self) -> None:
+        ops.pack_conv_weight(self.plan.store.p(self.pre + "conv.conv.weight"), self.wp)
+
+    def forward(self) -> None:
+        st, pl = self.plan.store, self.plan
+        if self.k > 1:
+            ops.im2col_reflect(self.x, self.ldx, self.col, pl.B, pl.T, self.cin, self.k, self.dil)
+        self.g_fwd()
+        if pl.train:
+            ops.bn_stats(self.a, self.cout, self.work, self.mean_rstd, self.running, self.M, self.cout, BN_EPS,
+                         BN_MOMENTUM, True)
+        else:
+            self.mean_rstd[:, 0].copy_(self.running[:self.cout])
+            self.mean_rstd[:, 1].copy_((self.running[self.cout:] + BN_EPS).rsqrt())
+        ops.bn_apply(self.a, self.cout, self.mean_rstd, st.p(self.pre + "norm.norm.weight"),
+                     st.p(self.pre + "norm.norm.bias"), self.y, self.ldy, self.M, self.cout, True)
+
+    def backward(self, dy: torch.Tensor, lddy: int, dx: Optional[torch.Tensor], lddx: int, accumulate: bool) -> None:
+        """dy = gradient of the block output (row stride lddy); dx (None: input needs no gradient) receives or, with
+        ``accumulate``, is incremented by the input gradient.  Parameter gradients go to the arena."""
+        st, pl = self.plan.store, self.plan
+        ops.bn_bwd(dy, lddy, self.a, self.cout, self.mean_rstd, st.p(self.pre + "norm.norm.weight"), self.work,
+                   st.g(self.pre + "norm.norm.weight"), st.g(self.pre + "norm.norm.bias"), self.da, self.cout, self.M,
+                   self.cout, True)
+        ops.colsum(self.da, st.g(self.pre + "conv.conv.bias"), self.M, self.cout)
+        self.g_dw()
+        if self.k > 1:
+            ops.unpack_conv_grad(self.dwp.view(self.cout, self.k, self.cin), st.g(self.pre + "conv.conv.weight"))
+        if dx is None:
+            return
+        key = (dx.data_ptr(), lddx, accumulate)
+        if key not in self._dx_gemm:
+            if self.k > 1:
+                self._dx_gemm[key] = Gemm(self.M, self.K, self.cout, self.da, self.wp, self.dcol, lda=self.cout,
+                                          ldb=self.K, ldc=self.K, transB=True)
+            elif accumulate:
+                self._dx_gemm[key] = Gemm(self.M, self.K, self.cout, self.da, self.wp, dx, lda=self.cout, ldb=self.K,
+                                          ldc=lddx, transB=True, epilogue=EPI_ADD, aux=dx, ldaux=lddx)
+            else:
+                self._dx_gemm[key] = Gemm(self.M, self.K, self.cout, self.da, self.wp, dx, lda=self.cout, ldb=self.K,
+                                          ldc=lddx, transB=True)
+        self._dx_gemm[key]()
+        if self.k > 1:
+            ops.col2im_reflect(self.dcol, dx, lddx, pl.B, pl.T, self.cin, self.k, self.dil, accumulate)
+
+
+class _SEBlock:
+    """s = mean_t x -> relu(W1 s + b1) -> sigmoid(W2 . + b2) = gate g [B, C];  y = x * g."""
+
+    def __init__(self, plan: "EcapaPlan", prefix: str, x: torch.Tensor, y: torch.Tensor, C: int):
+        st, B, dev, f32 = plan.store, plan.B, plan.dev, torch.float32
+        S = plan.cfg.se_channels
+        self.plan, self.pre, self.x, self.y, self.C, self.S = plan, FE + prefix, x, y, C, S
+        self.s = torch.empty(B, C, dtype=f32, device=dev)
+        self.z = torch.empty(B, S, dtype=f32, device=dev)
+        self.g = torch.empty(B, C, dtype=f32, device=dev)
+        p = st.p
+        W1, W2 = p(self.pre + "conv1.conv.weight").view(S, C), p(self.pre + "conv2.conv.weight").view(C, S)
+        self.g1 = Gemm(B, S, C, self.s, W1, self.z, lda=C, ldb=C, ldc=S, epilogue=EPI_BIAS,
+                       bias=p(self.pre + "conv1.conv.bias"))
+        self.g2 = Gemm(B, C, S, self.z, W2, self.g, lda=S, ldb=S, ldc=C, epilogue=EPI_BIAS,
+                       bias=p(self.pre + "conv2.conv.bias"))
+        if plan.train:
+            g = st.g
+            self.dg = torch.empty(B, C, dtype=f32, device=dev)
+            self.dz = torch.empty(B, S, dtype=f32, device=dev)
+            self.ds = torch.empty(B, C, dtype=f32, device=dev)
+            self.g_dw2 = Gemm(C, S, B, self.dg, self.z, g(self.pre + "conv2.conv.weight").view(C, S), lda=C, ldb=S,
+                              ldc=S, transA=True, transB=True, accumulate=True)
+            self.g_dz = Gemm(B, S, C, self.dg, W2, self.dz, lda=C, ldb=S, ldc=S, transB=True)
+            self.g_dw1 = Gemm(S, C, B, self.dz, self.s, g(self.pre + "conv1.conv.weight").view(S, C), lda=S, ldb=C,
+                              ldc=C, transA=True, transB=True, accumulate=True)
+            self.g_ds = Gemm(B, C, S, self.dz, W1, self.ds, lda=S, ldb=C, ldc=C, transB=True)
+
+    def forward(self) -> None:
+        pl = self.plan
+        ops.pool_fwd(self.x.view(pl.B, pl.T, self.C), self.s, ops.POOL_MODES["mean"])
+        self.g1()
+        ops.act_fwd(self.z, self.z, 0)
+        self.g2()
+        ops.act_fwd(self.g, self.g, 1)
+        ops.se_scale(self.x, self.g, self.y, pl.B, pl.T, self.C)
+
+    def backward(self, dy: torch.Tensor, dx: torch.Tensor) -> None:
+        """dy [M, C] contiguous -> dx [M, C] contiguous (written)."""
+        pl, st = self.plan, self.plan.store
+        ops.se_bwd_gate(dy, self.x, self.dg, pl.B, pl.T, self.C)
+        ops.act_bwd(self.dg, self.g, self.dg, 1)
+        self.g_dw2()
+        ops.colsum(self.dg, st.g(self.pre + "conv2.conv.bias"), pl.B, self.C)
+        self.g_dz()
+        ops.act_bwd(self.dz, self.z, self.dz, 0)
+        self.g_dw1()
+        ops.colsum(self.dz, st.g(self.pre + "conv1.conv.bias"), pl.B, self.S)
+        self.g_ds()
+        ops.se_bwd_x(dy, self.g, self.ds, dx, pl.B, pl.T, self.C)
+
+
+class _SERes2Net:
+    """tdnn1 (1x1) -> Res2Net (cumulative dilated k=3 TDNNs on channel slices) -> tdnn2 (1x1) -> SE -> + input."""
+
+    def __init__(self, plan: "EcapaPlan", idx: int, x: torch.Tensor, ldx: int, out: torch.Tensor, ldo: int):
+        cfg, B, T, dev, adt = plan.cfg, plan.B, plan.T, plan.dev, plan.adt
+        C, sc = cfg.channels[idx], cfg.res2net_scale
+        w, M = C // sc, B * T
+        p = f"blocks.{idx}."
+        self.plan, self.C, self.w, self.sc, self.x, self.ldx, self.out, self.ldo, self.M = plan, C, w, sc, x, ldx, out, ldo, M
+        e = lambda c: torch.empty(M, c, dtype=adt, device=dev)
+        self.t1, self.r2, self.t2, self.se_out = e(C), e(C), e(C), e(C)
+        self.tdnn1 = _Tdnn(plan, p + "tdnn1.", x, ldx, C, C, 1, 1, self.t1, C)
+        self.sums = [None, None] + [e(w) for _ in range(2, sc)]                  # x_i + y_{i-1}, i >= 2
+        self.chunks: List[Optional[_Tdnn]] = [None]
+        for i in range(1, sc):
+            src, ld = (self.t1[:, w:2 * w], C) if i == 1 else (self.sums[i], w)
+            self.chunks.append(_Tdnn(plan, p + f"res2net_block.blocks.{i - 1}.", src, ld, w, w,
+                                     cfg.kernel_sizes[idx], cfg.dilations[idx], self.r2[:, i * w:(i + 1) * w], C))
+        self.tdnn2 = _Tdnn(plan, p + "tdnn2.", self.r2, C, C, C, 1, 1, self.t2, C)
+        self.se = _SEBlock(plan, p + "se_block.", self.t2, self.se_out, C)
+        if plan.train:
+            self.d_se, self.d_t2, self.d_r2, self.d_t1 = e(C), e(C), e(C), e(C)
+            self.gtmp = e(w)
+
+    def blocks(self):
+        return [self.tdnn1] + [c for c in self.chunks if c is not None] + [self.tdnn2]
+
+    def forward(self) -> None:
+        w, C, M = self.w, self.C, self.M
+        self.tdnn1.forward()
+        self.r2[:, :w].copy_(self.t1[:, :w])                                     # chunk 0 passes through
+        for i in range(1, self.sc):
+            if i >= 2:
+                ops.add_strided(self.t1[:, i * w:], C, self.r2[:, (i - 1) * w:], C, self.sums[i], w, M, w)
+            self.chunks[i].forward()
+        self.tdnn2.forward()
+        self.se.forward()
+        ops.add_strided(self.se_out, C, self.x, self.ldx, self.out, self.ldo, M, C)
+
+    def backward(self, dout: torch.Tensor, lddo: int, dx: torch.Tensor, lddx: int, accumulate: bool) -> None:
+        """dout = gradient of the block output (view, row stride lddo); dx (+)= gradient of the block input."""
+        w, C, M, sc = self.w, self.C, self.M, self.sc
+        # residual branch: d(input) gets dout; SE branch: dout -> d_t2
+        self.d_se.copy_(dout[:, :C])
+        self.se.backward(self.d_se, self.d_t2)
+        self.tdnn2.backward(self.d_t2, C, self.d_r2, C, False)
+        # Res2Net, last slice first: the gradient of (x_i + y_{i-1}) lands in d_t1[:, i] and is carried to y_{i-1}
+        for i in range(sc - 1, 0, -1):
+            if i < sc - 1:
+                ops.add_strided(self.d_r2[:, i * w:], C, self.d_t1[:, (i + 1) * w:], C, self.gtmp, w, M, w)
+                dy, ld = self.gtmp, w
+            else:
+                dy, ld = self.d_r2[:, i * w:], C
+            self.chunks[i].backward(dy, ld, self.d_t1[:, i * w:(i + 1) * w], C, False)
+        self.d_t1[:, :w].copy_(self.d_r2[:, :w])
+        self.tdnn1.backward(self.d_t1, C, dx, lddx, accumulate)
+        # residual: dx += dout
+        ops.add_strided(dx, lddx, dout, lddo, dx, lddx, M, C)
+
+
+class EcapaPlan:
+    """Static plan of one ECAPA-TDNN forward (+ backward) for a fixed [B, T, n_mels] input."""
+
+    def __init__(self, store: EcapaStore, batch: int, frames: int, *, train: bool, aam_margin: float = 0.2,
+                 aam_scale: float = 30.0):
+        cfg = store.cfg
+        self.store, self.cfg, self.B, self.T, self.train = store, cfg, batch, frames, train
+        self.dev, self.adt = store.device, store.act_dtype
+        B, T, M, dev, adt, f32 = batch, frames, batch * frames, self.dev, self.adt, torch.float32
+        C = cfg.channels
+        nb = len(C) - 2                                                       # SE-Res2Net blocks
+        assert all(c == C[1] for c in C[1:-1]) and C[-1] == nb * C[1], "MFA concatenates the SE-Res2Net outputs"
+        F_ = cfg.input_mel_coefficients
+        self.feat = torch.zeros(M, F_, dtype=adt, device=dev)
+        self.x0 = torch.empty(M, C[0], dtype=adt, device=dev)
+        self.cat = torch.empty(M, C[-1], dtype=adt, device=dev)               # MFA input: block outputs side by side
+        self.block0 = _Tdnn(self, "blocks.0.", self.feat, F_, F_, C[0], cfg.kernel_sizes[0], cfg.dilations[0],
+                            self.x0, C[0])
+        self.blocks: List[_SERes2Net] = []
+        for i in range(1, nb + 1):
+            x, ldx = (self.x0, C[0]) if i == 1 else (self.cat[:, (i - 2) * C[1]:], C[-1])
+            self.blocks.append(_SERes2Net(self, i, x, ldx, self.cat[:, (i - 1) * C[1]:], C[-1]))
+        rows = (M + 63) // 64 * 64
+        full = torch.zeros(rows, C[-1], dtype=adt, device=dev)
+        self.mfa_out = full[:M]
+        self.mfa_out._w2v2_padded = full
+        self.mfa = _Tdnn(self, "mfa.", self.cat, C[-1], C[-1], C[-1], cfg.kernel_sizes[-1], cfg.dilations[-1],
+                         self.mfa_out, C[-1])
+        self.pooled = torch.empty(B, 2 * C[-1], dtype=f32, device=dev)
+        self.d_mfa = torch.zeros(rows, C[-1], dtype=adt, device=dev)[:M] if train else None
+        self.asp = AttentivePool(store, self.mfa_out, self.pooled, self.d_mfa, B, T, train, prefix=FE + "asp.")
+        E2, L = 2 * C[-1], cfg.lin_neurons
+        self.bn_mr = torch.empty(E2, 2, dtype=f32, device=dev)
+        self.bn_running = torch.cat([torch.zeros(E2), torch.ones(E2)]).to(dev)
+        self.bn_work = ops.bn_workspace(B, E2, dev)
+        self.e2 = torch.empty(B, E2, dtype=f32, device=dev)
+        self.emb = torch.empty(B, L, dtype=f32, device=dev)
+        p, g = store.p, store.g
+        Wfc = p(FE + "fc.conv.weight").view(L, E2)
+        self.g_fc = Gemm(B, L, E2, self.e2, Wfc, self.emb, lda=E2, ldb=E2, ldc=L, epilogue=EPI_BIAS,
+                         bias=p(FE + "fc.conv.bias"))
+        self.head = ClassifierHead("aam", B, L, store.num_speakers, w_master=p("loss_fn.fc_weights"),
+                                   w_operand=store.w("loss_fn.fc_weights"),
+                                   w_grad=g("loss_fn.fc_weights") if train else None, emb=self.emb, act_dtype=adt,
+                                   train=train, margin=aam_margin, scale=aam_scale)
+        if train:
+            self.de2 = torch.empty(B, E2, dtype=f32, device=dev)
+            self.dpooled = torch.empty(B, E2, dtype=f32, device=dev)
+            self.g_dwfc = Gemm(L, E2, B, self.head.demb, self.e2, g(FE + "fc.conv.weight").view(L, E2), lda=L, ldb=E2,
+                               ldc=E2, transA=True, transB=True, accumulate=True)
+            self.g_de2 = Gemm(B, E2, L, self.head.demb, Wfc, self.de2, lda=L, ldb=E2, ldc=E2, transB=True)
+            self.d_cat = torch.empty(M, C[-1], dtype=adt, device=dev)
+            self.d_x0 = torch.empty(M, C[0], dtype=adt, device=dev)
+        self._version = -1
+
+    def _tdnns(self) -> List[_Tdnn]:
+        out = [self.block0]
+        for b in self.blocks:
+            out += b.blocks()
+        return out + [self.mfa]
+
+    def _refresh(self) -> None:
+        if self._version != self.store.version:
+            for t in self._tdnns():
+                t.refresh()
+            self._version = self.store.version
+
+    def embed(self, feat: torch.Tensor) -> torch.Tensor:
+        """ref: ecapa_tdnn.py:110-118 (compute_speaker_embedding): feat [B, T, n_mels] -> [B, lin_neurons] f32."""
+        st, B, T = self.store, self.B, self.T
+        assert feat.shape == (B, T, self.cfg.input_mel_coefficients) and feat.is_cuda
+        self._refresh()
+        self.feat.copy_(feat.reshape(B * T, -1))
+        self.block0.forward()
+        for b in self.blocks:
+            b.forward()
+        self.mfa.forward()
+        self.asp.forward()
+        E2 = self.pooled.shape[1]
+        if self.train:
+            ops.bn_stats(self.pooled, E2, self.bn_work, self.bn_mr, self.bn_running, B, E2, BN_EPS, BN_MOMENTUM, False)
+        else:
+            self.bn_mr[:, 0].copy_(self.bn_running[:E2])
+            self.bn_mr[:, 1].copy_((self.bn_running[E2:] + BN_EPS).rsqrt())
+        ops.bn_apply(self.pooled, E2, self.bn_mr, st.p(FE + "asp_bn.norm.weight"), st.p(FE + "asp_bn.norm.bias"),
+                     self.e2, E2, B, E2, False)
+        self.g_fc()
+        return self.emb
+
+    def head_forward_backward(self, label: torch.Tensor):
+        return self.head.forward_backward(label)
+
+    def backward(self) -> None:
+        """Backward of embed() from the head's d(loss)/d(emb): every parameter gradient into store.grad."""
+        assert self.train
+        st, B = self.store, self.B
+        C = self.cfg.channels
+        E2, L = self.pooled.shape[1], self.cfg.lin_neurons
+        self.g_dwfc()
+        ops.colsum(self.head.demb, st.g(FE + "fc.conv.bias"), B, L)
+        self.g_de2()
+        ops.bn_bwd(self.de2, E2, self.pooled, E2, self.bn_mr, st.p(FE + "asp_bn.norm.weight"), self.bn_work,
+                   st.g(FE + "asp_bn.norm.weight"), st.g(FE + "asp_bn.norm.bias"), self.dpooled, E2, B, E2, False)
+        self.asp.backward(self.dpooled)                                          # -> d_mfa (written)
+        self.mfa.backward(self.d_mfa, C[-1], self.d_cat, C[-1], False)
+        nb = len(self.blocks)
+        for i in range(nb, 0, -1):                                                # block i reads block i-1's output
+            blk = self.blocks[i - 1]
+            dout = self.d_cat[:, (i - 1) * C[1]:]
+            if i == 1:
+                blk.backward(dout, C[-1], self.d_x0, C[0], False)
+            else:
+                blk.backward(dout, C[-1], self.d_cat[:, (i - 2) * C[1]:], C[-1], True)
+        self.block0.backward(self.d_x0, C[0], None, 0, False)
+
+
+class EcapaTrainer:
+    """One training step: forward, AAM head, backward, fused Adam (ref: speaker_recognition_module.py:207-220)."""
+
+    def __init__(self, store: EcapaStore, plan: EcapaPlan, schedule):
+        self.store, self.plan, self.schedule, self.step = store, plan, schedule, 0
+
+    def train_step(self, feat: torch.Tensor, label: torch.Tensor):
+        self.store.zero_grad()
+        self.plan.embed(feat)
+        loss, softmax = self.plan.head_forward_backward(label)
+        self.plan.backward()
+        lr, beta1 = self.schedule.at(self.step)
+        self.store.adam_step(lr, beta1)
+        self.step += 1
+        return loss, softmax

@@ -470,3 +470,73 @@ def asp_context_bwd(x, ctx, da, w1, dw1, dx, scratch, B: int, T: int, C: int, A:
     _lib.check(lib().w2v2_asp_context_bwd(x.data_ptr(), ctx.data_ptr(), da.data_ptr(), w1.data_ptr(), dw1.data_ptr(),
                                           dx.data_ptr(), scratch.data_ptr(), B, T, C, A, dt(x), stream()),
                "asp_context_bwd")
+
+
+# ------------------------------------------------------------------------------------------------ ECAPA-TDNN pieces
+def bn_workspace(M: int, C: int, device) -> torch.Tensor:
+    return torch.empty(lib().w2v2_bn_workspace_floats(M, C), dtype=torch.float32, device=device)
+
+
+def bn_stats(a, lda: int, work, mean_rstd, running, M: int, C: int, eps: float, momentum: float, relu: bool) -> None:
+    _dev(a, work, mean_rstd, running)
+    _lib.check(lib().w2v2_bn_stats(a.data_ptr(), lda, work.data_ptr(), mean_rstd.data_ptr(), _p(running), M, C, eps,
+                                   momentum, int(relu), dt(a), stream()), "bn_stats")
+
+
+def bn_apply(a, lda: int, mean_rstd, gamma, beta, y, ldy: int, M: int, C: int, relu: bool) -> None:
+    _dev(a, mean_rstd, gamma, beta, y)
+    _lib.check(lib().w2v2_bn_apply(a.data_ptr(), lda, mean_rstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                   y.data_ptr(), ldy, M, C, int(relu), dt(a), stream()), "bn_apply")
+
+
+def bn_bwd(dy, lddy: int, a, lda: int, mean_rstd, gamma, work, dgamma, dbeta, da, ldda: int, M: int, C: int,
+           relu: bool) -> None:
+    _dev(dy, a, mean_rstd, gamma, work, dgamma, dbeta, da)
+    _lib.check(lib().w2v2_bn_bwd(dy.data_ptr(), lddy, a.data_ptr(), lda, mean_rstd.data_ptr(), gamma.data_ptr(),
+                                 work.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), da.data_ptr(), ldda, M, C,
+                                 int(relu), dt(a), stream()), "bn_bwd")
+
+
+def im2col_reflect(x, ldx: int, col, B: int, T: int, Cin: int, k: int, dilation: int) -> None:
+    _dev(x, col)
+    _lib.check(lib().w2v2_im2col_reflect(x.data_ptr(), ldx, col.data_ptr(), B, T, Cin, k, dilation, dt(x), stream()),
+               "im2col_reflect")
+
+
+def col2im_reflect(dcol, dx, lddx: int, B: int, T: int, Cin: int, k: int, dilation: int, accumulate: bool) -> None:
+    _dev(dcol, dx)
+    _lib.check(lib().w2v2_col2im_reflect(dcol.data_ptr(), dx.data_ptr(), lddx, B, T, Cin, k, dilation,
+                                         int(accumulate), dt(dcol), stream()), "col2im_reflect")
+
+
+def add_strided(a, lda: int, b, ldb: int, y, ldy: int, M: int, C: int) -> None:
+    _dev(a, b, y)
+    _lib.check(lib().w2v2_add_strided(a.data_ptr(), lda, b.data_ptr(), ldb, y.data_ptr(), ldy, M, C, dt(a), stream()),
+               "add_strided")
+
+
+def se_scale(x, g, y, B: int, T: int, C: int) -> None:
+    _dev(x, g, y)
+    _lib.check(lib().w2v2_se_scale(x.data_ptr(), g.data_ptr(), y.data_ptr(), B, T, C, dt(x), stream()), "se_scale")
+
+
+def se_bwd_gate(dout, x, dg, B: int, T: int, C: int) -> None:
+    _dev(dout, x, dg)
+    _lib.check(lib().w2v2_se_bwd_gate(dout.data_ptr(), x.data_ptr(), dg.data_ptr(), B, T, C, dt(x), stream()),
+               "se_bwd_gate")
+
+
+def se_bwd_x(dout, g, ds, dx, B: int, T: int, C: int) -> None:
+    _dev(dout, g, ds, dx)
+    _lib.check(lib().w2v2_se_bwd_x(dout.data_ptr(), g.data_ptr(), ds.data_ptr(), dx.data_ptr(), B, T, C, dt(dout),
+                                   stream()), "se_bwd_x")
+
+
+def act_fwd(x, y, mode: int) -> None:
+    _dev(x, y)
+    _lib.check(lib().w2v2_act_fwd(x.data_ptr(), y.data_ptr(), x.numel(), mode, stream()), "act_fwd")
+
+
+def act_bwd(dy, y, dx, mode: int) -> None:
+    _dev(dy, y, dx)
+    _lib.check(lib().w2v2_act_bwd(dy.data_ptr(), y.data_ptr(), dx.data_ptr(), dy.numel(), mode, stream()), "act_bwd")
