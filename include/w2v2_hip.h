@@ -91,7 +91,7 @@ int w2v2_gemm(const w2v2_gemm_desc* d, void* stream);
 
 /* Grouped weight-gradient GEMM (the backward of HF:520-526,544,565-572 nn.Linear weights/biases):
  *   dW_p[o][i] = sum_t dY_p[t][o] * X_p[t][i]      dbias_p[o] = sum_t dY_p[t][o]   (dbias may be NULL)
- * for 1..8 (dY, X) pairs in ONE launch, bf16 operands [tokens][features] (K-major), f32 results
+ * for 1..12 (dY, X) pairs in ONE launch, bf16 operands [tokens][features] (K-major), f32 results
  * WRITTEN (not accumulated), no split-K, no atomics -> bitwise reproducible.
  * Contract: rows [tokens, tokens_padded) of every dY / X are readable and zero
  * (tokens_padded = tokens rounded up to 64); n_out, n_in multiples of 8; 16-byte aligned rows. */

@@ -1,5 +1,5 @@
 // wgrad.hip -- grouped weight-gradient GEMM:  dW_p[o][i] = sum_t dY_p[t][o] * X_p[t][i]   (+ dbias_p[o] = sum_t dY_p[t][o])
-// for up to 8 (dY, X) pairs in ONE launch (the four Linear layers of a transformer block: QKV, out-proj,
+// for up to 12 (dY, X) pairs in ONE launch (the four Linear layers of a transformer block: QKV, out-proj,
 // FFN1, FFN2 -> 432 full 128x128 tiles at w2v2-base, enough to fill 256 CUs without split-K, so there
 // are no atomics and the gradients are bitwise reproducible).
 //
@@ -24,7 +24,7 @@ typedef __attribute__((address_space(1))) const void gvoid_t;
 typedef __attribute__((address_space(3))) void lvoid_t;
 typedef __attribute__((address_space(3))) short4v lds_s4_t;
 
-constexpr int WG_MAXP = 8;
+constexpr int WG_MAXP = 12;
 
 struct WgProblem {
   const bf16_t* dY;

@@ -173,6 +173,14 @@ class EcapaStore:
         self.version += 1
 
 
+def _cols(v: torch.Tensor, c0: int, c1: Optional[int] = None) -> torch.Tensor:
+    """Column slice of a row-padded activation buffer that keeps its zero-padded parent (``_full``)."""
+    out = v[:, c0:c1]
+    if hasattr(v, "_full"):
+        out._full = v._full[:, c0:c1]
+    return out
+
+
 class _Tdnn:
     """TDNNBlock = Conv1d("same", reflect, dilation) -> ReLU -> BatchNorm1d over one [M, Cin] view -> [M, Cout] view."""
 
@@ -184,7 +192,7 @@ class _Tdnn:
         M, K = B * T, k * cin
         self.M, self.K = M, K
         self.wp = torch.empty(cout, K, dtype=adt, device=dev)                  # packed [cout][tap][cin] operand
-        self.col = torch.empty(M, K, dtype=adt, device=dev) if k > 1 else None
+        self.col = plan.buf(M, K) if k > 1 else None
         self.a = torch.empty(M, cout, dtype=adt, device=dev)                   # pre-activation (saved)
         self.mean_rstd = torch.empty(cout, 2, dtype=f32, device=dev)
         self.running = torch.cat([torch.zeros(cout), torch.ones(cout)]).to(dev)
@@ -193,9 +201,14 @@ class _Tdnn:
         self.g_fwd = Gemm(M, cout, K, A, self.wp, self.a, lda=lda, ldb=K, ldc=cout, epilogue=EPI_BIAS,
                           bias=st.p(self.pre + "conv.conv.bias"))
         if plan.train:
-            self.da = torch.empty(M, cout, dtype=adt, device=dev)
+            self.da = plan.buf(M, cout)
             self.dwp = torch.zeros(cout, K, dtype=f32, device=dev) if k > 1 else None
             dW = self.dwp if k > 1 else st.g(self.pre + "conv.conv.weight").view(cout, cin)
+            # bf16: weight + bias gradient through the grouped, atomic-free wgrad kernels (K-major operands: da and the
+            # conv input / im2col buffer, both zero-padded to a multiple of 64 rows), launched per group by the owner
+            self.grouped = adt == torch.bfloat16 and hasattr(A, "_full")
+            if self.grouped:
+                self.wg_problem = (self.da._full, A._full, dW, st.g(self.pre + "conv.conv.bias"))
             self.g_dw = Gemm(cout, K, M, self.da, A, dW, lda=cout, ldb=lda, ldc=K, transA=True, transB=True,
                              accumulate=(k == 1))
             self.dcol = torch.empty(M, K, dtype=adt, device=dev) if k > 1 else None
@@ -218,17 +231,34 @@ class _Tdnn:
         ops.bn_apply(self.a, self.cout, self.mean_rstd, st.p(self.pre + "norm.norm.weight"),
                      st.p(self.pre + "norm.norm.bias"), self.y, self.ldy, self.M, self.cout, True)
 
-    def backward(self, dy: torch.Tensor, lddy: int, dx: Optional[torch.Tensor], lddx: int, accumulate: bool) -> None:
+    def weight_grad_single(self) -> None:
+        """dW, db of this block alone (f32 mode, or a block that is not part of a deferred group)."""
+        st = self.plan.store
+        if self.grouped:
+            if not hasattr(self, "_wg"):
+                self._wg = ops.WgradGroup([self.wg_problem], self.M, self.da._full.shape[0])
+            self._wg()
+        else:
+            ops.colsum(self.da, st.g(self.pre + "conv.conv.bias"), self.M, self.cout)
+            self.g_dw()
+        self.finish_weight_grad()
+
+    def finish_weight_grad(self) -> None:
+        if self.k > 1:       # packed [cout][tap][cin] gradient -> torch layout [cout][cin][tap] (added into the arena)
+            ops.unpack_conv_grad(self.dwp.view(self.cout, self.k, self.cin),
+                                 self.plan.store.g(self.pre + "conv.conv.weight"))
+
+    def backward(self, dy: torch.Tensor, lddy: int, dx: Optional[torch.Tensor], lddx: int, accumulate: bool,
+                 defer_dw: bool = False) -> None:
         """dy = gradient of the block output (row stride lddy); dx (None: input needs no gradient) receives or, with
-        ``accumulate``, is incremented by the input gradient.  Parameter gradients go to the arena."""
+        ``accumulate``, is incremented by the input gradient.  Parameter gradients go to the arena; with ``defer_dw``
+        (bf16) the owner launches the weight gradients of several blocks in one grouped call afterwards."""
         st, pl = self.plan.store, self.plan
         ops.bn_bwd(dy, lddy, self.a, self.cout, self.mean_rstd, st.p(self.pre + "norm.norm.weight"), self.work,
                    st.g(self.pre + "norm.norm.weight"), st.g(self.pre + "norm.norm.bias"), self.da, self.cout, self.M,
                    self.cout, True)
-        ops.colsum(self.da, st.g(self.pre + "conv.conv.bias"), self.M, self.cout)
-        self.g_dw()
-        if self.k > 1:
-            ops.unpack_conv_grad(self.dwp.view(self.cout, self.k, self.cin), st.g(self.pre + "conv.conv.weight"))
+        if not (self.grouped and defer_dw):
+            self.weight_grad_single()
         if dx is None:
             return
         key = (dx.data_ptr(), lddx, accumulate)
@@ -308,13 +338,13 @@ class _SERes2Net:
         w, M = C // sc, B * T
         p = f"blocks.{idx}."
         self.plan, self.C, self.w, self.sc, self.x, self.ldx, self.out, self.ldo, self.M = plan, C, w, sc, x, ldx, out, ldo, M
-        e = lambda c: torch.empty(M, c, dtype=adt, device=dev)
+        e = lambda c: plan.buf(M, c)
         self.t1, self.r2, self.t2, self.se_out = e(C), e(C), e(C), e(C)
         self.tdnn1 = _Tdnn(plan, p + "tdnn1.", x, ldx, C, C, 1, 1, self.t1, C)
         self.sums = [None, None] + [e(w) for _ in range(2, sc)]                  # x_i + y_{i-1}, i >= 2
         self.chunks: List[Optional[_Tdnn]] = [None]
         for i in range(1, sc):
-            src, ld = (self.t1[:, w:2 * w], C) if i == 1 else (self.sums[i], w)
+            src, ld = (_cols(self.t1, w, 2 * w), C) if i == 1 else (self.sums[i], w)
             self.chunks.append(_Tdnn(plan, p + f"res2net_block.blocks.{i - 1}.", src, ld, w, w,
                                      cfg.kernel_sizes[idx], cfg.dilations[idx], self.r2[:, i * w:(i + 1) * w], C))
         self.tdnn2 = _Tdnn(plan, p + "tdnn2.", self.r2, C, C, C, 1, 1, self.t2, C)
@@ -344,7 +374,7 @@ class _SERes2Net:
         # residual branch: d(input) gets dout; SE branch: dout -> d_t2
         self.d_se.copy_(dout[:, :C])
         self.se.backward(self.d_se, self.d_t2)
-        self.tdnn2.backward(self.d_t2, C, self.d_r2, C, False)
+        self.tdnn2.backward(self.d_t2, C, self.d_r2, C, False, defer_dw=True)
         # Res2Net, last slice first: the gradient of (x_i + y_{i-1}) lands in d_t1[:, i] and is carried to y_{i-1}
         for i in range(sc - 1, 0, -1):
             if i < sc - 1:
@@ -352,11 +382,23 @@ class _SERes2Net:
                 dy, ld = self.gtmp, w
             else:
                 dy, ld = self.d_r2[:, i * w:], C
-            self.chunks[i].backward(dy, ld, self.d_t1[:, i * w:(i + 1) * w], C, False)
+            self.chunks[i].backward(dy, ld, self.d_t1[:, i * w:(i + 1) * w], C, False, defer_dw=True)
         self.d_t1[:, :w].copy_(self.d_r2[:, :w])
-        self.tdnn1.backward(self.d_t1, C, dx, lddx, accumulate)
+        self.tdnn1.backward(self.d_t1, C, dx, lddx, accumulate, defer_dw=True)
         # residual: dx += dout
         ops.add_strided(dx, lddx, dout, lddo, dx, lddx, M, C)
+        # every da / input of the block is final now: all its weight gradients (tdnn1, tdnn2, the Res2Net TDNNs) in
+        # grouped launches (the chain above is sequential, these products are not)
+        tds = self.blocks()
+        if tds[0].grouped:
+            if not hasattr(self, "_wgs"):
+                probs = [t.wg_problem for t in tds]
+                self._wgs = [ops.WgradGroup(probs[i:i + 12], M, self.tdnn1.da._full.shape[0])
+                             for i in range(0, len(probs), 12)]
+            for wg in self._wgs:
+                wg()
+            for t in tds:
+                t.finish_weight_grad()
 
 
 class EcapaPlan:
@@ -372,19 +414,18 @@ class EcapaPlan:
         nb = len(C) - 2                                                       # SE-Res2Net blocks
         assert all(c == C[1] for c in C[1:-1]) and C[-1] == nb * C[1], "MFA concatenates the SE-Res2Net outputs"
         F_ = cfg.input_mel_coefficients
-        self.feat = torch.zeros(M, F_, dtype=adt, device=dev)
-        self.x0 = torch.empty(M, C[0], dtype=adt, device=dev)
-        self.cat = torch.empty(M, C[-1], dtype=adt, device=dev)               # MFA input: block outputs side by side
+        self.feat = self.buf(M, F_)
+        self.x0 = self.buf(M, C[0])
+        self.cat = self.buf(M, C[-1])                                         # MFA input: block outputs side by side
         self.block0 = _Tdnn(self, "blocks.0.", self.feat, F_, F_, C[0], cfg.kernel_sizes[0], cfg.dilations[0],
                             self.x0, C[0])
         self.blocks: List[_SERes2Net] = []
         for i in range(1, nb + 1):
-            x, ldx = (self.x0, C[0]) if i == 1 else (self.cat[:, (i - 2) * C[1]:], C[-1])
+            x, ldx = (self.x0, C[0]) if i == 1 else (_cols(self.cat, (i - 2) * C[1], (i - 1) * C[1]), C[-1])
             self.blocks.append(_SERes2Net(self, i, x, ldx, self.cat[:, (i - 1) * C[1]:], C[-1]))
         rows = (M + 63) // 64 * 64
-        full = torch.zeros(rows, C[-1], dtype=adt, device=dev)
-        self.mfa_out = full[:M]
-        self.mfa_out._w2v2_padded = full
+        self.mfa_out = self.buf(M, C[-1])
+        self.mfa_out._w2v2_padded = self.mfa_out._full
         self.mfa = _Tdnn(self, "mfa.", self.cat, C[-1], C[-1], C[-1], cfg.kernel_sizes[-1], cfg.dilations[-1],
                          self.mfa_out, C[-1])
         self.pooled = torch.empty(B, 2 * C[-1], dtype=f32, device=dev)
@@ -413,6 +454,14 @@ class EcapaPlan:
             self.d_cat = torch.empty(M, C[-1], dtype=adt, device=dev)
             self.d_x0 = torch.empty(M, C[0], dtype=adt, device=dev)
         self._version = -1
+
+    def buf(self, rows: int, cols: int) -> torch.Tensor:
+        """[rows, cols] activation whose storage is zero-padded to a multiple of 64 rows (``_full``): legal K-major
+        operand of the grouped weight-gradient kernels (csrc/wgrad.hip contract)."""
+        full = torch.zeros((rows + 63) // 64 * 64, cols, dtype=self.adt, device=self.dev)
+        v = full[:rows]
+        v._full = full
+        return v
 
     def _tdnns(self) -> List[_Tdnn]:
         out = [self.block0]
