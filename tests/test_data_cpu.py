@@ -74,3 +74,24 @@ def test_shard_dataset_end_to_end_and_feeder_on_cpu(tmp_path):
     b0 = batches[0]
     assert b0.network_input.shape == (6, 1, 48000) and b0.ground_truth.shape == (6,)
     assert abs(float(b0.network_input.mean())) < 0.05          # chunk of a normalised utterance
+
+
+def test_fbank_shapes_and_tone_localisation():
+    """x-vector / ECAPA front-end (config/data/pipeline/xvector_pipeline.yaml): 3 s -> [301, 40] log-mel frames; a pure
+    tone lights up the filter whose centre is closest; then channel-wise normalisation as in the pipeline."""
+    import math
+    from w2v2_speaker_amd.data import Fbank, FilterBank, InputNormalizer2D
+    fb = Fbank(40)
+    t = torch.arange(48000) / 16000.0
+    for f in (300.0, 1000.0, 3000.0):
+        feat = fb(torch.sin(2 * math.pi * f * t)[None])
+        assert feat.shape == (301, 40) and torch.isfinite(feat).all()
+        mel = 2595.0 * math.log10(1 + f / 700.0)
+        centres = torch.linspace(0, 2595.0 * math.log10(1 + 8000 / 700.0), 42)[1:-1]
+        assert abs(int(feat[50:250].mean(0).argmax()) - int((centres - mel).abs().argmin())) <= 1
+        assert float(feat.max() - feat.min()) <= 80.0 + 1e-3
+    s = SpeakerClassificationDataSample("k", 0, 0.1 * torch.randn(1, 48000))
+    s = FilterBank(40).process(s)
+    s = InputNormalizer2D(normalize_over_channels=True).process(s)
+    assert s.network_input.shape == (301, 40) and float(s.network_input.mean(0).abs().max()) < 1e-4
+

@@ -5,7 +5,8 @@ from .pipeline import (AudioChunkSelector, BatchProcessor, InputNormalizer2D, Sp
                        default_collate_fn)
 from .shards import find_shards, iter_shard, read_meta, write_shards
 from .loader import DeviceFeeder, ShardDataset
+from .fbank import Fbank, FilterBank
 
 __all__ = ["AudioChunkSelector", "BatchProcessor", "InputNormalizer2D", "SpeakerClassificationDataSample",
            "default_collate_fn", "find_shards", "iter_shard", "read_meta", "write_shards", "DeviceFeeder",
-           "ShardDataset"]
+           "ShardDataset", "Fbank", "FilterBank"]

@@ -212,10 +212,15 @@ class _Tdnn:
             self.g_dw = Gemm(cout, K, M, self.da, A, dW, lda=cout, ldb=lda, ldc=K, transA=True, transB=True,
                              accumulate=(k == 1))
             self.dcol = torch.empty(M, K, dtype=adt, device=dev) if k > 1 else None
+            # bf16: the data-gradient product reads the packed weight TRANSPOSED ([K][cout], refreshed with the pack)
+            # so that it is an NT product on the LDS-DMA ring kernels instead of a K-major-B one on the generic kernel
+            self.wpt = torch.empty(K, cout, dtype=adt, device=dev) if adt == torch.bfloat16 else None
             self._dx_gemm = {}
 
     def refresh(self) -> None:
         ops.pack_conv_weight(self.plan.store.p(self.pre + "conv.conv.weight"), self.wp)
+        if self.plan.train and self.wpt is not None:
+            self.wpt.copy_(self.wp.t())            # layout change only (buffer plumbing), no arithmetic
 
     def forward(self) -> None:
         st, pl = self.plan.store, self.plan
@@ -263,15 +268,16 @@ class _Tdnn:
             return
         key = (dx.data_ptr(), lddx, accumulate)
         if key not in self._dx_gemm:
+            W, ldb, tb = (self.wpt, self.cout, False) if self.wpt is not None else (self.wp, self.K, True)
             if self.k > 1:
-                self._dx_gemm[key] = Gemm(self.M, self.K, self.cout, self.da, self.wp, self.dcol, lda=self.cout,
-                                          ldb=self.K, ldc=self.K, transB=True)
+                self._dx_gemm[key] = Gemm(self.M, self.K, self.cout, self.da, W, self.dcol, lda=self.cout, ldb=ldb,
+                                          ldc=self.K, transB=tb)
             elif accumulate:
-                self._dx_gemm[key] = Gemm(self.M, self.K, self.cout, self.da, self.wp, dx, lda=self.cout, ldb=self.K,
-                                          ldc=lddx, transB=True, epilogue=EPI_ADD, aux=dx, ldaux=lddx)
+                self._dx_gemm[key] = Gemm(self.M, self.K, self.cout, self.da, W, dx, lda=self.cout, ldb=ldb,
+                                          ldc=lddx, transB=tb, epilogue=EPI_ADD, aux=dx, ldaux=lddx)
             else:
-                self._dx_gemm[key] = Gemm(self.M, self.K, self.cout, self.da, self.wp, dx, lda=self.cout, ldb=self.K,
-                                          ldc=lddx, transB=True)
+                self._dx_gemm[key] = Gemm(self.M, self.K, self.cout, self.da, W, dx, lda=self.cout, ldb=ldb,
+                                          ldc=lddx, transB=tb)
         self._dx_gemm[key]()
         if self.k > 1:
             ops.col2im_reflect(self.dcol, dx, lddx, pl.B, pl.T, self.cin, self.k, self.dil, accumulate)
