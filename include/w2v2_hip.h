@@ -262,6 +262,13 @@ int w2v2_asp_pool_bwd(const void* x, const void* s, const float* out, const floa
 int w2v2_asp_context_bwd(const void* x, const float* ctx, const void* da, const float* w1, float* dw1, void* dx,
                          float* scratch, int B, int T, int C, int A, int dtype, void* stream);
 
+/* Paired-input head (ref: src/lightning_modules/speaker/wav2vec2_paired_input.py:200-206 nn.Linear(H,1) on the CLS
+ * token + src/optim/loss/binary_cross_entropy.py:24-40): prob = sigmoid(emb.w + b), loss_rows = BCE-with-logits per
+ * pair (mean taken by the caller); gradient outputs (all or none): dlogit[B] = (p-y)/B, demb[B][H], dw[H], db[1]. */
+int w2v2_bce_head_fwd_bwd(const float* emb, const float* w, const float* b, const int64_t* label, float* prob,
+                          float* loss_rows, float* dlogit, float* demb, float* dw, float* db, int B, int H,
+                          void* stream);
+
 /* ------------------------------------------------------------------------------ ECAPA-TDNN pieces
  * ref: src/lightning_modules/speaker/ecapa_tdnn.py:75-85 -> speechbrain 0.5.x ECAPA_TDNN (not part of the reference
  * tree; restated in oracle/ecapa_oracle.py).  Channels-last [B*T][C] activations; `ld*` = row stride in elements so

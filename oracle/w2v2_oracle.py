@@ -397,6 +397,28 @@ def speaker_embedding(wav_b1n: Tensor, sd: StateDict, cfg: OracleConfig, pooling
     return index_pool(h, pooling)
 
 
+def paired_equality_scores(wav_left: Tensor, wav_right: Tensor, sd: StateDict, cfg: OracleConfig, lin_w: Tensor,
+                           lin_b: Tensor, cls_token_constant: float = 1.0, sep_token_constant: float = -1.0,
+                           skip_layers: Sequence[int] = ()) -> Tensor:
+    """ref: src/lightning_modules/speaker/wav2vec2_paired_input.py:163-207 (compute_speaker_equality): both waveforms
+    through the conv stack + projection, sequence [CLS] left [SEP] right [SEP] (constant tokens) through the encoder
+    (no SpecAugment on this path), Linear(H, 1) on token 0 -> logits [B, 1]."""
+    f1 = feature_projection(feature_extractor(wav_left, sd, cfg).transpose(1, 2), sd, cfg)
+    f2 = feature_projection(feature_extractor(wav_right, sd, cfg).transpose(1, 2), sd, cfg)
+    B, _, H = f1.shape
+    tok = lambda c: torch.full((B, 1, H), float(c), dtype=f1.dtype)
+    seq = torch.cat([tok(cls_token_constant), f1, tok(sep_token_constant), f2, tok(sep_token_constant)], dim=1)
+    out = encoder(seq, sd, cfg, skip_layers)
+    return out[:, 0, :] @ lin_w.t() + lin_b
+
+
+def bce_with_logits(logits: Tensor, label: Tensor) -> Tuple[Tensor, Tensor]:
+    """ref: src/optim/loss/binary_cross_entropy.py:24-40 -> (mean loss, sigmoid prediction)."""
+    lg = logits.squeeze().to(torch.float32)
+    y = label.squeeze().to(torch.float32)
+    return F.binary_cross_entropy_with_logits(lg, y), torch.sigmoid(lg).detach()
+
+
 # --------------------------------------------------------------------------- optimiser
 def adam_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, step: int, lr: float, beta1: float,
               beta2: float = 0.999, eps: float = 1e-8) -> None:

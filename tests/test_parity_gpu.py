@@ -292,6 +292,51 @@ def test_attentive_statistics_pooling_step_vs_oracle(dtype):
     assert torch.isfinite(e2).all()
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_paired_input_bce_step_vs_oracle(dtype):
+    """SURVEY 8f row f4 (ref: wav2vec2_paired_input.py:163-207 + binary_cross_entropy.py): two waveforms per pair through
+    conv stack + projection, [CLS] left [SEP] right [SEP] through the encoder, Linear(H,1) on token 0, BCE; logits,
+    loss and every gradient (incl. the unfrozen conv stack in f32) against the oracle's autograd."""
+    from w2v2_speaker_amd.engine import Plan
+    from w2v2_speaker_amd.params import ParamStore
+    cfg, ocfg = _cfgs("tiny")
+    B, N = 3, 4000
+    f32 = dtype == torch.float32
+    st = ParamStore(cfg, DEV, dtype, head="bce", freeze_cnn=not f32)
+    sd = O.make_state_dict(ocfg, 20211)
+    sd["linear.weight"] = O.synth_tensor("linear.weight", (1, cfg.hidden_size), 20211)
+    sd["linear.bias"] = O.synth_tensor("linear.bias", (1,), 20211)
+    st.load_state_dict(sd)
+    wl, _ = O.synth_batch(B, N, 2, seed=21)
+    wr, _ = O.synth_batch(B, N, 2, seed=22)
+    label = torch.tensor([1, 0, 1])
+    sdg = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    logits_ref = O.paired_equality_scores(wl[:, 0], wr[:, 0], sdg, ocfg, sdg["linear.weight"], sdg["linear.bias"])
+    loss_ref, pred_ref = O.bce_with_logits(logits_ref, label)
+    loss_ref.backward()
+    plan = Plan(st, B, N, train=True, reg=_no_reg(), pooling="first", paired=True)
+    assert plan.T == 2 * plan.T0 + 3
+    st.zero_grad()
+    wav = torch.cat([wl[:, 0], wr[:, 0]], dim=0).to(DEV)            # [2B, N]: left utterances, then right
+    plan.embed(wav)
+    loss, pred = plan.head_forward_backward(label.to(DEV))
+    plan.backward()
+    torch.cuda.synchronize()
+    assert torch.allclose(pred.cpu(), pred_ref, atol=1e-5 if f32 else 3e-2)
+    assert abs(float(loss) - float(loss_ref)) < (1e-5 if f32 else 3e-2) * max(1.0, abs(float(loss_ref)))
+    gmax = max(float(v.grad.norm()) for v in sdg.values() if v.grad is not None)
+    bad = []
+    for n, v in sdg.items():
+        name = n if n.startswith("linear") else "wav2vec.model." + n
+        if v.grad is None or not st.is_trainable(name):
+            continue
+        got, ref = st.g(name).double().cpu().reshape(v.grad.shape), v.grad.double()
+        err = float((got - ref).norm())
+        if err > (2e-3 if f32 else 0.12) * float(ref.norm()) + (1e-6 if f32 else 5e-3) * gmax:
+            bad.append((n, round(err, 6), round(float(ref.norm()), 6)))
+    assert not bad, bad[:8]
+
+
 def test_large_shape_5s_clips_vs_oracle():
     """BASELINE configs[3] geometry (wav2vec2-large: H=1024, 16 heads, FFN 4096; 5 s clips -> T=249, which takes
     the T > 160 attention kernels), cut to 2 encoder layers so the CPU oracle finishes in seconds: eval embedding,

@@ -75,6 +75,7 @@ _SIGS = {
                                    c_f32, c_u64, c_i32, c_vp]),
     "w2v2_pool_fwd": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "w2v2_pool_bwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    "w2v2_bce_head_fwd_bwd": (c_i32, [c_vp] * 10 + [c_i32, c_i32, c_vp]),
     "w2v2_bn_workspace_floats": (c_i32, [c_i32, c_i32]),
     "w2v2_bn_stats": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_i32, c_i32, c_f32, c_f32, c_i32, c_i32, c_vp]),
     "w2v2_bn_apply": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_vp]),

@@ -158,3 +158,61 @@ extern "C" int w2v2_normalize_bwd(const float* g, const void* x, int64_t ldx, co
   W2V2_CHECK_LAUNCH("normalize_bwd");
   return 0;
 }
+
+// ------------------------------------------------------------------------------------------ paired-input BCE head
+// ref: src/lightning_modules/speaker/wav2vec2_paired_input.py:200-206 (nn.Linear(H, 1) on the CLS token) +
+// src/optim/loss/binary_cross_entropy.py:24-40 (binary_cross_entropy_with_logits, mean; prediction = sigmoid).
+// Row kernel (one wave per pair): logit, probability, loss row, dlogit = (p - y) / B, demb = dlogit * w.
+__global__ __launch_bounds__(64) void bce_row_kernel(const float* __restrict__ emb, const float* __restrict__ w,
+                                                     const float* __restrict__ b, const int64_t* __restrict__ label,
+                                                     float* __restrict__ prob, float* __restrict__ loss_rows,
+                                                     float* __restrict__ dlogit, float* __restrict__ demb, int B,
+                                                     int H) {
+  const int row = blockIdx.x, lane = threadIdx.x;
+  const float* e = emb + (int64_t)row * H;
+  float s = 0.f;
+  for (int h = lane; h < H; h += 64) s = fmaf(e[h], w[h], s);
+  s = wave_sum(s) + b[0];
+  const float y = (float)label[row];
+  const float p = 1.0f / (1.0f + __expf(-s));
+  // max(s, 0) - s*y + log(1 + exp(-|s|)): the numerically stable form torch uses
+  const float l = fmaxf(s, 0.f) - s * y + log1pf(__expf(-fabsf(s)));
+  const float dl = (p - y) / (float)B;
+  if (lane == 0) {
+    prob[row] = p;
+    loss_rows[row] = l;
+    if (dlogit != nullptr) dlogit[row] = dl;
+  }
+  if (demb != nullptr)
+    for (int h = lane; h < H; h += 64) demb[(int64_t)row * H + h] = dl * w[h];
+}
+// dW[h] = sum_b dlogit[b] emb[b][h] (fixed order), db = sum_b dlogit[b]    (written)
+__global__ void bce_wgrad_kernel(const float* __restrict__ emb, const float* __restrict__ dlogit,
+                                 float* __restrict__ dw, float* __restrict__ db, int B, int H) {
+  const int h = blockIdx.x * blockDim.x + threadIdx.x;
+  if (h < H) {
+    float s = 0.f;
+    for (int r = 0; r < B; ++r) s = fmaf(dlogit[r], emb[(int64_t)r * H + h], s);
+    dw[h] = s;
+  }
+  if (h == 0) {
+    float s = 0.f;
+    for (int r = 0; r < B; ++r) s += dlogit[r];
+    db[0] = s;
+  }
+}
+
+extern "C" int w2v2_bce_head_fwd_bwd(const float* emb, const float* w, const float* b, const int64_t* label, float* prob,
+                                     float* loss_rows, float* dlogit, float* demb, float* dw, float* db, int B, int H,
+                                     void* stream) {
+  W2V2_REQUIRE(emb && w && b && label && prob && loss_rows && B > 0 && H > 0, "bce_head: bad arguments");
+  W2V2_REQUIRE((dlogit == nullptr) == (demb == nullptr) && (demb == nullptr) == (dw == nullptr) &&
+                   (dw == nullptr) == (db == nullptr),
+               "bce_head: gradient outputs come together");
+  hipStream_t st = as_stream(stream);
+  hipLaunchKernelGGL(bce_row_kernel, dim3(B), dim3(64), 0, st, emb, w, b, label, prob, loss_rows, dlogit, demb, B, H);
+  if (dw != nullptr)
+    hipLaunchKernelGGL(bce_wgrad_kernel, dim3((unsigned)cdiv(H, 256)), dim3(256), 0, st, emb, dlogit, dw, db, B, H);
+  W2V2_CHECK_LAUNCH("bce_head");
+  return 0;
+}

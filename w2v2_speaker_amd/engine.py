@@ -62,9 +62,15 @@ class Plan:
                  reg: Optional[Wav2Vec2RegularisationConfig] = None, pooling: str = "mean+std",
                  insert_cls_token: bool = False, cls_token_constant: float = 1.0,
                  aam_margin: float = 0.2, aam_scale: float = 30.0, fused_attention: Optional[bool] = None,
-                 seed: int = 7, keep_hidden_states: bool = False):
+                 seed: int = 7, keep_hidden_states: bool = False, paired: bool = False,
+                 sep_token_constant: float = -1.0):
         cfg = store.cfg
         self.store, self.cfg, self.B, self.N, self.train = store, cfg, batch, n_samples, train
+        # paired input (ref: wav2vec2_paired_input.py:163-207): the conv stack and projection run on 2B waveforms (first
+        # B = left, last B = right utterance of each pair); the encoder sees B sequences [CLS] left [SEP] right [SEP]
+        self.paired, self.sep_c = paired, sep_token_constant
+        self.Bc = 2 * batch if paired else batch
+        assert not (paired and insert_cls_token)
         self.reg = reg if reg is not None else Wav2Vec2RegularisationConfig()
         self.pooling, self.pool_mode = pooling, POOL_MODES.get(pooling, -1)
         assert pooling == "attentive" or pooling in POOL_MODES, pooling
@@ -77,8 +83,8 @@ class Plan:
         self.dev, self.adt = store.device, store.act_dtype
         self.lens = cfg.conv_lengths(n_samples)
         self.T0 = self.lens[-1]                       # frames out of the CNN
-        self.T = self.T0 + (1 if insert_cls_token else 0)
-        self.M0, self.M = batch * self.T0, batch * self.T
+        self.T = 2 * self.T0 + 3 if paired else self.T0 + (1 if insert_cls_token else 0)
+        self.M0, self.M = self.Bc * self.T0, batch * self.T
         H, d = cfg.hidden_size, cfg.head_dim
         if fused_attention is None:
             fused_attention = (self.adt == torch.bfloat16 and d == 64 and self.T <= 256)
@@ -107,23 +113,24 @@ class Plan:
         cfg, B, T, M, H, I = self.cfg, self.B, self.T, self.M, self.cfg.hidden_size, self.cfg.intermediate_size
         f32 = torch.float32
         C = cfg.conv_dim
-        self.stats0 = ops.conv0_workspace(B, self.N, C[0], cfg.conv_kernel[0], cfg.conv_stride[0], self.dev)
-        self.conv = [self._e(B, L, c) for L, c in zip(self.lens, C)]
+        Bc = self.Bc
+        self.stats0 = ops.conv0_workspace(Bc, self.N, C[0], cfg.conv_kernel[0], cfg.conv_stride[0], self.dev)
+        self.conv = [self._e(Bc, L, c) for L, c in zip(self.lens, C)]
         cins = (1,) + tuple(C[:-1])
         self.convw = [None] + [self._e(C[i], cfg.conv_kernel[i] * cins[i]) for i in range(1, len(C))]
         self.zero_bias = torch.zeros(max(max(C), H), dtype=f32, device=self.dev)
         self.cnn_train = self.train and not self.store.freeze_cnn
         if self.cnn_train:      # unfrozen feature extractor: pre-activations saved, gradient + im2col scratch
-            self.conv_pre = [None] + [self._e(B, L, c) for L, c in zip(self.lens[1:], C[1:])]
-            self.dconv = [self._e(B, L, c) for L, c in zip(self.lens[:-1], C[:-1])]      # d(conv[i] output), i < last
-            self.col = self._e(max(B * self.lens[i] * cfg.conv_kernel[i] * cins[i] for i in range(1, len(C))))
+            self.conv_pre = [None] + [self._e(Bc, L, c) for L, c in zip(self.lens[1:], C[1:])]
+            self.dconv = [self._e(Bc, L, c) for L, c in zip(self.lens[:-1], C[:-1])]      # d(conv[i] output), i < last
+            self.col = self._e(max(Bc * self.lens[i] * cfg.conv_kernel[i] * cins[i] for i in range(1, len(C))))
             self.dwp = torch.zeros(max(C[i] * cfg.conv_kernel[i] * cins[i] for i in range(1, len(C))), dtype=f32,
                                    device=self.dev)
-            self.sums0 = self._e(B, C[0], 2, dtype=f32)
+            self.sums0 = self._e(Bc, C[0], 2, dtype=f32)
         self.ln_feat = self._ep(self.M0, C[-1])
         self.mean_f, self.rstd_f = self._e(self.M0, dtype=f32), self._e(self.M0, dtype=f32)
         self.h0 = self._e(self.M0, H)                          # projection output (pre-CLS)
-        self.hx = self._e(M, H) if self.cls else self.h0       # encoder input
+        self.hx = self._e(M, H) if (self.cls or self.paired) else self.h0       # encoder input
         G, K = cfg.num_conv_pos_embedding_groups, cfg.num_conv_pos_embeddings
         self.Cg, self.Tp = H // G, T + K - 1
         self.xg = self._e(B, G, self.Tp, self.Cg)
@@ -156,7 +163,12 @@ class Plan:
         self.emb = self._e(B, E, dtype=f32)
         st = self.store
         self.head = None
-        if st.head is not None:
+        if st.head == "bce":
+            from .heads import BceHead
+            self.head = BceHead(B, E, w=st.p("linear.weight"), b=st.p("linear.bias"),
+                                w_grad=st.g("linear.weight") if self.train else None,
+                                b_grad=st.g("linear.bias") if self.train else None, emb=self.emb, train=self.train)
+        elif st.head is not None:
             from .heads import ClassifierHead
             aam = st.head == "aam"
             wname = "loss_fn.fc_weights" if aam else "fc_list.0.0.weight"
@@ -181,7 +193,7 @@ class Plan:
             self.dwf = self._e(G, K * self.Cg, self.Cg, dtype=f32)
             self.pos_dot = self._e(129 * K, dtype=f32)
             self.dn = self._e(self.M0, C[-1])
-            self.G0 = self._ep(self.M0, H) if self.cls else None
+            self.G0 = self._ep(self.M0, H) if (self.cls or self.paired) else None
             if self.fused:
                 self.delta = self._e(B * heads * T, dtype=f32)
             else:
@@ -196,7 +208,7 @@ class Plan:
         self.g_conv = []
         for i in range(1, len(C)):
             k, s, ci, co = cfg.conv_kernel[i], cfg.conv_stride[i], cins[i], C[i]
-            self.g_conv.append(Gemm(B * self.lens[i], co, k * ci, self.conv[i - 1], self.convw[i], self.conv[i],
+            self.g_conv.append(Gemm(self.Bc * self.lens[i], co, k * ci, self.conv[i - 1], self.convw[i], self.conv[i],
                                     lda=s * ci, ldb=k * ci, ldc=co, a_seg=(self.lens[i], self.lens[i - 1] * ci),
                                     epilogue=EPI_BIAS_GELU, bias=self.zero_bias,
                                     aux=self.conv_pre[i] if self.cnn_train else None, ldaux=co))
@@ -205,7 +217,7 @@ class Plan:
             self.g_conv_dw, self.g_conv_dx = [None], [None]
             for i in range(1, len(C)):
                 k, sd, ci, co = cfg.conv_kernel[i], cfg.conv_stride[i], cins[i], C[i]
-                Mi = B * self.lens[i]
+                Mi = self.Bc * self.lens[i]
                 gout = self.dn if i == len(C) - 1 else self.dconv[i]          # d(conv[i] output) -> dpre in place
                 self.g_conv_dw.append(Gemm(co, k * ci, Mi, gout, self.conv[i - 1], self.dwp, lda=co, ldb=sd * ci,
                                            ldc=k * ci, transA=True, transB=True,
@@ -327,7 +339,7 @@ class Plan:
                                  a_seg=(T, G * Tp * Cg), batch=G, batch_inner=G, a_strides=(0, Tp * Cg),
                                  b_strides=(0, Cg * K * Cg), c_strides=(0, Cg), epilogue=EPI_ADD, aux=self.G, ldaux=H,
                                  aux_strides=(0, Cg))
-            g0 = self.G0 if self.cls else self.G
+            g0 = self.G0 if (self.cls or self.paired) else self.G
             if st.flat_lp_t is not None:
                 self.g_proj_dw = WgradGroup([(g0._w2v2_padded, self.ln_feat._w2v2_padded,
                                               mg("feature_projection.projection.weight"),
@@ -372,7 +384,7 @@ class Plan:
         if wav.dim() == 3:
             wav = wav[:, 0, :]
         wav = wav.contiguous()
-        assert wav.shape == (B, self.N) and wav.dtype == torch.float32 and wav.is_cuda
+        assert wav.shape == (self.Bc, self.N) and wav.dtype == torch.float32 and wav.is_cuda
         self._refresh_packs()
         self._wav = wav
         tr = self.train
@@ -392,6 +404,15 @@ class Plan:
             ops.dropout_(self.h0, reg.feat_proj_dropout, self._sd("featproj", 0, step))
         if self.cls:
             ops.prepend_token(self.h0.view(B, self.T0, H), self.hx.view(B, T, H), self.cls_c)
+        elif self.paired:
+            # [CLS] left [SEP] right [SEP] (constant tokens; no SpecAugment on this path) -- buffer plumbing only
+            assert mask is None
+            T0, hx, h0 = self.T0, self.hx.view(B, T, H), self.h0.view(2, B, self.T0, H)
+            hx[:, 0].fill_(self.cls_c)
+            hx[:, 1:1 + T0].copy_(h0[0])
+            hx[:, 1 + T0].fill_(self.sep_c)
+            hx[:, 2 + T0:2 + 2 * T0].copy_(h0[1])
+            hx[:, 2 + 2 * T0].fill_(self.sep_c)
         elif mask is not None:
             self._mask = mask.to(torch.uint8).contiguous().view(-1)
             ops.mask_fill(self.h0, self._mask, mp("masked_spec_embed"))
@@ -588,6 +609,11 @@ class Plan:
         if self.cls:
             self.G0.view(B, self.T0, H).copy_(self.G.view(B, T, H)[:, 1:, :])    # the CLS row has no input
             g0 = self.G0
+        elif self.paired:                     # the three constant tokens have no input
+            T0, G3, G0 = self.T0, self.G.view(B, T, H), self.G0.view(2, B, self.T0, H)
+            G0[0].copy_(G3[:, 1:1 + T0])
+            G0[1].copy_(G3[:, 2 + T0:2 + 2 * T0])
+            g0 = self.G0
         else:
             g0 = self.G
             if self._mask is not None:
@@ -609,7 +635,7 @@ class Plan:
     def _backward_cnn(self) -> None:
         """Backward of the 7-layer conv feature extractor (HF:382-419) -- the reference's
         ``completely_freeze_feature_extractor: false`` ablation.  self.dn holds d(conv[6] output)."""
-        cfg, st, B = self.cfg, self.store, self.B
+        cfg, st, B = self.cfg, self.store, self.Bc
         C = cfg.conv_dim
         cins = (1,) + tuple(C[:-1])
         mg = st.mg

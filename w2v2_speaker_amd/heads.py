@@ -83,3 +83,28 @@ class ClassifierHead:
                 self.g_dw()
                 ops.colsum(self.dcos_w, self.bias_grad, B, Cn, self.ldc)
         return loss, self.softmax[:, :Cn]
+
+
+class BceHead:
+    """ref: wav2vec2_paired_input.py:200-206 + binary_cross_entropy.py:24-40: Linear(H -> 1) on the CLS token,
+    BCE-with-logits (mean over pairs), prediction = sigmoid(logit).  Same interface as ClassifierHead."""
+
+    def __init__(self, batch: int, embed_dim: int, *, w: torch.Tensor, b: torch.Tensor,
+                 w_grad: Optional[torch.Tensor], b_grad: Optional[torch.Tensor], emb: torch.Tensor, train: bool):
+        dev, f32 = emb.device, torch.float32
+        self.B, self.E, self.w, self.b, self.w_grad, self.b_grad, self.emb, self.train = (batch, embed_dim, w, b, w_grad,
+                                                                                          b_grad, emb, train)
+        self.prob = torch.empty(batch, dtype=f32, device=dev)
+        self.loss_rows = torch.empty(batch, dtype=f32, device=dev)
+        self.dlogit = torch.empty(batch, dtype=f32, device=dev) if train else None
+        self.demb = torch.empty(batch, embed_dim, dtype=f32, device=dev) if train else None
+
+    def forward_backward(self, label: torch.Tensor):
+        """label [B] int64 in {0, 1} (1 = same speaker) -> (loss, prediction [B])."""
+        assert label.dtype == torch.int64 and label.is_cuda and label.shape == (self.B,)
+        tr = self.train
+        ops.bce_head_fwd_bwd(self.emb, self.w.view(-1), self.b, label, self.prob, self.loss_rows,
+                             self.dlogit if tr else None, self.demb if tr else None,
+                             self.w_grad.view(-1) if tr else None, self.b_grad if tr else None, self.B, self.E)
+        return self.loss_rows.mean(), self.prob
+

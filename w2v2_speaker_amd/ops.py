@@ -540,3 +540,11 @@ def act_fwd(x, y, mode: int) -> None:
 def act_bwd(dy, y, dx, mode: int) -> None:
     _dev(dy, y, dx)
     _lib.check(lib().w2v2_act_bwd(dy.data_ptr(), y.data_ptr(), dx.data_ptr(), dy.numel(), mode, stream()), "act_bwd")
+
+
+def bce_head_fwd_bwd(emb, w, b, label, prob, loss_rows, dlogit, demb, dw, db, B: int, H: int) -> None:
+    _dev(emb, w, b, label, prob, loss_rows, dlogit, demb, dw, db)
+    _lib.check(lib().w2v2_bce_head_fwd_bwd(emb.data_ptr(), w.data_ptr(), b.data_ptr(), label.data_ptr(), prob.data_ptr(),
+                                           loss_rows.data_ptr(), _p(dlogit), _p(demb), _p(dw), _p(db), B, H, stream()),
+               "bce_head")
+

@@ -75,7 +75,7 @@ class ParamStore:
                  head: Optional[str] = "aam", num_speakers: int = 5994, embed_dim: Optional[int] = None,
                  freeze_cnn: bool = True, attentive_pool: bool = False, attention_channels: int = 128):
         assert act_dtype in (torch.bfloat16, torch.float32)
-        assert head in (None, "aam", "ce")
+        assert head in (None, "aam", "ce", "bce")
         self.cfg, self.device, self.act_dtype = cfg, torch.device(device), act_dtype
         self.head, self.num_speakers, self.freeze_cnn = head, num_speakers, freeze_cnn
         self.embed_dim = embed_dim if embed_dim is not None else 2 * cfg.hidden_size
@@ -85,6 +85,10 @@ class ParamStore:
         elif head == "ce":
             shapes["fc_list.0.0.weight"] = (num_speakers, self.embed_dim)
             shapes["fc_list.0.0.bias"] = (num_speakers,)
+        elif head == "bce":         # paired-input equality head (ref: wav2vec2_paired_input.py:108-110 ``self.linear``)
+            self.embed_dim = embed_dim if embed_dim is not None else cfg.hidden_size
+            shapes["linear.weight"] = (1, self.embed_dim)
+            shapes["linear.bias"] = (1,)
         self.attentive_pool = attentive_pool
         # BatchNorm1d buffers {running_mean[A], running_var[A]} of the attentive pooling, shared by every plan
         self.asp_running = (torch.cat([torch.zeros(attention_channels), torch.ones(attention_channels)]).to(device)

@@ -98,7 +98,7 @@ class SpeakerTrainer:
 
     def sample_time_mask(self) -> Optional[torch.Tensor]:
         reg, plan = self.plan.reg, self.plan
-        if reg.mask_time_prob <= 0 or plan.cls:
+        if reg.mask_time_prob <= 0 or plan.cls or plan.paired:
             return None
         m = compute_mask_indices((plan.B, plan.T0), reg.mask_time_prob, reg.mask_time_length,
                                  plan.cfg.mask_time_min_masks, rng=self._mask_rng)
