@@ -295,8 +295,11 @@ class _SEBlock:
         self.g = torch.empty(B, C, dtype=f32, device=dev)
         p = st.p
         W1, W2 = p(self.pre + "conv1.conv.weight").view(S, C), p(self.pre + "conv2.conv.weight").view(C, S)
+        # M = B rows only: a handful of output tiles with a long K -> split-K (f32 atomics into a zeroed output; the
+        # bias is added by split 0)
+        self.sk1 = max(1, min(16, C // 128))
         self.g1 = Gemm(B, S, C, self.s, W1, self.z, lda=C, ldb=C, ldc=S, epilogue=EPI_BIAS,
-                       bias=p(self.pre + "conv1.conv.bias"))
+                       bias=p(self.pre + "conv1.conv.bias"), split_k=self.sk1, accumulate=self.sk1 > 1)
         self.g2 = Gemm(B, C, S, self.z, W2, self.g, lda=S, ldb=S, ldc=C, epilogue=EPI_BIAS,
                        bias=p(self.pre + "conv2.conv.bias"))
         if plan.train:
@@ -306,7 +309,8 @@ class _SEBlock:
             self.ds = torch.empty(B, C, dtype=f32, device=dev)
             self.g_dw2 = Gemm(C, S, B, self.dg, self.z, g(self.pre + "conv2.conv.weight").view(C, S), lda=C, ldb=S,
                               ldc=S, transA=True, transB=True, accumulate=True)
-            self.g_dz = Gemm(B, S, C, self.dg, W2, self.dz, lda=C, ldb=S, ldc=S, transB=True)
+            self.g_dz = Gemm(B, S, C, self.dg, W2, self.dz, lda=C, ldb=S, ldc=S, transB=True, split_k=self.sk1,
+                             accumulate=self.sk1 > 1)
             self.g_dw1 = Gemm(S, C, B, self.dz, self.s, g(self.pre + "conv1.conv.weight").view(S, C), lda=S, ldb=C,
                               ldc=C, transA=True, transB=True, accumulate=True)
             self.g_ds = Gemm(B, C, S, self.dz, W1, self.ds, lda=S, ldb=C, ldc=C, transB=True)
@@ -314,6 +318,8 @@ class _SEBlock:
     def forward(self) -> None:
         pl = self.plan
         ops.pool_fwd(self.x.view(pl.B, pl.T, self.C), self.s, ops.POOL_MODES["mean"])
+        if self.sk1 > 1:
+            self.z.zero_()
         self.g1()
         ops.act_fwd(self.z, self.z, 0)
         self.g2()
@@ -327,6 +333,8 @@ class _SEBlock:
         ops.act_bwd(self.dg, self.g, self.dg, 1)
         self.g_dw2()
         ops.colsum(self.dg, st.g(self.pre + "conv2.conv.bias"), pl.B, self.C)
+        if self.sk1 > 1:
+            self.dz.zero_()
         self.g_dz()
         ops.act_bwd(self.dz, self.z, self.dz, 0)
         self.g_dw1()
@@ -445,8 +453,9 @@ class EcapaPlan:
         self.emb = torch.empty(B, L, dtype=f32, device=dev)
         p, g = store.p, store.g
         Wfc = p(FE + "fc.conv.weight").view(L, E2)
+        self.sk_fc = max(1, min(32, E2 // 128))
         self.g_fc = Gemm(B, L, E2, self.e2, Wfc, self.emb, lda=E2, ldb=E2, ldc=L, epilogue=EPI_BIAS,
-                         bias=p(FE + "fc.conv.bias"))
+                         bias=p(FE + "fc.conv.bias"), split_k=self.sk_fc, accumulate=self.sk_fc > 1)
         self.head = ClassifierHead("aam", B, L, store.num_speakers, w_master=p("loss_fn.fc_weights"),
                                    w_operand=store.w("loss_fn.fc_weights"),
                                    w_grad=g("loss_fn.fc_weights") if train else None, emb=self.emb, act_dtype=adt,
@@ -500,6 +509,8 @@ class EcapaPlan:
             self.bn_mr[:, 1].copy_((self.bn_running[E2:] + BN_EPS).rsqrt())
         ops.bn_apply(self.pooled, E2, self.bn_mr, st.p(FE + "asp_bn.norm.weight"), st.p(FE + "asp_bn.norm.bias"),
                      self.e2, E2, B, E2, False)
+        if self.sk_fc > 1:
+            self.emb.zero_()
         self.g_fc()
         return self.emb
 
