@@ -245,3 +245,37 @@ def test_training_steps_fed_from_reference_format_shards(tmp_path):
             loss, _ = tr.train_step(batch.network_input, batch.ground_truth, skip_layers=())
             losses.append(float(loss))
     assert all(np.isfinite(losses)) and np.mean(losses[-4:]) < 0.7 * np.mean(losses[:4]), losses
+
+
+def test_ecapa_and_paired_module_surfaces_train():
+    """Mirrors of the reference's EcapaTdnnModule and Wav2vec2PairedSpeakerModule: config field names, method names,
+    one training step each through the public surface, finite decreasing losses."""
+    from w2v2_speaker_amd import config as C
+    from w2v2_speaker_amd.lightning_modules.speaker.ecapa_tdnn import EcapaTDNNModuleConfig, EcapaTdnnModule
+    from w2v2_speaker_amd.lightning_modules.speaker.wav2vec2_fc import SpeakerClassificationDataBatch
+    from w2v2_speaker_amd.lightning_modules.speaker.wav2vec2_paired_input import (
+        PairedSpeakerClassificationDataBatch, Wav2vec2PairedSpeakerModule, Wav2vec2PairedSpeakerModuleConfig)
+    g = torch.Generator().manual_seed(0)
+    ecfg = EcapaTDNNModuleConfig(input_mel_coefficients=16, lin_neurons=24, channels=[64, 64, 64, 64, 192],
+                                 attention_channels=16, res2net_scale=4, se_channels=16)
+    em = EcapaTdnnModule(ecfg, num_speakers=5, max_lr=2e-3, max_steps=50)
+    feat = torch.randn(6, 40, 16, generator=g)
+    batch = SpeakerClassificationDataBatch(6, [str(i) for i in range(6)], feat, torch.randint(0, 5, (6,), generator=g))
+    losses = [float(em.training_step(batch)["loss"]) for _ in range(12)]
+    assert np.isfinite(losses).all() and losses[-1] < losses[0]
+    emb, pred = em(feat)
+    assert emb.shape == (6, 24) and torch.isfinite(emb).all()
+    assert em.generate_example_input(True, 3).shape == (3, 100, 16)
+    tiny = C.W2V2Config.tiny()
+    orig = C.W2V2Config.from_huggingface_id
+    C.W2V2Config.from_huggingface_id = staticmethod(lambda _id: tiny)
+    try:
+        pm = Wav2vec2PairedSpeakerModule(Wav2vec2PairedSpeakerModuleConfig(), max_lr=2e-3, max_steps=50)
+        a, b = 0.3 * torch.randn(4, 4000, generator=g), 0.3 * torch.randn(4, 4000, generator=g)
+        pb = PairedSpeakerClassificationDataBatch(4, list("abcd"), a, list("efgh"), b, torch.tensor([1, 0, 1, 0]))
+        pl = [float(pm.training_step(pb)["loss"]) for _ in range(10)]
+        assert np.isfinite(pl).all() and pl[-1] < pl[0]
+        scores = pm(a, b)
+        assert scores.shape == (4, 1) and torch.isfinite(scores).all()
+    finally:
+        C.W2V2Config.from_huggingface_id = orig
