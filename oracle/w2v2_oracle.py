@@ -3,7 +3,7 @@
 TEST INFRASTRUCTURE ONLY -- see ``oracle/__init__.py``.  This file is our own
 restatement of the arithmetic the reference dispatches through HuggingFace
 ``Wav2Vec2Model`` / torch; it is pinned against the real reference (imported in
-the authoring container) by ``tools/make_goldens.py`` -> ``tests/golden/*.npz``
+the authoring container) by ``tests/golden/make_goldens.py`` -> ``tests/golden/*.npz``
 and by ``tests/test_oracle_vs_reference.py`` (skipped where /root/reference is
 absent).  Gradients come from torch autograd over these functions.
 

@@ -1,6 +1,6 @@
 import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import torch
 from oracle import w2v2_oracle as O
 from w2v2_speaker_amd.config import W2V2Config, Wav2Vec2RegularisationConfig

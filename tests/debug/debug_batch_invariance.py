@@ -1,6 +1,6 @@
 """Debug: where does utterance i's forward first differ between a B=66 plan and a B=1 plan?"""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from oracle import w2v2_oracle as O
 from w2v2_speaker_amd.config import W2V2Config

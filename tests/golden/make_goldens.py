@@ -6,7 +6,7 @@ Imports /root/reference (read-only) with the three shims of SURVEY.md App. C, bu
 from the name-keyed PCG64 generator in ``oracle.w2v2_oracle.synth_tensor`` and dumps small input /
 expected-output vectors.  The fixtures are data only; no reference source travels.
 
-    PYTHONDONTWRITEBYTECODE=1 python tools/make_goldens.py
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_goldens.py
 """
 import os
 import sys
@@ -14,7 +14,7 @@ import types
 
 os.environ.setdefault("PYTHONDONTWRITEBYTECODE", "1")
 sys.dont_write_bytecode = True
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
 import numpy as np

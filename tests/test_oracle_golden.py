@@ -1,5 +1,5 @@
 """Pin the CPU oracle (oracle/w2v2_oracle.py) against the golden vectors that were produced by
-running the reference itself (tools/make_goldens.py).  CPU only."""
+running the reference itself (tests/golden/make_goldens.py).  CPU only."""
 import os
 
 import numpy as np
