@@ -230,9 +230,8 @@ class _Tdnn:
         if pl.train:
             ops.bn_stats(self.a, self.cout, self.work, self.mean_rstd, self.running, self.M, self.cout, BN_EPS,
                          BN_MOMENTUM, True)
-        else:
-            self.mean_rstd[:, 0].copy_(self.running[:self.cout])
-            self.mean_rstd[:, 1].copy_((self.running[self.cout:] + BN_EPS).rsqrt())
+        else:                                        # BatchNorm1d.eval(): running statistics
+            ops.asp_bn_eval_stats(self.running, self.mean_rstd, self.cout, BN_EPS)
         ops.bn_apply(self.a, self.cout, self.mean_rstd, st.p(self.pre + "norm.norm.weight"),
                      st.p(self.pre + "norm.norm.bias"), self.y, self.ldy, self.M, self.cout, True)
 
@@ -505,8 +504,7 @@ class EcapaPlan:
         if self.train:
             ops.bn_stats(self.pooled, E2, self.bn_work, self.bn_mr, self.bn_running, B, E2, BN_EPS, BN_MOMENTUM, False)
         else:
-            self.bn_mr[:, 0].copy_(self.bn_running[:E2])
-            self.bn_mr[:, 1].copy_((self.bn_running[E2:] + BN_EPS).rsqrt())
+            ops.asp_bn_eval_stats(self.bn_running, self.bn_mr, E2, BN_EPS)
         ops.bn_apply(self.pooled, E2, self.bn_mr, st.p(FE + "asp_bn.norm.weight"), st.p(FE + "asp_bn.norm.bias"),
                      self.e2, E2, B, E2, False)
         if self.sk_fc > 1:

@@ -101,8 +101,12 @@ class Wav2vec2PairedSpeakerModule:
         wav = self._stack(wav_tensor, other_wav_tensor).to(self.device, torch.float32)
         plan = self._plan(wav.shape[0] // 2, wav.shape[1], False)
         emb = plan.embed(wav)
-        w, b = self.store.p("linear.weight"), self.store.p("linear.bias")
-        return emb @ w.t() + b                             # [B, H] x [H, 1]: tiny host-side head for inference
+        from ... import ops
+        B, H = emb.shape
+        out = torch.zeros(B, 4, dtype=torch.float32, device=self.device)          # ldc padded to 4
+        ops.gemm(B, 1, H, emb, self.store.p("linear.weight"), out, lda=H, ldb=H, ldc=4, epilogue=ops.EPI_BIAS,
+                 bias=self.store.p("linear.bias"))
+        return out[:, :1]
 
     def forward(self, input_tensor: torch.Tensor, other_input_tensor: torch.Tensor):
         return self.compute_speaker_equality(input_tensor, other_input_tensor)
