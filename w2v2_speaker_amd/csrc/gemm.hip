@@ -787,13 +787,13 @@ __global__ __launch_bounds__(512) void gemm_bf16_glds3_kernel(const GemmArgs g) 
   {                                                                \
     if (kt + 1 < nk) wait_vmcnt<6>(); else wait_vmcnt<0>();        \
     __builtin_amdgcn_s_barrier();                                  \
-    if (kt + 2 < nk) stage(nxt, kt + 2);                           \
-    compute(cur);                                                  \
+    if (kt + 2 < nk && !(g.dbg & 4)) stage(nxt, kt + 2);           \
+    if (!(g.dbg & 8)) compute(cur);                                \
     ++kt;                                                          \
   }
   __builtin_amdgcn_s_barrier();          // every wave has finished reading the previous tile's stages
-  if (nk > 0) stage(s0, 0);
-  if (nk > 1) stage(s1, 1);
+  if (nk > 0 && !(g.dbg & 4)) stage(s0, 0);
+  if (nk > 1 && !(g.dbg & 4)) stage(s1, 1);
   int kt = 0;
   while (kt < nk) {
     W2V2_RING_STEP(s0, s2)
@@ -811,6 +811,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_glds3_kernel(const GemmArgs g) 
   TC* auxz = g.aux ? reinterpret_cast<TC*>(g.aux) + z0 * g.aux_s0 + z1 * g.aux_s1 : nullptr;
   const float* bias = g.bias ? g.bias + z1 * g.bias_s1 : nullptr;
   const int nc = n0 + wn * 64 + fk * 16;
+  if ((g.dbg & 2) && acc[0][0][0] != 12345.f) continue;      // timing experiments: no epilogue
   float cv0[8], cv1[8];
   load_col8(g, bias, nc, cv0);
   load_col8(g, bias, nc + 8, cv1);
@@ -822,16 +823,25 @@ __global__ __launch_bounds__(512) void gemm_bf16_glds3_kernel(const GemmArgs g) 
 // The 256x128 kernel above is bound by the L2 -> LDS feed (48 KiB per 4.2 MFLOP tile step; all 256 CUs together draw
 // ~22 TB/s, tools/probes/load_path_probe).  A 256x256 tile halves the bytes per flop (32 KiB per 4.2 MFLOP step at
 // BK = 32).  8 waves as 2 (m) x 4 (n), 128 x 64 per wave (128 accumulator VGPRs); LDS holds FOUR 32 KiB stages
-// [256 + 256 rows][32 k] with 64-byte rows: three K steps in flight, `s_waitcnt vmcnt(8)` (4 DMA pieces per wave and
-// stage) and one s_barrier per step of 32 MFMAs.  64-byte rows: chunk map s(row) = ((row >> 2) & 1) << 1 is the
+// [256 + 256 rows][32 k] with 64-byte rows, counted `s_waitcnt vmcnt(4)` (4 DMA pieces per wave and stage) and one
+// s_barrier per step of 32 MFMAs.  64-byte rows: chunk map s(row) = ((row >> 2) & 1) << 1 is the
 // conflict-free one for the fragment ds_read_b128 (lds_bank_probe: 4.0 vs 6.0 clk unswizzled).  Used for products
 // whose 256x256 tiling fills the chip (FFN1, dH, the conv stack); B rows permuted for the register epilogue as above.
 __device__ __forceinline__ int swz64(int row) { return ((row >> 2) & 1) << 1; }
 __device__ __forceinline__ int swz64_b(int row) { return ((row >> 4) & 1) << 1; }   // fragment-local row (row>>4&3)*4+(row&3)
 
+// Software pipelining of the fragment reads.  Written as "read 12 fragments, then 32 MFMAs" the compiler emits
+// `ds_read x6 ; s_waitcnt lgkmcnt(0) ; mfma x8 ; ds_read x2 ; lgkmcnt(0) ; ...`:
+// every group of MFMAs waits for a full LDS drain, and since the per-step barrier keeps the two waves of a SIMD in
+// phase the matrix pipe idles for each of them (timing with DMA and epilogue switched off: the fragment-read + MFMA
+// loop alone runs at ~45 % of the MFMA rate).  Here the fragments of step kt+1 are read WHILE step kt multiplies:
+// B fragments double-buffered (16 VGPRs), A fragment i re-loaded in place right after its four MFMAs, so each
+// ds_read has ~a full step of MFMA time to land (glds4 590 vs 559 TFLOP/s in-step).  Stage kt+1 must have landed one
+// step earlier than in a read-then-multiply loop, i.e. two stages are in flight instead of three; a fifth stage
+// (160 KiB, the whole LDS) restored the distance and measured the same, so four it is.
 template <typename TC>
 __global__ __launch_bounds__(512) void gemm_bf16_glds4_kernel(const GemmArgs g) {
-  constexpr int BM = 256, BN = 256, FM = 8, FN = 4, BK = 32;
+  constexpr int BM = 256, BN = 256, FM = 8, FN = 4, BK = 32, S = 4;
   constexpr int STAGE = (BM + BN) * BK;           // elements per stage (A then B): 32 KiB
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);
@@ -847,11 +857,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_glds4_kernel(const GemmArgs g) 
   const int nk = g.K >> 5;
   const bf16_t* Ab = reinterpret_cast<const bf16_t*>(g.A.ptr) + z0 * g.a_s0 + z1 * g.a_s1;
   const bf16_t* Bb = reinterpret_cast<const bf16_t*>(g.B.ptr) + z0 * g.b_s0 + z1 * g.b_s1;
-  const int c4 = lane & 3, r16 = lane >> 2;        // DMA piece = 16 rows x 4 chunks of 16 B
+  const int c4 = lane & 3, r16 = lane >> 2;
   const int frow = lane & 15, fk = lane >> 4;
-  const int la = frow * BK + ((fk ^ swz64(frow)) << 3);
-  const int lb = ((frow >> 2) * 16 + (frow & 3)) * BK + ((fk ^ swz64(frow)) << 3);
-  const int aoff = wm * 128 * BK, boff = BM * BK + wn * 64 * BK;
+  const int la = wm * 128 * BK + frow * BK + ((fk ^ swz64(frow)) << 3);
+  const int lb = BM * BK + wn * 64 * BK + ((frow >> 2) * 16 + (frow & 3)) * BK + ((fk ^ swz64(frow)) << 3);
 
 #pragma unroll 1
   for (int t0 = 0; t0 < ntile; t0 += G) {
@@ -874,9 +883,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_glds4_kernel(const GemmArgs g) 
 #pragma unroll
       for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    auto stage = [&](bf16_t* base, int kt) {
-      bf16_t* ad = base + wave * 2 * 16 * BK;
-      bf16_t* bd = base + BM * BK + wave * 2 * 16 * BK;
+    auto stage = [&](int off, int kt) {
+      bf16_t* ad = smem + off + wave * 2 * 16 * BK;
+      bf16_t* bd = smem + off + BM * BK + wave * 2 * 16 * BK;
 #pragma unroll
       for (int j = 0; j < 2; ++j)
         __builtin_amdgcn_global_load_lds((gvoid_t*)(ap[j] + kt * BK), (lvoid_t*)(ad + j * 16 * BK), 16, 0, 0);
@@ -884,33 +893,61 @@ __global__ __launch_bounds__(512) void gemm_bf16_glds4_kernel(const GemmArgs g) 
       for (int j = 0; j < 2; ++j)
         __builtin_amdgcn_global_load_lds((gvoid_t*)(bp[j] + kt * BK), (lvoid_t*)(bd + j * 16 * BK), 16, 0, 0);
     };
-    auto compute = [&](const bf16_t* base) {
-      const bf16_t* pa = base + aoff + la;
-      const bf16_t* pb = base + boff + lb;
-      bf16x8 af[FM], bfr[FN];
+    // wait until all but the `newer` youngest stages of this wave's DMA have landed (4 pieces per stage)
+    auto wait_stages = [&](int newer) {
+      if (newer >= 2) wait_vmcnt<8>(); else if (newer == 1) wait_vmcnt<4>(); else wait_vmcnt<0>();
+    };
+
+    __builtin_amdgcn_s_barrier();          // every wave has finished reading the previous tile's stages
 #pragma unroll
-      for (int j = 0; j < FN; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(pb + j * 4 * BK);
+    for (int st = 0; st < S - 1; ++st)
+      if (st < nk) stage(st * STAGE, st);
+    wait_stages(min(nk, S - 1) - 1 > 2 ? 2 : min(nk, S - 1) - 1);
+    __builtin_amdgcn_s_barrier();
+    bf16x8 af[FM], bcur[FN], bnext[FN], alast;
 #pragma unroll
-      for (int i = 0; i < FM; ++i) af[i] = *reinterpret_cast<const bf16x8*>(pa + i * 16 * BK);
+    for (int j = 0; j < FN; ++j) bcur[j] = *reinterpret_cast<const bf16x8*>(smem + lb + j * 4 * BK);
+#pragma unroll
+    for (int i = 0; i < FM; ++i) af[i] = *reinterpret_cast<const bf16x8*>(smem + la + i * 16 * BK);
+
+    int nb = STAGE;                        // stage offset of step kt + 1
+    int fb = (S - 1) * STAGE;              // stage offset that step kt + S - 1 is loaded into
+#pragma unroll 1
+    for (int kt = 0; kt < nk - 1; ++kt) {
+      // stage kt+1 landed (own pieces), then everyone's: newer stages in flight = min(S - 3, nk - kt - 2)
+      wait_stages(min(S - 3, nk - kt - 2));
+      __builtin_amdgcn_s_barrier();
+      if (kt + S - 1 < nk) stage(fb, kt + S - 1);
+      const bf16_t* pa = smem + nb + la;
+      const bf16_t* pb = smem + nb + lb;
+      // the next step's B fragments go out behind the first MFMA group: the compiler's wait in front of that group
+      // then only covers reads issued a whole step ago
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bcur[j], af[i], acc[i][j], 0, 0, 0);
+        if (i == 0) {
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int j = 0; j < FN; ++j) bnext[j] = *reinterpret_cast<const bf16x8*>(pb + j * 4 * BK);
+          alast = *reinterpret_cast<const bf16x8*>(pa + (FM - 1) * 16 * BK);   // early: nothing may trail the last group
+        }
+        if (i < FM - 1) af[i] = *reinterpret_cast<const bf16x8*>(pa + i * 16 * BK);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      af[FM - 1] = alast;
+#pragma unroll
+      for (int j = 0; j < FN; ++j) bcur[j] = bnext[j];
+      nb = nb == (S - 1) * STAGE ? 0 : nb + STAGE;
+      fb = fb == (S - 1) * STAGE ? 0 : fb + STAGE;
+    }
+    if (nk > 0) {
 #pragma unroll
       for (int i = 0; i < FM; ++i)
 #pragma unroll
         for (int j = 0; j < FN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
-    };
-    // ring: K step kt sits in stage kt & 3; step kt+3 goes to the stage that held step kt-1.  The loop stays ROLLED
-    // (stage offset computed per step): unrolled by four the compiler materialises every stage's fragment addresses
-    // and spills ~400 registers of the 128-accumulator tile.
-    __builtin_amdgcn_s_barrier();          // every wave has finished reading the previous tile's stages
-    if (nk > 0) stage(smem, 0);
-    if (nk > 1) stage(smem + STAGE, 1);
-    if (nk > 2) stage(smem + 2 * STAGE, 2);
-#pragma unroll 1
-    for (int kt = 0; kt < nk; ++kt) {
-      if (kt + 2 < nk) wait_vmcnt<8>(); else if (kt + 1 < nk) wait_vmcnt<4>(); else wait_vmcnt<0>();
-      __builtin_amdgcn_s_barrier();
-      if (kt + 3 < nk) stage(smem + ((kt + 3) & 3) * STAGE, kt + 3);
-      compute(smem + (kt & 3) * STAGE);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bcur[j], af[i], acc[i][j], 0, 0, 0);
     }
 
     TC* Cz = reinterpret_cast<TC*>(g.C) + z0 * g.c_s0 + z1 * g.c_s1;
