@@ -753,3 +753,27 @@ def test_grouped_weight_gradient_gemm(shapes):
     o.WgradGroup(probs, tokens, tp)()
     torch.cuda.synchronize()
     assert all(torch.equal(a, p[2]) for a, p in zip(first, probs))
+
+
+@pytest.mark.gpu
+def test_transpose_many_vector_and_scalar_paths():
+    """Batched weight transposes (the bf16 W^T copies of the dX products): 16-byte path for aligned matrices,
+    scalar path for ragged ones, both inside one table."""
+    import torch
+    from w2v2_speaker_amd import ops
+    dev = "cuda"
+    shapes = [(768, 3072, 0), (2304, 768, 0), (200, 136, 0), (50, 70, 3), (64, 64, 0)]      # (R, C, extra offset)
+    offs, total = [], 0
+    for R, C, extra in shapes:
+        total += extra
+        offs.append(total)
+        total += R * C
+        total = (total + 7) // 8 * 8
+    src = torch.randn(total, device=dev).to(torch.bfloat16)
+    dst = torch.zeros_like(src)
+    table = torch.tensor([[o, o, R, C] for (R, C, _), o in zip(shapes, offs)], dtype=torch.int64, device=dev)
+    ops.transpose_many(src, dst, table, len(shapes))
+    torch.cuda.synchronize()
+    for (R, C, _), o in zip(shapes, offs):
+        want = src[o:o + R * C].view(R, C).t().contiguous().view(-1)
+        assert torch.equal(dst[o:o + R * C], want), (R, C)
