@@ -95,3 +95,70 @@ def test_fbank_shapes_and_tone_localisation():
     s = InputNormalizer2D(normalize_over_channels=True).process(s)
     assert s.network_input.shape == (301, 40) and float(s.network_input.mean(0).abs().max()) < 1e-4
 
+
+
+# ------------------------------------------------------------------------------------------------ pair batcher
+def _paired_stream(n_speakers, per_speaker, seq, seed):
+    import random as _r
+    from w2v2_speaker_amd.data import SpeakerClassificationDataSample
+    rng = _r.Random(seed)
+    runs = [(spk, r) for spk in range(n_speakers) for r in range(per_speaker // seq)]
+    rng.shuffle(runs)
+    for spk, r in runs:
+        for j in range(seq):
+            yield SpeakerClassificationDataSample(key=f"id{spk:03d}/vid{r:02d}/{j:05d}", ground_truth=spk,
+                                                  network_input=torch.full((1, 8), float(spk * 1000 + r * 10 + j)))
+
+
+def test_paired_batch_processor_matches_reference_goldens():
+    """tests/golden/paired_batcher.json was produced by the reference's own PairedBatchProcessor
+    (tests/golden/make_paired_goldens.py): same seed -> the same ordered pairs in the same batches."""
+    import json
+    import os
+    import random
+    from w2v2_speaker_amd.data.paired import EvaluationPair, PairedBatchProcessor
+    with open(os.path.join(os.path.dirname(__file__), "golden", "paired_batcher.json")) as f:
+        gold = json.load(f)
+    for case in gold["cases"]:
+        if case["mode"] == "generate":
+            proc = PairedBatchProcessor(case["batch_size"], case["max_queue_size"], "generate", case["seq"],
+                                        pos_neg_training_batch_ratio=case["ratio"])
+            random.seed(case["seed"])
+            src = _paired_stream(case["n_speakers"], case["per_speaker"], case["seq"], case["seed"])
+        else:
+            pairs = [EvaluationPair(*p) for p in case["pairs"]]
+            proc = PairedBatchProcessor(case["batch_size"], 8, "reproduce", 1, pairs=pairs)
+            src = _paired_stream(case["n_speakers"], case["per_speaker"], case["seq"], case["seed"])
+        got = [[[p, s, int(g)] for p, s, g in zip(b.primary_keys, b.secondary_keys, b.ground_truth.tolist())]
+               for b in proc(src)]
+        assert got == case["batches"], case["mode"]
+        for b in proc(_paired_stream(case["n_speakers"], case["per_speaker"], case["seq"], case["seed"])) \
+                if case["mode"] == "reproduce" else []:
+            assert b.primary_network_input.shape == (b.batch_size, 8)
+
+
+def test_paired_batch_processor_properties_and_errors(tmp_path):
+    import random
+    from w2v2_speaker_amd.data.paired import PairedBatchProcessor, read_test_pairs_file
+    with pytest.raises(ValueError):
+        PairedBatchProcessor(8, 4, "generate", 2, pos_neg_training_batch_ratio=0.5)        # queue < batch
+    with pytest.raises(ValueError):
+        PairedBatchProcessor(8, 16, "generate", 3, pos_neg_training_batch_ratio=0.5)       # batch % seq
+    with pytest.raises(ValueError):
+        PairedBatchProcessor(8, 16, "generate", 2)                                         # no ratio
+    with pytest.raises(ValueError):
+        PairedBatchProcessor(8, 16, "reproduce", 2)                                        # no pairs
+    with pytest.raises(ValueError):
+        PairedBatchProcessor(8, 16, "shuffle", 2)
+    random.seed(0)
+    proc = PairedBatchProcessor(8, 16, "generate", 2, pos_neg_training_batch_ratio=0.5, yield_limit=24)
+    batches = list(proc(_paired_stream(40, 2, 2, 0)))
+    assert len(batches) == 3                                                               # yield_limit / batch
+    for b in batches:
+        assert b.batch_size == 8 and int(b.ground_truth.sum()) == 4
+        for p, s, g in zip(b.primary_keys, b.secondary_keys, b.ground_truth.tolist()):
+            assert (p.split("/")[0] == s.split("/")[0]) == bool(g) and p != s
+    f = tmp_path / "trials.txt"
+    f.write_text("1 a/b/c.wav a/d/e.wav\nbroken line\n0 a/b/c.wav x/y/z.wav\n")
+    got = list(read_test_pairs_file(f))
+    assert [(p.same_speaker, p.sample1_id) for p in got] == [(True, "a/b/c.wav"), (False, "a/b/c.wav")]

@@ -6,7 +6,10 @@ from .pipeline import (AudioChunkSelector, BatchProcessor, InputNormalizer2D, Sp
 from .shards import find_shards, iter_shard, read_meta, write_shards
 from .loader import DeviceFeeder, ShardDataset
 from .fbank import Fbank, FilterBank
+from .paired import (EvaluationPair, PairedBatchProcessor, PairedSpeakerClassificationDataSample,
+                     paired_default_collate_fn, read_test_pairs_file)
 
 __all__ = ["AudioChunkSelector", "BatchProcessor", "InputNormalizer2D", "SpeakerClassificationDataSample",
            "default_collate_fn", "find_shards", "iter_shard", "read_meta", "write_shards", "DeviceFeeder",
-           "ShardDataset", "Fbank", "FilterBank"]
+           "ShardDataset", "Fbank", "FilterBank", "EvaluationPair", "PairedBatchProcessor",
+           "PairedSpeakerClassificationDataSample", "paired_default_collate_fn", "read_test_pairs_file"]
