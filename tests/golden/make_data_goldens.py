@@ -1,7 +1,8 @@
-"""Golden vectors for the pair batcher: runs the REFERENCE's PairedBatchProcessor (authoring container only; needs
-/root/reference) on a seeded synthetic sample stream and records which ordered pairs each batch holds.
+"""Golden vectors for the host-side data pipeline: runs the REFERENCE's PairedBatchProcessor, BatchProcessor and
+AudioChunkSelector (authoring container only; needs /root/reference) on seeded synthetic sample streams and records
+which (ordered pairs of) keys each batch holds and which crops are taken.
 
-    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_paired_goldens.py
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_data_goldens.py
 """
 import json
 import os
@@ -71,7 +72,37 @@ proc = PairedBatchProcessor(batch_size=4, max_queue_size=8, mode="reproduce", se
                             collate_fn=PairedSpeakerClassificationDataBatch.default_collate_fn, pairs=pairs)
 out["cases"].append({"mode": "reproduce", "batch_size": 4, "pairs": [[bool(p.same_speaker), p.sample1_id, p.sample2_id] for p in pairs],
                      "n_speakers": 5, "per_speaker": 4, "seq": 2, "seed": 1, "batches": record(proc(iter(samples)))})
-path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "paired_batcher.json")
+# ---- single-sample shuffle queue (voxceleb.py:829-886) and the chunk selector (random_chunks.py)
+from src.data.modules.speaker.voxceleb import BatchProcessor  # noqa: E402
+from src.data.modules.speaker.training_batch_speaker import SpeakerClassificationDataBatch  # noqa: E402
+from src.data.preprocess.random_chunks import AudioChunkSelector  # noqa: E402
+
+out["batch_processor"] = []
+for bs, qs, n_spk, seed in [(4, 10, 9, 2), (5, 5, 4, 8), (3, 64, 5, 1)]:
+    random.seed(seed)
+    bp = BatchProcessor(bs, qs, SpeakerClassificationDataBatch.default_collate_fn)
+    got = [list(b.keys) for b in bp(stream(n_spk, 2, 2, seed))]
+    out["batch_processor"].append({"max_batch_size": bs, "max_queue_size": qs, "n_speakers": n_spk, "seed": seed,
+                                   "batches": got})
+out["chunk_selector"] = []
+for strategy in ["start", "end", "random", "random_contiguous", "contiguous"]:
+    for n, sec in [(1000, 0.02), (321, 0.02), (200, 0.02)]:       # chunk = 320 samples at 16 kHz
+        random.seed(n + len(strategy))
+        sel = AudioChunkSelector(strategy, sec)
+        res = []
+        for rep in range(3):
+            smp = SpeakerClassificationDataSample(key="k", ground_truth=0,
+                                                  network_input=torch.arange(n, dtype=torch.float32).view(1, n),
+                                                  side_info=None)
+            try:
+                r = sel.process(smp)
+                r = r if isinstance(r, list) else [r]
+                res.append([[x.key, int(x.network_input[0, 0]), int(x.network_input.shape[-1])] for x in r])
+            except ValueError as e:
+                res.append("ValueError")
+        out["chunk_selector"].append({"strategy": strategy, "n": n, "sec": sec, "seed": n + len(strategy),
+                                      "results": res})
+path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data_pipeline.json")
 with open(path, "w") as f:
     json.dump(out, f, indent=0)
 print("wrote", path, [len(c["batches"]) for c in out["cases"]])

@@ -111,13 +111,13 @@ def _paired_stream(n_speakers, per_speaker, seq, seed):
 
 
 def test_paired_batch_processor_matches_reference_goldens():
-    """tests/golden/paired_batcher.json was produced by the reference's own PairedBatchProcessor
-    (tests/golden/make_paired_goldens.py): same seed -> the same ordered pairs in the same batches."""
+    """tests/golden/data_pipeline.json was produced by the reference's own PairedBatchProcessor
+    (tests/golden/make_data_goldens.py): same seed -> the same ordered pairs in the same batches."""
     import json
     import os
     import random
     from w2v2_speaker_amd.data.paired import EvaluationPair, PairedBatchProcessor
-    with open(os.path.join(os.path.dirname(__file__), "golden", "paired_batcher.json")) as f:
+    with open(os.path.join(os.path.dirname(__file__), "golden", "data_pipeline.json")) as f:
         gold = json.load(f)
     for case in gold["cases"]:
         if case["mode"] == "generate":
@@ -162,3 +162,32 @@ def test_paired_batch_processor_properties_and_errors(tmp_path):
     f.write_text("1 a/b/c.wav a/d/e.wav\nbroken line\n0 a/b/c.wav x/y/z.wav\n")
     got = list(read_test_pairs_file(f))
     assert [(p.same_speaker, p.sample1_id) for p in got] == [(True, "a/b/c.wav"), (False, "a/b/c.wav")]
+
+
+def test_batch_processor_and_chunk_selector_match_reference_goldens():
+    """Same golden file: the reference's BatchProcessor (shuffle queue) and AudioChunkSelector were run on seeded
+    inputs; ours must pop / crop identically under the same ``random.seed``."""
+    import json
+    import os
+    import random
+    from w2v2_speaker_amd.data import AudioChunkSelector, BatchProcessor, SpeakerClassificationDataSample
+    with open(os.path.join(os.path.dirname(__file__), "golden", "data_pipeline.json")) as f:
+        gold = json.load(f)
+    for c in gold["batch_processor"]:
+        random.seed(c["seed"])
+        bp = BatchProcessor(c["max_batch_size"], c["max_queue_size"])
+        got = [list(b.keys) for b in bp(_paired_stream(c["n_speakers"], 2, 2, c["seed"]))]
+        assert got == c["batches"], c
+    for c in gold["chunk_selector"]:
+        random.seed(c["seed"])
+        sel = AudioChunkSelector(c["strategy"], c["sec"])
+        for want in c["results"]:
+            smp = SpeakerClassificationDataSample(key="k", ground_truth=0,
+                                                  network_input=torch.arange(c["n"], dtype=torch.float32).view(1, -1))
+            if want == "ValueError":
+                with pytest.raises(ValueError):
+                    sel.process(smp)
+                continue
+            r = sel.process(smp)
+            r = r if isinstance(r, list) else [r]
+            assert [[x.key, int(x.network_input[0, 0]), int(x.network_input.shape[-1])] for x in r] == want, c
