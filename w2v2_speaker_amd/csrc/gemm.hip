@@ -893,6 +893,14 @@ __global__ __launch_bounds__(512) void gemm_bf16_glds4_kernel(const GemmArgs g) 
       for (int j = 0; j < 2; ++j)
         __builtin_amdgcn_global_load_lds((gvoid_t*)(bp[j] + kt * BK), (lvoid_t*)(bd + j * 16 * BK), 16, 0, 0);
     };
+    auto stage_piece = [&](int off, int kt, int j) {       // piece j of 4: A0, A1, B0, B1
+      if (j < 2)
+        __builtin_amdgcn_global_load_lds((gvoid_t*)(ap[j] + kt * BK),
+                                         (lvoid_t*)(smem + off + (wave * 2 + j) * 16 * BK), 16, 0, 0);
+      else
+        __builtin_amdgcn_global_load_lds((gvoid_t*)(bp[j - 2] + kt * BK),
+                                         (lvoid_t*)(smem + off + BM * BK + (wave * 2 + j - 2) * 16 * BK), 16, 0, 0);
+    };
     // wait until all but the `newer` youngest stages of this wave's DMA have landed (4 pieces per stage)
     auto wait_stages = [&](int newer) {
       if (newer >= 2) wait_vmcnt<8>(); else if (newer == 1) wait_vmcnt<4>(); else wait_vmcnt<0>();
@@ -901,7 +909,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_glds4_kernel(const GemmArgs g) 
     __builtin_amdgcn_s_barrier();          // every wave has finished reading the previous tile's stages
 #pragma unroll
     for (int st = 0; st < S - 1; ++st)
-      if (st < nk) stage(st * STAGE, st);
+      if (st < nk && !(g.dbg & 4)) stage(st * STAGE, st);
     wait_stages(min(nk, S - 1) - 1 > 2 ? 2 : min(nk, S - 1) - 1);
     __builtin_amdgcn_s_barrier();
     bf16x8 af[FM], bcur[FN], bnext[FN], alast;
@@ -917,7 +925,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_glds4_kernel(const GemmArgs g) 
       // stage kt+1 landed (own pieces), then everyone's: newer stages in flight = min(S - 3, nk - kt - 2)
       wait_stages(min(S - 3, nk - kt - 2));
       __builtin_amdgcn_s_barrier();
-      if (kt + S - 1 < nk) stage(fb, kt + S - 1);
+      // the four DMA pieces of stage kt+S-1 are spread over the MFMA groups: issued back to back behind the barrier
+      // they hold BOTH waves of a SIMD in the (slow, queue-limited) DMA issue while the matrix pipe idles
+      const bool do_stage = kt + S - 1 < nk && !(g.dbg & 4);
+      const bool spread = !(g.dbg & 16);
+      if (do_stage && !spread) stage(fb, kt + S - 1);
       const bf16_t* pa = smem + nb + la;
       const bf16_t* pb = smem + nb + lb;
       // the next step's B fragments go out behind the first MFMA group: the compiler's wait in front of that group
@@ -934,6 +946,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_glds4_kernel(const GemmArgs g) 
           alast = *reinterpret_cast<const bf16x8*>(pa + (FM - 1) * 16 * BK);   // early: nothing may trail the last group
         }
         if (i < FM - 1) af[i] = *reinterpret_cast<const bf16x8*>(pa + i * 16 * BK);
+        if ((i & 1) && do_stage && spread) stage_piece(fb, kt + S - 1, i >> 1);
         __builtin_amdgcn_sched_barrier(0);
       }
       af[FM - 1] = alast;
@@ -954,6 +967,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_glds4_kernel(const GemmArgs g) 
     TC* auxz = g.aux ? reinterpret_cast<TC*>(g.aux) + z0 * g.aux_s0 + z1 * g.aux_s1 : nullptr;
     const float* bias = g.bias ? g.bias + z1 * g.bias_s1 : nullptr;
     const int nc = n0 + wn * 64 + fk * 16;
+    if ((g.dbg & 2) && acc[0][0][0] != 12345.f) continue;      // timing experiments: no epilogue
     float cv0[8], cv1[8];
     load_col8(g, bias, nc, cv0);
     load_col8(g, bias, nc + 8, cv1);
