@@ -759,7 +759,18 @@ __global__ __launch_bounds__(512) void gemm_bf16_glds3_kernel(const GemmArgs g) 
   const int lb0 = brow * 64 + ((fk ^ swz(frow)) << 3);
   const int lb1 = brow * 64 + (((4 + fk) ^ swz(frow)) << 3);
   const int aoff = wm * 64 * 64, boff = BM * 64 + wn * 64 * 64;
-  auto compute = [&](const bf16_t* base) {
+  // piece p of the 6 DMA pieces of one stage: A0..A3, B0, B1
+  auto stage_piece = [&](bf16_t* base, int kt, int p) {
+    if (p < 4)
+      __builtin_amdgcn_global_load_lds((gvoid_t*)(ap[p] + kt * 64), (lvoid_t*)(base + (wave * 4 + p) * 8 * 64), 16, 0,
+                                       0);
+    else
+      __builtin_amdgcn_global_load_lds((gvoid_t*)(bp[p - 4] + kt * 64),
+                                       (lvoid_t*)(base + BM * 64 + (wave * 2 + p - 4) * 8 * 64), 16, 0, 0);
+  };
+  // multiply stage `base`; when kload >= 0 the DMA pieces of K tile kload go to `nxt`, spread over the MFMA groups
+  // (issued back to back behind the barrier they keep both waves of a SIMD in the queue-limited DMA issue)
+  auto compute = [&](const bf16_t* base, bf16_t* nxt, int kload) {
     const bf16_t* a0 = base + aoff + lo0;
     const bf16_t* a1 = base + aoff + lo1;
     const bf16_t* b0 = base + boff + lb0;
@@ -772,10 +783,20 @@ __global__ __launch_bounds__(512) void gemm_bf16_glds3_kernel(const GemmArgs g) 
 #pragma unroll
       for (int j = 0; j < FN; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>((kk ? b1 : b0) + j * 4 * 64);
 #pragma unroll
-      for (int i = 0; i < FM; ++i)
+      for (int i = 0; i < FM; ++i) {
 #pragma unroll
         for (int j = 0; j < FN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+        if (kload >= 0) {
+          __builtin_amdgcn_sched_barrier(0);
+          if (kk == 0) {
+            stage_piece(nxt, kload, i);                  // pieces 0..3 behind the four groups of the first half
+          } else if (i < 2) {
+            stage_piece(nxt, kload, 4 + i);              // pieces 4, 5
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
     }
   };
   bf16_t* s0 = smem;
@@ -787,8 +808,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_glds3_kernel(const GemmArgs g) 
   {                                                                \
     if (kt + 1 < nk) wait_vmcnt<6>(); else wait_vmcnt<0>();        \
     __builtin_amdgcn_s_barrier();                                  \
-    if (kt + 2 < nk && !(g.dbg & 4)) stage(nxt, kt + 2);           \
-    if (!(g.dbg & 8)) compute(cur);                                \
+    const bool ld = kt + 2 < nk && !(g.dbg & 4);                   \
+    if (ld && (g.dbg & 16)) stage(nxt, kt + 2);                    \
+    if (!(g.dbg & 8)) compute(cur, nxt, (ld && !(g.dbg & 16)) ? kt + 2 : -1); \
     ++kt;                                                          \
   }
   __builtin_amdgcn_s_barrier();          // every wave has finished reading the previous tile's stages
