@@ -193,6 +193,12 @@ int w2v2_prepend_token(const void* x, void* y, float c, int B, int T, int H, int
  * partials that are folded in a fixed order (bitwise reproducible packed weights). */
 int w2v2_posconv_regroup(const void* x, void* xg, int B, int T, int H, int G, int K, int pad_left,
                          int dtype, void* stream);
+/* Weight gradient of the grouped positional conv as a correlation on the matrix cores (replaces the implicit-GEMM
+ * call for bf16): dY [B*T, H] bf16 = gradient at the conv output (before the weight-norm), xg [B, G, T+K-1, H/G]
+ * bf16 = posconv_regroup(x, pad_left = K/2); dwf [G][K*Cg][Cg] f32 is OVERWRITTEN (row (tap, ci), column co).
+ * Cg = H/G in {16, 32, 48, 64}, K a multiple of 16.  (ref: the autograd of HF:360-368 `self.conv`.) */
+int w2v2_posconv_wgrad(const void* dY, const void* xg, float* dwf, int B, int T, int H, int G, int K,
+                       void* stream);
 int w2v2_weightnorm_pack(const float* g, const float* v, float* sumsq /*[129*K]*/, void* wf,
                          void* wb, int H, int G, int K, int dtype, void* stream);
 int w2v2_weightnorm_bwd(const float* g, const float* v, const float* sumsq, const float* dwf,

@@ -777,3 +777,32 @@ def test_transpose_many_vector_and_scalar_paths():
     for (R, C, _), o in zip(shapes, offs):
         want = src[o:o + R * C].view(R, C).t().contiguous().view(-1)
         assert torch.equal(dst[o:o + R * C], want), (R, C)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,T,G,Cg,K", [(3, 149, 16, 48, 128), (2, 249, 16, 64, 128), (2, 37, 4, 16, 16),
+                                         (2, 170, 2, 32, 32)])
+def test_posconv_wgrad_correlation_kernel(B, T, G, Cg, K):
+    """dW[g][(j,c)][o] = sum_{b,t} xg[b,g,t+j,c] dY[b,t,g*Cg+o] against an f64 einsum on the same bf16 inputs
+    (T > 160 exercises the second time chunk, T = 37 the zero-filled tail rows)."""
+    import torch
+    from w2v2_speaker_amd import ops
+    dev = "cuda"
+    H = G * Cg
+    torch.manual_seed(B * 1000 + T)
+    x = torch.randn(B, T, H, device=dev).to(torch.bfloat16)
+    dY = torch.randn(B * T, H, device=dev).to(torch.bfloat16)
+    Tp = T + K - 1
+    xg = torch.zeros(B, G, Tp, Cg, dtype=torch.bfloat16, device=dev)
+    ops.posconv_regroup(x, xg, B, T, H, G, K, K // 2)
+    dwf = torch.full((G, K * Cg, Cg), float("nan"), dtype=torch.float32, device=dev)
+    ops.posconv_wgrad(dY, xg, dwf, B, T, H, G, K)
+    torch.cuda.synchronize()
+    xw = xg.double().unfold(2, T, 1)                     # [B, G, K, Cg, T]: xw[b,g,j,c,t] = xg[b,g,t+j,c]
+    dy = dY.double().view(B, T, G, Cg)
+    want = torch.einsum("bgjct,btgo->gjco", xw, dy).reshape(G, K * Cg, Cg)
+    err = float((dwf.double() - want).abs().max() / want.abs().max())
+    assert torch.isfinite(dwf).all() and err < 2e-5, err
+    dwf2 = torch.zeros_like(dwf)
+    ops.posconv_wgrad(dY, xg, dwf2, B, T, H, G, K)
+    assert torch.equal(dwf, dwf2)                        # deterministic

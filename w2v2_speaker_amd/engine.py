@@ -599,7 +599,10 @@ class Plan:
         ops.gelu_bwd(self.G, self.pos_pre, self.P1)
         ops.colsum(self.P1, mg("encoder.pos_conv_embed.conv.bias"), M, H)
         G_, K = cfg.num_conv_pos_embedding_groups, cfg.num_conv_pos_embeddings
-        self.g_pos_dw()
+        if self.P1.dtype == torch.bfloat16 and not os.environ.get("W2V2_POS_DW_GEMM"):
+            ops.posconv_wgrad(self.P1, self.xg, self.dwf, B, T, H, G_, K)      # correlation kernel (posconv_wgrad.hip)
+        else:
+            self.g_pos_dw()                                                    # exact-f32 mode: implicit GEMM
         ops.weightnorm_bwd(mp("encoder.pos_conv_embed.conv.parametrizations.weight.original0"),
                            mp("encoder.pos_conv_embed.conv.parametrizations.weight.original1"), self.pos_sumsq,
                            self.dwf, self.pos_dot, mg("encoder.pos_conv_embed.conv.parametrizations.weight.original0"),

@@ -318,6 +318,14 @@ def prepend_token(x, y, c: float) -> None:
 
 
 # ------------------------------------------------------------------------------------------------ pos-conv
+def posconv_wgrad(dY, xg, dwf, B: int, T: int, H: int, G: int, K: int) -> None:
+    """dwf[g][(tap, ci)][co] = sum_{b,t} xg[b,g,t+tap,ci] * dY[b,t,g*Cg+co]  (bf16 operands, f32 result, overwritten)."""
+    _dev(dY, xg, dwf)
+    assert dY.dtype == torch.bfloat16 and xg.dtype == torch.bfloat16 and dwf.dtype == torch.float32
+    _lib.check(lib().w2v2_posconv_wgrad(dY.data_ptr(), xg.data_ptr(), dwf.data_ptr(), B, T, H, G, K, stream()),
+               "posconv_wgrad")
+
+
 def posconv_regroup(x, xg, B: int, T: int, H: int, G: int, K: int, pad_left: int) -> None:
     _dev(x, xg)
     _lib.check(lib().w2v2_posconv_regroup(x.data_ptr(), xg.data_ptr(), B, T, H, G, K, pad_left, dt(x), stream()),
