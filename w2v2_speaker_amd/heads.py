@@ -43,7 +43,18 @@ class ClassifierHead:
             self.coldot = torch.empty(Cn, dtype=f32, device=dev)
             self.G1 = torch.empty(B, E, dtype=f32, device=dev)
             self.demb = torch.empty(B, E, dtype=f32, device=dev)
-            self.g_dx = Gemm(B, E, Cn, self.dcos_w, w_operand, self.G1, lda=self.ldc, ldb=E, ldc=E, transB=True)
+            # d emb = dcos_w [B, C] . W [C, E]: 66 rows = ONE row of tiles, so the class dimension is cut into S chunks
+            # (one batched launch + the ragged rest) whose f32 partials are then summed in a fixed order -- the single
+            # launch walked all 5994 classes on 12 workgroups (144 us)
+            S = max(1, min(16, Cn // 256))
+            Kc = (Cn // S) // 8 * 8 if S > 1 else Cn
+            rest = Cn - S * Kc
+            self.dx_parts = torch.empty(S + (1 if rest else 0), B, E, dtype=f32, device=dev)
+            self.g_dx = [Gemm(B, E, Kc, self.dcos_w, w_operand, self.dx_parts, lda=self.ldc, ldb=E, ldc=E, transB=True,
+                              batch=S, batch_inner=S, a_strides=(0, Kc), b_strides=(0, Kc * E), c_strides=(0, B * E))]
+            if rest:
+                self.g_dx.append(Gemm(B, E, rest, self.dcos_w.view(-1)[S * Kc:], w_operand.view(-1)[S * Kc * E:],
+                                      self.dx_parts[S], lda=self.ldc, ldb=E, ldc=E, transB=True))
             if aam:
                 self.H1 = torch.empty(Cn, E, dtype=f32, device=dev)
                 self.g_dw = Gemm(Cn, E, B, self.dcos_x, self.emb_lp, self.H1, lda=self.ldc, ldb=E, ldc=E,
@@ -73,7 +84,10 @@ class ClassifierHead:
                                 B, Cn, self.ldc, self.margin if aam else -1.0, self.scale)
         loss = self.loss_rows.mean()
         if tr:
-            self.g_dx()
+            for g in self.g_dx:
+                g()
+            self.G1.zero_()
+            ops.colsum(self.dx_parts, self.G1.view(-1), self.dx_parts.shape[0], B * E)    # <= 128 rows: one writer
             if aam:
                 ops.normalize_bwd(self.G1, self.emb, self.inv_x, self.rowdot, self.demb, B, E)
                 self.g_dw()
