@@ -196,7 +196,9 @@ def test_base_bf16_fused_attention_vs_reference_and_vs_f32_mode():
     assert rel_l2(emb.cpu(), g["train.embedding"]) < 3e-2
     assert abs(float(loss) - float(g["train.loss"])) < 3e-2 * abs(float(g["train.loss"]))
     norms = dict(zip(g["grad_names"].tolist(), g["grad_norms"].tolist()))
-    floor = 1e-3 * max(norms.values())
+    # gradients that cancel analytically (k_proj: softmax is invariant to a shift of the keys) are pure bf16 rounding
+    # noise of ~1e-3 of the largest gradient norm; the floor has to sit above that noise, not at it
+    floor = 2e-3 * max(norms.values())
     bad = []
     for n, ref in norms.items():
         name = n if n.startswith("loss_fn") else "wav2vec.model." + n

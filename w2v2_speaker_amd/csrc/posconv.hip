@@ -61,7 +61,28 @@ __global__ __launch_bounds__(256) void tap_reduce_kernel(const float* __restrict
   const int kpt = threadIdx.x % K, rlane = threadIdx.x / K, rlanes = 256 / K;
   float acc = 0.f;
   if (rlane < rlanes) {
-    for (int r = blockIdx.x * rlanes + rlane; r < rows; r += gridDim.x * rlanes) {
+    const int stride = gridDim.x * rlanes;
+    int r = blockIdx.x * rlanes + rlane;
+    // eight independent loads in flight per thread (the loop is latency-bound: 128 blocks x 144 dependent trips, and
+    // the dwf operand is a 9 KiB-stride gather); the accumulation order is the plain loop's
+    for (; r + 7 * stride < rows; r += 8 * stride) {
+      float t[8], d[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int ru = r + u * stride;
+        t[u] = v[(int64_t)ru * K + kpt];
+        if constexpr (WITH_DW) {
+          const int o = ru / Cg, i = ru - o * Cg;
+          const int g = o / Cg, co = o - g * Cg;
+          d[u] = dwf[(((int64_t)g * K + kpt) * Cg + i) * Cg + co];
+        } else {
+          d[u] = t[u];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += t[u] * d[u];
+    }
+    for (; r < rows; r += stride) {
       const float vv = v[(int64_t)r * K + kpt];
       if constexpr (WITH_DW) {
         const int o = r / Cg, i = r - o * Cg;
