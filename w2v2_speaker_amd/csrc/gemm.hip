@@ -14,6 +14,7 @@
 //               (embeddings within 1e-3 rel-L2 of the f32 reference, BASELINE.json north_star);
 //               throughput runs use bf16.
 #include "common.cuh"
+#include <type_traits>
 #include <stdlib.h>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -46,6 +47,7 @@ struct GemmArgs {
   int c_vec_ok;    // 8-element vector stores to C legal
   int aux_vec_ok;  // 8-element vector access to aux legal
   int dbg;
+  int defer_ok;    // 256x128 ring kernel: stores of a tile may be issued under the next tile's main loop
 };
 
 __device__ __forceinline__ int64_t outer_off(const OpDev& o, int64_t idx) {
@@ -152,10 +154,10 @@ __device__ __forceinline__ void epilogue_store4(const GemmArgs& g, TC* __restric
 // ONCE per thread (a thread keeps the same 8 columns for every row it stores) and the aux rows of a
 // whole pass are fetched up front with 16-byte loads, so no global-load latency sits between the LDS
 // read-back and the store.  The kind is wave-uniform: one scalar branch selects a specialised body.
-template <typename TC, int EPI>
+template <typename TC, int EPI, bool DEFER = false>
 __device__ __forceinline__ void epilogue_row8_impl(const GemmArgs& g, TC* __restrict__ Cz, TC* __restrict__ auxz,
                                                    int m, int n, float (&v)[8], const float (&cv)[8],
-                                                   const float (&ax)[8], bool lead) {
+                                                   const float (&ax)[8], bool lead, uint4* dout = nullptr) {
   const bool full = n + 8 <= g.N;
   float pre[8];
   float rs = 1.0f;
@@ -171,6 +173,11 @@ __device__ __forceinline__ void epilogue_row8_impl(const GemmArgs& g, TC* __rest
     v[e] = x;
   }
   TC* cp = Cz + (int64_t)m * g.ldc + n;
+  if constexpr (DEFER) {             // deferred store (host guarantees full, aligned, non-atomic, single output)
+    *dout = make_uint4(f32x2_to_bf16x2(v[0], v[1]), f32x2_to_bf16x2(v[2], v[3]), f32x2_to_bf16x2(v[4], v[5]),
+                       f32x2_to_bf16x2(v[6], v[7]));
+    return;
+  }
   if (g.atomic) {
     if constexpr (sizeof(TC) == 4) {
 #pragma unroll
@@ -263,10 +270,10 @@ __device__ __forceinline__ void load_col8(const GemmArgs& g, const float* __rest
   }
 }
 
-template <typename TC, int EPI, int FM, int I0>
+template <typename TC, int EPI, int FM, int I0, bool DEFER = false>
 __device__ __forceinline__ void epilogue_direct4(const GemmArgs& g, TC* __restrict__ Cz, TC* __restrict__ auxz,
                                                  f32x4 (&acc)[FM][4], int m, int n, const float (&cv0)[8],
-                                                 const float (&cv1)[8]) {
+                                                 const float (&cv1)[8], uint4 (&pend)[8]) {
   // row fragments I0 .. I0+3 of the wave tile (rows m + 16 i); four at a time bounds the aux staging registers
   float ax[4][16];
   if constexpr (EPI == W2V2_EPI_GELU_BWD || EPI == W2V2_EPI_ADD) {
@@ -295,7 +302,7 @@ __device__ __forceinline__ void epilogue_direct4(const GemmArgs& g, TC* __restri
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int mi = m + 16 * (I0 + i);
-    if (mi >= g.M) continue;
+    if (mi >= g.M && !DEFER) continue;                 // (deferred: rows past M are dropped at the flush)
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       if (n + 8 * h >= g.N) continue;
@@ -305,7 +312,10 @@ __device__ __forceinline__ void epilogue_direct4(const GemmArgs& g, TC* __restri
       float a8[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) a8[e] = (EPI == W2V2_EPI_GELU_BWD || EPI == W2V2_EPI_ADD) ? ax[i][8 * h + e] : 0.f;
-      epilogue_row8_impl<TC, EPI>(g, Cz, auxz, mi, n + 8 * h, v, h ? cv1 : cv0, a8, true);
+      if constexpr (DEFER && FM == 4)
+        epilogue_row8_impl<TC, EPI, true>(g, Cz, auxz, mi, n + 8 * h, v, h ? cv1 : cv0, a8, true, &pend[i * 2 + h]);
+      else
+        epilogue_row8_impl<TC, EPI>(g, Cz, auxz, mi, n + 8 * h, v, h ? cv1 : cv0, a8, true);
     }
   }
 }
@@ -315,8 +325,9 @@ __device__ __forceinline__ void epilogue_direct(const GemmArgs& g, TC* __restric
                                                 f32x4 (&acc)[FM][4], int m, int n, const float (&cv0)[8],
                                                 const float (&cv1)[8]) {
   if (n >= g.N) return;
-  epilogue_direct4<TC, EPI, FM, 0>(g, Cz, auxz, acc, m, n, cv0, cv1);
-  if constexpr (FM > 4) epilogue_direct4<TC, EPI, FM, 4>(g, Cz, auxz, acc, m, n, cv0, cv1);
+  uint4 unused[8];
+  epilogue_direct4<TC, EPI, FM, 0>(g, Cz, auxz, acc, m, n, cv0, cv1, unused);
+  if constexpr (FM > 4) epilogue_direct4<TC, EPI, FM, 4>(g, Cz, auxz, acc, m, n, cv0, cv1, unused);
 }
 
 #define W2V2_EPI_DISPATCH(CALL)                                              \
@@ -698,6 +709,24 @@ __global__ __launch_bounds__(512) void gemm_bf16_glds3_kernel(const GemmArgs g) 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // 0..7
   const int wm = wave >> 1, wn = wave & 1;
 
+  // Deferred stores (g.defer_ok): the 8 x 16-byte stores of a tile are kept packed in registers and issued in the
+  // first three ring steps of the NEXT tile (ahead of that step's DMA pieces, so the counted vmcnt waits stay valid):
+  // issued together at the tile end they leave at the HBM write rate (~9 B/clk per CU) while nothing else runs.
+  uint4 pend[8];
+  bool pending = false;
+  int pend_m = 0, pend_n = 0;
+  TC* const Cdef = reinterpret_cast<TC*>(g.C) + (blockIdx.z / g.batch_inner) * g.c_s0 +
+                   (blockIdx.z % g.batch_inner) * g.c_s1;
+  auto flush = [&](auto first, auto count) {
+    if constexpr (sizeof(TC) == 2) {
+#pragma unroll
+      for (int q = decltype(first)::value; q < decltype(first)::value + decltype(count)::value; ++q) {
+        const int mi = pend_m + 16 * (q >> 1);
+        if (mi < g.M)
+          *reinterpret_cast<uint4*>(Cdef + (int64_t)mi * g.ldc + pend_n + 8 * (q & 1)) = pend[q];
+      }
+    }
+  };
   // Persistent over tiles: gridDim.x = min(tiles, CUs) workgroups, each takes tiles t, t + G, ...  (one 144 KiB
   // workgroup per CU anyway).  The next tile's first two DMA stages are issued right behind the epilogue's stores,
   // so their latency -- and a workgroup launch -- hides under the store drain instead of following it.
@@ -817,6 +846,28 @@ __global__ __launch_bounds__(512) void gemm_bf16_glds3_kernel(const GemmArgs g) 
   if (nk > 0 && !(g.dbg & 4)) stage(s0, 0);
   if (nk > 1 && !(g.dbg & 4)) stage(s1, 1);
   int kt = 0;
+  if (pending) {
+    if (nk >= 3) {                                         // one peeled rotation of the ring carries the stores
+      wait_vmcnt<6>();
+      __builtin_amdgcn_s_barrier();
+      flush(std::integral_constant<int, 0>{}, std::integral_constant<int, 3>{});
+      compute(s0, s2, nk > 2 ? 2 : -1);
+      kt = 1;
+      wait_vmcnt<6>();
+      __builtin_amdgcn_s_barrier();
+      flush(std::integral_constant<int, 3>{}, std::integral_constant<int, 3>{});
+      compute(s1, s0, nk > 3 ? 3 : -1);
+      kt = 2;
+      if (nk > 3) wait_vmcnt<6>(); else wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+      flush(std::integral_constant<int, 6>{}, std::integral_constant<int, 2>{});
+      compute(s2, s1, nk > 4 ? 4 : -1);
+      kt = 3;
+    } else {
+      flush(std::integral_constant<int, 0>{}, std::integral_constant<int, 8>{});
+    }
+    pending = false;
+  }
   while (kt < nk) {
     W2V2_RING_STEP(s0, s2)
     if (kt >= nk) break;
@@ -837,8 +888,16 @@ __global__ __launch_bounds__(512) void gemm_bf16_glds3_kernel(const GemmArgs g) 
   float cv0[8], cv1[8];
   load_col8(g, bias, nc, cv0);
   load_col8(g, bias, nc + 8, cv1);
-  W2V2_EPI_DISPATCH((epilogue_direct<TC, EPI, 4>(g, Cz, auxz, acc, m0 + wm * 64 + frow, nc, cv0, cv1)));
+  if (sizeof(TC) == 2 && g.defer_ok) {
+    W2V2_EPI_DISPATCH((epilogue_direct4<TC, EPI, 4, 0, true>(g, Cz, auxz, acc, m0 + wm * 64 + frow, nc, cv0, cv1, pend)));
+    pending = true;
+    pend_m = m0 + wm * 64 + frow;
+    pend_n = nc;
+  } else {
+    W2V2_EPI_DISPATCH((epilogue_direct<TC, EPI, 4>(g, Cz, auxz, acc, m0 + wm * 64 + frow, nc, cv0, cv1)));
+  }
   }   // tile loop
+  if (pending) flush(std::integral_constant<int, 0>{}, std::integral_constant<int, 8>{});
 }
 
 // ------------------------------------------------------------------------------ 256 x 256 x 32, 4-stage ring
@@ -1187,6 +1246,8 @@ extern "C" int w2v2_gemm(const w2v2_gemm_desc* d, void* stream) {
   a.row_scale = d->row_scale; a.col_scale = d->col_scale;
   a.alpha = d->alpha;
   a.dbg = getenv("W2V2_GEMM_DBG") ? atoi(getenv("W2V2_GEMM_DBG")) : 0;
+  static const bool defer_env = getenv("W2V2_NO_DEFER") == nullptr;   // A/B switch
+  a.defer_ok = 0;
   const int cal = d->dtype_c == W2V2_F32 ? 4 : 8;     // elements per 16 bytes
   a.c_vec_ok = aligned16(d->C) && (d->ldc % cal == 0) && (d->c_stride0 % cal == 0) && (d->c_stride1 % cal == 0);
   a.aux_vec_ok = d->aux && aligned16(d->aux) && (d->ldaux % cal == 0) && (d->aux_stride0 % cal == 0) &&
@@ -1216,6 +1277,8 @@ extern "C" int w2v2_gemm(const w2v2_gemm_desc* d, void* stream) {
       if (d->dtype_c == W2V2_F32) launch_glds4<float>(a, d->M, d->N, d->batch, st);
       else launch_glds4<bf16_t>(a, d->M, d->N, d->batch, st);
     } else if (big) {
+      a.defer_ok = defer_env && d->dtype_c == W2V2_BF16 && a.c_vec_ok && (d->N % 128 == 0) && !atomic &&
+                   d->epilogue != W2V2_EPI_BIAS_GELU;
       if (d->dtype_c == W2V2_F32) launch_glds3<float>(a, d->M, d->N, d->batch, st);
       else launch_glds3<bf16_t>(a, d->M, d->N, d->batch, st);
     } else if (glds) {
