@@ -302,7 +302,7 @@ __device__ __forceinline__ void epilogue_direct4(const GemmArgs& g, TC* __restri
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int mi = m + 16 * (I0 + i);
-    if (mi >= g.M && !DEFER) continue;                 // (deferred: rows past M are dropped at the flush)
+    if (mi >= g.M) continue;                           // (deferred: the flush repeats this test)
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       if (n + 8 * h >= g.N) continue;
