@@ -1063,6 +1063,10 @@ static int device_cus() {
     (void)hipGetDevice(&dev);
     if (hipDeviceGetAttribute(&g_w2v2_ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || g_w2v2_ncu <= 0)
       g_w2v2_ncu = 256;
+    // data-parallel runs: the persistent ring kernels fill every CU's registers, so RCCL's all-reduce workgroups
+    // (side stream) only run between them; W2V2_RESERVE_CUS=n keeps n CUs out of the persistent grids
+    const char* r = getenv("W2V2_RESERVE_CUS");
+    if (r && atoi(r) > 0 && atoi(r) < g_w2v2_ncu) g_w2v2_ncu -= atoi(r);
   }
   return g_w2v2_ncu;
 }
