@@ -155,6 +155,15 @@ int w2v2_layernorm_bwd(const void* dy, const void* s, const float* mean, const f
                        const float* gamma, void* ds, void* d_r, float* dgamma, float* dbeta,
                        float* workspace, int M, int H, float drop_p, uint64_t seed, int dtype,
                        void* stream);
+/* Deferred fold: call w2v2_layernorm_bwd with dgamma = dbeta = NULL and a workspace -> the per-block column partials
+ * stay in the workspace (one workspace per LayerNorm); this entry folds up to 8 of them (same M, H) into their
+ * dgamma / dbeta (+=, fixed order) in ONE launch. */
+typedef struct {
+  const float* partial;    /* the workspace given to w2v2_layernorm_bwd */
+  float* dgamma;
+  float* dbeta;
+} w2v2_ln_fold;
+int w2v2_layernorm_bwd_fold(const w2v2_ln_fold* entries, int n, int M, int H, void* stream);
 
 /* ---------------------------------------------------------------------------------- elementwise */
 /* nn.Dropout fwd == bwd (same mask): y = x * keep(seed,i)/(1-p); in place allowed. */

@@ -31,6 +31,10 @@ class GemmDesc(C.Structure):
                 ("alpha", c_f32), ("split_k", c_i32), ("accumulate", c_i32), ("_pad", c_i32)]
 
 
+class LnFold(C.Structure):
+    _fields_ = [("partial", c_vp), ("dgamma", c_vp), ("dbeta", c_vp)]
+
+
 class WgradProblem(C.Structure):
     _fields_ = [("dY", c_vp), ("ld_dy", c_i64), ("X", c_vp), ("ld_x", c_i64), ("dW", c_vp), ("ld_dw", c_i64),
                 ("dbias", c_vp), ("n_out", c_i32), ("n_in", c_i32)]
@@ -55,6 +59,7 @@ _SIGS = {
     "w2v2_layernorm_bwd_workspace_floats": (c_i32, [c_i32]),
     "w2v2_layernorm_bwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32,
                                    c_f32, c_u64, c_i32, c_vp]),
+    "w2v2_layernorm_bwd_fold": (c_i32, [C.POINTER(LnFold), c_i32, c_i32, c_i32, c_vp]),
     "w2v2_dropout": (c_i32, [c_vp, c_vp, c_i64, c_f32, c_u64, c_i32, c_vp]),
     "w2v2_gelu_bwd": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, c_vp]),
     "w2v2_add": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, c_vp]),

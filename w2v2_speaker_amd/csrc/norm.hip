@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
       }
     }
   }
-  if (dgamma == nullptr) return;
+  if (dgamma == nullptr && partial == nullptr) return;
   // cross-wave reduction of the per-lane column partials, then one atomic per column per block
   for (int pass = 0; pass < 2; ++pass) {
     __syncthreads();
@@ -188,6 +188,51 @@ __global__ __launch_bounds__(256) void ln_bwd_finalize_kernel(const float* __res
   }
 }
 
+// the same fold for up to 8 LayerNorms in one launch (blockIdx.y selects the entry): the engine defers the folds of a
+// gradient bucket (two transformer blocks = four LayerNorms) to a single launch instead of four 6-us ones
+struct LnFoldArgs {
+  const float* partial[8];
+  float* dgamma[8];
+  float* dbeta[8];
+};
+__global__ __launch_bounds__(256) void ln_bwd_finalize_many_kernel(const LnFoldArgs a, int nblk, int H) {
+  __shared__ float red[8][32];
+  const float* __restrict__ partial = a.partial[blockIdx.y];
+  const int cl = threadIdx.x & 31, bl = threadIdx.x >> 5;
+  const int i = blockIdx.x * 32 + cl;                 // index into [2][H]
+  float s = 0.f;
+  if (i < 2 * H) {
+    const int pass = i / H, col = i - pass * H;
+#pragma unroll 8
+    for (int b = bl; b < nblk; b += 8) s += partial[((int64_t)b * 2 + pass) * H + col];
+  }
+  red[bl][cl] = s;
+  __syncthreads();
+  if (bl == 0 && i < 2 * H) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += red[k][cl];
+    const int pass = i / H, col = i - pass * H;
+    float* dst = (pass == 0 ? a.dgamma[blockIdx.y] : a.dbeta[blockIdx.y]) + col;
+    *dst += t;
+  }
+}
+
+extern "C" int w2v2_layernorm_bwd_fold(const w2v2_ln_fold* e, int n, int M, int H, void* stream) {
+  W2V2_REQUIRE(e && n >= 0 && n <= 8 && H > 0, "layernorm_bwd_fold: bad arguments (at most 8 entries)");
+  if (n == 0 || M <= 0) return 0;
+  LnFoldArgs a;
+  for (int i = 0; i < n; ++i) {
+    W2V2_REQUIRE(e[i].partial && e[i].dgamma && e[i].dbeta, "layernorm_bwd_fold: null pointer in entry %d", i);
+    a.partial[i] = e[i].partial; a.dgamma[i] = e[i].dgamma; a.dbeta[i] = e[i].dbeta;
+  }
+  const int nb = (int)(cdiv(M, 4) < 512 ? cdiv(M, 4) : 512);
+  hipLaunchKernelGGL(ln_bwd_finalize_many_kernel, dim3((unsigned)cdiv(2 * H, 32), n), dim3(256), 0, as_stream(stream),
+                     a, nb, H);
+  W2V2_CHECK_LAUNCH("layernorm_bwd_fold");
+  return 0;
+}
+
 extern "C" int w2v2_layernorm_fwd(const void* x, void* r, const float* gamma, const float* beta, void* y,
                                   float* mean, float* rstd, int M, int H, float eps, float drop_p,
                                   uint64_t seed, int dtype, void* stream) {
@@ -219,7 +264,8 @@ extern "C" int w2v2_layernorm_bwd(const void* dy, const void* s, const float* me
   W2V2_REQUIRE((dgamma == nullptr) == (dbeta == nullptr), "layernorm_bwd: dgamma/dbeta must come together");
   if (M <= 0) return 0;
   const int nb = (int)(cdiv(M, 4) < 512 ? cdiv(M, 4) : 512);
-  float* partial = dgamma ? workspace : nullptr;
+  // dgamma == NULL with a workspace: leave the per-block partials in it for w2v2_layernorm_bwd_fold
+  float* partial = workspace;
   if (dtype == W2V2_BF16)
     hipLaunchKernelGGL(ln_bwd_kernel<bf16_t>, dim3(nb), dim3(256), 0, as_stream(stream), (const bf16_t*)dy,
                        (const bf16_t*)s, mean, rstd, gamma, (bf16_t*)ds, (bf16_t*)d_r, dgamma, dbeta, partial, M, H,
@@ -230,7 +276,7 @@ extern "C" int w2v2_layernorm_bwd(const void* dy, const void* s, const float* me
                        drop_p, seed);
   else
     W2V2_FAIL("layernorm_bwd: bad dtype %d", dtype);
-  if (partial != nullptr)
+  if (partial != nullptr && dgamma != nullptr)
     hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3((unsigned)cdiv(2 * H, 32)), dim3(256), 0, as_stream(stream),
                        partial, dgamma, dbeta, nb, H);
   W2V2_CHECK_LAUNCH("layernorm_bwd");

@@ -528,11 +528,16 @@ class Plan:
         pa, ph = reg.attention_dropout, reg.hidden_dropout
         Ltop = cfg.num_hidden_layers - 1
         held = None            # upper layer of a pair whose weight-gradient launch waits for its partner
+        if getattr(self, "_lnfold", None) is None:
+            self._lnfold = ops.LnFoldGroup(H, self.dev)
+        lnfold = self._lnfold if not os.environ.get("W2V2_NO_LN_FOLD") else None
         for l in reversed(range(cfg.num_hidden_layers)):
             upper = (Ltop - l) % 2 == 0 and l > 0 and l in self.g_wgrad_pair     # l pairs with l-1
             if l in self._skip:
                 if held is not None:                  # partner skipped by LayerDrop: the held layer goes alone
                     self.g_layer[held]["wgrad"]()
+                    if lnfold is not None:
+                        lnfold.fold()
                     notify(f"layer{held}")
                     held = None
                 notify(f"layer{l}")
@@ -544,7 +549,7 @@ class Plan:
             # x2 = LN2(x1 + drop(f)):  G <- ds2 (residual path), Gd <- df = ds2 * dropmask
             ops.layernorm_bwd(self.G, lb.f, lb.mean2, lb.rstd2, mp(pre + "final_layer_norm.weight"), self.G, gs["Gd"],
                               mg(pre + "final_layer_norm.weight"), mg(pre + "final_layer_norm.bias"), ph,
-                              self._sd("ffn", l, step))
+                              self._sd("ffn", l, step), defer_to=lnfold)
             if not grouped:
                 gl["dW2"]()
                 ops.colsum(gs["Gd"], mg(pre + "feed_forward.output_dense.bias"), M, H)
@@ -558,7 +563,7 @@ class Plan:
             # x1 = LN1(x + drop(a)):  G <- ds1, Gd1 <- da
             ops.layernorm_bwd(self.G, lb.a, lb.mean1, lb.rstd1, mp(pre + "layer_norm.weight"), self.G, gs["Gd1"],
                               mg(pre + "layer_norm.weight"), mg(pre + "layer_norm.bias"), ph,
-                              self._sd("post_attn", l, step))
+                              self._sd("post_attn", l, step), defer_to=lnfold)
             if not grouped:
                 gl["dWo"]()
                 ops.colsum(gs["Gd1"], mg(pre + "attention.out_proj.bias"), M, H)
@@ -587,6 +592,8 @@ class Plan:
             if defer:
                 held = l
                 continue
+            if lnfold is not None:
+                lnfold.fold()                         # gamma / beta of the bucket's LayerNorms: one launch
             if held is not None:
                 notify(f"layer{held}")
                 held = None

@@ -252,14 +252,51 @@ def _ln_workspace(H: int, device) -> torch.Tensor:
     return _LN_WS[key]
 
 
-def layernorm_bwd(dy, s, mean, rstd, gamma, ds, d_r, dgamma, dbeta, drop_p: float = 0.0, seed: int = 0) -> None:
+def layernorm_bwd(dy, s, mean, rstd, gamma, ds, d_r, dgamma, dbeta, drop_p: float = 0.0, seed: int = 0,
+                  defer_to: Optional["LnFoldGroup"] = None) -> None:
+    """With ``defer_to`` the column partials stay in a workspace of that group and dgamma/dbeta are folded later by
+    ``defer_to.fold()`` (one launch for up to 8 LayerNorms)."""
     _dev(dy, s, mean, rstd, gamma, ds, d_r, dgamma, dbeta)
     H = dy.shape[-1]
     M = dy.numel() // H
+    if defer_to is not None and dgamma is not None:
+        ws = defer_to.add(dgamma, dbeta, M, H)
+        _lib.check(lib().w2v2_layernorm_bwd(dy.data_ptr(), s.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                            gamma.data_ptr(), ds.data_ptr(), _p(d_r), None, None, ws.data_ptr(), M, H,
+                                            drop_p, seed, dt(dy), stream()), "layernorm_bwd")
+        return
     ws = _ln_workspace(H, dy.device) if dgamma is not None else None
     _lib.check(lib().w2v2_layernorm_bwd(dy.data_ptr(), s.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
                                         gamma.data_ptr(), ds.data_ptr(), _p(d_r), _p(dgamma), _p(dbeta), _p(ws), M, H,
                                         drop_p, seed, dt(dy), stream()), "layernorm_bwd")
+
+
+class LnFoldGroup:
+    """Pending LayerNorm gamma/beta folds of one gradient bucket: each deferred layernorm_bwd gets its own workspace
+    slot (allocated once), fold() issues ONE w2v2_layernorm_bwd_fold launch for all of them."""
+
+    def __init__(self, H: int, device, slots: int = 8):
+        n = lib().w2v2_layernorm_bwd_workspace_floats(H)
+        self._ws = torch.empty(slots, n, dtype=torch.float32, device=device)
+        self._arr = (_lib.LnFold * slots)()
+        self._n, self._M, self._H, self._keep = 0, 0, H, []
+
+    def add(self, dgamma, dbeta, M: int, H: int) -> torch.Tensor:
+        if self._n == len(self._arr):
+            self.fold()
+        assert H == self._H and (self._n == 0 or M == self._M)
+        e = self._arr[self._n]
+        e.partial, e.dgamma, e.dbeta = self._ws[self._n].data_ptr(), dgamma.data_ptr(), dbeta.data_ptr()
+        self._keep.append((dgamma, dbeta))
+        self._M = M
+        self._n += 1
+        return self._ws[self._n - 1]
+
+    def fold(self) -> None:
+        if self._n:
+            _lib.check(lib().w2v2_layernorm_bwd_fold(self._arr, self._n, self._M, self._H, stream()),
+                       "layernorm_bwd_fold")
+        self._n, self._keep = 0, []
 
 
 # ------------------------------------------------------------------------------------------------ elementwise
