@@ -806,3 +806,34 @@ def test_posconv_wgrad_correlation_kernel(B, T, G, Cg, K):
     dwf2 = torch.zeros_like(dwf)
     ops.posconv_wgrad(dY, xg, dwf2, B, T, H, G, K)
     assert torch.equal(dwf, dwf2)                        # deterministic
+
+
+@pytest.mark.gpu
+def test_layernorm_bwd_deferred_fold_equals_immediate():
+    """w2v2_layernorm_bwd with dgamma = NULL + w2v2_layernorm_bwd_fold (one launch for several LayerNorms) must give
+    bitwise the same dgamma / dbeta and ds as the immediate path."""
+    import torch
+    from w2v2_speaker_amd import ops
+    dev = "cuda"
+    M, H = 66 * 149, 768
+    torch.manual_seed(5)
+    group = ops.LnFoldGroup(H, dev)
+    want, got = [], []
+    for k in range(3):
+        dy = torch.randn(M, H, device=dev).to(torch.bfloat16)
+        s = torch.randn(M, H, device=dev).to(torch.bfloat16)
+        mean, rstd = torch.randn(M, device=dev), torch.rand(M, device=dev) + 0.5
+        gamma = torch.randn(H, device=dev)
+        out = []
+        for defer in (None, group):
+            ds, dr = torch.empty_like(dy), torch.empty_like(dy)
+            dg, db = torch.full((H,), 0.25, device=dev), torch.full((H,), -1.0, device=dev)   # fold ADDS
+            ops.layernorm_bwd(dy, s, mean, rstd, gamma, ds, dr, dg, db, 0.1, 11 + k, defer_to=defer)
+            out.append((ds, dr, dg, db))
+        want.append(out[0])
+        got.append(out[1])
+    group.fold()
+    torch.cuda.synchronize()
+    for w, g in zip(want, got):
+        for a, b in zip(w, g):
+            assert torch.equal(a, b)
