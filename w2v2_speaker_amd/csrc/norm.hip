@@ -3,6 +3,9 @@
 #include "common.cuh"
 
 constexpr int LN_MAXC = 2;  // vec8 chunks per lane: H <= 1024
+// workgroups of the backward (= rows of the gamma/beta partial buffer): four 4-wave workgroups per CU; the kernel is
+// held to 128 VGPRs so that all of them are resident
+constexpr int LN_BWD_BLOCKS = 1024;
 
 template <typename T>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, T* __restrict__ r,
@@ -69,7 +72,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, T*
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ s,
+__global__ __launch_bounds__(256, 4) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ s,
                                                      const float* __restrict__ mean,
                                                      const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, T* __restrict__ ds,
@@ -226,7 +229,7 @@ extern "C" int w2v2_layernorm_bwd_fold(const w2v2_ln_fold* e, int n, int M, int 
     W2V2_REQUIRE(e[i].partial && e[i].dgamma && e[i].dbeta, "layernorm_bwd_fold: null pointer in entry %d", i);
     a.partial[i] = e[i].partial; a.dgamma[i] = e[i].dgamma; a.dbeta[i] = e[i].dbeta;
   }
-  const int nb = (int)(cdiv(M, 4) < 512 ? cdiv(M, 4) : 512);
+  const int nb = (int)(cdiv(M, 4) < LN_BWD_BLOCKS ? cdiv(M, 4) : LN_BWD_BLOCKS);
   hipLaunchKernelGGL(ln_bwd_finalize_many_kernel, dim3((unsigned)cdiv(2 * H, 32), n), dim3(256), 0, as_stream(stream),
                      a, nb, H);
   W2V2_CHECK_LAUNCH("layernorm_bwd_fold");
@@ -253,7 +256,7 @@ extern "C" int w2v2_layernorm_fwd(const void* x, void* r, const float* gamma, co
   return 0;
 }
 
-extern "C" int w2v2_layernorm_bwd_workspace_floats(int H) { return 512 * 2 * H; }
+extern "C" int w2v2_layernorm_bwd_workspace_floats(int H) { return LN_BWD_BLOCKS * 2 * H; }
 
 extern "C" int w2v2_layernorm_bwd(const void* dy, const void* s, const float* mean, const float* rstd,
                                   const float* gamma, void* ds, void* d_r, float* dgamma, float* dbeta,
@@ -263,7 +266,7 @@ extern "C" int w2v2_layernorm_bwd(const void* dy, const void* s, const float* me
   W2V2_REQUIRE(H % 8 == 0 && H <= 8 * 64 * LN_MAXC, "layernorm_bwd: H=%d unsupported", H);
   W2V2_REQUIRE((dgamma == nullptr) == (dbeta == nullptr), "layernorm_bwd: dgamma/dbeta must come together");
   if (M <= 0) return 0;
-  const int nb = (int)(cdiv(M, 4) < 512 ? cdiv(M, 4) : 512);
+  const int nb = (int)(cdiv(M, 4) < LN_BWD_BLOCKS ? cdiv(M, 4) : LN_BWD_BLOCKS);
   // dgamma == NULL with a workspace: leave the per-block partials in it for w2v2_layernorm_bwd_fold
   float* partial = workspace;
   if (dtype == W2V2_BF16)
