@@ -102,7 +102,7 @@ __device__ __forceinline__ bf16_t c0_lo(float x) { return f32_to_bf16(x - bf16_t
 constexpr int C0_CPB = 5;        // 128-frame chunks per workgroup: amortises the weight / scale fragments
 
 template <bool APPLY>
-__global__ __launch_bounds__(256) void conv0_mfma_kernel(const float* __restrict__ wav, const float* __restrict__ w,
+__global__ __launch_bounds__(256, 2) void conv0_mfma_kernel(const float* __restrict__ wav, const float* __restrict__ w,
                                                          float* __restrict__ partial, const float* __restrict__ mr,
                                                          const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, bf16_t* __restrict__ y,
