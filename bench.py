@@ -89,7 +89,7 @@ def main():
     ap.add_argument("--batch", type=int, default=66, help="utterances per GPU (paper batch size)")
     ap.add_argument("--seconds", type=float, default=3.0)
     ap.add_argument("--speakers", type=int, default=5994)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--dtype", default="bf16", choices=["f16", "bf16", "f32"])
     ap.add_argument("--pooling", default="mean+std", choices=["mean+std", "attentive", "first+cls"],
                     help="mean+std = the metric's workload; attentive = BASELINE configs[2]")
     ap.add_argument("--model", default="base", choices=["base", "large"],
@@ -125,7 +125,7 @@ def main():
 
     cfg = W2V2Config.from_huggingface_id("facebook/wav2vec2-" + args.model)
     n_samples = int(round(args.seconds * 16000))
-    adt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    adt = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[args.dtype]
     store = ParamStore(cfg, dev, adt, head="aam", num_speakers=args.speakers, freeze_cnn=not args.unfreeze_cnn,
                        attentive_pool=args.pooling == "attentive",
                        embed_dim=cfg.hidden_size * (1 if args.pooling == "first+cls" else 2))
@@ -171,7 +171,7 @@ def main():
             "value": round(utt / elapsed, 2), "unit": "utterances/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16" if adt == torch.bfloat16 else "f32", "data": "synthetic",
+            "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"wav2vec2-{args.model} + AAM-softmax({args.speakers}), {args.pooling} pooling, "
                                    f"{args.seconds:g} s synthetic audio, "
                                    f"bs={args.batch} per GPU, CNN {'trainable' if args.unfreeze_cnn else 'frozen'}, "
@@ -180,6 +180,8 @@ def main():
                        "global_batch": args.batch * world, "samples_per_utt": n_samples,
                        "parallelism": f"dp{world}", "regularisation": not args.no_regularisation,
                        "final_loss": round(float(loss), 4)},
+            "loss_scale": (None if store.scaler is None else
+                           {"scale": float(store.scaler[0]), "skipped_steps": int(store.scaler[3])}),
             "utt_per_sec_per_gpu": round(utt / elapsed / world, 2),
             "model_tflops_per_gpu": round(fl["train_full" if args.unfreeze_cnn else "train_frozen_cnn"] * utt / elapsed
                                           / world / 1e12, 2),

@@ -13,8 +13,10 @@
  *     workspace); the library never allocates or frees device memory and keeps no pointer past a call.
  *   - every call only ENQUEUES work on `stream` (a hipStream_t passed as void*); no implicit sync.
  *   - return 0 on success, negative on error; w2v2_last_error() gives the message (thread local).
- *   - dtype codes: W2V2_F32 = 0, W2V2_BF16 = 1.  "act dtype" is the storage type of activations;
- *     statistics, reductions, biases, LayerNorm/GroupNorm parameters and gradients are always f32.
+ *   - dtype codes: W2V2_F32 = 0, W2V2_BF16 = 1, W2V2_F16 = 2 (IEEE half: the precision of the reference's own
+ *     fp16-AMP runs, config/experiment/speaker_wav2vec2_aam.yaml:17; its backward runs under the loss scale of
+ *     w2v2_grad_scaler_*).  "act dtype" is the storage type of activations; statistics, reductions, biases,
+ *     LayerNorm/GroupNorm parameters and gradients are always f32.
  *   - activations are channels-last: [B, T, C] row-major ("tokens x channels").
  */
 #ifndef W2V2_HIP_H
@@ -29,6 +31,7 @@ extern "C" {
 
 #define W2V2_F32 0
 #define W2V2_BF16 1
+#define W2V2_F16 2
 
 int w2v2_version(void);
 const char* w2v2_last_error(void);
@@ -91,7 +94,7 @@ int w2v2_gemm(const w2v2_gemm_desc* d, void* stream);
 
 /* Grouped weight-gradient GEMM (the backward of HF:520-526,544,565-572 nn.Linear weights/biases):
  *   dW_p[o][i] = sum_t dY_p[t][o] * X_p[t][i]      dbias_p[o] = sum_t dY_p[t][o]   (dbias may be NULL)
- * for 1..12 (dY, X) pairs in ONE launch, bf16 operands [tokens][features] (K-major), f32 results
+ * for 1..12 (dY, X) pairs in ONE launch, 16-bit operands [tokens][features] (K-major), f32 results
  * WRITTEN (not accumulated), no split-K, no atomics -> bitwise reproducible.
  * Contract: rows [tokens, tokens_padded) of every dY / X are readable and zero
  * (tokens_padded = tokens rounded up to 64); n_out, n_in multiples of 8; 16-byte aligned rows. */
@@ -103,7 +106,7 @@ typedef struct {
   int32_t n_out, n_in;
 } w2v2_wgrad_problem;
 int w2v2_wgrad_grouped(const w2v2_wgrad_problem* problems, int n, int tokens, int tokens_padded,
-                       void* stream);
+                       int dtype /* W2V2_BF16 or W2V2_F16: element type of dY and X */, void* stream);
 
 /* ------------------------------------------------------------------------ conv feature extractor
  * Layer 0 of HF:382-419: Conv1d(1->C,k,stride,no bias) + GroupNorm(C groups == per-(b,c) over time,
@@ -203,11 +206,11 @@ int w2v2_prepend_token(const void* x, void* y, float c, int B, int T, int H, int
 int w2v2_posconv_regroup(const void* x, void* xg, int B, int T, int H, int G, int K, int pad_left,
                          int dtype, void* stream);
 /* Weight gradient of the grouped positional conv as a correlation on the matrix cores (replaces the implicit-GEMM
- * call for bf16): dY [B*T, H] bf16 = gradient at the conv output (before the weight-norm), xg [B, G, T+K-1, H/G]
- * bf16 = posconv_regroup(x, pad_left = K/2); dwf [G][K*Cg][Cg] f32 is OVERWRITTEN (row (tap, ci), column co).
+ * call for 16-bit activations): dY [B*T, H] = gradient at the conv output (before the weight-norm), xg [B, G, T+K-1, H/G]
+ * = posconv_regroup(x, pad_left = K/2); dwf [G][K*Cg][Cg] f32 is OVERWRITTEN (row (tap, ci), column co).
  * Cg = H/G in {16, 32, 48, 64}, K a multiple of 16.  (ref: the autograd of HF:360-368 `self.conv`.) */
 int w2v2_posconv_wgrad(const void* dY, const void* xg, float* dwf, int B, int T, int H, int G, int K,
-                       void* stream);
+                       int dtype /* W2V2_BF16 or W2V2_F16 */, void* stream);
 int w2v2_weightnorm_pack(const float* g, const float* v, float* sumsq /*[129*K]*/, void* wf,
                          void* wb, int H, int G, int K, int dtype, void* stream);
 int w2v2_weightnorm_bwd(const float* g, const float* v, const float* sumsq, const float* dwf,
@@ -279,10 +282,11 @@ int w2v2_asp_context_bwd(const void* x, const float* ctx, const void* da, const 
 
 /* Paired-input head (ref: src/lightning_modules/speaker/wav2vec2_paired_input.py:200-206 nn.Linear(H,1) on the CLS
  * token + src/optim/loss/binary_cross_entropy.py:24-40): prob = sigmoid(emb.w + b), loss_rows = BCE-with-logits per
- * pair (mean taken by the caller); gradient outputs (all or none): dlogit[B] = (p-y)/B, demb[B][H], dw[H], db[1]. */
+ * pair (mean taken by the caller); gradient outputs (all or none): dlogit[B] = (p-y)/B, demb[B][H], dw[H], db[1],
+ * all multiplied by *loss_scale when that device pointer is given. */
 int w2v2_bce_head_fwd_bwd(const float* emb, const float* w, const float* b, const int64_t* label, float* prob,
                           float* loss_rows, float* dlogit, float* demb, float* dw, float* db, int B, int H,
-                          void* stream);
+                          const float* loss_scale, void* stream);
 
 /* ------------------------------------------------------------------------------ ECAPA-TDNN pieces
  * ref: src/lightning_modules/speaker/ecapa_tdnn.py:75-85 -> speechbrain 0.5.x ECAPA_TDNN (not part of the reference
@@ -326,11 +330,14 @@ int w2v2_row_invnorm(const void* x, int64_t ld, float* inv, int rows, int cols, 
  * and for the backward, with g = dLoss/dcos (loss = mean over B):
  *   dcos_w[b][c] = g * inv_w[c]   (A operand of the embedding-gradient GEMM; inv_w NULL -> g)
  *   dcos_x[b][c] = g * inv_x[b]   (A operand of the weight-gradient GEMM;    inv_x NULL -> g)
- *   rowdot[b] = sum_c g*cos,  coldot[c] += sum_b g*cos (caller zeroes coldot); any may be NULL. */
+ *   rowdot[b] = sum_c g*cos,  coldot[c] += sum_b g*cos (caller zeroes coldot); any may be NULL.
+ * loss_scale (device pointer, may be NULL = 1): g is multiplied by *loss_scale (w2v2_grad_scaler_*); the loss
+ * rows and the softmax are never scaled.  Labels outside [0, C) give loss = NaN for that row and zero gradients. */
 int w2v2_aam_softmax_fwd_bwd(const float* cos, const int64_t* label, float* softmax,
                              float* loss_rows, void* dcos_w, void* dcos_x, const float* inv_x,
                              const float* inv_w, float* rowdot, float* coldot, int B, int C,
-                             int64_t ldc, float margin, float scale, int dtype, void* stream);
+                             int64_t ldc, float margin, float scale, const float* loss_scale, int dtype,
+                             void* stream);
 /* F.normalize backward: dx = inv[r] * (g[r] - x[r] * inv[r] * dot[r]);  g, dx f32 (dx written or
  * added), x f32 or act dtype. */
 int w2v2_normalize_bwd(const float* g, const void* x, int64_t ldx, const float* inv,
@@ -339,11 +346,23 @@ int w2v2_normalize_bwd(const float* g, const void* x, int64_t ldx, const float* 
 
 /* ------------------------------------------------------------------------------------ optimiser
  * torch.optim.Adam (ref: config/optim/algo/adam.yaml, src/main.py:323-335) over one flat f32
- * parameter arena; also refreshes the bf16 copy the GEMMs read (pb may be NULL).  grad_scale
- * folds the 1/world_size of the data-parallel average. */
-int w2v2_adam_step(float* p, const float* g, float* m, float* v, void* pb, int64_t n, float lr,
+ * parameter arena; also refreshes the 16-bit copy (pb_dtype = W2V2_BF16 / W2V2_F16) the GEMMs read
+ * (pb may be NULL).  grad_scale folds the 1/world_size of the data-parallel average.
+ * scaler_state (may be NULL): the 4-float device record of w2v2_grad_scaler_*: gradients are divided by
+ * state[0] and the whole step is skipped when state[1] != 0. */
+int w2v2_adam_step(float* p, const float* g, float* m, float* v, void* pb, int pb_dtype, int64_t n, float lr,
                    float beta1, float beta2, float eps, float bias_corr1, float bias_corr2,
-                   float grad_scale, void* stream);
+                   float grad_scale, const float* scaler_state, void* stream);
+
+/* Dynamic loss scaling for fp16 activations = torch.cuda.amp.GradScaler, which PL `precision: 16` of the
+ * reference's runs installs (ref: config/experiment/speaker_wav2vec2_aam.yaml:17).
+ * state (device, 4 floats) = {scale, found_inf, growth_tracker, skipped_steps}; the heads multiply the loss
+ * gradient by state[0] (w2v2_aam_softmax_fwd_bwd / w2v2_bce_head_fwd_bwd `loss_scale`), so every gradient of the
+ * step carries it.  check: state[1] = 1 if any of g[0..n) is non-finite.  update (after the optimiser step):
+ * found_inf ? scale *= backoff : (every growth_interval clean steps scale *= growth); clears found_inf.
+ * No host synchronisation anywhere. */
+int w2v2_grad_scaler_check(const float* g, int64_t n, float* state, void* stream);
+int w2v2_grad_scaler_update(float* state, float growth, float backoff, int growth_interval, void* stream);
 
 #ifdef __cplusplus
 }

@@ -24,8 +24,7 @@ def rnd(*shape, seed=0, scale=1.0, dtype=torch.float32):
     return (torch.randn(*shape, generator=g) * scale).to(dtype)
 
 
-def bf(t):
-    return t.to(torch.bfloat16)
+LP16 = [torch.bfloat16, torch.float16]      # the two 16-bit activation formats of the matrix-core kernels
 
 
 def gelu(x):
@@ -36,8 +35,8 @@ def gelu(x):
 def _gemm_case(o, M, N, K, ta, tb, dtype, cdtype, epi="none", split=1, seed=0):
     A = rnd(M, K, seed=seed + 1, scale=0.5)
     Bm = rnd(N, K, seed=seed + 2, scale=0.5)
-    if dtype == torch.bfloat16:
-        A, Bm = bf(A).float(), bf(Bm).float()
+    if dtype != torch.float32:
+        A, Bm = A.to(dtype).float(), Bm.to(dtype).float()
     ref = A.double() @ Bm.double().t()
     Ad = (A.t().contiguous() if ta else A).to(dtype).to(DEV)
     Bd = (Bm.t().contiguous() if tb else Bm).to(dtype).to(DEV)
@@ -48,8 +47,8 @@ def _gemm_case(o, M, N, K, ta, tb, dtype, cdtype, epi="none", split=1, seed=0):
     kw = {}
     bias = rnd(N, seed=seed + 3)
     aux_host = rnd(M, ldc, seed=seed + 4)
-    if cdtype == torch.bfloat16:
-        aux_host = bf(aux_host).float()
+    if cdtype != torch.float32:
+        aux_host = aux_host.to(cdtype).float()
     aux = None
     if epi == "bias":
         kw.update(epilogue=o.EPI_BIAS, bias=bias.to(DEV))
@@ -75,7 +74,7 @@ def _gemm_case(o, M, N, K, ta, tb, dtype, cdtype, epi="none", split=1, seed=0):
     o.gemm(M, N, K, Ad, Bd, C, lda=lda, ldb=ldb, ldc=ldc, transA=ta, transB=tb, alpha=1.0, split_k=split, **kw)
     torch.cuda.synchronize()
     got = C[:, :N].float().cpu().double()
-    tol = 2e-5 if dtype == torch.float32 else (1.2e-2 if cdtype == torch.bfloat16 else 2e-3)
+    tol = 2e-5 if dtype == torch.float32 else (1.2e-2 if cdtype != torch.float32 else 2e-3)
     err = rel_l2(got, ref)
     assert err < tol, (M, N, K, ta, tb, dtype, cdtype, epi, split, err)
     if epi == "bias_gelu":
@@ -84,56 +83,60 @@ def _gemm_case(o, M, N, K, ta, tb, dtype, cdtype, epi="none", split=1, seed=0):
 
 
 @pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, False), (True, True)])
-def test_gemm_bf16_layouts_and_ragged_shapes(ta, tb):
+@pytest.mark.parametrize("lp", LP16)
+def test_gemm_bf16_layouts_and_ragged_shapes(ta, tb, lp):
     o = ops()
     for (M, N, K) in [(256, 256, 128), (149, 48, 96), (300, 130, 200), (66, 5994, 72), (1000, 64, 6144 // 8)]:
-        _gemm_case(o, M, N, K, ta, tb, torch.bfloat16, torch.float32)
-    _gemm_case(o, 298, 768, 256, ta, tb, torch.bfloat16, torch.bfloat16)
+        _gemm_case(o, M, N, K, ta, tb, lp, torch.float32)
+    _gemm_case(o, 298, 768, 256, ta, tb, lp, lp)
 
 
-def test_gemm_bf16_identity_asymmetric():
+@pytest.mark.parametrize("lp", LP16)
+def test_gemm_bf16_identity_asymmetric(lp):
     """A = I with an asymmetric B: catches a transposed C write (guide rule 16)."""
     o = ops()
     n = 128
     Bm = torch.arange(n * n, dtype=torch.float32).view(n, n) % 251
     A = torch.eye(n)
     C = torch.zeros(n, n, dtype=torch.float32, device=DEV)
-    o.gemm(n, n, n, bf(A).to(DEV), bf(Bm).to(DEV), C, lda=n, ldb=n, ldc=n)
+    o.gemm(n, n, n, A.to(lp).to(DEV), Bm.to(lp).to(DEV), C, lda=n, ldb=n, ldc=n)
     torch.cuda.synchronize()
-    assert torch.equal(C.cpu(), bf(Bm).float().t())
+    assert torch.equal(C.cpu(), Bm.to(lp).float().t())
 
 
 @pytest.mark.parametrize("epi", ["bias", "bias_gelu", "gelu_bwd", "add", "scale_rc"])
-def test_gemm_epilogues(epi):
+@pytest.mark.parametrize("lp", LP16)
+def test_gemm_epilogues(epi, lp):
     o = ops()
-    _gemm_case(o, 200, 136, 160, False, False, torch.bfloat16, torch.bfloat16, epi)
-    _gemm_case(o, 200, 136, 160, False, True, torch.bfloat16, torch.float32, epi)
+    _gemm_case(o, 200, 136, 160, False, False, lp, lp, epi)
+    _gemm_case(o, 200, 136, 160, False, True, lp, torch.float32, epi)
     _gemm_case(o, 70, 52, 40, True, False, torch.float32, torch.float32, epi)
 
 
 @pytest.mark.parametrize("M,N,K", [(9834, 3072, 768), (32768, 2048, 64), (16384, 2004, 192), (2100, 768, 256),
                                    (9834, 768, 3072)])
 @pytest.mark.parametrize("epi", ["none", "bias_gelu", "gelu_bwd", "add"])
-def test_gemm_ring_kernels_at_full_size(M, N, K, epi):
+@pytest.mark.parametrize("lp", LP16)
+def test_gemm_ring_kernels_at_full_size(M, N, K, epi, lp):
     """The persistent LDS-DMA ring kernels only take products that fill the chip: 256x256 tiles (4-stage ring) for
     the first three shapes, 256x128 (3-stage) for the last two.  Ragged M, ragged N (2004: scalar tail path), K of
     only two ring steps, every fused epilogue; reference = f32 matmul of the same bf16-rounded operands."""
     o = ops()
     g = torch.Generator(device="cpu").manual_seed(M + N + K)
-    A = torch.randn(M, K, generator=g).to(torch.bfloat16).to(DEV)
-    Bm = (torch.randn(N, K, generator=g) / K ** 0.5).to(torch.bfloat16).to(DEV)
+    A = torch.randn(M, K, generator=g).to(lp).to(DEV)
+    Bm = (torch.randn(N, K, generator=g) / K ** 0.5).to(lp).to(DEV)
     ldc = (N + 7) // 8 * 8
-    C = torch.zeros(M, ldc, dtype=torch.bfloat16, device=DEV)
+    C = torch.zeros(M, ldc, dtype=lp, device=DEV)
     ref = A.float() @ Bm.float().t()
     kw = {}
     if epi == "bias_gelu":
         bias = torch.randn(N, generator=g).to(DEV)
-        aux = torch.zeros(M, ldc, dtype=torch.bfloat16, device=DEV)
+        aux = torch.zeros(M, ldc, dtype=lp, device=DEV)
         kw.update(epilogue=o.EPI_BIAS_GELU, bias=bias, aux=aux, ldaux=ldc)
         pre = ref + bias
         ref = torch.nn.functional.gelu(pre)
     elif epi in ("gelu_bwd", "add"):
-        aux = torch.randn(M, ldc, generator=g).to(torch.bfloat16).to(DEV)
+        aux = torch.randn(M, ldc, generator=g).to(lp).to(DEV)
         a = aux[:, :N].float()
         if epi == "add":
             kw.update(epilogue=o.EPI_ADD, aux=aux, ldaux=ldc)
@@ -153,7 +156,7 @@ def test_gemm_ring_kernels_at_full_size(M, N, K, epi):
 
 def test_gemm_split_k_and_accumulate():
     o = ops()
-    for dtype in (torch.bfloat16, torch.float32):
+    for dtype in (torch.bfloat16, torch.float16, torch.float32):
         _gemm_case(o, 192, 160, 2000, True, True, dtype, torch.float32, "none", split=5)
         _gemm_case(o, 192, 160, 2000, False, False, dtype, torch.float32, "bias", split=3)
 
@@ -165,15 +168,15 @@ def test_gemm_f32_exact(ta, tb):
         _gemm_case(o, M, N, K, ta, tb, torch.float32, torch.float32)
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 def test_gemm_batched_heads_and_implicit_conv(dtype):
     o = ops()
     # attention-style batch: q,k from a fused [B,T,3,heads,d] buffer
     B, T, heads, d = 2, 21, 3, 16
     H = heads * d
     qkv = rnd(B, T, 3 * H, seed=3, scale=0.5)
-    if dtype == torch.bfloat16:
-        qkv = bf(qkv).float()
+    if dtype != torch.float32:
+        qkv = qkv.to(dtype).float()
     q = qkv[:, :, :H].view(B, T, heads, d).transpose(1, 2)
     k = qkv[:, :, H:2 * H].view(B, T, heads, d).transpose(1, 2)
     ref = (q.double() @ k.double().transpose(2, 3)) * 0.25
@@ -189,8 +192,8 @@ def test_gemm_batched_heads_and_implicit_conv(dtype):
     Bn, L, Cin, Cout, kk, st = 3, 41, 32, 40, 3, 2
     x = rnd(Bn, L, Cin, seed=5)
     w = rnd(Cout, Cin, kk, seed=6, scale=0.2)
-    if dtype == torch.bfloat16:
-        x, w = bf(x).float(), bf(w).float()
+    if dtype != torch.float32:
+        x, w = x.to(dtype).float(), w.to(dtype).float()
     ref = torch.nn.functional.conv1d(x.transpose(1, 2).double(), w.double(), stride=st).transpose(1, 2)
     Lo = (L - kk) // st + 1
     wp = torch.zeros(Cout, kk * Cin, dtype=dtype, device=DEV)
@@ -203,7 +206,7 @@ def test_gemm_batched_heads_and_implicit_conv(dtype):
 
 
 # ----------------------------------------------------------------------------------------------- conv0
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 def test_conv0_groupnorm_gelu(dtype):
     o = ops()
     B, N, C, k, s = 3, 4000, 96, 10, 5
@@ -222,7 +225,8 @@ def test_conv0_groupnorm_gelu(dtype):
 
 
 @pytest.mark.parametrize("C,N", [(128, 4000), (512, 3333), (640, 1291)])
-def test_conv0_matrix_core_path(C, N):
+@pytest.mark.parametrize("lp", LP16)
+def test_conv0_matrix_core_path(C, N, lp):
     """bf16 outputs with C % 128 == 0 take the split-bf16 MFMA convolution (conv0.hip): f32-class statistics
     (mean / rstd within 1e-5 of the f64 reference), ragged tail chunk, several channel groups per wave."""
     o = ops()
@@ -233,7 +237,7 @@ def test_conv0_matrix_core_path(C, N):
     u = torch.nn.functional.conv1d(wav[:, None].double(), w.double(), stride=s)          # [B, C, L]
     ref = gelu(torch.nn.functional.group_norm(u, C, gamma.double(), beta.double(), eps=1e-5)).transpose(1, 2)
     L = ref.shape[1]
-    out = torch.zeros(B, L, C, dtype=torch.bfloat16, device=DEV)
+    out = torch.zeros(B, L, C, dtype=lp, device=DEV)
     work = o.conv0_workspace(B, N, C, k, s, DEV)
     o.conv0_groupnorm_gelu(wav.to(DEV), w.to(DEV), gamma.to(DEV), beta.to(DEV), out, work, k, s)
     torch.cuda.synchronize()
@@ -243,30 +247,32 @@ def test_conv0_matrix_core_path(C, N):
     assert (mr[..., 0] - mean_ref).abs().max() < 4 * 2.0 ** -16 * u.abs().max() / L ** 0.5
     assert ((mr[..., 1] - (var_ref + 1e-5).rsqrt()) / (var_ref + 1e-5).rsqrt()).abs().max() < 2e-5
     assert rel_l2(out.float().cpu(), ref) < 4e-3
-    # against the exact-f32 VALU kernel rounded to bf16: at most an occasional one-ulp flip
+    # against the exact-f32 VALU kernel rounded to the output format: at most an occasional one-ulp flip (the split
+    # product's 2^-16 error is 1/128 of a bf16 ulp but 1/16 of an fp16 ulp)
     out32 = torch.zeros(B, L, C, dtype=torch.float32, device=DEV)
     o.conv0_groupnorm_gelu(wav.to(DEV), w.to(DEV), gamma.to(DEV), beta.to(DEV), out32, work, k, s)
     torch.cuda.synchronize()
-    d = (out.float() - out32.to(torch.bfloat16).float()).abs().cpu()
-    assert (d > 0).float().mean() < 0.02 and rel_l2(out.float().cpu(), out32.cpu().double()) < 3e-3
+    d = (out.float() - out32.to(lp).float()).abs().cpu()
+    assert (d > 0).float().mean() < (0.02 if lp == torch.bfloat16 else 0.08) and rel_l2(out.float().cpu(), out32.cpu().double()) < 3e-3
 
 
 # ----------------------------------------------------------------------------------------------- LayerNorm
 @pytest.mark.parametrize("dtype,H", [(torch.float32, 768), (torch.bfloat16, 768), (torch.float32, 64),
-                                     (torch.bfloat16, 1024), (torch.float32, 512)])
+                                     (torch.bfloat16, 1024), (torch.float32, 512), (torch.float16, 768),
+                                     (torch.float16, 1024)])
 def test_layernorm_fwd_bwd(dtype, H):
     o = ops()
     M = 37
     x, r = rnd(M, H, seed=1), rnd(M, H, seed=2)
-    if dtype == torch.bfloat16:
-        x, r = bf(x).float(), bf(r).float()
+    if dtype != torch.float32:
+        x, r = x.to(dtype).float(), r.to(dtype).float()
     gamma, beta = 1 + 0.1 * rnd(H, seed=3), 0.1 * rnd(H, seed=4)
     dy = rnd(M, H, seed=5)
-    if dtype == torch.bfloat16:
-        dy = bf(dy).float()
+    if dtype != torch.float32:
+        dy = dy.to(dtype).float()
     xs = (x + r).double().requires_grad_(True)
-    if dtype == torch.bfloat16:
-        xs = bf(x + r).double().requires_grad_(True)       # the kernel saves s in bf16 and normalises that
+    if dtype != torch.float32:
+        xs = (x + r).to(dtype).double().requires_grad_(True)       # the kernel saves s in bf16 and normalises that
     gd = gamma.double().requires_grad_(True)
     bd = beta.double().requires_grad_(True)
     yref = torch.nn.functional.layer_norm(xs, (H,), gd, bd, 1e-5)
@@ -322,13 +328,13 @@ def test_layernorm_dropout_mask_consistent_fwd_bwd():
 
 
 # ----------------------------------------------------------------------------------------------- elementwise
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 def test_elementwise_family(dtype):
     o = ops()
     n = 8 * 1000 + 5
     a, b = rnd(n, seed=1), rnd(n, seed=2)
-    if dtype == torch.bfloat16:
-        a, b = bf(a).float(), bf(b).float()
+    if dtype != torch.float32:
+        a, b = a.to(dtype).float(), b.to(dtype).float()
     ad, bd = a.to(dtype).to(DEV), b.to(dtype).to(DEV)
     out = torch.zeros(n, dtype=dtype, device=DEV)
     o.add(ad, bd, out)
@@ -343,8 +349,8 @@ def test_elementwise_family(dtype):
     # colsum (vector path and ragged scalar path)
     for (M, N, ld) in [(333, 768, 768), (50, 30, 34)]:
         x = rnd(M, ld, seed=3)
-        if dtype == torch.bfloat16:
-            x = bf(x).float()
+        if dtype != torch.float32:
+            x = x.to(dtype).float()
         acc = torch.ones(N, device=DEV)
         o.colsum(x.to(dtype).to(DEV), acc, M, N, ld)
         torch.cuda.synchronize()
@@ -358,8 +364,8 @@ def test_elementwise_family(dtype):
     # mask fill fwd / bwd
     M, H = 40, 64
     h = rnd(M, H, seed=5)
-    if dtype == torch.bfloat16:
-        h = bf(h).float()
+    if dtype != torch.float32:
+        h = h.to(dtype).float()
     mask = (torch.arange(M) % 7 == 0)
     emb = rnd(H, seed=6)
     hd = h.to(dtype).to(DEV)
@@ -382,7 +388,7 @@ def test_elementwise_family(dtype):
 
 
 # ----------------------------------------------------------------------------------------------- pos-conv
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 def test_posconv_forward_backward(dtype):
     """Grouped weight-normed conv (HF:326-379) through regroup + weightnorm_pack + implicit GEMM."""
     o = ops()
@@ -393,8 +399,8 @@ def test_posconv_forward_backward(dtype):
     v = rnd(H, Cg, K, seed=3, scale=0.1)
     bias = 0.1 * rnd(H, seed=4)
     up = rnd(B, T, H, seed=5)
-    if dtype == torch.bfloat16:
-        x, up = bf(x).float(), bf(up).float()
+    if dtype != torch.float32:
+        x, up = x.to(dtype).float(), up.to(dtype).float()
     xr = x.double().requires_grad_(True)
     gr, vr = g.double().requires_grad_(True), v.double().requires_grad_(True)
     w = gr * vr / torch.sqrt((vr * vr).sum(dim=(0, 1), keepdim=True))
@@ -438,7 +444,7 @@ def test_posconv_forward_backward(dtype):
 
 
 # ----------------------------------------------------------------------------------------------- attention
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 def test_softmax_fwd_bwd_unfused(dtype):
     o = ops()
     rows, T, ld = 50, 149, 152
@@ -470,19 +476,20 @@ def _attn_ref(qkv, B, T, heads, d, mask=None, keep=1.0):
 
 
 @pytest.mark.parametrize("T", [149, 150, 249, 64, 12, 256])
-def test_fused_attention_fwd_bwd(T):
+@pytest.mark.parametrize("lp", LP16)
+def test_fused_attention_fwd_bwd(T, lp):
     o = ops()
     B, heads, d = 2, 3, 64
     H = heads * d
     qkv = rnd(B, T, 3 * H, seed=T, scale=1.0)
     qkv[..., :2 * H] *= 1.5                         # non-trivial softmax
-    qkv = bf(qkv).float()
-    dctx = bf(rnd(B, T, H, seed=T + 1)).float()
+    qkv = qkv.to(lp).float()
+    dctx = (rnd(B, T, H, seed=T + 1)).to(lp).float()
     qr = qkv.double().requires_grad_(True)
     ref = _attn_ref(qr, B, T, heads, d)
     ref.backward(dctx.double())
-    qd = qkv.to(torch.bfloat16).to(DEV)
-    ctx = torch.zeros(B, T, H, dtype=torch.bfloat16, device=DEV)
+    qd = qkv.to(lp).to(DEV)
+    ctx = torch.zeros(B, T, H, dtype=lp, device=DEV)
     lse = torch.zeros(B * heads * T, device=DEV)
     o.attention_fwd(qd, ctx, lse, B, T, heads, d, d ** -0.5, 0.0, 0)
     torch.cuda.synchronize()
@@ -490,16 +497,17 @@ def test_fused_attention_fwd_bwd(T):
     q_, k_ = [qkv[:, :, i * H:(i + 1) * H].reshape(B, T, heads, d).transpose(1, 2).double() for i in range(2)]
     lref = torch.logsumexp(q_ @ k_.transpose(2, 3) * d ** -0.5, dim=-1)
     assert float((lse.cpu().view(B, heads, T) - lref).abs().max()) < 2e-2
-    dqkv = torch.zeros(B, T, 3 * H, dtype=torch.bfloat16, device=DEV)
+    dqkv = torch.zeros(B, T, 3 * H, dtype=lp, device=DEV)
     delta = torch.zeros(B * heads * T, device=DEV)
-    o.attention_bwd(qd, ctx, dctx.to(torch.bfloat16).to(DEV), lse, dqkv, delta, B, T, heads, d, d ** -0.5, 0.0, 0)
+    o.attention_bwd(qd, ctx, dctx.to(lp).to(DEV), lse, dqkv, delta, B, T, heads, d, d ** -0.5, 0.0, 0)
     torch.cuda.synchronize()
     g = dqkv.float().cpu()
     for i, nm in enumerate("qkv"):
         assert rel_l2(g[..., i * H:(i + 1) * H], qr.grad[..., i * H:(i + 1) * H]) < 2e-2, (T, nm)
 
 
-def test_fused_attention_dropout_mask_recovered_and_consistent():
+@pytest.mark.parametrize("lp", LP16)
+def test_fused_attention_dropout_mask_recovered_and_consistent(lp):
     """T = 64: with q = k = 0 (uniform P) and V = identity the output IS the dropout mask; then the
     forward/backward with that exact mask must match the torch reference."""
     o = ops()
@@ -507,23 +515,23 @@ def test_fused_attention_dropout_mask_recovered_and_consistent():
     H = heads * d
     probe = torch.zeros(B, T, 3 * H)
     probe[..., 2 * H:] = torch.eye(T).repeat(1, heads)[None]
-    ctx = torch.zeros(B, T, H, dtype=torch.bfloat16, device=DEV)
+    ctx = torch.zeros(B, T, H, dtype=lp, device=DEV)
     lse = torch.zeros(B * heads * T, device=DEV)
-    o.attention_fwd(probe.to(torch.bfloat16).to(DEV), ctx, lse, B, T, heads, d, d ** -0.5, p, seed)
+    o.attention_fwd(probe.to(lp).to(DEV), ctx, lse, B, T, heads, d, d ** -0.5, p, seed)
     torch.cuda.synchronize()
     m = (ctx.float().cpu().view(B, T, heads, d).transpose(1, 2) > 0).double()       # [B,h,q,key]
     keep = float(m.mean())
     assert abs(keep - (1 - p)) < 0.02
-    qkv = bf(rnd(B, T, 3 * H, seed=5)).float()
-    dctx = bf(rnd(B, T, H, seed=6)).float()
+    qkv = (rnd(B, T, 3 * H, seed=5)).to(lp).float()
+    dctx = (rnd(B, T, H, seed=6)).to(lp).float()
     qr = qkv.double().requires_grad_(True)
     ref = _attn_ref(qr, B, T, heads, d, mask=m, keep=1 - p)
     ref.backward(dctx.double())
-    qd = qkv.to(torch.bfloat16).to(DEV)
+    qd = qkv.to(lp).to(DEV)
     o.attention_fwd(qd, ctx, lse, B, T, heads, d, d ** -0.5, p, seed)
-    dqkv = torch.zeros(B, T, 3 * H, dtype=torch.bfloat16, device=DEV)
+    dqkv = torch.zeros(B, T, 3 * H, dtype=lp, device=DEV)
     delta = torch.zeros(B * heads * T, device=DEV)
-    o.attention_bwd(qd, ctx, dctx.to(torch.bfloat16).to(DEV), lse, dqkv, delta, B, T, heads, d, d ** -0.5, p, seed)
+    o.attention_bwd(qd, ctx, dctx.to(lp).to(DEV), lse, dqkv, delta, B, T, heads, d, d ** -0.5, p, seed)
     torch.cuda.synchronize()
     assert rel_l2(ctx.float().cpu(), ref.detach()) < 1e-2
     assert rel_l2(dqkv.float().cpu(), qr.grad) < 2.5e-2
@@ -557,7 +565,7 @@ def test_dropout_stream_statistics():
 
 
 # ----------------------------------------------------------------------------------------------- attentive pooling
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 def test_attentive_pooling_stages_at_base_size(dtype):
     """Every stage of csrc/asp.hip (+ its GEMMs) at the BASELINE configs[2] size (T=149, C=768, A=128) against an
     f64 torch evaluation of the SAME stage on the stage's own inputs as stored by the HIP path -- so bf16 is tested
@@ -649,13 +657,13 @@ def test_attentive_pooling_stages_at_base_size(dtype):
 
 
 # ----------------------------------------------------------------------------------------------- pooling
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 def test_pooling_all_modes(dtype):
     o = ops()
     B, T, H = 3, 149, 768
     x = rnd(B, T, H, seed=1, scale=2.0) + 0.5
-    if dtype == torch.bfloat16:
-        x = bf(x).float()
+    if dtype != torch.float32:
+        x = x.to(dtype).float()
     xd = x.to(dtype).to(DEV)
     refs = {"mean+std": lambda t: torch.cat(torch.std_mean(t, dim=1), 1), "mean": lambda t: t.mean(1),
             "max": lambda t: t.max(1).values, "first": lambda t: t[:, 0], "last": lambda t: t[:, -1],
@@ -694,18 +702,19 @@ def test_pooling_golden_edges():
 
 
 # ----------------------------------------------------------------------------------------------- Adam
-def test_fused_adam_matches_torch_and_golden():
+@pytest.mark.parametrize("lp", LP16)
+def test_fused_adam_matches_torch_and_golden(lp):
     o = ops()
     g = np.load(os.path.join(GOLDEN, "g8_optim.npz"))
     p = torch.from_numpy(g["p0"]).clone().to(DEV)
     m, v = torch.zeros_like(p), torch.zeros_like(p)
-    pb = torch.zeros(16, dtype=torch.bfloat16, device=DEV)
+    pb = torch.zeros(16, dtype=lp, device=DEV)
     for i in range(100):
         gr = torch.from_numpy(g["grads"][i]).to(DEV)
         o.adam_step(p, gr, m, v, pb, 16, float(g["lr"][i]), float(g["beta1"][i]), 0.999, 1e-8, i + 1)
     torch.cuda.synchronize()
     assert np.allclose(p.cpu().numpy(), g["params"][99], atol=2e-7)
-    assert torch.equal(pb.cpu(), p.cpu().to(torch.bfloat16))
+    assert torch.equal(pb.cpu(), p.cpu().to(lp))
     n = 4 * 1000 + 3
     pp = rnd(n, seed=1)
     ref = torch.nn.Parameter(pp.clone())
@@ -721,12 +730,56 @@ def test_fused_adam_matches_torch_and_golden():
     assert np.allclose(pd.cpu().numpy(), ref.detach().numpy(), atol=1e-6)
 
 
+def test_grad_scaler_check_update_and_adam_skip():
+    """Dynamic loss scaling (csrc/optim.hip) = torch.cuda.amp.GradScaler: gradients are divided by the scale inside
+    Adam, a step with a non-finite gradient changes nothing and halves the scale, `growth_interval` clean steps
+    double it; all on a 4-float device record."""
+    o = ops()
+    n = 4 * 1000 + 3
+    pp = rnd(n, seed=1)
+    ref = torch.nn.Parameter(pp.clone())
+    opt = torch.optim.Adam([ref], lr=1e-3)
+    pd = pp.clone().to(DEV)
+    md, vd = torch.zeros_like(pd), torch.zeros_like(pd)
+    state = torch.tensor([1024.0, 0.0, 0.0, 0.0], device=DEV)
+    for i in range(2):
+        gr = rnd(n, seed=10 + i)
+        ref.grad = gr.clone()
+        opt.step()
+        gs = (gr * 1024.0).to(DEV)
+        o.grad_scaler_check(gs, n, state)
+        o.adam_step(pd, gs, md, vd, None, n, 1e-3, 0.9, 0.999, 1e-8, i + 1, scaler=state)
+        o.grad_scaler_update(state, 2.0, 0.5, 2)
+    torch.cuda.synchronize()
+    assert np.allclose(pd.cpu().numpy(), ref.detach().numpy(), atol=1e-6)
+    assert state.tolist() == [2048.0, 0.0, 0.0, 0.0]          # two clean steps at interval 2: doubled, tracker reset
+    before = (pd.clone(), md.clone(), vd.clone())
+    for bad, pos in ((float("inf"), n - 1), (float("nan"), 17), (-float("inf"), 4 * 512)):
+        gs = rnd(n, seed=3).to(DEV)
+        gs[pos] = bad
+        sc = float(state[0])
+        o.grad_scaler_check(gs, n, state)
+        torch.cuda.synchronize()
+        assert float(state[1]) == 1.0
+        o.adam_step(pd, gs, md, vd, None, n, 1e-3, 0.9, 0.999, 1e-8, 3, scaler=state)
+        o.grad_scaler_update(state, 2.0, 0.5, 2)
+        torch.cuda.synchronize()
+        assert all(torch.equal(a, b) for a, b in zip(before, (pd, md, vd)))      # the whole step was skipped
+        assert float(state[0]) == sc * 0.5 and float(state[1]) == 0.0 and float(state[2]) == 0.0
+    assert float(state[3]) == 3.0
+    ok = rnd(n, seed=4).to(DEV)
+    o.grad_scaler_check(ok, n, state)
+    torch.cuda.synchronize()
+    assert float(state[1]) == 0.0
+
+
 # ----------------------------------------------------------------------------------------------- grouped wgrad
 @pytest.mark.parametrize("shapes", [
     [(768, 3072), (3072, 768), (768, 768), (2304, 768), (64, 128), (136, 72)],            # 256x128 ring kernel
     [(768, 3072), (3072, 768), (768, 776), (2304, 768), (768, 3072), (3072, 768), (520, 768), (2304, 768)],  # 256x256
     [(64, 128), (136, 72)]])                                                               # 128x128 kernel
-def test_grouped_weight_gradient_gemm(shapes):
+@pytest.mark.parametrize("lp", LP16)
+def test_grouped_weight_gradient_gemm(shapes, lp):
     """dW = dY^T X and dbias = colsum(dY) for several Linear layers in one launch (LDS-DMA staging +
     ds_read_b64_tr_b16 transposing fragment reads); ragged feature sizes, token tail zero-padded.  The second
     set is two transformer blocks' worth of problems: 219 tiles of 256x256 -> the four-stage ring kernel."""
@@ -737,11 +790,11 @@ def test_grouped_weight_gradient_gemm(shapes):
     for i, (no, ni) in enumerate(shapes):
         dY = torch.zeros(tp, no)
         X = torch.zeros(tp, ni)
-        dY[:tokens] = bf(rnd(tokens, no, seed=2 * i + 1, scale=0.5)).float()
-        X[:tokens] = bf(rnd(tokens, ni, seed=2 * i + 2, scale=0.5)).float()
+        dY[:tokens] = (rnd(tokens, no, seed=2 * i + 1, scale=0.5)).to(lp).float()
+        X[:tokens] = (rnd(tokens, ni, seed=2 * i + 2, scale=0.5)).to(lp).float()
         dW = torch.full((no, ni), 7.0, device=DEV)           # must be overwritten, not accumulated
         db = torch.full((no,), 7.0, device=DEV)
-        probs.append((dY.to(torch.bfloat16).to(DEV), X.to(torch.bfloat16).to(DEV), dW, db))
+        probs.append((dY.to(lp).to(DEV), X.to(lp).to(DEV), dW, db))
         refs.append((dY.double().t() @ X.double(), dY.double().sum(0)))
     o.WgradGroup(probs, tokens, tp)()
     torch.cuda.synchronize()
@@ -756,7 +809,8 @@ def test_grouped_weight_gradient_gemm(shapes):
 
 
 @pytest.mark.gpu
-def test_transpose_many_vector_and_scalar_paths():
+@pytest.mark.parametrize("lp", LP16)
+def test_transpose_many_vector_and_scalar_paths(lp):
     """Batched weight transposes (the bf16 W^T copies of the dX products): 16-byte path for aligned matrices,
     scalar path for ragged ones, both inside one table."""
     import torch
@@ -769,7 +823,7 @@ def test_transpose_many_vector_and_scalar_paths():
         offs.append(total)
         total += R * C
         total = (total + 7) // 8 * 8
-    src = torch.randn(total, device=dev).to(torch.bfloat16)
+    src = torch.randn(total, device=dev).to(lp)
     dst = torch.zeros_like(src)
     table = torch.tensor([[o, o, R, C] for (R, C, _), o in zip(shapes, offs)], dtype=torch.int64, device=dev)
     ops.transpose_many(src, dst, table, len(shapes))
@@ -782,7 +836,8 @@ def test_transpose_many_vector_and_scalar_paths():
 @pytest.mark.gpu
 @pytest.mark.parametrize("B,T,G,Cg,K", [(3, 149, 16, 48, 128), (2, 249, 16, 64, 128), (2, 37, 4, 16, 16),
                                          (2, 170, 2, 32, 32)])
-def test_posconv_wgrad_correlation_kernel(B, T, G, Cg, K):
+@pytest.mark.parametrize("lp", LP16)
+def test_posconv_wgrad_correlation_kernel(B, T, G, Cg, K, lp):
     """dW[g][(j,c)][o] = sum_{b,t} xg[b,g,t+j,c] dY[b,t,g*Cg+o] against an f64 einsum on the same bf16 inputs
     (T > 160 exercises the second time chunk, T = 37 the zero-filled tail rows)."""
     import torch
@@ -790,10 +845,10 @@ def test_posconv_wgrad_correlation_kernel(B, T, G, Cg, K):
     dev = "cuda"
     H = G * Cg
     torch.manual_seed(B * 1000 + T)
-    x = torch.randn(B, T, H, device=dev).to(torch.bfloat16)
-    dY = torch.randn(B * T, H, device=dev).to(torch.bfloat16)
+    x = torch.randn(B, T, H, device=dev).to(lp)
+    dY = torch.randn(B * T, H, device=dev).to(lp)
     Tp = T + K - 1
-    xg = torch.zeros(B, G, Tp, Cg, dtype=torch.bfloat16, device=dev)
+    xg = torch.zeros(B, G, Tp, Cg, dtype=lp, device=dev)
     ops.posconv_regroup(x, xg, B, T, H, G, K, K // 2)
     dwf = torch.full((G, K * Cg, Cg), float("nan"), dtype=torch.float32, device=dev)
     ops.posconv_wgrad(dY, xg, dwf, B, T, H, G, K)
@@ -809,7 +864,8 @@ def test_posconv_wgrad_correlation_kernel(B, T, G, Cg, K):
 
 
 @pytest.mark.gpu
-def test_layernorm_bwd_deferred_fold_equals_immediate():
+@pytest.mark.parametrize("lp", LP16)
+def test_layernorm_bwd_deferred_fold_equals_immediate(lp):
     """w2v2_layernorm_bwd with dgamma = NULL + w2v2_layernorm_bwd_fold (one launch for several LayerNorms) must give
     bitwise the same dgamma / dbeta and ds as the immediate path."""
     import torch
@@ -820,8 +876,8 @@ def test_layernorm_bwd_deferred_fold_equals_immediate():
     group = ops.LnFoldGroup(H, dev)
     want, got = [], []
     for k in range(3):
-        dy = torch.randn(M, H, device=dev).to(torch.bfloat16)
-        s = torch.randn(M, H, device=dev).to(torch.bfloat16)
+        dy = torch.randn(M, H, device=dev).to(lp)
+        s = torch.randn(M, H, device=dev).to(lp)
         mean, rstd = torch.randn(M, device=dev), torch.rand(M, device=dev) + 0.5
         gamma = torch.randn(H, device=dev)
         out = []

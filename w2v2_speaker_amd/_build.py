@@ -32,6 +32,18 @@ def needs_build() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def build_locked(force: bool = False, verbose: bool = False) -> str:
+    """build() under an exclusive file lock: concurrent ranks of a data-parallel job build once."""
+    import fcntl
+    os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
+    with open(os.path.join(HERE, "build", ".lock"), "w") as lk:
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        try:
+            return build(force=force, verbose=verbose)
+        finally:
+            fcntl.flock(lk, fcntl.LOCK_UN)
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
         return LIB
@@ -56,7 +68,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
     with ThreadPoolExecutor(max_workers=min(6, os.cpu_count() or 1)) as ex:
         objs = list(ex.map(compile_one, SOURCES))
-    tmp = LIB + ".tmp"
+    tmp = LIB + f".tmp{os.getpid()}"
     r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs,
                        capture_output=True, text=True)
     if r.returncode != 0:

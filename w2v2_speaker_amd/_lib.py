@@ -10,7 +10,7 @@ import os
 
 from . import _build
 
-F32, BF16 = 0, 1
+F32, BF16, F16 = 0, 1, 2
 EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_GELU_BWD, EPI_ADD, EPI_SCALE_RC = range(6)
 
 c_i32, c_i64, c_u64, c_f32, c_vp = C.c_int32, C.c_int64, C.c_uint64, C.c_float, C.c_void_p
@@ -44,7 +44,7 @@ _SIGS = {
     "w2v2_version": (c_i32, []),
     "w2v2_last_error": (C.c_char_p, []),
     "w2v2_gemm": (c_i32, [C.POINTER(GemmDesc), c_vp]),
-    "w2v2_wgrad_grouped": (c_i32, [C.POINTER(WgradProblem), c_i32, c_i32, c_i32, c_vp]),
+    "w2v2_wgrad_grouped": (c_i32, [C.POINTER(WgradProblem), c_i32, c_i32, c_i32, c_i32, c_vp]),
     "w2v2_conv0_workspace_floats": (c_i32, [c_i32, c_i32, c_i32, c_i32]),
     "w2v2_conv0_stats": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp]),
     "w2v2_conv0_stats_mfma": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp]),
@@ -70,7 +70,7 @@ _SIGS = {
     "w2v2_mask_fill_bwd": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
     "w2v2_prepend_token": (c_i32, [c_vp, c_vp, c_f32, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "w2v2_posconv_regroup": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
-    "w2v2_posconv_wgrad": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    "w2v2_posconv_wgrad": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "w2v2_weightnorm_pack": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "w2v2_weightnorm_bwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
     "w2v2_softmax_fwd": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, c_i64, c_f32, c_u64, c_i32, c_vp]),
@@ -81,7 +81,7 @@ _SIGS = {
                                    c_f32, c_u64, c_i32, c_vp]),
     "w2v2_pool_fwd": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "w2v2_pool_bwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
-    "w2v2_bce_head_fwd_bwd": (c_i32, [c_vp] * 10 + [c_i32, c_i32, c_vp]),
+    "w2v2_bce_head_fwd_bwd": (c_i32, [c_vp] * 10 + [c_i32, c_i32, c_vp, c_vp]),
     "w2v2_bn_workspace_floats": (c_i32, [c_i32, c_i32]),
     "w2v2_bn_stats": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_i32, c_i32, c_f32, c_f32, c_i32, c_i32, c_vp]),
     "w2v2_bn_apply": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_vp]),
@@ -107,10 +107,12 @@ _SIGS = {
     "w2v2_asp_context_bwd": (c_i32, [c_vp] * 7 + [c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "w2v2_row_invnorm": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_i32, c_i32, c_vp]),
     "w2v2_aam_softmax_fwd_bwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32,
-                                         c_i32, c_i64, c_f32, c_f32, c_i32, c_vp]),
+                                         c_i32, c_i64, c_f32, c_f32, c_vp, c_i32, c_vp]),
     "w2v2_normalize_bwd": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
-    "w2v2_adam_step": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32,
-                               c_f32, c_f32, c_vp]),
+    "w2v2_adam_step": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32,
+                               c_f32, c_f32, c_vp, c_vp]),
+    "w2v2_grad_scaler_check": (c_i32, [c_vp, c_i64, c_vp, c_vp]),
+    "w2v2_grad_scaler_update": (c_i32, [c_vp, c_f32, c_f32, c_i32, c_vp]),
 }
 
 EXPORTS = tuple(_SIGS)
@@ -131,11 +133,13 @@ def load():
     if alt and os.path.exists(alt):
         path = alt
     elif _build.needs_build():
+        # one process per GPU: every rank may get here at once, so the build is serialised on a file lock (the
+        # losers find an up-to-date library when they get it).  A failed rebuild is never papered over with a stale
+        # library whose ctypes signatures may no longer match: no compiler + sources newer than the .so -> raise.
         try:
-            _build.build()
-        except Exception as e:  # no compiler on this box and no prebuilt library -> loud failure
-            if not os.path.exists(path):
-                raise RuntimeError(f"libw2v2hip.so is missing and could not be built: {e}") from e
+            _build.build_locked()
+        except Exception as e:
+            raise RuntimeError(f"libw2v2hip.so is missing or older than its sources and could not be built: {e}") from e
     lib = C.CDLL(path)
     for name, (res, args) in _SIGS.items():
         fn = getattr(lib, name)          # AttributeError if the ABI symbol is missing

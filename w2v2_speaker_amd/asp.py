@@ -75,7 +75,7 @@ class AttentivePool:
                          ldaux=C)
         dW1 = g(ASP_PREFIX + "tdnn.conv.conv.weight").view(A, 3 * C)
         dW2 = g(ASP_PREFIX + "conv.conv.weight").view(C, A)
-        self.grouped = adt == torch.bfloat16 and hasattr(x, "_w2v2_padded")
+        self.grouped = ops.is16(adt) and hasattr(x, "_w2v2_padded")
         if self.grouped:
             pad = lambda t: t._w2v2_padded
             self.g_w = WgradGroup([(pad(self.ds), pad(self.h), dW2, g(ASP_PREFIX + "conv.conv.bias")),

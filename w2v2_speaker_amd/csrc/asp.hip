@@ -336,20 +336,15 @@ __global__ void asp_context_bwd_kernel(const T* __restrict__ x, const float* __r
 }
 
 // ------------------------------------------------------------------------------------------ C ABI
-#define ASP_DT(CALL_BF16, CALL_F32, NAME)                \
-  if (dtype == W2V2_BF16) { CALL_BF16; }                 \
-  else if (dtype == W2V2_F32) { CALL_F32; }              \
-  else W2V2_FAIL(NAME ": bad dtype %d", dtype);          \
-  W2V2_CHECK_LAUNCH(NAME);                               \
-  return 0
 
 extern "C" int w2v2_asp_context(const void* x, float* ctx, int B, int T, int C, int dtype, void* stream) {
   W2V2_REQUIRE(x && ctx && B > 0 && T > 0 && C > 0, "asp_context: bad arguments");
   dim3 grid((unsigned)cdiv(C, 64), B), blk(64, ASP_TL);
   hipStream_t st = as_stream(stream);
-  ASP_DT(hipLaunchKernelGGL(asp_context_kernel<bf16_t>, grid, blk, 0, st, (const bf16_t*)x, ctx, T, C),
-         hipLaunchKernelGGL(asp_context_kernel<float>, grid, blk, 0, st, (const float*)x, ctx, T, C),
-         "asp_context");
+  W2V2_DISPATCH_ACT(dtype, "asp_context",
+    hipLaunchKernelGGL(asp_context_kernel<AT>, grid, blk, 0, st, (const AT*)x, ctx, T, C););
+  W2V2_CHECK_LAUNCH("asp_context");
+  return 0;
 }
 
 extern "C" int w2v2_asp_context_bias(const float* ctx, const float* w1, const float* b1, float* cb, int B, int A,
@@ -368,12 +363,8 @@ extern "C" int w2v2_asp_bn_stats(const void* a_pre, float* workspace, float* mea
   const int nblk = (int)cdiv(M, ASP_ROWS);
   dim3 grid((unsigned)cdiv(A, 128), nblk);
   hipStream_t st = as_stream(stream);
-  if (dtype == W2V2_BF16)
-    hipLaunchKernelGGL(asp_bn_partial_kernel<bf16_t>, grid, dim3(128), 0, st, (const bf16_t*)a_pre, workspace, M, A);
-  else if (dtype == W2V2_F32)
-    hipLaunchKernelGGL(asp_bn_partial_kernel<float>, grid, dim3(128), 0, st, (const float*)a_pre, workspace, M, A);
-  else
-    W2V2_FAIL("asp_bn_stats: bad dtype %d", dtype);
+  W2V2_DISPATCH_ACT(dtype, "asp_bn_stats",
+    hipLaunchKernelGGL(asp_bn_partial_kernel<AT>, grid, dim3(128), 0, st, (const AT*)a_pre, workspace, M, A););
   hipLaunchKernelGGL(asp_bn_finalize_kernel, dim3((unsigned)cdiv(A, 128)), dim3(128, 8), 0, st, workspace, mean_rstd,
                      running, nblk, M, A, eps, momentum);
   W2V2_CHECK_LAUNCH("asp_bn_stats");
@@ -394,11 +385,11 @@ extern "C" int w2v2_asp_bn_tanh(const void* a_pre, const float* mean_rstd, const
   const int64_t n = (int64_t)M * A;
   const int nb = (int)(cdiv(n, 256) > 4096 ? 4096 : cdiv(n, 256));
   hipStream_t st = as_stream(stream);
-  ASP_DT(hipLaunchKernelGGL(asp_bn_tanh_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, (const bf16_t*)a_pre, mean_rstd,
-                            gamma, beta, (bf16_t*)h, n, A),
-         hipLaunchKernelGGL(asp_bn_tanh_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)a_pre, mean_rstd,
-                            gamma, beta, (float*)h, n, A),
-         "asp_bn_tanh");
+  W2V2_DISPATCH_ACT(dtype, "asp_bn_tanh",
+    hipLaunchKernelGGL(asp_bn_tanh_kernel<AT>, dim3(nb), dim3(256), 0, st, (const AT*)a_pre, mean_rstd,
+                            gamma, beta, (AT*)h, n, A););
+  W2V2_CHECK_LAUNCH("asp_bn_tanh");
+  return 0;
 }
 
 extern "C" int w2v2_asp_bn_bwd(const void* dh, const void* a_pre, const float* mean_rstd, const float* gamma,
@@ -419,9 +410,7 @@ extern "C" int w2v2_asp_bn_bwd(const void* dh, const void* a_pre, const float* m
                      dgamma, dbeta, nblk, A);                                                                        \
   hipLaunchKernelGGL(asp_bn_bwd_apply_kernel<T_>, dim3(nb), dim3(256), 0, st, (const T_*)dh, (const T_*)a_pre,       \
                      mean_rstd, gamma, beta, sums, (T_*)da, n, A, 1.0f / (float)M)
-  if (dtype == W2V2_BF16) { ASP_BNB(bf16_t); }
-  else if (dtype == W2V2_F32) { ASP_BNB(float); }
-  else W2V2_FAIL("asp_bn_bwd: bad dtype %d", dtype);
+  W2V2_DISPATCH_ACT(dtype, "asp_bn_bwd", ASP_BNB(AT););
 #undef ASP_BNB
   W2V2_CHECK_LAUNCH("asp_bn_bwd");
   return 0;
@@ -432,11 +421,11 @@ extern "C" int w2v2_asp_pool_fwd(const void* x, const void* s, float* out, float
   W2V2_REQUIRE(x && s && out && stats && B > 0 && T > 0 && C > 0, "asp_pool_fwd: bad arguments");
   dim3 grid((unsigned)cdiv(C, 64), B), blk(64, ASP_TL);
   hipStream_t st = as_stream(stream);
-  ASP_DT(hipLaunchKernelGGL(asp_pool_fwd_kernel<bf16_t>, grid, blk, 0, st, (const bf16_t*)x, (const bf16_t*)s,
-                            out, stats, T, C),
-         hipLaunchKernelGGL(asp_pool_fwd_kernel<float>, grid, blk, 0, st, (const float*)x, (const float*)s, out,
-                            stats, T, C),
-         "asp_pool_fwd");
+  W2V2_DISPATCH_ACT(dtype, "asp_pool_fwd",
+    hipLaunchKernelGGL(asp_pool_fwd_kernel<AT>, grid, blk, 0, st, (const AT*)x, (const AT*)s,
+                            out, stats, T, C););
+  W2V2_CHECK_LAUNCH("asp_pool_fwd");
+  return 0;
 }
 
 extern "C" int w2v2_asp_pool_bwd(const void* x, const void* s, const float* out, const float* stats, const float* dout,
@@ -444,11 +433,11 @@ extern "C" int w2v2_asp_pool_bwd(const void* x, const void* s, const float* out,
   W2V2_REQUIRE(x && s && out && stats && dout && ds && dx && B > 0 && T > 0 && C > 0, "asp_pool_bwd: bad arguments");
   dim3 grid((unsigned)cdiv(C, 64), B), blk(64, ASP_TL);
   hipStream_t st = as_stream(stream);
-  ASP_DT(hipLaunchKernelGGL(asp_pool_bwd_kernel<bf16_t>, grid, blk, 0, st, (const bf16_t*)x, (const bf16_t*)s,
-                            out, stats, dout, (bf16_t*)ds, (bf16_t*)dx, T, C),
-         hipLaunchKernelGGL(asp_pool_bwd_kernel<float>, grid, blk, 0, st, (const float*)x, (const float*)s, out,
-                            stats, dout, (float*)ds, (float*)dx, T, C),
-         "asp_pool_bwd");
+  W2V2_DISPATCH_ACT(dtype, "asp_pool_bwd",
+    hipLaunchKernelGGL(asp_pool_bwd_kernel<AT>, grid, blk, 0, st, (const AT*)x, (const AT*)s,
+                            out, stats, dout, (AT*)ds, (AT*)dx, T, C););
+  W2V2_CHECK_LAUNCH("asp_pool_bwd");
+  return 0;
 }
 
 // scratch: B*A (dsum) + B*2C (dctx) floats
@@ -459,23 +448,14 @@ extern "C" int w2v2_asp_context_bwd(const void* x, const float* ctx, const void*
   float* dsum = scratch;
   float* dctx = scratch + (int64_t)B * A;
   hipStream_t st = as_stream(stream);
-  if (dtype == W2V2_BF16)
-    hipLaunchKernelGGL(asp_dsum_kernel<bf16_t>, dim3((unsigned)cdiv(A, 64), B), dim3(64, ASP_TL), 0, st,
-                       (const bf16_t*)da, dsum, T, A);
-  else if (dtype == W2V2_F32)
-    hipLaunchKernelGGL(asp_dsum_kernel<float>, dim3((unsigned)cdiv(A, 64), B), dim3(64, ASP_TL), 0, st,
-                       (const float*)da, dsum, T, A);
-  else
-    W2V2_FAIL("asp_context_bwd: bad dtype %d", dtype);
+  W2V2_DISPATCH_ACT(dtype, "asp_context_bwd",
+    hipLaunchKernelGGL(asp_dsum_kernel<AT>, dim3((unsigned)cdiv(A, 64), B), dim3(64, ASP_TL), 0, st,
+                       (const AT*)da, dsum, T, A););
   hipLaunchKernelGGL(asp_dw_ctx_kernel, dim3((unsigned)cdiv(2 * C, 256), A), dim3(256), 0, st, dsum, ctx, dw1, B, A, C);
   hipLaunchKernelGGL(asp_dctx_kernel, dim3((unsigned)cdiv(2 * C, 64), B), dim3(64, ASP_TL), 0, st, dsum, w1, dctx, A, C);
   dim3 grid((unsigned)cdiv(C, 64), B), blk(64, ASP_TL);
-  if (dtype == W2V2_BF16)
-    hipLaunchKernelGGL(asp_context_bwd_kernel<bf16_t>, grid, blk, 0, st, (const bf16_t*)x, ctx, dctx,
-                       (bf16_t*)dx, T, C);
-  else
-    hipLaunchKernelGGL(asp_context_bwd_kernel<float>, grid, blk, 0, st, (const float*)x, ctx, dctx, (float*)dx,
-                       T, C);
+  W2V2_DISPATCH_ACT(dtype, "asp_context_bwd",
+    hipLaunchKernelGGL(asp_context_bwd_kernel<AT>, grid, blk, 0, st, (const AT*)x, ctx, dctx, (AT*)dx, T, C););
   W2V2_CHECK_LAUNCH("asp_context_bwd");
   return 0;
 }

@@ -20,7 +20,6 @@
 #include "common.cuh"
 #include <stdlib.h>
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 constexpr int HD = 64;  // head dim
@@ -61,18 +60,36 @@ __device__ __forceinline__ void attn_drop4_rows(uint64_t seed, int64_t bh, int q
 }
 __device__ __forceinline__ int aswz(int row) { return ((row ^ (row >> 1)) & 3) | (row & 4); }   // measured map, see gemm.hip swz()
 
-__device__ __forceinline__ bf16x8 as_frag(uint4 v) {
-  union { uint4 u; bf16x8 f; } c;
+__device__ __forceinline__ frag8_t as_frag(uint4 v) {
+  union { uint4 u; frag8_t f; } c;
   c.u = v;
   return c.f;
 }
-__device__ __forceinline__ bf16x8 pack_frag(const float a[4], const float b[4]) {
+template <typename TE>
+__device__ __forceinline__ frag8_t pack_frag(const float a[4], const float b[4]) {
   uint4 v;
-  v.x = f32x2_to_bf16x2(a[0], a[1]);
-  v.y = f32x2_to_bf16x2(a[2], a[3]);
-  v.z = f32x2_to_bf16x2(b[0], b[1]);
-  v.w = f32x2_to_bf16x2(b[2], b[3]);
+  v.x = pack2<TE>(a[0], a[1]);
+  v.y = pack2<TE>(a[2], a[3]);
+  v.z = pack2<TE>(b[0], b[1]);
+  v.w = pack2<TE>(b[2], b[3]);
   return as_frag(v);
+}
+// sum_e a[e] * b[e] over the 8 elements of two fragments (f32)
+template <typename TE>
+__device__ __forceinline__ float frag_dot(frag8_t a, frag8_t b) {
+  union { frag8_t f; uint32_t w[4]; } ua, ub;
+  ua.f = a;
+  ub.f = b;
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float a0, a1, b0, b1;
+    unpack2<TE>(ua.w[i], a0, a1);
+    unpack2<TE>(ub.w[i], b0, b1);
+    s = fmaf(a0, b0, s);
+    s = fmaf(a1, b1, s);
+  }
+  return s;
 }
 
 // rows [0, n_pad) x 64 bf16 from global (row stride gs elements) -> LDS [n_pad][64], chunk-swizzled
@@ -113,19 +130,19 @@ __device__ __forceinline__ void lds_load_rows_t(bf16_t* ldst, const bf16_t* g, i
   }
 }
 // MFMA fragment (16 rows x 32 k) from the swizzled row-major image
-__device__ __forceinline__ bf16x8 lds_frag(const bf16_t* lds, int row0, int kk, int lane) {
+__device__ __forceinline__ frag8_t lds_frag(const bf16_t* lds, int row0, int kk, int lane) {
   const int fr = lane & 15;                         // row0 is a multiple of 16: swizzle depends on fr only
   const int lane_off = fr * 64 + (((kk * 4 + (lane >> 4)) ^ aswz(fr)) << 3);
   return as_frag(*reinterpret_cast<const uint4*>(lds + lane_off + row0 * 64));
 }
 // MFMA fragment from the transposed image: row d0 + lane&15, k-slots of 32-column block `blk`
-__device__ __forceinline__ bf16x8 lds_frag_t(const bf16_t* ldst, int pitch, int d0, int blk, int lane) {
+__device__ __forceinline__ frag8_t lds_frag_t(const bf16_t* ldst, int pitch, int d0, int blk, int lane) {
   const bf16_t* p = ldst + (d0 + (lane & 15)) * pitch + blk * 32 + (lane >> 4) * 4;
   const uint2 a = *reinterpret_cast<const uint2*>(p), b = *reinterpret_cast<const uint2*>(p + 16);
   return as_frag(make_uint4(a.x, a.y, b.x, b.y));
 }
 // the wave's own 16 rows straight from global into registers (2 k-steps)
-__device__ __forceinline__ void reg_frag(bf16x8 f[2], const bf16_t* g, int64_t gs, int row, int n_valid, int lane) {
+__device__ __forceinline__ void reg_frag(frag8_t f[2], const bf16_t* g, int64_t gs, int row, int n_valid, int lane) {
 #pragma unroll
   for (int kk = 0; kk < 2; ++kk) {
     uint4 v = make_uint4(0, 0, 0, 0);
@@ -143,7 +160,7 @@ __device__ __forceinline__ float quad_sum(float v) {
 }
 
 // ------------------------------------------------------------------------------------- forward
-template <int NF>
+template <typename TE, int NF>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx,
                                                        float* __restrict__ lse, int Tn, int heads, float scale,
                                                        float dp, float inv_keep, uint64_t seed) {
@@ -159,7 +176,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
   lds_load_rows_t(Vt, qb + 2 * H, gs, Tn, TP, PITCH);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
   const int q = blockIdx.x * 64 + wave * 16 + (lane & 15);
-  bf16x8 qf[2];
+  frag8_t qf[2];
   reg_frag(qf, qb, gs, q, Tn, lane);
   __syncthreads();
 
@@ -170,7 +187,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk)
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(Ks, fj * 16, kk, lane), qf[kk], acc, 0, 0, 0);
+      acc = mfma16<TE>(lds_frag(Ks, fj * 16, kk, lane), qf[kk], acc);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int key = fj * 16 + g * 4 + j;
@@ -201,25 +218,25 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
   for (int df = 0; df < 4; ++df) o[df] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int kb = 0; kb < NF / 2; ++kb) {
-    const bf16x8 pf = pack_frag(s[2 * kb], s[2 * kb + 1]);
+    const frag8_t pf = pack_frag<TE>(s[2 * kb], s[2 * kb + 1]);
 #pragma unroll
     for (int df = 0; df < 4; ++df)
-      o[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag_t(Vt, PITCH, df * 16, kb, lane), pf, o[df], 0, 0, 0);
+      o[df] = mfma16<TE>(lds_frag_t(Vt, PITCH, df * 16, kb, lane), pf, o[df]);
   }
   if (q < Tn) {
     bf16_t* dst = ctx + ((int64_t)b * Tn + q) * H + h * HD + g * 4;
 #pragma unroll
     for (int df = 0; df < 4; ++df) {
       uint2 w;
-      w.x = f32x2_to_bf16x2(o[df][0], o[df][1]);
-      w.y = f32x2_to_bf16x2(o[df][2], o[df][3]);
+      w.x = pack2<TE>(o[df][0], o[df][1]);
+      w.y = pack2<TE>(o[df][2], o[df][3]);
       *reinterpret_cast<uint2*>(dst + df * 16) = w;
     }
   }
 }
 
 // ------------------------------------------------------------------------------------- backward: dQ
-template <int NF>
+template <typename TE, int NF>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv,
                                                           const bf16_t* __restrict__ ctx,
                                                           const bf16_t* __restrict__ dctx,
@@ -241,7 +258,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
   const int q = blockIdx.x * 64 + wave * 16 + (lane & 15);
   const int64_t bh = (int64_t)b * heads + h;
-  bf16x8 qf[2], dof[2], of[2];
+  frag8_t qf[2], dof[2], of[2];
   reg_frag(qf, qb, gs, q, Tn, lane);
   const bf16_t* dob = dctx + (int64_t)b * Tn * H + h * HD;
   const bf16_t* ob = ctx + (int64_t)b * Tn * H + h * HD;
@@ -250,9 +267,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
   // delta[q] = sum_d dO*O
   float dl = 0.f;
 #pragma unroll
-  for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-    for (int e = 0; e < 8; ++e) dl += (float)dof[kk][e] * (float)of[kk][e];
+  for (int kk = 0; kk < 2; ++kk) dl += frag_dot<TE>(dof[kk], of[kk]);
   dl = quad_sum(dl);
   if (g == 0 && q < Tn) delta[bh * Tn + q] = dl;
   const float l = q < Tn ? lse[bh * Tn + q] : 0.f;
@@ -264,8 +279,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
     f32x4 sa = {0.f, 0.f, 0.f, 0.f}, pa = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-      sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(Ks, fj * 16, kk, lane), qf[kk], sa, 0, 0, 0);
-      pa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(Vs, fj * 16, kk, lane), dof[kk], pa, 0, 0, 0);
+      sa = mfma16<TE>(lds_frag(Ks, fj * 16, kk, lane), qf[kk], sa);
+      pa = mfma16<TE>(lds_frag(Vs, fj * 16, kk, lane), dof[kk], pa);
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -281,25 +296,25 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
   for (int df = 0; df < 4; ++df) o[df] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int kb = 0; kb < NF / 2; ++kb) {
-    const bf16x8 pf = pack_frag(ds[2 * kb], ds[2 * kb + 1]);
+    const frag8_t pf = pack_frag<TE>(ds[2 * kb], ds[2 * kb + 1]);
 #pragma unroll
     for (int df = 0; df < 4; ++df)
-      o[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag_t(Kt, PITCH, df * 16, kb, lane), pf, o[df], 0, 0, 0);
+      o[df] = mfma16<TE>(lds_frag_t(Kt, PITCH, df * 16, kb, lane), pf, o[df]);
   }
   if (q < Tn) {
     bf16_t* dst = dqkv + ((int64_t)b * Tn + q) * gs + h * HD + g * 4;
 #pragma unroll
     for (int df = 0; df < 4; ++df) {
       uint2 w;
-      w.x = f32x2_to_bf16x2(o[df][0], o[df][1]);
-      w.y = f32x2_to_bf16x2(o[df][2], o[df][3]);
+      w.x = pack2<TE>(o[df][0], o[df][1]);
+      w.y = pack2<TE>(o[df][2], o[df][3]);
       *reinterpret_cast<uint2*>(dst + df * 16) = w;
     }
   }
 }
 
 // ------------------------------------------------------------------------------------- backward: dK, dV
-template <int NF>
+template <typename TE, int NF>
 __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const bf16_t* __restrict__ qkv,
                                                           const bf16_t* __restrict__ dctx,
                                                           const float* __restrict__ lse,
@@ -330,7 +345,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const bf16_t* __restri
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
   const int key = blockIdx.x * 64 + wave * 16 + (lane & 15);
-  bf16x8 kf[2], vf[2];
+  frag8_t kf[2], vf[2];
   reg_frag(kf, qb + H, gs, key, Tn, lane);
   reg_frag(vf, qb + 2 * H, gs, key, Tn, lane);
   __syncthreads();
@@ -341,8 +356,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const bf16_t* __restri
     f32x4 sa = {0.f, 0.f, 0.f, 0.f}, pa = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-      sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(Qs, fq * 16, kk, lane), kf[kk], sa, 0, 0, 0);
-      pa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(Os, fq * 16, kk, lane), vf[kk], pa, 0, 0, 0);
+      sa = mfma16<TE>(lds_frag(Qs, fq * 16, kk, lane), kf[kk], sa);
+      pa = mfma16<TE>(lds_frag(Os, fq * 16, kk, lane), vf[kk], pa);
     }
     const float4 l4 = *reinterpret_cast<const float4*>(lse_s + fq * 16 + g * 4);
     const float4 d4 = *reinterpret_cast<const float4*>(del_s + fq * 16 + g * 4);
@@ -362,12 +377,12 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const bf16_t* __restri
   for (int df = 0; df < 4; ++df) { dv[df] = f32x4{0.f, 0.f, 0.f, 0.f}; dk[df] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
   for (int qb2 = 0; qb2 < NF / 2; ++qb2) {
-    const bf16x8 pf = pack_frag(pt[2 * qb2], pt[2 * qb2 + 1]);
-    const bf16x8 sf = pack_frag(dst_[2 * qb2], dst_[2 * qb2 + 1]);
+    const frag8_t pf = pack_frag<TE>(pt[2 * qb2], pt[2 * qb2 + 1]);
+    const frag8_t sf = pack_frag<TE>(dst_[2 * qb2], dst_[2 * qb2 + 1]);
 #pragma unroll
     for (int df = 0; df < 4; ++df) {
-      dv[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag_t(Ot, PITCH, df * 16, qb2, lane), pf, dv[df], 0, 0, 0);
-      dk[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag_t(Qt, PITCH, df * 16, qb2, lane), sf, dk[df], 0, 0, 0);
+      dv[df] = mfma16<TE>(lds_frag_t(Ot, PITCH, df * 16, qb2, lane), pf, dv[df]);
+      dk[df] = mfma16<TE>(lds_frag_t(Qt, PITCH, df * 16, qb2, lane), sf, dk[df]);
     }
   }
   if (key < Tn) {
@@ -376,11 +391,11 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const bf16_t* __restri
 #pragma unroll
     for (int df = 0; df < 4; ++df) {
       uint2 w;
-      w.x = f32x2_to_bf16x2(dk[df][0], dk[df][1]);
-      w.y = f32x2_to_bf16x2(dk[df][2], dk[df][3]);
+      w.x = pack2<TE>(dk[df][0], dk[df][1]);
+      w.y = pack2<TE>(dk[df][2], dk[df][3]);
       *reinterpret_cast<uint2*>(dstk + df * 16) = w;
-      w.x = f32x2_to_bf16x2(dv[df][0], dv[df][1]);
-      w.y = f32x2_to_bf16x2(dv[df][2], dv[df][3]);
+      w.x = pack2<TE>(dv[df][0], dv[df][1]);
+      w.y = pack2<TE>(dv[df][2], dv[df][3]);
       *reinterpret_cast<uint2*>(dstv + df * 16) = w;
     }
   }
@@ -455,17 +470,18 @@ __device__ __forceinline__ void blk_store_t(const BlkRegs<NF>& r, bf16_t* ldst, 
     }
   }
 }
+template <typename TE>
 __device__ __forceinline__ void store_row4x4(bf16_t* dst, const f32x4 (&o)[4]) {
 #pragma unroll
   for (int df = 0; df < 4; ++df) {
     uint2 w;
-    w.x = f32x2_to_bf16x2(o[df][0], o[df][1]);
-    w.y = f32x2_to_bf16x2(o[df][2], o[df][3]);
+    w.x = pack2<TE>(o[df][0], o[df][1]);
+    w.y = pack2<TE>(o[df][2], o[df][3]);
     *reinterpret_cast<uint2*>(dst + df * 16) = w;
   }
 }
 
-template <int NF>
+template <typename TE, int NF>
 __global__ __launch_bounds__(256) void attn_fwd2_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx,
                                                         float* __restrict__ lse, int Tn, int heads, float scale,
                                                         float dp, float inv_keep, uint64_t seed) {
@@ -496,7 +512,7 @@ __global__ __launch_bounds__(256) void attn_fwd2_kernel(const bf16_t* __restrict
     const int q = qf * 16 + (lane & 15);
     int g4 = g * 4;
     asm volatile("" : "+v"(g4));          // opaque: no hoisting of the 40 per-column index / RNG-counter values
-    bf16x8 qfr[2] = {lds_frag(Qs, qf * 16, 0, lane), lds_frag(Qs, qf * 16, 1, lane)};
+    frag8_t qfr[2] = {lds_frag(Qs, qf * 16, 0, lane), lds_frag(Qs, qf * 16, 1, lane)};
     float s[NF][4];
     float mx = -INFINITY;
 #pragma unroll
@@ -504,7 +520,7 @@ __global__ __launch_bounds__(256) void attn_fwd2_kernel(const bf16_t* __restrict
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk)
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(Ks, fj * 16, kk, lane), qfr[kk], acc, 0, 0, 0);
+        acc = mfma16<TE>(lds_frag(Ks, fj * 16, kk, lane), qfr[kk], acc);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int key = fj * 16 + g4 + j;
@@ -533,16 +549,16 @@ __global__ __launch_bounds__(256) void attn_fwd2_kernel(const bf16_t* __restrict
     for (int df = 0; df < 4; ++df) o[df] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int kb = 0; kb < NF / 2; ++kb) {
-      const bf16x8 pf = pack_frag(s[2 * kb], s[2 * kb + 1]);
+      const frag8_t pf = pack_frag<TE>(s[2 * kb], s[2 * kb + 1]);
 #pragma unroll
       for (int df = 0; df < 4; ++df)
-        o[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag_t(Vt, PITCH, df * 16, kb, lane), pf, o[df], 0, 0, 0);
+        o[df] = mfma16<TE>(lds_frag_t(Vt, PITCH, df * 16, kb, lane), pf, o[df]);
     }
-    if (q < Tn) store_row4x4(ctx + ((int64_t)b * Tn + q) * H + h * HD + g * 4, o);
+    if (q < Tn) store_row4x4<TE>(ctx + ((int64_t)b * Tn + q) * H + h * HD + g * 4, o);
   }
 }
 
-template <int NF>
+template <typename TE, int NF>
 __global__ __launch_bounds__(256) void attn_bwd2_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ ctx,
                                                         const bf16_t* __restrict__ dctx,
                                                         const float* __restrict__ lse, bf16_t* __restrict__ dqkv,
@@ -589,15 +605,13 @@ __global__ __launch_bounds__(256) void attn_bwd2_kernel(const bf16_t* __restrict
   for (int qf = wave; qf < NF; qf += 4) {
     asm volatile("" ::: "memory");   // no LICM of the loop-invariant LDS fragment loads
     const int q = qf * 16 + (lane & 15);
-    bf16x8 qfr[2] = {lds_frag(Qs, qf * 16, 0, lane), lds_frag(Qs, qf * 16, 1, lane)};
-    bf16x8 dof[2] = {lds_frag(Os, qf * 16, 0, lane), lds_frag(Os, qf * 16, 1, lane)};
-    bf16x8 of[2];
+    frag8_t qfr[2] = {lds_frag(Qs, qf * 16, 0, lane), lds_frag(Qs, qf * 16, 1, lane)};
+    frag8_t dof[2] = {lds_frag(Os, qf * 16, 0, lane), lds_frag(Os, qf * 16, 1, lane)};
+    frag8_t of[2];
     reg_frag(of, ob, H, q, Tn, lane);
     float dl = 0.f;
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-      for (int e = 0; e < 8; ++e) dl += (float)dof[kk][e] * (float)of[kk][e];
+    for (int kk = 0; kk < 2; ++kk) dl += frag_dot<TE>(dof[kk], of[kk]);
     dl = quad_sum(dl);
     if (g == 0) del_s[q] = q < Tn ? dl : 0.f;
     const float l = lse_s[q];
@@ -607,8 +621,8 @@ __global__ __launch_bounds__(256) void attn_bwd2_kernel(const bf16_t* __restrict
       f32x4 sa = {0.f, 0.f, 0.f, 0.f}, pa = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
-        sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(Ks, fj * 16, kk, lane), qfr[kk], sa, 0, 0, 0);
-        pa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(Vs, fj * 16, kk, lane), dof[kk], pa, 0, 0, 0);
+        sa = mfma16<TE>(lds_frag(Ks, fj * 16, kk, lane), qfr[kk], sa);
+        pa = mfma16<TE>(lds_frag(Vs, fj * 16, kk, lane), dof[kk], pa);
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -624,12 +638,12 @@ __global__ __launch_bounds__(256) void attn_bwd2_kernel(const bf16_t* __restrict
     for (int df = 0; df < 4; ++df) o[df] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int kb = 0; kb < NF / 2; ++kb) {
-      const bf16x8 pf = pack_frag(ds[2 * kb], ds[2 * kb + 1]);
+      const frag8_t pf = pack_frag<TE>(ds[2 * kb], ds[2 * kb + 1]);
 #pragma unroll
       for (int df = 0; df < 4; ++df)
-        o[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag_t(Kt, PITCH, df * 16, kb, lane), pf, o[df], 0, 0, 0);
+        o[df] = mfma16<TE>(lds_frag_t(Kt, PITCH, df * 16, kb, lane), pf, o[df]);
     }
-    if (q < Tn) store_row4x4(dqkv + ((int64_t)b * Tn + q) * gs + h * HD + g * 4, o);
+    if (q < Tn) store_row4x4<TE>(dqkv + ((int64_t)b * Tn + q) * gs + h * HD + g * 4, o);
   }
   __syncthreads();          // delta complete
 
@@ -638,16 +652,16 @@ __global__ __launch_bounds__(256) void attn_bwd2_kernel(const bf16_t* __restrict
   for (int kf = wave; kf < NF; kf += 4) {
     asm volatile("" ::: "memory");
     const int key = kf * 16 + (lane & 15);
-    bf16x8 kfr[2] = {lds_frag(Ks, kf * 16, 0, lane), lds_frag(Ks, kf * 16, 1, lane)};
-    bf16x8 vfr[2] = {lds_frag(Vs, kf * 16, 0, lane), lds_frag(Vs, kf * 16, 1, lane)};
+    frag8_t kfr[2] = {lds_frag(Ks, kf * 16, 0, lane), lds_frag(Ks, kf * 16, 1, lane)};
+    frag8_t vfr[2] = {lds_frag(Vs, kf * 16, 0, lane), lds_frag(Vs, kf * 16, 1, lane)};
     float pt[NF][4], dst_[NF][4];
 #pragma unroll
     for (int fq = 0; fq < NF; ++fq) {
       f32x4 sa = {0.f, 0.f, 0.f, 0.f}, pa = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
-        sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(Qs, fq * 16, kk, lane), kfr[kk], sa, 0, 0, 0);
-        pa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(Os, fq * 16, kk, lane), vfr[kk], pa, 0, 0, 0);
+        sa = mfma16<TE>(lds_frag(Qs, fq * 16, kk, lane), kfr[kk], sa);
+        pa = mfma16<TE>(lds_frag(Os, fq * 16, kk, lane), vfr[kk], pa);
       }
       const float4 l4 = *reinterpret_cast<const float4*>(lse_s + fq * 16 + g * 4);
       const float4 d4 = *reinterpret_cast<const float4*>(del_s + fq * 16 + g * 4);
@@ -667,18 +681,18 @@ __global__ __launch_bounds__(256) void attn_bwd2_kernel(const bf16_t* __restrict
     for (int df = 0; df < 4; ++df) { dv[df] = f32x4{0.f, 0.f, 0.f, 0.f}; dk[df] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
     for (int qb2 = 0; qb2 < NF / 2; ++qb2) {
-      const bf16x8 pf = pack_frag(pt[2 * qb2], pt[2 * qb2 + 1]);
-      const bf16x8 sf = pack_frag(dst_[2 * qb2], dst_[2 * qb2 + 1]);
+      const frag8_t pf = pack_frag<TE>(pt[2 * qb2], pt[2 * qb2 + 1]);
+      const frag8_t sf = pack_frag<TE>(dst_[2 * qb2], dst_[2 * qb2 + 1]);
 #pragma unroll
       for (int df = 0; df < 4; ++df) {
-        dv[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag_t(Ot, PITCH, df * 16, qb2, lane), pf, dv[df], 0, 0, 0);
-        dk[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag_t(Qt, PITCH, df * 16, qb2, lane), sf, dk[df], 0, 0, 0);
+        dv[df] = mfma16<TE>(lds_frag_t(Ot, PITCH, df * 16, qb2, lane), pf, dv[df]);
+        dk[df] = mfma16<TE>(lds_frag_t(Qt, PITCH, df * 16, qb2, lane), sf, dk[df]);
       }
     }
     if (key < Tn) {
       bf16_t* dstk = dqkv + ((int64_t)b * Tn + key) * gs + H + h * HD + g * 4;
-      store_row4x4(dstk, dk);
-      store_row4x4(dstk + H, dv);
+      store_row4x4<TE>(dstk, dk);
+      store_row4x4<TE>(dstk + H, dv);
     }
   }
 }
@@ -708,17 +722,17 @@ __device__ __forceinline__ TrOff tr_offsets(int lane) {
   for (int df = 0; df < 4; ++df) t.o[df] = r * 64 + (((2 * df + ((i & 3) >> 1)) ^ sw) << 3) + ((i & 1) << 2);
   return t;
 }
-__device__ __forceinline__ bf16x8 lds_frag_tr(const bf16_t* img, const TrOff& t, int df, int blk) {
+__device__ __forceinline__ frag8_t lds_frag_tr(const bf16_t* img, const TrOff& t, int df, int blk) {
   const bf16_t* p0 = img + t.o[df] + blk * 2048;
   const short4v_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v_t*)p0);
   const short4v_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v_t*)(p0 + 1024));
-  union { struct { short4v_t a, b; } s; bf16x8 v; } u;
+  union { struct { short4v_t a, b; } s; frag8_t v; } u;
   u.s.a = lo;
   u.s.b = hi;
   return u.v;
 }
 
-template <int NF>
+template <typename TE, int NF>
 __global__ __launch_bounds__(256, 2) void attn_bwd3_kernel(const bf16_t* __restrict__ qkv,
                                                            const bf16_t* __restrict__ ctx,
                                                            const bf16_t* __restrict__ dctx,
@@ -760,15 +774,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd3_kernel(const bf16_t* __restr
   for (int qf = wave; qf < NF; qf += 4) {
     asm volatile("" ::: "memory");
     const int q = qf * 16 + (lane & 15);
-    bf16x8 qfr[2] = {lds_frag(Qs, qf * 16, 0, lane), lds_frag(Qs, qf * 16, 1, lane)};
-    bf16x8 dof[2] = {lds_frag(Os, qf * 16, 0, lane), lds_frag(Os, qf * 16, 1, lane)};
-    bf16x8 of[2];
+    frag8_t qfr[2] = {lds_frag(Qs, qf * 16, 0, lane), lds_frag(Qs, qf * 16, 1, lane)};
+    frag8_t dof[2] = {lds_frag(Os, qf * 16, 0, lane), lds_frag(Os, qf * 16, 1, lane)};
+    frag8_t of[2];
     reg_frag(of, ob, H, q, Tn, lane);
     float dl = 0.f;
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-      for (int e = 0; e < 8; ++e) dl += (float)dof[kk][e] * (float)of[kk][e];
+    for (int kk = 0; kk < 2; ++kk) dl += frag_dot<TE>(dof[kk], of[kk]);
     dl = quad_sum(dl);
     if (g == 0 && q < Tn) del_b[q] = dl;
     const float l = q < Tn ? lse_b[q] : 0.f;
@@ -788,8 +800,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd3_kernel(const bf16_t* __restr
         f32x4 sa = {0.f, 0.f, 0.f, 0.f}, pa = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-          sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(Ks, fj * 16, kk, lane), qfr[kk], sa, 0, 0, 0);
-          pa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(Vs, fj * 16, kk, lane), dof[kk], pa, 0, 0, 0);
+          sa = mfma16<TE>(lds_frag(Ks, fj * 16, kk, lane), qfr[kk], sa);
+          pa = mfma16<TE>(lds_frag(Vs, fj * 16, kk, lane), dof[kk], pa);
         }
         float ms[4] = {1.f, 1.f, 1.f, 1.f};
         if (dp > 0.f) attn_drop4_keys(seed, bh, q, fj * 16 + g4, Tn, dp, inv_keep, ms);
@@ -800,12 +812,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd3_kernel(const bf16_t* __restr
           ds2[hf][j] = p * (pa[j] * ms[j] - dl) * scale;
         }
       }
-      const bf16x8 pf = pack_frag(ds2[0], ds2[1]);
+      const frag8_t pf = pack_frag<TE>(ds2[0], ds2[1]);
 #pragma unroll
       for (int df = 0; df < 4; ++df)
-        o[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag_tr(Ks, troff, df, kb), pf, o[df], 0, 0, 0);
+        o[df] = mfma16<TE>(lds_frag_tr(Ks, troff, df, kb), pf, o[df]);
     }
-    if (q < Tn) store_row4x4(dqkv + ((int64_t)b * Tn + q) * gs + h * HD + g * 4, o);
+    if (q < Tn) store_row4x4<TE>(dqkv + ((int64_t)b * Tn + q) * gs + h * HD + g * 4, o);
   }
   __threadfence_block();
   __syncthreads();          // delta of every query row of this (b, h) is visible to the workgroup
@@ -825,8 +837,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd3_kernel(const bf16_t* __restr
   for (int kf = wave; kf < NF; kf += 4) {
     asm volatile("" ::: "memory");
     const int key = kf * 16 + (lane & 15);
-    bf16x8 kfr[2] = {lds_frag(Ks, kf * 16, 0, lane), lds_frag(Ks, kf * 16, 1, lane)};
-    bf16x8 vfr[2] = {lds_frag(Vs, kf * 16, 0, lane), lds_frag(Vs, kf * 16, 1, lane)};
+    frag8_t kfr[2] = {lds_frag(Ks, kf * 16, 0, lane), lds_frag(Ks, kf * 16, 1, lane)};
+    frag8_t vfr[2] = {lds_frag(Vs, kf * 16, 0, lane), lds_frag(Vs, kf * 16, 1, lane)};
     f32x4 dv[4], dk[4];
 #pragma unroll
     for (int df = 0; df < 4; ++df) { dv[df] = f32x4{0.f, 0.f, 0.f, 0.f}; dk[df] = f32x4{0.f, 0.f, 0.f, 0.f}; }
@@ -846,8 +858,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd3_kernel(const bf16_t* __restr
         f32x4 sa = {0.f, 0.f, 0.f, 0.f}, pa = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-          sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(Qs, fq * 16, kk, lane), kfr[kk], sa, 0, 0, 0);
-          pa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(Os, fq * 16, kk, lane), vfr[kk], pa, 0, 0, 0);
+          sa = mfma16<TE>(lds_frag(Qs, fq * 16, kk, lane), kfr[kk], sa);
+          pa = mfma16<TE>(lds_frag(Os, fq * 16, kk, lane), vfr[kk], pa);
         }
         float ms[4] = {1.f, 1.f, 1.f, 1.f};
         if (dp > 0.f) attn_drop4_rows(seed, bh, fq * 16 + g4, key, Tn, dp, inv_keep, ms);
@@ -862,18 +874,18 @@ __global__ __launch_bounds__(256, 2) void attn_bwd3_kernel(const bf16_t* __restr
           ds2[hf][j] = p * (pa[j] * ms[j] - da) * scale;
         }
       }
-      const bf16x8 pf = pack_frag(pt2[0], pt2[1]);
-      const bf16x8 sf = pack_frag(ds2[0], ds2[1]);
+      const frag8_t pf = pack_frag<TE>(pt2[0], pt2[1]);
+      const frag8_t sf = pack_frag<TE>(ds2[0], ds2[1]);
 #pragma unroll
       for (int df = 0; df < 4; ++df) {
-        dv[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag_tr(Os, troff, df, qb2), pf, dv[df], 0, 0, 0);
-        dk[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag_tr(Qs, troff, df, qb2), sf, dk[df], 0, 0, 0);
+        dv[df] = mfma16<TE>(lds_frag_tr(Os, troff, df, qb2), pf, dv[df]);
+        dk[df] = mfma16<TE>(lds_frag_tr(Qs, troff, df, qb2), sf, dk[df]);
       }
     }
     if (key < Tn) {
       bf16_t* dstk = dqkv + ((int64_t)b * Tn + key) * gs + H + h * HD + g * 4;
-      store_row4x4(dstk, dk);
-      store_row4x4(dstk + H, dv);
+      store_row4x4<TE>(dstk, dk);
+      store_row4x4<TE>(dstk + H, dv);
     }
   }
 }
@@ -896,7 +908,8 @@ static int attn_check(const char* nm, int B, int T, int heads, int d, int dtype,
   W2V2_REQUIRE(B > 0 && T > 0 && heads > 0, "%s: bad shape", nm);
   W2V2_REQUIRE(d == HD, "%s: fused attention needs head dim 64 (got %d); use the unfused path", nm, d);
   W2V2_REQUIRE(T <= 256, "%s: fused attention covers T <= 256 (got %d); use the unfused path", nm, T);
-  W2V2_REQUIRE(dtype == W2V2_BF16, "%s: fused attention is bf16 only; the f32 parity mode uses the unfused path", nm);
+  W2V2_REQUIRE(dtype == W2V2_BF16 || dtype == W2V2_F16,
+               "%s: fused attention needs 16-bit activations; the f32 parity mode uses the unfused path", nm);
   W2V2_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "%s: bad dropout p", nm);
   return 0;
 }
@@ -925,10 +938,9 @@ static const bool g_attn_v2 = getenv("W2V2_ATTN_V2") != nullptr;
     default: { constexpr int NF = 16; CALL; } break; \
   }
 
-extern "C" int w2v2_attention_fwd(const void* qkv, void* ctx, float* lse, int B, int T, int heads, int d, float scale,
-                                  float drop_p, uint64_t seed, int dtype, void* stream) {
-  if (attn_check("attention_fwd", B, T, heads, d, dtype, drop_p)) return -1;
-  W2V2_REQUIRE(qkv && ctx && lse, "attention_fwd: null pointer");
+template <typename TE>
+static int attention_fwd_t(const void* qkv, void* ctx, float* lse, int B, int T, int heads, float scale, float drop_p,
+                           uint64_t seed, void* stream) {
   const int nf = (int)cdiv(T, 32) * 2;
   dim3 grid((unsigned)cdiv(T, 64), heads, B);
   const float ik = 1.0f / (1.0f - drop_p);
@@ -936,27 +948,35 @@ extern "C" int w2v2_attention_fwd(const void* qkv, void* ctx, float* lse, int B,
   if (nf <= 10 && !g_attn_v1) {
     dim3 grid2(heads, B);
     ATTN_DISPATCH_SMALL(nf, {
-      set_lds(attn_fwd2_kernel<NF>, fwd2_lds<NF>());
-      hipLaunchKernelGGL(attn_fwd2_kernel<NF>, grid2, dim3(256), fwd2_lds<NF>(), st, (const bf16_t*)qkv, (bf16_t*)ctx,
+      set_lds(attn_fwd2_kernel<TE, NF>, fwd2_lds<NF>());
+      hipLaunchKernelGGL((attn_fwd2_kernel<TE, NF>), grid2, dim3(256), fwd2_lds<NF>(), st, (const bf16_t*)qkv, (bf16_t*)ctx,
                          lse, T, heads, scale, drop_p, ik, seed);
     });
     W2V2_CHECK_LAUNCH("attention_fwd");
     return 0;
   }
   ATTN_DISPATCH(nf, {
-    set_lds(attn_fwd_kernel<NF>, fwd_lds<NF>());
-    hipLaunchKernelGGL(attn_fwd_kernel<NF>, grid, dim3(256), fwd_lds<NF>(), st, (const bf16_t*)qkv, (bf16_t*)ctx, lse,
+    set_lds(attn_fwd_kernel<TE, NF>, fwd_lds<NF>());
+    hipLaunchKernelGGL((attn_fwd_kernel<TE, NF>), grid, dim3(256), fwd_lds<NF>(), st, (const bf16_t*)qkv, (bf16_t*)ctx, lse,
                        T, heads, scale, drop_p, ik, seed);
   });
   W2V2_CHECK_LAUNCH("attention_fwd");
   return 0;
 }
 
-extern "C" int w2v2_attention_bwd(const void* qkv, const void* ctx, const void* dctx, const float* lse, void* dqkv,
-                                  float* delta, int B, int T, int heads, int d, float scale, float drop_p,
-                                  uint64_t seed, int dtype, void* stream) {
-  if (attn_check("attention_bwd", B, T, heads, d, dtype, drop_p)) return -1;
-  W2V2_REQUIRE(qkv && ctx && dctx && lse && dqkv && delta, "attention_bwd: null pointer");
+extern "C" int w2v2_attention_fwd(const void* qkv, void* ctx, float* lse, int B, int T, int heads, int d, float scale,
+                                  float drop_p, uint64_t seed, int dtype, void* stream) {
+  if (attn_check("attention_fwd", B, T, heads, d, dtype, drop_p)) return -1;
+  W2V2_REQUIRE(qkv && ctx && lse, "attention_fwd: null pointer");
+  W2V2_DISPATCH_16(dtype, "attention_fwd",
+                   return attention_fwd_t<AT>(qkv, ctx, lse, B, T, heads, scale, drop_p, seed, stream););
+  return 0;
+}
+
+template <typename TE>
+static int attention_bwd_t(const void* qkv, const void* ctx, const void* dctx, const float* lse, void* dqkv,
+                           float* delta, int B, int T, int heads, float scale, float drop_p, uint64_t seed,
+                           void* stream) {
   const int nf = (int)cdiv(T, 32) * 2;
   dim3 grid((unsigned)cdiv(T, 64), heads, B);
   const float ik = 1.0f / (1.0f - drop_p);
@@ -965,15 +985,15 @@ extern "C" int w2v2_attention_bwd(const void* qkv, const void* ctx, const void* 
     dim3 grid2(heads, B);
     if (g_attn_v2) {
       ATTN_DISPATCH_SMALL(nf, {
-        set_lds(attn_bwd2_kernel<NF>, bwd2_lds<NF>());
-        hipLaunchKernelGGL(attn_bwd2_kernel<NF>, grid2, dim3(256), bwd2_lds<NF>(), st, (const bf16_t*)qkv,
+        set_lds(attn_bwd2_kernel<TE, NF>, bwd2_lds<NF>());
+        hipLaunchKernelGGL((attn_bwd2_kernel<TE, NF>), grid2, dim3(256), bwd2_lds<NF>(), st, (const bf16_t*)qkv,
                            (const bf16_t*)ctx, (const bf16_t*)dctx, lse, (bf16_t*)dqkv, T, heads, scale, drop_p, ik,
                            seed);
       });
     } else {
       ATTN_DISPATCH_SMALL(nf, {
-        set_lds(attn_bwd3_kernel<NF>, bwd3_lds<NF>());
-        hipLaunchKernelGGL(attn_bwd3_kernel<NF>, grid2, dim3(256), bwd3_lds<NF>(), st, (const bf16_t*)qkv,
+        set_lds(attn_bwd3_kernel<TE, NF>, bwd3_lds<NF>());
+        hipLaunchKernelGGL((attn_bwd3_kernel<TE, NF>), grid2, dim3(256), bwd3_lds<NF>(), st, (const bf16_t*)qkv,
                            (const bf16_t*)ctx, (const bf16_t*)dctx, lse, (bf16_t*)dqkv, delta, T, heads, scale, drop_p,
                            ik, seed);
       });
@@ -982,14 +1002,24 @@ extern "C" int w2v2_attention_bwd(const void* qkv, const void* ctx, const void* 
     return 0;
   }
   ATTN_DISPATCH(nf, {
-    set_lds(attn_bwd_dq_kernel<NF>, dq_lds<NF>());
-    set_lds(attn_bwd_kv_kernel<NF>, kv_lds<NF>());
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<NF>, grid, dim3(256), dq_lds<NF>(), st, (const bf16_t*)qkv,
+    set_lds(attn_bwd_dq_kernel<TE, NF>, dq_lds<NF>());
+    set_lds(attn_bwd_kv_kernel<TE, NF>, kv_lds<NF>());
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<TE, NF>), grid, dim3(256), dq_lds<NF>(), st, (const bf16_t*)qkv,
                        (const bf16_t*)ctx, (const bf16_t*)dctx, lse, (bf16_t*)dqkv, delta, T, heads, scale, drop_p, ik,
                        seed);
-    hipLaunchKernelGGL(attn_bwd_kv_kernel<NF>, grid, dim3(256), kv_lds<NF>(), st, (const bf16_t*)qkv,
+    hipLaunchKernelGGL((attn_bwd_kv_kernel<TE, NF>), grid, dim3(256), kv_lds<NF>(), st, (const bf16_t*)qkv,
                        (const bf16_t*)dctx, lse, (const float*)delta, (bf16_t*)dqkv, T, heads, scale, drop_p, ik, seed);
   });
   W2V2_CHECK_LAUNCH("attention_bwd");
+  return 0;
+}
+
+extern "C" int w2v2_attention_bwd(const void* qkv, const void* ctx, const void* dctx, const float* lse, void* dqkv,
+                                  float* delta, int B, int T, int heads, int d, float scale, float drop_p,
+                                  uint64_t seed, int dtype, void* stream) {
+  if (attn_check("attention_bwd", B, T, heads, d, dtype, drop_p)) return -1;
+  W2V2_REQUIRE(qkv && ctx && dctx && lse && dqkv && delta, "attention_bwd: null pointer");
+  W2V2_DISPATCH_16(dtype, "attention_bwd",
+                   return attention_bwd_t<AT>(qkv, ctx, dctx, lse, dqkv, delta, B, T, heads, scale, drop_p, seed, stream););
   return 0;
 }

@@ -42,12 +42,46 @@ __device__ __forceinline__ uint32_t f32x2_to_bf16x2(float lo, float hi) {
   return __builtin_bit_cast(uint32_t, v);
 }
 
+// ---------------------------------------------------------------- fp16 storage type
+// IEEE half (11-bit significand: 8x the precision of bf16 at the same MFMA rate; the reference itself trains under
+// fp16 AMP, config/experiment/speaker_wav2vec2_aam.yaml:17).  A distinct C++ type so templates can tell the two
+// 16-bit activation formats apart; the backward runs under a loss scale (see optim.hip).
+typedef _Float16 f16_t;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_hw;
+typedef __attribute__((ext_vector_type(2))) float f32x2_hw;
+__device__ __forceinline__ float f16_to_f32(f16_t v) { return (float)v; }
+__device__ __forceinline__ f16_t f32_to_f16(float f) { return (f16_t)f; }
+__device__ __forceinline__ uint32_t f32x2_to_f16x2(float lo, float hi) {
+  f32x2_hw f;
+  f[0] = lo;
+  f[1] = hi;
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, f16x2_hw));   // v_cvt_pk_f16_f32 (RNE)
+}
+
 template <typename T> __device__ __forceinline__ float to_f32(T v);
 template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }
 template <> __device__ __forceinline__ float to_f32<bf16_t>(bf16_t v) { return bf16_to_f32(v); }
 template <typename T> __device__ __forceinline__ T from_f32(float v);
 template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
 template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return f32_to_bf16(v); }
+template <> __device__ __forceinline__ float to_f32<f16_t>(f16_t v) { return f16_to_f32(v); }
+template <> __device__ __forceinline__ f16_t from_f32<f16_t>(float v) { return f32_to_f16(v); }
+
+// two f32 -> one packed dword of the 16-bit activation type T (low half = first value)
+template <typename T> __device__ __forceinline__ uint32_t pack2(float lo, float hi);
+template <> __device__ __forceinline__ uint32_t pack2<bf16_t>(float lo, float hi) { return f32x2_to_bf16x2(lo, hi); }
+template <> __device__ __forceinline__ uint32_t pack2<f16_t>(float lo, float hi) { return f32x2_to_f16x2(lo, hi); }
+// one packed dword -> two f32
+template <typename T> __device__ __forceinline__ void unpack2(uint32_t w, float& lo, float& hi);
+template <> __device__ __forceinline__ void unpack2<bf16_t>(uint32_t w, float& lo, float& hi) {
+  lo = __uint_as_float(w << 16);
+  hi = __uint_as_float(w & 0xffff0000u);
+}
+template <> __device__ __forceinline__ void unpack2<f16_t>(uint32_t w, float& lo, float& hi) {
+  const f16x2_hw h = __builtin_bit_cast(f16x2_hw, w);
+  lo = (float)h[0];
+  hi = (float)h[1];
+}
 
 // 8-element vector access (16 B for bf16, 32 B for f32); p must be 16-byte aligned.
 template <typename T> struct Vec8;
@@ -80,6 +114,81 @@ template <> struct Vec8<bf16_t> {
     *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
   }
 };
+
+template <> struct Vec8<f16_t> {
+  float v[8];
+  __device__ __forceinline__ void load(const f16_t* p) {
+    uint4 a = *reinterpret_cast<const uint4*>(p);
+    uint32_t w[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) unpack2<f16_t>(w[i], v[2 * i], v[2 * i + 1]);
+  }
+  __device__ __forceinline__ void store(f16_t* p) const {
+    uint32_t w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w[i] = f32x2_to_f16x2(v[2 * i], v[2 * i + 1]);
+    *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+};
+
+// ---------------------------------------------------------------- matrix cores: one 16x16x32 step on raw 16-bit fragments
+// Fragments travel as 8 x 16 raw bits (LDS images and registers do not care about the number format); the
+// instruction is picked by the activation type: v_mfma_f32_16x16x32_bf16 / v_mfma_f32_16x16x32_f16 (same rate).
+typedef __attribute__((ext_vector_type(8))) short frag8_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_hw;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_hw;
+typedef __attribute__((ext_vector_type(4))) float f32x4_hw;
+template <typename T> __device__ __forceinline__ f32x4_hw mfma16(frag8_t a, frag8_t b, f32x4_hw c);
+template <> __device__ __forceinline__ f32x4_hw mfma16<bf16_t>(frag8_t a, frag8_t b, f32x4_hw c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_hw, a), __builtin_bit_cast(bf16x8_hw, b), c, 0,
+                                                 0, 0);
+}
+template <> __device__ __forceinline__ f32x4_hw mfma16<f16_t>(frag8_t a, frag8_t b, f32x4_hw c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_hw, a), __builtin_bit_cast(f16x8_hw, b), c, 0, 0,
+                                                0);
+}
+
+// acc + lo + hi of one packed pair, as ONE v_dot2c_f32_{bf16,f16} against a (1, 1) pair: column sums of fragments
+// that are in registers anyway (bias gradients).  The (1, 1) operand must live in a VGPR: as a 32-bit literal
+// (what the compiler emits for a constant) the packed-16 operand of v_dot2c is not read as two halves on gfx950 and
+// the sums come out wrong -- ones_pair() therefore hides the constant behind an empty asm.
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_dot_t;
+template <typename T> __device__ __forceinline__ uint32_t ones_pair();
+template <> __device__ __forceinline__ uint32_t ones_pair<bf16_t>() {
+  uint32_t w = 0x3f803f80u;
+  asm volatile("" : "+v"(w));
+  return w;
+}
+template <> __device__ __forceinline__ uint32_t ones_pair<f16_t>() {
+  uint32_t w = 0x3c003c00u;
+  asm volatile("" : "+v"(w));
+  return w;
+}
+template <typename T> __device__ __forceinline__ float pair_sum_add(uint32_t w, uint32_t ones, float acc);
+template <> __device__ __forceinline__ float pair_sum_add<bf16_t>(uint32_t w, uint32_t ones, float acc) {
+  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_dot_t, w), __builtin_bit_cast(bf16x2_dot_t, ones), acc,
+                                         false);
+}
+template <> __device__ __forceinline__ float pair_sum_add<f16_t>(uint32_t w, uint32_t ones, float acc) {
+  return __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2_hw, w), __builtin_bit_cast(f16x2_hw, ones), acc, false);
+}
+
+// ---------------------------------------------------------------- activation-dtype dispatch of the C entry points
+// `AT` names the storage type inside the statement; unknown codes fail with the entry point's name.
+#define W2V2_DISPATCH_ACT(DT, NAME, ...)                                       \
+  switch (DT) {                                                                \
+    case W2V2_BF16: { using AT = bf16_t; __VA_ARGS__; } break;                  \
+    case W2V2_F16: { using AT = f16_t; __VA_ARGS__; } break;                    \
+    case W2V2_F32: { using AT = float; __VA_ARGS__; } break;                    \
+    default: W2V2_FAIL("%s: bad dtype %d", NAME, (int)(DT));                   \
+  }
+// the two 16-bit formats only (kernels that need the matrix cores)
+#define W2V2_DISPATCH_16(DT, NAME, ...)                                        \
+  switch (DT) {                                                                \
+    case W2V2_BF16: { using AT = bf16_t; __VA_ARGS__; } break;                  \
+    case W2V2_F16: { using AT = f16_t; __VA_ARGS__; } break;                    \
+    default: W2V2_FAIL("%s: needs a 16-bit activation dtype (got %d)", NAME, (int)(DT)); \
+  }
 
 // ---------------------------------------------------------------- math
 // erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, i.e. f32 round-off class): 1 rcp + 1 exp + 7 fma

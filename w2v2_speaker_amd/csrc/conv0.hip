@@ -101,12 +101,13 @@ __device__ __forceinline__ bf16_t c0_lo(float x) { return f32_to_bf16(x - bf16_t
 
 constexpr int C0_CPB = 5;        // 128-frame chunks per workgroup: amortises the weight / scale fragments
 
-template <bool APPLY>
+template <bool APPLY, typename TO>
 __global__ __launch_bounds__(256, 2) void conv0_mfma_kernel(const float* __restrict__ wav, const float* __restrict__ w,
                                                          float* __restrict__ partial, const float* __restrict__ mr,
                                                          const float* __restrict__ gamma,
-                                                         const float* __restrict__ beta, bf16_t* __restrict__ y,
+                                                         const float* __restrict__ beta, TO* __restrict__ y,
                                                          int N, int L, int C, int k, int stride) {
+  // TO = 16-bit output type (bf16 or fp16); the convolution itself is always the split-bf16 product below
   extern __shared__ bf16_t c0_lds[];                 // xh[nmax] | xl[nmax] | one zero slot
   const int nmax = (C0_FRAMES - 1) * stride + k;
   const int b = blockIdx.y;
@@ -191,10 +192,10 @@ __global__ __launch_bounds__(256, 2) void conv0_mfma_kernel(const float* __restr
           acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf, c0_f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
         if constexpr (APPLY) {
           if (live) {
-            bf16_t* dst = y + ((int64_t)b * L + l0 + f0 + r) * C + cl;
+            TO* dst = y + ((int64_t)b * L + l0 + f0 + r) * C + cl;
 #pragma unroll
             for (int h = 0; h < 4; ++h) {             // 8 channels = fragments 2h, 2h+1
-              Vec8<bf16_t> o;
+              Vec8<TO> o;
 #pragma unroll
               for (int e = 0; e < 8; ++e) {
                 const int q = h * 8 + e;
@@ -271,7 +272,7 @@ extern "C" int w2v2_conv0_stats_mfma(const float* wav, const float* w, float* pa
   const int nchunk = (int)cdiv(cdiv(L, C0_FRAMES), C0_CPB);      // one partial per workgroup (C0_CPB chunks)
   dim3 grid((unsigned)nchunk, B);
   const size_t lds2 = (2 * ((size_t)(C0_FRAMES - 1) * stride + k) + 8) * sizeof(bf16_t);
-  hipLaunchKernelGGL((conv0_mfma_kernel<false>), grid, dim3(256), lds2, as_stream(stream), wav, w, partial,
+  hipLaunchKernelGGL((conv0_mfma_kernel<false, bf16_t>), grid, dim3(256), lds2, as_stream(stream), wav, w, partial,
                      (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (bf16_t*)nullptr, N, L, C, k,
                      stride);
   hipLaunchKernelGGL(conv0_finalize_kernel, dim3((unsigned)cdiv((int64_t)B * C, 256)), dim3(256), 0,
@@ -293,19 +294,15 @@ extern "C" int w2v2_conv0_apply(const float* wav, const float* w, const float* m
   const int L = (N - k) / stride + 1;
   dim3 grid((unsigned)cdiv(L, C0_FRAMES), B);
   const size_t lds = ((size_t)(C0_FRAMES - 1) * stride + k) * sizeof(float);
-  if (dtype == W2V2_BF16 && conv0_mfma_ok(C, k)) {
+  if ((dtype == W2V2_BF16 || dtype == W2V2_F16) && conv0_mfma_ok(C, k)) {
     const size_t lds2 = (2 * ((size_t)(C0_FRAMES - 1) * stride + k) + 8) * sizeof(bf16_t);
     dim3 grid2((unsigned)cdiv(cdiv(L, C0_FRAMES), C0_CPB), B);
-    hipLaunchKernelGGL((conv0_mfma_kernel<true>), grid2, dim3(256), lds2, as_stream(stream), wav, w, (float*)nullptr,
-                       mean_rstd, gamma, beta, (bf16_t*)y, N, L, C, k, stride);
-  } else if (dtype == W2V2_BF16)
-    hipLaunchKernelGGL((conv0_kernel<bf16_t, true>), grid, dim3(256), lds, as_stream(stream), wav, w,
-                       (float*)nullptr, mean_rstd, gamma, beta, (bf16_t*)y, N, L, C, k, stride, 0.f);
-  else if (dtype == W2V2_F32)
-    hipLaunchKernelGGL((conv0_kernel<float, true>), grid, dim3(256), lds, as_stream(stream), wav, w,
-                       (float*)nullptr, mean_rstd, gamma, beta, (float*)y, N, L, C, k, stride, 0.f);
-  else
-    W2V2_FAIL("conv0_apply: bad dtype %d", dtype);
+    W2V2_DISPATCH_16(dtype, "conv0_apply",
+      hipLaunchKernelGGL((conv0_mfma_kernel<true, AT>), grid2, dim3(256), lds2, as_stream(stream), wav, w,
+                         (float*)nullptr, mean_rstd, gamma, beta, (AT*)y, N, L, C, k, stride););
+  } else W2V2_DISPATCH_ACT(dtype, "conv0_apply",
+    hipLaunchKernelGGL((conv0_kernel<AT, true>), grid, dim3(256), lds, as_stream(stream), wav, w,
+                       (float*)nullptr, mean_rstd, gamma, beta, (AT*)y, N, L, C, k, stride, 0.f););
   W2V2_CHECK_LAUNCH("conv0_apply");
   return 0;
 }
@@ -327,12 +324,8 @@ extern "C" int w2v2_pack_conv_weight(const float* w, void* out, int dtype, int C
   W2V2_REQUIRE(w && out && Cout > 0 && Cin > 0 && k > 0, "pack_conv_weight: bad arguments");
   const int64_t total = (int64_t)Cout * Cin * k;
   int nb = (int)(cdiv(total, 256) > 4096 ? 4096 : cdiv(total, 256));
-  if (dtype == W2V2_BF16)
-    hipLaunchKernelGGL(pack_conv_kernel<bf16_t>, dim3(nb), dim3(256), 0, as_stream(stream), w, (bf16_t*)out, Cout, Cin, k);
-  else if (dtype == W2V2_F32)
-    hipLaunchKernelGGL(pack_conv_kernel<float>, dim3(nb), dim3(256), 0, as_stream(stream), w, (float*)out, Cout, Cin, k);
-  else
-    W2V2_FAIL("pack_conv_weight: bad dtype %d", dtype);
+  W2V2_DISPATCH_ACT(dtype, "pack_conv_weight",
+    hipLaunchKernelGGL(pack_conv_kernel<AT>, dim3(nb), dim3(256), 0, as_stream(stream), w, (AT*)out, Cout, Cin, k););
   W2V2_CHECK_LAUNCH("pack_conv_weight");
   return 0;
 }
@@ -426,9 +419,7 @@ extern "C" int w2v2_conv0_bwd(const float* wav, const float* w, const float* mea
 #define W2V2_C0B(T_, P_)                                                                                       \
   hipLaunchKernelGGL((conv0_bwd_kernel<T_, P_>), grid, dim3(256), lds, st, wav, w, mean_rstd, gamma, beta,     \
                      (const T_*)dz, sums, dw, dgamma, dbeta, N, L, C, k, stride)
-  if (dtype == W2V2_BF16) { W2V2_C0B(bf16_t, 1); W2V2_C0B(bf16_t, 2); }
-  else if (dtype == W2V2_F32) { W2V2_C0B(float, 1); W2V2_C0B(float, 2); }
-  else W2V2_FAIL("conv0_bwd: bad dtype %d", dtype);
+  W2V2_DISPATCH_ACT(dtype, "conv0_bwd", { W2V2_C0B(AT, 1); W2V2_C0B(AT, 2); });
 #undef W2V2_C0B
   W2V2_CHECK_LAUNCH("conv0_bwd");
   return 0;
@@ -468,12 +459,8 @@ extern "C" int w2v2_col2im(const void* col, void* dx, int B, int Lin, int Lout, 
   W2V2_REQUIRE(col && dx && B > 0 && Lin > 0 && Lout > 0 && Cin % 8 == 0 && k > 0 && stride > 0, "col2im: bad arguments");
   const int64_t total = (int64_t)B * Lin * (Cin >> 3);
   int nb = (int)(cdiv(total, 256) > 16384 ? 16384 : cdiv(total, 256));
-  if (dtype == W2V2_BF16)
-    hipLaunchKernelGGL(col2im_kernel<bf16_t>, dim3(nb), dim3(256), 0, as_stream(stream), (const bf16_t*)col, (bf16_t*)dx, B, Lin, Lout, Cin, k, stride);
-  else if (dtype == W2V2_F32)
-    hipLaunchKernelGGL(col2im_kernel<float>, dim3(nb), dim3(256), 0, as_stream(stream), (const float*)col, (float*)dx, B, Lin, Lout, Cin, k, stride);
-  else
-    W2V2_FAIL("col2im: bad dtype %d", dtype);
+  W2V2_DISPATCH_ACT(dtype, "col2im",
+    hipLaunchKernelGGL(col2im_kernel<AT>, dim3(nb), dim3(256), 0, as_stream(stream), (const AT*)col, (AT*)dx, B, Lin, Lout, Cin, k, stride););
   W2V2_CHECK_LAUNCH("col2im");
   return 0;
 }

@@ -36,14 +36,9 @@ extern "C" int w2v2_dropout(const void* x, void* y, int64_t n, float p, uint64_t
   W2V2_REQUIRE(x && y && n >= 0 && p >= 0.f && p < 1.f, "dropout: bad arguments");
   if (n == 0) return 0;
   const float ik = 1.0f / (1.0f - p);
-  if (dtype == W2V2_BF16)
-    hipLaunchKernelGGL(dropout_kernel<bf16_t>, dim3(ew_blocks(n >> 3)), dim3(256), 0, as_stream(stream),
-                       (const bf16_t*)x, (bf16_t*)y, n, p, ik, seed);
-  else if (dtype == W2V2_F32)
-    hipLaunchKernelGGL(dropout_kernel<float>, dim3(ew_blocks(n >> 3)), dim3(256), 0, as_stream(stream),
-                       (const float*)x, (float*)y, n, p, ik, seed);
-  else
-    W2V2_FAIL("dropout: bad dtype %d", dtype);
+  W2V2_DISPATCH_ACT(dtype, "dropout",
+    hipLaunchKernelGGL(dropout_kernel<AT>, dim3(ew_blocks(n >> 3)), dim3(256), 0, as_stream(stream),
+                       (const AT*)x, (AT*)y, n, p, ik, seed););
   W2V2_CHECK_LAUNCH("dropout");
   return 0;
 }
@@ -71,14 +66,9 @@ template <int OP>
 static int launch_binary(const void* a, const void* b, void* y, int64_t n, int dtype, void* stream, const char* nm) {
   W2V2_REQUIRE(a && b && y && n >= 0, "%s: bad arguments", nm);
   if (n == 0) return 0;
-  if (dtype == W2V2_BF16)
-    hipLaunchKernelGGL((binary_kernel<bf16_t, OP>), dim3(ew_blocks(n >> 3)), dim3(256), 0, as_stream(stream),
-                       (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)y, n);
-  else if (dtype == W2V2_F32)
-    hipLaunchKernelGGL((binary_kernel<float, OP>), dim3(ew_blocks(n >> 3)), dim3(256), 0, as_stream(stream),
-                       (const float*)a, (const float*)b, (float*)y, n);
-  else
-    W2V2_FAIL("%s: bad dtype %d", nm, dtype);
+  W2V2_DISPATCH_ACT(dtype, nm,
+    hipLaunchKernelGGL((binary_kernel<AT, OP>), dim3(ew_blocks(n >> 3)), dim3(256), 0, as_stream(stream),
+                       (const AT*)a, (const AT*)b, (AT*)y, n););
   W2V2_CHECK_LAUNCH(nm);
   return 0;
 }
@@ -134,15 +124,10 @@ extern "C" int w2v2_colsum(const void* x, int64_t ld, float* out, int M, int N, 
   if (gy < 1) gy = 1;
   dim3 grid((unsigned)cdiv(N, 64 * VECW), gy), block(64, 4);
   hipStream_t st = as_stream(stream);
-  if (dtype == W2V2_BF16) {
-    if (vec) hipLaunchKernelGGL((colsum_kernel<bf16_t, 8>), grid, block, 0, st, (const bf16_t*)x, ld, out, M, N);
-    else hipLaunchKernelGGL((colsum_kernel<bf16_t, 1>), grid, block, 0, st, (const bf16_t*)x, ld, out, M, N);
-  } else if (dtype == W2V2_F32) {
-    if (vec) hipLaunchKernelGGL((colsum_kernel<float, 8>), grid, block, 0, st, (const float*)x, ld, out, M, N);
-    else hipLaunchKernelGGL((colsum_kernel<float, 1>), grid, block, 0, st, (const float*)x, ld, out, M, N);
-  } else {
-    W2V2_FAIL("colsum: bad dtype %d", dtype);
-  }
+  W2V2_DISPATCH_ACT(dtype, "colsum", {
+    if (vec) hipLaunchKernelGGL((colsum_kernel<AT, 8>), grid, block, 0, st, (const AT*)x, ld, out, M, N);
+    else hipLaunchKernelGGL((colsum_kernel<AT, 1>), grid, block, 0, st, (const AT*)x, ld, out, M, N);
+  });
   W2V2_CHECK_LAUNCH("colsum");
   return 0;
 }
@@ -168,12 +153,8 @@ __global__ void cast_kernel(const float* __restrict__ x, T* __restrict__ y, int6
 extern "C" int w2v2_cast(const float* x, void* y, int64_t n, int dtype, void* stream) {
   W2V2_REQUIRE(x && y && n >= 0, "cast: bad arguments");
   if (n == 0) return 0;
-  if (dtype == W2V2_BF16)
-    hipLaunchKernelGGL(cast_kernel<bf16_t>, dim3(ew_blocks(n >> 3)), dim3(256), 0, as_stream(stream), x, (bf16_t*)y, n);
-  else if (dtype == W2V2_F32)
-    hipLaunchKernelGGL(cast_kernel<float>, dim3(ew_blocks(n >> 3)), dim3(256), 0, as_stream(stream), x, (float*)y, n);
-  else
-    W2V2_FAIL("cast: bad dtype %d", dtype);
+  W2V2_DISPATCH_ACT(dtype, "cast",
+    hipLaunchKernelGGL(cast_kernel<AT>, dim3(ew_blocks(n >> 3)), dim3(256), 0, as_stream(stream), x, (AT*)y, n););
   W2V2_CHECK_LAUNCH("cast");
   return 0;
 }
@@ -232,12 +213,8 @@ extern "C" int w2v2_mask_fill(void* h, const uint8_t* mask, const float* embed, 
   W2V2_REQUIRE(h && mask && embed && H % 8 == 0, "mask_fill: bad arguments");
   if (M <= 0) return 0;
   const int nb = ew_blocks((int64_t)M * (H >> 3));
-  if (dtype == W2V2_BF16)
-    hipLaunchKernelGGL(mask_fill_kernel<bf16_t>, dim3(nb), dim3(256), 0, as_stream(stream), (bf16_t*)h, mask, embed, M, H);
-  else if (dtype == W2V2_F32)
-    hipLaunchKernelGGL(mask_fill_kernel<float>, dim3(nb), dim3(256), 0, as_stream(stream), (float*)h, mask, embed, M, H);
-  else
-    W2V2_FAIL("mask_fill: bad dtype %d", dtype);
+  W2V2_DISPATCH_ACT(dtype, "mask_fill",
+    hipLaunchKernelGGL(mask_fill_kernel<AT>, dim3(nb), dim3(256), 0, as_stream(stream), (AT*)h, mask, embed, M, H););
   W2V2_CHECK_LAUNCH("mask_fill");
   return 0;
 }
@@ -248,12 +225,8 @@ extern "C" int w2v2_mask_fill_bwd(void* dh, const uint8_t* mask, float* d_embed,
   int gy = (int)cdiv(M, 32 * 16);
   if (gy < 1) gy = 1;
   dim3 grid((unsigned)cdiv(H, 64), gy);
-  if (dtype == W2V2_BF16)
-    hipLaunchKernelGGL(mask_fill_bwd_kernel<bf16_t>, grid, dim3(256), 0, as_stream(stream), (bf16_t*)dh, mask, d_embed, M, H);
-  else if (dtype == W2V2_F32)
-    hipLaunchKernelGGL(mask_fill_bwd_kernel<float>, grid, dim3(256), 0, as_stream(stream), (float*)dh, mask, d_embed, M, H);
-  else
-    W2V2_FAIL("mask_fill_bwd: bad dtype %d", dtype);
+  W2V2_DISPATCH_ACT(dtype, "mask_fill_bwd",
+    hipLaunchKernelGGL(mask_fill_bwd_kernel<AT>, grid, dim3(256), 0, as_stream(stream), (AT*)dh, mask, d_embed, M, H););
   W2V2_CHECK_LAUNCH("mask_fill_bwd");
   return 0;
 }
@@ -281,12 +254,8 @@ __global__ void prepend_kernel(const T* __restrict__ x, T* __restrict__ y, float
 extern "C" int w2v2_prepend_token(const void* x, void* y, float c, int B, int T, int H, int dtype, void* stream) {
   W2V2_REQUIRE(x && y && B > 0 && T > 0 && H % 8 == 0, "prepend_token: bad arguments");
   const int nb = ew_blocks((int64_t)B * (T + 1) * (H >> 3));
-  if (dtype == W2V2_BF16)
-    hipLaunchKernelGGL(prepend_kernel<bf16_t>, dim3(nb), dim3(256), 0, as_stream(stream), (const bf16_t*)x, (bf16_t*)y, c, B, T, H);
-  else if (dtype == W2V2_F32)
-    hipLaunchKernelGGL(prepend_kernel<float>, dim3(nb), dim3(256), 0, as_stream(stream), (const float*)x, (float*)y, c, B, T, H);
-  else
-    W2V2_FAIL("prepend_token: bad dtype %d", dtype);
+  W2V2_DISPATCH_ACT(dtype, "prepend_token",
+    hipLaunchKernelGGL(prepend_kernel<AT>, dim3(nb), dim3(256), 0, as_stream(stream), (const AT*)x, (AT*)y, c, B, T, H););
   W2V2_CHECK_LAUNCH("prepend_token");
   return 0;
 }
@@ -354,7 +323,7 @@ extern "C" int w2v2_transpose_many(const void* src, void* dst, const int64_t* ta
   W2V2_REQUIRE(src && dst && table && n >= 0 && blocks_per_matrix > 0, "transpose_many: bad arguments");
   if (n == 0) return 0;
   dim3 grid(blocks_per_matrix, n);
-  if (dtype == W2V2_BF16)
+  if (dtype == W2V2_BF16 || dtype == W2V2_F16)      // pure data movement: the two 16-bit formats share one instantiation
     hipLaunchKernelGGL(transpose_many_kernel<bf16_t>, grid, dim3(256), 0, as_stream(stream), (const bf16_t*)src,
                        (bf16_t*)dst, table);
   else if (dtype == W2V2_F32)

@@ -17,7 +17,6 @@
 #include <type_traits>
 #include <stdlib.h>
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 struct OpDev {
@@ -127,8 +126,8 @@ __device__ __forceinline__ void epilogue_store4(const GemmArgs& g, TC* __restric
       *reinterpret_cast<float4*>(crow + n0) = make_float4(out[0], out[1], out[2], out[3]);
     } else {
       uint2 w;
-      w.x = f32x2_to_bf16x2(out[0], out[1]);
-      w.y = f32x2_to_bf16x2(out[2], out[3]);
+      w.x = pack2<TC>(out[0], out[1]);
+      w.y = pack2<TC>(out[2], out[3]);
       *reinterpret_cast<uint2*>(crow + n0) = w;
     }
   } else {
@@ -174,8 +173,8 @@ __device__ __forceinline__ void epilogue_row8_impl(const GemmArgs& g, TC* __rest
   }
   TC* cp = Cz + (int64_t)m * g.ldc + n;
   if constexpr (DEFER) {             // deferred store (host guarantees full, aligned, non-atomic, single output)
-    *dout = make_uint4(f32x2_to_bf16x2(v[0], v[1]), f32x2_to_bf16x2(v[2], v[3]), f32x2_to_bf16x2(v[4], v[5]),
-                       f32x2_to_bf16x2(v[6], v[7]));
+    if constexpr (sizeof(TC) == 2)
+      *dout = make_uint4(pack2<TC>(v[0], v[1]), pack2<TC>(v[2], v[3]), pack2<TC>(v[4], v[5]), pack2<TC>(v[6], v[7]));
     return;
   }
   if (g.atomic) {
@@ -468,7 +467,7 @@ struct Stager {
   }
 };
 
-template <int FM, int FN, bool TA, bool TB, typename TC>
+template <typename TE, int FM, int FN, bool TA, bool TB, typename TC>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmArgs g) {
   constexpr int BM = 32 * FM, BN = 32 * FN;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -538,23 +537,23 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmArgs g) {
     const bf16_t* Bc = Bs + cur * BN * 64;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-      bf16x8 af[FM], bfr[FN];
+      frag8_t af[FM], bfr[FN];
 #pragma unroll
       for (int i = 0; i < FM; ++i) {
         const int row = wm * (16 * FM) + i * 16 + frow;
-        af[i] = *reinterpret_cast<const bf16x8*>(Ac + row * 64 + (((kk * 4 + fk) ^ swz_rs(row)) << 3));
+        af[i] = *reinterpret_cast<const frag8_t*>(Ac + row * 64 + (((kk * 4 + fk) ^ swz_rs(row)) << 3));
       }
 #pragma unroll
       for (int j = 0; j < FN; ++j) {
         const int row = wn * (16 * FN) + j * 16 + frow;
-        bfr[j] = *reinterpret_cast<const bf16x8*>(Bc + row * 64 + (((kk * 4 + fk) ^ swz_rs(row)) << 3));
+        bfr[j] = *reinterpret_cast<const frag8_t*>(Bc + row * 64 + (((kk * 4 + fk) ^ swz_rs(row)) << 3));
       }
 #pragma unroll
       for (int i = 0; i < FM; ++i)
 #pragma unroll
         for (int j = 0; j < FN; ++j)
           // operands swapped: D[row = n][col = m] so each lane owns 4 consecutive n of one m
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+          acc[i][j] = mfma16<TE>(bfr[j], af[i], acc[i][j]);
     }
     if (kt + 1 < nk) {
       sa.store(As + (cur ^ 1) * BM * 64, tid);
@@ -577,7 +576,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmArgs g) {
 typedef __attribute__((address_space(1))) const void gvoid_t;
 typedef __attribute__((address_space(3))) void lvoid_t;
 
-template <int FM, int FN, typename TC>
+template <typename TE, int FM, int FN, typename TC>
 __global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(const GemmArgs g) {
   constexpr int BM = 32 * FM, BN = 32 * FN;
   constexpr int NA = BM / 32, NB = BN / 32;      // 1 KiB pieces per wave per operand tile
@@ -642,22 +641,22 @@ __global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(const GemmArgs g) {
     const bf16_t* Bc = Bs + buf * BN * 64;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-      bf16x8 af[FM], bfr[FN];
+      frag8_t af[FM], bfr[FN];
 #pragma unroll
       for (int i = 0; i < FM; ++i) {
         const int row = wm * (16 * FM) + i * 16 + frow;
-        af[i] = *reinterpret_cast<const bf16x8*>(Ac + row * 64 + (((kk * 4 + fk) ^ swz(row)) << 3));
+        af[i] = *reinterpret_cast<const frag8_t*>(Ac + row * 64 + (((kk * 4 + fk) ^ swz(row)) << 3));
       }
 #pragma unroll
       for (int j = 0; j < FN; ++j) {
         const int row = wn * (16 * FN) + j * 16 + frow;
-        bfr[j] = *reinterpret_cast<const bf16x8*>(Bc + row * 64 + (((kk * 4 + fk) ^ swz(row)) << 3));
+        bfr[j] = *reinterpret_cast<const frag8_t*>(Bc + row * 64 + (((kk * 4 + fk) ^ swz(row)) << 3));
       }
 #pragma unroll
       for (int i = 0; i < FM; ++i)
 #pragma unroll
         for (int j = 0; j < FN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+          acc[i][j] = mfma16<TE>(bfr[j], af[i], acc[i][j]);
     }
   };
 
@@ -697,7 +696,7 @@ template <int S> __device__ __forceinline__ void wait_vmcnt() {
   else static_assert(S == 0 || S == 4 || S == 6 || S == 8, "unsupported count");
 }
 
-template <typename TC>
+template <typename TE, typename TC>
 __global__ __launch_bounds__(512) void gemm_bf16_glds3_kernel(const GemmArgs g) {
   constexpr int BM = 256, BN = 128, FM = 4, FN = 4;
   constexpr int STAGE = (BM + BN) * 64;           // elements per stage (A then B)
@@ -806,16 +805,16 @@ __global__ __launch_bounds__(512) void gemm_bf16_glds3_kernel(const GemmArgs g) 
     const bf16_t* b1 = base + boff + lb1;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-      bf16x8 af[FM], bfr[FN];
+      frag8_t af[FM], bfr[FN];
 #pragma unroll
-      for (int i = 0; i < FM; ++i) af[i] = *reinterpret_cast<const bf16x8*>((kk ? a1 : a0) + i * 16 * 64);
+      for (int i = 0; i < FM; ++i) af[i] = *reinterpret_cast<const frag8_t*>((kk ? a1 : a0) + i * 16 * 64);
 #pragma unroll
-      for (int j = 0; j < FN; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>((kk ? b1 : b0) + j * 4 * 64);
+      for (int j = 0; j < FN; ++j) bfr[j] = *reinterpret_cast<const frag8_t*>((kk ? b1 : b0) + j * 4 * 64);
 #pragma unroll
       for (int i = 0; i < FM; ++i) {
 #pragma unroll
         for (int j = 0; j < FN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+          acc[i][j] = mfma16<TE>(bfr[j], af[i], acc[i][j]);
         if (kload >= 0) {
           __builtin_amdgcn_sched_barrier(0);
           if (kk == 0) {
@@ -920,7 +919,7 @@ __device__ __forceinline__ int swz64_b(int row) { return ((row >> 4) & 1) << 1; 
 // ds_read has ~a full step of MFMA time to land (glds4 590 vs 559 TFLOP/s in-step).  Stage kt+1 must have landed one
 // step earlier than in a read-then-multiply loop, i.e. two stages are in flight instead of three; a fifth stage
 // (160 KiB, the whole LDS) restored the distance and measured the same, so four it is.
-template <typename TC>
+template <typename TE, typename TC>
 __global__ __launch_bounds__(512) void gemm_bf16_glds4_kernel(const GemmArgs g) {
   constexpr int BM = 256, BN = 256, FM = 8, FN = 4, BK = 32, S = 4;
   constexpr int STAGE = (BM + BN) * BK;           // elements per stage (A then B): 32 KiB
@@ -993,11 +992,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_glds4_kernel(const GemmArgs g) 
       if (st < nk && !(g.dbg & 4)) stage(st * STAGE, st);
     wait_stages(min(nk, S - 1) - 1 > 2 ? 2 : min(nk, S - 1) - 1);
     __builtin_amdgcn_s_barrier();
-    bf16x8 af[FM], bcur[FN], bnext[FN], alast;
+    frag8_t af[FM], bcur[FN], bnext[FN], alast;
 #pragma unroll
-    for (int j = 0; j < FN; ++j) bcur[j] = *reinterpret_cast<const bf16x8*>(smem + lb + j * 4 * BK);
+    for (int j = 0; j < FN; ++j) bcur[j] = *reinterpret_cast<const frag8_t*>(smem + lb + j * 4 * BK);
 #pragma unroll
-    for (int i = 0; i < FM; ++i) af[i] = *reinterpret_cast<const bf16x8*>(smem + la + i * 16 * BK);
+    for (int i = 0; i < FM; ++i) af[i] = *reinterpret_cast<const frag8_t*>(smem + la + i * 16 * BK);
 
     int nb = STAGE;                        // stage offset of step kt + 1
     int fb = (S - 1) * STAGE;              // stage offset that step kt + S - 1 is loaded into
@@ -1019,14 +1018,14 @@ __global__ __launch_bounds__(512) void gemm_bf16_glds4_kernel(const GemmArgs g) 
       for (int i = 0; i < FM; ++i) {
 #pragma unroll
         for (int j = 0; j < FN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bcur[j], af[i], acc[i][j], 0, 0, 0);
+          acc[i][j] = mfma16<TE>(bcur[j], af[i], acc[i][j]);
         if (i == 0) {
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int j = 0; j < FN; ++j) bnext[j] = *reinterpret_cast<const bf16x8*>(pb + j * 4 * BK);
-          alast = *reinterpret_cast<const bf16x8*>(pa + (FM - 1) * 16 * BK);   // early: nothing may trail the last group
+          for (int j = 0; j < FN; ++j) bnext[j] = *reinterpret_cast<const frag8_t*>(pb + j * 4 * BK);
+          alast = *reinterpret_cast<const frag8_t*>(pa + (FM - 1) * 16 * BK);   // early: nothing may trail the last group
         }
-        if (i < FM - 1) af[i] = *reinterpret_cast<const bf16x8*>(pa + i * 16 * BK);
+        if (i < FM - 1) af[i] = *reinterpret_cast<const frag8_t*>(pa + i * 16 * BK);
         if ((i & 1) && do_stage && spread) stage_piece(fb, kt + S - 1, i >> 1);
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -1041,7 +1040,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_glds4_kernel(const GemmArgs g) 
       for (int i = 0; i < FM; ++i)
 #pragma unroll
         for (int j = 0; j < FN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bcur[j], af[i], acc[i][j], 0, 0, 0);
+          acc[i][j] = mfma16<TE>(bcur[j], af[i], acc[i][j]);
     }
 
     TC* Cz = reinterpret_cast<TC*>(g.C) + z0 * g.c_s0 + z1 * g.c_s1;
@@ -1071,12 +1070,12 @@ static int device_cus() {
   return g_w2v2_ncu;
 }
 
-template <typename TC>
+template <typename TE, typename TC>
 static void launch_glds4(GemmArgs a, int M, int N, int batch, hipStream_t st) {
   constexpr size_t lds = (size_t)4 * (256 + 256) * 32 * sizeof(bf16_t);   // 128 KiB
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_glds4_kernel<TC>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_glds4_kernel<TE, TC>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
@@ -1084,15 +1083,15 @@ static void launch_glds4(GemmArgs a, int M, int N, int batch, hipStream_t st) {
   a.tiles_n = (int)cdiv(N, 256);
   const int tiles = a.tiles_m * a.tiles_n, ncu = device_cus();
   dim3 grid(tiles < ncu ? tiles : ncu, 1, batch);
-  hipLaunchKernelGGL((gemm_bf16_glds4_kernel<TC>), grid, dim3(512), lds, st, a);
+  hipLaunchKernelGGL((gemm_bf16_glds4_kernel<TE, TC>), grid, dim3(512), lds, st, a);
 }
 
-template <typename TC>
+template <typename TE, typename TC>
 static void launch_glds3(GemmArgs a, int M, int N, int batch, hipStream_t st) {
   constexpr size_t lds = (size_t)3 * (256 + 128) * 64 * sizeof(bf16_t);   // 144 KiB
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_glds3_kernel<TC>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_glds3_kernel<TE, TC>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
@@ -1101,19 +1100,19 @@ static void launch_glds3(GemmArgs a, int M, int N, int batch, hipStream_t st) {
   const int ncu = getenv("W2V2_G3_NONPERSISTENT") ? (1 << 30) : device_cus();
   const int tiles = a.tiles_m * a.tiles_n;
   dim3 grid(tiles < ncu ? tiles : ncu, 1, batch);
-  hipLaunchKernelGGL((gemm_bf16_glds3_kernel<TC>), grid, dim3(512), lds, st, a);
+  hipLaunchKernelGGL((gemm_bf16_glds3_kernel<TE, TC>), grid, dim3(512), lds, st, a);
 }
 
-template <int FM, int FN, typename TC>
+template <typename TE, int FM, int FN, typename TC>
 static void launch_glds(const GemmArgs& a, dim3 grid, hipStream_t st) {
   constexpr size_t lds = (size_t)2 * (32 * FM + 32 * FN) * 64 * sizeof(bf16_t);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_glds_kernel<FM, FN, TC>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_glds_kernel<TE, FM, FN, TC>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_bf16_glds_kernel<FM, FN, TC>), grid, dim3(256), lds, st, a);
+  hipLaunchKernelGGL((gemm_bf16_glds_kernel<TE, FM, FN, TC>), grid, dim3(256), lds, st, a);
 }
 
 // ------------------------------------------------------------------------------ exact f32 kernel
@@ -1188,7 +1187,7 @@ static const bool g_w2v2_glds3 = getenv("W2V2_NO_GLDS3") == nullptr;
 
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-template <int FM, int FN, typename TC>
+template <typename TE, int FM, int FN, typename TC>
 static void launch_bf16(const GemmArgs& a, dim3 grid, hipStream_t st) {
   constexpr size_t lds = (size_t)2 * (32 * FM + 32 * FN) * 64 * sizeof(bf16_t);
   const bool ta = a.A.trans, tb = a.B.trans;
@@ -1196,11 +1195,11 @@ static void launch_bf16(const GemmArgs& a, dim3 grid, hipStream_t st) {
   do {                                                                                          \
     static bool attr_set = false;                                                               \
     if (!attr_set) {                                                                            \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<FM, FN, TA_, TB_, TC>), \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<TE, FM, FN, TA_, TB_, TC>), \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);          \
       attr_set = true;                                                                          \
     }                                                                                           \
-    hipLaunchKernelGGL((gemm_bf16_kernel<FM, FN, TA_, TB_, TC>), grid, dim3(256), lds, st, a);  \
+    hipLaunchKernelGGL((gemm_bf16_kernel<TE, FM, FN, TA_, TB_, TC>), grid, dim3(256), lds, st, a);  \
   } while (0)
   if (!ta && !tb) W2V2_LAUNCH(false, false);
   else if (!ta && tb) W2V2_LAUNCH(false, true);
@@ -1214,8 +1213,10 @@ extern "C" int w2v2_gemm(const w2v2_gemm_desc* d, void* stream) {
   W2V2_REQUIRE(d->M > 0 && d->N > 0 && d->K >= 0 && d->batch > 0, "w2v2_gemm: bad shape M=%d N=%d K=%d batch=%d",
                d->M, d->N, d->K, d->batch);
   W2V2_REQUIRE(d->A.ptr && d->B.ptr && d->C, "w2v2_gemm: null operand");
-  W2V2_REQUIRE(d->dtype_ab == W2V2_F32 || d->dtype_ab == W2V2_BF16, "w2v2_gemm: bad dtype_ab %d", d->dtype_ab);
-  W2V2_REQUIRE(d->dtype_c == W2V2_F32 || d->dtype_c == W2V2_BF16, "w2v2_gemm: bad dtype_c %d", d->dtype_c);
+  W2V2_REQUIRE(d->dtype_ab == W2V2_F32 || d->dtype_ab == W2V2_BF16 || d->dtype_ab == W2V2_F16,
+               "w2v2_gemm: bad dtype_ab %d", d->dtype_ab);
+  W2V2_REQUIRE(d->dtype_c == W2V2_F32 || d->dtype_c == d->dtype_ab, "w2v2_gemm: dtype_c %d must be f32 or dtype_ab (%d)",
+               d->dtype_c, d->dtype_ab);
   W2V2_REQUIRE(d->epilogue >= 0 && d->epilogue <= W2V2_EPI_SCALE_RC, "w2v2_gemm: bad epilogue %d", d->epilogue);
   const int split = d->split_k > 1 ? d->split_k : 1;
   const int atomic = (split > 1 || d->accumulate) ? 1 : 0;
@@ -1258,7 +1259,7 @@ extern "C" int w2v2_gemm(const w2v2_gemm_desc* d, void* stream) {
                  (d->aux_stride1 % cal == 0);
   hipStream_t st = as_stream(stream);
 
-  if (d->dtype_ab == W2V2_BF16) {
+  if (d->dtype_ab != W2V2_F32) {
     const bool narrow = d->N <= 64;
     const int BM = 128, BN = narrow ? 64 : 128;
     a.tiles_m = (int)cdiv(d->M, BM); a.tiles_n = (int)cdiv(d->N, BN);
@@ -1277,25 +1278,23 @@ extern "C" int w2v2_gemm(const w2v2_gemm_desc* d, void* stream) {
       huge = t4 >= ncu && (double)t4 / (double)(cdiv(t4, ncu) * ncu) >= 0.85 &&
              (double)d->N / (double)(cdiv(d->N, 256) * 256) >= 0.9;
     }
-    if (huge) {
-      if (d->dtype_c == W2V2_F32) launch_glds4<float>(a, d->M, d->N, d->batch, st);
-      else launch_glds4<bf16_t>(a, d->M, d->N, d->batch, st);
-    } else if (big) {
-      a.defer_ok = defer_env && d->dtype_c == W2V2_BF16 && a.c_vec_ok && (d->N % 128 == 0) && !atomic &&
+    // TE = operand element type (selects the MFMA instruction), TC = float or TE
+#define W2V2_GEMM_LAUNCH(TE, TC)                                                                         \
+    do {                                                                                                 \
+      if (huge) launch_glds4<TE, TC>(a, d->M, d->N, d->batch, st);                                       \
+      else if (big) launch_glds3<TE, TC>(a, d->M, d->N, d->batch, st);                                   \
+      else if (glds) { if (narrow) launch_glds<TE, 4, 2, TC>(a, grid, st); else launch_glds<TE, 4, 4, TC>(a, grid, st); } \
+      else { if (narrow) launch_bf16<TE, 4, 2, TC>(a, grid, st); else launch_bf16<TE, 4, 4, TC>(a, grid, st); }         \
+    } while (0)
+    if (big && !huge)
+      a.defer_ok = defer_env && d->dtype_c != W2V2_F32 && a.c_vec_ok && (d->N % 128 == 0) && !atomic &&
                    d->epilogue != W2V2_EPI_BIAS_GELU;
-      if (d->dtype_c == W2V2_F32) launch_glds3<float>(a, d->M, d->N, d->batch, st);
-      else launch_glds3<bf16_t>(a, d->M, d->N, d->batch, st);
-    } else if (glds) {
-      if (d->dtype_c == W2V2_F32) {
-        if (narrow) launch_glds<4, 2, float>(a, grid, st); else launch_glds<4, 4, float>(a, grid, st);
-      } else {
-        if (narrow) launch_glds<4, 2, bf16_t>(a, grid, st); else launch_glds<4, 4, bf16_t>(a, grid, st);
-      }
-    } else if (d->dtype_c == W2V2_F32) {
-      if (narrow) launch_bf16<4, 2, float>(a, grid, st); else launch_bf16<4, 4, float>(a, grid, st);
+    if (d->dtype_ab == W2V2_BF16) {
+      if (d->dtype_c == W2V2_F32) W2V2_GEMM_LAUNCH(bf16_t, float); else W2V2_GEMM_LAUNCH(bf16_t, bf16_t);
     } else {
-      if (narrow) launch_bf16<4, 2, bf16_t>(a, grid, st); else launch_bf16<4, 4, bf16_t>(a, grid, st);
+      if (d->dtype_c == W2V2_F32) W2V2_GEMM_LAUNCH(f16_t, float); else W2V2_GEMM_LAUNCH(f16_t, f16_t);
     }
+#undef W2V2_GEMM_LAUNCH
   } else {
     W2V2_REQUIRE(d->dtype_c == W2V2_F32, "w2v2_gemm: f32 operands need an f32 C");
     a.tiles_m = (int)cdiv(d->M, 64); a.tiles_n = (int)cdiv(d->N, 64);

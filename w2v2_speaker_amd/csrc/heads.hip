@@ -21,12 +21,8 @@ __global__ __launch_bounds__(256) void row_invnorm_kernel(const T* __restrict__ 
 extern "C" int w2v2_row_invnorm(const void* x, int64_t ld, float* inv, int rows, int cols, int dtype, void* stream) {
   W2V2_REQUIRE(x && inv && rows > 0 && cols > 0 && ld >= cols, "row_invnorm: bad arguments");
   dim3 grid((unsigned)cdiv(rows, 4));
-  if (dtype == W2V2_BF16)
-    hipLaunchKernelGGL(row_invnorm_kernel<bf16_t>, grid, dim3(256), 0, as_stream(stream), (const bf16_t*)x, ld, inv, rows, cols);
-  else if (dtype == W2V2_F32)
-    hipLaunchKernelGGL(row_invnorm_kernel<float>, grid, dim3(256), 0, as_stream(stream), (const float*)x, ld, inv, rows, cols);
-  else
-    W2V2_FAIL("row_invnorm: bad dtype %d", dtype);
+  W2V2_DISPATCH_ACT(dtype, "row_invnorm",
+    hipLaunchKernelGGL(row_invnorm_kernel<AT>, grid, dim3(256), 0, as_stream(stream), (const AT*)x, ld, inv, rows, cols););
   W2V2_CHECK_LAUNCH("row_invnorm");
   return 0;
 }
@@ -50,10 +46,14 @@ __global__ __launch_bounds__(256) void aam_row_kernel(const float* __restrict__ 
                                                       const float* __restrict__ inv_x,
                                                       const float* __restrict__ inv_w, float* __restrict__ rowdot,
                                                       float* __restrict__ coldot, int B, int C, int64_t ldc,
-                                                      float margin, float scale) {
+                                                      float margin, float scale, const float* __restrict__ loss_scale) {
   __shared__ float sh[4];
   const int b = blockIdx.x;
-  const int y = (int)label[b];
+  const int64_t yl = label[b];
+  // a label outside [0, C) (data module with more speakers than the head): NaN loss for the row, no gradient, no
+  // out-of-range read (torch's CE would raise a device assert)
+  const bool bad_label = yl < 0 || yl >= C;
+  const int y = bad_label ? 0 : (int)yl;
   const float* cr = cosv + (int64_t)b * ldc;
   const bool plain = margin < 0.f;
   float zy, dphi = 1.0f, sc = plain ? 1.0f : scale;
@@ -83,8 +83,8 @@ __global__ __launch_bounds__(256) void aam_row_kernel(const float* __restrict__ 
   for (int c = threadIdx.x; c < C; c += 256) sum += __expf((c == y ? zy : cr[c] * sc) - mx);
   sum = block_reduce(sum, sh, false);
   const float inv = 1.0f / sum;
-  if (threadIdx.x == 0) loss_rows[b] = (mx + __logf(sum)) - zy;
-  const float invB = 1.0f / (float)B;
+  if (threadIdx.x == 0) loss_rows[b] = bad_label ? __builtin_nanf("") : (mx + __logf(sum)) - zy;
+  const float invB = bad_label ? 0.f : (loss_scale ? loss_scale[0] : 1.0f) / (float)B;
   float rd = 0.f;
   for (int c = threadIdx.x; c < C; c += 256) {
     const float cv = cr[c];
@@ -111,18 +111,12 @@ __global__ __launch_bounds__(256) void aam_row_kernel(const float* __restrict__ 
 extern "C" int w2v2_aam_softmax_fwd_bwd(const float* cos, const int64_t* label, float* softmax, float* loss_rows,
                                         void* dcos_w, void* dcos_x, const float* inv_x, const float* inv_w,
                                         float* rowdot, float* coldot, int B, int C, int64_t ldc, float margin,
-                                        float scale, int dtype, void* stream) {
+                                        float scale, const float* loss_scale, int dtype, void* stream) {
   W2V2_REQUIRE(cos && label && softmax && loss_rows && B > 0 && C > 0 && ldc >= C, "aam_softmax: bad arguments");
-  if (dtype == W2V2_BF16)
-    hipLaunchKernelGGL(aam_row_kernel<bf16_t>, dim3(B), dim3(256), 0, as_stream(stream), cos, label, softmax,
-                       loss_rows, (bf16_t*)dcos_w, (bf16_t*)dcos_x, inv_x, inv_w, rowdot, coldot, B, C, ldc, margin,
-                       scale);
-  else if (dtype == W2V2_F32)
-    hipLaunchKernelGGL(aam_row_kernel<float>, dim3(B), dim3(256), 0, as_stream(stream), cos, label, softmax,
-                       loss_rows, (float*)dcos_w, (float*)dcos_x, inv_x, inv_w, rowdot, coldot, B, C, ldc, margin,
-                       scale);
-  else
-    W2V2_FAIL("aam_softmax: bad dtype %d", dtype);
+  W2V2_DISPATCH_ACT(dtype, "aam_softmax",
+    hipLaunchKernelGGL(aam_row_kernel<AT>, dim3(B), dim3(256), 0, as_stream(stream), cos, label, softmax,
+                       loss_rows, (AT*)dcos_w, (AT*)dcos_x, inv_x, inv_w, rowdot, coldot, B, C, ldc, margin,
+                       scale, loss_scale););
   W2V2_CHECK_LAUNCH("aam_softmax");
   return 0;
 }
@@ -147,14 +141,9 @@ extern "C" int w2v2_normalize_bwd(const float* g, const void* x, int64_t ldx, co
   W2V2_REQUIRE(g && x && inv && dot && dx && rows > 0 && cols > 0 && ldx >= cols, "normalize_bwd: bad arguments");
   const int64_t total = (int64_t)rows * cols;
   int nb = (int)(cdiv(total, 256) > 4096 ? 4096 : cdiv(total, 256));
-  if (x_dtype == W2V2_BF16)
-    hipLaunchKernelGGL(normalize_bwd_kernel<bf16_t>, dim3(nb), dim3(256), 0, as_stream(stream), g, (const bf16_t*)x,
-                       ldx, inv, dot, dx, rows, cols, add);
-  else if (x_dtype == W2V2_F32)
-    hipLaunchKernelGGL(normalize_bwd_kernel<float>, dim3(nb), dim3(256), 0, as_stream(stream), g, (const float*)x,
-                       ldx, inv, dot, dx, rows, cols, add);
-  else
-    W2V2_FAIL("normalize_bwd: bad dtype %d", x_dtype);
+  W2V2_DISPATCH_ACT(x_dtype, "normalize_bwd",
+    hipLaunchKernelGGL(normalize_bwd_kernel<AT>, dim3(nb), dim3(256), 0, as_stream(stream), g, (const AT*)x,
+                       ldx, inv, dot, dx, rows, cols, add););
   W2V2_CHECK_LAUNCH("normalize_bwd");
   return 0;
 }
@@ -167,20 +156,22 @@ __global__ __launch_bounds__(64) void bce_row_kernel(const float* __restrict__ e
                                                      const float* __restrict__ b, const int64_t* __restrict__ label,
                                                      float* __restrict__ prob, float* __restrict__ loss_rows,
                                                      float* __restrict__ dlogit, float* __restrict__ demb, int B,
-                                                     int H) {
+                                                     int H, const float* __restrict__ loss_scale) {
   const int row = blockIdx.x, lane = threadIdx.x;
   const float* e = emb + (int64_t)row * H;
   float s = 0.f;
   for (int h = lane; h < H; h += 64) s = fmaf(e[h], w[h], s);
   s = wave_sum(s) + b[0];
-  const float y = (float)label[row];
+  const int64_t yl = label[row];
+  const bool bad_label = yl != 0 && yl != 1;          // NaN loss, zero gradient (see aam_row_kernel)
+  const float y = (float)yl;
   const float p = 1.0f / (1.0f + __expf(-s));
   // max(s, 0) - s*y + log(1 + exp(-|s|)): the numerically stable form torch uses
   const float l = fmaxf(s, 0.f) - s * y + log1pf(__expf(-fabsf(s)));
-  const float dl = (p - y) / (float)B;
+  const float dl = bad_label ? 0.f : (p - y) * (loss_scale ? loss_scale[0] : 1.0f) / (float)B;
   if (lane == 0) {
     prob[row] = p;
-    loss_rows[row] = l;
+    loss_rows[row] = bad_label ? __builtin_nanf("") : l;
     if (dlogit != nullptr) dlogit[row] = dl;
   }
   if (demb != nullptr)
@@ -204,13 +195,14 @@ __global__ void bce_wgrad_kernel(const float* __restrict__ emb, const float* __r
 
 extern "C" int w2v2_bce_head_fwd_bwd(const float* emb, const float* w, const float* b, const int64_t* label, float* prob,
                                      float* loss_rows, float* dlogit, float* demb, float* dw, float* db, int B, int H,
-                                     void* stream) {
+                                     const float* loss_scale, void* stream) {
   W2V2_REQUIRE(emb && w && b && label && prob && loss_rows && B > 0 && H > 0, "bce_head: bad arguments");
   W2V2_REQUIRE((dlogit == nullptr) == (demb == nullptr) && (demb == nullptr) == (dw == nullptr) &&
                    (dw == nullptr) == (db == nullptr),
                "bce_head: gradient outputs come together");
   hipStream_t st = as_stream(stream);
-  hipLaunchKernelGGL(bce_row_kernel, dim3(B), dim3(64), 0, st, emb, w, b, label, prob, loss_rows, dlogit, demb, B, H);
+  hipLaunchKernelGGL(bce_row_kernel, dim3(B), dim3(64), 0, st, emb, w, b, label, prob, loss_rows, dlogit, demb, B, H,
+                     loss_scale);
   if (dw != nullptr)
     hipLaunchKernelGGL(bce_wgrad_kernel, dim3((unsigned)cdiv(H, 256)), dim3(256), 0, st, emb, dlogit, dw, db, B, H);
   W2V2_CHECK_LAUNCH("bce_head");

@@ -244,14 +244,9 @@ extern "C" int w2v2_layernorm_fwd(const void* x, void* r, const float* gamma, co
   W2V2_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "layernorm_fwd: bad dropout p");
   if (M <= 0) return 0;
   dim3 grid((unsigned)cdiv(M, 4));
-  if (dtype == W2V2_BF16)
-    hipLaunchKernelGGL(ln_fwd_kernel<bf16_t>, grid, dim3(256), 0, as_stream(stream), (const bf16_t*)x,
-                       (bf16_t*)r, gamma, beta, (bf16_t*)y, mean, rstd, M, H, eps, drop_p, seed);
-  else if (dtype == W2V2_F32)
-    hipLaunchKernelGGL(ln_fwd_kernel<float>, grid, dim3(256), 0, as_stream(stream), (const float*)x,
-                       (float*)r, gamma, beta, (float*)y, mean, rstd, M, H, eps, drop_p, seed);
-  else
-    W2V2_FAIL("layernorm_fwd: bad dtype %d", dtype);
+  W2V2_DISPATCH_ACT(dtype, "layernorm_fwd",
+    hipLaunchKernelGGL(ln_fwd_kernel<AT>, grid, dim3(256), 0, as_stream(stream), (const AT*)x,
+                       (AT*)r, gamma, beta, (AT*)y, mean, rstd, M, H, eps, drop_p, seed););
   W2V2_CHECK_LAUNCH("layernorm_fwd");
   return 0;
 }
@@ -269,16 +264,10 @@ extern "C" int w2v2_layernorm_bwd(const void* dy, const void* s, const float* me
   const int nb = (int)(cdiv(M, 4) < LN_BWD_BLOCKS ? cdiv(M, 4) : LN_BWD_BLOCKS);
   // dgamma == NULL with a workspace: leave the per-block partials in it for w2v2_layernorm_bwd_fold
   float* partial = workspace;
-  if (dtype == W2V2_BF16)
-    hipLaunchKernelGGL(ln_bwd_kernel<bf16_t>, dim3(nb), dim3(256), 0, as_stream(stream), (const bf16_t*)dy,
-                       (const bf16_t*)s, mean, rstd, gamma, (bf16_t*)ds, (bf16_t*)d_r, dgamma, dbeta, partial, M, H,
-                       drop_p, seed);
-  else if (dtype == W2V2_F32)
-    hipLaunchKernelGGL(ln_bwd_kernel<float>, dim3(nb), dim3(256), 0, as_stream(stream), (const float*)dy,
-                       (const float*)s, mean, rstd, gamma, (float*)ds, (float*)d_r, dgamma, dbeta, partial, M, H,
-                       drop_p, seed);
-  else
-    W2V2_FAIL("layernorm_bwd: bad dtype %d", dtype);
+  W2V2_DISPATCH_ACT(dtype, "layernorm_bwd",
+    hipLaunchKernelGGL(ln_bwd_kernel<AT>, dim3(nb), dim3(256), 0, as_stream(stream), (const AT*)dy,
+                       (const AT*)s, mean, rstd, gamma, (AT*)ds, (AT*)d_r, dgamma, dbeta, partial, M, H,
+                       drop_p, seed););
   if (partial != nullptr && dgamma != nullptr)
     hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3((unsigned)cdiv(2 * H, 32)), dim3(256), 0, as_stream(stream),
                        partial, dgamma, dbeta, nb, H);

@@ -4,10 +4,18 @@
 // 4 f32 streams read (p, g, m, v) + 3 written (p, m, v) + 2 B/param bf16 copy = 30 B/param.
 #include "common.cuh"
 
+template <typename TB>
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v,
-                                                   bf16_t* __restrict__ pb, int64_t n, float lr, float b1, float b2,
-                                                   float eps, float step_size, float inv_sqrt_bc2, float gscale) {
+                                                   TB* __restrict__ pb, int64_t n, float lr, float b1, float b2,
+                                                   float eps, float step_size, float inv_sqrt_bc2, float gscale,
+                                                   const float* __restrict__ scaler) {
+  // dynamic loss scaling (fp16 activations): gradients carry the factor scaler[0]; a step whose gradients held a
+  // non-finite value (scaler[1] != 0, set by grad_scaler_check) is skipped as a whole, like torch's GradScaler.step
+  if (scaler != nullptr) {
+    if (scaler[1] != 0.f) return;
+    gscale /= scaler[0];
+  }
   const int64_t nv = n >> 2;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nv; i += (int64_t)gridDim.x * blockDim.x) {
     float4 pp = reinterpret_cast<float4*>(p)[i];
@@ -28,8 +36,8 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     reinterpret_cast<float4*>(v)[i] = vv;
     if (pb != nullptr) {
       uint2 w;
-      w.x = f32x2_to_bf16x2(pp.x, pp.y);
-      w.y = f32x2_to_bf16x2(pp.z, pp.w);
+      w.x = pack2<TB>(pp.x, pp.y);
+      w.y = pack2<TB>(pp.z, pp.w);
       reinterpret_cast<uint2*>(pb)[i] = w;
     }
   }
@@ -41,21 +49,77 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     m[i] = mi; v[i] = vi;
     const float pn = p[i] - step_size * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
     p[i] = pn;
-    if (pb != nullptr) pb[i] = f32_to_bf16(pn);
+    if (pb != nullptr) pb[i] = from_f32<TB>(pn);
   }
 }
 
-extern "C" int w2v2_adam_step(float* p, const float* g, float* m, float* v, void* pb, int64_t n, float lr,
-                              float beta1, float beta2, float eps, float bias_corr1, float bias_corr2,
-                              float grad_scale, void* stream) {
+// ------------------------------------------------------------------------------ dynamic loss scaling (fp16 activations)
+// The reference trains under PL `precision: 16` = torch.cuda.amp.GradScaler (config/experiment/
+// speaker_wav2vec2_aam.yaml:17): the loss is multiplied by `scale` before backward so that fp16 activation
+// gradients stay in range; a step with a non-finite gradient is skipped and the scale halved, and after
+// `growth_interval` clean steps it is doubled.  Everything lives in a 4-float device record, so a training step
+// never synchronises with the host:  state = {scale, found_inf, growth_tracker, skipped_steps}.
+__global__ __launch_bounds__(256) void scaler_check_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ state) {
+  const int64_t nv = n >> 2;
+  bool bad = false;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nv; i += (int64_t)gridDim.x * blockDim.x) {
+    const float4 v = reinterpret_cast<const float4*>(g)[i];
+    // finite <=> |x| <= FLT_MAX; the sum of absolute values is inf or NaN iff any element is
+    const float a = fabsf(v.x) + fabsf(v.y) + fabsf(v.z) + fabsf(v.w);
+    bad |= !(a <= 3.402823466e38f);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) bad |= !(fabsf(g[(nv << 2) + threadIdx.x]) <= 3.402823466e38f);
+  if (__any(bad) && (threadIdx.x & 63) == 0) state[1] = 1.0f;      // benign race: every writer stores the same value
+}
+__global__ void scaler_update_kernel(float* __restrict__ state, float growth, float backoff, int interval) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (state[1] != 0.f) {
+    state[0] = fmaxf(state[0] * backoff, 1.0f);
+    state[2] = 0.f;
+    state[3] += 1.0f;
+  } else {
+    state[2] += 1.0f;
+    if (state[2] >= (float)interval) {
+      state[0] = fminf(state[0] * growth, 16777216.0f);
+      state[2] = 0.f;
+    }
+  }
+  state[1] = 0.f;
+}
+
+extern "C" int w2v2_grad_scaler_check(const float* g, int64_t n, float* state, void* stream) {
+  W2V2_REQUIRE(g && state && n >= 0, "grad_scaler_check: bad arguments");
+  if (n == 0) return 0;
+  int64_t nb = cdiv(n >> 2, 256 * 8);
+  if (nb > 4096) nb = 4096;
+  if (nb < 1) nb = 1;
+  hipLaunchKernelGGL(scaler_check_kernel, dim3((unsigned)nb), dim3(256), 0, as_stream(stream), g, n, state);
+  W2V2_CHECK_LAUNCH("grad_scaler_check");
+  return 0;
+}
+
+extern "C" int w2v2_grad_scaler_update(float* state, float growth, float backoff, int growth_interval, void* stream) {
+  W2V2_REQUIRE(state && growth >= 1.f && backoff > 0.f && backoff <= 1.f && growth_interval > 0,
+               "grad_scaler_update: bad arguments");
+  hipLaunchKernelGGL(scaler_update_kernel, dim3(1), dim3(64), 0, as_stream(stream), state, growth, backoff,
+                     growth_interval);
+  W2V2_CHECK_LAUNCH("grad_scaler_update");
+  return 0;
+}
+
+extern "C" int w2v2_adam_step(float* p, const float* g, float* m, float* v, void* pb, int pb_dtype, int64_t n,
+                              float lr, float beta1, float beta2, float eps, float bias_corr1, float bias_corr2,
+                              float grad_scale, const float* scaler_state, void* stream) {
   W2V2_REQUIRE(p && g && m && v && n >= 0, "adam_step: bad arguments");
   W2V2_REQUIRE(bias_corr1 > 0.f && bias_corr2 > 0.f, "adam_step: bias corrections must be > 0");
   if (n == 0) return 0;
   int64_t nb = cdiv(n >> 2, 256);
   if (nb > 8192) nb = 8192;
   if (nb < 1) nb = 1;
-  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)nb), dim3(256), 0, as_stream(stream), p, g, m, v, (bf16_t*)pb, n, lr,
-                     beta1, beta2, eps, lr / bias_corr1, 1.0f / sqrtf(bias_corr2), grad_scale);
+  if (pb == nullptr) pb_dtype = W2V2_BF16;
+  W2V2_DISPATCH_16(pb_dtype, "adam_step",
+    hipLaunchKernelGGL(adam_kernel<AT>, dim3((unsigned)nb), dim3(256), 0, as_stream(stream), p, g, m, v, (AT*)pb, n, lr,
+                       beta1, beta2, eps, lr / bias_corr1, 1.0f / sqrtf(bias_corr2), grad_scale, scaler_state););
   W2V2_CHECK_LAUNCH("adam_step");
   return 0;
 }

@@ -153,20 +153,12 @@ extern "C" int w2v2_pool_fwd(const void* x, float* out, int B, int T, int H, int
   if (mode <= 1) {
     W2V2_REQUIRE(H % 8 == 0, "pool_fwd: H must be a multiple of 8");
     dim3 grid((unsigned)cdiv(H, 128), B);
-    if (dtype == W2V2_BF16)
-      hipLaunchKernelGGL(pool_meanstd_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, out, T, H, mode == 0);
-    else if (dtype == W2V2_F32)
-      hipLaunchKernelGGL(pool_meanstd_kernel<float>, grid, dim3(256), 0, st, (const float*)x, out, T, H, mode == 0);
-    else
-      W2V2_FAIL("pool_fwd: bad dtype %d", dtype);
+    W2V2_DISPATCH_ACT(dtype, "pool_fwd",
+      hipLaunchKernelGGL(pool_meanstd_kernel<AT>, grid, dim3(256), 0, st, (const AT*)x, out, T, H, mode == 0););
   } else {
     dim3 grid((unsigned)cdiv((int64_t)B * H, 256));
-    if (dtype == W2V2_BF16)
-      hipLaunchKernelGGL(pool_select_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, out, B, T, H, mode);
-    else if (dtype == W2V2_F32)
-      hipLaunchKernelGGL(pool_select_kernel<float>, grid, dim3(256), 0, st, (const float*)x, out, B, T, H, mode);
-    else
-      W2V2_FAIL("pool_fwd: bad dtype %d", dtype);
+    W2V2_DISPATCH_ACT(dtype, "pool_fwd",
+      hipLaunchKernelGGL(pool_select_kernel<AT>, grid, dim3(256), 0, st, (const AT*)x, out, B, T, H, mode););
   }
   W2V2_CHECK_LAUNCH("pool_fwd");
   return 0;
@@ -180,24 +172,14 @@ extern "C" int w2v2_pool_bwd(const void* x, const float* out, const float* dout,
     W2V2_REQUIRE(H % 8 == 0, "pool_bwd: H must be a multiple of 8");
     const int64_t total = (int64_t)B * T * (H >> 3);
     int nb = (int)(cdiv(total, 256) > 4096 ? 4096 : cdiv(total, 256));
-    if (dtype == W2V2_BF16)
-      hipLaunchKernelGGL(pool_meanstd_bwd_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, (const bf16_t*)x, out, dout,
-                         (bf16_t*)dx, B, T, H, mode == 0);
-    else if (dtype == W2V2_F32)
-      hipLaunchKernelGGL(pool_meanstd_bwd_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)x, out, dout,
-                         (float*)dx, B, T, H, mode == 0);
-    else
-      W2V2_FAIL("pool_bwd: bad dtype %d", dtype);
+    W2V2_DISPATCH_ACT(dtype, "pool_bwd",
+      hipLaunchKernelGGL(pool_meanstd_bwd_kernel<AT>, dim3(nb), dim3(256), 0, st, (const AT*)x, out, dout,
+                         (AT*)dx, B, T, H, mode == 0););
   } else {
     dim3 grid((unsigned)cdiv((int64_t)B * H, 256));
-    if (dtype == W2V2_BF16)
-      hipLaunchKernelGGL(pool_select_bwd_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, dout, (bf16_t*)dx,
-                         B, T, H, mode);
-    else if (dtype == W2V2_F32)
-      hipLaunchKernelGGL(pool_select_bwd_kernel<float>, grid, dim3(256), 0, st, (const float*)x, dout, (float*)dx, B,
-                         T, H, mode);
-    else
-      W2V2_FAIL("pool_bwd: bad dtype %d", dtype);
+    W2V2_DISPATCH_ACT(dtype, "pool_bwd",
+      hipLaunchKernelGGL(pool_select_bwd_kernel<AT>, grid, dim3(256), 0, st, (const AT*)x, dout, (AT*)dx,
+                         B, T, H, mode););
   }
   W2V2_CHECK_LAUNCH("pool_bwd");
   return 0;

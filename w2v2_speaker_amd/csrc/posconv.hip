@@ -36,14 +36,9 @@ extern "C" int w2v2_posconv_regroup(const void* x, void* xg, int B, int T, int H
                "posconv_regroup: bad arguments (H/G must be a multiple of 8)");
   const int64_t total = (int64_t)B * G * (T + K - 1) * ((H / G) >> 3);
   int nb = (int)(cdiv(total, 256) > 8192 ? 8192 : cdiv(total, 256));
-  if (dtype == W2V2_BF16)
-    hipLaunchKernelGGL(regroup_kernel<bf16_t>, dim3(nb), dim3(256), 0, as_stream(stream), (const bf16_t*)x,
-                       (bf16_t*)xg, B, T, H, G, K, pad_left);
-  else if (dtype == W2V2_F32)
-    hipLaunchKernelGGL(regroup_kernel<float>, dim3(nb), dim3(256), 0, as_stream(stream), (const float*)x,
-                       (float*)xg, B, T, H, G, K, pad_left);
-  else
-    W2V2_FAIL("posconv_regroup: bad dtype %d", dtype);
+  W2V2_DISPATCH_ACT(dtype, "posconv_regroup",
+    hipLaunchKernelGGL(regroup_kernel<AT>, dim3(nb), dim3(256), 0, as_stream(stream), (const AT*)x,
+                       (AT*)xg, B, T, H, G, K, pad_left););
   W2V2_CHECK_LAUNCH("posconv_regroup");
   return 0;
 }
@@ -136,12 +131,8 @@ extern "C" int w2v2_weightnorm_pack(const float* g, const float* v, float* sumsq
   hipLaunchKernelGGL(tap_finalize_kernel, dim3((unsigned)cdiv(K, 128)), dim3(128), 0, st, sumsq + K, sumsq, K);
   const int64_t total = (int64_t)H * Cg * K;
   int nb = (int)(cdiv(total, 256) > 4096 ? 4096 : cdiv(total, 256));
-  if (dtype == W2V2_BF16)
-    hipLaunchKernelGGL(wn_pack_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, g, v, sumsq, (bf16_t*)wf, (bf16_t*)wb, H, Cg, K);
-  else if (dtype == W2V2_F32)
-    hipLaunchKernelGGL(wn_pack_kernel<float>, dim3(nb), dim3(256), 0, st, g, v, sumsq, (float*)wf, (float*)wb, H, Cg, K);
-  else
-    W2V2_FAIL("weightnorm_pack: bad dtype %d", dtype);
+  W2V2_DISPATCH_ACT(dtype, "weightnorm_pack",
+    hipLaunchKernelGGL(wn_pack_kernel<AT>, dim3(nb), dim3(256), 0, st, g, v, sumsq, (AT*)wf, (AT*)wb, H, Cg, K););
   W2V2_CHECK_LAUNCH("weightnorm_pack");
   return 0;
 }

@@ -18,7 +18,6 @@
 #include "common.cuh"
 #include <type_traits>
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) short short4v;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((address_space(1))) const void gvoid_t;
@@ -30,7 +29,7 @@ constexpr int PW_TC = 160;                 // time rows per work item (5 MFMA k 
 
 union PwFrag {
   struct { short4v a, b; } s;
-  bf16x8 v;
+  frag8_t v;
 };
 
 template <int OFF0, int OFF1>
@@ -52,7 +51,7 @@ __device__ __forceinline__ void pw_static_for(F&& f) {
 }
 
 // NF = Cg / 16 fragments per channel dimension, TW = taps per wave (4 waves -> 4 TW taps per workgroup)
-template <int NF, int TW>
+template <typename TE, int NF, int TW>
 __global__ __launch_bounds__(256) void posconv_wgrad_kernel(const bf16_t* __restrict__ dY,
                                                             const bf16_t* __restrict__ xg, float* __restrict__ dwf,
                                                             int B, int T, int H, int G, int K) {
@@ -155,7 +154,7 @@ __global__ __launch_bounds__(256) void posconv_wgrad_kernel(const bf16_t* __rest
       for (int fo = 0; fo < NF; ++fo)
 #pragma unroll
         for (int fc = 0; fc < NF; ++fc)
-          acc[tw][fo][fc] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks][fo].v, xf[cur][fc].v, acc[tw][fo][fc], 0, 0, 0);
+          acc[tw][fo][fc] = mfma16<TE>(af[ks][fo].v, xf[cur][fc].v, acc[tw][fo][fc]);
       __builtin_amdgcn_sched_barrier(0);
     });
   }
@@ -174,7 +173,7 @@ __global__ __launch_bounds__(256) void posconv_wgrad_kernel(const bf16_t* __rest
       }
 }
 
-template <int NF, int TW>
+template <typename TE, int NF, int TW>
 int launch_posconv_wgrad(const bf16_t* dY, const bf16_t* xg, float* dwf, int B, int T, int H, int G, int K,
                          hipStream_t st) {
   const int CG = 16 * NF;
@@ -182,11 +181,11 @@ int launch_posconv_wgrad(const bf16_t* dY, const bf16_t* xg, float* dwf, int B, 
   W2V2_REQUIRE(lds <= 160 * 1024, "posconv_wgrad: K=%d Cg=%d needs %zu bytes of LDS", K, CG, lds);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&posconv_wgrad_kernel<NF, TW>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&posconv_wgrad_kernel<TE, NF, TW>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL((posconv_wgrad_kernel<NF, TW>), dim3(G * (K / (4 * TW))), dim3(256), lds, st, dY, xg, dwf, B, T,
+  hipLaunchKernelGGL((posconv_wgrad_kernel<TE, NF, TW>), dim3(G * (K / (4 * TW))), dim3(256), lds, st, dY, xg, dwf, B, T,
                      H, G, K);
   return 0;
 }
@@ -195,21 +194,26 @@ int launch_posconv_wgrad(const bf16_t* dY, const bf16_t* xg, float* dwf, int B, 
 
 // dY [B*T, H] bf16 (gradient at the conv output), xg [B, G, T+K-1, Cg] bf16 from w2v2_posconv_regroup(pad_left),
 // dwf [G][K*Cg][Cg] f32 (row (j, c), column o) -- the layout w2v2_weightnorm_bwd consumes.  Overwrites dwf.
+template <typename TE>
+static int posconv_wgrad_geom(const void* dY, const void* xg, float* dwf, int B, int T, int H, int G, int K, hipStream_t st) {
+  const int Cg = H / G;
+  // Cg = 48: 2 taps per wave = 8 per workgroup -> 256 workgroups at K = 128 (4 taps: 128 workgroups, 175 vs 135 us)
+  if (Cg == 48 && K % 8 == 0) return launch_posconv_wgrad<TE, 3, 2>((const bf16_t*)dY, (const bf16_t*)xg, dwf, B, T, H, G, K, st);
+  if (Cg == 64 && K % 8 == 0) return launch_posconv_wgrad<TE, 4, 2>((const bf16_t*)dY, (const bf16_t*)xg, dwf, B, T, H, G, K, st);
+  if (Cg == 16 && K % 16 == 0) return launch_posconv_wgrad<TE, 1, 4>((const bf16_t*)dY, (const bf16_t*)xg, dwf, B, T, H, G, K, st);
+  if (Cg == 32 && K % 16 == 0) return launch_posconv_wgrad<TE, 2, 4>((const bf16_t*)dY, (const bf16_t*)xg, dwf, B, T, H, G, K, st);
+  W2V2_FAIL("posconv_wgrad: unsupported geometry Cg=%d K=%d (Cg in {16,32,48,64}, K a multiple of 16)", Cg, K);
+}
+
 extern "C" int w2v2_posconv_wgrad(const void* dY, const void* xg, float* dwf, int B, int T, int H, int G, int K,
-                                  void* stream) {
+                                  int dtype, void* stream) {
   W2V2_REQUIRE(dY && xg && dwf && B > 0 && T > 0 && G > 0 && K > 0 && H % G == 0,
                "posconv_wgrad: bad arguments");
-  const int Cg = H / G;
   W2V2_REQUIRE((reinterpret_cast<uintptr_t>(dY) & 15) == 0 && (reinterpret_cast<uintptr_t>(xg) & 15) == 0 &&
                    (reinterpret_cast<uintptr_t>(dwf) & 15) == 0, "posconv_wgrad: operands must be 16-byte aligned");
   hipStream_t st = as_stream(stream);
-  int rc;
-  // Cg = 48: 2 taps per wave = 8 per workgroup -> 256 workgroups at K = 128 (4 taps: 128 workgroups, 175 vs 135 us)
-  if (Cg == 48 && K % 8 == 0) rc = launch_posconv_wgrad<3, 2>((const bf16_t*)dY, (const bf16_t*)xg, dwf, B, T, H, G, K, st);
-  else if (Cg == 64 && K % 8 == 0) rc = launch_posconv_wgrad<4, 2>((const bf16_t*)dY, (const bf16_t*)xg, dwf, B, T, H, G, K, st);
-  else if (Cg == 16 && K % 16 == 0) rc = launch_posconv_wgrad<1, 4>((const bf16_t*)dY, (const bf16_t*)xg, dwf, B, T, H, G, K, st);
-  else if (Cg == 32 && K % 16 == 0) rc = launch_posconv_wgrad<2, 4>((const bf16_t*)dY, (const bf16_t*)xg, dwf, B, T, H, G, K, st);
-  else W2V2_FAIL("posconv_wgrad: unsupported geometry Cg=%d K=%d (Cg in {16,32,48,64}, K a multiple of 16)", Cg, K);
+  int rc = -1;
+  W2V2_DISPATCH_16(dtype, "posconv_wgrad", rc = posconv_wgrad_geom<AT>(dY, xg, dwf, B, T, H, G, K, st););
   if (rc) return rc;
   W2V2_CHECK_LAUNCH("w2v2_posconv_wgrad");
   return 0;

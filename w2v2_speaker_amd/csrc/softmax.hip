@@ -56,14 +56,9 @@ extern "C" int w2v2_softmax_fwd(const float* s, void* p, void* p_drop, int64_t r
   else W2V2_REQUIRE(p_drop != nullptr, "softmax_fwd: drop_p > 0 needs p_drop");
   const float ik = 1.0f / (1.0f - drop_p);
   dim3 grid((unsigned)cdiv(rows, 4));
-  if (dtype == W2V2_BF16)
-    hipLaunchKernelGGL(softmax_fwd_kernel<bf16_t>, grid, dim3(256), 0, as_stream(stream), s, (bf16_t*)p,
-                       (bf16_t*)p_drop, rows, T, ld, drop_p, ik, seed);
-  else if (dtype == W2V2_F32)
-    hipLaunchKernelGGL(softmax_fwd_kernel<float>, grid, dim3(256), 0, as_stream(stream), s, (float*)p,
-                       (float*)p_drop, rows, T, ld, drop_p, ik, seed);
-  else
-    W2V2_FAIL("softmax_fwd: bad dtype %d", dtype);
+  W2V2_DISPATCH_ACT(dtype, "softmax_fwd",
+    hipLaunchKernelGGL(softmax_fwd_kernel<AT>, grid, dim3(256), 0, as_stream(stream), s, (AT*)p,
+                       (AT*)p_drop, rows, T, ld, drop_p, ik, seed););
   W2V2_CHECK_LAUNCH("softmax_fwd");
   return 0;
 }
@@ -75,14 +70,9 @@ extern "C" int w2v2_softmax_bwd(const float* dp_drop, const void* p, void* ds, i
   if (rows == 0) return 0;
   const float ik = 1.0f / (1.0f - drop_p);
   dim3 grid((unsigned)cdiv(rows, 4));
-  if (dtype == W2V2_BF16)
-    hipLaunchKernelGGL(softmax_bwd_kernel<bf16_t>, grid, dim3(256), 0, as_stream(stream), dp_drop, (const bf16_t*)p,
-                       (bf16_t*)ds, rows, T, ld, drop_p, ik, seed);
-  else if (dtype == W2V2_F32)
-    hipLaunchKernelGGL(softmax_bwd_kernel<float>, grid, dim3(256), 0, as_stream(stream), dp_drop, (const float*)p,
-                       (float*)ds, rows, T, ld, drop_p, ik, seed);
-  else
-    W2V2_FAIL("softmax_bwd: bad dtype %d", dtype);
+  W2V2_DISPATCH_ACT(dtype, "softmax_bwd",
+    hipLaunchKernelGGL(softmax_bwd_kernel<AT>, grid, dim3(256), 0, as_stream(stream), dp_drop, (const AT*)p,
+                       (AT*)ds, rows, T, ld, drop_p, ik, seed););
   W2V2_CHECK_LAUNCH("softmax_bwd");
   return 0;
 }

@@ -288,12 +288,6 @@ __global__ void act_bwd_kernel(const float* __restrict__ dy, const float* __rest
 
 // ------------------------------------------------------------------------------------------ C ABI
 static int td_blocks(int64_t n) { return (int)(cdiv(n, 256) > 8192 ? 8192 : (cdiv(n, 256) < 1 ? 1 : cdiv(n, 256))); }
-#define TD_DT(T_BF16, T_F32, NAME)                       \
-  if (dtype == W2V2_BF16) { T_BF16; }                    \
-  else if (dtype == W2V2_F32) { T_F32; }                 \
-  else W2V2_FAIL(NAME ": bad dtype %d", dtype);          \
-  W2V2_CHECK_LAUNCH(NAME);                               \
-  return 0
 
 extern "C" int w2v2_bn_workspace_floats(int M, int C) { return (int)cdiv(M, TD_ROWS) * C * 2 + 2 * C; }
 
@@ -303,12 +297,8 @@ extern "C" int w2v2_bn_stats(const void* a, int64_t lda, float* workspace, float
   const int nblk = (int)cdiv(M, TD_ROWS);
   dim3 grid((unsigned)cdiv(C, 128), nblk);
   hipStream_t st = as_stream(stream);
-  if (dtype == W2V2_BF16)
-    hipLaunchKernelGGL(bn_partial_kernel<bf16_t>, grid, dim3(128), 0, st, (const bf16_t*)a, lda, workspace, M, C, relu);
-  else if (dtype == W2V2_F32)
-    hipLaunchKernelGGL(bn_partial_kernel<float>, grid, dim3(128), 0, st, (const float*)a, lda, workspace, M, C, relu);
-  else
-    W2V2_FAIL("bn_stats: bad dtype %d", dtype);
+  W2V2_DISPATCH_ACT(dtype, "bn_stats",
+    hipLaunchKernelGGL(bn_partial_kernel<AT>, grid, dim3(128), 0, st, (const AT*)a, lda, workspace, M, C, relu););
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)cdiv(C, 128)), dim3(128, 8), 0, st, workspace, mean_rstd,
                      running, nblk, M, C, eps, momentum);
   W2V2_CHECK_LAUNCH("bn_stats");
@@ -320,11 +310,11 @@ extern "C" int w2v2_bn_apply(const void* a, int64_t lda, const float* mean_rstd,
   W2V2_REQUIRE(a && mean_rstd && gamma && beta && y && M > 0 && C > 0, "bn_apply: bad arguments");
   const int nb = td_blocks((int64_t)M * C);
   hipStream_t st = as_stream(stream);
-  TD_DT(hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, (const bf16_t*)a, lda, mean_rstd, gamma,
-                           beta, (bf16_t*)y, ldy, M, C, relu),
-        hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)a, lda, mean_rstd, gamma,
-                           beta, (float*)y, ldy, M, C, relu),
-        "bn_apply");
+  W2V2_DISPATCH_ACT(dtype, "bn_apply",
+    hipLaunchKernelGGL(bn_apply_kernel<AT>, dim3(nb), dim3(256), 0, st, (const AT*)a, lda, mean_rstd, gamma,
+                           beta, (AT*)y, ldy, M, C, relu););
+  W2V2_CHECK_LAUNCH("bn_apply");
+  return 0;
 }
 
 extern "C" int w2v2_bn_bwd(const void* dy, int64_t lddy, const void* a, int64_t lda, const float* mean_rstd,
@@ -344,9 +334,7 @@ extern "C" int w2v2_bn_bwd(const void* dy, int64_t lddy, const void* a, int64_t 
                      dgamma, dbeta, nblk, C);                                                                       \
   hipLaunchKernelGGL(bn_bwd_apply_kernel<T_>, dim3(nb), dim3(256), 0, st, (const T_*)dy, lddy, (const T_*)a, lda,   \
                      mean_rstd, gamma, sums, (T_*)da, ldda, M, C, relu, 1.0f / (float)M)
-  if (dtype == W2V2_BF16) { TD_BNB(bf16_t); }
-  else if (dtype == W2V2_F32) { TD_BNB(float); }
-  else W2V2_FAIL("bn_bwd: bad dtype %d", dtype);
+  W2V2_DISPATCH_ACT(dtype, "bn_bwd", TD_BNB(AT););
 #undef TD_BNB
   W2V2_CHECK_LAUNCH("bn_bwd");
   return 0;
@@ -359,11 +347,11 @@ extern "C" int w2v2_im2col_reflect(const void* x, int64_t ldx, void* col, int B,
                "im2col_reflect: bad arguments (odd k, Cin %% 8 == 0, padding < T)");
   const int nb = td_blocks((int64_t)B * T * k * (Cin >> 3));
   hipStream_t st = as_stream(stream);
-  TD_DT(hipLaunchKernelGGL(im2col_reflect_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, (const bf16_t*)x, ldx,
-                           (bf16_t*)col, B, T, Cin, k, dilation),
-        hipLaunchKernelGGL(im2col_reflect_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)x, ldx, (float*)col,
-                           B, T, Cin, k, dilation),
-        "im2col_reflect");
+  W2V2_DISPATCH_ACT(dtype, "im2col_reflect",
+    hipLaunchKernelGGL(im2col_reflect_kernel<AT>, dim3(nb), dim3(256), 0, st, (const AT*)x, ldx,
+                           (AT*)col, B, T, Cin, k, dilation););
+  W2V2_CHECK_LAUNCH("im2col_reflect");
+  return 0;
 }
 
 extern "C" int w2v2_col2im_reflect(const void* dcol, void* dx, int64_t lddx, int B, int T, int Cin, int k, int dilation,
@@ -373,11 +361,11 @@ extern "C" int w2v2_col2im_reflect(const void* dcol, void* dx, int64_t lddx, int
                "col2im_reflect: bad arguments");
   const int nb = td_blocks((int64_t)B * T * (Cin >> 3));
   hipStream_t st = as_stream(stream);
-  TD_DT(hipLaunchKernelGGL(col2im_reflect_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, (const bf16_t*)dcol, (bf16_t*)dx,
-                           lddx, B, T, Cin, k, dilation, accumulate),
-        hipLaunchKernelGGL(col2im_reflect_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)dcol, (float*)dx,
-                           lddx, B, T, Cin, k, dilation, accumulate),
-        "col2im_reflect");
+  W2V2_DISPATCH_ACT(dtype, "col2im_reflect",
+    hipLaunchKernelGGL(col2im_reflect_kernel<AT>, dim3(nb), dim3(256), 0, st, (const AT*)dcol, (AT*)dx,
+                           lddx, B, T, Cin, k, dilation, accumulate););
+  W2V2_CHECK_LAUNCH("col2im_reflect");
+  return 0;
 }
 
 extern "C" int w2v2_add_strided(const void* a, int64_t lda, const void* b, int64_t ldb, void* y, int64_t ldy, int M,
@@ -386,20 +374,21 @@ extern "C" int w2v2_add_strided(const void* a, int64_t lda, const void* b, int64
                "add_strided: bad arguments");
   const int nb = td_blocks((int64_t)M * (C >> 3));
   hipStream_t st = as_stream(stream);
-  TD_DT(hipLaunchKernelGGL(add_strided_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, (const bf16_t*)a, lda,
-                           (const bf16_t*)b, ldb, (bf16_t*)y, ldy, M, C),
-        hipLaunchKernelGGL(add_strided_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)a, lda, (const float*)b,
-                           ldb, (float*)y, ldy, M, C),
-        "add_strided");
+  W2V2_DISPATCH_ACT(dtype, "add_strided",
+    hipLaunchKernelGGL(add_strided_kernel<AT>, dim3(nb), dim3(256), 0, st, (const AT*)a, lda,
+                           (const AT*)b, ldb, (AT*)y, ldy, M, C););
+  W2V2_CHECK_LAUNCH("add_strided");
+  return 0;
 }
 
 extern "C" int w2v2_se_scale(const void* x, const float* g, void* y, int B, int T, int C, int dtype, void* stream) {
   W2V2_REQUIRE(x && g && y && B > 0 && T > 0 && C > 0, "se_scale: bad arguments");
   const int nb = td_blocks((int64_t)B * T * C);
   hipStream_t st = as_stream(stream);
-  TD_DT(hipLaunchKernelGGL(se_scale_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, (const bf16_t*)x, g, (bf16_t*)y, B, T, C),
-        hipLaunchKernelGGL(se_scale_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)x, g, (float*)y, B, T, C),
-        "se_scale");
+  W2V2_DISPATCH_ACT(dtype, "se_scale",
+    hipLaunchKernelGGL(se_scale_kernel<AT>, dim3(nb), dim3(256), 0, st, (const AT*)x, g, (AT*)y, B, T, C););
+  W2V2_CHECK_LAUNCH("se_scale");
+  return 0;
 }
 
 extern "C" int w2v2_se_bwd_gate(const void* dout, const void* x, float* dg, int B, int T, int C, int dtype,
@@ -407,9 +396,10 @@ extern "C" int w2v2_se_bwd_gate(const void* dout, const void* x, float* dg, int 
   W2V2_REQUIRE(dout && x && dg && B > 0 && T > 0 && C > 0, "se_bwd_gate: bad arguments");
   dim3 grid((unsigned)cdiv(C, 64), B), blk(64, TD_TL);
   hipStream_t st = as_stream(stream);
-  TD_DT(hipLaunchKernelGGL(se_bwd_gate_kernel<bf16_t>, grid, blk, 0, st, (const bf16_t*)dout, (const bf16_t*)x, dg, T, C),
-        hipLaunchKernelGGL(se_bwd_gate_kernel<float>, grid, blk, 0, st, (const float*)dout, (const float*)x, dg, T, C),
-        "se_bwd_gate");
+  W2V2_DISPATCH_ACT(dtype, "se_bwd_gate",
+    hipLaunchKernelGGL(se_bwd_gate_kernel<AT>, grid, blk, 0, st, (const AT*)dout, (const AT*)x, dg, T, C););
+  W2V2_CHECK_LAUNCH("se_bwd_gate");
+  return 0;
 }
 
 extern "C" int w2v2_se_bwd_x(const void* dout, const float* g, const float* ds, void* dx, int B, int T, int C, int dtype,
@@ -417,11 +407,11 @@ extern "C" int w2v2_se_bwd_x(const void* dout, const float* g, const float* ds, 
   W2V2_REQUIRE(dout && g && ds && dx && B > 0 && T > 0 && C > 0, "se_bwd_x: bad arguments");
   const int nb = td_blocks((int64_t)B * T * C);
   hipStream_t st = as_stream(stream);
-  TD_DT(hipLaunchKernelGGL(se_bwd_x_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, (const bf16_t*)dout, g, ds, (bf16_t*)dx,
-                           B, T, C),
-        hipLaunchKernelGGL(se_bwd_x_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)dout, g, ds, (float*)dx, B,
-                           T, C),
-        "se_bwd_x");
+  W2V2_DISPATCH_ACT(dtype, "se_bwd_x",
+    hipLaunchKernelGGL(se_bwd_x_kernel<AT>, dim3(nb), dim3(256), 0, st, (const AT*)dout, g, ds, (AT*)dx,
+                           B, T, C););
+  W2V2_CHECK_LAUNCH("se_bwd_x");
+  return 0;
 }
 
 extern "C" int w2v2_act_fwd(const float* x, float* y, int64_t n, int mode, void* stream) {

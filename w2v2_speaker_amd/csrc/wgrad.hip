@@ -16,8 +16,6 @@
 #include <stdlib.h>
 #include <type_traits>
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 typedef __attribute__((ext_vector_type(4))) short short4v;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((address_space(1))) const void gvoid_t;
@@ -42,7 +40,7 @@ struct WgArgs {
 
 __device__ __forceinline__ int wg_f(int r) { return (r & 3) | ((r >> 1) & 4); }
 
-__device__ __forceinline__ bf16x8 tr_frag(const bf16_t* tile, int kk, int seg, int lane) {
+__device__ __forceinline__ frag8_t tr_frag(const bf16_t* tile, int kk, int seg, int lane) {
   // k-slots of lane group g: rows kk*32 + g*8 + {0..7}; two 4x16 transposing reads
   const int i = lane & 15, g = lane >> 4;
   const int r = kk * 32 + g * 8 + (i >> 2);
@@ -50,12 +48,13 @@ __device__ __forceinline__ bf16x8 tr_frag(const bf16_t* tile, int kk, int seg, i
   const bf16_t* p = tile + r * 128 + ((seg ^ f) << 4) + ((i & 3) << 2);
   const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_t*)p);
   const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_t*)(p + 4 * 128));
-  union { struct { short4v a, b; } s; bf16x8 v; } u;
+  union { struct { short4v a, b; } s; frag8_t v; } u;
   u.s.a = lo;
   u.s.b = hi;
   return u.v;
 }
 
+template <typename TE>
 __global__ __launch_bounds__(256) void wgrad_grouped_kernel(const WgArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   bf16_t* As = reinterpret_cast<bf16_t*>(smem_raw);   // [2][64 k][128 m]
@@ -102,6 +101,7 @@ __global__ __launch_bounds__(256) void wgrad_grouped_kernel(const WgArgs a) {
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   float bsum[4] = {0.f, 0.f, 0.f, 0.f};
   const bool do_bias = (P.dbias != nullptr) && tn == 0 && wn == 0;
+  const uint32_t one2 = ones_pair<TE>();
 
   auto stage = [&](int buf, int kt) {
     bf16_t* ad = As + buf * 64 * 128 + wave * 16 * 128;
@@ -118,22 +118,25 @@ __global__ __launch_bounds__(256) void wgrad_grouped_kernel(const WgArgs a) {
     const bf16_t* Bc = Bs + buf * 64 * 128;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-      bf16x8 af[4], bfr[4];
+      frag8_t af[4], bfr[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) af[i] = tr_frag(Ac, kk, wm * 4 + i, lane);
 #pragma unroll
       for (int j = 0; j < 4; ++j) bfr[j] = tr_frag(Bc, kk, wn * 4 + j, lane);
       if (do_bias) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i) {
+          union { frag8_t v; uint32_t p[4]; } u;
+          u.v = af[i];
 #pragma unroll
-          for (int e = 0; e < 8; ++e) bsum[i] += (float)af[i][e];
+          for (int e = 0; e < 4; ++e) bsum[i] = pair_sum_add<TE>(u.p[e], one2, bsum[i]);
+        }
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+          acc[i][j] = mfma16<TE>(bfr[j], af[i], acc[i][j]);
     }
   };
 
@@ -200,6 +203,7 @@ template <int S> __device__ __forceinline__ void wg_wait_vmcnt() {
   else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
 }
 
+template <typename TE>
 __global__ __launch_bounds__(512) void wgrad_grouped_ring_kernel(const WgArgs a) {
   constexpr int BM = 256, BN = 128;
   constexpr int STAGE = 64 * (BM + BN);             // elements per stage: A [64][256] then B [64][128]
@@ -253,9 +257,7 @@ __global__ __launch_bounds__(512) void wgrad_grouped_ring_kernel(const WgArgs a)
   // v_dot2c_f32_bf16 against (1, 1) -- 4 VALU ops per fragment instead of 16 converts+adds
   float bsum[4] = {0.f, 0.f, 0.f, 0.f};
   const bool do_bias = (P.dbias != nullptr) && tn == 0 && wn == 0;
-  bf16x2 one2;
-  one2[0] = (__bf16)1.0f;
-  one2[1] = (__bf16)1.0f;
+  const uint32_t one2 = ones_pair<TE>();
 
   auto stage = [&](bf16_t* base, int kt) {
     bf16_t* ad = base + wave * 8 * BM;
@@ -282,7 +284,7 @@ __global__ __launch_bounds__(512) void wgrad_grouped_ring_kernel(const WgArgs a)
     aoff[x] = lds0 + 2u * (fr * BM + (((((wm ^ fhi) & 3) << 2) | (x ^ flo)) << 4) + ((li & 3) << 2));
     boff[x] = lds0 + 2u * (64 * BM + fr * BN + (((((wn ^ fhi) & 1) << 2) | (x ^ flo)) << 4) + ((li & 3) << 2));
   }
-  union Frag { struct { short4v a, b; } s; bf16x8 v; };
+  union Frag { struct { short4v a, b; } s; frag8_t v; };
 #define W2V2_TR_READ(dst, addr, OFF) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:" #OFF : "=v"(dst) : "v"(addr) : "memory")
 #define W2V2_FRAG_A(f, addr, KK)                                   \
   if (KK == 0) { W2V2_TR_READ(f.s.a, addr, 0);     W2V2_TR_READ(f.s.b, addr, 2048); }  \
@@ -300,17 +302,17 @@ __global__ __launch_bounds__(512) void wgrad_grouped_ring_kernel(const WgArgs a)
     if (do_bias) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        union { bf16x8 v; bf16x2 p[4]; } u;
+        union { frag8_t v; uint32_t p[4]; } u;
         u.v = af[i].v;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) bsum[i] = __builtin_amdgcn_fdot2_f32_bf16(u.p[e], one2, bsum[i], false);
+        for (int e = 0; e < 4; ++e) bsum[i] = pair_sum_add<TE>(u.p[e], one2, bsum[i]);
       }
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j].v, af[i].v, acc[i][j], 0, 0, 0);
+        acc[i][j] = mfma16<TE>(bfr[j].v, af[i].v, acc[i][j]);
   };
   auto compute = [&](uint32_t sbytes) {
     uint32_t aa[4], ba[4];
@@ -403,6 +405,7 @@ __global__ __launch_bounds__(512) void wgrad_grouped_ring_kernel(const WgArgs a)
 // tiles, one round on 256 CUs): still no split-K, no atomics, bitwise reproducible.  8 waves as 2 (n_out) x 4 (n_in),
 // 128 x 64 per wave; four 32 KiB stages [32 tokens][256 + 256] in natural K-major layout, three in flight
 // (`s_waitcnt vmcnt(8)`, 4 DMA pieces per wave and stage); rolled ring loop (see gemm.hip on why).
+template <typename TE>
 __global__ __launch_bounds__(512) void wgrad_grouped_ring4_kernel(const WgArgs a) {
   constexpr int BM = 256, BN = 256, BK = 32;
   constexpr int STAGE = BK * (BM + BN);             // elements per stage: A [32][256] then B [32][256]
@@ -446,9 +449,7 @@ __global__ __launch_bounds__(512) void wgrad_grouped_ring4_kernel(const WgArgs a
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   const bool do_bias = (P.dbias != nullptr) && tn == 0 && wn == 0;
-  bf16x2 one2;
-  one2[0] = (__bf16)1.0f;
-  one2[1] = (__bf16)1.0f;
+  const uint32_t one2 = ones_pair<TE>();
 
   auto stage = [&](int sidx, int kt) {
     bf16_t* ad = smem + sidx * STAGE + wave * 4 * BM;
@@ -471,7 +472,7 @@ __global__ __launch_bounds__(512) void wgrad_grouped_ring4_kernel(const WgArgs a
   for (int x = 0; x < 8; ++x) aoff[x] = lds0 + 2u * (fr * BM + (((wm * 8 + x) ^ ff) << 4) + ((li & 3) << 2));
 #pragma unroll
   for (int x = 0; x < 4; ++x) boff[x] = lds0 + 2u * (BK * BM + fr * BN + (((wn * 4 + x) ^ ff) << 4) + ((li & 3) << 2));
-  union Frag { struct { short4v a, b; } s; bf16x8 v; };
+  union Frag { struct { short4v a, b; } s; frag8_t v; };
 #define W2V2_TR4(f, addr)                                                                              \
   asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f.s.a) : "v"(addr) : "memory");                      \
   asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "=v"(f.s.b) : "v"(addr) : "memory")
@@ -505,34 +506,34 @@ __global__ __launch_bounds__(512) void wgrad_grouped_ring4_kernel(const WgArgs a
     if (do_bias) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        union { bf16x8 v; bf16x2 p[4]; } u;
+        union { frag8_t v; uint32_t p[4]; } u;
         u.v = af[i].v;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) bsum[i] = __builtin_amdgcn_fdot2_f32_bf16(u.p[e], one2, bsum[i], false);
+        for (int e = 0; e < 4; ++e) bsum[i] = pair_sum_add<TE>(u.p[e], one2, bsum[i]);
       }
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf_[j].v, af[i].v, acc[i][j], 0, 0, 0);
+        acc[i][j] = mfma16<TE>(bf_[j].v, af[i].v, acc[i][j]);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int x = 4; x < 8; ++x) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[x].s.a), "+v"(af[x].s.b));
     if (do_bias) {
 #pragma unroll
       for (int i = 4; i < 8; ++i) {
-        union { bf16x8 v; bf16x2 p[4]; } u;
+        union { frag8_t v; uint32_t p[4]; } u;
         u.v = af[i].v;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) bsum[i] = __builtin_amdgcn_fdot2_f32_bf16(u.p[e], one2, bsum[i], false);
+        for (int e = 0; e < 4; ++e) bsum[i] = pair_sum_add<TE>(u.p[e], one2, bsum[i]);
       }
     }
 #pragma unroll
     for (int i = 4; i < 8; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf_[j].v, af[i].v, acc[i][j], 0, 0, 0);
+        acc[i][j] = mfma16<TE>(bf_[j].v, af[i].v, acc[i][j]);
   }
 #undef W2V2_TR4
 
@@ -577,7 +578,40 @@ __global__ __launch_bounds__(512) void wgrad_grouped_ring4_kernel(const WgArgs a
   }
 }
 
-extern "C" int w2v2_wgrad_grouped(const w2v2_wgrad_problem* probs, int n, int tokens, int tokens_padded, void* stream) {
+template <typename TE>
+static void wgrad_launch(const WgArgs& a, int tiles, bool ring, bool ring4, hipStream_t st) {
+  if (ring4) {
+    constexpr size_t lds = (size_t)4 * 32 * (256 + 256) * sizeof(bf16_t);   // 128 KiB
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_grouped_ring4_kernel<TE>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(wgrad_grouped_ring4_kernel<TE>, dim3(tiles), dim3(512), lds, st, a);
+  } else if (ring) {
+    constexpr size_t lds = (size_t)3 * 64 * (256 + 128) * sizeof(bf16_t);   // 144 KiB
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_grouped_ring_kernel<TE>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(wgrad_grouped_ring_kernel<TE>, dim3(tiles), dim3(512), lds, st, a);
+  } else {
+    constexpr size_t lds = (size_t)2 * 2 * 64 * 128 * sizeof(bf16_t);   // 64 KiB
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_grouped_kernel<TE>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(wgrad_grouped_kernel<TE>, dim3(tiles), dim3(256), lds, st, a);
+  }
+}
+
+extern "C" int w2v2_wgrad_grouped(const w2v2_wgrad_problem* probs, int n, int tokens, int tokens_padded, int dtype,
+                                  void* stream) {
   W2V2_REQUIRE(probs && n > 0 && n <= WG_MAXP, "wgrad_grouped: need 1..%d problems", WG_MAXP);
   W2V2_REQUIRE(tokens > 0 && tokens_padded >= tokens && tokens_padded % 64 == 0,
                "wgrad_grouped: tokens_padded must be tokens rounded up to a multiple of 64");
@@ -620,34 +654,7 @@ extern "C" int w2v2_wgrad_grouped(const w2v2_wgrad_problem* probs, int n, int to
   a.n_problems = n;
   a.total_tiles = tiles;
   a.ktiles = tokens_padded / 64;
-  if (ring4) {
-    constexpr size_t lds = (size_t)4 * 32 * (256 + 256) * sizeof(bf16_t);   // 128 KiB
-    static bool attr_set = false;
-    if (!attr_set) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_grouped_ring4_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      attr_set = true;
-    }
-    hipLaunchKernelGGL(wgrad_grouped_ring4_kernel, dim3(tiles), dim3(512), lds, as_stream(stream), a);
-  } else if (ring) {
-    constexpr size_t lds = (size_t)3 * 64 * (256 + 128) * sizeof(bf16_t);   // 144 KiB
-    static bool attr_set = false;
-    if (!attr_set) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_grouped_ring_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      attr_set = true;
-    }
-    hipLaunchKernelGGL(wgrad_grouped_ring_kernel, dim3(tiles), dim3(512), lds, as_stream(stream), a);
-  } else {
-    constexpr size_t lds = (size_t)2 * 2 * 64 * 128 * sizeof(bf16_t);   // 64 KiB
-    static bool attr_set = false;
-    if (!attr_set) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_grouped_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      attr_set = true;
-    }
-    hipLaunchKernelGGL(wgrad_grouped_kernel, dim3(tiles), dim3(256), lds, as_stream(stream), a);
-  }
+  W2V2_DISPATCH_16(dtype, "wgrad_grouped", wgrad_launch<AT>(a, tiles, ring, ring4, as_stream(stream)););
   W2V2_CHECK_LAUNCH("wgrad_grouped");
   return 0;
 }

@@ -93,7 +93,7 @@ class EcapaStore:
     the subset of ParamStore's interface that AttentivePool / ClassifierHead / the plan below use."""
 
     def __init__(self, cfg: EcapaConfig, device, act_dtype: torch.dtype = torch.bfloat16, num_speakers: int = 5994):
-        assert act_dtype in (torch.bfloat16, torch.float32)
+        assert act_dtype in (torch.bfloat16, torch.float32), "ECAPA: bf16 or f32 (the reference runs it in fp32; no loss scaler here)"
         self.cfg, self.device, self.act_dtype, self.num_speakers = cfg, torch.device(device), act_dtype, num_speakers
         self.embed_dim = cfg.lin_neurons
         shapes: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()
@@ -109,7 +109,7 @@ class EcapaStore:
         self.flat = torch.zeros(off, dtype=torch.float32, device=dev)
         self.grad = torch.zeros(off, dtype=torch.float32, device=dev)
         self.exp_avg = self.exp_avg_sq = None
-        self.flat_lp = torch.zeros(off, dtype=torch.bfloat16, device=dev) if act_dtype == torch.bfloat16 else None
+        self.flat_lp = torch.zeros(off, dtype=act_dtype, device=dev) if ops.is16(act_dtype) else None
         self.asp_running = torch.cat([torch.zeros(cfg.attention_channels), torch.ones(cfg.attention_channels)]).to(dev)
         self.version, self.step_count = 0, 0
 
@@ -206,7 +206,7 @@ class _Tdnn:
             dW = self.dwp if k > 1 else st.g(self.pre + "conv.conv.weight").view(cout, cin)
             # bf16: weight + bias gradient through the grouped, atomic-free wgrad kernels (K-major operands: da and the
             # conv input / im2col buffer, both zero-padded to a multiple of 64 rows), launched per group by the owner
-            self.grouped = adt == torch.bfloat16 and hasattr(A, "_full")
+            self.grouped = ops.is16(adt) and hasattr(A, "_full")
             if self.grouped:
                 self.wg_problem = (self.da._full, A._full, dW, st.g(self.pre + "conv.conv.bias"))
             self.g_dw = Gemm(cout, K, M, self.da, A, dW, lda=cout, ldb=lda, ldc=K, transA=True, transB=True,
@@ -214,7 +214,7 @@ class _Tdnn:
             self.dcol = torch.empty(M, K, dtype=adt, device=dev) if k > 1 else None
             # bf16: the data-gradient product reads the packed weight TRANSPOSED ([K][cout], refreshed with the pack)
             # so that it is an NT product on the LDS-DMA ring kernels instead of a K-major-B one on the generic kernel
-            self.wpt = torch.empty(K, cout, dtype=adt, device=dev) if adt == torch.bfloat16 else None
+            self.wpt = torch.empty(K, cout, dtype=adt, device=dev) if ops.is16(adt) else None
             self._dx_gemm = {}
 
     def refresh(self) -> None:

@@ -87,7 +87,7 @@ class Plan:
         self.M0, self.M = self.Bc * self.T0, batch * self.T
         H, d = cfg.hidden_size, cfg.head_dim
         if fused_attention is None:
-            fused_attention = (self.adt == torch.bfloat16 and d == 64 and self.T <= 256)
+            fused_attention = (ops.is16(self.adt) and d == 64 and self.T <= 256)
         self.fused = fused_attention
         self.embed_dim = H * (2 if pooling in ("mean+std", "attentive") else 1)
         self._pack_version = -1
@@ -167,7 +167,8 @@ class Plan:
             from .heads import BceHead
             self.head = BceHead(B, E, w=st.p("linear.weight"), b=st.p("linear.bias"),
                                 w_grad=st.g("linear.weight") if self.train else None,
-                                b_grad=st.g("linear.bias") if self.train else None, emb=self.emb, train=self.train)
+                                b_grad=st.g("linear.bias") if self.train else None, emb=self.emb, train=self.train,
+                                loss_scale=st.scaler)
         elif st.head is not None:
             from .heads import ClassifierHead
             aam = st.head == "aam"
@@ -177,7 +178,7 @@ class Plan:
                                        bias=None if aam else st.p("fc_list.0.0.bias"),
                                        bias_grad=None if (aam or not self.train) else st.g("fc_list.0.0.bias"),
                                        emb=self.emb, act_dtype=self.adt, train=self.train, margin=self.margin,
-                                       scale=self.scale)
+                                       scale=self.scale, loss_scale=st.scaler)
         if self.train:
             self.demb = self.head.demb if self.head is not None else self._e(B, E, dtype=f32)
             self.G = self._ep(M, H)           # running activation gradient
@@ -606,7 +607,7 @@ class Plan:
         ops.gelu_bwd(self.G, self.pos_pre, self.P1)
         ops.colsum(self.P1, mg("encoder.pos_conv_embed.conv.bias"), M, H)
         G_, K = cfg.num_conv_pos_embedding_groups, cfg.num_conv_pos_embeddings
-        if self.P1.dtype == torch.bfloat16 and not os.environ.get("W2V2_POS_DW_GEMM"):
+        if ops.is16(self.P1.dtype) and not os.environ.get("W2V2_POS_DW_GEMM"):
             ops.posconv_wgrad(self.P1, self.xg, self.dwf, B, T, H, G_, K)      # correlation kernel (posconv_wgrad.hip)
         else:
             self.g_pos_dw()                                                    # exact-f32 mode: implicit GEMM

@@ -16,8 +16,9 @@ class ClassifierHead:
     def __init__(self, kind: str, batch: int, embed_dim: int, classes: int, *, w_master: torch.Tensor,
                  w_operand: torch.Tensor, w_grad: Optional[torch.Tensor], bias: Optional[torch.Tensor] = None,
                  bias_grad: Optional[torch.Tensor] = None, emb: torch.Tensor, act_dtype: torch.dtype,
-                 train: bool, margin: float = 0.2, scale: float = 30.0):
+                 train: bool, margin: float = 0.2, scale: float = 30.0, loss_scale: Optional[torch.Tensor] = None):
         assert kind in ("aam", "ce")
+        self.loss_scale = loss_scale          # device record of the dynamic loss scale (fp16 activations) or None
         self.kind, self.B, self.E, self.C, self.train = kind, batch, embed_dim, classes, train
         self.margin, self.scale = margin, scale
         self.w_master, self.w_grad, self.bias, self.bias_grad, self.emb = w_master, w_grad, bias, bias_grad, emb
@@ -81,7 +82,7 @@ class ClassifierHead:
                                 self.dcos_w if tr else None, (self.dcos_x if aam else None) if tr else None,
                                 self.inv_x if aam else None, self.inv_w if aam else None,
                                 self.rowdot if (tr and aam) else None, self.coldot if (tr and aam) else None,
-                                B, Cn, self.ldc, self.margin if aam else -1.0, self.scale)
+                                B, Cn, self.ldc, self.margin if aam else -1.0, self.scale, self.loss_scale if tr else None)
         loss = self.loss_rows.mean()
         if tr:
             for g in self.g_dx:
@@ -104,8 +105,10 @@ class BceHead:
     BCE-with-logits (mean over pairs), prediction = sigmoid(logit).  Same interface as ClassifierHead."""
 
     def __init__(self, batch: int, embed_dim: int, *, w: torch.Tensor, b: torch.Tensor,
-                 w_grad: Optional[torch.Tensor], b_grad: Optional[torch.Tensor], emb: torch.Tensor, train: bool):
+                 w_grad: Optional[torch.Tensor], b_grad: Optional[torch.Tensor], emb: torch.Tensor, train: bool,
+                 loss_scale: Optional[torch.Tensor] = None):
         dev, f32 = emb.device, torch.float32
+        self.loss_scale = loss_scale
         self.B, self.E, self.w, self.b, self.w_grad, self.b_grad, self.emb, self.train = (batch, embed_dim, w, b, w_grad,
                                                                                           b_grad, emb, train)
         self.prob = torch.empty(batch, dtype=f32, device=dev)
@@ -119,6 +122,7 @@ class BceHead:
         tr = self.train
         ops.bce_head_fwd_bwd(self.emb, self.w.view(-1), self.b, label, self.prob, self.loss_rows,
                              self.dlogit if tr else None, self.demb if tr else None,
-                             self.w_grad.view(-1) if tr else None, self.b_grad if tr else None, self.B, self.E)
+                             self.w_grad.view(-1) if tr else None, self.b_grad if tr else None, self.B, self.E,
+                             self.loss_scale if tr else None)
         return self.loss_rows.mean(), self.prob
 

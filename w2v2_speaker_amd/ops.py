@@ -12,7 +12,7 @@ from typing import Optional, Tuple
 import torch
 
 from . import _lib
-from ._lib import (BF16, EPI_ADD, EPI_BIAS, EPI_BIAS_GELU, EPI_GELU_BWD, EPI_NONE, EPI_SCALE_RC, F32,
+from ._lib import (BF16, EPI_ADD, EPI_BIAS, EPI_BIAS_GELU, EPI_GELU_BWD, EPI_NONE, EPI_SCALE_RC, F16, F32,
                    GemmDesc)
 
 POOL_MODES = {"mean+std": 0, "mean": 1, "max": 2, "first": 3, "first+cls": 3, "last": 4, "middle": 4}
@@ -25,9 +25,16 @@ def lib():
 def dt(t: torch.Tensor) -> int:
     if t.dtype == torch.bfloat16:
         return BF16
+    if t.dtype == torch.float16:
+        return F16
     if t.dtype == torch.float32:
         return F32
     raise TypeError(f"unsupported dtype {t.dtype}")
+
+
+def is16(dtype: torch.dtype) -> bool:
+    """A 16-bit activation format (bf16 or IEEE fp16): the matrix-core kernels exist for both."""
+    return dtype in (torch.bfloat16, torch.float16)
 
 
 def stream() -> int:
@@ -91,11 +98,12 @@ class Gemm:
         esz = A.element_size()
         self.bytes = float(batch) * ((M * K + N * K) * esz + M * N * Cmat.element_size() * (2 if aux is not None else 1))
         # which template instantiation of csrc/gemm.hip this descriptor launches (for profiling)
-        self.kernel_class = ("bf16" if dt(A) == BF16 else "f32") + "_" + ("t" if transA else "n") + ("n" if transB else "t")
+        lp = dt(A) != F32
+        self.kernel_class = ("mfma16" if lp else "f32") + "_" + ("t" if transA else "n") + ("n" if transB else "t")
         self.narrow = N <= 64
-        self.out_is_act = Cmat.dtype == torch.bfloat16
+        self.out_is_act = is16(Cmat.dtype)
         # mirrors the host dispatch of csrc/gemm.hip (w2v2_gemm): which kernel this descriptor launches
-        fast = (dt(A) == BF16 and not transA and not transB and K % 64 == 0 and K >= 64 and lda % 8 == 0 and ldb % 8 == 0)
+        fast = (lp and not transA and not transB and K % 64 == 0 and K >= 64 and lda % 8 == 0 and ldb % 8 == 0)
         if fast and N >= 512 and M >= 1024 and split_k <= 1 and not accumulate:
             self.kernel_name = "gemm_bf16_glds3_kernel"
             t4 = -(-M // 256) * -(-N // 256)          # 256x256 tiling fills >= 85 % of the last round of 256 CUs
@@ -105,7 +113,7 @@ class Gemm:
         elif fast:
             self.kernel_name = "gemm_bf16_glds_kernel"
         else:
-            self.kernel_name = "gemm_bf16_kernel" if dt(A) == BF16 else "gemm_f32_kernel"
+            self.kernel_name = "gemm_bf16_kernel" if lp else "gemm_f32_kernel"
 
     _prof = None
 
@@ -160,7 +168,8 @@ class WgradGroup:
         self.flops = 0.0
         for i, (dY, X, dW, db) in enumerate(problems):
             _dev(dY, X, dW, db)
-            assert dY.dtype == torch.bfloat16 and X.dtype == torch.bfloat16 and dW.dtype == torch.float32
+            assert is16(dY.dtype) and X.dtype == dY.dtype and dW.dtype == torch.float32
+            assert i == 0 or dY.dtype == problems[0][0].dtype, "one element type per grouped launch"
             assert dY.shape[0] >= tokens_padded and X.shape[0] >= tokens_padded
             q = arr[i]
             q.dY, q.ld_dy = dY.data_ptr(), dY.stride(0)
@@ -172,10 +181,11 @@ class WgradGroup:
             self.flops += 2.0 * tokens * dW.shape[0] * dW.shape[1]
         self._arr, self._keep, self._n = arr, keep, n
         self._tokens, self._tpad = tokens, tokens_padded
+        self._dt = dt(problems[0][0])
         self._fn = lib().w2v2_wgrad_grouped
 
     def __call__(self) -> None:
-        rc = self._fn(self._arr, self._n, self._tokens, self._tpad, stream())
+        rc = self._fn(self._arr, self._n, self._tokens, self._tpad, self._dt, stream())
         if rc:
             _lib.check(rc, "wgrad_grouped")
 
@@ -196,7 +206,7 @@ def conv0_groupnorm_gelu(wav: torch.Tensor, w: torch.Tensor, gamma: torch.Tensor
     mr = work[work.numel() - B * Cc * 2:]
     L = lib()
     # bf16 activations: conv on the matrix cores (split-bf16, ~2^-16), statistics from the same arithmetic
-    stats = L.w2v2_conv0_stats_mfma if out.dtype == torch.bfloat16 else L.w2v2_conv0_stats
+    stats = L.w2v2_conv0_stats_mfma if is16(out.dtype) else L.w2v2_conv0_stats
     _lib.check(stats(wav.data_ptr(), w.data_ptr(), work.data_ptr(), mr.data_ptr(), B, N, Cc, k, stride,
                      eps, stream()), "conv0_stats")
     _lib.check(L.w2v2_conv0_apply(wav.data_ptr(), w.data_ptr(), mr.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
@@ -358,8 +368,8 @@ def prepend_token(x, y, c: float) -> None:
 def posconv_wgrad(dY, xg, dwf, B: int, T: int, H: int, G: int, K: int) -> None:
     """dwf[g][(tap, ci)][co] = sum_{b,t} xg[b,g,t+tap,ci] * dY[b,t,g*Cg+co]  (bf16 operands, f32 result, overwritten)."""
     _dev(dY, xg, dwf)
-    assert dY.dtype == torch.bfloat16 and xg.dtype == torch.bfloat16 and dwf.dtype == torch.float32
-    _lib.check(lib().w2v2_posconv_wgrad(dY.data_ptr(), xg.data_ptr(), dwf.data_ptr(), B, T, H, G, K, stream()),
+    assert is16(dY.dtype) and xg.dtype == dY.dtype and dwf.dtype == torch.float32
+    _lib.check(lib().w2v2_posconv_wgrad(dY.data_ptr(), xg.data_ptr(), dwf.data_ptr(), B, T, H, G, K, dt(dY), stream()),
                "posconv_wgrad")
 
 
@@ -431,12 +441,14 @@ def row_invnorm(x, inv, rows: int, cols: int, ld: Optional[int] = None) -> None:
 
 
 def aam_softmax_fwd_bwd(cos, label, softmax, loss_rows, dcos_w, dcos_x, inv_x, inv_w, rowdot, coldot, B: int,
-                        Cn: int, ldc: int, margin: float, scale: float) -> None:
-    _dev(cos, label, softmax, loss_rows, dcos_w, dcos_x, inv_x, inv_w, rowdot, coldot)
+                        Cn: int, ldc: int, margin: float, scale: float, loss_scale=None) -> None:
+    """loss_scale: device tensor whose first element multiplies the loss gradient (fp16 loss scaling), or None."""
+    _dev(cos, label, softmax, loss_rows, dcos_w, dcos_x, inv_x, inv_w, rowdot, coldot, loss_scale)
     dty = dt(dcos_w) if dcos_w is not None else F32
     _lib.check(lib().w2v2_aam_softmax_fwd_bwd(cos.data_ptr(), label.data_ptr(), softmax.data_ptr(),
                                               loss_rows.data_ptr(), _p(dcos_w), _p(dcos_x), _p(inv_x), _p(inv_w),
-                                              _p(rowdot), _p(coldot), B, Cn, ldc, margin, scale, dty, stream()),
+                                              _p(rowdot), _p(coldot), B, Cn, ldc, margin, scale, _p(loss_scale), dty,
+                                              stream()),
                "aam_softmax")
 
 
@@ -449,12 +461,27 @@ def normalize_bwd(g, x, inv, dot, dx, rows: int, cols: int, ldx: Optional[int] =
 
 # ------------------------------------------------------------------------------------------------ optimiser
 def adam_step(p, g, m, v, pb, n: int, lr: float, beta1: float, beta2: float, eps: float, step: int,
-              grad_scale: float = 1.0) -> None:
-    _dev(p, g, m, v, pb)
+              grad_scale: float = 1.0, scaler=None) -> None:
+    """scaler: the 4-float device record of the dynamic loss scale (see grad_scaler_*), or None."""
+    _dev(p, g, m, v, pb, scaler)
     bc1 = 1.0 - beta1 ** step
     bc2 = 1.0 - beta2 ** step
-    _lib.check(lib().w2v2_adam_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), _p(pb), n, lr, beta1,
-                                    beta2, eps, bc1, bc2, grad_scale, stream()), "adam_step")
+    _lib.check(lib().w2v2_adam_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), _p(pb),
+                                    dt(pb) if pb is not None else BF16, n, lr, beta1, beta2, eps, bc1, bc2, grad_scale,
+                                    _p(scaler), stream()), "adam_step")
+
+
+def grad_scaler_check(g, n: int, state) -> None:
+    """state[1] = 1 if any of g[:n] is non-finite (torch GradScaler's unscale_ / found_inf)."""
+    _dev(g, state)
+    _lib.check(lib().w2v2_grad_scaler_check(g.data_ptr(), n, state.data_ptr(), stream()), "grad_scaler_check")
+
+
+def grad_scaler_update(state, growth: float = 2.0, backoff: float = 0.5, growth_interval: int = 2000) -> None:
+    """torch GradScaler.update() on the device record {scale, found_inf, growth_tracker, skipped_steps}."""
+    _dev(state)
+    _lib.check(lib().w2v2_grad_scaler_update(state.data_ptr(), growth, backoff, growth_interval, stream()),
+               "grad_scaler_update")
 
 
 # ------------------------------------------------------------------------------------------------ attentive pooling
@@ -587,9 +614,9 @@ def act_bwd(dy, y, dx, mode: int) -> None:
     _lib.check(lib().w2v2_act_bwd(dy.data_ptr(), y.data_ptr(), dx.data_ptr(), dy.numel(), mode, stream()), "act_bwd")
 
 
-def bce_head_fwd_bwd(emb, w, b, label, prob, loss_rows, dlogit, demb, dw, db, B: int, H: int) -> None:
-    _dev(emb, w, b, label, prob, loss_rows, dlogit, demb, dw, db)
+def bce_head_fwd_bwd(emb, w, b, label, prob, loss_rows, dlogit, demb, dw, db, B: int, H: int, loss_scale=None) -> None:
+    _dev(emb, w, b, label, prob, loss_rows, dlogit, demb, dw, db, loss_scale)
     _lib.check(lib().w2v2_bce_head_fwd_bwd(emb.data_ptr(), w.data_ptr(), b.data_ptr(), label.data_ptr(), prob.data_ptr(),
-                                           loss_rows.data_ptr(), _p(dlogit), _p(demb), _p(dw), _p(db), B, H, stream()),
-               "bce_head")
+                                           loss_rows.data_ptr(), _p(dlogit), _p(demb), _p(dw), _p(db), B, H,
+                                           _p(loss_scale), stream()), "bce_head")
 

@@ -73,8 +73,9 @@ _WN_OLD = {"encoder.pos_conv_embed.conv.weight_g": "encoder.pos_conv_embed.conv.
 class ParamStore:
     def __init__(self, cfg: W2V2Config, device, act_dtype: torch.dtype = torch.bfloat16,
                  head: Optional[str] = "aam", num_speakers: int = 5994, embed_dim: Optional[int] = None,
-                 freeze_cnn: bool = True, attentive_pool: bool = False, attention_channels: int = 128):
-        assert act_dtype in (torch.bfloat16, torch.float32)
+                 freeze_cnn: bool = True, attentive_pool: bool = False, attention_channels: int = 128,
+                 init_loss_scale: float = 16384.0):
+        assert act_dtype in (torch.bfloat16, torch.float16, torch.float32)
         assert head in (None, "aam", "ce", "bce")
         self.cfg, self.device, self.act_dtype = cfg, torch.device(device), act_dtype
         self.head, self.num_speakers, self.freeze_cnn = head, num_speakers, freeze_cnn
@@ -115,8 +116,11 @@ class ParamStore:
         self.grad = torch.zeros(self.n_train, dtype=torch.float32, device=dev)
         self.exp_avg: Optional[torch.Tensor] = None
         self.exp_avg_sq: Optional[torch.Tensor] = None
-        self.flat_lp = (torch.zeros(self.n_total, dtype=torch.bfloat16, device=dev)
-                        if act_dtype == torch.bfloat16 else None)
+        self.flat_lp = torch.zeros(self.n_total, dtype=act_dtype, device=dev) if ops.is16(act_dtype) else None
+        # fp16 activations: dynamic loss scale, device record {scale, found_inf, growth_tracker, skipped_steps}
+        # (torch GradScaler semantics -- the reference trains under PL precision 16; csrc/optim.hip)
+        self.scaler = (torch.tensor([init_loss_scale, 0.0, 0.0, 0.0], dtype=torch.float32, device=dev)
+                       if act_dtype == torch.float16 else None)
         # pre-transposed bf16 copies of the 2-D weights whose data-gradient product dX = dY W is on the
         # training path (refreshed by one batched-transpose launch after every optimiser step)
         self.flat_lp_t = None
@@ -134,7 +138,7 @@ class ParamStore:
                     ent.append((self.offsets[pre + n], self.offsets[pre + n], r, c))
             n = W2V_PREFIX + "feature_projection.projection.weight"
             ent.append((self.offsets[n], self.offsets[n], shapes[n][0], shapes[n][1]))
-            self.flat_lp_t = torch.zeros(self.n_total, dtype=torch.bfloat16, device=dev)
+            self.flat_lp_t = torch.zeros(self.n_total, dtype=act_dtype, device=dev)
             self._t_table = torch.tensor(ent, dtype=torch.int64, device=dev)
         self.version = 0          # bumped whenever weights change (derived packs are re-made lazily)
         self.cnn_version = 0      # bumped whenever the CNN weights change
@@ -311,15 +315,19 @@ class ParamStore:
             self.step_body += 1
         self.step_count = max(self.step_head, self.step_body)
         a = (self.flat, self.grad, self.exp_avg, self.exp_avg_sq)
-        lp = self.flat_lp
+        lp, sc = self.flat_lp, self.scaler
+        if sc is not None:        # found_inf over the slice this step updates; Adam skips itself when it is set
+            ops.grad_scaler_check(self.grad, h if head_only else self.n_train, sc)
         if head_only:
-            ops.adam_step(*a, lp, h, lr, beta1, beta2, eps, self.step_head, grad_scale)
+            ops.adam_step(*a, lp, h, lr, beta1, beta2, eps, self.step_head, grad_scale, sc)
         elif self.step_head == self.step_body or h == 0:
-            ops.adam_step(*a, lp, self.n_train, lr, beta1, beta2, eps, self.step_body, grad_scale)
+            ops.adam_step(*a, lp, self.n_train, lr, beta1, beta2, eps, self.step_body, grad_scale, sc)
         else:
-            ops.adam_step(*a, lp, h, lr, beta1, beta2, eps, self.step_head, grad_scale)
+            ops.adam_step(*a, lp, h, lr, beta1, beta2, eps, self.step_head, grad_scale, sc)
             ops.adam_step(*(t[h:] for t in a), lp[h:] if lp is not None else None, self.n_train - h, lr, beta1,
-                          beta2, eps, self.step_body, grad_scale)
+                          beta2, eps, self.step_body, grad_scale, sc)
+        if sc is not None:
+            ops.grad_scaler_update(sc)
         self.sync_transposed()
         self.version += 1
         if not self.freeze_cnn:
