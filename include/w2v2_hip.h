@@ -88,6 +88,14 @@ typedef struct {
                               f32 C the caller zeroed (EPI_NONE only)                     */
   int32_t accumulate;      /* 1: C += result (f32 C, atomics; implied by split_k>1)       */
   int32_t _pad;
+  /* Two-term weights (fp16 activations; 0 = off): B = B_hi + B_lo with B_lo = fp16(W - fp16(W)) stored
+   * b_lo_offset ELEMENTS behind B_hi (same layout).  Output columns n >= n_ext_from run k_ext (= K) extra
+   * K steps  sum_k A(m,k) * B_lo(n,k), i.e. C = A (B_hi + B_lo)^T with the weight rounding error of ~2^-22
+   * instead of 2^-11.  Used for the value and output projections of the attention block, whose weight
+   * rounding is the largest term of the embedding error budget (DESIGN.md "precision").  Runs on the 256x128
+   * LDS-DMA ring kernel: plain NT product, K % 64 == 0, 16-byte aligned rows; anything else is an error. */
+  int32_t k_ext, n_ext_from;
+  int64_t b_lo_offset;
 } w2v2_gemm_desc;
 
 int w2v2_gemm(const w2v2_gemm_desc* d, void* stream);
@@ -361,6 +369,9 @@ int w2v2_adam_step(float* p, const float* g, float* m, float* v, void* pb, int p
  * step carries it.  check: state[1] = 1 if any of g[0..n) is non-finite.  update (after the optimiser step):
  * found_inf ? scale *= backoff : (every growth_interval clean steps scale *= growth); clears found_inf.
  * No host synchronisation anywhere. */
+/* lo[off_i .. off_i + n_i) = fp16(p[..] - fp16(p[..])) for every (off_i, n_i) of `table` ([n_ranges][2] int64, device):
+ * the residual plane of the two-term weights above (p = f32 master arena, lo = a 16-bit arena of the same layout). */
+int w2v2_weight_residual(const float* p, void* lo, const int64_t* table, int n_ranges, int dtype, void* stream);
 int w2v2_grad_scaler_check(const float* g, int64_t n, float* state, void* stream);
 int w2v2_grad_scaler_update(float* state, float growth, float backoff, int growth_interval, void* stream);
 

@@ -154,6 +154,42 @@ def test_gemm_ring_kernels_at_full_size(M, N, K, epi, lp):
         assert float(C[:, N:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("M,N,K,nfrom", [(2100, 768, 256, 0), (9834, 2304, 768, 1536), (1500, 640, 64, 256)])
+def test_gemm_two_term_weights(M, N, K, nfrom):
+    """fp16 products with two-term weights (w2v2_gemm_desc.k_ext): columns >= n_ext_from see W = hi + lo, i.e. the
+    f32 weight to ~2^-22, the others fp16(W).  Reference: f64 products of the fp16 activations with the respective
+    weights; the residual plane removes the weight-rounding error (asserted 100x below the one-term error)."""
+    o = ops()
+    g = torch.Generator(device="cpu").manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g).to(torch.float16)
+    W = torch.randn(N, K, generator=g) / K ** 0.5
+    planes = torch.zeros(2, N * K, dtype=torch.float16, device=DEV)
+    hi = W.to(torch.float16)
+    lo = (W - hi.float()).to(torch.float16)
+    planes[0].copy_(hi.view(-1))
+    planes[1].copy_(lo.view(-1))
+    bias = torch.randn(N, generator=g)
+    C = torch.zeros(M, N, dtype=torch.float32, device=DEV)
+    o.gemm(M, N, K, A.to(DEV), planes[0].view(N, K), C, lda=K, ldb=K, ldc=N, epilogue=o.EPI_BIAS, bias=bias.to(DEV),
+           b_lo=planes[1].view(N, K), n_ext_from=nfrom)
+    torch.cuda.synchronize()
+    got = C.cpu().double()
+    exact = A.double() @ W.double().t() + bias.double()
+    one = A.double() @ hi.double().t() + bias.double()
+    if nfrom:
+        assert rel_l2(got[:, :nfrom], one[:, :nfrom]) < 2e-6             # one-term columns: fp16(W) exactly
+    e2 = rel_l2(got[:, nfrom:], exact[:, nfrom:])
+    e1 = rel_l2(one[:, nfrom:], exact[:, nfrom:])
+    print("two-term error", e2, "one-term error", e1)
+    assert e2 < 2e-6 and e1 > 100 * e2
+    # 16-bit output with the deferred-store epilogue
+    C16 = torch.zeros(M, N, dtype=torch.float16, device=DEV)
+    o.gemm(M, N, K, A.to(DEV), planes[0].view(N, K), C16, lda=K, ldb=K, ldc=N, epilogue=o.EPI_BIAS, bias=bias.to(DEV),
+           b_lo=planes[1].view(N, K), n_ext_from=nfrom)
+    torch.cuda.synchronize()
+    assert rel_l2(C16.float().cpu()[:, nfrom:], exact[:, nfrom:]) < 4e-4
+
+
 def test_gemm_split_k_and_accumulate():
     o = ops()
     for dtype in (torch.bfloat16, torch.float16, torch.float32):

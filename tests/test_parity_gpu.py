@@ -180,10 +180,12 @@ def test_base_f32_embeddings_within_1e3_of_reference_and_grad_norms():
 
 
 # embedding rel-L2 of the base model against the reference golden, per 16-bit format.  fp16 is the mode bench.py
-# runs: measured 1.04e-3 (eval) / 1.00e-3 (train forward) on this golden, exactly what the CPU simulation of fp16
-# operand rounding predicts (tests/debug/error_budget2.py: 1.04e-3, of which the rounding of the encoder WEIGHTS is
-# 0.84e-3 -- a systematic, token-independent error that mean pooling cannot average out).
-EMB_BOUND = {torch.float16: 1.1e-3, torch.bfloat16: 3e-2}
+# runs and carries north_star's bar (< 1e-3): measured 7.7e-4 (eval) / 7.6e-4 (train forward).  Plain fp16 operands
+# give 1.04e-3, exactly what the CPU simulation of the storage roundings predicts (tests/debug/error_budget2.py):
+# 0.84e-3 of it is the rounding of the encoder WEIGHTS, a systematic, token-independent error that mean pooling cannot
+# average out, and most of that comes from the value / output projections -- hence their two-term weights
+# (ParamStore.two_term, w2v2_gemm_desc.k_ext), which bring the simulation to 7.5e-4.
+EMB_BOUND = {torch.float16: 1e-3, torch.bfloat16: 3e-2}
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])

@@ -28,7 +28,8 @@ class GemmDesc(C.Structure):
                 ("C", c_vp), ("ldc", c_i64), ("c_stride0", c_i64), ("c_stride1", c_i64),
                 ("aux", c_vp), ("ldaux", c_i64), ("aux_stride0", c_i64), ("aux_stride1", c_i64),
                 ("bias", c_vp), ("bias_stride1", c_i64), ("row_scale", c_vp), ("col_scale", c_vp),
-                ("alpha", c_f32), ("split_k", c_i32), ("accumulate", c_i32), ("_pad", c_i32)]
+                ("alpha", c_f32), ("split_k", c_i32), ("accumulate", c_i32), ("_pad", c_i32),
+                ("k_ext", c_i32), ("n_ext_from", c_i32), ("b_lo_offset", c_i64)]
 
 
 class LnFold(C.Structure):
@@ -111,6 +112,7 @@ _SIGS = {
     "w2v2_normalize_bwd": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "w2v2_adam_step": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32,
                                c_f32, c_f32, c_vp, c_vp]),
+    "w2v2_weight_residual": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_vp]),
     "w2v2_grad_scaler_check": (c_i32, [c_vp, c_i64, c_vp, c_vp]),
     "w2v2_grad_scaler_update": (c_i32, [c_vp, c_f32, c_f32, c_i32, c_vp]),
 }

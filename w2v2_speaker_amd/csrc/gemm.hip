@@ -47,6 +47,9 @@ struct GemmArgs {
   int aux_vec_ok;  // 8-element vector access to aux legal
   int dbg;
   int defer_ok;    // 256x128 ring kernel: stores of a tile may be issued under the next tile's main loop
+  // two-term weights (w2v2_hip.h): tiles with n0 >= n_ext_from run k_ext more K steps against B + b_lo_off
+  int k_ext, n_ext_from;
+  int64_t b_lo_off;
 };
 
 __device__ __forceinline__ int64_t outer_off(const OpDev& o, int64_t idx) {
@@ -740,7 +743,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_glds3_kernel(const GemmArgs g) 
   const int tm = tile / g.tiles_n, tn = tile - tm * g.tiles_n;
   const int m0 = tm * BM, n0 = tn * BN;
   const int z0 = z / g.batch_inner, z1 = z - z0 * g.batch_inner;
-  const int nk = g.K >> 6;
+  // K steps of this tile: nk1 over (A, B) + for the tiles of the two-term weight columns nk - nk1 more over (A, B_lo)
+  const int nk1 = g.K >> 6;
+  const int nk = nk1 + ((g.k_ext > 0 && n0 >= g.n_ext_from) ? (g.k_ext >> 6) : 0);
+  auto koff_a = [&](int kt) -> int { return (kt < nk1 ? kt : kt - nk1) * 64; };
+  auto koff_b = [&](int kt) -> int64_t { return kt < nk1 ? (int64_t)kt * 64 : (int64_t)(kt - nk1) * 64 + g.b_lo_off; };
 
   const bf16_t* Ab = reinterpret_cast<const bf16_t*>(g.A.ptr) + z0 * g.a_s0 + z1 * g.a_s1;
   const bf16_t* Bb = reinterpret_cast<const bf16_t*>(g.B.ptr) + z0 * g.b_s0 + z1 * g.b_s1;
@@ -770,12 +777,14 @@ __global__ __launch_bounds__(512) void gemm_bf16_glds3_kernel(const GemmArgs g) 
   auto stage = [&](bf16_t* base, int kt) {
     bf16_t* ad = base + wave * 4 * 8 * 64;
     bf16_t* bd = base + BM * 64 + wave * 2 * 8 * 64;
+    const int ka = koff_a(kt);
+    const int64_t kb = koff_b(kt);
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-      __builtin_amdgcn_global_load_lds((gvoid_t*)(ap[j] + kt * 64), (lvoid_t*)(ad + j * 8 * 64), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gvoid_t*)(ap[j] + ka), (lvoid_t*)(ad + j * 8 * 64), 16, 0, 0);
 #pragma unroll
     for (int j = 0; j < 2; ++j)
-      __builtin_amdgcn_global_load_lds((gvoid_t*)(bp[j] + kt * 64), (lvoid_t*)(bd + j * 8 * 64), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gvoid_t*)(bp[j] + kb), (lvoid_t*)(bd + j * 8 * 64), 16, 0, 0);
   };
   const int frow = lane & 15, fk = lane >> 4;
   // per-lane fragment offsets (elements) for k-step 0 / 1; everything else is a compile-time constant
@@ -790,10 +799,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_glds3_kernel(const GemmArgs g) 
   // piece p of the 6 DMA pieces of one stage: A0..A3, B0, B1
   auto stage_piece = [&](bf16_t* base, int kt, int p) {
     if (p < 4)
-      __builtin_amdgcn_global_load_lds((gvoid_t*)(ap[p] + kt * 64), (lvoid_t*)(base + (wave * 4 + p) * 8 * 64), 16, 0,
-                                       0);
+      __builtin_amdgcn_global_load_lds((gvoid_t*)(ap[p] + koff_a(kt)), (lvoid_t*)(base + (wave * 4 + p) * 8 * 64), 16,
+                                       0, 0);
     else
-      __builtin_amdgcn_global_load_lds((gvoid_t*)(bp[p - 4] + kt * 64),
+      __builtin_amdgcn_global_load_lds((gvoid_t*)(bp[p - 4] + koff_b(kt)),
                                        (lvoid_t*)(base + BM * 64 + (wave * 2 + p - 4) * 8 * 64), 16, 0, 0);
   };
   // multiply stage `base`; when kload >= 0 the DMA pieces of K tile kload go to `nxt`, spread over the MFMA groups
@@ -1250,6 +1259,7 @@ extern "C" int w2v2_gemm(const w2v2_gemm_desc* d, void* stream) {
   a.bias = d->bias; a.bias_s1 = d->bias_stride1;
   a.row_scale = d->row_scale; a.col_scale = d->col_scale;
   a.alpha = d->alpha;
+  a.k_ext = d->k_ext; a.n_ext_from = d->n_ext_from; a.b_lo_off = d->b_lo_offset;
   a.dbg = getenv("W2V2_GEMM_DBG") ? atoi(getenv("W2V2_GEMM_DBG")) : 0;
   static const bool defer_env = getenv("W2V2_NO_DEFER") == nullptr;   // A/B switch
   a.defer_ok = 0;
@@ -1270,14 +1280,21 @@ extern "C" int w2v2_gemm(const w2v2_gemm_desc* d, void* stream) {
                       !g_w2v2_no_glds;
     // 256x128 3-stage kernel for the encoder shapes; the conv stack (N = 512, M ~ 3e5) measures
     // slightly faster on the 128x128 kernel at 2 workgroups per CU
-    const bool big = glds && d->N >= (getenv("W2V2_G3N") ? atoi(getenv("W2V2_G3N")) : 512) && split == 1 && !atomic && d->M >= 1024 && g_w2v2_glds3;
+    // (two-term weights exist on this kernel only: such a request takes it whatever the shape)
+    const bool big = glds && split == 1 && !atomic &&
+                     (d->k_ext != 0 || (d->N >= (getenv("W2V2_G3N") ? atoi(getenv("W2V2_G3N")) : 512) && d->M >= 1024 && g_w2v2_glds3));
     // 256x256 tiles when they fill the chip: >= 85 % of the CU slots of the last round busy (FFN1, dH, conv stack)
     bool huge = false;
-    if (big && d->N >= 512 && d->batch == 1 && !getenv("W2V2_NO_GLDS4")) {
+    if (big && d->k_ext == 0 && d->N >= 512 && d->batch == 1 && !getenv("W2V2_NO_GLDS4")) {
       const int64_t t4 = cdiv(d->M, 256) * cdiv(d->N, 256), ncu = device_cus();
       huge = t4 >= ncu && (double)t4 / (double)(cdiv(t4, ncu) * ncu) >= 0.85 &&
              (double)d->N / (double)(cdiv(d->N, 256) * 256) >= 0.9;
     }
+    if (d->k_ext != 0)
+      W2V2_REQUIRE(big && !huge && d->k_ext == d->K && d->n_ext_from >= 0 && d->n_ext_from % 128 == 0 &&
+                       d->b_lo_offset % 8 == 0,
+                   "w2v2_gemm: two-term weights (k_ext) need k_ext == K, n_ext_from %% 128 == 0 and K-contiguous 16-byte "
+                   "aligned operands with K %% 64 == 0 (M=%d N=%d K=%d)", d->M, d->N, d->K);
     // TE = operand element type (selects the MFMA instruction), TC = float or TE
 #define W2V2_GEMM_LAUNCH(TE, TC)                                                                         \
     do {                                                                                                 \

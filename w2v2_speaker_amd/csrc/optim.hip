@@ -87,6 +87,40 @@ __global__ void scaler_update_kernel(float* __restrict__ state, float growth, fl
   state[1] = 0.f;
 }
 
+// residual plane of the two-term 16-bit weights: lo = T(p - T(p)) over a table of (offset, count) ranges
+template <typename TB>
+__global__ __launch_bounds__(256) void weight_residual_kernel(const float* __restrict__ p, TB* __restrict__ lo,
+                                                              const int64_t* __restrict__ table) {
+  const int64_t off = table[2 * blockIdx.y], n = table[2 * blockIdx.y + 1];
+  const int64_t nv = n >> 2;              // ranges are 64-element aligned in the arena; the tail loop covers any rest
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nv; i += (int64_t)gridDim.x * blockDim.x) {
+    const float4 v = reinterpret_cast<const float4*>(p + off)[i];
+    const float a[4] = {v.x, v.y, v.z, v.w};
+    float r[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r[e] = a[e] - to_f32<TB>(from_f32<TB>(a[e]));
+    uint2 w;
+    w.x = pack2<TB>(r[0], r[1]);
+    w.y = pack2<TB>(r[2], r[3]);
+    reinterpret_cast<uint2*>(lo + off)[i] = w;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const int64_t i = off + (nv << 2) + threadIdx.x;
+    lo[i] = from_f32<TB>(p[i] - to_f32<TB>(from_f32<TB>(p[i])));
+  }
+}
+
+extern "C" int w2v2_weight_residual(const float* p, void* lo, const int64_t* table, int n_ranges, int dtype,
+                                    void* stream) {
+  W2V2_REQUIRE(p && lo && table && n_ranges >= 0, "weight_residual: bad arguments");
+  if (n_ranges == 0) return 0;
+  W2V2_DISPATCH_16(dtype, "weight_residual",
+    hipLaunchKernelGGL(weight_residual_kernel<AT>, dim3(64, n_ranges), dim3(256), 0, as_stream(stream), p, (AT*)lo,
+                       table););
+  W2V2_CHECK_LAUNCH("weight_residual");
+  return 0;
+}
+
 extern "C" int w2v2_grad_scaler_check(const float* g, int64_t n, float* state, void* stream) {
   W2V2_REQUIRE(g && state && n >= 0, "grad_scaler_check: bad arguments");
   if (n == 0) return 0;

@@ -21,7 +21,7 @@ from . import ops
 from .config import W2V2Config, Wav2Vec2RegularisationConfig
 from .ops import (EPI_ADD, EPI_BIAS, EPI_BIAS_GELU, EPI_GELU_BWD, EPI_NONE, EPI_SCALE_RC, Gemm, POOL_MODES,
                   WgradGroup)
-from .params import ParamStore
+from .params import W2V_PREFIX, ParamStore
 
 _SITE = {"featproj": 1, "prologue": 2, "attn": 3, "post_attn": 4, "ffn": 5, "act": 6}
 
@@ -243,8 +243,11 @@ class Plan:
             xin = self.X[l] if self.all_x else self.X[l % 2]
             pre = f"encoder.layers.{l}."
             gl: Dict[str, Gemm] = {}
+            # fp16: the value and output projections run with two-term weights (W = hi + lo planes, 2 x K steps on
+            # those columns): their rounding is the largest single term of the embedding error (DESIGN "precision")
+            two = st.two_term and H % 64 == 0
             gl["qkv"] = Gemm(M, 3 * H, H, xin, st.qkv(l, "w"), lb.qkv, lda=H, ldb=H, ldc=3 * H, epilogue=EPI_BIAS,
-                             bias=st.qkv(l, "p", "bias"))
+                             bias=st.qkv(l, "p", "bias"), b_lo=st.qkv_lo(l) if two else None, n_ext_from=2 * H)
             if not self.fused:
                 qkv = lb.qkv.view(-1)
                 sc = (heads * T * self.Tl, T * self.Tl)
@@ -255,7 +258,8 @@ class Plan:
                                  batch=B * heads, batch_inner=heads, a_strides=sc, b_strides=(T * 3 * H, d),
                                  c_strides=(T * H, d))
             gl["out"] = Gemm(M, H, H, lb.ctx, mw(pre + "attention.out_proj.weight"), lb.a, lda=H, ldb=H, ldc=H,
-                             epilogue=EPI_BIAS, bias=mp(pre + "attention.out_proj.bias"))
+                             epilogue=EPI_BIAS, bias=mp(pre + "attention.out_proj.bias"),
+                             b_lo=st.w_lo(W2V_PREFIX + pre + "attention.out_proj.weight") if two else None)
             gl["ffn1"] = Gemm(M, I, H, lb.x1, mw(pre + "feed_forward.intermediate_dense.weight"), lb.h, lda=H, ldb=H,
                               ldc=I, epilogue=EPI_BIAS_GELU, bias=mp(pre + "feed_forward.intermediate_dense.bias"),
                               aux=lb.hpre, ldaux=I)

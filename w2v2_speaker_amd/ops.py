@@ -63,8 +63,11 @@ class Gemm:
                  epilogue: int = EPI_NONE, bias: Optional[torch.Tensor] = None, bias_stride1: int = 0,
                  aux: Optional[torch.Tensor] = None, ldaux: int = 0, aux_strides: Tuple[int, int] = (0, 0),
                  row_scale: Optional[torch.Tensor] = None, col_scale: Optional[torch.Tensor] = None,
-                 alpha: float = 1.0, split_k: int = 1, accumulate: bool = False):
-        _dev(A, B, Cmat, bias, aux, row_scale, col_scale)
+                 alpha: float = 1.0, split_k: int = 1, accumulate: bool = False,
+                 b_lo: Optional[torch.Tensor] = None, n_ext_from: int = 0):
+        """b_lo: residual plane of two-term weights (same layout as B, b_lo = T(W - T(W))): output columns
+        n >= n_ext_from are computed as A (B + b_lo)^T (include/w2v2_hip.h, w2v2_gemm_desc.k_ext)."""
+        _dev(A, B, Cmat, bias, aux, row_scale, col_scale, b_lo)
         if dt(A) != dt(B):
             raise TypeError("GEMM operands must share a dtype")
         if aux is not None and aux.dtype != Cmat.dtype:
@@ -89,9 +92,14 @@ class Gemm:
         d.bias, d.bias_stride1 = _p(bias), bias_stride1
         d.row_scale, d.col_scale = _p(row_scale), _p(col_scale)
         d.alpha, d.split_k, d.accumulate = alpha, split_k, int(accumulate)
+        d.k_ext, d.n_ext_from, d.b_lo_offset = 0, 0, 0
+        if b_lo is not None:
+            assert b_lo.dtype == B.dtype and (b_lo.data_ptr() - B.data_ptr()) % B.element_size() == 0
+            d.k_ext, d.n_ext_from = K, n_ext_from
+            d.b_lo_offset = (b_lo.data_ptr() - B.data_ptr()) // B.element_size()
         self.desc = d
         self._ref = C.byref(d)
-        self._keep = (A, B, Cmat, bias, aux, row_scale, col_scale)   # keep buffers alive
+        self._keep = (A, B, Cmat, bias, aux, row_scale, col_scale, b_lo)   # keep buffers alive
         self._fn = lib().w2v2_gemm
         self.flops = 2.0 * M * N * K * batch
         # algorithmic HBM bytes: each operand read once, C written once (+ the aux tensor read or written once)
@@ -104,10 +112,10 @@ class Gemm:
         self.out_is_act = is16(Cmat.dtype)
         # mirrors the host dispatch of csrc/gemm.hip (w2v2_gemm): which kernel this descriptor launches
         fast = (lp and not transA and not transB and K % 64 == 0 and K >= 64 and lda % 8 == 0 and ldb % 8 == 0)
-        if fast and N >= 512 and M >= 1024 and split_k <= 1 and not accumulate:
+        if fast and split_k <= 1 and not accumulate and (b_lo is not None or (N >= 512 and M >= 1024)):
             self.kernel_name = "gemm_bf16_glds3_kernel"
             t4 = -(-M // 256) * -(-N // 256)          # 256x256 tiling fills >= 85 % of the last round of 256 CUs
-            if (batch == 1 and t4 >= 256 and t4 / (-(-t4 // 256) * 256) >= 0.85 and N / (-(-N // 256) * 256) >= 0.9
+            if (b_lo is None and N >= 512 and batch == 1 and t4 >= 256 and t4 / (-(-t4 // 256) * 256) >= 0.85 and N / (-(-N // 256) * 256) >= 0.9
                     and not os.environ.get("W2V2_NO_GLDS4")):
                 self.kernel_name = "gemm_bf16_glds4_kernel"
         elif fast:
@@ -469,6 +477,13 @@ def adam_step(p, g, m, v, pb, n: int, lr: float, beta1: float, beta2: float, eps
     _lib.check(lib().w2v2_adam_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), _p(pb),
                                     dt(pb) if pb is not None else BF16, n, lr, beta1, beta2, eps, bc1, bc2, grad_scale,
                                     _p(scaler), stream()), "adam_step")
+
+
+def weight_residual(p, lo, table) -> None:
+    """lo[off:off+n] = T(p[off:off+n] - T(p[off:off+n])) for every (off, n) row of the int64 device table."""
+    _dev(p, lo, table)
+    _lib.check(lib().w2v2_weight_residual(p.data_ptr(), lo.data_ptr(), table.data_ptr(), table.shape[0], dt(lo), stream()),
+               "weight_residual")
 
 
 def grad_scaler_check(g, n: int, state) -> None:

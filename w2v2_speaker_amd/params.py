@@ -13,6 +13,7 @@ Names are the reference's state-dict keys (``wav2vec.model.<HF name>``, ``loss_f
 from __future__ import annotations
 
 import math
+import os
 from collections import OrderedDict
 from typing import Dict, List, Optional, Tuple
 
@@ -74,7 +75,7 @@ class ParamStore:
     def __init__(self, cfg: W2V2Config, device, act_dtype: torch.dtype = torch.bfloat16,
                  head: Optional[str] = "aam", num_speakers: int = 5994, embed_dim: Optional[int] = None,
                  freeze_cnn: bool = True, attentive_pool: bool = False, attention_channels: int = 128,
-                 init_loss_scale: float = 16384.0):
+                 init_loss_scale: float = 16384.0, two_term_weights: bool = True):
         assert act_dtype in (torch.bfloat16, torch.float16, torch.float32)
         assert head in (None, "aam", "ce", "bce")
         self.cfg, self.device, self.act_dtype = cfg, torch.device(device), act_dtype
@@ -116,7 +117,22 @@ class ParamStore:
         self.grad = torch.zeros(self.n_train, dtype=torch.float32, device=dev)
         self.exp_avg: Optional[torch.Tensor] = None
         self.exp_avg_sq: Optional[torch.Tensor] = None
-        self.flat_lp = torch.zeros(self.n_total, dtype=act_dtype, device=dev) if ops.is16(act_dtype) else None
+        # fp16: a second plane holds the residuals fp16(W - fp16(W)) of the weights whose products run with two-term
+        # weights (value and output projections of every attention block, see Plan._build_gemms / DESIGN "precision")
+        self.two_term = (act_dtype == torch.float16 and two_term_weights and not os.environ.get("W2V2_NO_TWO_TERM"))
+        self._lp_planes = (torch.zeros(2 if self.two_term else 1, self.n_total, dtype=act_dtype, device=dev)
+                           if ops.is16(act_dtype) else None)
+        self.flat_lp = self._lp_planes[0] if self._lp_planes is not None else None
+        self.flat_lp_lo = self._lp_planes[1] if self.two_term else None
+        self._lo_table = None
+        if self.two_term:
+            H = cfg.hidden_size
+            rng = []
+            for l in range(cfg.num_hidden_layers):
+                pre = W2V_PREFIX + f"encoder.layers.{l}.attention."
+                rng.append((self.offsets[pre + "v_proj.weight"], H * H))
+                rng.append((self.offsets[pre + "out_proj.weight"], H * H))
+            self._lo_table = torch.tensor(rng, dtype=torch.int64, device=dev)
         # fp16 activations: dynamic loss scale, device record {scale, found_inf, growth_tracker, skipped_steps}
         # (torch GradScaler semantics -- the reference trains under PL precision 16; csrc/optim.hip)
         self.scaler = (torch.tensor([init_loss_scale, 0.0, 0.0, 0.0], dtype=torch.float32, device=dev)
@@ -180,6 +196,20 @@ class ParamStore:
     def sync_transposed(self) -> None:
         if self.flat_lp_t is not None:
             ops.transpose_many(self.flat_lp, self.flat_lp_t, self._t_table, self._t_table.shape[0])
+        if self.two_term:
+            ops.weight_residual(self.flat, self.flat_lp_lo, self._lo_table)
+
+    def w_lo(self, name: str) -> Optional[torch.Tensor]:
+        """Residual-plane view of a two-term weight (None when the store has no second plane)."""
+        return self._view(self.flat_lp_lo, name) if self.two_term else None
+
+    def qkv_lo(self, layer: int) -> Optional[torch.Tensor]:
+        """Residual plane of the fused [3H, H] QKV operand (only its value rows are filled)."""
+        if not self.two_term:
+            return None
+        H = self.cfg.hidden_size
+        o = self.offsets[W2V_PREFIX + f"encoder.layers.{layer}.attention.q_proj.weight"]
+        return self.flat_lp_lo[o:o + 3 * H * H].view(3 * H, H)
 
     def is_trainable(self, name: str) -> bool:
         return self.offsets[name] < self.n_train
