@@ -1,20 +1,28 @@
 #!/usr/bin/env python3
 """bench.py -- utterances/sec of one full training step of the hot path (fwd + bwd + gradient
 all-reduce + fused Adam) on synthetic 3 s utterances: wav2vec2-base + mean+std pooling + AAM-softmax,
-batch 66 per GPU, bf16 activations/weights with f32 accumulation, f32 master weights and optimiser
-(BASELINE.json configs[1]; the reference's defaults: frozen CNN, dropout 0.1, LayerDrop 0.05,
-SpecAugment time masks).
+batch 66 per GPU (BASELINE.json configs[1]; the reference's defaults: frozen CNN, dropout 0.1, LayerDrop 0.05,
+SpecAugment time masks).  Arithmetic: fp16 activations / weight copies on the matrix cores with f32
+accumulation, f32 master weights and optimiser, dynamic loss scaling -- the reference's own precision
+(PL `precision: 16`, config/experiment/speaker_wav2vec2_aam.yaml:17), the mode whose embeddings sit within
+1e-3 rel-L2 of the f32 reference (tests/test_parity_gpu.py).  `--dtype bf16|f32` select the other modes.
 
-    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
 
-Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel (the forward-layout MFMA GEMM
-`gemm_bf16_glds3_kernel<bf16>`): algorithmic FLOPs of its launches divided
-by their HIP-event-measured durations inside the timed region.  `cpu_baseline` times the CPU oracle
-(oracle/w2v2_oracle.py, kind "port") on a bounded sample of the same workload on the host cores.
+N > 1: either launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` (RANK / LOCAL_RANK /
+WORLD_SIZE in the environment) or plainly as above, in which case this process starts N fresh children -- one per GPU,
+before it has touched a GPU itself -- and waits for them.  One rank per GPU over RCCL (torch.distributed "nccl").
+
+Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel of the step (largest total time among the
+MFMA GEMM kernels): algorithmic FLOPs of its launches divided by their HIP-event-measured durations inside the timed
+region; `traffic` / `mfma_busy` come from the committed rocprofv3 PMC passes of the same command under profiles/.
+`cpu_baseline` times the CPU oracle (oracle/w2v2_oracle.py, kind "port") on the host cores with the protocol of
+BASELINE.md section 3 (config 1: bs 8, CE head).
 """
 import argparse
 import json
 import os
+import socket
 import sys
 import time
 
@@ -25,7 +33,8 @@ if ROOT not in sys.path:
 import numpy as np
 import torch
 
-MFMA_BF16_PEAK_TFLOPS = 2500.0      # /opt/skills/guides/MI355X_MICROARCH.md: dense bf16 MFMA peak
+MFMA_PEAK_TFLOPS = 2500.0      # /opt/skills/guides/MI355X_MICROARCH.md: dense bf16 / fp16 MFMA peak
+PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_counters.json")   # tools/pmc_traffic.py + tools/pmc_mfma.py
 
 
 def synth_batch(batch, n_samples, num_speakers, seed, device):
@@ -39,49 +48,60 @@ def synth_batch(batch, n_samples, num_speakers, seed, device):
     return wav.to(device), label.to(device)
 
 
-def cpu_baseline(batch=2, n_samples=48000, num_speakers=5994):
-    """The CPU oracle on a bounded sample of the same workload: `batch` utterances of 3 s through
-    w2v2-base + mean+std + AAM, forward + backward (CNN frozen) + Adam, f32, all host cores."""
+def cpu_baseline(batch=8, n_samples=48000, num_speakers=1211):
+    """the CPU oracle on BASELINE config 1 -- w2v2-base + CE head (C = 1211), batch 8 x 3 s,
+    f32, forward + backward (CNN frozen) + Adam; 2 warm-up + 5 timed steps with all host cores (torch's CPU kernels
+    stop scaling beyond a few dozen threads: capped at 64, the number used is reported), median utt/s; and a short
+    second run at 8 threads for comparability with the 8-core authoring container."""
     from oracle import w2v2_oracle as O
-    # torch's CPU kernels stop scaling (and then collapse) beyond a few dozen threads at these sizes:
-    # use up to 32 host cores and report that number
-    torch.set_num_threads(min(32, os.cpu_count() or 1))
-    cores = torch.get_num_threads()
     cfg = O.OracleConfig.base()
     sd = O.make_state_dict(cfg, 20211)
-    W = O.synth_tensor("loss_fn.fc_weights", (num_speakers, 2 * cfg.hidden_size), 20211)
+    E = 2 * cfg.hidden_size
+    W = O.synth_tensor("fc_list.0.0.weight", (num_speakers, E), 20211).requires_grad_(True)
+    b = O.synth_tensor("fc_list.0.0.bias", (num_speakers,), 20211).requires_grad_(True)
     train = {k: v.requires_grad_(not k.startswith("feature_extractor")) for k, v in sd.items()}
-    W.requires_grad_(True)
     wav, label = O.synth_batch(batch, n_samples, num_speakers, seed=42133724)
-    params = [v for k, v in train.items() if v.requires_grad] + [W]
+    params = [v for k, v in train.items() if v.requires_grad] + [W, b]
     state = [(torch.zeros_like(p), torch.zeros_like(p)) for p in params]
 
     def step(i):
         for p in params:
             p.grad = None
         emb = O.speaker_embedding(wav, train, cfg, "mean+std")
-        loss, _ = O.aam_softmax(emb, W, label, 0.2, 30.0)
+        loss, _ = O.ce_head(emb, W, b, label)
         loss.backward()
         with torch.no_grad():
             for p, (m, v) in zip(params, state):
                 if p.grad is not None:
                     O.adam_step(p, p.grad, m, v, i + 1, 1e-5, 0.9)
-        return float(loss)
+        return float(loss.detach())
 
-    t0 = time.perf_counter()
-    step(0)                                   # warm-up (thread pools, allocator)
-    warm = time.perf_counter() - t0
-    n = 2 if warm < 12 else 1                 # bound the sample to ~10-30 s of CPU work
-    t0 = time.perf_counter()
-    for i in range(n):
-        step(i + 1)
-    dt = (time.perf_counter() - t0) / n
-    return {"value": round(batch / dt, 4), "unit": "utterances/sec", "cores": cores, "kind": "port",
-            "sample": f"{n} timed step(s) of {batch} x 3 s utterances, w2v2-base + mean+std + AAM(5994), "
-                      f"fwd+bwd (CNN frozen) + Adam, f32 torch CPU oracle ({dt:.2f} s/step)"}
+    def run(threads, warm, timed):
+        torch.set_num_threads(threads)
+        for i in range(warm):
+            step(i)
+        ts = []
+        for i in range(timed):
+            t0 = time.perf_counter()
+            step(warm + i)
+            ts.append(time.perf_counter() - t0)
+        return float(np.median(ts))
+
+    ncpu = os.cpu_count() or 1
+    cores = min(64, ncpu)
+    dt = run(cores, 2, 5)
+    out = {"value": round(batch / dt, 4), "unit": "utterances/sec", "cores": cores, "kind": "port",
+           "gflops": round(97.73 * batch / dt, 1),
+           "sample": f"BASELINE config 1: median of 5 timed steps (2 warm-up) of {batch} x 3 s utterances, w2v2-base + "
+                     f"mean+std + CE({num_speakers}), fwd+bwd (CNN frozen) + Adam, f32 torch CPU oracle, {cores} of "
+                     f"{ncpu} host threads ({dt:.2f} s/step)"}
+    if cores != 8 and dt < 6.0:         # bounded: skip the comparison run on a slow host
+        dt8 = run(8, 1, 2)
+        out["at_8_threads"] = {"value": round(batch / dt8, 4), "s_per_step": round(dt8, 2)}
+    return out
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -89,32 +109,82 @@ def main():
     ap.add_argument("--batch", type=int, default=66, help="utterances per GPU (paper batch size)")
     ap.add_argument("--seconds", type=float, default=3.0)
     ap.add_argument("--speakers", type=int, default=5994)
-    ap.add_argument("--dtype", default="bf16", choices=["f16", "bf16", "f32"])
+    ap.add_argument("--dtype", default="f16", choices=["f16", "bf16", "f32"],
+                    help="f16 (default): the reference's fp16-AMP precision, embeddings within 1e-3 of the f32 reference; "
+                         "bf16: 8-bit significand option; f32: exact parity mode")
     ap.add_argument("--pooling", default="mean+std", choices=["mean+std", "attentive", "first+cls"],
                     help="mean+std = the metric's workload; attentive = BASELINE configs[2]")
-    ap.add_argument("--model", default="base", choices=["base", "large"],
+    ap.add_argument("--model", default="base", choices=["base", "large", "ecapa"],
                     help="base = BASELINE configs[1] (the metric's workload); large = configs[3] geometry "
-                         "(24 layers, H=1024; use --seconds 5 --batch 32)")
+                         "(24 layers, H=1024; use --seconds 5 --batch 32); ecapa = configs[4] (ECAPA-TDNN on 300 x 40 "
+                         "filterbank frames, HBM-roofline entry)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-regularisation", action="store_true", help="dropout/LayerDrop/mask off")
+    ap.add_argument("--no-regularisation", action="store_true", help="dropout / LayerDrop / masks off")
     ap.add_argument("--unfreeze-cnn", action="store_true",
                     help="completely_freeze_feature_extractor=False ablation (127.2 GFLOP/utt)")
-    args = ap.parse_args()
+    return ap.parse_args()
 
+
+def _free_port() -> int:
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _child(rank: int, world: int, port: int, argv):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    sys.argv = argv
+    run(parse_args())
+
+
+def main():
+    args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # self-launch: N fresh processes ("spawn": nothing of this process is inherited), started before this one
+        # has made any GPU call; it only waits for them (never an exec of a process that has touched the GPU)
+        import torch.multiprocessing as mp
+        ctx = mp.get_context("spawn")
+        port = _free_port()
+        procs = [ctx.Process(target=_child, args=(r, args.gpus, port, list(sys.argv))) for r in range(args.gpus)]
+        for p in procs:
+            p.start()
+        rc = 0
+        for p in procs:
+            p.join()
+            rc = rc or (p.exitcode or 0)
+        raise SystemExit(rc)
+    run(args)
+
+
+def run(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
+    rccl = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # nccl == RCCL on ROCm
+        # per-rank confirmation that the collective runs on the GPUs over RCCL: every rank contributes rank + 1
+        chk = torch.full((1024,), float(rank + 1), device=dev)
+        dist.all_reduce(chk)
+        torch.cuda.synchronize()
+        ok = bool((chk == world * (world + 1) / 2).all())
+        flags = [None] * world
+        dist.all_gather_object(flags, {"rank": rank, "device": torch.cuda.get_device_name(local_rank), "allreduce_ok": ok})
+        rccl = {"backend": dist.get_backend(), "ranks": flags}
+
+    if args.model == "ecapa":
+        from tools.ecapa_bench import bench_ecapa
+        return bench_ecapa(args, world, rank, dev, dist)
 
     from w2v2_speaker_amd import ops
     from w2v2_speaker_amd.config import W2V2Config, Wav2Vec2RegularisationConfig
@@ -150,11 +220,14 @@ def main():
     for _ in range(args.warmup):
         trainer.train_step(wav, label)
     sync()
-    # dominant kernel = the 256x128 3-stage LDS-DMA GEMM (encoder forward products + all data gradients)
-    ops.Gemm.profile_begin(lambda g: g.kernel_name in ("gemm_bf16_glds3_kernel", "gemm_bf16_glds4_kernel"))
+    skipped0 = int(store.scaler[3]) if store.scaler is not None else 0
+    ring = ("gemm_bf16_glds3_kernel", "gemm_bf16_glds4_kernel")
+    ops.Gemm.profile_begin(lambda g: g.kernel_name in ring)
+    n_skip_layers = 0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss, _ = trainer.train_step(wav, label)
+        n_skip_layers += len(plan._skip)
     sync()
     elapsed = time.perf_counter() - t0
     prof = ops.Gemm.profile_end()
@@ -165,6 +238,10 @@ def main():
     if rank == 0:
         utt = args.batch * world * args.steps
         fl = cfg.flops_per_utt(n_samples, args.speakers)
+        raw = fl["train_full" if args.unfreeze_cnn else "train_frozen_cnn"]
+        # LayerDrop: a skipped layer does no forward and no backward work (3 x its forward FLOPs); the expectation is
+        # p = 0.05 of the encoder, the figure below uses the layers this rank actually skipped in the timed steps
+        done = raw - 3.0 * fl["layer"] * n_skip_layers / args.steps
         out = {
             "metric": (f"utterances/sec (w2v2-{args.model} + {args.pooling} + AAM-softmax training step, "
                        f"{args.seconds:g} s clips)"),
@@ -179,30 +256,39 @@ def main():
                                    + ("configs[1])" if args.model == "base" else "configs[3] geometry)"),
                        "global_batch": args.batch * world, "samples_per_utt": n_samples,
                        "parallelism": f"dp{world}", "regularisation": not args.no_regularisation,
-                       "final_loss": round(float(loss), 4)},
+                       "final_loss": round(float(loss), 4),
+                       "precision": {"f16": "fp16 operands (two-term fp16 weights on the value / output projections), f32 "
+                                            "accumulation, f32 master weights + Adam, dynamic loss scale",
+                                     "bf16": "bf16 operands, f32 accumulation, f32 master weights + Adam",
+                                     "f32": "exact f32"}[args.dtype]},
             "loss_scale": (None if store.scaler is None else
-                           {"scale": float(store.scaler[0]), "skipped_steps": int(store.scaler[3])}),
+                           {"scale": float(store.scaler[0]),
+                            "skipped_steps_in_timed_region": int(store.scaler[3]) - skipped0}),
             "utt_per_sec_per_gpu": round(utt / elapsed / world, 2),
-            "model_tflops_per_gpu": round(fl["train_full" if args.unfreeze_cnn else "train_frozen_cnn"] * utt / elapsed
-                                          / world / 1e12, 2),
+            "model_tflops_per_gpu": round(raw * utt / elapsed / world / 1e12, 2),
+            "model_tflops_per_gpu_layerdrop_adjusted": round(done * utt / elapsed / world / 1e12, 2),
+            "layerdrop_skipped_layers_per_step": round(n_skip_layers / args.steps, 3),
         }
+        if rccl is not None:
+            out["rccl"] = rccl
         if prof["launches"]:
-            # the two persistent LDS-DMA ring GEMM kernels; the roofline entry is the one with the larger total time
             desc = {"gemm_bf16_glds3_kernel": "256x128x64 3-stage LDS-DMA ring MFMA GEMM: conv4-6, projection, QKV, "
                                               "out-proj, FFN2 forward + the N<=2304 data-gradient products",
                     "gemm_bf16_glds4_kernel": "256x256x32 4-stage LDS-DMA ring MFMA GEMM: conv1-3, FFN1 forward, dH"}
             pmc = {}
-            try:     # HBM bytes per launch from the PMC passes (tools/pmc_traffic.py)
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")))["kernels"]
+            try:     # HBM bytes per launch and matrix-pipe busy fraction from the PMC passes (tools/pmc_*.py)
+                pmc = json.load(open(PMC_FILE))["kernels"]
             except Exception:
                 pass
+            tsym = {"f16": "_Float16", "bf16": "unsigned short"}.get(args.dtype, "")
 
             def entry(name, k):
                 ach = k["flops"] / (k["ms"] * 1e-3) / 1e12
-                t = pmc.get(name + "<unsigned short>", {}).get("hbm_bytes_per_launch")
-                return {"bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": t,
-                        "kernel": f"{name}<bf16> ({desc[name]})", "launches": k["launches"],
+                rec = pmc.get(f"{name}<{tsym}, {tsym}>", {})
+                return {"bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": rec.get("hbm_bytes_per_launch"),
+                        "mfma_busy": rec.get("mfma_busy"),
+                        "kernel": f"{name}<{args.dtype}> ({desc[name]})", "launches": k["launches"],
                         "ms_per_step": round(k["ms"] / args.steps, 3),
                         "avg_us": round(1e3 * k["ms"] / k["launches"], 2),
                         "avg_gflop_per_launch": round(k["flops"] / k["launches"] / 1e9, 3),
@@ -211,7 +297,7 @@ def main():
             out["roofline"] = entry(*ranked[0])
             if len(ranked) > 1:
                 out["roofline_second_kernel"] = entry(*ranked[1])
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if world > 1:

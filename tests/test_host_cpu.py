@@ -124,6 +124,72 @@ def test_bucketed_allreduce_two_ranks_gloo():
     assert all(ok and same for _, ok, same in res), res
 
 
+def _check_schedule(L, skip, pair_uppers, members):
+    """Invariants of engine.encoder_backward_schedule against the bucketing of trainer.BucketAllReducer."""
+    from w2v2_speaker_amd.engine import encoder_backward_schedule
+    ev = encoder_backward_schedule(L, skip, pair_uppers)
+    last_write, parked, notified = {}, [], []
+    for i, e in enumerate(ev):
+        if e[0] == "body":
+            assert e[1] not in skip
+            parked.append(e[1])                       # its LayerNorm partials wait for the next fold
+        elif e[0] == "wgrad":
+            for l in e[1]:
+                assert l not in skip and ("w", l) not in last_write, "weight gradients of a layer are written once"
+                last_write[("w", l)] = i
+        elif e[0] == "fold":
+            for l in parked:
+                last_write[("ln", l)] = i
+            parked = []
+        elif e[0] == "notify":
+            notified.append((i, e[1]))
+    assert [l for _, l in notified] == list(range(L - 1, -1, -1)), "every layer bucket once, in backward order"
+    assert not parked
+    when = {l: i for i, l in notified}
+    for l in range(L):
+        if l in skip:
+            assert ("w", l) not in last_write and ("ln", l) not in last_write       # zero gradient, never written
+            continue
+        assert last_write[("w", l)] < when[l] and last_write[("ln", l)] < when[l], (l, skip)
+    # a merged collective fires on its LAST member: every writer of every member must have run by then
+    for fire, mem in members.items():
+        if not fire.startswith("layer"):
+            continue
+        t = when[int(fire[5:])]
+        for m in mem:
+            lm = int(m[5:])
+            assert when[lm] <= t
+            if lm not in skip:
+                assert last_write[("w", lm)] < t and last_write[("ln", lm)] < t, (fire, m, skip)
+
+
+def test_backward_schedule_notifies_every_bucket_after_its_last_writer():
+    """Plan.backward's order of launches and bucket notifications (LayerDrop skip patterns, paired
+    weight-gradient launches, deferred LayerNorm folds) against the reducer's merged buckets -- exhaustively for 6
+    layers, randomly for the 12- and 24-layer models."""
+    import dataclasses
+    import itertools
+    from w2v2_speaker_amd.config import W2V2Config
+    from w2v2_speaker_amd.params import ParamStore
+    from w2v2_speaker_amd.trainer import BucketAllReducer
+    rng = np.random.RandomState(0)
+    for L in (1, 2, 5, 6, 12, 24):
+        cfg = dataclasses.replace(W2V2Config.tiny(), num_hidden_layers=L)
+        st = ParamStore(cfg, "cpu", torch.float32, head="aam", num_speakers=10)
+        pair_uppers = list(range(L - 1, 0, -2))                       # Plan._build_gemms
+        for merge in (1, 2, 3):
+            members = BucketAllReducer(st, bucket_merge=merge).members
+            covered = sorted(m for mem in members.values() for m in mem)
+            assert covered == sorted(n for n, _, _ in st.grad_buckets())            # each raw bucket in one collective
+            if L <= 6:
+                pats = [tuple(i for i in range(L) if (mask >> i) & 1) for mask in range(1 << L)]
+            else:
+                pats = [()] + [tuple(np.nonzero(rng.rand(L) < p)[0].tolist()) for p in (0.05, 0.3, 0.5, 0.9) for _ in range(40)]
+            for skip in pats:
+                _check_schedule(L, set(skip), pair_uppers, members)
+                _check_schedule(L, set(skip), [], members)            # W2V2_NO_WGRAD_PAIRS
+
+
 def test_eval_metrics_and_evaluator_match_reference_golden():
     from w2v2_speaker_amd.eval_metrics import calculate_eer, calculate_mdc
     from w2v2_speaker_amd.evaluation.speaker.cosine_distance import (CosineDistanceEvaluator, EmbeddingSample,

@@ -517,3 +517,46 @@ def test_unfrozen_cnn_every_gradient_vs_reference_golden(dtype):
     before = st.mp("feature_extractor.conv_layers.3.conv.weight").clone()
     st.adam_step(1e-3)
     assert not torch.equal(before, st.mp("feature_extractor.conv_layers.3.conv.weight"))
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16, torch.float32])
+def test_gradient_buckets_are_final_when_notified_under_layerdrop(dtype):
+    """The overlapped all-reduce reads a bucket the moment Plan.backward notifies it: snapshot every bucket (raw and
+    as merged by BucketAllReducer) at its notification, under LayerDrop patterns that exercise the paired /
+    single / held weight-gradient launches and the deferred LayerNorm folds, and compare with the gradient after the
+    whole backward -- bit for bit (the CPU twin of this test checks the schedule: test_host_cpu.py)."""
+    import dataclasses
+    from w2v2_speaker_amd.engine import Plan
+    from w2v2_speaker_amd.trainer import BucketAllReducer
+    cfg, ocfg = _cfgs("tiny")
+    cfg = dataclasses.replace(cfg, num_hidden_layers=6)
+    ocfg = dataclasses.replace(ocfg, num_hidden_layers=6)
+    st, _ = _store(cfg, ocfg, dtype, "aam", 10)
+    if st.scaler is not None:
+        st.scaler[0] = 256.0
+    wav, label = O.synth_batch(4, 4000, 10, seed=3)
+    wav, label = wav.to(DEV), label.to(DEV)
+    plan = Plan(st, 4, 4000, train=True, reg=_no_reg())
+    raw = {n: (s, e) for n, s, e in st.grad_buckets()}
+    merged = BucketAllReducer(st, bucket_merge=2).ranges
+    for skip in [(), (5,), (4,), (3,), (2, 3), (0,), (1, 4), (0, 1, 2, 3, 4, 5), (5, 3, 1), (4, 2, 0)]:
+        st.zero_grad()
+        plan.embed(wav, None, skip)
+        plan.head_forward_backward(label)
+        snaps, order = [], []
+
+        def rec(name):
+            order.append(name)
+            for rng in (raw, merged):
+                if name in rng:
+                    s, e = rng[name]
+                    snaps.append((name, s, e, st.grad[s:e].clone()))
+        plan.backward(on_bucket_ready=rec)
+        torch.cuda.synchronize()
+        assert order == ["head"] + [f"layer{l}" for l in range(5, -1, -1)] + ["prologue"], order
+        for name, s, e, snap in snaps:
+            assert torch.equal(snap, st.grad[s:e]), (skip, name)
+        for l in skip:                                   # LayerDrop: zero gradient
+            s, e = raw[f"layer{l}"]
+            assert float(st.grad[s:e].abs().max()) == 0.0
+        assert torch.isfinite(st.grad).all()

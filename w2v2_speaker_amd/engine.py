@@ -39,6 +39,47 @@ def _tiles(n: int, t: int = 128) -> int:
     return (n + t - 1) // t
 
 
+def encoder_backward_schedule(num_layers: int, skip: Sequence[int], pair_uppers: Sequence[int], grouped: bool = True):
+    """Order of the encoder part of one backward pass, as plain data (no device work): a list of events
+        ("body", l)        data-gradient chain of layer l up to and including the attention backward; its LayerNorm
+                           gamma/beta partials are parked in the fold group; without the grouped weight-gradient
+                           kernel (f32 mode) it also writes the layer's weight gradients
+        ("wgrad", layers)  one grouped weight-gradient launch writing dW / dbias of `layers` (one layer, or a pair
+                           (upper, upper - 1) whose dY buffers live in the two alternating scratch sets)
+        ("dx", l)          G += DQKV Wqkv of layer l
+        ("fold",)          gamma/beta of every LayerNorm parked since the last fold are added to the gradients
+        ("notify", l)      gradient bucket "layer l" is final (LayerDrop-skipped layers: zero gradient, final at once)
+    `pair_uppers` = upper layers of the weight-gradient pairs (Plan.g_wgrad_pair); `skip` = this step's LayerDrop
+    decisions.  Plan.backward executes exactly this list; tests/test_host_cpu.py checks its invariants (every bucket
+    is notified once, in descending order, after its last writer) for every skip pattern."""
+    ev, held, Ltop, skip, pair_uppers = [], None, num_layers - 1, set(skip), set(pair_uppers)
+    for l in reversed(range(num_layers)):
+        upper = grouped and (Ltop - l) % 2 == 0 and l > 0 and l in pair_uppers      # l pairs with l - 1
+        if l in skip:
+            if held is not None:          # partner skipped by LayerDrop: the held layer goes alone
+                ev += [("wgrad", (held,)), ("fold",), ("notify", held)]
+                held = None
+            ev.append(("notify", l))
+            continue
+        ev.append(("body", l))
+        if grouped:
+            if held is not None:
+                ev.append(("wgrad", (held, l)))
+            elif not upper:
+                ev.append(("wgrad", (l,)))
+        ev.append(("dx", l))
+        if grouped and held is None and upper:
+            held = l                      # wait for layer l - 1 (its dY's live in the other buffer set)
+            continue
+        ev.append(("fold",))
+        if held is not None:
+            ev.append(("notify", held))
+            held = None
+        ev.append(("notify", l))
+    assert held is None
+    return ev
+
+
 @dataclass
 class LayerBufs:
     qkv: torch.Tensor
@@ -72,6 +113,9 @@ class Plan:
         self.Bc = 2 * batch if paired else batch
         assert not (paired and insert_cls_token)
         self.reg = reg if reg is not None else Wav2Vec2RegularisationConfig()
+        if train and self.reg.activation_dropout > 0:
+            raise NotImplementedError("activation_dropout > 0 has no backward here (the reference's default is 0.0, "
+                                      "config/network/wav2vec2_fc.yaml)")
         self.pooling, self.pool_mode = pooling, POOL_MODES.get(pooling, -1)
         assert pooling == "attentive" or pooling in POOL_MODES, pooling
         self.cls, self.cls_c = insert_cls_token, cls_token_constant
@@ -529,80 +573,23 @@ class Plan:
             else:
                 ops.pool_bwd(self.out, self.emb, demb, self.G.view(B, T, H), self.pool_mode)
         notify("head")
-        heads, d = cfg.num_attention_heads, cfg.head_dim
-        pa, ph = reg.attention_dropout, reg.hidden_dropout
-        Ltop = cfg.num_hidden_layers - 1
-        held = None            # upper layer of a pair whose weight-gradient launch waits for its partner
         if getattr(self, "_lnfold", None) is None:
             self._lnfold = ops.LnFoldGroup(H, self.dev)
         lnfold = self._lnfold if not os.environ.get("W2V2_NO_LN_FOLD") else None
-        for l in reversed(range(cfg.num_hidden_layers)):
-            upper = (Ltop - l) % 2 == 0 and l > 0 and l in self.g_wgrad_pair     # l pairs with l-1
-            if l in self._skip:
-                if held is not None:                  # partner skipped by LayerDrop: the held layer goes alone
-                    self.g_layer[held]["wgrad"]()
-                    if lnfold is not None:
-                        lnfold.fold()
-                    notify(f"layer{held}")
-                    held = None
-                notify(f"layer{l}")
-                continue
-            lb, gl = self.lb[l], self.g_layer[l]
-            gs = self._gsets[l % 2]
-            pre = f"encoder.layers.{l}."
-            grouped = self.grouped
-            # x2 = LN2(x1 + drop(f)):  G <- ds2 (residual path), Gd <- df = ds2 * dropmask
-            ops.layernorm_bwd(self.G, lb.f, lb.mean2, lb.rstd2, mp(pre + "final_layer_norm.weight"), self.G, gs["Gd"],
-                              mg(pre + "final_layer_norm.weight"), mg(pre + "final_layer_norm.bias"), ph,
-                              self._sd("ffn", l, step), defer_to=lnfold)
-            if not grouped:
-                gl["dW2"]()
-                ops.colsum(gs["Gd"], mg(pre + "feed_forward.output_dense.bias"), M, H)
-            gl["dh"]()                                          # DH = (df @ W2) * gelu'(hpre)
-            if reg.activation_dropout > 0:
-                raise NotImplementedError("activation_dropout > 0 (reference default is 0.0)")
-            if not grouped:
-                gl["dW1"]()
-                ops.colsum(gs["DH"], mg(pre + "feed_forward.intermediate_dense.bias"), M, cfg.intermediate_size)
-            gl["dx1"]()                                         # G = DH @ W1 + G
-            # x1 = LN1(x + drop(a)):  G <- ds1, Gd1 <- da
-            ops.layernorm_bwd(self.G, lb.a, lb.mean1, lb.rstd1, mp(pre + "layer_norm.weight"), self.G, gs["Gd1"],
-                              mg(pre + "layer_norm.weight"), mg(pre + "layer_norm.bias"), ph,
-                              self._sd("post_attn", l, step), defer_to=lnfold)
-            if not grouped:
-                gl["dWo"]()
-                ops.colsum(gs["Gd1"], mg(pre + "attention.out_proj.bias"), M, H)
-            gl["dctx"]()
-            if self.fused:
-                ops.attention_bwd(lb.qkv, lb.ctx, self.DC, lb.lse, gs["DQKV"], self.delta, B, T, heads, d, d ** -0.5,
-                                  pa, self._sd("attn", l, step))
+        for ev in encoder_backward_schedule(cfg.num_hidden_layers, self._skip, self.g_wgrad_pair, self.grouped):
+            kind = ev[0]
+            if kind == "body":
+                self._layer_backward_body(ev[1], lnfold)
+            elif kind == "wgrad":
+                layers = ev[1]
+                (self.g_wgrad_pair[layers[0]] if len(layers) == 2 else self.g_layer[layers[0]]["wgrad"])()
+            elif kind == "dx":
+                self.g_layer[ev[1]]["dx"]()                     # G = DQKV @ Wqkv + G
+            elif kind == "fold":
+                if lnfold is not None:
+                    lnfold.fold()                               # gamma / beta of the bucket's LayerNorms: one launch
             else:
-                gl["dP"]()
-                ops.softmax_bwd(self.S, lb.p, self.dS, B * heads * T, T, self.Tl, pa, self._sd("attn", l, step))
-                gl["dq"]()
-                gl["dk"]()
-                gl["dv"]()
-            defer = False
-            if grouped:         # dW2,db2 | dW1,db1 | dWo,dbo | dWqkv,dbqkv: one atomic-free launch per layer PAIR
-                if held is not None:
-                    self.g_wgrad_pair[held]()
-                elif upper:
-                    defer = True                      # wait for layer l-1 (its dY's live in the other buffer set)
-                else:
-                    gl["wgrad"]()
-            else:
-                gl["dWqkv"]()
-                ops.colsum(gs["DQKV"], st.qkv(l, "g", "bias"), M, 3 * H)
-            gl["dx"]()                                          # G = DQKV @ Wqkv + G
-            if defer:
-                held = l
-                continue
-            if lnfold is not None:
-                lnfold.fold()                         # gamma / beta of the bucket's LayerNorms: one launch
-            if held is not None:
-                notify(f"layer{held}")
-                held = None
-            notify(f"layer{l}")
+                notify(f"layer{ev[1]}")
         # encoder prologue: x0 = drop(LN(hx + pos)), pos = GELU(posconv(hx) + b)
         if ph > 0:
             ops.dropout_(self.G, ph, self._sd("prologue", 0, step))
@@ -646,6 +633,51 @@ class Plan:
         if not st.freeze_cnn:
             self._backward_cnn()
             notify("cnn")
+
+    def _layer_backward_body(self, l: int, lnfold) -> None:
+        """("body", l) of encoder_backward_schedule: the data-gradient chain of one transformer block."""
+        cfg, st, reg = self.cfg, self.store, self.reg
+        B, T, M, H = self.B, self.T, self.M, cfg.hidden_size
+        mp, mg = st.mp, st.mg
+        step = self._step
+        heads, d = cfg.num_attention_heads, cfg.head_dim
+        pa, ph = reg.attention_dropout, reg.hidden_dropout
+        lb, gl = self.lb[l], self.g_layer[l]
+        gs = self._gsets[l % 2]
+        pre = f"encoder.layers.{l}."
+        grouped = self.grouped
+        # x2 = LN2(x1 + drop(f)):  G <- ds2 (residual path), Gd <- df = ds2 * dropmask
+        ops.layernorm_bwd(self.G, lb.f, lb.mean2, lb.rstd2, mp(pre + "final_layer_norm.weight"), self.G, gs["Gd"],
+                          mg(pre + "final_layer_norm.weight"), mg(pre + "final_layer_norm.bias"), ph,
+                          self._sd("ffn", l, step), defer_to=lnfold)
+        if not grouped:
+            gl["dW2"]()
+            ops.colsum(gs["Gd"], mg(pre + "feed_forward.output_dense.bias"), M, H)
+        gl["dh"]()                                          # DH = (df @ W2) * gelu'(hpre)
+        if not grouped:
+            gl["dW1"]()
+            ops.colsum(gs["DH"], mg(pre + "feed_forward.intermediate_dense.bias"), M, cfg.intermediate_size)
+        gl["dx1"]()                                         # G = DH @ W1 + G
+        # x1 = LN1(x + drop(a)):  G <- ds1, Gd1 <- da
+        ops.layernorm_bwd(self.G, lb.a, lb.mean1, lb.rstd1, mp(pre + "layer_norm.weight"), self.G, gs["Gd1"],
+                          mg(pre + "layer_norm.weight"), mg(pre + "layer_norm.bias"), ph,
+                          self._sd("post_attn", l, step), defer_to=lnfold)
+        if not grouped:
+            gl["dWo"]()
+            ops.colsum(gs["Gd1"], mg(pre + "attention.out_proj.bias"), M, H)
+        gl["dctx"]()
+        if self.fused:
+            ops.attention_bwd(lb.qkv, lb.ctx, self.DC, lb.lse, gs["DQKV"], self.delta, B, T, heads, d, d ** -0.5,
+                              pa, self._sd("attn", l, step))
+        else:
+            gl["dP"]()
+            ops.softmax_bwd(self.S, lb.p, self.dS, B * heads * T, T, self.Tl, pa, self._sd("attn", l, step))
+            gl["dq"]()
+            gl["dk"]()
+            gl["dv"]()
+        if not grouped:
+            gl["dWqkv"]()
+            ops.colsum(gs["DQKV"], st.qkv(l, "g", "bias"), M, 3 * H)
 
     def _backward_cnn(self) -> None:
         """Backward of the 7-layer conv feature extractor (HF:382-419) -- the reference's

@@ -36,6 +36,7 @@ class BucketAllReducer:
         # merge neighbouring layer buckets so each collective carries >= ~2 layers (xGMI rings are
         # per-link bound: fewer, larger messages; SURVEY 5 "Distributed comm backend")
         self.ranges = {}
+        self.members = {}          # firing bucket name -> raw buckets its collective covers (final when IT is final)
         merged: List[Tuple[str, int, int]] = []
         i = 0
         while i < len(raw):
@@ -46,6 +47,7 @@ class BucketAllReducer:
                     j += 1
                 e = raw[j][2]
             merged.append((raw[j][0], s, e))      # fires when the LAST member is final
+            self.members[raw[j][0]] = [raw[k][0] for k in range(i, j + 1)]
             i = j + 1
         for n, s, e in merged:
             self.ranges[n] = (s, e)
