@@ -247,7 +247,9 @@ int w2v2_attention_bwd(const void* qkv, const void* ctx, const void* dctx, const
  * ref: src/layers/pooling.py:24-44,74-80,118-136.  x [B,T,H] act dtype -> out f32.
  * mode 0: mean+std  -> [B,2H] = cat(std_unbiased, mean)  (std FIRST, quirk Q1)
  * mode 1: mean      -> [B,H]       mode 2: max -> [B,H]
- * mode 3: first     -> [B,H]       mode 4: last / "middle" (quirk Q2) -> [B,H] */
+ * mode 3: first     -> [B,H]       mode 4: last / "middle" (quirk Q2) -> [B,H]
+ * mode 5: quantile  -> [B,5H] = the 0 / .25 / .5 / .75 / 1 quantiles over time, quantile-major
+ *         (ref: src/layers/pooling.py:51-67, torch.quantile with linear interpolation) */
 int w2v2_pool_fwd(const void* x, float* out, int B, int T, int H, int mode, int dtype, void* stream);
 /* dx [B,T,H] act dtype from dout f32 and the forward output (std/mean reused; max needs x). */
 int w2v2_pool_bwd(const void* x, const float* out, const float* dout, void* dx, int B, int T, int H,
@@ -340,12 +342,14 @@ int w2v2_row_invnorm(const void* x, int64_t ld, float* inv, int rows, int cols, 
  *   dcos_x[b][c] = g * inv_x[b]   (A operand of the weight-gradient GEMM;    inv_x NULL -> g)
  *   rowdot[b] = sum_c g*cos,  coldot[c] += sum_b g*cos (caller zeroes coldot); any may be NULL.
  * loss_scale (device pointer, may be NULL = 1): g is multiplied by *loss_scale (w2v2_grad_scaler_*); the loss
- * rows and the softmax are never scaled.  Labels outside [0, C) give loss = NaN for that row and zero gradients. */
+ * rows and the softmax are never scaled.  Labels outside [0, C) give loss = NaN for that row and zero gradients.
+ * correct_rows [B] (may be NULL): 1 if argmax_c softmax[b][c] == label[b] else 0 -- the reference's train_acc
+ * (ref: src/lightning_modules/speaker/speaker_recognition_module.py:296-307). */
 int w2v2_aam_softmax_fwd_bwd(const float* cos, const int64_t* label, float* softmax,
                              float* loss_rows, void* dcos_w, void* dcos_x, const float* inv_x,
                              const float* inv_w, float* rowdot, float* coldot, int B, int C,
-                             int64_t ldc, float margin, float scale, const float* loss_scale, int dtype,
-                             void* stream);
+                             int64_t ldc, float margin, float scale, const float* loss_scale,
+                             float* correct_rows, int dtype, void* stream);
 /* F.normalize backward: dx = inv[r] * (g[r] - x[r] * inv[r] * dot[r]);  g, dx f32 (dx written or
  * added), x f32 or act dtype. */
 int w2v2_normalize_bwd(const float* g, const void* x, int64_t ldx, const float* inv,

@@ -96,6 +96,36 @@ def test_ecapa_training_step_vs_oracle(dtype):
     assert not bad, bad[:8]
 
 
+def test_ecapa_batchnorm_running_statistics_are_shared_saved_and_used_by_eval():
+    """BatchNorm running statistics belong to the store, not to a plan: the evaluation plan must
+    normalise with what the training plan accumulated, and checkpoints must carry them under the speechbrain names."""
+    from w2v2_speaker_amd.ecapa import FE, EcapaPlan, EcapaStore
+    cfg, ocfg, st, sd, feat, label = _setup(torch.float32, B=4, T=50, classes=4)
+    tr = EcapaPlan(st, 4, 50, train=True)
+    ev = EcapaPlan(st, 4, 50, train=False)
+    for a, b in zip(tr._tdnns(), ev._tdnns()):
+        assert a.running.data_ptr() == b.running.data_ptr() == st.running(a.pre + "norm.norm.weight").data_ptr()
+    assert tr.bn_running.data_ptr() == ev.bn_running.data_ptr()
+    e_before = ev.embed(feat.to(DEV)).clone()
+    tr.embed(feat.to(DEV))                                   # one training forward: momentum 0.1 update
+    torch.cuda.synchronize()
+    t0 = tr._tdnns()[0]
+    act = torch.relu(t0.a.float()).double().cpu()            # BatchNorm input of block 0 (ReLU of the saved conv output)
+    C = t0.cout
+    assert rel_l2(t0.running[:C].cpu(), 0.1 * act.mean(0)) < 1e-4
+    assert rel_l2(t0.running[C:].cpu(), 0.9 + 0.1 * act.var(0, unbiased=True)) < 1e-4
+    e_after = ev.embed(feat.to(DEV)).clone()
+    torch.cuda.synchronize()
+    assert rel_l2(e_after.cpu(), e_before.cpu()) > 1e-3      # the evaluation plan sees the updated statistics
+    full = st.state_dict()
+    key = FE + "blocks.0.norm.norm.running_mean"
+    assert key in full and FE + "asp_bn.norm.running_var" in full and rel_l2(full[key], t0.running[:C].cpu()) == 0.0
+    st2 = EcapaStore(cfg, DEV, torch.float32, num_speakers=4)
+    st2.load_state_dict(full)
+    ev2 = EcapaPlan(st2, 4, 50, train=False)
+    assert rel_l2(ev2.embed(feat.to(DEV)).cpu(), e_after.cpu()) < 1e-6
+
+
 def test_ecapa_trainer_reduces_loss():
     from w2v2_speaker_amd.ecapa import EcapaPlan, EcapaTrainer
     from w2v2_speaker_amd.optim.schedule import Constant

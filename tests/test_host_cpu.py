@@ -247,18 +247,23 @@ def test_pl_format_checkpoint_round_trip_and_reheading(tmp_path):
     C.W2V2Config.from_huggingface_id = staticmethod(lambda _id: tiny)       # keep the CPU test small
     try:
         kw = dict(device="cpu", act_dtype=torch.float32)
-        a = Wav2vec2FCModule(Wav2vec2FCModuleConfig(), num_speakers=7, init_seed=1, **kw)
+        a = Wav2vec2FCModule.from_config(Wav2vec2FCModuleConfig(reset_weights=True), num_speakers=7, init_seed=1, **kw)
         path = str(tmp_path / "last.ckpt")
-        a.steps = 123
+        a.steps = a.schedule_step = 123
         a.save_checkpoint(path)
         ck = torch.load(path, weights_only=False)
         assert {"state_dict", "global_step", "pytorch-lightning_version"} <= set(ck)
         assert "loss_fn.fc_weights" in ck["state_dict"]
         assert "wav2vec.model.encoder.layers.0.attention.q_proj.weight" in ck["state_dict"]
-        b = Wav2vec2FCModule.load_from_checkpoint(path, cfg=Wav2vec2FCModuleConfig(), num_speakers=7, init_seed=2, **kw)
-        assert b.steps == 123 and all(torch.equal(v, b.state_dict()[k]) for k, v in a.state_dict().items())
+        from w2v2_speaker_amd.optim.loss import AngularAdditiveMarginSoftMaxLoss
+        ctor = lambda: AngularAdditiveMarginSoftMaxLoss(2, 2, margin=0.2, scale=30, device="cpu", act_dtype=torch.float32)
+        ref_kw = dict(hyperparameters_to_save=None, num_speakers=7, loss_fn_constructor=ctor, validation_pairs=[],
+                      test_pairs=[], evaluator=None)          # what ref: src/main.py:256-283 passes
+        b = Wav2vec2FCModule.load_from_checkpoint(path, cfg=Wav2vec2FCModuleConfig(), init_seed=2, **ref_kw, **kw)
+        assert b.steps == 123 and b.schedule_step == 123
+        assert all(torch.equal(v, b.state_dict()[k]) for k, v in a.state_dict().items())
         c = Wav2vec2FCModule.load_from_checkpoint(path, cfg=Wav2vec2FCModuleConfig(explicit_num_speakers=11),
-                                                  num_speakers=7, init_seed=3, **kw)
+                                                  init_seed=3, **ref_kw, **kw)
         sc, sa = c.state_dict(), a.state_dict()
         assert sc["loss_fn.fc_weights"].shape[0] == 11
         assert all(torch.equal(sa[k], sc[k]) for k in sa if k != "loss_fn.fc_weights")

@@ -127,7 +127,7 @@ def test_tiny_ce_head_and_other_pools_vs_golden():
     assert rel_l2(st.g("fc_list.0.0.weight").cpu(), W.grad) < 1e-3
     assert rel_l2(st.g("fc_list.0.0.bias").cpu(), b.grad) < 1e-3
     assert rel_l2(plan.demb.cpu(), emb.grad) < 1e-3
-    for pool in ("mean+std", "mean", "max", "first", "middle", "last"):
+    for pool in ("mean+std", "mean", "max", "first", "middle", "last", "quantile"):
         st2, _ = _store(cfg, ocfg, torch.float32, None, 10)
         p = Plan(st2, 2, wav.shape[-1], train=False, pooling=pool)
         e = p.embed(wav)

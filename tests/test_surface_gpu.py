@@ -66,6 +66,57 @@ def test_pooling_and_ce_modules_autograd():
     assert rel_l2(sm.cpu(), torch.softmax(logits.double(), 1)) < 1e-5
 
 
+@pytest.mark.parametrize("dim_to_reduce", [1, 2])
+def test_attentive_stat_pool_module_vs_restated_definition(dim_to_reduce):
+    """ref: src/layers/pooling.py:87-106 ``AttentiveStatPool1D(embedding_size, dim_to_reduce)`` as a class: forward,
+    input gradient and all six parameter gradients against autograd over oracle.attentive_stat_pool (speechbrain's
+    published definition restated -- speechbrain itself is not installable here, so this is a self-consistency check,
+    not reference parity), then eval mode on the running statistics the training call updated."""
+    from w2v2_speaker_amd.layers.pooling import AttentiveStatPool1D
+    B, Tn, C = 3, 37, 64
+    mod = AttentiveStatPool1D(C, dim_to_reduce, device=DEV, act_dtype=torch.float32, init_seed=3)
+    views = mod.named_views()
+    g = torch.Generator().manual_seed(5)
+    with torch.no_grad():
+        for n, v in views.items():
+            if "running" not in n:
+                v.copy_((torch.randn(v.shape, generator=g) * (0.3 if n.endswith("weight") else 0.1)
+                         + (1.0 if n.endswith("norm.norm.weight") else 0.0)).to(DEV))
+    od = {"tdnn.conv.weight": views["pooling_layer.tdnn.conv.conv.weight"], "tdnn.conv.bias": views["pooling_layer.tdnn.conv.conv.bias"],
+          "tdnn.norm.weight": views["pooling_layer.tdnn.norm.norm.weight"], "tdnn.norm.bias": views["pooling_layer.tdnn.norm.norm.bias"],
+          "conv.weight": views["pooling_layer.conv.conv.weight"], "conv.bias": views["pooling_layer.conv.conv.bias"]}
+    od = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in od.items()}
+    x = torch.randn(B, Tn, C, generator=g)
+    xr = x.clone().requires_grad_(True)
+    ref = O.attentive_stat_pool(xr, od)
+    up = torch.randn(B, 2 * C, generator=g)
+    (ref * up).sum().backward()
+    xin = (x if dim_to_reduce == 1 else x.transpose(1, 2).contiguous()).to(DEV).requires_grad_(True)
+    mod.train()
+    out = mod(xin)
+    (out * up.to(DEV)).sum().backward()
+    torch.cuda.synchronize()
+    assert out.shape == (B, 2 * C) and rel_l2(out.detach().cpu(), ref.detach()) < 2e-5
+    gx = xin.grad.cpu() if dim_to_reduce == 1 else xin.grad.cpu().transpose(1, 2)
+    assert rel_l2(gx, xr.grad) < 2e-3
+    st = mod._store
+    flat_grad = mod.flat.grad
+    for sb, oname in (("tdnn.conv.conv.weight", "tdnn.conv.weight"), ("tdnn.conv.conv.bias", "tdnn.conv.bias"),
+                      ("tdnn.norm.norm.weight", "tdnn.norm.weight"), ("tdnn.norm.norm.bias", "tdnn.norm.bias"),
+                      ("conv.conv.weight", "conv.weight"), ("conv.conv.bias", "conv.bias")):
+        n = "stat_pooling.pooling_layer." + sb
+        o, shp = st.offsets[n], st.shapes[n]
+        got = flat_grad[o:o + od[oname].numel()].view(*shp).cpu()
+        ref_g = od[oname].grad.view(*shp)
+        # (conv.conv.bias: the softmax over time is invariant to a per-channel shift -> its gradient is pure round-off)
+        assert float((got - ref_g).norm()) < 2e-3 * float(ref_g.norm()) + 1e-6, sb
+    assert float(views["pooling_layer.tdnn.norm.norm.running_mean"].abs().sum()) > 0         # updated by train()
+    mod.eval()
+    with torch.no_grad():
+        e = mod(xin.detach())
+    assert e.shape == (B, 2 * C) and torch.isfinite(e).all()
+
+
 def test_wrapper_module_forward_backward_matches_oracle():
     from w2v2_speaker_amd.config import Wav2Vec2RegularisationConfig
     from w2v2_speaker_amd.models.wav2vec2 import Wav2Vec2WrapperModule
@@ -116,8 +167,8 @@ def test_fc_module_training_and_eer_parity_on_synthetic_trials():
     orig = W2V2Config.from_huggingface_id
     W2V2Config.from_huggingface_id = staticmethod(lambda _id: cfg)
     try:
-        mod = Wav2vec2FCModule(Wav2vec2FCModuleConfig(), num_speakers=6, device=DEV, act_dtype=torch.float32,
-                               max_lr=1e-3, max_steps=50)
+        mod = Wav2vec2FCModule.from_config(Wav2vec2FCModuleConfig(reset_weights=True), num_speakers=6, device=DEV,
+                                           act_dtype=torch.float32, max_lr=1e-3, max_steps=50)
     finally:
         W2V2Config.from_huggingface_id = orig
     sd = O.make_state_dict(ocfg, 20211)
@@ -149,8 +200,12 @@ def test_fc_module_training_and_eer_parity_on_synthetic_trials():
     # a few optimisation steps through the module's own training_step reduce the loss
     mod.train()
     batch = SpeakerClassificationDataBatch(24, keys, torch.stack(wavs)[:, None, :], torch.tensor(spk))
-    losses = [float(mod.training_step(batch.to(DEV), i)["loss"]) for i in range(12)]
+    steps = [mod.training_step(batch.to(DEV), i) for i in range(12)]
+    losses = [float(o["loss"]) for o in steps]
     assert np.isfinite(losses).all() and losses[-1] < losses[0], losses
+    # train_acc (ref: speaker_recognition_module.py:296-307) = accuracy of the arg-max prediction
+    last = steps[-1]
+    assert abs(float(last["train_acc"]) - float((last["prediction"].argmax(1).cpu() == torch.tensor(spk)).float().mean())) < 1e-6
     emb, pred = mod(batch.network_input[:3])
     assert emb.shape == (3, 2 * cfg.hidden_size) and pred.shape == emb.shape
 
@@ -165,8 +220,9 @@ def test_initially_frozen_network_trains_head_only_then_unfreezes():
     orig = W2V2Config.from_huggingface_id
     W2V2Config.from_huggingface_id = staticmethod(lambda _id: cfg)
     try:
-        mod = Wav2vec2FCModule(Wav2vec2FCModuleConfig(wav2vec_initially_frozen=True, num_frozen_steps=2),
-                               num_speakers=5, device=DEV, act_dtype=torch.float32, max_lr=1e-2, max_steps=20)
+        mod = Wav2vec2FCModule.from_config(Wav2vec2FCModuleConfig(wav2vec_initially_frozen=True, num_frozen_steps=2,
+                                                                  reset_weights=True),
+                                           num_speakers=5, device=DEV, act_dtype=torch.float32, max_lr=1e-2, max_steps=20)
     finally:
         W2V2Config.from_huggingface_id = orig
     wav, label = O.synth_batch(4, 4000, 5, seed=9)
@@ -187,6 +243,88 @@ def test_initially_frozen_network_trains_head_only_then_unfreezes():
     torch.cuda.synchronize()
     assert not torch.equal(st.flat[h:st.n_train], mid[h:st.n_train])
     assert torch.equal(st.flat[st.n_train:], before[st.n_train:])   # CNN never updated
+
+
+def test_reference_construction_sequence_hidden_fc_layers_and_handles():
+    """the construction sequence of ref: src/main.py:223-285 (construct_speaker_recognition_module:
+    kwargs hyperparameters_to_save / cfg / num_speakers / loss_fn_constructor / validation_pairs / test_pairs /
+    evaluator, where loss_fn_constructor = lambda: instantiate(cfg.optim.loss), main.py:296-300) against the mirror,
+    with hidden FC layers (ref: wav2vec2_fc.py:185-228) and embedding_layer_idx (ref: :277-288, :363-412), the
+    wav2vec.model.* handles the reference touches (:347,361) and strict / non-strict state-dict loading.  The
+    FC + CE arithmetic (forward, loss, every head gradient) is checked against torch autograd on the same weights."""
+    from w2v2_speaker_amd.config import W2V2Config
+    from w2v2_speaker_amd.evaluation.speaker.cosine_distance import CosineDistanceEvaluator
+    from w2v2_speaker_amd.lightning_modules.speaker.wav2vec2_fc import (SpeakerClassificationDataBatch,
+                                                                         Wav2vec2FCModule, Wav2vec2FCModuleConfig)
+    from w2v2_speaker_amd.optim.loss import AngularAdditiveMarginSoftMaxLoss, CrossEntropyLoss
+    cfg_m, ocfg = W2V2Config.tiny(), O.OracleConfig.tiny()
+    H = cfg_m.hidden_size
+    orig = W2V2Config.from_huggingface_id
+    W2V2Config.from_huggingface_id = staticmethod(lambda _id: cfg_m)
+    try:
+        network_cfg = Wav2vec2FCModuleConfig(hidden_fc_layers_out=[48, 24], embedding_layer_idx=0, reset_weights=True,
+                                             attention_dropout=0.0, feat_proj_dropout=0.0, hidden_dropout=0.0,
+                                             layerdrop=0.0, mask_time_prob=0.0)
+        kwargs = {"hyperparameters_to_save": {"optim": {"loss": "cross_entropy"}}, "cfg": network_cfg, "num_speakers": 9,
+                  "loss_fn_constructor": lambda: CrossEntropyLoss(), "validation_pairs": [], "test_pairs": [],
+                  "evaluator": CosineDistanceEvaluator(False, False, 0)}
+        net = Wav2vec2FCModule(**kwargs, device=DEV, act_dtype=torch.float32, max_lr=1e-3, max_steps=10)
+        aam = Wav2vec2FCModule(**{**kwargs, "cfg": Wav2vec2FCModuleConfig(reset_weights=True),
+                                  "loss_fn_constructor": lambda: AngularAdditiveMarginSoftMaxLoss(
+                                      2, 2, margin=0.3, scale=15, device=DEV, act_dtype=torch.float32)},
+                               device=DEV, act_dtype=torch.float32)
+    finally:
+        W2V2Config.from_huggingface_id = orig
+    assert (aam.loss, aam.margin, aam.scale) == ("aam", 0.3, 15.0) and aam.embedding_size == 2 * H
+    assert net.embedding_size == 48 and net.stat_pool_dimension == 2 * H
+    assert {"fc_list.0.0.weight", "fc_list.1.0.bias", "fc_list.2.0.weight"} <= set(net.state_dict())
+    assert tuple(net.store.shapes["fc_list.2.0.weight"]) == (9, 24)
+    # handles of ref: wav2vec2_fc.py:339-361
+    net.on_train_start()
+    net.wav2vec.model.feature_extractor.requires_grad_(False)            # the default freeze: accepted
+    with pytest.raises(RuntimeError):
+        net.wav2vec.model.feature_extractor.requires_grad_(True)         # no CNN gradient buffers in this arena
+    assert net.wav2vec.num_features == H and len(list(net.wav2vec.model.encoder.parameters())) > 0
+    # strict load: missing / unexpected keys raise, non-strict skips them
+    sd = net.state_dict()
+    with pytest.raises(KeyError):
+        net.load_state_dict({k: v for k, v in sd.items() if k != "fc_list.1.0.bias"}, strict=True)
+    with pytest.raises(KeyError):
+        net.load_state_dict({**sd, "not.a.key": torch.zeros(1)}, strict=True)
+    net.load_state_dict({**sd, "not.a.key": torch.zeros(1)}, strict=False)
+    # arithmetic: pooled embedding (oracle) -> Linear/ReLU x2 -> Linear -> CE, against autograd
+    osd = {k[len("wav2vec.model."):]: v for k, v in sd.items() if k.startswith("wav2vec.model.")}
+    wav, label = O.synth_batch(5, 4000, 9, seed=13)
+    pooled = O.speaker_embedding(wav, osd, ocfg, "mean+std").detach()
+    Ws = [sd[f"fc_list.{i}.0.weight"].clone().requires_grad_(True) for i in range(3)]
+    bs = [sd[f"fc_list.{i}.0.bias"].clone().requires_grad_(True) for i in range(3)]
+    pr = pooled.clone().requires_grad_(True)
+    h0 = torch.relu(pr @ Ws[0].t() + bs[0])
+    h1 = torch.relu(h0 @ Ws[1].t() + bs[1])
+    logits = h1 @ Ws[2].t() + bs[2]
+    loss_ref = torch.nn.functional.cross_entropy(logits, label)
+    loss_ref.backward()
+    net.eval()
+    emb, pred = net(wav.to(DEV))
+    assert emb.shape == (5, 48) and rel_l2(emb.cpu(), h0.detach()) < 1e-4          # embedding_layer_idx = 0
+    assert rel_l2(pred.cpu(), logits.detach()) < 1e-4
+    net.train()
+    st = net.store
+    before = {n: st.p(n).clone() for n in st.shapes}
+    plan = net._plan(5, 4000, True)
+    st.zero_grad()
+    plan.embed(wav.to(DEV), None, ())
+    loss, sm = plan.head_forward_backward(label.to(DEV))
+    plan.backward()
+    torch.cuda.synchronize()
+    assert abs(float(loss) - float(loss_ref)) < 1e-4 and rel_l2(sm.cpu(), torch.softmax(logits.detach(), 1)) < 1e-4
+    for i in range(3):
+        assert rel_l2(st.g(f"fc_list.{i}.0.weight").cpu(), Ws[i].grad) < 1e-3, i
+        assert rel_l2(st.g(f"fc_list.{i}.0.bias").cpu(), bs[i].grad) < 1e-3, i
+    assert rel_l2(plan.demb.cpu(), pr.grad) < 1e-3                                 # gradient reaching the pooling
+    out = net.training_step(SpeakerClassificationDataBatch(5, list("abcde"), wav, label).to(DEV), 0)
+    assert np.isfinite(float(out["loss"])) and 0.0 <= float(out["train_acc"]) <= 1.0
+    assert any(not torch.equal(st.p(n), before[n]) for n in ("fc_list.0.0.weight", "fc_list.2.0.bias"))
 
 
 def test_ensemble_of_layers_embeddings_vs_oracle():

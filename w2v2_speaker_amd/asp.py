@@ -96,6 +96,8 @@ class AttentivePool:
         self.g_a()
         if self.train:      # batch statistics (and running-stat update) like BatchNorm1d.train()
             ops.asp_bn_stats(self.a_pre, self.work, self.mean_rstd, self.running, B * T, A, BN_EPS, BN_MOMENTUM)
+            if hasattr(st, "asp_batches_tracked"):
+                st.asp_batches_tracked += 1
         else:
             ops.asp_bn_eval_stats(self.running, self.mean_rstd, A, BN_EPS)
         ops.asp_bn_tanh(self.a_pre, self.mean_rstd, p(self.prefix + "tdnn.norm.norm.weight"),

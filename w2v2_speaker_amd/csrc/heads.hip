@@ -46,8 +46,10 @@ __global__ __launch_bounds__(256) void aam_row_kernel(const float* __restrict__ 
                                                       const float* __restrict__ inv_x,
                                                       const float* __restrict__ inv_w, float* __restrict__ rowdot,
                                                       float* __restrict__ coldot, int B, int C, int64_t ldc,
-                                                      float margin, float scale, const float* __restrict__ loss_scale) {
+                                                      float margin, float scale, const float* __restrict__ loss_scale,
+                                                      float* __restrict__ correct_rows) {
   __shared__ float sh[4];
+  __shared__ int shi[4];
   const int b = blockIdx.x;
   const int64_t yl = label[b];
   // a label outside [0, C) (data module with more speakers than the head): NaN loss for the row, no gradient, no
@@ -77,8 +79,25 @@ __global__ __launch_bounds__(256) void aam_row_kernel(const float* __restrict__ 
     }
   }
   float mx = -INFINITY;
-  for (int c = threadIdx.x; c < C; c += 256) mx = fmaxf(mx, c == y ? zy : cr[c] * sc);
+  int amax = 0;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const float z = c == y ? zy : cr[c] * sc;
+    if (z > mx) { mx = z; amax = c; }                  // first maximum of this thread's (ascending) columns
+  }
+  const float mine = mx;
   mx = block_reduce(mx, sh, true);
+  if (correct_rows != nullptr) {
+    // training accuracy (ref: speaker_recognition_module.py:296-307 torchmetrics.Accuracy on the prediction):
+    // arg-max of the softmax = smallest column holding the row maximum
+    int cand = (mine == mx) ? amax : 0x7fffffff;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cand = min(cand, __shfl_xor(cand, o, 64));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) shi[threadIdx.x >> 6] = cand;
+    __syncthreads();
+    if (threadIdx.x == 0)
+      correct_rows[b] = (!bad_label && min(min(shi[0], shi[1]), min(shi[2], shi[3])) == y) ? 1.0f : 0.0f;
+  }
   float sum = 0.f;
   for (int c = threadIdx.x; c < C; c += 256) sum += __expf((c == y ? zy : cr[c] * sc) - mx);
   sum = block_reduce(sum, sh, false);
@@ -111,12 +130,13 @@ __global__ __launch_bounds__(256) void aam_row_kernel(const float* __restrict__ 
 extern "C" int w2v2_aam_softmax_fwd_bwd(const float* cos, const int64_t* label, float* softmax, float* loss_rows,
                                         void* dcos_w, void* dcos_x, const float* inv_x, const float* inv_w,
                                         float* rowdot, float* coldot, int B, int C, int64_t ldc, float margin,
-                                        float scale, const float* loss_scale, int dtype, void* stream) {
+                                        float scale, const float* loss_scale, float* correct_rows, int dtype,
+                                        void* stream) {
   W2V2_REQUIRE(cos && label && softmax && loss_rows && B > 0 && C > 0 && ldc >= C, "aam_softmax: bad arguments");
   W2V2_DISPATCH_ACT(dtype, "aam_softmax",
     hipLaunchKernelGGL(aam_row_kernel<AT>, dim3(B), dim3(256), 0, as_stream(stream), cos, label, softmax,
                        loss_rows, (AT*)dcos_w, (AT*)dcos_x, inv_x, inv_w, rowdot, coldot, B, C, ldc, margin,
-                       scale, loss_scale););
+                       scale, loss_scale, correct_rows););
   W2V2_CHECK_LAUNCH("aam_softmax");
   return 0;
 }

@@ -110,8 +110,28 @@ class EcapaStore:
         self.grad = torch.zeros(off, dtype=torch.float32, device=dev)
         self.exp_avg = self.exp_avg_sq = None
         self.flat_lp = torch.zeros(off, dtype=act_dtype, device=dev) if ops.is16(act_dtype) else None
-        self.asp_running = torch.cat([torch.zeros(cfg.attention_channels), torch.ones(cfg.attention_channels)]).to(dev)
+        # BatchNorm1d buffers of EVERY norm layer live in the store (shared by the training and the evaluation plans,
+        # saved / loaded under the speechbrain names ``...norm.running_mean`` / ``running_var``): one f32 record
+        # {running_mean[C], running_var[C]} per layer, keyed by the name of its ``.weight``
+        self.bn_running: Dict[str, torch.Tensor] = {}
+        for n, shp in shapes.items():
+            if n.endswith("norm.weight"):
+                self.bn_running[n] = torch.cat([torch.zeros(shp[0]), torch.ones(shp[0])]).to(dev)
+        self.asp_running = self.bn_running[FE + "asp.tdnn.norm.norm.weight"]
+        self.bn_batches_tracked = 0
         self.version, self.step_count = 0, 0
+
+    def running(self, weight_name: str) -> torch.Tensor:
+        """{running_mean, running_var} record of the BatchNorm whose scale parameter is ``weight_name``."""
+        return self.bn_running[weight_name]
+
+    def _buffer_views(self) -> "OrderedDict[str, torch.Tensor]":
+        out: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+        for n, r in self.bn_running.items():
+            C = r.numel() // 2
+            base = n[:-len("weight")]
+            out[base + "running_mean"], out[base + "running_var"] = r[:C], r[C:]
+        return out
 
     def _view(self, buf, name):
         s, o = self.shapes[name], self.offsets[name]
@@ -131,7 +151,15 @@ class EcapaStore:
 
     def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = True) -> None:
         seen = set()
+        bufs = self._buffer_views()
         for k, v in sd.items():
+            bk = k if k in bufs else (FE + k if FE + k in bufs else None)
+            if bk is not None:                             # BatchNorm running statistics
+                bufs[bk].copy_(torch.as_tensor(v).to(self.device, torch.float32))
+                continue
+            if k.endswith("num_batches_tracked"):
+                self.bn_batches_tracked = int(v)
+                continue
             name = k if k in self.shapes else (FE + k if FE + k in self.shapes else None)
             if name is None:
                 if strict:
@@ -147,7 +175,12 @@ class EcapaStore:
         self.sync_lowp()
 
     def state_dict(self):
-        return OrderedDict((n, self.p(n).detach().clone().cpu()) for n in self.shapes)
+        sd = OrderedDict((n, self.p(n).detach().clone().cpu()) for n in self.shapes)
+        for n, b in self._buffer_views().items():
+            sd[n] = b.detach().clone().cpu()
+            if n.endswith("running_var"):
+                sd[n[:-len("running_var")] + "num_batches_tracked"] = torch.tensor(self.bn_batches_tracked)
+        return sd
 
     def init_weights(self, seed: int = 20211) -> None:
         g = torch.Generator(device="cpu").manual_seed(seed)
@@ -195,7 +228,7 @@ class _Tdnn:
         self.col = plan.buf(M, K) if k > 1 else None
         self.a = torch.empty(M, cout, dtype=adt, device=dev)                   # pre-activation (saved)
         self.mean_rstd = torch.empty(cout, 2, dtype=f32, device=dev)
-        self.running = torch.cat([torch.zeros(cout), torch.ones(cout)]).to(dev)
+        self.running = st.running(self.pre + "norm.norm.weight")            # shared BatchNorm1d buffers (store)
         self.work = ops.bn_workspace(M, cout, dev)
         A, lda = (self.col, K) if k > 1 else (x, ldx)
         self.g_fwd = Gemm(M, cout, K, A, self.wp, self.a, lda=lda, ldb=K, ldc=cout, epilogue=EPI_BIAS,
@@ -446,7 +479,7 @@ class EcapaPlan:
         self.asp = AttentivePool(store, self.mfa_out, self.pooled, self.d_mfa, B, T, train, prefix=FE + "asp.")
         E2, L = 2 * C[-1], cfg.lin_neurons
         self.bn_mr = torch.empty(E2, 2, dtype=f32, device=dev)
-        self.bn_running = torch.cat([torch.zeros(E2), torch.ones(E2)]).to(dev)
+        self.bn_running = store.running(FE + "asp_bn.norm.weight")
         self.bn_work = ops.bn_workspace(B, E2, dev)
         self.e2 = torch.empty(B, E2, dtype=f32, device=dev)
         self.emb = torch.empty(B, L, dtype=f32, device=dev)

@@ -133,7 +133,7 @@ class Plan:
         if fused_attention is None:
             fused_attention = (ops.is16(self.adt) and d == 64 and self.T <= 256)
         self.fused = fused_attention
-        self.embed_dim = H * (2 if pooling in ("mean+std", "attentive") else 1)
+        self.embed_dim = H * (2 if pooling == "attentive" else ops.POOL_WIDTH.get(self.pool_mode, 1))
         self._pack_version = -1
         self._cnn_version = -1
         self._asp = {}
@@ -206,7 +206,7 @@ class Plan:
         E = self.embed_dim
         self.emb = self._e(B, E, dtype=f32)
         st = self.store
-        self.head = None
+        self.head, self.fc = None, None
         if st.head == "bce":
             from .heads import BceHead
             self.head = BceHead(B, E, w=st.p("linear.weight"), b=st.p("linear.bias"),
@@ -214,17 +214,23 @@ class Plan:
                                 b_grad=st.g("linear.bias") if self.train else None, emb=self.emb, train=self.train,
                                 loss_scale=st.scaler)
         elif st.head is not None:
-            from .heads import ClassifierHead
+            from .heads import ClassifierHead, FcStack
             aam = st.head == "aam"
-            wname = "loss_fn.fc_weights" if aam else "fc_list.0.0.weight"
-            self.head = ClassifierHead(st.head, B, E, st.num_speakers, w_master=st.p(wname), w_operand=st.w(wname),
-                                       w_grad=st.g(wname) if self.train else None,
-                                       bias=None if aam else st.p("fc_list.0.0.bias"),
-                                       bias_grad=None if (aam or not self.train) else st.g("fc_list.0.0.bias"),
-                                       emb=self.emb, act_dtype=self.adt, train=self.train, margin=self.margin,
+            nh = len(st.hidden_fc)
+            # hidden Linear+ReLU layers between the pooled embedding and the head (ref: wav2vec2_fc.py:185-228)
+            self.fc = FcStack(st, B, E, st.hidden_fc, self.emb, self.train) if nh else None
+            head_in = self.fc.x[-1] if self.fc is not None else self.emb
+            wname = "loss_fn.fc_weights" if aam else f"fc_list.{nh}.0.weight"
+            bname = f"fc_list.{nh}.0.bias"
+            self.head = ClassifierHead(st.head, B, st.head_in_dim, st.num_speakers, w_master=st.p(wname),
+                                       w_operand=st.w(wname), w_grad=st.g(wname) if self.train else None,
+                                       bias=None if aam else st.p(bname),
+                                       bias_grad=None if (aam or not self.train) else st.g(bname),
+                                       emb=head_in, act_dtype=self.adt, train=self.train, margin=self.margin,
                                        scale=self.scale, loss_scale=st.scaler)
         if self.train:
-            self.demb = self.head.demb if self.head is not None else self._e(B, E, dtype=f32)
+            self.demb = (self.head.demb if (self.head is not None and getattr(self, "fc", None) is None)
+                         else self._e(B, E, dtype=f32))
             self.G = self._ep(M, H)           # running activation gradient
             # Gradient scratch of one layer's backward: Gd = df (after the dropout mask of the FFN residual branch),
             # Gd1 = da (attention residual branch), DH, DQKV.  TWO sets, used by alternating layers: the grouped
@@ -546,9 +552,33 @@ class Plan:
 
     # ------------------------------------------------------------------------------------------ head
     def head_forward_backward(self, label: torch.Tensor):
-        """Loss head on self.emb (heads.ClassifierHead): returns (loss scalar tensor, softmax [B,C]); a
-        training plan also leaves d(loss)/d(emb) in self.demb and the head gradients in the flat buffer."""
-        return self.head.forward_backward(label)
+        """Loss head on self.emb (hidden FC layers, then heads.ClassifierHead): returns (loss scalar tensor,
+        softmax [B,C]); a training plan also leaves d(loss)/d(pooled embedding) in self.demb and the head gradients
+        in the flat buffer."""
+        if self.fc is not None:
+            self.fc.forward()
+        out = self.head.forward_backward(label)
+        if self.fc is not None and self.train:
+            self.demb.copy_(self.fc.backward(self.head.demb))
+        return out
+
+    def speaker_embedding(self, embedding_layer_idx: int = -1) -> torch.Tensor:
+        """ref: wav2vec2_fc.py:363-398 (_fc_head_ops_pre_spk_embedding) after embed(): the pooled embedding
+        (idx < 0), the output of hidden layer idx, or (idx == number of hidden layers, CE head) the logits."""
+        if embedding_layer_idx < 0:
+            return self.emb
+        nh = len(self.store.hidden_fc)
+        if embedding_layer_idx < nh:
+            return self.fc.forward(upto=embedding_layer_idx)
+        if embedding_layer_idx == nh and self.store.head == "ce":
+            if self.fc is not None:
+                self.fc.forward()
+            h = self.head
+            if h.emb_lp is not h.emb:
+                ops.cast(h.emb, h.emb_lp)
+            h.g_fwd()
+            return h.logits[:, :h.C]
+        raise ValueError("could not determine the speaker embedding layer")
 
     # ------------------------------------------------------------------------------------------ backward
     def backward(self, demb: Optional[torch.Tensor] = None,
@@ -591,6 +621,7 @@ class Plan:
             else:
                 notify(f"layer{ev[1]}")
         # encoder prologue: x0 = drop(LN(hx + pos)), pos = GELU(posconv(hx) + b)
+        ph = reg.hidden_dropout
         if ph > 0:
             ops.dropout_(self.G, ph, self._sd("prologue", 0, step))
         ops.layernorm_bwd(self.G, self.pos, self.mean0, self.rstd0, mp("encoder.layer_norm.weight"), self.G, None,
@@ -631,7 +662,8 @@ class Plan:
                           mg("feature_projection.layer_norm.weight"), mg("feature_projection.layer_norm.bias"))
         notify("prologue")
         if not st.freeze_cnn:
-            self._backward_cnn()
+            if not st.cnn_runtime_frozen:         # feature_extractor.requires_grad_(False) at run time: zero gradient
+                self._backward_cnn()
             notify("cnn")
 
     def _layer_backward_body(self, l: int, lnfold) -> None:

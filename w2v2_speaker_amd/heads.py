@@ -29,6 +29,7 @@ class ClassifierHead:
         self.logits = torch.zeros(B, self.ldc, dtype=f32, device=dev)
         self.softmax = torch.zeros(B, self.ldc, dtype=f32, device=dev)
         self.loss_rows = torch.empty(B, dtype=f32, device=dev)
+        self.correct = torch.zeros(B, dtype=f32, device=dev)      # 1 where argmax(prediction) == label (train_acc)
         aam = kind == "aam"
         if aam:
             self.inv_x, self.inv_w = torch.empty(B, dtype=f32, device=dev), torch.empty(Cn, dtype=f32, device=dev)
@@ -82,7 +83,8 @@ class ClassifierHead:
                                 self.dcos_w if tr else None, (self.dcos_x if aam else None) if tr else None,
                                 self.inv_x if aam else None, self.inv_w if aam else None,
                                 self.rowdot if (tr and aam) else None, self.coldot if (tr and aam) else None,
-                                B, Cn, self.ldc, self.margin if aam else -1.0, self.scale, self.loss_scale if tr else None)
+                                B, Cn, self.ldc, self.margin if aam else -1.0, self.scale, self.loss_scale if tr else None,
+                                self.correct)
         loss = self.loss_rows.mean()
         if tr:
             for g in self.g_dx:
@@ -126,3 +128,48 @@ class BceHead:
                              self.loss_scale if tr else None)
         return self.loss_rows.mean(), self.prob
 
+
+
+class FcStack:
+    """Hidden ``nn.Sequential(nn.Linear, nn.ReLU)`` layers between the pooled embedding and the loss head
+    (ref: src/lightning_modules/speaker/wav2vec2_fc.py:185-228 ``fc_list``, :363-412 pre/post speaker-embedding ops).
+    f32 throughout (B x a few hundred features: negligible work, exact arithmetic): forward = GEMM + bias epilogue +
+    ReLU kernel, backward = ReLU', weight gradient GEMM (accumulated), bias column sums, data gradient GEMM."""
+
+    def __init__(self, store, batch: int, in_dim: int, hidden, x0: torch.Tensor, train: bool):
+        from .ops import EPI_BIAS
+        dev, f32 = x0.device, torch.float32
+        self.B, self.dims, self.train = batch, [in_dim] + list(hidden), train
+        self.x = [x0] + [torch.empty(batch, h, dtype=f32, device=dev) for h in hidden]
+        self.w = [store.p(f"fc_list.{i}.0.weight") for i in range(len(hidden))]
+        self.b = [store.p(f"fc_list.{i}.0.bias") for i in range(len(hidden))]
+        self.g_fwd = [Gemm(batch, h, self.dims[i], self.x[i], self.w[i], self.x[i + 1], lda=self.dims[i],
+                           ldb=self.dims[i], ldc=h, epilogue=EPI_BIAS, bias=self.b[i]) for i, h in enumerate(hidden)]
+        if train:
+            self.dw = [store.g(f"fc_list.{i}.0.weight") for i in range(len(hidden))]
+            self.db = [store.g(f"fc_list.{i}.0.bias") for i in range(len(hidden))]
+            self.dx = [torch.empty(batch, d, dtype=f32, device=dev) for d in self.dims]      # d(loss)/d(x[i])
+            self.g_dw = [Gemm(h, self.dims[i], batch, self.dx[i + 1], self.x[i], self.dw[i], lda=h, ldb=self.dims[i],
+                              ldc=self.dims[i], transA=True, transB=True, accumulate=True)
+                         for i, h in enumerate(hidden)]
+            self.g_dx = [Gemm(batch, self.dims[i], h, self.dx[i + 1], self.w[i], self.dx[i], lda=h, ldb=self.dims[i],
+                              ldc=self.dims[i], transB=True) for i, h in enumerate(hidden)]
+
+    def forward(self, upto: Optional[int] = None) -> torch.Tensor:
+        """Run layers 0 .. upto (all by default); returns the output of the last one run."""
+        n = len(self.g_fwd) if upto is None else upto + 1
+        for i in range(n):
+            self.g_fwd[i]()
+            ops.act_fwd(self.x[i + 1], self.x[i + 1], 0)           # ReLU in place
+        return self.x[n]
+
+    def backward(self, dout: torch.Tensor) -> torch.Tensor:
+        """dout = d(loss)/d(output of the last layer) -> d(loss)/d(x0); parameter gradients accumulated."""
+        n = len(self.g_fwd)
+        self.dx[n].copy_(dout)
+        for i in reversed(range(n)):
+            ops.act_bwd(self.dx[i + 1], self.x[i + 1], self.dx[i + 1], 0)      # through the ReLU (y > 0)
+            self.g_dw[i]()
+            ops.colsum(self.dx[i + 1], self.db[i], self.B, self.dims[i + 1])
+            self.g_dx[i]()
+        return self.dx[0]

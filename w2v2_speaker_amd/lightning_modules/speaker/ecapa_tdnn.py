@@ -45,8 +45,7 @@ class EcapaTdnnModule:
         self.store.init_weights(init_seed)
         if cfg.pretrained_weights_path is not None:       # ref :88-91: a bare ECAPA_TDNN state dict
             sd = torch.load(cfg.pretrained_weights_path, map_location="cpu", weights_only=False)
-            self.store.load_state_dict({k: v for k, v in sd.items() if "num_batches_tracked" not in k
-                                        and "running_" not in k}, strict=False)
+            self.store.load_state_dict(dict(sd), strict=False)    # incl. every BatchNorm running_mean / running_var
         self.margin, self.scale = aam_margin, aam_scale
         self.schedule = OneCycle(max_lr=max_lr, total_steps=max_steps)
         self.skip_classifier = True                        # AAM owns the classifier weight (ref :93-95, :129-131)

@@ -1,29 +1,38 @@
 """Mirror of ref: src/lightning_modules/speaker/wav2vec2_fc.py (``Wav2vec2FCModule``) and of the step
-semantics of ref: src/lightning_modules/speaker/speaker_recognition_module.py:148-220,322-359,462-519, on
-the HIP engine.  PyTorch-Lightning is not required: the class exposes the same method names
-(``compute_speaker_embedding``, ``compute_speaker_prediction``, ``forward``, ``training_step``,
-``validation_step``, ``test_step``, ``generate_example_input``, ``on_train_start`` / ``on_after_backward``
-freeze schedule) so a PL ``Trainer`` -- or the in-repo loop -- can drive it.
+semantics of ref: src/lightning_modules/speaker/speaker_recognition_module.py:148-220,296-307,322-359,462-519, on
+the HIP engine.  PyTorch-Lightning is not required: the class has the reference's constructor
+(``hyperparameters_to_save, cfg, num_speakers, loss_fn_constructor, validation_pairs, test_pairs, evaluator`` --
+what ref: src/main.py:223-285 passes) and the same method names (``compute_speaker_embedding``,
+``compute_speaker_prediction``, ``forward``, ``training_step``, ``validation_step``, ``test_step``,
+``generate_example_input``, ``on_train_start`` / ``on_after_backward`` freeze schedule, ``wav2vec.model.*`` handles)
+so a PL ``Trainer`` -- or the in-repo loop -- can drive it.
 
 Differences by design: the loss head lives in the same flat parameter arena as the encoder (one fused Adam
 launch, contiguous DDP buckets), ``training_step`` performs forward + the hand-written backward (+ the
-overlapped RCCL all-reduce) itself and returns a detached loss, and ``optimizer_step`` runs the fused Adam
-with the one-cycle schedule.  Only the reference's default AAM / CE configuration without hidden FC layers is
-on the path (``hidden_fc_layers_out == []``, ``embedding_layer_idx == -1``)."""
+overlapped RCCL all-reduce) + fused Adam itself and returns a detached loss.  ``loss_fn_constructor`` is called once
+and read for its type and hyper-parameters (AAM ``margin`` / ``scale``): the arithmetic of the loss runs in the
+engine's head kernels on the arena's weight, like the reference re-creates its AAM module with the right sizes
+(ref: wav2vec2_fc.py:212-224)."""
 from __future__ import annotations
 
-import dataclasses
+import warnings
+from collections import OrderedDict
 from dataclasses import dataclass, field
-from typing import Dict, List, Optional, Tuple
+from typing import Callable, Dict, List, Optional, Tuple
 
 import torch
 
+from ... import ops
 from ...config import W2V2Config, Wav2Vec2RegularisationConfig
 from ...engine import Plan
 from ...evaluation.speaker.cosine_distance import CosineDistanceEvaluator, EmbeddingSample, EvaluationPair
+from ...models.handles import ModelHandle
+from ...optim.loss import AngularAdditiveMarginSoftMaxLoss, CrossEntropyLoss
 from ...optim.schedule import OneCycle
 from ...params import ParamStore
 from ...trainer import SpeakerTrainer
+
+MAX_PLANS = 8      # static plans kept per module (LRU): evaluation over variable-length utterances builds one per length
 
 
 @dataclass
@@ -73,47 +82,135 @@ class SpeakerClassificationDataBatch:
                                               self.ground_truth.to(device), self.side_info)
 
 
+class _Wav2vecHandle:
+    """``module.wav2vec`` of the reference (a Wav2Vec2WrapperModule): ``.model.{feature_extractor,
+    feature_projection,encoder}``, ``.num_features``, PL's ``freeze()`` / ``unfreeze()`` (ref: wav2vec2_fc.py:339-361)."""
+
+    def __init__(self, owner: "Wav2vec2FCModule"):
+        self._owner = owner
+        self.model = ModelHandle(owner.store, on_body_grad=owner._set_body_trainable)
+        self.num_features = owner.model_cfg.hidden_size
+
+    @property
+    def num_embedding_features(self):
+        return self.num_features
+
+    def freeze(self) -> None:          # PL LightningModule.freeze(): requires_grad False + eval mode
+        self._owner._is_wav2vec_frozen = True
+
+    def unfreeze(self) -> None:
+        self._owner._is_wav2vec_frozen = False
+
+
+def _pool_width(pooling: str) -> int:
+    """ref: wav2vec2_fc.py:290-319 _determine_stat_pool_embedding_size."""
+    p = pooling.lower()
+    if p in ("mean", "first", "first+cls", "last", "middle", "random", "max", "none"):
+        return 1
+    if p in ("mean+std", "attentive"):
+        return 2
+    if p == "quantile":
+        return 5
+    raise ValueError(f"unknown value for stat_pooling_type={pooling!r}")
+
+
 class Wav2vec2FCModule:
-    def __init__(self, cfg: Wav2vec2FCModuleConfig, num_speakers: int, loss: str = "aam",
-                 aam_margin: float = 0.2, aam_scale: float = 30.0,
-                 validation_pairs: Optional[List[EvaluationPair]] = None,
+    def __init__(self, hyperparameters_to_save, cfg: Wav2vec2FCModuleConfig, num_speakers: int,
+                 loss_fn_constructor: Callable[[], object], validation_pairs: Optional[List[EvaluationPair]] = None,
                  test_pairs: Optional[List[EvaluationPair]] = None, evaluator=None, *, device="cuda",
-                 act_dtype: torch.dtype = torch.bfloat16, max_lr: float = 5e-5, max_steps: int = 100_000,
-                 process_group=None, init_seed: int = 20211):
-        if cfg.wav2vec_feature_encoder_only:
-            raise NotImplementedError("Wav2vecLiteWrapperModule (CNN-only) is outside the hot path")
-        if cfg.hidden_fc_layers_out or cfg.embedding_layer_idx >= 0:
-            raise NotImplementedError("hidden FC layers are not on the reference's default path")
-        if cfg.mask_feature_prob > 0 or cfg.final_channel_mask_prob > 0 and False:
-            raise NotImplementedError("feature-axis SpecAugment (reference default mask_feature_prob=0.0)")
-        assert loss in ("aam", "ce")
+                 act_dtype: torch.dtype = torch.float16, max_lr: float = 5e-5, max_steps: int = 100_000,
+                 process_group=None, init_seed: int = 20211, pretrained_state_dict=None):
+        """Positional arguments = ref: wav2vec2_fc.py:101-111.  Keyword-only extras: the device / activation dtype of
+        the engine, the one-cycle schedule the reference takes from ``cfg.optim`` (src/main.py:323-335), and
+        ``pretrained_state_dict`` (a path or a dict with HF ``facebook/wav2vec2-*`` weights: there is no network
+        here for ``from_pretrained``)."""
+        self.hyperparameters_to_save = hyperparameters_to_save
         self.cfg = cfg
+        if cfg.wav2vec_feature_encoder_only:
+            # ref: :118-128 Wav2vecLiteWrapperModule (CNN only) -- not on the hot path (SURVEY 8)
+            raise NotImplementedError("wav2vec_feature_encoder_only (Wav2vecLiteWrapperModule) is outside the hot path")
+        if cfg.mask_feature_prob > 0:
+            raise NotImplementedError("feature-axis SpecAugment (reference default mask_feature_prob=0.0)")
+        if cfg.stat_pooling_type.lower() in ("none", "random"):
+            raise NotImplementedError(f"stat_pooling_type={cfg.stat_pooling_type!r} is not on the hot path")
+        # ``final_channel_mask_prob`` is accepted and has NO effect, like in the reference: its EmbeddingMasker gates
+        # the channel mask on ``timestep_mask_prob``, which Wav2vec2FCModule hard-wires to 0 (quirk Q3,
+        # ref: src/layers/embedding_masking.py:79, wav2vec2_fc.py:162-169)
+        loss_fn = loss_fn_constructor()
+        if isinstance(loss_fn, AngularAdditiveMarginSoftMaxLoss):
+            loss, margin, scale = "aam", float(loss_fn.margin), float(loss_fn.scale)
+        elif isinstance(loss_fn, CrossEntropyLoss):
+            loss, margin, scale = "ce", 0.2, 30.0
+        else:
+            raise NotImplementedError(f"loss {type(loss_fn).__name__}: only AngularAdditiveMarginSoftMaxLoss and "
+                                      "CrossEntropyLoss are on the hot path (w2v2_speaker_amd.optim.loss)")
+        del loss_fn            # its sizes are placeholders (ref: config/optim/loss/aam_softmax.yaml), see module docstring
         self.model_cfg = W2V2Config.from_huggingface_id(cfg.wav2vec_hunggingface_id)
-        self.num_speakers = cfg.explicit_num_speakers or num_speakers
+        self.num_speakers = num_speakers
         self.reg = Wav2Vec2RegularisationConfig(
             activation_dropout=cfg.activation_dropout, attention_dropout=cfg.attention_dropout,
             feat_proj_dropout=cfg.feat_proj_dropout, hidden_dropout=cfg.hidden_dropout, layerdrop=cfg.layerdrop,
             mask_feature_length=cfg.mask_feature_length, mask_feature_prob=cfg.mask_feature_prob,
             mask_time_length=cfg.mask_time_length, mask_time_prob=cfg.mask_time_prob)
         H = self.model_cfg.hidden_size
-        self.stat_pool_dimension = cfg.explicit_stat_pool_embedding_size or (
-            2 * H if cfg.stat_pooling_type in ("mean+std", "attentive") else H)
-        self.store = ParamStore(self.model_cfg, device, act_dtype, head=loss, num_speakers=self.num_speakers,
-                                embed_dim=self.stat_pool_dimension,
+        self.stat_pool_dimension = (cfg.explicit_stat_pool_embedding_size
+                                    if cfg.explicit_stat_pool_embedding_size is not None
+                                    else H * _pool_width(cfg.stat_pooling_type))
+        hidden = tuple(cfg.hidden_fc_layers_out)
+        n_out = cfg.explicit_num_speakers if cfg.explicit_num_speakers else num_speakers
+        # ref: :277-288 _determine_embedding_size
+        if cfg.embedding_layer_idx < 0:
+            self.embedding_size = self.stat_pool_dimension
+        elif cfg.embedding_layer_idx < len(hidden):
+            self.embedding_size = hidden[cfg.embedding_layer_idx]
+        elif cfg.embedding_layer_idx == len(hidden) and loss == "ce":
+            self.embedding_size = num_speakers
+        else:
+            raise ValueError("could not determine size of speaker embeddings")
+        self.store = ParamStore(self.model_cfg, device, act_dtype, head=loss, num_speakers=n_out,
+                                embed_dim=self.stat_pool_dimension, hidden_fc=hidden,
                                 freeze_cnn=cfg.completely_freeze_feature_extractor,
                                 attentive_pool="attentive" in (cfg.stat_pooling_type, cfg.test_stat_pooling_type))
         self.store.init_weights(init_seed)
-        self.loss, self.margin, self.scale = loss, aam_margin, aam_scale
+        if pretrained_state_dict is not None:
+            sd = (torch.load(pretrained_state_dict, map_location="cpu", weights_only=False)
+                  if isinstance(pretrained_state_dict, str) else pretrained_state_dict)
+            self.store.load_state_dict({k: v for k, v in sd.items()}, strict=False, prefix_model=True)
+        elif not cfg.reset_weights:
+            warnings.warn("Wav2vec2FCModule: reset_weights=False asks for the pretrained "
+                          f"{cfg.wav2vec_hunggingface_id!r} weights, but none were given (pass pretrained_state_dict=; "
+                          "there is no network access for from_pretrained): the model starts from a RANDOM "
+                          "initialisation", stacklevel=2)
+        self.loss, self.margin, self.scale = loss, margin, scale
         self.validation_pairs, self.test_pairs = validation_pairs or [], test_pairs or []
         self.evaluator = evaluator or CosineDistanceEvaluator(False, False, 0)
         self.schedule = OneCycle(max_lr=max_lr, total_steps=max_steps)
         self.process_group = process_group
         self.training = True
-        self._plans: Dict[Tuple, Plan] = {}
+        self._plans: "OrderedDict[Tuple, Plan]" = OrderedDict()
         self._trainers: Dict[Tuple, SpeakerTrainer] = {}
-        self.steps = 0
+        self.steps = 0              # ref: counts backward calls since on_train_start (the freeze schedule)
+        self.schedule_step = 0      # position in the learning-rate schedule (restored from a checkpoint)
         self._is_wav2vec_frozen = False
         self.device = torch.device(device)
+        self.wav2vec = _Wav2vecHandle(self)
+        self.test_with_ensemble = cfg.use_transformers_as_ensembles
+        self.train_acc: Optional[torch.Tensor] = None
+
+    @classmethod
+    def from_config(cls, cfg: Wav2vec2FCModuleConfig, num_speakers: int, loss: str = "aam", aam_margin: float = 0.2,
+                    aam_scale: float = 30.0, **kw) -> "Wav2vec2FCModule":
+        """Short form for scripts and tests: the loss by name instead of a constructor."""
+        assert loss in ("aam", "ce")
+        dev = kw.get("device", "cuda")
+
+        def ctor():
+            if loss == "aam":      # placeholder sizes, like config/optim/loss/aam_softmax.yaml
+                return AngularAdditiveMarginSoftMaxLoss(2, 2, margin=aam_margin, scale=aam_scale, device=dev,
+                                                        act_dtype=torch.float32)
+            return CrossEntropyLoss()
+        return cls(None, cfg, num_speakers, ctor, kw.pop("validation_pairs", None), kw.pop("test_pairs", None),
+                   kw.pop("evaluator", None), **kw)
 
     # ------------------------------------------------------------------ PL-style mode switches
     def train(self, mode: bool = True):
@@ -123,28 +220,46 @@ class Wav2vec2FCModule:
     def eval(self):
         return self.train(False)
 
+    def _set_body_trainable(self, flag: bool) -> None:
+        """``wav2vec.model.{feature_projection,encoder}.requires_grad_``: only all-or-nothing freezes exist on this
+        path (the reference's ``wav2vec_initially_frozen``)."""
+        self._is_wav2vec_frozen = not flag
+
     def on_train_start(self) -> None:
         # ref: wav2vec2_fc.py:339-347
         self.steps = 0
         if self.cfg.wav2vec_initially_frozen:
-            self._is_wav2vec_frozen = True
+            self.wav2vec.freeze()
+        if self.cfg.completely_freeze_feature_extractor:
+            self.wav2vec.model.feature_extractor.requires_grad_(False)
 
     def on_after_backward(self) -> None:
         # ref: wav2vec2_fc.py:349-361 -- num_frozen_steps counts backward calls
         self.steps += 1
+        self.schedule_step += 1
         if (self._is_wav2vec_frozen and self.cfg.num_frozen_steps is not None
                 and self.steps >= self.cfg.num_frozen_steps):
-            self._is_wav2vec_frozen = False
+            self.wav2vec.unfreeze()
+            if self.cfg.completely_freeze_feature_extractor:
+                self.wav2vec.model.feature_extractor.requires_grad_(False)
 
-    # ------------------------------------------------------------------ plans
+    # ------------------------------------------------------------------ plans (bounded LRU cache)
+    def _cached_plan(self, key: Tuple, build: Callable[[], Plan]) -> Plan:
+        if key in self._plans:
+            self._plans.move_to_end(key)
+            return self._plans[key]
+        plan = build()
+        self._plans[key] = plan
+        while len(self._plans) > MAX_PLANS:
+            old, _ = self._plans.popitem(last=False)
+            self._trainers.pop(old, None)
+        return plan
+
     def _plan(self, batch: int, n: int, train: bool) -> Plan:
         pooling = self.cfg.stat_pooling_type if train else self.cfg.test_stat_pooling_type
-        key = (batch, n, train, pooling)
-        if key not in self._plans:
-            self._plans[key] = Plan(self.store, batch, n, train=train, reg=self.reg, pooling=pooling,
-                                    insert_cls_token=(pooling == "first+cls"), aam_margin=self.margin,
-                                    aam_scale=self.scale)
-        return self._plans[key]
+        return self._cached_plan((batch, n, train, pooling), lambda: Plan(
+            self.store, batch, n, train=train, reg=self.reg, pooling=pooling,
+            insert_cls_token=(pooling == "first+cls"), aam_margin=self.margin, aam_scale=self.scale))
 
     @staticmethod
     def _prep_input(input_tensor: torch.Tensor) -> torch.Tensor:
@@ -157,20 +272,34 @@ class Wav2vec2FCModule:
 
     # ------------------------------------------------------------------ reference surface
     def compute_speaker_embedding(self, input_tensor: torch.Tensor) -> torch.Tensor:
+        """ref: :414-431 -- wav2vec2 -> statistics pooling -> (identity masker) -> hidden FC layers up to
+        ``embedding_layer_idx``."""
         x = self._prep_input(input_tensor).to(self.device, torch.float32)
         plan = self._plan(x.shape[0], x.shape[1], False)
-        return plan.embed(x).clone()
+        plan.embed(x)
+        return plan.speaker_embedding(self.cfg.embedding_layer_idx).clone()
+
+    def _linear(self, x: torch.Tensor, i: int, relu: bool) -> torch.Tensor:
+        W, b = self.store.p(f"fc_list.{i}.0.weight"), self.store.p(f"fc_list.{i}.0.bias")
+        out = torch.empty(x.shape[0], W.shape[0], dtype=torch.float32, device=self.device)
+        ops.gemm(x.shape[0], W.shape[0], W.shape[1], x.float().contiguous(), W, out, lda=W.shape[1], ldb=W.shape[1],
+                 ldc=W.shape[0], epilogue=ops.EPI_BIAS, bias=b)
+        if relu:
+            ops.act_fwd(out, out, 0)
+        return out
 
     def compute_speaker_prediction(self, embedding_tensor: torch.Tensor) -> torch.Tensor:
-        if self.loss == "aam":        # AAM owns the classifier weight: the "prediction" is the embedding (Q6)
-            return embedding_tensor.squeeze()
-        W, b = self.store.p("fc_list.0.0.weight"), self.store.p("fc_list.0.0.bias")
-        from ... import ops
-        B, Cn = embedding_tensor.shape[0], W.shape[0]
-        out = torch.empty(B, Cn, dtype=torch.float32, device=self.device)
-        ops.gemm(B, Cn, W.shape[1], embedding_tensor.float().contiguous(), W, out, lda=W.shape[1], ldb=W.shape[1],
-                 ldc=Cn, epilogue=ops.EPI_BIAS, bias=b)
-        return out.squeeze()
+        """ref: :400-412,433-438 -- the FC layers after ``embedding_layer_idx``; with AAM the classifier weight
+        belongs to the loss, so the "prediction" of the default configuration is the embedding itself (quirk Q6)."""
+        x = embedding_tensor.to(self.device)
+        if x.dim() == 1:
+            x = x[None]
+        nh = len(self.cfg.hidden_fc_layers_out)
+        for i in range(self.cfg.embedding_layer_idx + 1, nh):
+            x = self._linear(x, i, relu=True)
+        if self.loss == "ce" and self.cfg.embedding_layer_idx < nh:
+            x = self._linear(x, nh, relu=False)
+        return x.squeeze()
 
     def forward(self, input_tensor: torch.Tensor):
         embedding = self.compute_speaker_embedding(input_tensor)
@@ -178,7 +307,7 @@ class Wav2vec2FCModule:
 
     __call__ = forward
 
-    def generate_example_input(self, include_batch_dimension: bool, batch_size: Optional[int]):
+    def generate_example_input(self, include_batch_dimension: bool, batch_size: Optional[int] = None):
         # ref: wav2vec2_fc.py:321-337
         shape = [batch_size, 16000] if include_batch_dimension else [16000]
         return torch.rand(size=shape)
@@ -186,33 +315,33 @@ class Wav2vec2FCModule:
     # ------------------------------------------------------------------ steps
     def training_step(self, batch: SpeakerClassificationDataBatch, batch_idx: int = 0,
                       optimizer_idx: Optional[int] = None):
-        """forward + backward (+ all-reduce) + fused Adam; returns {"loss", "prediction"} (device tensors)."""
+        """forward + backward (+ all-reduce) + fused Adam; returns {"loss", "prediction", "train_acc"} (device
+        tensors; train_acc = fraction of the batch whose arg-max prediction is the label, the quantity the
+        reference feeds torchmetrics.Accuracy, ref: speaker_recognition_module.py:296-307)."""
         x = self._prep_input(batch.network_input).to(self.device, torch.float32)
         label = batch.ground_truth.to(self.device)
-        key = (x.shape[0], x.shape[1])
-        if key not in self._trainers:
-            plan = self._plan(x.shape[0], x.shape[1], True)
-            tr = SpeakerTrainer(self.store, plan, self.schedule, process_group=self.process_group)
-            tr.step = self.steps
-            self._trainers[key] = tr
-        tr = self._trainers[key]
-        tr.step = self.steps
+        pkey = (x.shape[0], x.shape[1], True, self.cfg.stat_pooling_type)
+        plan = self._plan(x.shape[0], x.shape[1], True)
+        if pkey not in self._trainers:
+            self._trainers[pkey] = SpeakerTrainer(self.store, plan, self.schedule, process_group=self.process_group)
+        tr = self._trainers[pkey]
+        tr.step = self.schedule_step
         if self._is_wav2vec_frozen:
             # frozen network = eval-mode forward (PL freeze()), head-only backward + Adam
-            fkey = (x.shape[0], x.shape[1], "frozen")
-            if fkey not in self._plans:
-                noreg = Wav2Vec2RegularisationConfig(activation_dropout=0.0, attention_dropout=0.0,
-                                                     feat_proj_dropout=0.0, hidden_dropout=0.0, layerdrop=0.0,
-                                                     mask_time_prob=0.0)
-                self._plans[fkey] = Plan(self.store, x.shape[0], x.shape[1], train=True, reg=noreg,
-                                         pooling=self.cfg.stat_pooling_type,
-                                         insert_cls_token=(self.cfg.stat_pooling_type == "first+cls"),
-                                         aam_margin=self.margin, aam_scale=self.scale)
-            loss, pred = tr.train_step_frozen_encoder(self._plans[fkey], x, label)
+            noreg = Wav2Vec2RegularisationConfig(activation_dropout=0.0, attention_dropout=0.0, feat_proj_dropout=0.0,
+                                                 hidden_dropout=0.0, layerdrop=0.0, mask_time_prob=0.0)
+            fplan = self._cached_plan((x.shape[0], x.shape[1], "frozen"), lambda: Plan(
+                self.store, x.shape[0], x.shape[1], train=True, reg=noreg, pooling=self.cfg.stat_pooling_type,
+                insert_cls_token=(self.cfg.stat_pooling_type == "first+cls"), aam_margin=self.margin,
+                aam_scale=self.scale))
+            loss, pred = tr.train_step_frozen_encoder(fplan, x, label)
+            head = fplan.head
         else:
             loss, pred = tr.train_step(x, label)
+            head = plan.head
+        self.train_acc = head.correct.mean()
         self.on_after_backward()
-        return {"loss": loss, "prediction": pred}
+        return {"loss": loss, "prediction": pred, "train_acc": self.train_acc}
 
     def validation_step(self, batch: SpeakerClassificationDataBatch, batch_idx: int = 0):
         emb = self.compute_speaker_embedding(batch.network_input)
@@ -236,52 +365,62 @@ class Wav2vec2FCModule:
     def test_epoch_end(self, outputs: List[dict]):
         return self._evaluate_embeddings(outputs, self.test_pairs)
 
-    # ------------------------------------------------------------------ checkpoints (reference key names)
     def compute_ensemble_embedding(self, input_tensor: torch.Tensor):
         """ref: wav2vec2_fc.py:440-463 -- list of ``num_ensembles`` pooled embeddings, one per hidden state of the
         last transformer layers (``use_transformers_as_ensembles``); scored by CosineDistanceEvaluator as the mean
         of the per-layer cosine scores."""
-        x = input_tensor
-        if x.dim() == 3 and x.shape[1] == 1:
-            x = x[:, 0, :]
-        if x.dim() == 1:
-            x = x[None]
-        key = ("ensemble", x.shape[0], x.shape[1])
-        if key not in self._plans:
-            self._plans[key] = Plan(self.store, x.shape[0], x.shape[1], train=False, reg=self.reg,
-                                    pooling=self.cfg.stat_pooling_type, keep_hidden_states=True,
-                                    insert_cls_token=(self.cfg.stat_pooling_type == "first+cls"),
-                                    cls_token_constant=self.cfg.cls_token_constant
-                                    if hasattr(self.cfg, "cls_token_constant") else 1.0)
-        return self._plans[key].ensemble_embeddings(x.to(self.device), self.cfg.num_ensembles)
+        x = self._prep_input(input_tensor)
+        plan = self._cached_plan(("ensemble", x.shape[0], x.shape[1]), lambda: Plan(
+            self.store, x.shape[0], x.shape[1], train=False, reg=self.reg, pooling=self.cfg.stat_pooling_type,
+            keep_hidden_states=True, insert_cls_token=(self.cfg.stat_pooling_type == "first+cls")))
+        return plan.ensemble_embeddings(x.to(self.device), self.cfg.num_ensembles)
 
+    # ------------------------------------------------------------------ checkpoints (reference key names)
     def state_dict(self):
         return self.store.state_dict()
 
     def load_state_dict(self, sd, strict: bool = True):
         self.store.load_state_dict(sd, strict=strict, prefix_model=False)
 
-    # ------------------------------------------------------------------ PL-format checkpoints (SURVEY 8f row f3)
     def save_checkpoint(self, path: str) -> None:
         """A file ``Trainer.save_checkpoint`` / ``load_from_checkpoint`` of the reference can exchange: a pickled
-        dict whose ``state_dict`` uses the reference's parameter names (``wav2vec.model.<HF name>``,
-        ``loss_fn.fc_weights`` / ``fc_list.0.0.*``, ``stat_pooling.pooling_layer.*``)."""
-        torch.save({"state_dict": self.state_dict(), "global_step": self.steps, "epoch": 0,
+        dict whose ``state_dict`` uses the reference's parameter and buffer names (``wav2vec.model.<HF name>``,
+        ``loss_fn.fc_weights`` / ``fc_list.{i}.0.*``, ``stat_pooling.pooling_layer.*`` incl. the BatchNorm running
+        statistics), plus the optimiser and schedule state a PL checkpoint carries (``optimizer_states``: Adam
+        moments and step counts as one flat arena each; ``lr_schedulers``: the schedule position)."""
+        torch.save({"state_dict": self.state_dict(), "global_step": self.schedule_step, "epoch": 0,
                     "pytorch-lightning_version": "1.3.8",
+                    "optimizer_states": [self.store.optimizer_state()],
+                    "lr_schedulers": [{"last_epoch": self.schedule_step}],
+                    "freeze_schedule": {"steps": self.steps, "is_wav2vec_frozen": self._is_wav2vec_frozen},
                     "hyper_parameters": {"num_speakers": self.num_speakers, "loss": self.loss}}, path)
 
     @classmethod
     def load_from_checkpoint(cls, checkpoint_path: str, strict: bool = False, **kwargs) -> "Wav2vec2FCModule":
         """ref: src/main.py:272-283 (``network_class.load_from_checkpoint(path, strict=False, **kwargs)``): construct
-        from kwargs, then load ``checkpoint["state_dict"]``.  Non-strict: unknown keys (e.g. BatchNorm buffers,
-        ``num_batches_tracked``) are skipped, tensors whose shape differs from this module's (a head re-sized through
-        ``explicit_num_speakers``) and missing ones keep their fresh initialisation."""
-        module = cls(**kwargs)
+        from the reference's kwargs, then load ``checkpoint["state_dict"]``.  Non-strict: unknown keys are skipped,
+        tensors whose shape differs from this module's (a head re-sized through ``explicit_num_speakers``) and
+        missing ones keep their fresh initialisation.  Optimiser moments, the loss scale and the schedule position
+        resume when the checkpoint has them and the arena still has the same size."""
+        kwargs.setdefault("hyperparameters_to_save", None)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")              # weights come from the checkpoint, not from "pretrained"
+            module = cls(**kwargs)
         ckpt = torch.load(checkpoint_path, map_location="cpu", weights_only=False)
         sd = ckpt["state_dict"] if "state_dict" in ckpt else ckpt
         if not strict:
             shapes = module.store.shapes
             sd = {k: v for k, v in sd.items() if k not in shapes or tuple(v.shape) == tuple(shapes[k])}
         module.load_state_dict(sd, strict=strict)
-        module.steps = int(ckpt.get("global_step", 0)) if isinstance(ckpt, dict) else 0
+        if isinstance(ckpt, dict):
+            module.schedule_step = int(ckpt.get("global_step", 0))
+            fs = ckpt.get("freeze_schedule") or {}
+            module.steps = int(fs.get("steps", module.schedule_step))
+            module._is_wav2vec_frozen = bool(fs.get("is_wav2vec_frozen", False))
+            for ost in ckpt.get("optimizer_states") or []:
+                try:
+                    module.store.load_optimizer_state(ost)
+                except ValueError:
+                    if strict:
+                        raise
         return module

@@ -15,7 +15,8 @@ from . import _lib
 from ._lib import (BF16, EPI_ADD, EPI_BIAS, EPI_BIAS_GELU, EPI_GELU_BWD, EPI_NONE, EPI_SCALE_RC, F16, F32,
                    GemmDesc)
 
-POOL_MODES = {"mean+std": 0, "mean": 1, "max": 2, "first": 3, "first+cls": 3, "last": 4, "middle": 4}
+POOL_MODES = {"mean+std": 0, "mean": 1, "max": 2, "first": 3, "first+cls": 3, "last": 4, "middle": 4, "quantile": 5}
+POOL_WIDTH = {0: 2, 5: 5}      # output features per input feature (default 1)
 
 
 def lib():
@@ -449,14 +450,15 @@ def row_invnorm(x, inv, rows: int, cols: int, ld: Optional[int] = None) -> None:
 
 
 def aam_softmax_fwd_bwd(cos, label, softmax, loss_rows, dcos_w, dcos_x, inv_x, inv_w, rowdot, coldot, B: int,
-                        Cn: int, ldc: int, margin: float, scale: float, loss_scale=None) -> None:
-    """loss_scale: device tensor whose first element multiplies the loss gradient (fp16 loss scaling), or None."""
-    _dev(cos, label, softmax, loss_rows, dcos_w, dcos_x, inv_x, inv_w, rowdot, coldot, loss_scale)
+                        Cn: int, ldc: int, margin: float, scale: float, loss_scale=None, correct_rows=None) -> None:
+    """loss_scale: device tensor whose first element multiplies the loss gradient (fp16 loss scaling), or None.
+    correct_rows [B] f32 (optional): 1 where the arg-max prediction equals the label (train_acc)."""
+    _dev(cos, label, softmax, loss_rows, dcos_w, dcos_x, inv_x, inv_w, rowdot, coldot, loss_scale, correct_rows)
     dty = dt(dcos_w) if dcos_w is not None else F32
     _lib.check(lib().w2v2_aam_softmax_fwd_bwd(cos.data_ptr(), label.data_ptr(), softmax.data_ptr(),
                                               loss_rows.data_ptr(), _p(dcos_w), _p(dcos_x), _p(inv_x), _p(inv_w),
-                                              _p(rowdot), _p(coldot), B, Cn, ldc, margin, scale, _p(loss_scale), dty,
-                                              stream()),
+                                              _p(rowdot), _p(coldot), B, Cn, ldc, margin, scale, _p(loss_scale),
+                                              _p(correct_rows), dty, stream()),
                "aam_softmax")
 
 

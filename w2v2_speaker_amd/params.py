@@ -75,19 +75,34 @@ class ParamStore:
     def __init__(self, cfg: W2V2Config, device, act_dtype: torch.dtype = torch.bfloat16,
                  head: Optional[str] = "aam", num_speakers: int = 5994, embed_dim: Optional[int] = None,
                  freeze_cnn: bool = True, attentive_pool: bool = False, attention_channels: int = 128,
-                 init_loss_scale: float = 16384.0, two_term_weights: bool = True):
+                 init_loss_scale: float = 16384.0, two_term_weights: bool = True, hidden_fc: Tuple[int, ...] = ()):
+        """embed_dim: size of the pooled embedding (statistics-pooling output).  hidden_fc: output sizes of the hidden
+        Linear+ReLU layers between pooling and the loss head (ref: wav2vec2_fc.py:185-228 ``hidden_fc_layers_out``);
+        the CE head's Linear is fc_list.{len(hidden_fc)}.0, the AAM weight keeps input size embed_dim like the
+        reference (wav2vec2_fc.py:212-224)."""
         assert act_dtype in (torch.bfloat16, torch.float16, torch.float32)
         assert head in (None, "aam", "ce", "bce")
         self.cfg, self.device, self.act_dtype = cfg, torch.device(device), act_dtype
         self.head, self.num_speakers, self.freeze_cnn = head, num_speakers, freeze_cnn
         self.embed_dim = embed_dim if embed_dim is not None else 2 * cfg.hidden_size
         shapes: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()
+        self.hidden_fc = tuple(int(h) for h in hidden_fc)
+        dims = [self.embed_dim] + list(self.hidden_fc)
+        self.head_in_dim = dims[-1]
         if head == "aam":
+            if self.hidden_fc and dims[-1] != self.embed_dim:
+                raise ValueError("AAM head: the reference builds the AAM weight with input_features = the pooled "
+                                 f"embedding size ({self.embed_dim}); the last hidden layer must have that size")
             shapes["loss_fn.fc_weights"] = (num_speakers, self.embed_dim)
         elif head == "ce":
-            shapes["fc_list.0.0.weight"] = (num_speakers, self.embed_dim)
-            shapes["fc_list.0.0.bias"] = (num_speakers,)
-        elif head == "bce":         # paired-input equality head (ref: wav2vec2_paired_input.py:108-110 ``self.linear``)
+            n = len(self.hidden_fc)
+            shapes[f"fc_list.{n}.0.weight"] = (num_speakers, dims[-1])
+            shapes[f"fc_list.{n}.0.bias"] = (num_speakers,)
+        if head in ("aam", "ce"):
+            for i, h in enumerate(self.hidden_fc):
+                shapes[f"fc_list.{i}.0.weight"] = (h, dims[i])
+                shapes[f"fc_list.{i}.0.bias"] = (h,)
+        if head == "bce":         # paired-input equality head (ref: wav2vec2_paired_input.py:108-110 ``self.linear``)
             self.embed_dim = embed_dim if embed_dim is not None else cfg.hidden_size
             shapes["linear.weight"] = (1, self.embed_dim)
             shapes["linear.bias"] = (1,)
@@ -95,6 +110,7 @@ class ParamStore:
         # BatchNorm1d buffers {running_mean[A], running_var[A]} of the attentive pooling, shared by every plan
         self.asp_running = (torch.cat([torch.zeros(attention_channels), torch.ones(attention_channels)]).to(device)
                             if attentive_pool else None)
+        self.asp_batches_tracked = 0
         if attentive_pool:      # pooling parameters sit with the classifier: same gradient bucket and Adam slice
             from .asp import asp_param_shapes
             shapes.update(asp_param_shapes(cfg.hidden_size, attention_channels))
@@ -112,6 +128,10 @@ class ParamStore:
         self.n_total = off
         if self.n_train is None:
             self.n_train = off
+        # first arena element of the conv feature extractor; `cnn_runtime_frozen` is the run-time form of
+        # ``feature_extractor.requires_grad_(False)`` for a store that owns CNN gradient buffers
+        self.n_body = self.offsets[W2V_PREFIX + f"feature_extractor.conv_layers.{len(cfg.conv_dim) - 1}.conv.weight"]
+        self.cnn_runtime_frozen = False
         dev = self.device
         self.flat = torch.zeros(self.n_total, dtype=torch.float32, device=dev)
         self.grad = torch.zeros(self.n_train, dtype=torch.float32, device=dev)
@@ -261,7 +281,14 @@ class ParamStore:
         """Accepts reference-style keys (``wav2vec.model.*``) or bare HF keys (prefix_model adds the prefix),
         and both weight-norm namings."""
         seen = set()
+        buffers = self._buffers()
         for k, v in sd.items():
+            if k in buffers:                               # BatchNorm running statistics of the attentive pooling
+                buffers[k].copy_(torch.as_tensor(v).to(self.device, torch.float32))
+                continue
+            if k.endswith("num_batches_tracked") and self.asp_running is not None:
+                self.asp_batches_tracked = int(v)
+                continue
             k = _WN_OLD.get(k, k)
             for old, new in _WN_OLD.items():
                 if k.endswith(old):
@@ -281,8 +308,44 @@ class ParamStore:
             raise KeyError(f"missing keys: {missing[:5]}{'...' if len(missing) > 5 else ''}")
         self.sync_lowp()
 
+    def _buffers(self) -> "OrderedDict[str, torch.Tensor]":
+        """Non-parameter state under the reference's key names: the BatchNorm1d buffers of the attentive pooling
+        (speechbrain ``stat_pooling.pooling_layer.tdnn.norm.norm.running_{mean,var}``)."""
+        out: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+        if self.asp_running is not None:
+            from .asp import ASP_PREFIX
+            A = self.asp_running.numel() // 2
+            out[ASP_PREFIX + "tdnn.norm.norm.running_mean"] = self.asp_running[:A]
+            out[ASP_PREFIX + "tdnn.norm.norm.running_var"] = self.asp_running[A:]
+        return out
+
     def state_dict(self) -> "OrderedDict[str, torch.Tensor]":
-        return OrderedDict((n, self.p(n).detach().clone().cpu()) for n in self.shapes)
+        sd = OrderedDict((n, self.p(n).detach().clone().cpu()) for n in self.shapes)
+        for n, b in self._buffers().items():
+            sd[n] = b.detach().clone().cpu()
+        if self.asp_running is not None:
+            from .asp import ASP_PREFIX
+            sd[ASP_PREFIX + "tdnn.norm.norm.num_batches_tracked"] = torch.tensor(self.asp_batches_tracked)
+        return sd
+
+    # ------------------------------------------------------------------ optimiser / schedule state (resume)
+    def optimizer_state(self) -> Dict[str, object]:
+        """What a PL checkpoint keeps under ``optimizer_states`` (torch Adam's exp_avg / exp_avg_sq / step) plus the
+        fp16 loss-scale record: a resume continues the moments, the bias correction and the scale."""
+        z = lambda t: None if t is None else t.detach().clone().cpu()
+        return {"exp_avg": z(self.exp_avg), "exp_avg_sq": z(self.exp_avg_sq), "step_head": self.step_head,
+                "step_body": self.step_body, "loss_scaler": z(self.scaler)}
+
+    def load_optimizer_state(self, st: Dict[str, object]) -> None:
+        if st.get("exp_avg") is not None:
+            ea, es = torch.as_tensor(st["exp_avg"]), torch.as_tensor(st["exp_avg_sq"])
+            if ea.numel() != self.n_train:
+                raise ValueError(f"optimizer state of {ea.numel()} elements does not fit this arena ({self.n_train})")
+            self.exp_avg, self.exp_avg_sq = ea.to(self.device, torch.float32), es.to(self.device, torch.float32)
+        self.step_head, self.step_body = int(st.get("step_head", 0)), int(st.get("step_body", 0))
+        self.step_count = max(self.step_head, self.step_body)
+        if self.scaler is not None and st.get("loss_scaler") is not None:
+            self.scaler.copy_(torch.as_tensor(st["loss_scaler"]).to(self.device))
 
     def init_weights(self, seed: int = 20211) -> None:
         """Random initialisation in the spirit of HF ``_init_weights`` (HF:1100-1140) and
@@ -300,6 +363,8 @@ class ParamStore:
                 t = torch.zeros(s)
             elif n == "loss_fn.fc_weights":
                 t = torch.randn(s, generator=g) * math.sqrt(2.0 / (s[0] + s[1]))
+            elif n.startswith("fc_list.") and leaf == "weight":       # nn.Linear default: U(-1/sqrt(in), 1/sqrt(in))
+                t = (torch.rand(s, generator=g) * 2 - 1) / math.sqrt(s[1])
             elif n.endswith("original1"):
                 t = torch.randn(s, generator=g) * (2.0 * math.sqrt(1.0 / (s[2] * s[1] * self.cfg.num_conv_pos_embedding_groups)))
             elif "feature_extractor" in n:
@@ -346,15 +411,16 @@ class ParamStore:
         self.step_count = max(self.step_head, self.step_body)
         a = (self.flat, self.grad, self.exp_avg, self.exp_avg_sq)
         lp, sc = self.flat_lp, self.scaler
+        n_train = min(self.n_train, self.n_body) if self.cnn_runtime_frozen else self.n_train
         if sc is not None:        # found_inf over the slice this step updates; Adam skips itself when it is set
-            ops.grad_scaler_check(self.grad, h if head_only else self.n_train, sc)
+            ops.grad_scaler_check(self.grad, h if head_only else n_train, sc)
         if head_only:
             ops.adam_step(*a, lp, h, lr, beta1, beta2, eps, self.step_head, grad_scale, sc)
         elif self.step_head == self.step_body or h == 0:
-            ops.adam_step(*a, lp, self.n_train, lr, beta1, beta2, eps, self.step_body, grad_scale, sc)
+            ops.adam_step(*a, lp, n_train, lr, beta1, beta2, eps, self.step_body, grad_scale, sc)
         else:
             ops.adam_step(*a, lp, h, lr, beta1, beta2, eps, self.step_head, grad_scale, sc)
-            ops.adam_step(*(t[h:] for t in a), lp[h:] if lp is not None else None, self.n_train - h, lr, beta1,
+            ops.adam_step(*(t[h:] for t in a), lp[h:] if lp is not None else None, n_train - h, lr, beta1,
                           beta2, eps, self.step_body, grad_scale, sc)
         if sc is not None:
             ops.grad_scaler_update(sc)
