@@ -342,8 +342,26 @@ def golden_optim():
     print("g8_optim ok")
 
 
+def golden_bce():
+    """ref: src/optim/loss/binary_cross_entropy.py:24-40 (``BinaryCrossEntropyLoss``, the loss of the paired-input
+    model) run as is: loss, prediction and d(loss)/d(logits) on seeded logits incl. saturated ones (|logit| = 40:
+    the numerically stable branch) and both label values; [B, 1] logits like the module's nn.Linear(H, 1) output."""
+    from src.optim.loss.binary_cross_entropy import BinaryCrossEntropyLoss
+    rng = np.random.Generator(np.random.PCG64(9))
+    logits = rng.standard_normal((24, 1)).astype(np.float32) * 3.0
+    logits[:4, 0] = [40.0, -40.0, 0.0, 17.5]
+    label = rng.integers(0, 2, size=(24,)).astype(np.int64)
+    label[:4] = [0, 1, 1, 1]
+    lg = torch.from_numpy(logits).requires_grad_(True)
+    loss, pred = BinaryCrossEntropyLoss()(lg, torch.from_numpy(label))
+    loss.backward()
+    g = {"logits": logits, "label": label, "loss": loss.detach(), "prediction": pred, "dlogits": lg.grad}
+    np.savez_compressed(os.path.join(OUT, "g9_bce.npz"), **to_np(g))
+    print("g9_bce: loss", float(loss))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["tiny", "base", "aam", "pool", "eval", "optim"]
+    which = sys.argv[1:] or ["tiny", "base", "aam", "pool", "eval", "optim", "bce"]
     for wname in which:
         {"tiny": golden_tiny, "base": golden_base, "aam": golden_aam, "pool": golden_pool,
-         "eval": golden_eval, "optim": golden_optim}[wname]()
+         "eval": golden_eval, "optim": golden_optim, "bce": golden_bce}[wname]()

@@ -800,6 +800,38 @@ def test_fused_adam_matches_torch_and_golden(lp):
     assert np.allclose(pd.cpu().numpy(), ref.detach().numpy(), atol=1e-6)
 
 
+def test_bce_head_vs_reference_golden():
+    """w2v2_bce_head_fwd_bwd (Linear(H, 1) + BCE-with-logits) against the reference's BinaryCrossEntropyLoss golden
+    (ref: src/optim/loss/binary_cross_entropy.py:24-40; logits produced by a known embedding / weight pair), incl. the
+    saturated logits of the stable branch, the loss scale and an out-of-range label (NaN loss row, zero gradient)."""
+    o = ops()
+    g = np.load(os.path.join(GOLDEN, "g9_bce.npz"))
+    logits, label = torch.from_numpy(g["logits"])[:, 0], torch.from_numpy(g["label"])
+    B, H = logits.shape[0], 16
+    w = rnd(H, seed=1)
+    emb = torch.zeros(B, H)
+    emb[:, 0] = (logits - 0.25) / w[0]                     # emb . w + b == logits with b = 0.25
+    b = torch.tensor([0.25])
+    prob, rows = torch.zeros(B, device=DEV), torch.zeros(B, device=DEV)
+    dl, de = torch.zeros(B, device=DEV), torch.zeros(B, H, device=DEV)
+    dw, db = torch.zeros(H, device=DEV), torch.zeros(1, device=DEV)
+    o.bce_head_fwd_bwd(emb.to(DEV), w.to(DEV), b.to(DEV), label.to(DEV), prob, rows, dl, de, dw, db, B, H)
+    torch.cuda.synchronize()
+    assert abs(float(rows.mean()) - float(g["loss"])) < 2e-5
+    assert np.allclose(prob.cpu().numpy(), g["prediction"], atol=2e-6)
+    assert np.allclose(dl.cpu().numpy(), g["dlogits"][:, 0], atol=1e-7)
+    assert rel_l2(de.cpu(), torch.from_numpy(g["dlogits"]) * w[None, :]) < 1e-5
+    assert rel_l2(dw.cpu(), (torch.from_numpy(g["dlogits"]) * emb).sum(0)) < 1e-5
+    scale = torch.tensor([8.0, 0, 0, 0], device=DEV)
+    lab2 = label.clone()
+    lab2[5] = 2
+    o.bce_head_fwd_bwd(emb.to(DEV), w.to(DEV), b.to(DEV), lab2.to(DEV), prob, rows, dl, de, dw, db, B, H, scale)
+    torch.cuda.synchronize()
+    ref = torch.from_numpy(g["dlogits"][:, 0]).clone() * 8.0
+    ref[5] = 0.0
+    assert np.allclose(dl.cpu().numpy(), ref.numpy(), atol=1e-6) and bool(torch.isnan(rows[5])) and float(de[5].abs().max()) == 0
+
+
 def test_grad_scaler_check_update_and_adam_skip():
     """Dynamic loss scaling (csrc/optim.hip) = torch.cuda.amp.GradScaler: gradients are divided by the scale inside
     Adam, a step with a non-finite gradient changes nothing and halves the scale, `growth_interval` clean steps

@@ -128,6 +128,18 @@ def test_pooling_goldens_incl_edges():
         assert np.array_equal(O.index_pool(x, "middle").detach().numpy(), g[name + ".middle"])
 
 
+def test_bce_loss_vs_reference_golden():
+    """oracle.bce_with_logits pinned by ref: src/optim/loss/binary_cross_entropy.py:24-40 run in the authoring
+    container (tests/golden/make_goldens.py bce): loss, prediction, gradient wrt the logits."""
+    g = load("g9_bce.npz")
+    lg = T(g["logits"]).requires_grad_(True)
+    loss, pred = O.bce_with_logits(lg, T(g["label"]))
+    loss.backward()
+    assert abs(float(loss) - float(g["loss"])) < 1e-6
+    assert np.allclose(pred.numpy(), g["prediction"], atol=1e-7)
+    assert np.allclose(lg.grad.numpy(), g["dlogits"], atol=1e-8)
+
+
 def test_eer_mdc_cosine_normaliser():
     g = load("g6_eval.npz")
     eer, thr = O.calculate_eer(g["gt"], g["scores"])

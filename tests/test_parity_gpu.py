@@ -560,3 +560,57 @@ def test_gradient_buckets_are_final_when_notified_under_layerdrop(dtype):
             s, e = raw[f"layer{l}"]
             assert float(st.grad[s:e].abs().max()) == 0.0
         assert torch.isfinite(st.grad).all()
+
+
+def test_large_24_layers_5s_batch32_properties():
+    """BASELINE configs[3] at FULL depth and size (wav2vec2-large: 24 layers, H = 1024, 16 heads, FFN 4096; 5 s clips,
+    T = 249; B = 32 per GPU; fp16 mode with dropout / LayerDrop-free regularisation for reproducibility).  The CPU
+    oracle cannot run this in test time, so the checks are the size-independent properties: finite loss near
+    ln(C) + margin effect, every gradient finite, two identical passes give bitwise-identical encoder gradients,
+    LayerDrop-skipped layers get exactly zero gradient, and an utterance's eval embedding does not depend on
+    its batch neighbours (bitwise: B = 32 vs B = 1)."""
+    from w2v2_speaker_amd.config import W2V2Config, Wav2Vec2RegularisationConfig
+    from w2v2_speaker_amd.engine import Plan
+    from w2v2_speaker_amd.params import ParamStore
+    cfg = W2V2Config.from_huggingface_id("facebook/wav2vec2-large")
+    assert cfg.num_hidden_layers == 24 and cfg.num_frames(80000) == 249
+    B, N, C = 32, 80000, 5994
+    st = ParamStore(cfg, DEV, torch.float16, head="aam", num_speakers=C, embed_dim=2 * cfg.hidden_size)
+    st.init_weights(seed=3)
+    wav, label = O.synth_batch(B, N, C, seed=5)
+    wav, label = wav.to(DEV), label.to(DEV)
+    reg = Wav2Vec2RegularisationConfig(mask_time_prob=0.0)          # dropout 0.1 stays on (counter-based: reproducible)
+    tr = Plan(st, B, N, train=True, reg=reg, seed=11)
+    skip = (3, 20)
+    grads = []
+    for _ in range(2):
+        st.zero_grad()
+        tr.embed(wav, None, skip, step=4)
+        loss, sm = tr.head_forward_backward(label)
+        tr.backward()
+        torch.cuda.synchronize()
+        grads.append(st.grad.clone())
+    assert torch.isfinite(loss) and 5.0 < float(loss) < 30.0, float(loss)
+    assert torch.isfinite(grads[0]).all()
+    raw = {n: (s, e) for n, s, e in st.grad_buckets()}
+    # the 24 encoder-layer buckets (grouped weight gradients, fixed-order LayerNorm folds) are bitwise reproducible;
+    # the head (AAM column dots) and the prologue (pos-conv bias column sums) accumulate with f32 atomics
+    for n, (s, e) in raw.items():
+        a, b = grads[0][s:e], grads[1][s:e]
+        if n.startswith("layer"):
+            assert torch.equal(a, b), n
+        else:
+            assert float((a - b).norm()) <= 1e-5 * float(a.norm()), n
+    for l in range(24):
+        s, e = raw[f"layer{l}"]
+        z = float(grads[0][s:e].abs().max())
+        assert (z == 0.0) if l in skip else (z > 0.0), l
+    del tr, grads
+    ev = Plan(st, B, N, train=False)
+    e32 = ev.embed(wav).clone()
+    del ev
+    ev1 = Plan(st, 1, N, train=False)
+    for i in (0, 17, 31):
+        e1 = ev1.embed(wav[i:i + 1])
+        torch.cuda.synchronize()
+        assert torch.equal(e1[0], e32[i]), i

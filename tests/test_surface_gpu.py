@@ -109,7 +109,7 @@ def test_attentive_stat_pool_module_vs_restated_definition(dim_to_reduce):
         got = flat_grad[o:o + od[oname].numel()].view(*shp).cpu()
         ref_g = od[oname].grad.view(*shp)
         # (conv.conv.bias: the softmax over time is invariant to a per-channel shift -> its gradient is pure round-off)
-        assert float((got - ref_g).norm()) < 2e-3 * float(ref_g.norm()) + 1e-6, sb
+        assert float((got - ref_g).norm()) < 2e-3 * float(ref_g.norm()) + 1e-5, sb
     assert float(views["pooling_layer.tdnn.norm.norm.running_mean"].abs().sum()) > 0         # updated by train()
     mod.eval()
     with torch.no_grad():
