@@ -511,11 +511,14 @@ def _attn_ref(qkv, B, T, heads, d, mask=None, keep=1.0):
     return (p @ v).transpose(1, 2).reshape(B, T, H)
 
 
-@pytest.mark.parametrize("T", [149, 150, 249, 64, 12, 256])
+@pytest.mark.parametrize("T", [149, 150, 249, 64, 12, 256, 161, 301, 1024, 7249])
 @pytest.mark.parametrize("lp", LP16)
 def test_fused_attention_fwd_bwd(T, lp):
+    """T <= 160: one workgroup per (batch, head); longer: the tiled (online-softmax) kernels -- the paired-input
+    model's T = 301, 1024, and a ~145 s evaluation utterance (T = 7249) -- against an f64 reference of the same
+    16-bit-rounded inputs."""
     o = ops()
-    B, heads, d = 2, 3, 64
+    B, heads, d = (2, 3, 64) if T <= 1024 else (1, 2, 64)
     H = heads * d
     qkv = rnd(B, T, 3 * H, seed=T, scale=1.0)
     qkv[..., :2 * H] *= 1.5                         # non-trivial softmax
@@ -543,12 +546,16 @@ def test_fused_attention_fwd_bwd(T, lp):
 
 
 @pytest.mark.parametrize("lp", LP16)
-def test_fused_attention_dropout_mask_recovered_and_consistent(lp):
-    """T = 64: with q = k = 0 (uniform P) and V = identity the output IS the dropout mask; then the
-    forward/backward with that exact mask must match the torch reference."""
+@pytest.mark.parametrize("T", [64, 200])
+def test_fused_attention_dropout_mask_recovered_and_consistent(lp, T):
+    """With q = k = 0 (uniform P) and V = one-hot rows the output IS the dropout mask (T = 64: V = identity; T = 200,
+    the tiled kernels: four passes of 64 keys each, V rows of the pass's keys one-hot); then the forward/backward
+    with that exact mask must match the torch reference."""
     o = ops()
-    B, heads, d, T, p, seed = 2, 2, 64, 64, 0.1, 991
+    B, heads, d, p, seed = 2, 2, 64, 0.1, 991
     H = heads * d
+    if T > 64:
+        return _attention_dropout_tiled(o, lp, B, heads, d, T, p, seed)
     probe = torch.zeros(B, T, 3 * H)
     probe[..., 2 * H:] = torch.eye(T).repeat(1, heads)[None]
     ctx = torch.zeros(B, T, H, dtype=lp, device=DEV)
@@ -558,6 +565,36 @@ def test_fused_attention_dropout_mask_recovered_and_consistent(lp):
     m = (ctx.float().cpu().view(B, T, heads, d).transpose(1, 2) > 0).double()       # [B,h,q,key]
     keep = float(m.mean())
     assert abs(keep - (1 - p)) < 0.02
+    qkv = (rnd(B, T, 3 * H, seed=5)).to(lp).float()
+    dctx = (rnd(B, T, H, seed=6)).to(lp).float()
+    qr = qkv.double().requires_grad_(True)
+    ref = _attn_ref(qr, B, T, heads, d, mask=m, keep=1 - p)
+    ref.backward(dctx.double())
+    qd = qkv.to(lp).to(DEV)
+    o.attention_fwd(qd, ctx, lse, B, T, heads, d, d ** -0.5, p, seed)
+    dqkv = torch.zeros(B, T, 3 * H, dtype=lp, device=DEV)
+    delta = torch.zeros(B * heads * T, device=DEV)
+    o.attention_bwd(qd, ctx, dctx.to(lp).to(DEV), lse, dqkv, delta, B, T, heads, d, d ** -0.5, p, seed)
+    torch.cuda.synchronize()
+    assert rel_l2(ctx.float().cpu(), ref.detach()) < 1e-2
+    assert rel_l2(dqkv.float().cpu(), qr.grad) < 2.5e-2
+
+
+def _attention_dropout_tiled(o, lp, B, heads, d, T, p, seed):
+    H = heads * d
+    m = torch.zeros(B, heads, T, T, dtype=torch.float64)
+    ctx = torch.zeros(B, T, H, dtype=lp, device=DEV)
+    lse = torch.zeros(B * heads * T, device=DEV)
+    for k0 in range(0, T, d):                       # keys k0 .. k0+63 made visible through one-hot value rows
+        probe = torch.zeros(B, T, 3 * H)
+        n = min(d, T - k0)
+        for h in range(heads):
+            probe[:, k0:k0 + n, 2 * H + h * d:2 * H + h * d + n] = torch.eye(n)
+        o.attention_fwd(probe.to(lp).to(DEV), ctx, lse, B, T, heads, d, d ** -0.5, p, seed)
+        torch.cuda.synchronize()
+        c = ctx.float().cpu().view(B, T, heads, d).transpose(1, 2)            # [B, h, q, d] = P_drop[q, k0 + d]
+        m[..., k0:k0 + n] = (c[..., :n] > 0).double()
+    assert abs(float(m.mean()) - (1 - p)) < 0.02
     qkv = (rnd(B, T, 3 * H, seed=5)).to(lp).float()
     dctx = (rnd(B, T, H, seed=6)).to(lp).float()
     qr = qkv.double().requires_grad_(True)

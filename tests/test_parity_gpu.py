@@ -614,3 +614,66 @@ def test_large_24_layers_5s_batch32_properties():
         e1 = ev1.embed(wav[i:i + 1])
         torch.cuda.synchronize()
         assert torch.equal(e1[0], e32[i]), i
+
+
+def test_long_utterance_and_paired_model_run_on_the_tiled_attention():
+    """every real test utterance (B = 1, up to ~145 s = 7249 frames, ref:
+    speaker_recognition_module.py:462-500) and the paired model at its real size (T = 2*149+3 = 301, ref:
+    wav2vec2_paired_input.py:163-207) take the fused (tiled) attention.  (i) a small d = 64 model on a 20 s utterance
+    against the CPU oracle; (ii) w2v2-base on a 145 s utterance: fused vs the unfused path that materialises the
+    [12, 7249, 7249] scores; (iii) the paired base model: logits, loss and every gradient bucket fused vs unfused."""
+    import dataclasses
+    from w2v2_speaker_amd.config import W2V2Config
+    from w2v2_speaker_amd.engine import Plan
+    from w2v2_speaker_amd.params import ParamStore
+    # (i) oracle parity at T = 999 (> 160: tiled kernels), fp16
+    cfg = dataclasses.replace(W2V2Config.tiny(), hidden_size=128, num_attention_heads=2, intermediate_size=256)
+    ocfg = dataclasses.replace(O.OracleConfig.tiny(), hidden_size=128, num_attention_heads=2, intermediate_size=256)
+    N = 320000
+    assert cfg.num_frames(N) == 999 and cfg.head_dim == 64
+    st, sd = _store(cfg, ocfg, torch.float16, None, 1)
+    wav, _ = O.synth_batch(1, N, 2, seed=8)
+    ev = Plan(st, 1, N, train=False)
+    assert ev.fused
+    e = ev.embed(wav.to(DEV))
+    torch.cuda.synchronize()
+    assert rel_l2(e.cpu(), O.speaker_embedding(wav, sd, ocfg)) < 3e-3
+    del ev
+    # (ii) base model, 145 s
+    cfg, ocfg = _cfgs("base")
+    st, _ = _store(cfg, ocfg, torch.float16, None, 1)
+    N = 2319840
+    assert cfg.num_frames(N) == 7249
+    wav, _ = O.synth_batch(1, N, 2, seed=9)
+    ev = Plan(st, 1, N, train=False)
+    assert ev.fused and ev.T == 7249
+    e = ev.embed(wav.to(DEV)).clone()
+    del ev
+    un = Plan(st, 1, N, train=False, fused_attention=False)
+    e2 = un.embed(wav.to(DEV))
+    torch.cuda.synchronize()
+    assert torch.isfinite(e).all() and rel_l2(e.cpu(), e2.cpu()) < 2e-3
+    del un
+    # (iii) paired-input model at its real size
+    stp = ParamStore(cfg, DEV, torch.float16, head="bce")
+    stp.init_weights(seed=4)
+    stp.scaler[0] = 256.0
+    B = 3
+    wl, _ = O.synth_batch(2 * B, 48000, 2, seed=10)
+    label = torch.tensor([1, 0, 1], device=DEV)
+    res = []
+    for fused in (True, False):
+        plan = Plan(stp, B, 48000, train=True, reg=_no_reg(), pooling="first", paired=True, fused_attention=fused)
+        assert plan.T == 301 and plan.fused == fused
+        stp.zero_grad()
+        plan.embed(wl[:, 0].to(DEV))
+        loss, pred = plan.head_forward_backward(label)
+        plan.backward()
+        torch.cuda.synchronize()
+        res.append((float(loss), pred.clone(), stp.grad.clone()))
+        del plan
+    assert abs(res[0][0] - res[1][0]) < 2e-3 * abs(res[1][0]) and torch.allclose(res[0][1], res[1][1], atol=2e-3)
+    assert torch.isfinite(res[0][2]).all()
+    for n, s_, e_ in stp.grad_buckets():
+        a, b = res[0][2][s_:e_], res[1][2][s_:e_]
+        assert float((a - b).norm()) < 3e-2 * float(b.norm()) + 1e-6, n

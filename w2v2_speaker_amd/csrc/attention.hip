@@ -92,43 +92,6 @@ __device__ __forceinline__ float frag_dot(frag8_t a, frag8_t b) {
   return s;
 }
 
-// rows [0, n_pad) x 64 bf16 from global (row stride gs elements) -> LDS [n_pad][64], chunk-swizzled
-__device__ __forceinline__ void lds_load_rows(bf16_t* lds, const bf16_t* g, int64_t gs, int n_valid, int n_pad) {
-  for (int c = threadIdx.x; c < n_pad * 8; c += 256) {
-    const int row = c >> 3, ch = c & 7;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (row < n_valid) v = *reinterpret_cast<const uint4*>(g + (int64_t)row * gs + ch * 8);
-    *reinterpret_cast<uint4*>(lds + row * 64 + ((ch ^ aswz(row)) << 3)) = v;
-  }
-}
-// same rows, transposed -> LDS [64][pitch]; 4 rows x 8 cols micro-blocks transposed in registers
-__device__ __forceinline__ void lds_load_rows_t(bf16_t* ldst, const bf16_t* g, int64_t gs, int n_valid, int n_pad,
-                                                int pitch) {
-  for (int blk = threadIdx.x; blk < (n_pad >> 2) * 8; blk += 256) {
-    const int cb = blk & 7, rb = blk >> 3;
-    uint32_t w[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int row = rb * 4 + i;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (row < n_valid) v = *reinterpret_cast<const uint4*>(g + (int64_t)row * gs + cb * 8);
-      w[i][0] = v.x; w[i][1] = v.y; w[i][2] = v.z; w[i][3] = v.w;
-    }
-#pragma unroll
-    for (int ci = 0; ci < 8; ++ci) {
-      const int d = ci >> 1;
-      uint2 o;
-      if (ci & 1) {
-        o.x = (w[0][d] >> 16) | (w[1][d] & 0xffff0000u);
-        o.y = (w[2][d] >> 16) | (w[3][d] & 0xffff0000u);
-      } else {
-        o.x = (w[0][d] & 0xffffu) | (w[1][d] << 16);
-        o.y = (w[2][d] & 0xffffu) | (w[3][d] << 16);
-      }
-      *reinterpret_cast<uint2*>(ldst + (cb * 8 + ci) * pitch + rb * 4) = o;
-    }
-  }
-}
 // MFMA fragment (16 rows x 32 k) from the swizzled row-major image
 __device__ __forceinline__ frag8_t lds_frag(const bf16_t* lds, int row0, int kk, int lane) {
   const int fr = lane & 15;                         // row0 is a multiple of 16: swizzle depends on fr only
@@ -157,248 +120,6 @@ __device__ __forceinline__ float quad_max(float v) {
 __device__ __forceinline__ float quad_sum(float v) {
   v += __shfl_xor(v, 16, 64);
   return v + __shfl_xor(v, 32, 64);
-}
-
-// ------------------------------------------------------------------------------------- forward
-template <typename TE, int NF>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx,
-                                                       float* __restrict__ lse, int Tn, int heads, float scale,
-                                                       float dp, float inv_keep, uint64_t seed) {
-  constexpr int TP = NF * 16, PITCH = TP + 4;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  bf16_t* Ks = reinterpret_cast<bf16_t*>(smem);   // [TP][64]
-  bf16_t* Vt = Ks + TP * 64;                      // [64][PITCH]
-  const int b = blockIdx.z, h = blockIdx.y;
-  const int H = heads * HD;
-  const int64_t gs = 3 * (int64_t)H;
-  const bf16_t* qb = qkv + (int64_t)b * Tn * gs + h * HD;
-  lds_load_rows(Ks, qb + H, gs, Tn, TP);
-  lds_load_rows_t(Vt, qb + 2 * H, gs, Tn, TP, PITCH);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
-  const int q = blockIdx.x * 64 + wave * 16 + (lane & 15);
-  frag8_t qf[2];
-  reg_frag(qf, qb, gs, q, Tn, lane);
-  __syncthreads();
-
-  float s[NF][4];
-  float mx = -INFINITY;
-#pragma unroll
-  for (int fj = 0; fj < NF; ++fj) {
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
-      acc = mfma16<TE>(lds_frag(Ks, fj * 16, kk, lane), qf[kk], acc);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int key = fj * 16 + g * 4 + j;
-      s[fj][j] = key < Tn ? acc[j] * scale : -INFINITY;
-      mx = fmaxf(mx, s[fj][j]);
-    }
-  }
-  mx = quad_max(mx);
-  float sum = 0.f;
-#pragma unroll
-  for (int fj = 0; fj < NF; ++fj)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { s[fj][j] = __expf(s[fj][j] - mx); sum += s[fj][j]; }
-  sum = quad_sum(sum);
-  const float inv = 1.0f / sum;
-  const int64_t bh = (int64_t)b * heads + h;
-  if (g == 0 && q < Tn) lse[bh * Tn + q] = mx + __logf(sum);
-#pragma unroll
-  for (int fj = 0; fj < NF; ++fj)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      float pv = s[fj][j] * inv;
-      if (dp > 0.f) pv *= drop_scale(seed, attn_drop_idx(bh, q, fj * 16 + g * 4 + j, Tn), dp, inv_keep);
-      s[fj][j] = pv;
-    }
-  f32x4 o[4];
-#pragma unroll
-  for (int df = 0; df < 4; ++df) o[df] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int kb = 0; kb < NF / 2; ++kb) {
-    const frag8_t pf = pack_frag<TE>(s[2 * kb], s[2 * kb + 1]);
-#pragma unroll
-    for (int df = 0; df < 4; ++df)
-      o[df] = mfma16<TE>(lds_frag_t(Vt, PITCH, df * 16, kb, lane), pf, o[df]);
-  }
-  if (q < Tn) {
-    bf16_t* dst = ctx + ((int64_t)b * Tn + q) * H + h * HD + g * 4;
-#pragma unroll
-    for (int df = 0; df < 4; ++df) {
-      uint2 w;
-      w.x = pack2<TE>(o[df][0], o[df][1]);
-      w.y = pack2<TE>(o[df][2], o[df][3]);
-      *reinterpret_cast<uint2*>(dst + df * 16) = w;
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------- backward: dQ
-template <typename TE, int NF>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv,
-                                                          const bf16_t* __restrict__ ctx,
-                                                          const bf16_t* __restrict__ dctx,
-                                                          const float* __restrict__ lse, bf16_t* __restrict__ dqkv,
-                                                          float* __restrict__ delta, int Tn, int heads, float scale,
-                                                          float dp, float inv_keep, uint64_t seed) {
-  constexpr int TP = NF * 16, PITCH = TP + 4;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  bf16_t* Ks = reinterpret_cast<bf16_t*>(smem);   // [TP][64]
-  bf16_t* Vs = Ks + TP * 64;                      // [TP][64]
-  bf16_t* Kt = Vs + TP * 64;                      // [64][PITCH]
-  const int b = blockIdx.z, h = blockIdx.y;
-  const int H = heads * HD;
-  const int64_t gs = 3 * (int64_t)H;
-  const bf16_t* qb = qkv + (int64_t)b * Tn * gs + h * HD;
-  lds_load_rows(Ks, qb + H, gs, Tn, TP);
-  lds_load_rows(Vs, qb + 2 * H, gs, Tn, TP);
-  lds_load_rows_t(Kt, qb + H, gs, Tn, TP, PITCH);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
-  const int q = blockIdx.x * 64 + wave * 16 + (lane & 15);
-  const int64_t bh = (int64_t)b * heads + h;
-  frag8_t qf[2], dof[2], of[2];
-  reg_frag(qf, qb, gs, q, Tn, lane);
-  const bf16_t* dob = dctx + (int64_t)b * Tn * H + h * HD;
-  const bf16_t* ob = ctx + (int64_t)b * Tn * H + h * HD;
-  reg_frag(dof, dob, H, q, Tn, lane);
-  reg_frag(of, ob, H, q, Tn, lane);
-  // delta[q] = sum_d dO*O
-  float dl = 0.f;
-#pragma unroll
-  for (int kk = 0; kk < 2; ++kk) dl += frag_dot<TE>(dof[kk], of[kk]);
-  dl = quad_sum(dl);
-  if (g == 0 && q < Tn) delta[bh * Tn + q] = dl;
-  const float l = q < Tn ? lse[bh * Tn + q] : 0.f;
-  __syncthreads();
-
-  float ds[NF][4];
-#pragma unroll
-  for (int fj = 0; fj < NF; ++fj) {
-    f32x4 sa = {0.f, 0.f, 0.f, 0.f}, pa = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      sa = mfma16<TE>(lds_frag(Ks, fj * 16, kk, lane), qf[kk], sa);
-      pa = mfma16<TE>(lds_frag(Vs, fj * 16, kk, lane), dof[kk], pa);
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int key = fj * 16 + g * 4 + j;
-      const float p = (key < Tn && q < Tn) ? __expf(sa[j] * scale - l) : 0.f;
-      float dpv = pa[j];
-      if (dp > 0.f) dpv *= drop_scale(seed, attn_drop_idx(bh, q, key, Tn), dp, inv_keep);
-      ds[fj][j] = p * (dpv - dl) * scale;
-    }
-  }
-  f32x4 o[4];
-#pragma unroll
-  for (int df = 0; df < 4; ++df) o[df] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int kb = 0; kb < NF / 2; ++kb) {
-    const frag8_t pf = pack_frag<TE>(ds[2 * kb], ds[2 * kb + 1]);
-#pragma unroll
-    for (int df = 0; df < 4; ++df)
-      o[df] = mfma16<TE>(lds_frag_t(Kt, PITCH, df * 16, kb, lane), pf, o[df]);
-  }
-  if (q < Tn) {
-    bf16_t* dst = dqkv + ((int64_t)b * Tn + q) * gs + h * HD + g * 4;
-#pragma unroll
-    for (int df = 0; df < 4; ++df) {
-      uint2 w;
-      w.x = pack2<TE>(o[df][0], o[df][1]);
-      w.y = pack2<TE>(o[df][2], o[df][3]);
-      *reinterpret_cast<uint2*>(dst + df * 16) = w;
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------- backward: dK, dV
-template <typename TE, int NF>
-__global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const bf16_t* __restrict__ qkv,
-                                                          const bf16_t* __restrict__ dctx,
-                                                          const float* __restrict__ lse,
-                                                          const float* __restrict__ delta, bf16_t* __restrict__ dqkv,
-                                                          int Tn, int heads, float scale, float dp, float inv_keep,
-                                                          uint64_t seed) {
-  constexpr int TP = NF * 16, PITCH = TP + 4;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  bf16_t* Qs = reinterpret_cast<bf16_t*>(smem);   // [TP][64]
-  bf16_t* Os = Qs + TP * 64;                      // [TP][64]   dO
-  bf16_t* Qt = Os + TP * 64;                      // [64][PITCH]
-  bf16_t* Ot = Qt + 64 * PITCH;                   // [64][PITCH]  dO^T
-  float* lse_s = reinterpret_cast<float*>(Ot + 64 * PITCH);  // [TP]
-  float* del_s = lse_s + TP;                                 // [TP]
-  const int b = blockIdx.z, h = blockIdx.y;
-  const int H = heads * HD;
-  const int64_t gs = 3 * (int64_t)H;
-  const bf16_t* qb = qkv + (int64_t)b * Tn * gs + h * HD;
-  const bf16_t* dob = dctx + (int64_t)b * Tn * H + h * HD;
-  const int64_t bh = (int64_t)b * heads + h;
-  lds_load_rows(Qs, qb, gs, Tn, TP);
-  lds_load_rows(Os, dob, H, Tn, TP);
-  lds_load_rows_t(Qt, qb, gs, Tn, TP, PITCH);
-  lds_load_rows_t(Ot, dob, H, Tn, TP, PITCH);
-  for (int i = threadIdx.x; i < TP; i += 256) {
-    lse_s[i] = i < Tn ? lse[bh * Tn + i] : 0.f;
-    del_s[i] = i < Tn ? delta[bh * Tn + i] : 0.f;
-  }
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
-  const int key = blockIdx.x * 64 + wave * 16 + (lane & 15);
-  frag8_t kf[2], vf[2];
-  reg_frag(kf, qb + H, gs, key, Tn, lane);
-  reg_frag(vf, qb + 2 * H, gs, key, Tn, lane);
-  __syncthreads();
-
-  float pt[NF][4], dst_[NF][4];
-#pragma unroll
-  for (int fq = 0; fq < NF; ++fq) {
-    f32x4 sa = {0.f, 0.f, 0.f, 0.f}, pa = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      sa = mfma16<TE>(lds_frag(Qs, fq * 16, kk, lane), kf[kk], sa);
-      pa = mfma16<TE>(lds_frag(Os, fq * 16, kk, lane), vf[kk], pa);
-    }
-    const float4 l4 = *reinterpret_cast<const float4*>(lse_s + fq * 16 + g * 4);
-    const float4 d4 = *reinterpret_cast<const float4*>(del_s + fq * 16 + g * 4);
-    const float la[4] = {l4.x, l4.y, l4.z, l4.w}, da[4] = {d4.x, d4.y, d4.z, d4.w};
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int q = fq * 16 + g * 4 + j;
-      const float p = (q < Tn && key < Tn) ? __expf(sa[j] * scale - la[j]) : 0.f;
-      float ms = 1.0f;
-      if (dp > 0.f) ms = drop_scale(seed, attn_drop_idx(bh, q, key, Tn), dp, inv_keep);
-      pt[fq][j] = p * ms;
-      dst_[fq][j] = p * (pa[j] * ms - da[j]) * scale;
-    }
-  }
-  f32x4 dv[4], dk[4];
-#pragma unroll
-  for (int df = 0; df < 4; ++df) { dv[df] = f32x4{0.f, 0.f, 0.f, 0.f}; dk[df] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-#pragma unroll
-  for (int qb2 = 0; qb2 < NF / 2; ++qb2) {
-    const frag8_t pf = pack_frag<TE>(pt[2 * qb2], pt[2 * qb2 + 1]);
-    const frag8_t sf = pack_frag<TE>(dst_[2 * qb2], dst_[2 * qb2 + 1]);
-#pragma unroll
-    for (int df = 0; df < 4; ++df) {
-      dv[df] = mfma16<TE>(lds_frag_t(Ot, PITCH, df * 16, qb2, lane), pf, dv[df]);
-      dk[df] = mfma16<TE>(lds_frag_t(Qt, PITCH, df * 16, qb2, lane), sf, dk[df]);
-    }
-  }
-  if (key < Tn) {
-    bf16_t* dstk = dqkv + ((int64_t)b * Tn + key) * gs + H + h * HD + g * 4;
-    bf16_t* dstv = dstk + H;
-#pragma unroll
-    for (int df = 0; df < 4; ++df) {
-      uint2 w;
-      w.x = pack2<TE>(dk[df][0], dk[df][1]);
-      w.y = pack2<TE>(dk[df][2], dk[df][3]);
-      *reinterpret_cast<uint2*>(dstk + df * 16) = w;
-      w.x = pack2<TE>(dv[df][0], dv[df][1]);
-      w.y = pack2<TE>(dv[df][2], dv[df][3]);
-      *reinterpret_cast<uint2*>(dstv + df * 16) = w;
-    }
-  }
 }
 
 // ===================================================================================== v2: one workgroup per (b, h)
@@ -555,145 +276,6 @@ __global__ __launch_bounds__(256) void attn_fwd2_kernel(const bf16_t* __restrict
         o[df] = mfma16<TE>(lds_frag_t(Vt, PITCH, df * 16, kb, lane), pf, o[df]);
     }
     if (q < Tn) store_row4x4<TE>(ctx + ((int64_t)b * Tn + q) * H + h * HD + g * 4, o);
-  }
-}
-
-template <typename TE, int NF>
-__global__ __launch_bounds__(256) void attn_bwd2_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ ctx,
-                                                        const bf16_t* __restrict__ dctx,
-                                                        const float* __restrict__ lse, bf16_t* __restrict__ dqkv,
-                                                        int Tn, int heads, float scale, float dp, float inv_keep,
-                                                        uint64_t seed) {
-  constexpr int TP = NF * 16, PITCH = TP + 4;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  bf16_t* Ks = reinterpret_cast<bf16_t*>(smem);   // row-major images [TP][64]
-  bf16_t* Vs = Ks + TP * 64;
-  bf16_t* Qs = Vs + TP * 64;
-  bf16_t* Os = Qs + TP * 64;                      // dO
-  bf16_t* Kt = Os + TP * 64;                      // transposed images [64][PITCH]
-  bf16_t* Qt = Kt + 64 * PITCH;
-  bf16_t* Ot = Qt + 64 * PITCH;                   // dO^T
-  float* lse_s = reinterpret_cast<float*>(Ot + 64 * PITCH);   // [TP]
-  float* del_s = lse_s + TP;                                  // [TP]
-  const int b = blockIdx.y, h = blockIdx.x;
-  const int H = heads * HD;
-  const int64_t gs = 3 * (int64_t)H;
-  const bf16_t* qb = qkv + (int64_t)b * Tn * gs + h * HD;
-  const bf16_t* dob = dctx + (int64_t)b * Tn * H + h * HD;
-  const bf16_t* ob = ctx + (int64_t)b * Tn * H + h * HD;
-  const int64_t bh = (int64_t)b * heads + h;
-  {   // two rounds of batched loads (64 staging VGPRs each) instead of one of 128
-    BlkRegs<NF> ra, rb;
-    blk_load<NF>(ra, qb, gs, Tn);
-    blk_load<NF>(rb, qb + H, gs, Tn);
-    blk_store_rows<NF>(ra, Qs);
-    blk_store_t<NF>(ra, Qt, PITCH);
-    blk_store_rows<NF>(rb, Ks);
-    blk_store_t<NF>(rb, Kt, PITCH);
-    blk_load<NF>(ra, qb + 2 * H, gs, Tn);
-    blk_load<NF>(rb, dob, H, Tn);
-    blk_store_rows<NF>(ra, Vs);
-    blk_store_rows<NF>(rb, Os);
-    blk_store_t<NF>(rb, Ot, PITCH);
-  }
-  for (int i = threadIdx.x; i < TP; i += 256) lse_s[i] = i < Tn ? lse[bh * Tn + i] : 0.f;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
-  __syncthreads();
-
-  // ---- phase A: waves own query fragments -> dQ, delta
-#pragma unroll 1
-  for (int qf = wave; qf < NF; qf += 4) {
-    asm volatile("" ::: "memory");   // no LICM of the loop-invariant LDS fragment loads
-    const int q = qf * 16 + (lane & 15);
-    frag8_t qfr[2] = {lds_frag(Qs, qf * 16, 0, lane), lds_frag(Qs, qf * 16, 1, lane)};
-    frag8_t dof[2] = {lds_frag(Os, qf * 16, 0, lane), lds_frag(Os, qf * 16, 1, lane)};
-    frag8_t of[2];
-    reg_frag(of, ob, H, q, Tn, lane);
-    float dl = 0.f;
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) dl += frag_dot<TE>(dof[kk], of[kk]);
-    dl = quad_sum(dl);
-    if (g == 0) del_s[q] = q < Tn ? dl : 0.f;
-    const float l = lse_s[q];
-    float ds[NF][4];
-#pragma unroll
-    for (int fj = 0; fj < NF; ++fj) {
-      f32x4 sa = {0.f, 0.f, 0.f, 0.f}, pa = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        sa = mfma16<TE>(lds_frag(Ks, fj * 16, kk, lane), qfr[kk], sa);
-        pa = mfma16<TE>(lds_frag(Vs, fj * 16, kk, lane), dof[kk], pa);
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int key = fj * 16 + g * 4 + j;
-        const float p = (key < Tn && q < Tn) ? __expf(sa[j] * scale - l) : 0.f;
-        float dpv = pa[j];
-        if (dp > 0.f) dpv *= drop_scale(seed, attn_drop_idx(bh, q, key, Tn), dp, inv_keep);
-        ds[fj][j] = p * (dpv - dl) * scale;
-      }
-    }
-    f32x4 o[4];
-#pragma unroll
-    for (int df = 0; df < 4; ++df) o[df] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int kb = 0; kb < NF / 2; ++kb) {
-      const frag8_t pf = pack_frag<TE>(ds[2 * kb], ds[2 * kb + 1]);
-#pragma unroll
-      for (int df = 0; df < 4; ++df)
-        o[df] = mfma16<TE>(lds_frag_t(Kt, PITCH, df * 16, kb, lane), pf, o[df]);
-    }
-    if (q < Tn) store_row4x4<TE>(dqkv + ((int64_t)b * Tn + q) * gs + h * HD + g * 4, o);
-  }
-  __syncthreads();          // delta complete
-
-  // ---- phase B: waves own key fragments -> dK, dV
-#pragma unroll 1
-  for (int kf = wave; kf < NF; kf += 4) {
-    asm volatile("" ::: "memory");
-    const int key = kf * 16 + (lane & 15);
-    frag8_t kfr[2] = {lds_frag(Ks, kf * 16, 0, lane), lds_frag(Ks, kf * 16, 1, lane)};
-    frag8_t vfr[2] = {lds_frag(Vs, kf * 16, 0, lane), lds_frag(Vs, kf * 16, 1, lane)};
-    float pt[NF][4], dst_[NF][4];
-#pragma unroll
-    for (int fq = 0; fq < NF; ++fq) {
-      f32x4 sa = {0.f, 0.f, 0.f, 0.f}, pa = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        sa = mfma16<TE>(lds_frag(Qs, fq * 16, kk, lane), kfr[kk], sa);
-        pa = mfma16<TE>(lds_frag(Os, fq * 16, kk, lane), vfr[kk], pa);
-      }
-      const float4 l4 = *reinterpret_cast<const float4*>(lse_s + fq * 16 + g * 4);
-      const float4 d4 = *reinterpret_cast<const float4*>(del_s + fq * 16 + g * 4);
-      const float la[4] = {l4.x, l4.y, l4.z, l4.w}, da[4] = {d4.x, d4.y, d4.z, d4.w};
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int q = fq * 16 + g * 4 + j;
-        const float p = (q < Tn && key < Tn) ? __expf(sa[j] * scale - la[j]) : 0.f;
-        float ms = 1.0f;
-        if (dp > 0.f) ms = drop_scale(seed, attn_drop_idx(bh, q, key, Tn), dp, inv_keep);
-        pt[fq][j] = p * ms;
-        dst_[fq][j] = p * (pa[j] * ms - da[j]) * scale;
-      }
-    }
-    f32x4 dv[4], dk[4];
-#pragma unroll
-    for (int df = 0; df < 4; ++df) { dv[df] = f32x4{0.f, 0.f, 0.f, 0.f}; dk[df] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-#pragma unroll
-    for (int qb2 = 0; qb2 < NF / 2; ++qb2) {
-      const frag8_t pf = pack_frag<TE>(pt[2 * qb2], pt[2 * qb2 + 1]);
-      const frag8_t sf = pack_frag<TE>(dst_[2 * qb2], dst_[2 * qb2 + 1]);
-#pragma unroll
-      for (int df = 0; df < 4; ++df) {
-        dv[df] = mfma16<TE>(lds_frag_t(Ot, PITCH, df * 16, qb2, lane), pf, dv[df]);
-        dk[df] = mfma16<TE>(lds_frag_t(Qt, PITCH, df * 16, qb2, lane), sf, dk[df]);
-      }
-    }
-    if (key < Tn) {
-      bf16_t* dstk = dqkv + ((int64_t)b * Tn + key) * gs + H + h * HD + g * 4;
-      store_row4x4<TE>(dstk, dk);
-      store_row4x4<TE>(dstk + H, dv);
-    }
   }
 }
 
@@ -890,15 +472,311 @@ __global__ __launch_bounds__(256, 2) void attn_bwd3_kernel(const bf16_t* __restr
   }
 }
 
-template <int NF> static size_t bwd3_lds() { return (size_t)(4 * NF * 16 * 64) * 2; }
+// ===================================================================================== tiled kernels: any T
+// Sequences longer than one workgroup's LDS images (T > 160: the paired-input model at T = 2*149+3 = 301, the 5 s
+// clips of the large model at T = 249, evaluation utterances of up to ~145 s = 7249 frames) stream the OTHER
+// sequence axis through LDS in tiles of 64 rows (double-buffered, next tile's global loads in flight under the
+// current tile's MFMAs): the forward is an online-softmax (flash) loop over key tiles, the backward two kernels that
+// recompute the probabilities from the saved log-sum-exp -- dQ (+ delta) over key tiles, dK / dV over query tiles --
+// with the same per-fragment arithmetic, dropout stream and k-slot mapping as the single-workgroup kernels above.
+// No [B, h, T, T] tensor exists anywhere; work per launch is O(T^2 d), LDS is 32-33 KiB whatever T is.
+constexpr int AT_TILE = 64;
 
-template <int NF> static size_t fwd2_lds() { return (size_t)(2 * NF * 16 * 64 + 64 * (NF * 16 + 4)) * 2; }
-template <int NF> static size_t bwd2_lds() { return (size_t)(4 * NF * 16 * 64 + 3 * 64 * (NF * 16 + 4)) * 2 + 2 * NF * 16 * 4; }
+struct TileRegs { uint4 v[2]; };
+// rows row0 .. row0+63 (x 64 elements) of a [*, 64]-column slab with row stride gs -> registers (2 x 16 B per thread)
+__device__ __forceinline__ void tile_load(TileRegs& r, const bf16_t* g, int64_t gs, int row0, int n_valid) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int c = threadIdx.x + 256 * i;
+    const int row = row0 + (c >> 3), ch = c & 7;
+    r.v[i] = make_uint4(0, 0, 0, 0);
+    if (row < n_valid) r.v[i] = *reinterpret_cast<const uint4*>(g + (int64_t)row * gs + ch * 8);
+  }
+}
+__device__ __forceinline__ void tile_store(const TileRegs& r, bf16_t* lds) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int c = threadIdx.x + 256 * i;
+    const int row = c >> 3, ch = c & 7;
+    *reinterpret_cast<uint4*>(lds + row * 64 + ((ch ^ aswz(row)) << 3)) = r.v[i];
+  }
+}
+
+template <typename TE>
+__global__ __launch_bounds__(256) void attn_fwd_tiled_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx,
+                                                             float* __restrict__ lse, int Tn, int heads, float scale,
+                                                             float dp, float inv_keep, uint64_t seed) {
+  __shared__ __attribute__((aligned(16))) bf16_t Ks[2][AT_TILE * 64];
+  __shared__ __attribute__((aligned(16))) bf16_t Vs[2][AT_TILE * 64];
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int H = heads * HD;
+  const int64_t gs = 3 * (int64_t)H;
+  const bf16_t* qb = qkv + (int64_t)b * Tn * gs + h * HD;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
+  const int q = blockIdx.x * 64 + wave * 16 + (lane & 15);
+  const int64_t bh = (int64_t)b * heads + h;
+  frag8_t qf[2];
+  reg_frag(qf, qb, gs, q, Tn, lane);
+  const TrOff troff = tr_offsets(lane);
+  const int ntile = (Tn + AT_TILE - 1) / AT_TILE;
+  TileRegs rk, rv;
+  tile_load(rk, qb + H, gs, 0, Tn);
+  tile_load(rv, qb + 2 * H, gs, 0, Tn);
+  tile_store(rk, Ks[0]);
+  tile_store(rv, Vs[0]);
+  __syncthreads();
+  float m = -INFINITY, l = 0.f;
+  f32x4 o[4];
+#pragma unroll
+  for (int df = 0; df < 4; ++df) o[df] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+  for (int t = 0; t < ntile; ++t) {
+    const int cur = t & 1;
+    if (t + 1 < ntile) {                              // next tile's loads fly under this tile's arithmetic
+      tile_load(rk, qb + H, gs, (t + 1) * AT_TILE, Tn);
+      tile_load(rv, qb + 2 * H, gs, (t + 1) * AT_TILE, Tn);
+    }
+    float s[4][4];
+    float tmax = -INFINITY;
+#pragma unroll
+    for (int fj = 0; fj < 4; ++fj) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) acc = mfma16<TE>(lds_frag(Ks[cur], fj * 16, kk, lane), qf[kk], acc);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int key = t * AT_TILE + fj * 16 + g * 4 + j;
+        s[fj][j] = key < Tn ? acc[j] * scale : -INFINITY;
+        tmax = fmaxf(tmax, s[fj][j]);
+      }
+    }
+    tmax = quad_max(tmax);
+    const float mn = fmaxf(m, tmax);                  // finite: every tile holds at least one valid key
+    const float alpha = __expf(m - mn);               // first tile: exp(-inf) = 0
+    m = mn;
+    float psum = 0.f;
+#pragma unroll
+    for (int fj = 0; fj < 4; ++fj) {
+      float ms[4] = {1.f, 1.f, 1.f, 1.f};
+      if (dp > 0.f) attn_drop4_keys(seed, bh, q, t * AT_TILE + fj * 16 + g * 4, Tn, dp, inv_keep, ms);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float p = __expf(s[fj][j] - mn);
+        psum += p;                                    // the normaliser sums the probabilities BEFORE dropout
+        s[fj][j] = p * ms[j];
+      }
+    }
+    l = l * alpha + quad_sum(psum);
+#pragma unroll
+    for (int df = 0; df < 4; ++df) o[df] *= alpha;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      const frag8_t pf = pack_frag<TE>(s[2 * kb], s[2 * kb + 1]);
+#pragma unroll
+      for (int df = 0; df < 4; ++df) o[df] = mfma16<TE>(lds_frag_tr(Vs[cur], troff, df, kb), pf, o[df]);
+    }
+    if (t + 1 < ntile) {
+      tile_store(rk, Ks[cur ^ 1]);                    // last read in iteration t-1, behind that iteration's barrier
+      tile_store(rv, Vs[cur ^ 1]);
+    }
+    __syncthreads();
+  }
+  if (q < Tn) {
+    const float inv = 1.0f / l;
+#pragma unroll
+    for (int df = 0; df < 4; ++df) o[df] *= inv;
+    store_row4x4<TE>(ctx + ((int64_t)b * Tn + q) * H + h * HD + g * 4, o);
+    if (g == 0) lse[bh * Tn + q] = m + __logf(l);
+  }
+}
+
+// dQ (and delta[q] = sum_d dO O) for 64 queries per workgroup, streaming key tiles
+template <typename TE>
+__global__ __launch_bounds__(256) void attn_bwd_dq_tiled_kernel(const bf16_t* __restrict__ qkv,
+                                                                const bf16_t* __restrict__ ctx,
+                                                                const bf16_t* __restrict__ dctx,
+                                                                const float* __restrict__ lse,
+                                                                bf16_t* __restrict__ dqkv, float* __restrict__ delta,
+                                                                int Tn, int heads, float scale, float dp,
+                                                                float inv_keep, uint64_t seed) {
+  __shared__ __attribute__((aligned(16))) bf16_t Ks[2][AT_TILE * 64];
+  __shared__ __attribute__((aligned(16))) bf16_t Vs[2][AT_TILE * 64];
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int H = heads * HD;
+  const int64_t gs = 3 * (int64_t)H;
+  const bf16_t* qb = qkv + (int64_t)b * Tn * gs + h * HD;
+  const bf16_t* dob = dctx + (int64_t)b * Tn * H + h * HD;
+  const bf16_t* ob = ctx + (int64_t)b * Tn * H + h * HD;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
+  const int q = blockIdx.x * 64 + wave * 16 + (lane & 15);
+  const int64_t bh = (int64_t)b * heads + h;
+  frag8_t qf[2], dof[2], of[2];
+  reg_frag(qf, qb, gs, q, Tn, lane);
+  reg_frag(dof, dob, H, q, Tn, lane);
+  reg_frag(of, ob, H, q, Tn, lane);
+  float dl = 0.f;
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) dl += frag_dot<TE>(dof[kk], of[kk]);
+  dl = quad_sum(dl);
+  if (g == 0 && q < Tn) delta[bh * Tn + q] = dl;
+  const float l = q < Tn ? lse[bh * Tn + q] : 0.f;
+  const TrOff troff = tr_offsets(lane);
+  const int ntile = (Tn + AT_TILE - 1) / AT_TILE;
+  TileRegs rk, rv;
+  tile_load(rk, qb + H, gs, 0, Tn);
+  tile_load(rv, qb + 2 * H, gs, 0, Tn);
+  tile_store(rk, Ks[0]);
+  tile_store(rv, Vs[0]);
+  __syncthreads();
+  f32x4 o[4];
+#pragma unroll
+  for (int df = 0; df < 4; ++df) o[df] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+  for (int t = 0; t < ntile; ++t) {
+    const int cur = t & 1;
+    if (t + 1 < ntile) {
+      tile_load(rk, qb + H, gs, (t + 1) * AT_TILE, Tn);
+      tile_load(rv, qb + 2 * H, gs, (t + 1) * AT_TILE, Tn);
+    }
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      float ds2[2][4];
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        const int fj = 2 * kb + hf;
+        f32x4 sa = {0.f, 0.f, 0.f, 0.f}, pa = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          sa = mfma16<TE>(lds_frag(Ks[cur], fj * 16, kk, lane), qf[kk], sa);
+          pa = mfma16<TE>(lds_frag(Vs[cur], fj * 16, kk, lane), dof[kk], pa);
+        }
+        const int key0 = t * AT_TILE + fj * 16 + g * 4;
+        float ms[4] = {1.f, 1.f, 1.f, 1.f};
+        if (dp > 0.f) attn_drop4_keys(seed, bh, q, key0, Tn, dp, inv_keep, ms);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float p = (key0 + j < Tn && q < Tn) ? __expf(sa[j] * scale - l) : 0.f;
+          ds2[hf][j] = p * (pa[j] * ms[j] - dl) * scale;
+        }
+      }
+      const frag8_t pf = pack_frag<TE>(ds2[0], ds2[1]);
+#pragma unroll
+      for (int df = 0; df < 4; ++df) o[df] = mfma16<TE>(lds_frag_tr(Ks[cur], troff, df, kb), pf, o[df]);
+    }
+    if (t + 1 < ntile) {
+      tile_store(rk, Ks[cur ^ 1]);
+      tile_store(rv, Vs[cur ^ 1]);
+    }
+    __syncthreads();
+  }
+  if (q < Tn) store_row4x4<TE>(dqkv + ((int64_t)b * Tn + q) * gs + h * HD + g * 4, o);
+}
+
+// dK, dV for 64 keys per workgroup, streaming query tiles (Q, dO, LSE, delta)
+template <typename TE>
+__global__ __launch_bounds__(256) void attn_bwd_kv_tiled_kernel(const bf16_t* __restrict__ qkv,
+                                                                const bf16_t* __restrict__ dctx,
+                                                                const float* __restrict__ lse,
+                                                                const float* __restrict__ delta,
+                                                                bf16_t* __restrict__ dqkv, int Tn, int heads,
+                                                                float scale, float dp, float inv_keep, uint64_t seed) {
+  __shared__ __attribute__((aligned(16))) bf16_t Qs[2][AT_TILE * 64];
+  __shared__ __attribute__((aligned(16))) bf16_t Os[2][AT_TILE * 64];      // dO
+  __shared__ __attribute__((aligned(16))) float lse_s[2][AT_TILE];
+  __shared__ __attribute__((aligned(16))) float del_s[2][AT_TILE];
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int H = heads * HD;
+  const int64_t gs = 3 * (int64_t)H;
+  const bf16_t* qb = qkv + (int64_t)b * Tn * gs + h * HD;
+  const bf16_t* dob = dctx + (int64_t)b * Tn * H + h * HD;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
+  const int key = blockIdx.x * 64 + wave * 16 + (lane & 15);
+  const int64_t bh = (int64_t)b * heads + h;
+  frag8_t kf[2], vf[2];
+  reg_frag(kf, qb + H, gs, key, Tn, lane);
+  reg_frag(vf, qb + 2 * H, gs, key, Tn, lane);
+  const TrOff troff = tr_offsets(lane);
+  const int ntile = (Tn + AT_TILE - 1) / AT_TILE;
+  TileRegs rq, ro;
+  float rl = 0.f, rd = 0.f;
+  auto row_load = [&](int t) {
+    if (threadIdx.x < AT_TILE) {
+      const int r = t * AT_TILE + threadIdx.x;
+      rl = r < Tn ? lse[bh * Tn + r] : 0.f;
+      rd = r < Tn ? delta[bh * Tn + r] : 0.f;
+    }
+  };
+  auto row_store = [&](int buf) {
+    if (threadIdx.x < AT_TILE) { lse_s[buf][threadIdx.x] = rl; del_s[buf][threadIdx.x] = rd; }
+  };
+  tile_load(rq, qb, gs, 0, Tn);
+  tile_load(ro, dob, H, 0, Tn);
+  row_load(0);
+  tile_store(rq, Qs[0]);
+  tile_store(ro, Os[0]);
+  row_store(0);
+  __syncthreads();
+  f32x4 dv[4], dk[4];
+#pragma unroll
+  for (int df = 0; df < 4; ++df) { dv[df] = f32x4{0.f, 0.f, 0.f, 0.f}; dk[df] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll 1
+  for (int t = 0; t < ntile; ++t) {
+    const int cur = t & 1;
+    if (t + 1 < ntile) {
+      tile_load(rq, qb, gs, (t + 1) * AT_TILE, Tn);
+      tile_load(ro, dob, H, (t + 1) * AT_TILE, Tn);
+      row_load(t + 1);
+    }
+#pragma unroll
+    for (int qb2 = 0; qb2 < 2; ++qb2) {
+      float pt2[2][4], ds2[2][4];
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        const int fq = 2 * qb2 + hf;
+        f32x4 sa = {0.f, 0.f, 0.f, 0.f}, pa = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          sa = mfma16<TE>(lds_frag(Qs[cur], fq * 16, kk, lane), kf[kk], sa);
+          pa = mfma16<TE>(lds_frag(Os[cur], fq * 16, kk, lane), vf[kk], pa);
+        }
+        const float4 l4 = *reinterpret_cast<const float4*>(&lse_s[cur][fq * 16 + g * 4]);
+        const float4 d4 = *reinterpret_cast<const float4*>(&del_s[cur][fq * 16 + g * 4]);
+        const float la[4] = {l4.x, l4.y, l4.z, l4.w}, da[4] = {d4.x, d4.y, d4.z, d4.w};
+        const int q0 = t * AT_TILE + fq * 16 + g * 4;
+        float ms[4] = {1.f, 1.f, 1.f, 1.f};
+        if (dp > 0.f) attn_drop4_rows(seed, bh, q0, key, Tn, dp, inv_keep, ms);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float p = (q0 + j < Tn && key < Tn) ? __expf(sa[j] * scale - la[j]) : 0.f;
+          pt2[hf][j] = p * ms[j];
+          ds2[hf][j] = p * (pa[j] * ms[j] - da[j]) * scale;
+        }
+      }
+      const frag8_t pf = pack_frag<TE>(pt2[0], pt2[1]);
+      const frag8_t sf = pack_frag<TE>(ds2[0], ds2[1]);
+#pragma unroll
+      for (int df = 0; df < 4; ++df) {
+        dv[df] = mfma16<TE>(lds_frag_tr(Os[cur], troff, df, qb2), pf, dv[df]);
+        dk[df] = mfma16<TE>(lds_frag_tr(Qs[cur], troff, df, qb2), sf, dk[df]);
+      }
+    }
+    if (t + 1 < ntile) {
+      tile_store(rq, Qs[cur ^ 1]);
+      tile_store(ro, Os[cur ^ 1]);
+      row_store(cur ^ 1);
+    }
+    __syncthreads();
+  }
+  if (key < Tn) {
+    bf16_t* dstk = dqkv + ((int64_t)b * Tn + key) * gs + H + h * HD + g * 4;
+    store_row4x4<TE>(dstk, dk);
+    store_row4x4<TE>(dstk + H, dv);
+  }
+}
 
 // ------------------------------------------------------------------------------------- host
-template <int NF> static size_t fwd_lds() { return (size_t)(NF * 16 * 64 + 64 * (NF * 16 + 4)) * 2; }
-template <int NF> static size_t dq_lds() { return (size_t)(2 * NF * 16 * 64 + 64 * (NF * 16 + 4)) * 2; }
-template <int NF> static size_t kv_lds() { return (size_t)(2 * NF * 16 * 64 + 2 * 64 * (NF * 16 + 4)) * 2 + 2 * NF * 16 * 4; }
+template <int NF> static size_t bwd3_lds() { return (size_t)(4 * NF * 16 * 64) * 2; }
+template <int NF> static size_t fwd2_lds() { return (size_t)(2 * NF * 16 * 64 + 64 * (NF * 16 + 4)) * 2; }
 
 template <typename K> static void set_lds(K kern, size_t bytes) {
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
@@ -907,15 +785,15 @@ template <typename K> static void set_lds(K kern, size_t bytes) {
 static int attn_check(const char* nm, int B, int T, int heads, int d, int dtype, float drop_p) {
   W2V2_REQUIRE(B > 0 && T > 0 && heads > 0, "%s: bad shape", nm);
   W2V2_REQUIRE(d == HD, "%s: fused attention needs head dim 64 (got %d); use the unfused path", nm, d);
-  W2V2_REQUIRE(T <= 256, "%s: fused attention covers T <= 256 (got %d); use the unfused path", nm, T);
   W2V2_REQUIRE(dtype == W2V2_BF16 || dtype == W2V2_F16,
                "%s: fused attention needs 16-bit activations; the f32 parity mode uses the unfused path", nm);
   W2V2_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "%s: bad dropout p", nm);
   return 0;
 }
 
-static const bool g_attn_v1 = getenv("W2V2_ATTN_V1") != nullptr;   // A/B switches
-static const bool g_attn_v2 = getenv("W2V2_ATTN_V2") != nullptr;
+// T <= 160 (the 3 s training clips): one workgroup per (batch, head); longer sequences: the tiled kernels.
+// W2V2_ATTN_TILED=1 sends every length to the tiled kernels (A/B runs and tests of their short-sequence edge cases).
+static const bool g_attn_tiled = getenv("W2V2_ATTN_TILED") != nullptr;
 
 #define ATTN_DISPATCH_SMALL(NFV, CALL)       \
   switch (NFV) {                             \
@@ -926,40 +804,24 @@ static const bool g_attn_v2 = getenv("W2V2_ATTN_V2") != nullptr;
     default: { constexpr int NF = 10; CALL; } break; \
   }
 
-#define ATTN_DISPATCH(NFV, CALL)             \
-  switch (NFV) {                             \
-    case 2: { constexpr int NF = 2; CALL; } break;   \
-    case 4: { constexpr int NF = 4; CALL; } break;   \
-    case 6: { constexpr int NF = 6; CALL; } break;   \
-    case 8: { constexpr int NF = 8; CALL; } break;   \
-    case 10: { constexpr int NF = 10; CALL; } break; \
-    case 12: { constexpr int NF = 12; CALL; } break; \
-    case 14: { constexpr int NF = 14; CALL; } break; \
-    default: { constexpr int NF = 16; CALL; } break; \
-  }
-
 template <typename TE>
 static int attention_fwd_t(const void* qkv, void* ctx, float* lse, int B, int T, int heads, float scale, float drop_p,
                            uint64_t seed, void* stream) {
   const int nf = (int)cdiv(T, 32) * 2;
-  dim3 grid((unsigned)cdiv(T, 64), heads, B);
   const float ik = 1.0f / (1.0f - drop_p);
   hipStream_t st = as_stream(stream);
-  if (nf <= 10 && !g_attn_v1) {
+  if (nf <= 10 && !g_attn_tiled) {
     dim3 grid2(heads, B);
     ATTN_DISPATCH_SMALL(nf, {
       set_lds(attn_fwd2_kernel<TE, NF>, fwd2_lds<NF>());
       hipLaunchKernelGGL((attn_fwd2_kernel<TE, NF>), grid2, dim3(256), fwd2_lds<NF>(), st, (const bf16_t*)qkv, (bf16_t*)ctx,
                          lse, T, heads, scale, drop_p, ik, seed);
     });
-    W2V2_CHECK_LAUNCH("attention_fwd");
-    return 0;
+  } else {
+    dim3 grid((unsigned)cdiv(T, 64), heads, B);
+    hipLaunchKernelGGL((attn_fwd_tiled_kernel<TE>), grid, dim3(256), 0, st, (const bf16_t*)qkv, (bf16_t*)ctx, lse, T,
+                       heads, scale, drop_p, ik, seed);
   }
-  ATTN_DISPATCH(nf, {
-    set_lds(attn_fwd_kernel<TE, NF>, fwd_lds<NF>());
-    hipLaunchKernelGGL((attn_fwd_kernel<TE, NF>), grid, dim3(256), fwd_lds<NF>(), st, (const bf16_t*)qkv, (bf16_t*)ctx, lse,
-                       T, heads, scale, drop_p, ik, seed);
-  });
   W2V2_CHECK_LAUNCH("attention_fwd");
   return 0;
 }
@@ -978,38 +840,23 @@ static int attention_bwd_t(const void* qkv, const void* ctx, const void* dctx, c
                            float* delta, int B, int T, int heads, float scale, float drop_p, uint64_t seed,
                            void* stream) {
   const int nf = (int)cdiv(T, 32) * 2;
-  dim3 grid((unsigned)cdiv(T, 64), heads, B);
   const float ik = 1.0f / (1.0f - drop_p);
   hipStream_t st = as_stream(stream);
-  if (nf <= 10 && !g_attn_v1) {
+  if (nf <= 10 && !g_attn_tiled) {
     dim3 grid2(heads, B);
-    if (g_attn_v2) {
-      ATTN_DISPATCH_SMALL(nf, {
-        set_lds(attn_bwd2_kernel<TE, NF>, bwd2_lds<NF>());
-        hipLaunchKernelGGL((attn_bwd2_kernel<TE, NF>), grid2, dim3(256), bwd2_lds<NF>(), st, (const bf16_t*)qkv,
-                           (const bf16_t*)ctx, (const bf16_t*)dctx, lse, (bf16_t*)dqkv, T, heads, scale, drop_p, ik,
-                           seed);
-      });
-    } else {
-      ATTN_DISPATCH_SMALL(nf, {
-        set_lds(attn_bwd3_kernel<TE, NF>, bwd3_lds<NF>());
-        hipLaunchKernelGGL((attn_bwd3_kernel<TE, NF>), grid2, dim3(256), bwd3_lds<NF>(), st, (const bf16_t*)qkv,
-                           (const bf16_t*)ctx, (const bf16_t*)dctx, lse, (bf16_t*)dqkv, delta, T, heads, scale, drop_p,
-                           ik, seed);
-      });
-    }
-    W2V2_CHECK_LAUNCH("attention_bwd");
-    return 0;
+    ATTN_DISPATCH_SMALL(nf, {
+      set_lds(attn_bwd3_kernel<TE, NF>, bwd3_lds<NF>());
+      hipLaunchKernelGGL((attn_bwd3_kernel<TE, NF>), grid2, dim3(256), bwd3_lds<NF>(), st, (const bf16_t*)qkv,
+                         (const bf16_t*)ctx, (const bf16_t*)dctx, lse, (bf16_t*)dqkv, delta, T, heads, scale, drop_p,
+                         ik, seed);
+    });
+  } else {
+    dim3 grid((unsigned)cdiv(T, 64), heads, B);
+    hipLaunchKernelGGL((attn_bwd_dq_tiled_kernel<TE>), grid, dim3(256), 0, st, (const bf16_t*)qkv, (const bf16_t*)ctx,
+                       (const bf16_t*)dctx, lse, (bf16_t*)dqkv, delta, T, heads, scale, drop_p, ik, seed);
+    hipLaunchKernelGGL((attn_bwd_kv_tiled_kernel<TE>), grid, dim3(256), 0, st, (const bf16_t*)qkv, (const bf16_t*)dctx,
+                       lse, (const float*)delta, (bf16_t*)dqkv, T, heads, scale, drop_p, ik, seed);
   }
-  ATTN_DISPATCH(nf, {
-    set_lds(attn_bwd_dq_kernel<TE, NF>, dq_lds<NF>());
-    set_lds(attn_bwd_kv_kernel<TE, NF>, kv_lds<NF>());
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<TE, NF>), grid, dim3(256), dq_lds<NF>(), st, (const bf16_t*)qkv,
-                       (const bf16_t*)ctx, (const bf16_t*)dctx, lse, (bf16_t*)dqkv, delta, T, heads, scale, drop_p, ik,
-                       seed);
-    hipLaunchKernelGGL((attn_bwd_kv_kernel<TE, NF>), grid, dim3(256), kv_lds<NF>(), st, (const bf16_t*)qkv,
-                       (const bf16_t*)dctx, lse, (const float*)delta, (bf16_t*)dqkv, T, heads, scale, drop_p, ik, seed);
-  });
   W2V2_CHECK_LAUNCH("attention_bwd");
   return 0;
 }

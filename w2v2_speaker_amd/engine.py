@@ -131,7 +131,7 @@ class Plan:
         self.M0, self.M = self.Bc * self.T0, batch * self.T
         H, d = cfg.hidden_size, cfg.head_dim
         if fused_attention is None:
-            fused_attention = (ops.is16(self.adt) and d == 64 and self.T <= 256)
+            fused_attention = ops.is16(self.adt) and d == 64        # any T (tiled kernels beyond 160 frames)
         self.fused = fused_attention
         self.embed_dim = H * (2 if pooling == "attentive" else ops.POOL_WIDTH.get(self.pool_mode, 1))
         self._pack_version = -1
