@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""Per-kernel hardware counters from three separate rocprofv3 PMC passes of the SAME bench command (rocpd sqlite):
+
+    rocprofv3 --kernel-trace --pmc FETCH_SIZE -d <dirF> -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline
+    rocprofv3 --kernel-trace --pmc WRITE_SIZE -d <dirW> -- python3 bench.py ...
+    rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d <dirM> -- python3 bench.py ...
+    python tools/pmc_counters.py <dirF> <dirW> <dirM> > profiles/rNN_pmc_counters.json
+
+HBM traffic (MI355X_MICROARCH.md, HBM section; calibrated on adam_kernel whose traffic is known exactly): FETCH_SIZE
+counts 64 B per 128-B request on gfx950 -> read bytes = 2 * FETCH_SIZE KiB; WRITE_SIZE (KiB) is exact.
+Matrix-pipe utilisation: SQ_VALU_MFMA_BUSY_CYCLES counts the cycles a SIMD's matrix pipe is busy (16-17 per
+v_mfma_f32_16x16x32: checked against the launches' MFMA counts), summed over the chip's 256 CUs x 4 SIMDs;
+GRBM_GUI_ACTIVE is the dispatch's duration in shader clocks, reported as the SUM over the 8 XCD instances (one row per
+dispatch in the rocpd database; GUI_ACTIVE / 8 / duration = 2.2 GHz, the clock under profiling).
+mfma_busy = MFMA_BUSY / (1024 SIMDs * GUI_ACTIVE / 8)."""
+import glob
+import json
+import re
+import sqlite3
+import sys
+
+N_SIMD = 4 * 256
+N_XCD = 8
+
+
+def per_kernel(d, counter, how="sum"):
+    db = glob.glob(d + "/**/*.db", recursive=True)[0]
+    cur = sqlite3.connect(db).cursor()
+    # one row per (dispatch, counter instance): fold the instances of a dispatch first, then the dispatches of a kernel
+    q = ("select k.name, c.dispatch_id, sum(c.value), avg(c.value), count(*) from counters_collection c join kernels k "
+         "on k.dispatch_id = c.dispatch_id where c.counter_name = ? group by k.name, c.dispatch_id")
+    out = {}
+    for name, _, s, a, _n in cur.execute(q, (counter,)):
+        name = re.sub(r"\(.*", "", name).replace("void ", "")
+        e = out.setdefault(name, [0, 0.0])
+        e[0] += 1
+        e[1] += s if how == "sum" else a
+    return out
+
+
+def main():
+    dF, dW, dM = sys.argv[1:4]
+    f, w = per_kernel(dF, "FETCH_SIZE"), per_kernel(dW, "WRITE_SIZE")
+    mf = per_kernel(dM, "SQ_VALU_MFMA_BUSY_CYCLES")
+    sb = per_kernel(dM, "SQ_BUSY_CYCLES")
+    ga = per_kernel(dM, "GRBM_GUI_ACTIVE")
+    out = {"note": "rocprofv3 PMC passes of `python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline` (B=66, fp16 mode), "
+                   "one counter group per pass; read bytes = 2 * FETCH_SIZE KiB (gfx950 correction), write bytes = "
+                   "WRITE_SIZE KiB; mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs * GRBM_GUI_ACTIVE / 8 XCD instances).",
+           "kernels": {}}
+    for name in sorted(f, key=lambda n: -(2 * f[n][1] + w.get(n, (0, 0))[1])):
+        n, fk = f[name]
+        wk = w.get(name, (n, 0.0))[1]
+        rec = {"launches": n, "fetch_kib_raw": round(fk / n, 1), "write_kib": round(wk / n, 1),
+               "hbm_bytes_per_launch": int((2 * fk + wk) / n * 1024)}
+        if name in mf and name in ga and ga[name][1] > 0:
+            rec["mfma_busy_cycles_per_launch"] = round(mf[name][1] / mf[name][0], 1)
+            rec["gui_active_cycles_per_launch"] = round(ga[name][1] / ga[name][0] / N_XCD, 1)
+            rec["mfma_busy"] = round(mf[name][1] / (N_SIMD * ga[name][1] / N_XCD), 4)
+            if name in sb and sb[name][1] > 0:
+                rec["sq_busy_cycles_per_launch"] = round(sb[name][1] / sb[name][0], 1)
+        out["kernels"][name] = rec
+    json.dump(out, sys.stdout, indent=1)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,22 +1,21 @@
-// attention.hip -- fused multi-head self-attention for training-length sequences (T <= 256,
-// head dim 64): HF:438-548 minus the q/k/v/out projections.  bf16 in, f32 softmax, bf16 out.
+// attention.hip -- fused multi-head self-attention for ANY sequence length (head dim 64): HF:438-548 minus the
+// q/k/v/out projections.  16-bit in (bf16 or fp16), f32 softmax, 16-bit out.
 //
-// All three kernels share one skeleton.  A wave owns 16 "rows" (queries in fwd / dQ, keys in dK/dV)
-// whose operand fragments live in registers; the whole "column" matrix of the (batch, head) sits in
-// LDS twice: row-major [n][64] (XOR-swizzled 16-B chunks, read as ds_read_b128 MFMA fragments) for
-// the score-like products, and transposed [64][n] (read as 2 x ds_read_b64) for the product that
-// contracts over n.  Scores are computed with swapped MFMA operands (D[row=n][col=m]) so each lane
-// holds, for ONE of its 16 rows, 4 consecutive columns per 16x16 fragment: the softmax row
-// reductions are in-register + two wave shuffles (xor 16, 32), and the probabilities feed the second
-// MFMA directly from registers (never through LDS or HBM).  The MFMA k-slot <-> column mapping
-// (slot (g,e): column blk*32 + (e<4 ? g*4+e : 16+g*4+e-4)) is applied identically to the register
-// operand and the transposed-LDS operand, which is all a contraction needs.
+// One skeleton for the three kernels.  A workgroup owns 64 "rows" (queries in the forward / dQ kernel, keys in the
+// dK/dV kernel), 16 per wave, whose operand fragments live in registers; the OTHER sequence axis streams through LDS in
+// tiles of 64 rows (double-buffered row-major images, 16-B chunks XOR-swizzled, next tile's global loads in flight under
+// the current tile's MFMAs).  Scores are computed with swapped MFMA operands (D[row = n][col = m]) so each lane holds,
+// for ONE of its 16 rows, 4 consecutive columns per 16x16 fragment: the softmax row reductions are in-register + two wave
+// shuffles (xor 16, 32), and the probabilities feed the second MFMA straight from registers (never through LDS or
+// HBM).  The MFMA k-slot <-> column mapping (slot (g,e): column blk*32 + (e<4 ? g*4+e : 16+g*4+e-4)) is applied
+// identically to the register operand and to the transposing LDS read, which is all a contraction needs.
 //
-//   fwd   : S = QK^T*scale -> P = softmax(S) (+dropout) -> O = P V            saves LSE[b,h,q]
-//   bwd_dq: recompute P; dP = dO V^T; dS = P*(dP - delta)*scale; dQ = dS K    writes delta[b,h,q]
-//   bwd_kv: (rows = keys) recompute P^T; dV = Pdrop^T dO; dK = dS^T Q
-// Backward recomputes the scores in both kernels (7 matmul units instead of 5) in exchange for
-// no [B,h,T,T] tensor in HBM at all; attention is 3 % of the step's FLOPs.
+//   fwd   : online softmax over key tiles: S = QK^T*scale -> P (+dropout) -> O += P V      saves LSE[b,h,q]
+//   bwd_dq: recompute P from LSE; dP = dO V^T; dS = P*(dP - delta)*scale; dQ += dS K       writes delta[b,h,q]
+//   bwd_kv: (rows = keys, streams query tiles) recompute P^T; dV += Pdrop^T dO; dK += dS^T Q
+// The backward recomputes the scores in both kernels (7 matmul units instead of 5) in exchange for no [B,h,T,T] tensor
+// in HBM at all; attention is 3 % of the step's FLOPs.  Waves whose 16 rows lie entirely beyond T skip the arithmetic
+// (T = 149: the third 64-row block has two idle waves) but keep loading tiles and taking the barriers.
 #include "common.cuh"
 #include <stdlib.h>
 
@@ -98,12 +97,6 @@ __device__ __forceinline__ frag8_t lds_frag(const bf16_t* lds, int row0, int kk,
   const int lane_off = fr * 64 + (((kk * 4 + (lane >> 4)) ^ aswz(fr)) << 3);
   return as_frag(*reinterpret_cast<const uint4*>(lds + lane_off + row0 * 64));
 }
-// MFMA fragment from the transposed image: row d0 + lane&15, k-slots of 32-column block `blk`
-__device__ __forceinline__ frag8_t lds_frag_t(const bf16_t* ldst, int pitch, int d0, int blk, int lane) {
-  const bf16_t* p = ldst + (d0 + (lane & 15)) * pitch + blk * 32 + (lane >> 4) * 4;
-  const uint2 a = *reinterpret_cast<const uint2*>(p), b = *reinterpret_cast<const uint2*>(p + 16);
-  return as_frag(make_uint4(a.x, a.y, b.x, b.y));
-}
 // the wave's own 16 rows straight from global into registers (2 k-steps)
 __device__ __forceinline__ void reg_frag(frag8_t f[2], const bf16_t* g, int64_t gs, int row, int n_valid, int lane) {
 #pragma unroll
@@ -122,75 +115,6 @@ __device__ __forceinline__ float quad_sum(float v) {
   return v + __shfl_xor(v, 32, 64);
 }
 
-// ===================================================================================== v2: one workgroup per (b, h)
-// For T <= 160 (the 3 s training clips: T = 149 / 150) a single workgroup owns a whole (batch, head):
-// K/V/Q/dO are fetched ONCE, with all global loads of a thread issued before the first LDS store (the
-// v1 fill loops were a chain of dependent load->store round trips, ~18 us per workgroup), and both the
-// row-major and the transposed LDS images are produced from the same registers.  The backward is one
-// kernel: phase A (waves own query fragments) produces dQ and delta, phase B (waves own key fragments)
-// produces dK and dV from the same LDS images.
-template <int NF> struct BlkRegs {
-  static constexpr int NIT = (NF * 16 / 4 * 8 + 255) / 256;   // 4-row x 8-col micro-blocks per thread
-  uint4 v[NIT][4];
-};
-
-template <int NF>
-__device__ __forceinline__ void blk_load(BlkRegs<NF>& r, const bf16_t* g, int64_t gs, int n_valid) {
-  constexpr int NB = NF * 16 / 4 * 8;
-#pragma unroll
-  for (int it = 0; it < BlkRegs<NF>::NIT; ++it) {
-    const int blk = threadIdx.x + 256 * it;
-    const int cb = blk & 7, rb = blk >> 3;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int row = rb * 4 + i;
-      r.v[it][i] = make_uint4(0, 0, 0, 0);
-      if (blk < NB && row < n_valid) r.v[it][i] = *reinterpret_cast<const uint4*>(g + (int64_t)row * gs + cb * 8);
-    }
-  }
-}
-template <int NF>
-__device__ __forceinline__ void blk_store_rows(const BlkRegs<NF>& r, bf16_t* lds) {
-  constexpr int NB = NF * 16 / 4 * 8;
-#pragma unroll
-  for (int it = 0; it < BlkRegs<NF>::NIT; ++it) {
-    const int blk = threadIdx.x + 256 * it;
-    if (blk >= NB) continue;
-    const int cb = blk & 7, rb = blk >> 3;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int row = rb * 4 + i;
-      *reinterpret_cast<uint4*>(lds + row * 64 + ((cb ^ aswz(row)) << 3)) = r.v[it][i];
-    }
-  }
-}
-template <int NF>
-__device__ __forceinline__ void blk_store_t(const BlkRegs<NF>& r, bf16_t* ldst, int pitch) {
-  constexpr int NB = NF * 16 / 4 * 8;
-#pragma unroll
-  for (int it = 0; it < BlkRegs<NF>::NIT; ++it) {
-    const int blk = threadIdx.x + 256 * it;
-    if (blk >= NB) continue;
-    const int cb = blk & 7, rb = blk >> 3;
-    const uint32_t w[4][4] = {{r.v[it][0].x, r.v[it][0].y, r.v[it][0].z, r.v[it][0].w},
-                              {r.v[it][1].x, r.v[it][1].y, r.v[it][1].z, r.v[it][1].w},
-                              {r.v[it][2].x, r.v[it][2].y, r.v[it][2].z, r.v[it][2].w},
-                              {r.v[it][3].x, r.v[it][3].y, r.v[it][3].z, r.v[it][3].w}};
-#pragma unroll
-    for (int ci = 0; ci < 8; ++ci) {
-      const int d = ci >> 1;
-      uint2 o;
-      if (ci & 1) {
-        o.x = (w[0][d] >> 16) | (w[1][d] & 0xffff0000u);
-        o.y = (w[2][d] >> 16) | (w[3][d] & 0xffff0000u);
-      } else {
-        o.x = (w[0][d] & 0xffffu) | (w[1][d] << 16);
-        o.y = (w[2][d] & 0xffffu) | (w[3][d] << 16);
-      }
-      *reinterpret_cast<uint2*>(ldst + (cb * 8 + ci) * pitch + rb * 4) = o;
-    }
-  }
-}
 template <typename TE>
 __device__ __forceinline__ void store_row4x4(bf16_t* dst, const f32x4 (&o)[4]) {
 #pragma unroll
@@ -202,91 +126,10 @@ __device__ __forceinline__ void store_row4x4(bf16_t* dst, const f32x4 (&o)[4]) {
   }
 }
 
-template <typename TE, int NF>
-__global__ __launch_bounds__(256) void attn_fwd2_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx,
-                                                        float* __restrict__ lse, int Tn, int heads, float scale,
-                                                        float dp, float inv_keep, uint64_t seed) {
-  constexpr int TP = NF * 16, PITCH = TP + 4;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  bf16_t* Ks = reinterpret_cast<bf16_t*>(smem);   // [TP][64]
-  bf16_t* Qs = Ks + TP * 64;                      // [TP][64]
-  bf16_t* Vt = Qs + TP * 64;                      // [64][PITCH]
-  const int b = blockIdx.y, h = blockIdx.x;
-  const int H = heads * HD;
-  const int64_t gs = 3 * (int64_t)H;
-  const bf16_t* qb = qkv + (int64_t)b * Tn * gs + h * HD;
-  {
-    BlkRegs<NF> rq, rk, rv;
-    blk_load<NF>(rq, qb, gs, Tn);
-    blk_load<NF>(rk, qb + H, gs, Tn);
-    blk_load<NF>(rv, qb + 2 * H, gs, Tn);
-    blk_store_rows<NF>(rq, Qs);
-    blk_store_rows<NF>(rk, Ks);
-    blk_store_t<NF>(rv, Vt, PITCH);
-  }
-  __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
-  const int64_t bh = (int64_t)b * heads + h;
-#pragma unroll 1
-  for (int qf = wave; qf < NF; qf += 4) {
-    asm volatile("" ::: "memory");   // keep the K / V^T fragment loads inside the loop (LICM would hoist 240 VGPRs)
-    const int q = qf * 16 + (lane & 15);
-    int g4 = g * 4;
-    asm volatile("" : "+v"(g4));          // opaque: no hoisting of the 40 per-column index / RNG-counter values
-    frag8_t qfr[2] = {lds_frag(Qs, qf * 16, 0, lane), lds_frag(Qs, qf * 16, 1, lane)};
-    float s[NF][4];
-    float mx = -INFINITY;
-#pragma unroll
-    for (int fj = 0; fj < NF; ++fj) {
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk)
-        acc = mfma16<TE>(lds_frag(Ks, fj * 16, kk, lane), qfr[kk], acc);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int key = fj * 16 + g4 + j;
-        s[fj][j] = key < Tn ? acc[j] * scale : -INFINITY;
-        mx = fmaxf(mx, s[fj][j]);
-      }
-    }
-    mx = quad_max(mx);
-    float sum = 0.f;
-#pragma unroll
-    for (int fj = 0; fj < NF; ++fj)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) { s[fj][j] = __expf(s[fj][j] - mx); sum += s[fj][j]; }
-    sum = quad_sum(sum);
-    const float inv = 1.0f / sum;
-    if (g == 0 && q < Tn) lse[bh * Tn + q] = mx + __logf(sum);
-#pragma unroll
-    for (int fj = 0; fj < NF; ++fj) {
-      float ms[4] = {1.f, 1.f, 1.f, 1.f};
-      if (dp > 0.f) attn_drop4_keys(seed, bh, q, fj * 16 + g4, Tn, dp, inv_keep, ms);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) s[fj][j] = s[fj][j] * inv * ms[j];
-    }
-    f32x4 o[4];
-#pragma unroll
-    for (int df = 0; df < 4; ++df) o[df] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int kb = 0; kb < NF / 2; ++kb) {
-      const frag8_t pf = pack_frag<TE>(s[2 * kb], s[2 * kb + 1]);
-#pragma unroll
-      for (int df = 0; df < 4; ++df)
-        o[df] = mfma16<TE>(lds_frag_t(Vt, PITCH, df * 16, kb, lane), pf, o[df]);
-    }
-    if (q < Tn) store_row4x4<TE>(ctx + ((int64_t)b * Tn + q) * H + h * HD + g * 4, o);
-  }
-}
-
-// ===================================================================================== v3 backward: tr-read, 2 workgroups / CU
-// The merged backward above keeps 4 row-major and 3 transposed LDS images (144 KiB): ONE workgroup of 4 waves
-// per CU, i.e. one wave per SIMD and every LDS / MFMA / exp latency exposed.  Here the contraction-side
-// operands (K for dQ, dO and Q for dV / dK) are read straight from the ROW-MAJOR images with the hardware
-// transpose read ds_read_b64_tr_b16 (16 lanes x 8 B = a 4(row) x 16(col) block, lane i receives column i), so
-// only K, V, Q, dO row-major remain: exactly 80 KiB -> two workgroups per CU (8 waves, 2 per SIMD).  dS / P are
-// consumed per 32-column block as soon as they exist (no [T] x 4 register arrays), delta goes through a
-// global scratch row (written in phase A, read in phase B of the same workgroup).
+// ------------------------------------------------------------------------------------- transposing fragment reads
+// The products that contract over the streamed axis (P V, dS K, P^T dO, dS^T Q) need their LDS operand transposed.
+// The images stay ROW-MAJOR and the operand comes from the hardware transpose read ds_read_b64_tr_b16 (16 lanes x 8 B =
+// a 4(row) x 16(col) block, lane i receives column i): no transposed copies in LDS.
 typedef __attribute__((ext_vector_type(4))) short short4v_t;
 typedef __attribute__((address_space(3))) short4v_t lds_s4v_t;
 
@@ -312,164 +155,6 @@ __device__ __forceinline__ frag8_t lds_frag_tr(const bf16_t* img, const TrOff& t
   u.s.a = lo;
   u.s.b = hi;
   return u.v;
-}
-
-template <typename TE, int NF>
-__global__ __launch_bounds__(256, 2) void attn_bwd3_kernel(const bf16_t* __restrict__ qkv,
-                                                           const bf16_t* __restrict__ ctx,
-                                                           const bf16_t* __restrict__ dctx,
-                                                           const float* __restrict__ lse, bf16_t* __restrict__ dqkv,
-                                                           float* __restrict__ delta, int Tn, int heads, float scale,
-                                                           float dp, float inv_keep, uint64_t seed) {
-  constexpr int TP = NF * 16;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  bf16_t* Ks = reinterpret_cast<bf16_t*>(smem);   // row-major swizzled images [TP][64]
-  bf16_t* Vs = Ks + TP * 64;
-  bf16_t* Qs = Vs + TP * 64;
-  bf16_t* Os = Qs + TP * 64;                      // dO
-  const int b = blockIdx.y, h = blockIdx.x;
-  const int H = heads * HD;
-  const int64_t gs = 3 * (int64_t)H;
-  const bf16_t* qb = qkv + (int64_t)b * Tn * gs + h * HD;
-  const bf16_t* dob = dctx + (int64_t)b * Tn * H + h * HD;
-  const bf16_t* ob = ctx + (int64_t)b * Tn * H + h * HD;
-  const int64_t bh = (int64_t)b * heads + h;
-  {
-    BlkRegs<NF> ra, rb;
-    blk_load<NF>(ra, qb, gs, Tn);
-    blk_load<NF>(rb, qb + H, gs, Tn);
-    blk_store_rows<NF>(ra, Qs);
-    blk_store_rows<NF>(rb, Ks);
-    blk_load<NF>(ra, qb + 2 * H, gs, Tn);
-    blk_load<NF>(rb, dob, H, Tn);
-    blk_store_rows<NF>(ra, Vs);
-    blk_store_rows<NF>(rb, Os);
-  }
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
-  const float* lse_b = lse + bh * Tn;
-  float* del_b = delta + bh * Tn;
-  const TrOff troff = tr_offsets(lane);
-  __syncthreads();
-
-  // ---- phase A: waves own query fragments -> dQ, delta
-#pragma unroll 1
-  for (int qf = wave; qf < NF; qf += 4) {
-    asm volatile("" ::: "memory");
-    const int q = qf * 16 + (lane & 15);
-    frag8_t qfr[2] = {lds_frag(Qs, qf * 16, 0, lane), lds_frag(Qs, qf * 16, 1, lane)};
-    frag8_t dof[2] = {lds_frag(Os, qf * 16, 0, lane), lds_frag(Os, qf * 16, 1, lane)};
-    frag8_t of[2];
-    reg_frag(of, ob, H, q, Tn, lane);
-    float dl = 0.f;
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) dl += frag_dot<TE>(dof[kk], of[kk]);
-    dl = quad_sum(dl);
-    if (g == 0 && q < Tn) del_b[q] = dl;
-    const float l = q < Tn ? lse_b[q] : 0.f;
-    f32x4 o[4];
-#pragma unroll
-    for (int df = 0; df < 4; ++df) o[df] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int kb = 0; kb < NF / 2; ++kb) {
-      asm volatile("" ::: "memory");      // bound the scheduler's load hoisting to one 32-key block
-      int g4 = g * 4;
-      asm volatile("" : "+v"(g4));        // opaque: keeps the per-column index / predicate / RNG-counter math of
-                                          // all 40 columns from being hoisted out of the fragment loop (and spilled)
-      float ds2[2][4];
-#pragma unroll
-      for (int hf = 0; hf < 2; ++hf) {
-        const int fj = 2 * kb + hf;
-        f32x4 sa = {0.f, 0.f, 0.f, 0.f}, pa = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-          sa = mfma16<TE>(lds_frag(Ks, fj * 16, kk, lane), qfr[kk], sa);
-          pa = mfma16<TE>(lds_frag(Vs, fj * 16, kk, lane), dof[kk], pa);
-        }
-        float ms[4] = {1.f, 1.f, 1.f, 1.f};
-        if (dp > 0.f) attn_drop4_keys(seed, bh, q, fj * 16 + g4, Tn, dp, inv_keep, ms);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int key = fj * 16 + g4 + j;
-          const float p = (key < Tn && q < Tn) ? __expf(sa[j] * scale - l) : 0.f;
-          ds2[hf][j] = p * (pa[j] * ms[j] - dl) * scale;
-        }
-      }
-      const frag8_t pf = pack_frag<TE>(ds2[0], ds2[1]);
-#pragma unroll
-      for (int df = 0; df < 4; ++df)
-        o[df] = mfma16<TE>(lds_frag_tr(Ks, troff, df, kb), pf, o[df]);
-    }
-    if (q < Tn) store_row4x4<TE>(dqkv + ((int64_t)b * Tn + q) * gs + h * HD + g * 4, o);
-  }
-  __threadfence_block();
-  __syncthreads();          // delta of every query row of this (b, h) is visible to the workgroup
-
-  // ---- phase B: waves own key fragments -> dK, dV
-  // every wave keeps the (b, h)'s LSE and delta rows distributed over its lanes (3 VGPRs each: row r lives in
-  // lane r & 63, register r >> 6) and fetches the 4 values a fragment needs with cross-lane reads
-  constexpr int NR = (TP + 63) / 64;
-  float lse_r[NR], del_r[NR];
-#pragma unroll
-  for (int k2 = 0; k2 < NR; ++k2) {
-    const int r = k2 * 64 + lane;
-    lse_r[k2] = r < Tn ? lse_b[r] : 0.f;
-    del_r[k2] = r < Tn ? del_b[r] : 0.f;
-  }
-#pragma unroll 1
-  for (int kf = wave; kf < NF; kf += 4) {
-    asm volatile("" ::: "memory");
-    const int key = kf * 16 + (lane & 15);
-    frag8_t kfr[2] = {lds_frag(Ks, kf * 16, 0, lane), lds_frag(Ks, kf * 16, 1, lane)};
-    frag8_t vfr[2] = {lds_frag(Vs, kf * 16, 0, lane), lds_frag(Vs, kf * 16, 1, lane)};
-    f32x4 dv[4], dk[4];
-#pragma unroll
-    for (int df = 0; df < 4; ++df) { dv[df] = f32x4{0.f, 0.f, 0.f, 0.f}; dk[df] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-#pragma unroll
-    for (int qb2 = 0; qb2 < NF / 2; ++qb2) {
-      asm volatile("" ::: "memory");
-      // opaque redefinition: the cross-lane reads below are loop-invariant in kf and would otherwise be hoisted
-      // out of the key-fragment loop as 80 live VGPRs
-#pragma unroll
-      for (int k2 = 0; k2 < NR; ++k2) asm volatile("" : "+v"(lse_r[k2]), "+v"(del_r[k2]));
-      int g4 = g * 4;
-      asm volatile("" : "+v"(g4));
-      float pt2[2][4], ds2[2][4];
-#pragma unroll
-      for (int hf = 0; hf < 2; ++hf) {
-        const int fq = 2 * qb2 + hf;
-        f32x4 sa = {0.f, 0.f, 0.f, 0.f}, pa = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-          sa = mfma16<TE>(lds_frag(Qs, fq * 16, kk, lane), kfr[kk], sa);
-          pa = mfma16<TE>(lds_frag(Os, fq * 16, kk, lane), vfr[kk], pa);
-        }
-        float ms[4] = {1.f, 1.f, 1.f, 1.f};
-        if (dp > 0.f) attn_drop4_rows(seed, bh, fq * 16 + g4, key, Tn, dp, inv_keep, ms);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int q = fq * 16 + g4 + j;
-          const bool ok = q < Tn && key < Tn;
-          const float la = __shfl(lse_r[(fq * 16) >> 6], q & 63, 64);
-          const float da = __shfl(del_r[(fq * 16) >> 6], q & 63, 64);
-          const float p = ok ? __expf(sa[j] * scale - la) : 0.f;
-          pt2[hf][j] = p * ms[j];
-          ds2[hf][j] = p * (pa[j] * ms[j] - da) * scale;
-        }
-      }
-      const frag8_t pf = pack_frag<TE>(pt2[0], pt2[1]);
-      const frag8_t sf = pack_frag<TE>(ds2[0], ds2[1]);
-#pragma unroll
-      for (int df = 0; df < 4; ++df) {
-        dv[df] = mfma16<TE>(lds_frag_tr(Os, troff, df, qb2), pf, dv[df]);
-        dk[df] = mfma16<TE>(lds_frag_tr(Qs, troff, df, qb2), sf, dk[df]);
-      }
-    }
-    if (key < Tn) {
-      bf16_t* dstk = dqkv + ((int64_t)b * Tn + key) * gs + H + h * HD + g * 4;
-      store_row4x4<TE>(dstk, dk);
-      store_row4x4<TE>(dstk + H, dv);
-    }
-  }
 }
 
 // ===================================================================================== tiled kernels: any T
@@ -529,6 +214,7 @@ __global__ __launch_bounds__(256) void attn_fwd_tiled_kernel(const bf16_t* __res
   f32x4 o[4];
 #pragma unroll
   for (int df = 0; df < 4; ++df) o[df] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bool active = blockIdx.x * 64 + wave * 16 < Tn;       // wave-uniform: any of this wave's 16 rows valid
 #pragma unroll 1
   for (int t = 0; t < ntile; ++t) {
     const int cur = t & 1;
@@ -536,6 +222,7 @@ __global__ __launch_bounds__(256) void attn_fwd_tiled_kernel(const bf16_t* __res
       tile_load(rk, qb + H, gs, (t + 1) * AT_TILE, Tn);
       tile_load(rv, qb + 2 * H, gs, (t + 1) * AT_TILE, Tn);
     }
+    if (active) {
     float s[4][4];
     float tmax = -INFINITY;
 #pragma unroll
@@ -575,6 +262,7 @@ __global__ __launch_bounds__(256) void attn_fwd_tiled_kernel(const bf16_t* __res
 #pragma unroll
       for (int df = 0; df < 4; ++df) o[df] = mfma16<TE>(lds_frag_tr(Vs[cur], troff, df, kb), pf, o[df]);
     }
+    }   // active
     if (t + 1 < ntile) {
       tile_store(rk, Ks[cur ^ 1]);                    // last read in iteration t-1, behind that iteration's barrier
       tile_store(rv, Vs[cur ^ 1]);
@@ -631,6 +319,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_tiled_kernel(const bf16_t* __
   f32x4 o[4];
 #pragma unroll
   for (int df = 0; df < 4; ++df) o[df] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bool active = blockIdx.x * 64 + wave * 16 < Tn;
 #pragma unroll 1
   for (int t = 0; t < ntile; ++t) {
     const int cur = t & 1;
@@ -638,6 +327,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_tiled_kernel(const bf16_t* __
       tile_load(rk, qb + H, gs, (t + 1) * AT_TILE, Tn);
       tile_load(rv, qb + 2 * H, gs, (t + 1) * AT_TILE, Tn);
     }
+    if (active)
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
       float ds2[2][4];
@@ -719,6 +409,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_tiled_kernel(const bf16_t* __
   f32x4 dv[4], dk[4];
 #pragma unroll
   for (int df = 0; df < 4; ++df) { dv[df] = f32x4{0.f, 0.f, 0.f, 0.f}; dk[df] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  const bool active = blockIdx.x * 64 + wave * 16 < Tn;
 #pragma unroll 1
   for (int t = 0; t < ntile; ++t) {
     const int cur = t & 1;
@@ -727,6 +418,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_tiled_kernel(const bf16_t* __
       tile_load(ro, dob, H, (t + 1) * AT_TILE, Tn);
       row_load(t + 1);
     }
+    if (active)
 #pragma unroll
     for (int qb2 = 0; qb2 < 2; ++qb2) {
       float pt2[2][4], ds2[2][4];
@@ -775,13 +467,6 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_tiled_kernel(const bf16_t* __
 }
 
 // ------------------------------------------------------------------------------------- host
-template <int NF> static size_t bwd3_lds() { return (size_t)(4 * NF * 16 * 64) * 2; }
-template <int NF> static size_t fwd2_lds() { return (size_t)(2 * NF * 16 * 64 + 64 * (NF * 16 + 4)) * 2; }
-
-template <typename K> static void set_lds(K kern, size_t bytes) {
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-}
-
 static int attn_check(const char* nm, int B, int T, int heads, int d, int dtype, float drop_p) {
   W2V2_REQUIRE(B > 0 && T > 0 && heads > 0, "%s: bad shape", nm);
   W2V2_REQUIRE(d == HD, "%s: fused attention needs head dim 64 (got %d); use the unfused path", nm, d);
@@ -791,37 +476,14 @@ static int attn_check(const char* nm, int B, int T, int heads, int d, int dtype,
   return 0;
 }
 
-// T <= 160 (the 3 s training clips): one workgroup per (batch, head); longer sequences: the tiled kernels.
-// W2V2_ATTN_TILED=1 sends every length to the tiled kernels (A/B runs and tests of their short-sequence edge cases).
-static const bool g_attn_tiled = getenv("W2V2_ATTN_TILED") != nullptr;
-
-#define ATTN_DISPATCH_SMALL(NFV, CALL)       \
-  switch (NFV) {                             \
-    case 2: { constexpr int NF = 2; CALL; } break;   \
-    case 4: { constexpr int NF = 4; CALL; } break;   \
-    case 6: { constexpr int NF = 6; CALL; } break;   \
-    case 8: { constexpr int NF = 8; CALL; } break;   \
-    default: { constexpr int NF = 10; CALL; } break; \
-  }
-
 template <typename TE>
 static int attention_fwd_t(const void* qkv, void* ctx, float* lse, int B, int T, int heads, float scale, float drop_p,
                            uint64_t seed, void* stream) {
-  const int nf = (int)cdiv(T, 32) * 2;
   const float ik = 1.0f / (1.0f - drop_p);
   hipStream_t st = as_stream(stream);
-  if (nf <= 10 && !g_attn_tiled) {
-    dim3 grid2(heads, B);
-    ATTN_DISPATCH_SMALL(nf, {
-      set_lds(attn_fwd2_kernel<TE, NF>, fwd2_lds<NF>());
-      hipLaunchKernelGGL((attn_fwd2_kernel<TE, NF>), grid2, dim3(256), fwd2_lds<NF>(), st, (const bf16_t*)qkv, (bf16_t*)ctx,
-                         lse, T, heads, scale, drop_p, ik, seed);
-    });
-  } else {
-    dim3 grid((unsigned)cdiv(T, 64), heads, B);
-    hipLaunchKernelGGL((attn_fwd_tiled_kernel<TE>), grid, dim3(256), 0, st, (const bf16_t*)qkv, (bf16_t*)ctx, lse, T,
-                       heads, scale, drop_p, ik, seed);
-  }
+  dim3 grid((unsigned)cdiv(T, 64), heads, B);
+  hipLaunchKernelGGL((attn_fwd_tiled_kernel<TE>), grid, dim3(256), 0, st, (const bf16_t*)qkv, (bf16_t*)ctx, lse, T,
+                     heads, scale, drop_p, ik, seed);
   W2V2_CHECK_LAUNCH("attention_fwd");
   return 0;
 }
@@ -839,24 +501,13 @@ template <typename TE>
 static int attention_bwd_t(const void* qkv, const void* ctx, const void* dctx, const float* lse, void* dqkv,
                            float* delta, int B, int T, int heads, float scale, float drop_p, uint64_t seed,
                            void* stream) {
-  const int nf = (int)cdiv(T, 32) * 2;
   const float ik = 1.0f / (1.0f - drop_p);
   hipStream_t st = as_stream(stream);
-  if (nf <= 10 && !g_attn_tiled) {
-    dim3 grid2(heads, B);
-    ATTN_DISPATCH_SMALL(nf, {
-      set_lds(attn_bwd3_kernel<TE, NF>, bwd3_lds<NF>());
-      hipLaunchKernelGGL((attn_bwd3_kernel<TE, NF>), grid2, dim3(256), bwd3_lds<NF>(), st, (const bf16_t*)qkv,
-                         (const bf16_t*)ctx, (const bf16_t*)dctx, lse, (bf16_t*)dqkv, delta, T, heads, scale, drop_p,
-                         ik, seed);
-    });
-  } else {
-    dim3 grid((unsigned)cdiv(T, 64), heads, B);
-    hipLaunchKernelGGL((attn_bwd_dq_tiled_kernel<TE>), grid, dim3(256), 0, st, (const bf16_t*)qkv, (const bf16_t*)ctx,
-                       (const bf16_t*)dctx, lse, (bf16_t*)dqkv, delta, T, heads, scale, drop_p, ik, seed);
-    hipLaunchKernelGGL((attn_bwd_kv_tiled_kernel<TE>), grid, dim3(256), 0, st, (const bf16_t*)qkv, (const bf16_t*)dctx,
-                       lse, (const float*)delta, (bf16_t*)dqkv, T, heads, scale, drop_p, ik, seed);
-  }
+  dim3 grid((unsigned)cdiv(T, 64), heads, B);
+  hipLaunchKernelGGL((attn_bwd_dq_tiled_kernel<TE>), grid, dim3(256), 0, st, (const bf16_t*)qkv, (const bf16_t*)ctx,
+                     (const bf16_t*)dctx, lse, (bf16_t*)dqkv, delta, T, heads, scale, drop_p, ik, seed);
+  hipLaunchKernelGGL((attn_bwd_kv_tiled_kernel<TE>), grid, dim3(256), 0, st, (const bf16_t*)qkv, (const bf16_t*)dctx,
+                     lse, (const float*)delta, (bf16_t*)dqkv, T, heads, scale, drop_p, ik, seed);
   W2V2_CHECK_LAUNCH("attention_bwd");
   return 0;
 }

@@ -45,7 +45,6 @@ struct GemmArgs {
   float alpha;
   int c_vec_ok;    // 8-element vector stores to C legal
   int aux_vec_ok;  // 8-element vector access to aux legal
-  int dbg;
   int defer_ok;    // 256x128 ring kernel: stores of a tile may be issued under the next tile's main loop
   // two-term weights (w2v2_hip.h): tiles with n0 >= n_ext_from run k_ext more K steps against B + b_lo_off
   int k_ext, n_ext_from;
@@ -665,7 +664,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(const GemmArgs g) {
 
   if (nk > 0) stage(0, 0);
   __syncthreads();
-  for (int kt = 0; kt < ((g.dbg & 1) ? 0 : nk); kt += 2) {
+  for (int kt = 0; kt < nk; kt += 2) {
     if (kt + 1 < nk) stage(1, kt + 1);
     compute(0);
     __syncthreads();
@@ -680,7 +679,6 @@ __global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(const GemmArgs g) {
   const TC* auxz = g.aux ? reinterpret_cast<const TC*>(g.aux) + z0 * g.aux_s0 + z1 * g.aux_s1 : nullptr;
   TC* auxo = g.aux ? reinterpret_cast<TC*>(g.aux) + z0 * g.aux_s0 + z1 * g.aux_s1 : nullptr;
   const float* bias = g.bias ? g.bias + z1 * g.bias_s1 : nullptr;
-  if ((g.dbg & 2) && acc[0][0][0] != 12345.f) return;
   tile_epilogue<TC, FM, FN>(g, acc, reinterpret_cast<float*>(smem_raw), m0, n0, wm, wn, z0, z1, split);
 }
 
@@ -845,14 +843,12 @@ __global__ __launch_bounds__(512) void gemm_bf16_glds3_kernel(const GemmArgs g) 
   {                                                                \
     if (kt + 1 < nk) wait_vmcnt<6>(); else wait_vmcnt<0>();        \
     __builtin_amdgcn_s_barrier();                                  \
-    const bool ld = kt + 2 < nk && !(g.dbg & 4);                   \
-    if (ld && (g.dbg & 16)) stage(nxt, kt + 2);                    \
-    if (!(g.dbg & 8)) compute(cur, nxt, (ld && !(g.dbg & 16)) ? kt + 2 : -1); \
+    compute(cur, nxt, kt + 2 < nk ? kt + 2 : -1);                  \
     ++kt;                                                          \
   }
   __builtin_amdgcn_s_barrier();          // every wave has finished reading the previous tile's stages
-  if (nk > 0 && !(g.dbg & 4)) stage(s0, 0);
-  if (nk > 1 && !(g.dbg & 4)) stage(s1, 1);
+  if (nk > 0) stage(s0, 0);
+  if (nk > 1) stage(s1, 1);
   int kt = 0;
   if (pending) {
     if (nk >= 3) {                                         // one peeled rotation of the ring carries the stores
@@ -892,7 +888,6 @@ __global__ __launch_bounds__(512) void gemm_bf16_glds3_kernel(const GemmArgs g) 
   TC* auxz = g.aux ? reinterpret_cast<TC*>(g.aux) + z0 * g.aux_s0 + z1 * g.aux_s1 : nullptr;
   const float* bias = g.bias ? g.bias + z1 * g.bias_s1 : nullptr;
   const int nc = n0 + wn * 64 + fk * 16;
-  if ((g.dbg & 2) && acc[0][0][0] != 12345.f) continue;      // timing experiments: no epilogue
   float cv0[8], cv1[8];
   load_col8(g, bias, nc, cv0);
   load_col8(g, bias, nc + 8, cv1);
@@ -998,7 +993,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_glds4_kernel(const GemmArgs g) 
     __builtin_amdgcn_s_barrier();          // every wave has finished reading the previous tile's stages
 #pragma unroll
     for (int st = 0; st < S - 1; ++st)
-      if (st < nk && !(g.dbg & 4)) stage(st * STAGE, st);
+      if (st < nk) stage(st * STAGE, st);
     wait_stages(min(nk, S - 1) - 1 > 2 ? 2 : min(nk, S - 1) - 1);
     __builtin_amdgcn_s_barrier();
     frag8_t af[FM], bcur[FN], bnext[FN], alast;
@@ -1016,9 +1011,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_glds4_kernel(const GemmArgs g) 
       __builtin_amdgcn_s_barrier();
       // the four DMA pieces of stage kt+S-1 are spread over the MFMA groups: issued back to back behind the barrier
       // they hold BOTH waves of a SIMD in the (slow, queue-limited) DMA issue while the matrix pipe idles
-      const bool do_stage = kt + S - 1 < nk && !(g.dbg & 4);
-      const bool spread = !(g.dbg & 16);
-      if (do_stage && !spread) stage(fb, kt + S - 1);
+      const bool do_stage = kt + S - 1 < nk;
       const bf16_t* pa = smem + nb + la;
       const bf16_t* pb = smem + nb + lb;
       // the next step's B fragments go out behind the first MFMA group: the compiler's wait in front of that group
@@ -1035,7 +1028,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_glds4_kernel(const GemmArgs g) 
           alast = *reinterpret_cast<const frag8_t*>(pa + (FM - 1) * 16 * BK);   // early: nothing may trail the last group
         }
         if (i < FM - 1) af[i] = *reinterpret_cast<const frag8_t*>(pa + i * 16 * BK);
-        if ((i & 1) && do_stage && spread) stage_piece(fb, kt + S - 1, i >> 1);
+        if ((i & 1) && do_stage) stage_piece(fb, kt + S - 1, i >> 1);
         __builtin_amdgcn_sched_barrier(0);
       }
       af[FM - 1] = alast;
@@ -1056,12 +1049,237 @@ __global__ __launch_bounds__(512) void gemm_bf16_glds4_kernel(const GemmArgs g) 
     TC* auxz = g.aux ? reinterpret_cast<TC*>(g.aux) + z0 * g.aux_s0 + z1 * g.aux_s1 : nullptr;
     const float* bias = g.bias ? g.bias + z1 * g.bias_s1 : nullptr;
     const int nc = n0 + wn * 64 + fk * 16;
-    if ((g.dbg & 2) && acc[0][0][0] != 12345.f) continue;      // timing experiments: no epilogue
-    float cv0[8], cv1[8];
+      float cv0[8], cv1[8];
     load_col8(g, bias, nc, cv0);
     load_col8(g, bias, nc + 8, cv1);
     W2V2_EPI_DISPATCH((epilogue_direct<TC, EPI, FM>(g, Cz, auxz, acc, m0 + wm * 128 + frow, nc, cv0, cv1)));
   }   // tile loop
+}
+
+// ------------------------------------------------------------------------------ 256 x 256 x 64, phased (anti-phase wave groups)
+// PMC on the two ring kernels above (tools/gemm_pmc.py): ~40 % of all wave cycles are parked at s_waitcnt / s_barrier
+// and the matrix pipes are busy 25 % of the time.  Both waves of a SIMD run the same read -> wait -> MFMA sequence in
+// lockstep behind the per-step barrier, so the pipe idles whenever they wait for LDS or for a DMA stage.
+// This kernel schedules the two waves of every SIMD in ANTI-PHASE (cdna_hip_programming.md 5, "8-phase" structure):
+//   * 8 waves as 2 (m) x 4 (n), wave tile 128 x 64 (128 accumulator VGPRs); waves w and w + 4 share a SIMD and
+//     form the two groups (m halves).  A K tile of 64 is worked off in FOUR phases of 16 MFMAs (A half x B half x 2
+//     k-steps); a phase is  {ds_read the operands this phase needs | issue 2 DMA pieces | counted vmcnt} s_barrier
+//     {lgkmcnt(0) | 16 MFMAs} s_barrier.  Group 1 runs ONE barrier behind group 0, so on every SIMD one wave multiplies
+//     while the other reads: the matrix pipe always has a wave with its operands in registers.
+//   * LDS = two K-tile buffers of 64 KiB ([256 A rows | 256 B rows] x 128 B, chunk-swizzled as in the ring kernels),
+//     refilled by QUARTERS of 16 KiB in the order the phases consume them -- QA0 (first 64 rows of each group's A
+//     half) and QB0 (B rows with row & 8 == 0) are read in phase 1, QB1 in phase 2, QA1 in phase 3 -- and each quarter
+//     is re-issued two phases after its last read (strictly after BOTH groups' reads have returned): a quarter is in
+//     flight for 5-6 phases (~1.5 us), four quarters at a time, `s_waitcnt vmcnt(8)`, never vmcnt(0) in steady state.
+//   * same register epilogue as the 256x256 ring kernel (B rows permuted so a lane owns 16 consecutive columns).
+template <int N> __device__ __forceinline__ void wait_vm() {
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+}
+// wait until all but the `newer` most recently issued quarters (2 DMA pieces each) of this wave have landed
+__device__ __forceinline__ void wait_quarters(int newer) {
+  if (newer >= 4) wait_vm<8>();
+  else if (newer == 3) wait_vm<6>();
+  else if (newer == 2) wait_vm<4>();
+  else if (newer == 1) wait_vm<2>();
+  else wait_vm<0>();
+}
+
+template <typename TE, typename TC>
+__global__ __launch_bounds__(512) void gemm_ph_kernel(const GemmArgs g) {
+  constexpr int BM = 256, BN = 256, BK = 64, FM = 8, FN = 4;
+  constexpr int BUF = (BM + BN) * BK;             // elements per K-tile buffer: A [256][64] then B [256][64]
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // 0..7
+  const int wr = wave >> 2, wc = wave & 3;                     // wr = wave group (waves w, w + 4 share a SIMD)
+  const int ntile = g.tiles_m * g.tiles_n;
+  const int G = gridDim.x;
+  const int z = blockIdx.z;
+  const int z0 = z / g.batch_inner, z1 = z - z0 * g.batch_inner;
+  const int nk = g.K >> 6;
+  const bf16_t* Ab = reinterpret_cast<const bf16_t*>(g.A.ptr) + z0 * g.a_s0 + z1 * g.a_s1;
+  const bf16_t* Bb = reinterpret_cast<const bf16_t*>(g.B.ptr) + z0 * g.b_s0 + z1 * g.b_s1;
+  const int c8 = lane & 7, r8 = lane >> 3;
+  const int frow = lane & 15, fk = lane >> 4;
+  // fragment offsets (elements) inside a buffer, k-step 0 / 1
+  const int sw = swz(frow);
+  const int la0 = (wr * 128 + frow) * 64 + ((fk ^ sw) << 3);
+  const int la1 = (wr * 128 + frow) * 64 + (((4 + fk) ^ sw) << 3);
+  const int brow = (frow >> 2) * 16 + (frow & 3);
+  const int lb0 = BM * 64 + (wc * 64 + brow) * 64 + ((fk ^ sw) << 3);
+  const int lb1 = BM * 64 + (wc * 64 + brow) * 64 + (((4 + fk) ^ sw) << 3);
+  // DMA pieces of this wave: quarter q in {QA0, QB0, QB1, QA1}, piece j in {0, 1}; a piece = 8 consecutive LDS rows
+  //   QA0: piece p < 8 -> A rows p*8 .., p >= 8 -> 128 + (p-8)*8 ..      QA1: the same + 64
+  //   QB0: B rows p*16 ..                                                QB1: p*16 + 8 ..
+  auto piece_row = [&](int q, int j) -> int {
+    const int p = wave * 2 + j;
+    if (q == 0) return (p < 8 ? p * 8 : 128 + (p - 8) * 8);
+    if (q == 3) return (p < 8 ? p * 8 : 128 + (p - 8) * 8) + 64;
+    return p * 16 + (q == 2 ? 8 : 0);
+  };
+
+#pragma unroll 1
+  for (int t0 = 0; t0 < ntile; t0 += G) {
+    const int nchunk = min(G, ntile - t0);
+    if ((int)blockIdx.x >= nchunk) break;
+    const int tile = t0 + xcd_remap(blockIdx.x, nchunk);
+    const int tm = tile / g.tiles_n, tn = tile - tm * g.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    // per-lane source pointers of the 8 pieces (K offset added at issue)
+    const bf16_t* src[4][2];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int row = piece_row(q, j) + r8;
+        if (q == 0 || q == 3) src[q][j] = Ab + outer_off(g.A, min(m0 + row, g.M - 1)) + ((c8 ^ swz(row)) << 3);
+        else src[q][j] = Bb + outer_off(g.B, min(n0 + row, g.N - 1)) + ((c8 ^ swz_b(row)) << 3);
+      }
+    auto issue = [&](int q, int kt) {               // quarter q of K tile kt -> buffer kt & 1
+      bf16_t* base = smem + (kt & 1) * BUF + ((q == 0 || q == 3) ? 0 : BM * 64);
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        __builtin_amdgcn_global_load_lds((gvoid_t*)(src[q][j] + kt * 64), (lvoid_t*)(base + piece_row(q, j) * 64), 16,
+                                         0, 0);
+    };
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // ---- prologue: K tile 0 entirely, QA0 / QB0 of K tile 1 (issue order = consumption order)
+    issue(0, 0); issue(1, 0); issue(2, 0); issue(3, 0);
+    if (nk > 1) { issue(0, 1); issue(1, 1); }
+    wait_quarters(2 + (nk > 1 ? 2 : 0));             // QA0(0), QB0(0) landed (this wave's pieces)
+    __builtin_amdgcn_s_barrier();                    // ... everyone's
+    if (wr == 1) __builtin_amdgcn_s_barrier();       // group 1 runs one barrier behind from here on
+
+    frag8_t af[4][2], b0[2][2], b1[2][2];
+#pragma unroll 1
+    for (int kt = 0; kt < nk; ++kt) {
+      const bf16_t* bufp = smem + (kt & 1) * BUF;
+      const bool more1 = kt + 1 < nk, more2 = kt + 2 < nk;
+      // ---------------- phase 1: read B0 + A lo; issue QB1(kt+1); MFMA A lo x B0
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        b0[j][0] = *reinterpret_cast<const frag8_t*>(bufp + lb0 + j * 4 * 64);
+        b0[j][1] = *reinterpret_cast<const frag8_t*>(bufp + lb1 + j * 4 * 64);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        af[i][0] = *reinterpret_cast<const frag8_t*>(bufp + la0 + i * 16 * 64);
+        af[i][1] = *reinterpret_cast<const frag8_t*>(bufp + la1 + i * 16 * 64);
+      }
+      if (more1) issue(2, kt + 1);
+      wait_quarters(1 + (more1 ? 3 : 0));            // QB1(kt) for phase 2
+      __builtin_amdgcn_s_barrier();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = mfma16<TE>(b0[j][kk], af[i][kk], acc[i][j]);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_s_barrier();
+      // ---------------- phase 2: read B1; issue QA1(kt+1); MFMA A lo x B1
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        b1[j][0] = *reinterpret_cast<const frag8_t*>(bufp + lb0 + (2 + j) * 4 * 64);
+        b1[j][1] = *reinterpret_cast<const frag8_t*>(bufp + lb1 + (2 + j) * 4 * 64);
+      }
+      if (more1) issue(3, kt + 1);
+      wait_quarters(more1 ? 4 : 0);                  // QA1(kt) for phase 3
+      __builtin_amdgcn_s_barrier();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][2 + j] = mfma16<TE>(b1[j][kk], af[i][kk], acc[i][2 + j]);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_s_barrier();
+      // ---------------- phase 3: read A hi; issue QA0(kt+2); MFMA A hi x B1
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        af[i][0] = *reinterpret_cast<const frag8_t*>(bufp + la0 + (4 + i) * 16 * 64);
+        af[i][1] = *reinterpret_cast<const frag8_t*>(bufp + la1 + (4 + i) * 16 * 64);
+      }
+      if (more2) issue(0, kt + 2);
+      __builtin_amdgcn_s_barrier();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[4 + i][2 + j] = mfma16<TE>(b1[j][kk], af[i][kk], acc[4 + i][2 + j]);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_s_barrier();
+      // ---------------- phase 4: (operands in registers); issue QB0(kt+2); MFMA A hi x B0
+      if (more2) issue(1, kt + 2);
+      if (more1) wait_quarters(2 + (more2 ? 2 : 0)); // QA0(kt+1), QB0(kt+1) for the next K tile's phase 1
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[4 + i][j] = mfma16<TE>(b0[j][kk], af[i][kk], acc[4 + i][j]);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_s_barrier();
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();       // group 0 catches up: every read of this tile's buffers is done
+
+    TC* Cz = reinterpret_cast<TC*>(g.C) + z0 * g.c_s0 + z1 * g.c_s1;
+    TC* auxz = g.aux ? reinterpret_cast<TC*>(g.aux) + z0 * g.aux_s0 + z1 * g.aux_s1 : nullptr;
+    const float* bias = g.bias ? g.bias + z1 * g.bias_s1 : nullptr;
+    const int nc = n0 + wc * 64 + fk * 16;
+    float cv0[8], cv1[8];
+    load_col8(g, bias, nc, cv0);
+    load_col8(g, bias, nc + 8, cv1);
+    W2V2_EPI_DISPATCH((epilogue_direct<TC, EPI, FM>(g, Cz, auxz, acc, m0 + wr * 128 + frow, nc, cv0, cv1)));
+  }   // tile loop
+}
+
+template <typename TE, typename TC>
+static void launch_ph(GemmArgs a, int M, int N, int batch, hipStream_t st) {
+  constexpr size_t lds = (size_t)2 * (256 + 256) * 64 * sizeof(bf16_t);   // 128 KiB
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ph_kernel<TE, TC>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  a.tiles_m = (int)cdiv(M, 256);
+  a.tiles_n = (int)cdiv(N, 256);
+  const int tiles = a.tiles_m * a.tiles_n;
+  int ncu = 256;
+  {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
+  }
+  dim3 grid(tiles < ncu ? tiles : ncu, 1, batch);
+  hipLaunchKernelGGL((gemm_ph_kernel<TE, TC>), grid, dim3(512), lds, st, a);
 }
 
 static int g_w2v2_ncu = 0;
@@ -1193,6 +1411,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
 // ------------------------------------------------------------------------------ host dispatch
 static const bool g_w2v2_no_glds = getenv("W2V2_NO_GLDS") != nullptr;   // A/B switches for benchmarking
 static const bool g_w2v2_glds3 = getenv("W2V2_NO_GLDS3") == nullptr;
+static const bool g_w2v2_ph = getenv("W2V2_NO_GEMM_PH") == nullptr;
 
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
@@ -1260,7 +1479,6 @@ extern "C" int w2v2_gemm(const w2v2_gemm_desc* d, void* stream) {
   a.row_scale = d->row_scale; a.col_scale = d->col_scale;
   a.alpha = d->alpha;
   a.k_ext = d->k_ext; a.n_ext_from = d->n_ext_from; a.b_lo_off = d->b_lo_offset;
-  a.dbg = getenv("W2V2_GEMM_DBG") ? atoi(getenv("W2V2_GEMM_DBG")) : 0;
   static const bool defer_env = getenv("W2V2_NO_DEFER") == nullptr;   // A/B switch
   a.defer_ok = 0;
   const int cal = d->dtype_c == W2V2_F32 ? 4 : 8;     // elements per 16 bytes
@@ -1298,7 +1516,8 @@ extern "C" int w2v2_gemm(const w2v2_gemm_desc* d, void* stream) {
     // TE = operand element type (selects the MFMA instruction), TC = float or TE
 #define W2V2_GEMM_LAUNCH(TE, TC)                                                                         \
     do {                                                                                                 \
-      if (huge) launch_glds4<TE, TC>(a, d->M, d->N, d->batch, st);                                       \
+      if (huge && g_w2v2_ph) launch_ph<TE, TC>(a, d->M, d->N, d->batch, st);                              \
+      else if (huge) launch_glds4<TE, TC>(a, d->M, d->N, d->batch, st);                                  \
       else if (big) launch_glds3<TE, TC>(a, d->M, d->N, d->batch, st);                                   \
       else if (glds) { if (narrow) launch_glds<TE, 4, 2, TC>(a, grid, st); else launch_glds<TE, 4, 4, TC>(a, grid, st); } \
       else { if (narrow) launch_bf16<TE, 4, 2, TC>(a, grid, st); else launch_bf16<TE, 4, 4, TC>(a, grid, st); }         \

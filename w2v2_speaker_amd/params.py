@@ -412,8 +412,18 @@ class ParamStore:
         a = (self.flat, self.grad, self.exp_avg, self.exp_avg_sq)
         lp, sc = self.flat_lp, self.scaler
         n_train = min(self.n_train, self.n_body) if self.cnn_runtime_frozen else self.n_train
-        if sc is not None:        # found_inf over the slice this step updates; Adam skips itself when it is set
-            ops.grad_scaler_check(self.grad, h if head_only else n_train, sc)
+        if sc is not None:
+            # found_inf (torch GradScaler.unscale_): an overflow of ANY fp16 activation gradient (the only 16-bit
+            # tensors of the backward; weight gradients are f32 sums of finite products) propagates down the chain into
+            # the LAST bucket backward writes, so scanning that bucket (1.4 M of 99 M elements) decides for the step.
+            # Head-only steps and steps with a trainable CNN scan their whole slice.
+            if head_only:
+                ops.grad_scaler_check(self.grad, h, sc)
+            elif n_train > self.n_body:
+                ops.grad_scaler_check(self.grad, n_train, sc)
+            else:
+                lo = self.offsets[W2V_PREFIX + "encoder.layer_norm.weight"]
+                ops.grad_scaler_check(self.grad[lo:], n_train - lo, sc)
         if head_only:
             ops.adam_step(*a, lp, h, lr, beta1, beta2, eps, self.step_head, grad_scale, sc)
         elif self.step_head == self.step_body or h == 0:
