@@ -184,7 +184,11 @@ def run(args):
 
     if args.model == "ecapa":
         from tools.ecapa_bench import bench_ecapa
-        return bench_ecapa(args, world, rank, dev, dist)
+        bench_ecapa(args, world, rank, dev, dist)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     from w2v2_speaker_amd import ops
     from w2v2_speaker_amd.config import W2V2Config, Wav2Vec2RegularisationConfig
@@ -221,7 +225,7 @@ def run(args):
         trainer.train_step(wav, label)
     sync()
     skipped0 = int(store.scaler[3]) if store.scaler is not None else 0
-    ring = ("gemm_bf16_glds3_kernel", "gemm_bf16_glds4_kernel")
+    ring = ("gemm_bf16_glds3_kernel", "gemm_bf16_glds4_kernel", "gemm_ph_kernel")
     ops.Gemm.profile_begin(lambda g: g.kernel_name in ring)
     n_skip_layers = 0
     t0 = time.perf_counter()
@@ -274,7 +278,9 @@ def run(args):
         if prof["launches"]:
             desc = {"gemm_bf16_glds3_kernel": "256x128x64 3-stage LDS-DMA ring MFMA GEMM: conv4-6, projection, QKV, "
                                               "out-proj, FFN2 forward + the N<=2304 data-gradient products",
-                    "gemm_bf16_glds4_kernel": "256x256x32 4-stage LDS-DMA ring MFMA GEMM: conv1-3, FFN1 forward, dH"}
+                    "gemm_bf16_glds4_kernel": "256x256x32 4-stage LDS-DMA ring MFMA GEMM: conv1-3, FFN1 forward, dH",
+                    "gemm_ph_kernel": "256x256x64 phased LDS-DMA MFMA GEMM (two wave groups in anti-phase): conv1-3, "
+                                      "FFN1 forward, dH"}
             pmc = {}
             try:     # HBM bytes per launch and matrix-pipe busy fraction from the PMC passes (tools/pmc_*.py)
                 pmc = json.load(open(PMC_FILE))["kernels"]

@@ -102,7 +102,7 @@ int w2v2_gemm(const w2v2_gemm_desc* d, void* stream);
 
 /* Grouped weight-gradient GEMM (the backward of HF:520-526,544,565-572 nn.Linear weights/biases):
  *   dW_p[o][i] = sum_t dY_p[t][o] * X_p[t][i]      dbias_p[o] = sum_t dY_p[t][o]   (dbias may be NULL)
- * for 1..12 (dY, X) pairs in ONE launch, 16-bit operands [tokens][features] (K-major), f32 results
+ * for 1..32 (dY, X) pairs in ONE launch, 16-bit operands [tokens][features] (K-major), f32 results
  * WRITTEN (not accumulated), no split-K, no atomics -> bitwise reproducible.
  * Contract: rows [tokens, tokens_padded) of every dY / X are readable and zero
  * (tokens_padded = tokens rounded up to 64); n_out, n_in multiples of 8; 16-byte aligned rows. */
@@ -302,13 +302,14 @@ int w2v2_bce_head_fwd_bwd(const float* emb, const float* w, const float* b, cons
  * ref: src/lightning_modules/speaker/ecapa_tdnn.py:75-85 -> speechbrain 0.5.x ECAPA_TDNN (not part of the reference
  * tree; restated in oracle/ecapa_oracle.py).  Channels-last [B*T][C] activations; `ld*` = row stride in elements so
  * Res2Net channel slices and the MFA concatenation are views of their parent tensors.
- * BatchNorm1d with batch statistics over the M rows (biased variance), optionally on relu(a) (TDNNBlock = conv ->
- * ReLU -> BatchNorm): stats -> mean_rstd[C][2]; running = {mean[C], var[C]} updated like torch or NULL. */
+ * BatchNorm1d over the M rows of a channels-last [M][C] view (C, strides multiples of 8), optionally on relu(a)
+ * (TDNNBlock = conv -> ReLU -> BatchNorm).  train = 1: batch statistics (biased variance) through `workspace`
+ * partial sums, mean_rstd[C][2] written for the backward, running = {mean[C], var[C]} updated like torch or NULL;
+ * train = 0: the running statistics (BatchNorm1d.eval()).  Two launches (partial sums, fold + apply), deterministic. */
 int w2v2_bn_workspace_floats(int M, int C);
-int w2v2_bn_stats(const void* a, int64_t lda, float* workspace, float* mean_rstd, float* running, int M, int C,
-                  float eps, float momentum, int relu, int dtype, void* stream);
-int w2v2_bn_apply(const void* a, int64_t lda, const float* mean_rstd, const float* gamma, const float* beta, void* y,
-                  int64_t ldy, int M, int C, int relu, int dtype, void* stream);
+int w2v2_bn_fwd(const void* a, int64_t lda, float* workspace, float* mean_rstd, float* running, const float* gamma,
+                const float* beta, void* y, int64_t ldy, int M, int C, float eps, float momentum, int relu, int train,
+                int dtype, void* stream);
 /* dy -> da (through BatchNorm and the optional relu); writes dgamma[C], dbeta[C] */
 int w2v2_bn_bwd(const void* dy, int64_t lddy, const void* a, int64_t lda, const float* mean_rstd, const float* gamma,
                 float* workspace, float* dgamma, float* dbeta, void* da, int64_t ldda, int M, int C, int relu,
@@ -329,6 +330,20 @@ int w2v2_se_bwd_x(const void* dout, const float* g, const float* ds, void* dx, i
 /* f32 vectors; mode 0 relu, 1 sigmoid; the backward takes the forward output */
 int w2v2_act_fwd(const float* x, float* y, int64_t n, int mode, void* stream);
 int w2v2_act_bwd(const float* dy, const float* y, float* dx, int64_t n, int mode, void* stream);
+
+/* ---------------------------------------------------------------------------------------- skinny linear layers
+ * Exact-f32 nn.Linear / Conv1d(k=1) over a handful of rows (one per utterance): the SE bottleneck and the embedding
+ * layer of ECAPA (speechbrain SEBlock / ECAPA_TDNN.fc) and the hidden fc_list of the wav2vec2 head (ref:
+ * src/lightning_modules/speaker/wav2vec2_fc.py:108-141).  x [B][K], W [N][K], y [B][N] row-major, K % 4 == 0.
+ * act: 0 none, 1 relu, 2 sigmoid.  fwd: y = act(x W^T + bias).  The backward entries take the forward OUTPUT y and
+ * use dy' = dy * act'(y):  bwd_x: dx = dy' W;  bwd_w: dW (+)= dy'^T x, dbias (+)= column sums of dy' (dbias may be
+ * NULL). */
+int w2v2_skinny_linear_fwd(const float* x, const float* W, const float* bias, float* y, int B, int N, int K, int act,
+                           void* stream);
+int w2v2_skinny_linear_bwd_x(const float* dy, const float* y, const float* W, float* dx, int B, int N, int K, int act,
+                             void* stream);
+int w2v2_skinny_linear_bwd_w(const float* dy, const float* y, const float* x, float* dW, float* dbias, int B, int N,
+                             int K, int act, int accumulate, void* stream);
 
 /* ---------------------------------------------------------------------------------------- heads
  * Row inverse L2 norms 1/max(||x||,1e-12) (F.normalize, ref: src/optim/loss/aam_softmax.py:55). */

@@ -134,3 +134,73 @@ def test_ecapa_trainer_reduces_loss():
     tr = EcapaTrainer(st, plan, Constant(2e-3, 0.9))
     losses = [float(tr.train_step(feat.to(DEV), label.to(DEV))[0]) for _ in range(25)]
     assert all(math.isfinite(l) for l in losses) and losses[-1] < 0.6 * losses[0], losses
+
+
+@pytest.mark.parametrize("B,N,K", [(66, 128, 1024), (66, 1024, 128), (66, 192, 6144), (5, 24, 20), (1, 3, 4), (33, 130, 260)])
+@pytest.mark.parametrize("act", [0, 1, 2])
+def test_skinny_linear_kernels_vs_torch(B, N, K, act):
+    """csrc/skinny.hip (SE bottleneck, ECAPA fc, wav2vec2 fc_list): forward and both gradients against torch in f64."""
+    from w2v2_speaker_amd import ops
+    g = torch.Generator().manual_seed(B * 131 + N + K + act)
+    x, W, b = torch.randn(B, K, generator=g), torch.randn(N, K, generator=g) / K ** 0.5, torch.randn(N, generator=g)
+    dy = torch.randn(B, N, generator=g)
+    xr, Wr, br = x.double().requires_grad_(), W.double().requires_grad_(), b.double().requires_grad_()
+    pre = xr @ Wr.t() + br
+    yr = pre if act == 0 else torch.relu(pre) if act == 1 else torch.sigmoid(pre)
+    yr.backward(dy.double())
+    dev = "cuda"
+    xd, Wd, bd, dyd = x.to(dev), W.to(dev), b.to(dev), dy.to(dev)
+    y = torch.empty(B, N, device=dev)
+    ops.skinny_linear_fwd(xd, Wd, bd, y, act)
+    assert rel_l2(y.cpu().double(), yr.detach()) < 2e-6
+    dx = torch.empty(B, K, device=dev)
+    ops.skinny_linear_bwd_x(dyd, y if act else None, Wd, dx, act)
+    assert rel_l2(dx.cpu().double(), xr.grad) < 5e-6
+    dW, db = torch.full((N, K), 0.5, device=dev), torch.full((N,), -0.25, device=dev)
+    ops.skinny_linear_bwd_w(dyd, y if act else None, xd, dW, db, act, True)         # accumulate onto the fill values
+    assert rel_l2(dW.cpu().double() - 0.5, Wr.grad) < 5e-6
+    assert rel_l2(db.cpu().double() + 0.25, br.grad) < 5e-6
+    ops.skinny_linear_bwd_w(dyd, y if act else None, xd, dW, db, act, False)        # overwrite
+    assert rel_l2(dW.cpu().double(), Wr.grad) < 5e-6 and rel_l2(db.cpu().double(), br.grad) < 5e-6
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,C,ld,relu", [(9900, 128, 1024, True), (3300, 1024, 1024, True), (66, 6144, 6144, False),
+                                          (257, 8, 8, True), (130, 200, 208, False)])
+def test_batchnorm_kernels_vs_torch(dtype, M, C, ld, relu):
+    """csrc/tdnn.hip BatchNorm (partial sums + fold/apply) on a row-strided [M, C] view against torch BatchNorm1d
+    in f64: output, running statistics, input gradient, dgamma / dbeta; then the evaluation mode."""
+    from w2v2_speaker_amd import ops
+    dev = "cuda"
+    g = torch.Generator().manual_seed(M + C)
+    a = (torch.randn(M, ld, generator=g) * 1.5 + 0.3).to(dtype)
+    dy = torch.randn(M, ld, generator=g).to(dtype)
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    ar = a[:, :C].double().requires_grad_()
+    bn = torch.nn.BatchNorm1d(C, eps=1e-5, momentum=0.1).double()
+    bn.weight.data.copy_(gamma)
+    bn.bias.data.copy_(beta)
+    yr = bn(torch.relu(ar) if relu else ar)
+    yr.backward(dy[:, :C].double())
+    ad, dyd = a.to(dev), dy.to(dev)
+    y, da = torch.zeros(M, ld, dtype=dtype, device=dev), torch.zeros(M, ld, dtype=dtype, device=dev)
+    work, mr = ops.bn_workspace(M, C, dev), torch.empty(C, 2, device=dev)
+    running = torch.cat([torch.zeros(C), torch.ones(C)]).to(dev)
+    gd, bd = gamma.to(dev), beta.to(dev)
+    ops.bn_fwd(ad, ld, work, mr, running, gd, bd, y, ld, M, C, 1e-5, 0.1, relu, True)
+    tol = 1e-5 if dtype == torch.float32 else 6e-3
+    assert rel_l2(y[:, :C].cpu().double(), yr.detach()) < tol
+    assert float(y[:, C:].abs().max()) == 0.0 if ld > C else True               # columns outside the view untouched
+    assert rel_l2(running[:C].cpu().double(), bn.running_mean) < 1e-5
+    assert rel_l2(running[C:].cpu().double(), bn.running_var) < 1e-5
+    dgam, dbet = torch.empty(C, device=dev), torch.empty(C, device=dev)
+    ops.bn_bwd(dyd, ld, ad, ld, mr, gd, work, dgam, dbet, da, ld, M, C, relu)
+    gtol = 2e-5 if dtype == torch.float32 else 8e-3
+    assert rel_l2(da[:, :C].cpu().double(), ar.grad) < gtol
+    assert rel_l2(dgam.cpu().double(), bn.weight.grad) < 1e-4 and rel_l2(dbet.cpu().double(), bn.bias.grad) < 1e-4
+    bn.eval()
+    ye = bn(torch.relu(ar) if relu else ar)
+    run0 = running.clone()
+    ops.bn_fwd(ad, ld, None, mr, running, gd, bd, y, ld, M, C, 1e-5, 0.1, relu, False)
+    assert rel_l2(y[:, :C].cpu().double(), ye.detach()) < tol
+    assert torch.equal(running, run0)

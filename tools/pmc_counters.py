@@ -17,10 +17,30 @@ import glob
 import json
 import re
 import sqlite3
+import subprocess
 import sys
 
 N_SIMD = 4 * 256
 N_XCD = 8
+
+
+_DEMANGLED = {}
+
+
+def demangle(name):
+    """rocprofv3 leaves names with the _Float16 builtin (DF16_) mangled; binutils' c++filt does not know that code
+    either, so it is swapped for the other half type (Dh; builtin types are not substitution candidates, the rest of
+    the name is unaffected) and the printed `half` is renamed back."""
+    if not name.startswith("_Z"):
+        return name
+    if name not in _DEMANGLED:
+        try:
+            txt = subprocess.run(["c++filt", name.replace("DF16_", "Dh")], capture_output=True, text=True,
+                                 check=True).stdout.strip()
+            _DEMANGLED[name] = re.sub(r"\bhalf\b", "_Float16", txt) if txt and not txt.startswith("_Z") else name
+        except Exception:
+            _DEMANGLED[name] = name
+    return _DEMANGLED[name]
 
 
 def per_kernel(d, counter, how="sum"):
@@ -31,7 +51,7 @@ def per_kernel(d, counter, how="sum"):
          "on k.dispatch_id = c.dispatch_id where c.counter_name = ? group by k.name, c.dispatch_id")
     out = {}
     for name, _, s, a, _n in cur.execute(q, (counter,)):
-        name = re.sub(r"\(.*", "", name).replace("void ", "")
+        name = re.sub(r"\(.*", "", demangle(name)).replace("void ", "")
         e = out.setdefault(name, [0, 0.0])
         e[0] += 1
         e[1] += s if how == "sum" else a

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libw2v2hip.so")
 SOURCES = ["api.hip", "gemm.hip", "wgrad.hip", "norm.hip", "elementwise.hip", "conv0.hip", "posconv.hip", "posconv_wgrad.hip",
-           "softmax.hip", "attention.hip", "pool.hip", "asp.hip", "tdnn.hip", "heads.hip", "optim.hip"]
+           "softmax.hip", "attention.hip", "pool.hip", "asp.hip", "tdnn.hip", "skinny.hip", "heads.hip", "optim.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
 
 

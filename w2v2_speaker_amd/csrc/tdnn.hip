@@ -12,125 +12,256 @@
 // Res2Net slices and the MFA concatenation live inside their parent tensors without copies.
 #include "common.cuh"
 
-constexpr int TD_ROWS = 64;       // rows per partial-sum block of the BatchNorm reductions
-constexpr int TD_TL = 8;          // time lanes of the per-(utterance, channel) walks
+constexpr int BN_CW = 128;        // channels per workgroup of the BatchNorm kernels: 16 lanes x 8 channels (16 B)
+constexpr int BN_RL = 16;         // row lanes of a BatchNorm workgroup (blockDim = (16, BN_RL))
+constexpr int BN_AROWS = 256;     // rows one workgroup of the apply kernels walks
+constexpr int BN_UN = 4;          // rows in flight per thread (memory-level parallelism of the row walks)
 
 // ------------------------------------------------------------------------------------------ BatchNorm (+ReLU)
-template <typename T>
-__global__ void bn_partial_kernel(const T* __restrict__ a, int64_t lda, float* __restrict__ partial, int M, int C,
-                                  int relu) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  const int m0 = blockIdx.y * TD_ROWS, m1 = min(M, m0 + TD_ROWS);
-  float s1 = 0.f, s2 = 0.f;
-  for (int m = m0; m < m1; ++m) {
-    float r = to_f32<T>(a[(int64_t)m * lda + c]);
-    if (relu) r = fmaxf(r, 0.f);
-    s1 += r;
-    s2 = fmaf(r, r, s2);
+// Two launches per direction.  (1) partial: every workgroup reduces `rows` rows of a 128-channel strip to one
+// (sum, sum of squares) pair per channel -- 16-byte loads, 16 row lanes, an LDS fold in a fixed order.  (2) apply:
+// every workgroup first folds the partial blocks of ITS 128 channels (a few tens of KiB out of L2, in double, in
+// block order -- the same numbers in every workgroup, so the result does not depend on the grid), then walks its
+// rows.  The workgroups of row-block 0 publish mean / rstd (the backward reads them), update the running
+// statistics, and in the backward write dgamma / dbeta.  No finalize launch, no atomics, no grid-wide fence.
+constexpr int BN_PROWS = 256;     // rows per partial-sum block
+__device__ __forceinline__ int bn_rows(int) { return BN_PROWS; }
+static int bn_rows_host(int) { return BN_PROWS; }
+
+// red[row lane][channel][2] -> partial[blockIdx.y][channel][2]
+__device__ __forceinline__ void bn_store_partial(float (*red)[BN_CW][2], const float* s1, const float* s2,
+                                                 float* __restrict__ partial, int C) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    red[threadIdx.y][threadIdx.x * 8 + e][0] = s1[e];
+    red[threadIdx.y][threadIdx.x * 8 + e][1] = s2[e];
   }
-  float* pt = partial + ((int64_t)blockIdx.y * C + c) * 2;
-  pt[0] = s1;
-  pt[1] = s2;
-}
-// blockDim = (128 channels, 8 groups): group y folds partial blocks y, y+8, ... in order, thread y == 0 folds the groups
-__device__ __forceinline__ void td_fold(const float* __restrict__ partial, int nblk, int C, int c, double& s1,
-                                        double& s2, double (*red)[128][2]) {
-  double p1 = 0.0, p2 = 0.0;
-  if (c < C)
-    for (int j = threadIdx.y; j < nblk; j += 8) {
-      p1 += (double)partial[((int64_t)j * C + c) * 2];
-      p2 += (double)partial[((int64_t)j * C + c) * 2 + 1];
-    }
-  red[threadIdx.y][threadIdx.x][0] = p1;
-  red[threadIdx.y][threadIdx.x][1] = p2;
   __syncthreads();
-  s1 = 0.0;
-  s2 = 0.0;
-  if (threadIdx.y == 0)
-    for (int y = 0; y < 8; ++y) { s1 += red[y][threadIdx.x][0]; s2 += red[y][threadIdx.x][1]; }
+  const int tid = threadIdx.y * 16 + threadIdx.x;
+  const int c = tid & (BN_CW - 1), w = tid >> 7;
+  float s = 0.f;
+#pragma unroll
+  for (int y = 0; y < BN_RL; ++y) s += red[y][c][w];
+  const int cc = blockIdx.x * BN_CW + c;
+  if (cc < C) partial[((int64_t)blockIdx.y * C + cc) * 2 + w] = s;
 }
-__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ partial,
-                                                           float* __restrict__ mean_rstd, float* __restrict__ running,
-                                                           int nblk, int M, int C, float eps, float momentum) {
-  __shared__ double red[8][128][2];
-  const int c = blockIdx.x * 128 + threadIdx.x;
+template <typename T>
+__global__ __launch_bounds__(256) void bn_partial_kernel(const T* __restrict__ a, int64_t lda,
+                                                         float* __restrict__ partial, int M, int C, int relu) {
+  __shared__ float red[BN_RL][BN_CW][2];
+  const int cg = blockIdx.x * BN_CW + threadIdx.x * 8;
+  const int rows = bn_rows(C);
+  const int m0 = blockIdx.y * rows, m1 = min(M, m0 + rows);
+  float s1[8] = {}, s2[8] = {};
+  if (cg < C)
+    for (int m = m0 + threadIdx.y; m < m1; m += BN_UN * BN_RL) {      // BN_UN independent 16-byte loads in flight
+      Vec8<T> v[BN_UN];
+#pragma unroll
+      for (int u = 0; u < BN_UN; ++u) v[u].load(a + (int64_t)min(m + u * BN_RL, m1 - 1) * lda + cg);
+#pragma unroll
+      for (int u = 0; u < BN_UN; ++u)
+        if (m + u * BN_RL < m1) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float r = relu ? fmaxf(v[u].v[e], 0.f) : v[u].v[e];
+            s1[e] += r;
+            s2[e] = fmaf(r, r, s2[e]);
+          }
+        }
+    }
+  bn_store_partial(red, s1, s2, partial, C);
+}
+// the two column sums of channel blockIdx.x*128 + (tid & 127), folded over the partial blocks in a fixed order: wave g
+// takes blocks g, g+4, ... (one 16-byte load = 2 channels x 2 sums per lane, four loads in flight), then the four
+// wave results are added in wave order
+__device__ __forceinline__ void bn_fold(const float* __restrict__ partial, int nblk, int C, double (*fold)[BN_CW][2],
+                                        double& s1, double& s2) {
+  const int tid = threadIdx.y * 16 + threadIdx.x;
+  const int q = tid & 63, grp = tid >> 6;
+  const int cq = blockIdx.x * BN_CW + 2 * q;
+  double p[4] = {0.0, 0.0, 0.0, 0.0};
+  if (cq < C) {
+    const float* src = partial + (int64_t)cq * 2;
+    int j = grp;
+    for (; j + 12 < nblk; j += 16) {
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(src + (int64_t)(j + 4 * u) * C * 2);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        p[0] += (double)v[u].x; p[1] += (double)v[u].y; p[2] += (double)v[u].z; p[3] += (double)v[u].w;
+      }
+    }
+    for (; j < nblk; j += 4) {
+      const float4 v = *reinterpret_cast<const float4*>(src + (int64_t)j * C * 2);
+      p[0] += (double)v.x; p[1] += (double)v.y; p[2] += (double)v.z; p[3] += (double)v.w;
+    }
+  }
+  fold[grp][2 * q][0] = p[0];
+  fold[grp][2 * q][1] = p[1];
+  fold[grp][2 * q + 1][0] = p[2];
+  fold[grp][2 * q + 1][1] = p[3];
+  __syncthreads();
+  const int c = tid & (BN_CW - 1);
+  s1 = ((fold[0][c][0] + fold[1][c][0]) + fold[2][c][0]) + fold[3][c][0];
+  s2 = ((fold[0][c][1] + fold[1][c][1]) + fold[2][c][1]) + fold[3][c][1];
+}
+// mode 1: batch statistics from `partial` (training); mode 0: the running statistics (BatchNorm1d.eval())
+template <typename T>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ a, int64_t lda,
+                                                       const float* __restrict__ partial, int nblk,
+                                                       float* __restrict__ mean_rstd, float* __restrict__ running,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       T* __restrict__ y, int64_t ldy, int M, int C, int relu,
+                                                       float eps, float momentum, int mode) {
+  __shared__ double fold[4][BN_CW][2];
+  __shared__ float cf[4][BN_CW];                 // mean, rstd, gamma, beta of the strip
+  const int tid = threadIdx.y * 16 + threadIdx.x;
+  const int c = tid & (BN_CW - 1), cc = blockIdx.x * BN_CW + c;
+  float mu = 0.f, rstd = 0.f;
+  if (mode) {
+    double s1, s2;
+    bn_fold(partial, nblk, C, fold, s1, s2);
+    const double mud = s1 / M;
+    double var = s2 / M - mud * mud;
+    var = var > 0.0 ? var : 0.0;
+    mu = (float)mud;
+    rstd = (float)(1.0 / sqrt(var + (double)eps));
+    if (blockIdx.y == 0 && tid < BN_CW && cc < C && running != nullptr) {   // torch BatchNorm1d buffers: momentum
+      const double unb = M > 1 ? var * M / (M - 1) : var;                  // update with the unbiased variance
+      running[cc] = (1.f - momentum) * running[cc] + momentum * mu;
+      running[C + cc] = (1.f - momentum) * running[C + cc] + momentum * (float)unb;
+    }
+  } else if (cc < C) {
+    mu = running[cc];
+    rstd = 1.0f / sqrtf(running[C + cc] + eps);
+  }
+  if (tid < BN_CW && cc < C) {
+    cf[0][c] = mu;
+    cf[1][c] = rstd;
+    cf[2][c] = gamma[cc];
+    cf[3][c] = beta[cc];
+    if (blockIdx.y == 0) {
+      mean_rstd[2 * cc] = mu;
+      mean_rstd[2 * cc + 1] = rstd;
+    }
+  }
+  __syncthreads();
+  const int cl = threadIdx.x * 8, cg = blockIdx.x * BN_CW + cl;
+  if (cg >= C) return;
+  const int m0 = blockIdx.y * BN_AROWS, m1 = min(M, m0 + BN_AROWS);
+  float mus[8], rs[8], ga[8], be[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { mus[e] = cf[0][cl + e]; rs[e] = cf[1][cl + e]; ga[e] = cf[2][cl + e]; be[e] = cf[3][cl + e]; }
+  for (int m = m0 + threadIdx.y; m < m1; m += BN_UN * BN_RL) {
+    Vec8<T> v[BN_UN];
+#pragma unroll
+    for (int u = 0; u < BN_UN; ++u) v[u].load(a + (int64_t)min(m + u * BN_RL, m1 - 1) * lda + cg);
+#pragma unroll
+    for (int u = 0; u < BN_UN; ++u)
+      if (m + u * BN_RL < m1) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float r = relu ? fmaxf(v[u].v[e], 0.f) : v[u].v[e];
+          v[u].v[e] = (r - mus[e]) * rs[e] * ga[e] + be[e];
+        }
+        v[u].store(y + (int64_t)(m + u * BN_RL) * ldy + cg);
+      }
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const T* __restrict__ dy, int64_t lddy,
+                                                             const T* __restrict__ a, int64_t lda,
+                                                             const float* __restrict__ mean_rstd,
+                                                             float* __restrict__ partial, int M, int C, int relu) {
+  __shared__ float red[BN_RL][BN_CW][2];
+  const int cg = blockIdx.x * BN_CW + threadIdx.x * 8;
+  const int rows = bn_rows(C);
+  const int m0 = blockIdx.y * rows, m1 = min(M, m0 + rows);
+  float s1[8] = {}, s2[8] = {};
+  if (cg < C) {
+    float mu[8], rs[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { mu[e] = mean_rstd[2 * (cg + e)]; rs[e] = mean_rstd[2 * (cg + e) + 1]; }
+    for (int m = m0 + threadIdx.y; m < m1; m += BN_UN * BN_RL) {
+      Vec8<T> v[BN_UN], d[BN_UN];
+#pragma unroll
+      for (int u = 0; u < BN_UN; ++u) {
+        const int64_t mm = min(m + u * BN_RL, m1 - 1);
+        v[u].load(a + mm * lda + cg);
+        d[u].load(dy + mm * lddy + cg);
+      }
+#pragma unroll
+      for (int u = 0; u < BN_UN; ++u)
+        if (m + u * BN_RL < m1) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float r = relu ? fmaxf(v[u].v[e], 0.f) : v[u].v[e];
+            s1[e] += d[u].v[e];
+            s2[e] = fmaf(d[u].v[e], (r - mu[e]) * rs[e], s2[e]);
+          }
+        }
+    }
+  }
+  bn_store_partial(red, s1, s2, partial, C);
+}
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dy, int64_t lddy,
+                                                           const T* __restrict__ a, int64_t lda,
+                                                           const float* __restrict__ mean_rstd,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ partial, int nblk,
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                           T* __restrict__ da, int64_t ldda, int M, int C, int relu,
+                                                           float invM) {
+  __shared__ double fold[4][BN_CW][2];
+  __shared__ float cf[5][BN_CW];                 // mean, rstd, gamma*rstd, sum dy / M, sum dy xhat / M
+  const int tid = threadIdx.y * 16 + threadIdx.x;
+  const int c = tid & (BN_CW - 1), cc = blockIdx.x * BN_CW + c;
   double s1, s2;
-  td_fold(partial, nblk, C, c, s1, s2, red);
-  if (threadIdx.y != 0 || c >= C) return;
-  const double mu = s1 / M;
-  double var = s2 / M - mu * mu;
-  var = var > 0.0 ? var : 0.0;
-  mean_rstd[2 * c] = (float)mu;
-  mean_rstd[2 * c + 1] = (float)(1.0 / sqrt(var + (double)eps));
-  if (running != nullptr) {                       // torch BatchNorm1d buffers: momentum update, unbiased variance
-    const double unb = M > 1 ? var * M / (M - 1) : var;
-    running[c] = (1.f - momentum) * running[c] + momentum * (float)mu;
-    running[C + c] = (1.f - momentum) * running[C + c] + momentum * (float)unb;
+  bn_fold(partial, nblk, C, fold, s1, s2);
+  if (tid < BN_CW && cc < C) {
+    const float f1 = (float)s1, f2 = (float)s2, rstd = mean_rstd[2 * cc + 1];
+    cf[0][c] = mean_rstd[2 * cc];
+    cf[1][c] = rstd;
+    cf[2][c] = gamma[cc] * rstd;
+    cf[3][c] = f1 * invM;
+    cf[4][c] = f2 * invM;
+    if (blockIdx.y == 0) {                       // written, not accumulated
+      dbeta[cc] = f1;
+      dgamma[cc] = f2;
+    }
   }
-}
-template <typename T>
-__global__ void bn_apply_kernel(const T* __restrict__ a, int64_t lda, const float* __restrict__ mean_rstd,
-                                const float* __restrict__ gamma, const float* __restrict__ beta, T* __restrict__ y,
-                                int64_t ldy, int M, int C, int relu) {
-  const int64_t n = (int64_t)M * C;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const int c = (int)(i % C);
-    const int64_t m = i / C;
-    float r = to_f32<T>(a[m * lda + c]);
-    if (relu) r = fmaxf(r, 0.f);
-    y[m * ldy + c] = from_f32<T>((r - mean_rstd[2 * c]) * mean_rstd[2 * c + 1] * gamma[c] + beta[c]);
+  __syncthreads();
+  const int cl = threadIdx.x * 8, cg = blockIdx.x * BN_CW + cl;
+  if (cg >= C) return;
+  const int m0 = blockIdx.y * BN_AROWS, m1 = min(M, m0 + BN_AROWS);
+  float mu[8], rs[8], gr[8], m1s[8], m2s[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    mu[e] = cf[0][cl + e]; rs[e] = cf[1][cl + e]; gr[e] = cf[2][cl + e]; m1s[e] = cf[3][cl + e]; m2s[e] = cf[4][cl + e];
   }
-}
-template <typename T>
-__global__ void bn_bwd_partial_kernel(const T* __restrict__ dy, int64_t lddy, const T* __restrict__ a, int64_t lda,
-                                      const float* __restrict__ mean_rstd, float* __restrict__ partial, int M, int C,
-                                      int relu) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  const int m0 = blockIdx.y * TD_ROWS, m1 = min(M, m0 + TD_ROWS);
-  const float mu = mean_rstd[2 * c], rs = mean_rstd[2 * c + 1];
-  float s1 = 0.f, s2 = 0.f;
-  for (int m = m0; m < m1; ++m) {
-    float r = to_f32<T>(a[(int64_t)m * lda + c]);
-    if (relu) r = fmaxf(r, 0.f);
-    const float dz = to_f32<T>(dy[(int64_t)m * lddy + c]);
-    s1 += dz;
-    s2 = fmaf(dz, (r - mu) * rs, s2);
-  }
-  float* pt = partial + ((int64_t)blockIdx.y * C + c) * 2;
-  pt[0] = s1;
-  pt[1] = s2;
-}
-__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ partial,
-                                                               float* __restrict__ sums, float* __restrict__ dgamma,
-                                                               float* __restrict__ dbeta, int nblk, int C) {
-  __shared__ double red[8][128][2];
-  const int c = blockIdx.x * 128 + threadIdx.x;
-  double s1, s2;
-  td_fold(partial, nblk, C, c, s1, s2, red);
-  if (threadIdx.y != 0 || c >= C) return;
-  sums[2 * c] = (float)s1;
-  sums[2 * c + 1] = (float)s2;
-  dbeta[c] = (float)s1;                 // written, not accumulated
-  dgamma[c] = (float)s2;
-}
-template <typename T>
-__global__ void bn_bwd_apply_kernel(const T* __restrict__ dy, int64_t lddy, const T* __restrict__ a, int64_t lda,
-                                    const float* __restrict__ mean_rstd, const float* __restrict__ gamma,
-                                    const float* __restrict__ sums, T* __restrict__ da, int64_t ldda, int M, int C,
-                                    int relu, float invM) {
-  const int64_t n = (int64_t)M * C;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const int c = (int)(i % C);
-    const int64_t m = i / C;
-    const float av = to_f32<T>(a[m * lda + c]);
-    const float r = relu ? fmaxf(av, 0.f) : av;
-    const float rstd = mean_rstd[2 * c + 1];
-    const float rh = (r - mean_rstd[2 * c]) * rstd;
-    const float dz = to_f32<T>(dy[m * lddy + c]);
-    const float dr = gamma[c] * rstd * (dz - sums[2 * c] * invM - rh * sums[2 * c + 1] * invM);
-    da[m * ldda + c] = from_f32<T>((relu && !(av > 0.f)) ? 0.f : dr);
+  for (int m = m0 + threadIdx.y; m < m1; m += BN_UN * BN_RL) {
+    Vec8<T> v[BN_UN], d[BN_UN];
+#pragma unroll
+    for (int u = 0; u < BN_UN; ++u) {
+      const int64_t mm = min(m + u * BN_RL, m1 - 1);
+      v[u].load(a + mm * lda + cg);
+      d[u].load(dy + mm * lddy + cg);
+    }
+#pragma unroll
+    for (int u = 0; u < BN_UN; ++u)
+      if (m + u * BN_RL < m1) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float av = v[u].v[e];
+          const float r = relu ? fmaxf(av, 0.f) : av;
+          const float rh = (r - mu[e]) * rs[e];
+          const float dr = gr[e] * (d[u].v[e] - m1s[e] - rh * m2s[e]);
+          d[u].v[e] = (relu && !(av > 0.f)) ? 0.f : dr;
+        }
+        d[u].store(da + (int64_t)(m + u * BN_RL) * ldda + cg);
+      }
   }
 }
 
@@ -220,53 +351,70 @@ __global__ void add_strided_kernel(const T* __restrict__ a, int64_t lda, const T
 }
 
 // ------------------------------------------------------------------------------------------ squeeze-excitation gate
-__device__ __forceinline__ float td_block_sum(float v, float (*red)[64]) {
-  __syncthreads();
-  red[threadIdx.y][threadIdx.x] = v;
-  __syncthreads();
-  float s = 0.f;
-#pragma unroll
-  for (int y = 0; y < TD_TL; ++y) s += red[y][threadIdx.x];
-  return s;
-}
+// 8 channels (16 B) per thread; C % 8 == 0.
 // y[b,t,c] = x[b,t,c] * g[b,c]
 template <typename T>
 __global__ void se_scale_kernel(const T* __restrict__ x, const float* __restrict__ g, T* __restrict__ y, int B, int Tn,
                                 int C) {
-  const int64_t n = (int64_t)B * Tn * C;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const int c = (int)(i % C);
-    const int b = (int)(i / ((int64_t)Tn * C));
-    y[i] = from_f32<T>(to_f32<T>(x[i]) * g[(int64_t)b * C + c]);
+  const int nch = C >> 3;
+  const int total = B * Tn * nch;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int row = i / nch, ch = i - row * nch;
+    const int b = row / Tn;
+    Vec8<T> v;
+    Vec8<float> gv;
+    v.load(x + (int64_t)row * C + ch * 8);
+    gv.load(g + (int64_t)b * C + ch * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v.v[e] *= gv.v[e];
+    v.store(y + (int64_t)row * C + ch * 8);
   }
 }
-// dg[b,c] = sum_t dout[b,t,c] * x[b,t,c]        blockDim = (64 channels, TD_TL time lanes)
+// dg[b,c] = sum_t dout[b,t,c] * x[b,t,c]        blockDim = (16 channel groups of 8, 16 time lanes)
 template <typename T>
-__global__ void se_bwd_gate_kernel(const T* __restrict__ dout, const T* __restrict__ x, float* __restrict__ dg, int Tn,
-                                   int C) {
-  __shared__ float red[TD_TL][64];
-  const int b = blockIdx.y, c = blockIdx.x * 64 + threadIdx.x;
-  const bool ok = c < C;
-  float s = 0.f;
-  if (ok)
-    for (int t = threadIdx.y; t < Tn; t += TD_TL) {
-      const int64_t i = ((int64_t)b * Tn + t) * C + c;
-      s = fmaf(to_f32<T>(dout[i]), to_f32<T>(x[i]), s);
+__global__ __launch_bounds__(256) void se_bwd_gate_kernel(const T* __restrict__ dout, const T* __restrict__ x,
+                                                          float* __restrict__ dg, int Tn, int C) {
+  __shared__ float red[16][BN_CW];
+  const int b = blockIdx.y, cg = blockIdx.x * BN_CW + threadIdx.x * 8;
+  float s[8] = {};
+  if (cg < C)
+    for (int t = threadIdx.y; t < Tn; t += 16) {
+      const int64_t i = ((int64_t)b * Tn + t) * C + cg;
+      Vec8<T> d, v;
+      d.load(dout + i);
+      v.load(x + i);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s[e] = fmaf(d.v[e], v.v[e], s[e]);
     }
-  s = td_block_sum(s, red);
-  if (ok && threadIdx.y == 0) dg[(int64_t)b * C + c] = s;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[threadIdx.y][threadIdx.x * 8 + e] = s[e];
+  __syncthreads();
+  const int tid = threadIdx.y * 16 + threadIdx.x;
+  if (tid < BN_CW && blockIdx.x * BN_CW + tid < C) {
+    float acc = 0.f;
+#pragma unroll
+    for (int yy = 0; yy < 16; ++yy) acc += red[yy][tid];
+    dg[(int64_t)b * C + blockIdx.x * BN_CW + tid] = acc;
+  }
 }
 // dx[b,t,c] = dout[b,t,c] * g[b,c] + ds[b,c] / T      (ds = gradient wrt the time mean that feeds the gate)
 template <typename T>
 __global__ void se_bwd_x_kernel(const T* __restrict__ dout, const float* __restrict__ g, const float* __restrict__ ds,
                                 T* __restrict__ dx, int B, int Tn, int C) {
-  const int64_t n = (int64_t)B * Tn * C;
+  const int nch = C >> 3;
+  const int total = B * Tn * nch;
   const float invT = 1.0f / (float)Tn;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const int c = (int)(i % C);
-    const int b = (int)(i / ((int64_t)Tn * C));
-    const int64_t bc = (int64_t)b * C + c;
-    dx[i] = from_f32<T>(fmaf(to_f32<T>(dout[i]), g[bc], ds[bc] * invT));
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int row = i / nch, ch = i - row * nch;
+    const int b = row / Tn;
+    Vec8<T> v;
+    Vec8<float> gv, sv;
+    v.load(dout + (int64_t)row * C + ch * 8);
+    gv.load(g + (int64_t)b * C + ch * 8);
+    sv.load(ds + (int64_t)b * C + ch * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v.v[e] = fmaf(v.v[e], gv.v[e], sv.v[e] * invT);
+    v.store(dx + (int64_t)row * C + ch * 8);
   }
 }
 
@@ -289,51 +437,42 @@ __global__ void act_bwd_kernel(const float* __restrict__ dy, const float* __rest
 // ------------------------------------------------------------------------------------------ C ABI
 static int td_blocks(int64_t n) { return (int)(cdiv(n, 256) > 8192 ? 8192 : (cdiv(n, 256) < 1 ? 1 : cdiv(n, 256))); }
 
-extern "C" int w2v2_bn_workspace_floats(int M, int C) { return (int)cdiv(M, TD_ROWS) * C * 2 + 2 * C; }
+extern "C" int w2v2_bn_workspace_floats(int M, int C) { return (int)cdiv(M, 128) * C * 2; }
 
-extern "C" int w2v2_bn_stats(const void* a, int64_t lda, float* workspace, float* mean_rstd, float* running, int M,
-                             int C, float eps, float momentum, int relu, int dtype, void* stream) {
-  W2V2_REQUIRE(a && workspace && mean_rstd && M > 0 && C > 0 && lda >= C, "bn_stats: bad arguments");
-  const int nblk = (int)cdiv(M, TD_ROWS);
-  dim3 grid((unsigned)cdiv(C, 128), nblk);
+extern "C" int w2v2_bn_fwd(const void* a, int64_t lda, float* workspace, float* mean_rstd, float* running,
+                           const float* gamma, const float* beta, void* y, int64_t ldy, int M, int C, float eps,
+                           float momentum, int relu, int train, int dtype, void* stream) {
+  W2V2_REQUIRE(a && mean_rstd && gamma && beta && y && M > 0 && C > 0 && C % 8 == 0 && lda >= C && lda % 8 == 0 &&
+                   ldy % 8 == 0, "bn_fwd: bad arguments (C, lda, ldy multiples of 8)");
+  W2V2_REQUIRE(train ? workspace != nullptr : running != nullptr,
+               "bn_fwd: training needs the workspace, evaluation the running statistics");
+  const int nblk = (int)cdiv(M, bn_rows_host(C));
+  const dim3 blk(16, BN_RL), gp((unsigned)cdiv(C, BN_CW), nblk), ga((unsigned)cdiv(C, BN_CW), (unsigned)cdiv(M, BN_AROWS));
   hipStream_t st = as_stream(stream);
-  W2V2_DISPATCH_ACT(dtype, "bn_stats",
-    hipLaunchKernelGGL(bn_partial_kernel<AT>, grid, dim3(128), 0, st, (const AT*)a, lda, workspace, M, C, relu););
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)cdiv(C, 128)), dim3(128, 8), 0, st, workspace, mean_rstd,
-                     running, nblk, M, C, eps, momentum);
-  W2V2_CHECK_LAUNCH("bn_stats");
-  return 0;
-}
-
-extern "C" int w2v2_bn_apply(const void* a, int64_t lda, const float* mean_rstd, const float* gamma, const float* beta,
-                             void* y, int64_t ldy, int M, int C, int relu, int dtype, void* stream) {
-  W2V2_REQUIRE(a && mean_rstd && gamma && beta && y && M > 0 && C > 0, "bn_apply: bad arguments");
-  const int nb = td_blocks((int64_t)M * C);
-  hipStream_t st = as_stream(stream);
-  W2V2_DISPATCH_ACT(dtype, "bn_apply",
-    hipLaunchKernelGGL(bn_apply_kernel<AT>, dim3(nb), dim3(256), 0, st, (const AT*)a, lda, mean_rstd, gamma,
-                           beta, (AT*)y, ldy, M, C, relu););
-  W2V2_CHECK_LAUNCH("bn_apply");
+#define TD_BNF(T_)                                                                                                   \
+  if (train)                                                                                                         \
+    hipLaunchKernelGGL(bn_partial_kernel<T_>, gp, blk, 0, st, (const T_*)a, lda, workspace, M, C, relu);             \
+  hipLaunchKernelGGL(bn_apply_kernel<T_>, ga, blk, 0, st, (const T_*)a, lda, workspace, nblk, mean_rstd, running,    \
+                     gamma, beta, (T_*)y, ldy, M, C, relu, eps, momentum, train)
+  W2V2_DISPATCH_ACT(dtype, "bn_fwd", TD_BNF(AT););
+#undef TD_BNF
+  W2V2_CHECK_LAUNCH("bn_fwd");
   return 0;
 }
 
 extern "C" int w2v2_bn_bwd(const void* dy, int64_t lddy, const void* a, int64_t lda, const float* mean_rstd,
                            const float* gamma, float* workspace, float* dgamma, float* dbeta, void* da, int64_t ldda,
                            int M, int C, int relu, int dtype, void* stream) {
-  W2V2_REQUIRE(dy && a && mean_rstd && gamma && workspace && dgamma && dbeta && da && M > 0 && C > 0,
-               "bn_bwd: bad arguments");
-  const int nblk = (int)cdiv(M, TD_ROWS);
-  float* sums = workspace + (int64_t)nblk * C * 2;
-  dim3 grid((unsigned)cdiv(C, 128), nblk);
-  const int nb = td_blocks((int64_t)M * C);
+  W2V2_REQUIRE(dy && a && mean_rstd && gamma && workspace && dgamma && dbeta && da && M > 0 && C > 0 && C % 8 == 0 &&
+                   lda % 8 == 0 && lddy % 8 == 0 && ldda % 8 == 0, "bn_bwd: bad arguments (C and strides multiples of 8)");
+  const int nblk = (int)cdiv(M, bn_rows_host(C));
+  const dim3 blk(16, BN_RL), gp((unsigned)cdiv(C, BN_CW), nblk), ga((unsigned)cdiv(C, BN_CW), (unsigned)cdiv(M, BN_AROWS));
   hipStream_t st = as_stream(stream);
 #define TD_BNB(T_)                                                                                                  \
-  hipLaunchKernelGGL(bn_bwd_partial_kernel<T_>, grid, dim3(128), 0, st, (const T_*)dy, lddy, (const T_*)a, lda,     \
-                     mean_rstd, workspace, M, C, relu);                                                             \
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)cdiv(C, 128)), dim3(128, 8), 0, st, workspace, sums,    \
-                     dgamma, dbeta, nblk, C);                                                                       \
-  hipLaunchKernelGGL(bn_bwd_apply_kernel<T_>, dim3(nb), dim3(256), 0, st, (const T_*)dy, lddy, (const T_*)a, lda,   \
-                     mean_rstd, gamma, sums, (T_*)da, ldda, M, C, relu, 1.0f / (float)M)
+  hipLaunchKernelGGL(bn_bwd_partial_kernel<T_>, gp, blk, 0, st, (const T_*)dy, lddy, (const T_*)a, lda, mean_rstd,  \
+                     workspace, M, C, relu);                                                                        \
+  hipLaunchKernelGGL(bn_bwd_apply_kernel<T_>, ga, blk, 0, st, (const T_*)dy, lddy, (const T_*)a, lda, mean_rstd,    \
+                     gamma, workspace, nblk, dgamma, dbeta, (T_*)da, ldda, M, C, relu, 1.0f / (float)M)
   W2V2_DISPATCH_ACT(dtype, "bn_bwd", TD_BNB(AT););
 #undef TD_BNB
   W2V2_CHECK_LAUNCH("bn_bwd");
@@ -382,8 +521,8 @@ extern "C" int w2v2_add_strided(const void* a, int64_t lda, const void* b, int64
 }
 
 extern "C" int w2v2_se_scale(const void* x, const float* g, void* y, int B, int T, int C, int dtype, void* stream) {
-  W2V2_REQUIRE(x && g && y && B > 0 && T > 0 && C > 0, "se_scale: bad arguments");
-  const int nb = td_blocks((int64_t)B * T * C);
+  W2V2_REQUIRE(x && g && y && B > 0 && T > 0 && C > 0 && C % 8 == 0, "se_scale: bad arguments (C %% 8 == 0)");
+  const int nb = td_blocks((int64_t)B * T * (C >> 3));
   hipStream_t st = as_stream(stream);
   W2V2_DISPATCH_ACT(dtype, "se_scale",
     hipLaunchKernelGGL(se_scale_kernel<AT>, dim3(nb), dim3(256), 0, st, (const AT*)x, g, (AT*)y, B, T, C););
@@ -393,8 +532,8 @@ extern "C" int w2v2_se_scale(const void* x, const float* g, void* y, int B, int 
 
 extern "C" int w2v2_se_bwd_gate(const void* dout, const void* x, float* dg, int B, int T, int C, int dtype,
                                 void* stream) {
-  W2V2_REQUIRE(dout && x && dg && B > 0 && T > 0 && C > 0, "se_bwd_gate: bad arguments");
-  dim3 grid((unsigned)cdiv(C, 64), B), blk(64, TD_TL);
+  W2V2_REQUIRE(dout && x && dg && B > 0 && T > 0 && C > 0 && C % 8 == 0, "se_bwd_gate: bad arguments (C %% 8 == 0)");
+  dim3 grid((unsigned)cdiv(C, BN_CW), B), blk(16, 16);
   hipStream_t st = as_stream(stream);
   W2V2_DISPATCH_ACT(dtype, "se_bwd_gate",
     hipLaunchKernelGGL(se_bwd_gate_kernel<AT>, grid, blk, 0, st, (const AT*)dout, (const AT*)x, dg, T, C););
@@ -404,8 +543,8 @@ extern "C" int w2v2_se_bwd_gate(const void* dout, const void* x, float* dg, int 
 
 extern "C" int w2v2_se_bwd_x(const void* dout, const float* g, const float* ds, void* dx, int B, int T, int C, int dtype,
                              void* stream) {
-  W2V2_REQUIRE(dout && g && ds && dx && B > 0 && T > 0 && C > 0, "se_bwd_x: bad arguments");
-  const int nb = td_blocks((int64_t)B * T * C);
+  W2V2_REQUIRE(dout && g && ds && dx && B > 0 && T > 0 && C > 0 && C % 8 == 0, "se_bwd_x: bad arguments (C %% 8 == 0)");
+  const int nb = td_blocks((int64_t)B * T * (C >> 3));
   hipStream_t st = as_stream(stream);
   W2V2_DISPATCH_ACT(dtype, "se_bwd_x",
     hipLaunchKernelGGL(se_bwd_x_kernel<AT>, dim3(nb), dim3(256), 0, st, (const AT*)dout, g, ds, (AT*)dx,

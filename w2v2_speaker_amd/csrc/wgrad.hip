@@ -22,7 +22,7 @@ typedef __attribute__((address_space(1))) const void gvoid_t;
 typedef __attribute__((address_space(3))) void lvoid_t;
 typedef __attribute__((address_space(3))) short4v lds_s4_t;
 
-constexpr int WG_MAXP = 12;
+constexpr int WG_MAXP = 32;
 
 struct WgProblem {
   const bf16_t* dY;
@@ -630,7 +630,13 @@ extern "C" int w2v2_wgrad_grouped(const w2v2_wgrad_problem* probs, int n, int to
     (void)hipGetDevice(&dev);
     if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
   }
-  const bool ring4 = ring && t4 * 10 >= (int64_t)ncu * 8 && getenv("W2V2_NO_WGRAD4") == nullptr;
+  // ... and when their rounds over the chip cost less than the rounds of 256x128 tiles (a 256x256 tile takes ~1.7x
+  // the time of a 256x128 one; problems narrower than 256 rows -- the 128-channel Res2Net TDNNs of ECAPA -- leave
+  // half of a 256x256 tile empty, so a mixed group can need MORE time on the large tiles)
+  int64_t t3 = 0;
+  for (int i = 0; i < n; ++i) t3 += cdiv(probs[i].n_out, 256) * cdiv(probs[i].n_in, 128);
+  const bool ring4 = ring && t4 * 10 >= (int64_t)ncu * 8 && cdiv(t4, ncu) * 17 <= cdiv(t3, ncu) * 10 &&
+                     getenv("W2V2_NO_WGRAD4") == nullptr;
   const int bm = ring ? 256 : 128;
   const int bn = ring4 ? 256 : 128;
   for (int i = 0; i < n; ++i) {

@@ -260,13 +260,9 @@ class _Tdnn:
         if self.k > 1:
             ops.im2col_reflect(self.x, self.ldx, self.col, pl.B, pl.T, self.cin, self.k, self.dil)
         self.g_fwd()
-        if pl.train:
-            ops.bn_stats(self.a, self.cout, self.work, self.mean_rstd, self.running, self.M, self.cout, BN_EPS,
-                         BN_MOMENTUM, True)
-        else:                                        # BatchNorm1d.eval(): running statistics
-            ops.asp_bn_eval_stats(self.running, self.mean_rstd, self.cout, BN_EPS)
-        ops.bn_apply(self.a, self.cout, self.mean_rstd, st.p(self.pre + "norm.norm.weight"),
-                     st.p(self.pre + "norm.norm.bias"), self.y, self.ldy, self.M, self.cout, True)
+        ops.bn_fwd(self.a, self.cout, self.work, self.mean_rstd, self.running, st.p(self.pre + "norm.norm.weight"),
+                   st.p(self.pre + "norm.norm.bias"), self.y, self.ldy, self.M, self.cout, BN_EPS, BN_MOMENTUM, True,
+                   pl.train)
 
     def weight_grad_single(self) -> None:
         """dW, db of this block alone (f32 mode, or a block that is not part of a deferred group)."""
@@ -326,52 +322,30 @@ class _SEBlock:
         self.z = torch.empty(B, S, dtype=f32, device=dev)
         self.g = torch.empty(B, C, dtype=f32, device=dev)
         p = st.p
-        W1, W2 = p(self.pre + "conv1.conv.weight").view(S, C), p(self.pre + "conv2.conv.weight").view(C, S)
-        # M = B rows only: a handful of output tiles with a long K -> split-K (f32 atomics into a zeroed output; the
-        # bias is added by split 0)
-        self.sk1 = max(1, min(16, C // 128))
-        self.g1 = Gemm(B, S, C, self.s, W1, self.z, lda=C, ldb=C, ldc=S, epilogue=EPI_BIAS,
-                       bias=p(self.pre + "conv1.conv.bias"), split_k=self.sk1, accumulate=self.sk1 > 1)
-        self.g2 = Gemm(B, C, S, self.z, W2, self.g, lda=S, ldb=S, ldc=C, epilogue=EPI_BIAS,
-                       bias=p(self.pre + "conv2.conv.bias"))
+        self.W1, self.W2 = p(self.pre + "conv1.conv.weight").view(S, C), p(self.pre + "conv2.conv.weight").view(C, S)
+        self.b1, self.b2 = p(self.pre + "conv1.conv.bias"), p(self.pre + "conv2.conv.bias")
         if plan.train:
-            g = st.g
             self.dg = torch.empty(B, C, dtype=f32, device=dev)
             self.dz = torch.empty(B, S, dtype=f32, device=dev)
             self.ds = torch.empty(B, C, dtype=f32, device=dev)
-            self.g_dw2 = Gemm(C, S, B, self.dg, self.z, g(self.pre + "conv2.conv.weight").view(C, S), lda=C, ldb=S,
-                              ldc=S, transA=True, transB=True, accumulate=True)
-            self.g_dz = Gemm(B, S, C, self.dg, W2, self.dz, lda=C, ldb=S, ldc=S, transB=True, split_k=self.sk1,
-                             accumulate=self.sk1 > 1)
-            self.g_dw1 = Gemm(S, C, B, self.dz, self.s, g(self.pre + "conv1.conv.weight").view(S, C), lda=S, ldb=C,
-                              ldc=C, transA=True, transB=True, accumulate=True)
-            self.g_ds = Gemm(B, C, S, self.dz, W1, self.ds, lda=S, ldb=C, ldc=C, transB=True)
 
     def forward(self) -> None:
         pl = self.plan
         ops.pool_fwd(self.x.view(pl.B, pl.T, self.C), self.s, ops.POOL_MODES["mean"])
-        if self.sk1 > 1:
-            self.z.zero_()
-        self.g1()
-        ops.act_fwd(self.z, self.z, 0)
-        self.g2()
-        ops.act_fwd(self.g, self.g, 1)
+        ops.skinny_linear_fwd(self.s, self.W1, self.b1, self.z, ops.ACT_RELU)
+        ops.skinny_linear_fwd(self.z, self.W2, self.b2, self.g, ops.ACT_SIGMOID)
         ops.se_scale(self.x, self.g, self.y, pl.B, pl.T, self.C)
 
     def backward(self, dy: torch.Tensor, dx: torch.Tensor) -> None:
         """dy [M, C] contiguous -> dx [M, C] contiguous (written)."""
-        pl, st = self.plan, self.plan.store
-        ops.se_bwd_gate(dy, self.x, self.dg, pl.B, pl.T, self.C)
-        ops.act_bwd(self.dg, self.g, self.dg, 1)
-        self.g_dw2()
-        ops.colsum(self.dg, st.g(self.pre + "conv2.conv.bias"), pl.B, self.C)
-        if self.sk1 > 1:
-            self.dz.zero_()
-        self.g_dz()
-        ops.act_bwd(self.dz, self.z, self.dz, 0)
-        self.g_dw1()
-        ops.colsum(self.dz, st.g(self.pre + "conv1.conv.bias"), pl.B, self.S)
-        self.g_ds()
+        pl, g = self.plan, self.plan.store.g
+        ops.se_bwd_gate(dy, self.x, self.dg, pl.B, pl.T, self.C)                  # d/d gate (before sigmoid')
+        ops.skinny_linear_bwd_w(self.dg, self.g, self.z, g(self.pre + "conv2.conv.weight").view(self.C, self.S),
+                                g(self.pre + "conv2.conv.bias"), ops.ACT_SIGMOID, True)
+        ops.skinny_linear_bwd_x(self.dg, self.g, self.W2, self.dz, ops.ACT_SIGMOID)          # d/d z (before relu')
+        ops.skinny_linear_bwd_w(self.dz, self.z, self.s, g(self.pre + "conv1.conv.weight").view(self.S, self.C),
+                                g(self.pre + "conv1.conv.bias"), ops.ACT_RELU, True)
+        ops.skinny_linear_bwd_x(self.dz, self.z, self.W1, self.ds, ops.ACT_RELU)
         ops.se_bwd_x(dy, self.g, self.ds, dx, pl.B, pl.T, self.C)
 
 
@@ -433,18 +407,8 @@ class _SERes2Net:
         self.tdnn1.backward(self.d_t1, C, dx, lddx, accumulate, defer_dw=True)
         # residual: dx += dout
         ops.add_strided(dx, lddx, dout, lddo, dx, lddx, M, C)
-        # every da / input of the block is final now: all its weight gradients (tdnn1, tdnn2, the Res2Net TDNNs) in
-        # grouped launches (the chain above is sequential, these products are not)
-        tds = self.blocks()
-        if tds[0].grouped:
-            if not hasattr(self, "_wgs"):
-                probs = [t.wg_problem for t in tds]
-                self._wgs = [ops.WgradGroup(probs[i:i + 12], M, self.tdnn1.da._full.shape[0])
-                             for i in range(0, len(probs), 12)]
-            for wg in self._wgs:
-                wg()
-            for t in tds:
-                t.finish_weight_grad()
+        # the weight gradients of the block (tdnn1, tdnn2, the Res2Net TDNNs) are independent of the chain above: 16-bit
+        # mode leaves them to ONE grouped launch at the end of the plan's backward (EcapaPlan.backward)
 
 
 class EcapaPlan:
@@ -485,9 +449,7 @@ class EcapaPlan:
         self.emb = torch.empty(B, L, dtype=f32, device=dev)
         p, g = store.p, store.g
         Wfc = p(FE + "fc.conv.weight").view(L, E2)
-        self.sk_fc = max(1, min(32, E2 // 128))
-        self.g_fc = Gemm(B, L, E2, self.e2, Wfc, self.emb, lda=E2, ldb=E2, ldc=L, epilogue=EPI_BIAS,
-                         bias=p(FE + "fc.conv.bias"), split_k=self.sk_fc, accumulate=self.sk_fc > 1)
+        self.Wfc = Wfc
         self.head = ClassifierHead("aam", B, L, store.num_speakers, w_master=p("loss_fn.fc_weights"),
                                    w_operand=store.w("loss_fn.fc_weights"),
                                    w_grad=g("loss_fn.fc_weights") if train else None, emb=self.emb, act_dtype=adt,
@@ -495,12 +457,10 @@ class EcapaPlan:
         if train:
             self.de2 = torch.empty(B, E2, dtype=f32, device=dev)
             self.dpooled = torch.empty(B, E2, dtype=f32, device=dev)
-            self.g_dwfc = Gemm(L, E2, B, self.head.demb, self.e2, g(FE + "fc.conv.weight").view(L, E2), lda=L, ldb=E2,
-                               ldc=E2, transA=True, transB=True, accumulate=True)
-            self.g_de2 = Gemm(B, E2, L, self.head.demb, Wfc, self.de2, lda=L, ldb=E2, ldc=E2, transB=True)
             self.d_cat = torch.empty(M, C[-1], dtype=adt, device=dev)
             self.d_x0 = torch.empty(M, C[0], dtype=adt, device=dev)
         self._version = -1
+        self._wgs = None
 
     def buf(self, rows: int, cols: int) -> torch.Tensor:
         """[rows, cols] activation whose storage is zero-padded to a multiple of 64 rows (``_full``): legal K-major
@@ -534,15 +494,9 @@ class EcapaPlan:
         self.mfa.forward()
         self.asp.forward()
         E2 = self.pooled.shape[1]
-        if self.train:
-            ops.bn_stats(self.pooled, E2, self.bn_work, self.bn_mr, self.bn_running, B, E2, BN_EPS, BN_MOMENTUM, False)
-        else:
-            ops.asp_bn_eval_stats(self.bn_running, self.bn_mr, E2, BN_EPS)
-        ops.bn_apply(self.pooled, E2, self.bn_mr, st.p(FE + "asp_bn.norm.weight"), st.p(FE + "asp_bn.norm.bias"),
-                     self.e2, E2, B, E2, False)
-        if self.sk_fc > 1:
-            self.emb.zero_()
-        self.g_fc()
+        ops.bn_fwd(self.pooled, E2, self.bn_work, self.bn_mr, self.bn_running, st.p(FE + "asp_bn.norm.weight"),
+                   st.p(FE + "asp_bn.norm.bias"), self.e2, E2, B, E2, BN_EPS, BN_MOMENTUM, False, self.train)
+        ops.skinny_linear_fwd(self.e2, self.Wfc, st.p(FE + "fc.conv.bias"), self.emb, ops.ACT_NONE)
         return self.emb
 
     def head_forward_backward(self, label: torch.Tensor):
@@ -554,13 +508,13 @@ class EcapaPlan:
         st, B = self.store, self.B
         C = self.cfg.channels
         E2, L = self.pooled.shape[1], self.cfg.lin_neurons
-        self.g_dwfc()
-        ops.colsum(self.head.demb, st.g(FE + "fc.conv.bias"), B, L)
-        self.g_de2()
+        ops.skinny_linear_bwd_w(self.head.demb, None, self.e2, st.g(FE + "fc.conv.weight").view(L, E2),
+                                st.g(FE + "fc.conv.bias"), ops.ACT_NONE, True)
+        ops.skinny_linear_bwd_x(self.head.demb, None, self.Wfc, self.de2, ops.ACT_NONE)
         ops.bn_bwd(self.de2, E2, self.pooled, E2, self.bn_mr, st.p(FE + "asp_bn.norm.weight"), self.bn_work,
                    st.g(FE + "asp_bn.norm.weight"), st.g(FE + "asp_bn.norm.bias"), self.dpooled, E2, B, E2, False)
         self.asp.backward(self.dpooled)                                          # -> d_mfa (written)
-        self.mfa.backward(self.d_mfa, C[-1], self.d_cat, C[-1], False)
+        self.mfa.backward(self.d_mfa, C[-1], self.d_cat, C[-1], False, defer_dw=True)
         nb = len(self.blocks)
         for i in range(nb, 0, -1):                                                # block i reads block i-1's output
             blk = self.blocks[i - 1]
@@ -569,21 +523,43 @@ class EcapaPlan:
                 blk.backward(dout, C[-1], self.d_x0, C[0], False)
             else:
                 blk.backward(dout, C[-1], self.d_cat[:, (i - 2) * C[1]:], C[-1], True)
-        self.block0.backward(self.d_x0, C[0], None, 0, False)
+        self.block0.backward(self.d_x0, C[0], None, 0, False, defer_dw=True)
+        # every da / conv input is final (each TDNN owns its buffers): the weight + bias gradients of ALL grouped TDNN
+        # blocks in one launch (29 problems, ~550 tiles of equal length: three full rounds of the chip instead of one
+        # third-filled round per SE-Res2Net block), then the tap-major -> torch layout unpack of the k > 1 kernels
+        tds = [t for t in self._tdnns() if t.grouped]
+        if tds:
+            if self._wgs is None:
+                tds.sort(key=lambda t: -t.cout * t.K)
+                probs = [t.wg_problem for t in tds]
+                self._wgs = [ops.WgradGroup(probs[i:i + 32], tds[0].M, tds[0].da._full.shape[0])
+                             for i in range(0, len(probs), 32)]
+            for wg in self._wgs:
+                wg()
+            for t in tds:
+                t.finish_weight_grad()
 
 
 class EcapaTrainer:
     """One training step: forward, AAM head, backward, fused Adam (ref: speaker_recognition_module.py:207-220)."""
 
-    def __init__(self, store: EcapaStore, plan: EcapaPlan, schedule):
+    def __init__(self, store: EcapaStore, plan: EcapaPlan, schedule, process_group=None):
         self.store, self.plan, self.schedule, self.step = store, plan, schedule, 0
+        self.pg = process_group                      # data parallel: ONE all-reduce of the flat gradient arena (25 MB)
+        self.world = 1
+        if process_group is not None:
+            import torch.distributed as dist
+            self.world = dist.get_world_size(process_group)
 
     def train_step(self, feat: torch.Tensor, label: torch.Tensor):
         self.store.zero_grad()
         self.plan.embed(feat)
         loss, softmax = self.plan.head_forward_backward(label)
         self.plan.backward()
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(self.store.grad, group=self.pg)
         lr, beta1 = self.schedule.at(self.step)
-        self.store.adam_step(lr, beta1)
+        self.store.adam_step(lr, beta1, grad_scale=1.0 / self.world)
         self.step += 1
         return loss, softmax

@@ -133,43 +133,32 @@ class BceHead:
 class FcStack:
     """Hidden ``nn.Sequential(nn.Linear, nn.ReLU)`` layers between the pooled embedding and the loss head
     (ref: src/lightning_modules/speaker/wav2vec2_fc.py:185-228 ``fc_list``, :363-412 pre/post speaker-embedding ops).
-    f32 throughout (B x a few hundred features: negligible work, exact arithmetic): forward = GEMM + bias epilogue +
-    ReLU kernel, backward = ReLU', weight gradient GEMM (accumulated), bias column sums, data gradient GEMM."""
+    f32 throughout (B x a few hundred features: negligible work, exact arithmetic) on the skinny linear kernels
+    (csrc/skinny.hip): one launch per layer forward (bias + ReLU fused), two per layer backward (ReLU' fused)."""
 
     def __init__(self, store, batch: int, in_dim: int, hidden, x0: torch.Tensor, train: bool):
-        from .ops import EPI_BIAS
         dev, f32 = x0.device, torch.float32
         self.B, self.dims, self.train = batch, [in_dim] + list(hidden), train
         self.x = [x0] + [torch.empty(batch, h, dtype=f32, device=dev) for h in hidden]
         self.w = [store.p(f"fc_list.{i}.0.weight") for i in range(len(hidden))]
         self.b = [store.p(f"fc_list.{i}.0.bias") for i in range(len(hidden))]
-        self.g_fwd = [Gemm(batch, h, self.dims[i], self.x[i], self.w[i], self.x[i + 1], lda=self.dims[i],
-                           ldb=self.dims[i], ldc=h, epilogue=EPI_BIAS, bias=self.b[i]) for i, h in enumerate(hidden)]
         if train:
             self.dw = [store.g(f"fc_list.{i}.0.weight") for i in range(len(hidden))]
             self.db = [store.g(f"fc_list.{i}.0.bias") for i in range(len(hidden))]
             self.dx = [torch.empty(batch, d, dtype=f32, device=dev) for d in self.dims]      # d(loss)/d(x[i])
-            self.g_dw = [Gemm(h, self.dims[i], batch, self.dx[i + 1], self.x[i], self.dw[i], lda=h, ldb=self.dims[i],
-                              ldc=self.dims[i], transA=True, transB=True, accumulate=True)
-                         for i, h in enumerate(hidden)]
-            self.g_dx = [Gemm(batch, self.dims[i], h, self.dx[i + 1], self.w[i], self.dx[i], lda=h, ldb=self.dims[i],
-                              ldc=self.dims[i], transB=True) for i, h in enumerate(hidden)]
 
     def forward(self, upto: Optional[int] = None) -> torch.Tensor:
         """Run layers 0 .. upto (all by default); returns the output of the last one run."""
-        n = len(self.g_fwd) if upto is None else upto + 1
+        n = len(self.w) if upto is None else upto + 1
         for i in range(n):
-            self.g_fwd[i]()
-            ops.act_fwd(self.x[i + 1], self.x[i + 1], 0)           # ReLU in place
+            ops.skinny_linear_fwd(self.x[i], self.w[i], self.b[i], self.x[i + 1], ops.ACT_RELU)
         return self.x[n]
 
     def backward(self, dout: torch.Tensor) -> torch.Tensor:
         """dout = d(loss)/d(output of the last layer) -> d(loss)/d(x0); parameter gradients accumulated."""
-        n = len(self.g_fwd)
+        n = len(self.w)
         self.dx[n].copy_(dout)
         for i in reversed(range(n)):
-            ops.act_bwd(self.dx[i + 1], self.x[i + 1], self.dx[i + 1], 0)      # through the ReLU (y > 0)
-            self.g_dw[i]()
-            ops.colsum(self.dx[i + 1], self.db[i], self.B, self.dims[i + 1])
-            self.g_dx[i]()
+            ops.skinny_linear_bwd_w(self.dx[i + 1], self.x[i + 1], self.x[i], self.dw[i], self.db[i], ops.ACT_RELU, True)
+            ops.skinny_linear_bwd_x(self.dx[i + 1], self.x[i + 1], self.w[i], self.dx[i], ops.ACT_RELU)
         return self.dx[0]

@@ -118,7 +118,7 @@ class Gemm:
             t4 = -(-M // 256) * -(-N // 256)          # 256x256 tiling fills >= 85 % of the last round of 256 CUs
             if (b_lo is None and N >= 512 and batch == 1 and t4 >= 256 and t4 / (-(-t4 // 256) * 256) >= 0.85 and N / (-(-N // 256) * 256) >= 0.9
                     and not os.environ.get("W2V2_NO_GLDS4")):
-                self.kernel_name = "gemm_bf16_glds4_kernel"
+                self.kernel_name = "gemm_bf16_glds4_kernel" if os.environ.get("W2V2_NO_GEMM_PH") else "gemm_ph_kernel"
         elif fast:
             self.kernel_name = "gemm_bf16_glds_kernel"
         else:
@@ -566,16 +566,13 @@ def bn_workspace(M: int, C: int, device) -> torch.Tensor:
     return torch.empty(lib().w2v2_bn_workspace_floats(M, C), dtype=torch.float32, device=device)
 
 
-def bn_stats(a, lda: int, work, mean_rstd, running, M: int, C: int, eps: float, momentum: float, relu: bool) -> None:
-    _dev(a, work, mean_rstd, running)
-    _lib.check(lib().w2v2_bn_stats(a.data_ptr(), lda, work.data_ptr(), mean_rstd.data_ptr(), _p(running), M, C, eps,
-                                   momentum, int(relu), dt(a), stream()), "bn_stats")
-
-
-def bn_apply(a, lda: int, mean_rstd, gamma, beta, y, ldy: int, M: int, C: int, relu: bool) -> None:
-    _dev(a, mean_rstd, gamma, beta, y)
-    _lib.check(lib().w2v2_bn_apply(a.data_ptr(), lda, mean_rstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
-                                   y.data_ptr(), ldy, M, C, int(relu), dt(a), stream()), "bn_apply")
+def bn_fwd(a, lda: int, work, mean_rstd, running, gamma, beta, y, ldy: int, M: int, C: int, eps: float,
+           momentum: float, relu: bool, train: bool) -> None:
+    """BatchNorm1d (optionally on relu(a)): batch statistics + running update (train) or the running statistics."""
+    _dev(a, work, mean_rstd, running, gamma, beta, y)
+    _lib.check(lib().w2v2_bn_fwd(a.data_ptr(), lda, _p(work), mean_rstd.data_ptr(), _p(running), gamma.data_ptr(),
+                                 beta.data_ptr(), y.data_ptr(), ldy, M, C, eps, momentum, int(relu), int(train), dt(a),
+                                 stream()), "bn_fwd")
 
 
 def bn_bwd(dy, lddy: int, a, lda: int, mean_rstd, gamma, work, dgamma, dbeta, da, ldda: int, M: int, C: int,
@@ -619,6 +616,40 @@ def se_bwd_x(dout, g, ds, dx, B: int, T: int, C: int) -> None:
     _dev(dout, g, ds, dx)
     _lib.check(lib().w2v2_se_bwd_x(dout.data_ptr(), g.data_ptr(), ds.data_ptr(), dx.data_ptr(), B, T, C, dt(dout),
                                    stream()), "se_bwd_x")
+
+
+ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
+
+
+def skinny_linear_fwd(x, W, bias, y, act: int) -> None:
+    """y [B, N] = act(x [B, K] @ W [N, K]^T + bias) in exact f32 (csrc/skinny.hip)."""
+    _dev(x, W, bias, y)
+    assert x.dtype == W.dtype == y.dtype == torch.float32 and x.is_contiguous() and W.is_contiguous() and y.is_contiguous()
+    B, K = x.shape
+    N = W.shape[0]
+    assert W.numel() == N * K and y.shape == (B, N)
+    _lib.check(lib().w2v2_skinny_linear_fwd(x.data_ptr(), W.data_ptr(), _p(bias), y.data_ptr(), B, N, K, act, stream()),
+               "skinny_linear_fwd")
+
+
+def skinny_linear_bwd_x(dy, y, W, dx, act: int) -> None:
+    """dx [B, K] = (dy * act'(y)) [B, N] @ W [N, K]."""
+    _dev(dy, y, W, dx)
+    B, N = dy.shape
+    K = dx.shape[1]
+    assert W.numel() == N * K and dx.shape == (B, K) and dx.is_contiguous() and dy.is_contiguous()
+    _lib.check(lib().w2v2_skinny_linear_bwd_x(dy.data_ptr(), _p(y), W.data_ptr(), dx.data_ptr(), B, N, K, act, stream()),
+               "skinny_linear_bwd_x")
+
+
+def skinny_linear_bwd_w(dy, y, x, dW, dbias, act: int, accumulate: bool) -> None:
+    """dW [N, K] (+)= (dy * act'(y))^T @ x [B, K]; dbias [N] (+)= its column sums."""
+    _dev(dy, y, x, dW, dbias)
+    B, N = dy.shape
+    K = x.shape[1]
+    assert dW.numel() == N * K and x.shape == (B, K) and x.is_contiguous() and dy.is_contiguous()
+    _lib.check(lib().w2v2_skinny_linear_bwd_w(dy.data_ptr(), _p(y), x.data_ptr(), dW.data_ptr(), _p(dbias), B, N, K, act,
+                                              int(accumulate), stream()), "skinny_linear_bwd_w")
 
 
 def act_fwd(x, y, mode: int) -> None:
