@@ -282,10 +282,7 @@ class Wav2vec2FCModule:
     def _linear(self, x: torch.Tensor, i: int, relu: bool) -> torch.Tensor:
         W, b = self.store.p(f"fc_list.{i}.0.weight"), self.store.p(f"fc_list.{i}.0.bias")
         out = torch.empty(x.shape[0], W.shape[0], dtype=torch.float32, device=self.device)
-        ops.gemm(x.shape[0], W.shape[0], W.shape[1], x.float().contiguous(), W, out, lda=W.shape[1], ldb=W.shape[1],
-                 ldc=W.shape[0], epilogue=ops.EPI_BIAS, bias=b)
-        if relu:
-            ops.act_fwd(out, out, 0)
+        ops.skinny_linear_fwd(x.float().contiguous(), W, b, out, ops.ACT_RELU if relu else ops.ACT_NONE)
         return out
 
     def compute_speaker_prediction(self, embedding_tensor: torch.Tensor) -> torch.Tensor:
