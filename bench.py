@@ -166,13 +166,21 @@ def run(args):
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    if os.environ.get("W2V2_SHARE_GPU"):
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
     rccl = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # nccl == RCCL on ROCm
+        # nccl == RCCL on ROCm.  W2V2_DIST_BACKEND=gloo + W2V2_SHARE_GPU=1 exist only to rehearse the N > 1 control flow
+        # (self-spawn, bucket events, side stream) on a ONE-GPU box, where RCCL refuses two ranks on one device
+        backend = os.environ.get("W2V2_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
         # per-rank confirmation that the collective runs on the GPUs over RCCL: every rank contributes rank + 1
         chk = torch.full((1024,), float(rank + 1), device=dev)
         dist.all_reduce(chk)

@@ -49,7 +49,7 @@ def test_reflect_im2col_and_its_adjoint():
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_ecapa_training_step_vs_oracle(dtype):
+def test_ecapa_training_step_vs_unpinned_restatement(dtype):
     from w2v2_speaker_amd.ecapa import FE, EcapaPlan
     cfg, ocfg, st, sd, feat, label = _setup(dtype)
     sdg = {k: v.clone().requires_grad_(True) for k, v in sd.items()}

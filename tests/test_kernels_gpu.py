@@ -639,7 +639,7 @@ def test_dropout_stream_statistics():
 
 # ----------------------------------------------------------------------------------------------- attentive pooling
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
-def test_attentive_pooling_stages_at_base_size(dtype):
+def test_attentive_pooling_stages_at_base_size_vs_unpinned_restatement(dtype):
     """Every stage of csrc/asp.hip (+ its GEMMs) at the BASELINE configs[2] size (T=149, C=768, A=128) against an
     f64 torch evaluation of the SAME stage on the stage's own inputs as stored by the HIP path -- so bf16 is tested
     per stage, free of the noise amplification of the chained BatchNorm backward."""

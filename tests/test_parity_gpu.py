@@ -258,7 +258,7 @@ def _asp_weights(store, seed=5):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_attentive_statistics_pooling_step_vs_oracle(dtype):
+def test_attentive_statistics_pooling_step_vs_unpinned_restatement(dtype):
     """SURVEY 8a row a10 / BASELINE configs[2]: wav2vec2 -> attentive statistics pooling (global context, BatchNorm
     with batch statistics) -> AAM.  Embedding, loss and EVERY gradient (encoder + the six pooling tensors) against
     the oracle's autograd.  The oracle restates speechbrain's published definition (speechbrain is not available
