@@ -370,6 +370,35 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& g, f32x4 (&acc)[FM
   }
 }
 
+// Per-lane global source pointers of NP DMA pieces of one operand tile: piece j covers tile row row0 + j * step (this
+// lane's row of the piece), at element column col[j] of the K-contiguous row.  The general form costs a clamp, a
+// (segmented: 64-bit division) row offset and a 64-bit multiply PER PIECE -- with six pieces ~600 serially dependent
+// instructions = 1.7 us between kernel entry and the first DMA (s_memtime stamps), paid again for every tile of a
+// persistent workgroup.  When the whole tile lies inside the operand and inside ONE segment (uniform test, scalar
+// unit) the pieces are an arithmetic progression: one row offset, then NP - 1 additions.
+template <int NP>
+__device__ __forceinline__ void tile_ptrs(const OpDev& o, const bf16_t* base, int t0, int TR, int bound, int row0,
+                                          int step, const int* col, const bf16_t** out) {
+  bool fast = t0 + TR <= bound;
+  int64_t seg_base = 0;
+  int first = t0;
+  if (o.seg_len > 0) {
+    const int sl = (int)o.seg_len;
+    const int q0 = t0 / sl, q1 = (t0 + TR - 1) / sl;       // uniform 32-bit divisions (row counts fit an int)
+    fast = fast && q0 == q1;
+    seg_base = (int64_t)q0 * o.seg_stride;
+    first = t0 - q0 * sl;
+  }
+  if (fast) {
+    const bf16_t* p0 = base + seg_base + (int64_t)(first + row0) * o.ld;
+#pragma unroll
+    for (int j = 0; j < NP; ++j) out[j] = p0 + (int64_t)(j * step) * o.ld + col[j];
+  } else {
+#pragma unroll
+    for (int j = 0; j < NP; ++j) out[j] = base + outer_off(o, min(t0 + row0 + j * step, bound - 1)) + col[j];
+  }
+}
+
 // XCD-aware tile order: consecutive workgroup ids land on different XCDs (id % 8); remap so each
 // XCD owns a contiguous run of tiles (neighbouring tiles share the A row panel in its private L2).
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
@@ -753,17 +782,14 @@ __global__ __launch_bounds__(512) void gemm_bf16_glds3_kernel(const GemmArgs g) 
   const int c8 = lane & 7, r8 = lane >> 3;
   const bf16_t* ap[4];
   const bf16_t* bp[2];
+  {
+    int ca[4], cb[2];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int row = (wave * 4 + j) * 8 + r8;
-    const int grow = min(m0 + row, g.M - 1);
-    ap[j] = Ab + outer_off(g.A, grow) + ((c8 ^ swz(row)) << 3);
-  }
+    for (int j = 0; j < 4; ++j) ca[j] = (c8 ^ swz((wave * 4 + j) * 8 + r8)) << 3;
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int row = (wave * 2 + j) * 8 + r8;
-    const int grow = min(n0 + row, g.N - 1);
-    bp[j] = Bb + outer_off(g.B, grow) + ((c8 ^ swz_b(row)) << 3);
+    for (int j = 0; j < 2; ++j) cb[j] = (c8 ^ swz_b((wave * 2 + j) * 8 + r8)) << 3;
+    tile_ptrs<4>(g.A, Ab, m0, BM, g.M, wave * 32 + r8, 8, ca, ap);
+    tile_ptrs<2>(g.B, Bb, n0, BN, g.N, wave * 16 + r8, 8, cb, bp);
   }
 
   f32x4 acc[FM][FN];
@@ -1135,13 +1161,18 @@ __global__ __launch_bounds__(512) void gemm_ph_kernel(const GemmArgs g) {
     // per-lane source pointers of the 8 pieces (K offset added at issue)
     const bf16_t* src[4][2];
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
+    for (int q = 0; q < 4; ++q) {
+      const bool isa = q == 0 || q == 3;
+      int col[2];
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const int row = piece_row(q, j) + r8;
-        if (q == 0 || q == 3) src[q][j] = Ab + outer_off(g.A, min(m0 + row, g.M - 1)) + ((c8 ^ swz(row)) << 3);
-        else src[q][j] = Bb + outer_off(g.B, min(n0 + row, g.N - 1)) + ((c8 ^ swz_b(row)) << 3);
+        col[j] = (c8 ^ (isa ? swz(row) : swz_b(row))) << 3;
       }
+      // the two pieces of a quarter are 8 (A) / 16 (B) rows apart
+      if (isa) tile_ptrs<2>(g.A, Ab, m0, BM, g.M, piece_row(q, 0) + r8, 8, col, src[q]);
+      else tile_ptrs<2>(g.B, Bb, n0, BN, g.N, piece_row(q, 0) + r8, 16, col, src[q]);
+    }
     auto issue = [&](int q, int kt) {               // quarter q of K tile kt -> buffer kt & 1
       bf16_t* base = smem + (kt & 1) * BUF + ((q == 0 || q == 3) ? 0 : BM * 64);
 #pragma unroll
