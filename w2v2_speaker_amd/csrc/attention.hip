@@ -222,19 +222,24 @@ __global__ __launch_bounds__(256) void attn_fwd_tiled_kernel(const bf16_t* __res
       tile_load(rk, qb + H, gs, (t + 1) * AT_TILE, Tn);
       tile_load(rv, qb + 2 * H, gs, (t + 1) * AT_TILE, Tn);
     }
+    // 16-key blocks of this tile that hold a valid key (uniform): the blocks past the end of the sequence are skipped
+    // outright -- at T = 149 that is two of the twelve blocks a query tile walks
+    const int nfj = min(4, (Tn - t * AT_TILE + 15) >> 4);
     if (active) {
     float s[4][4];
     float tmax = -INFINITY;
 #pragma unroll
     for (int fj = 0; fj < 4; ++fj) {
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      if (fj < nfj) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk) acc = mfma16<TE>(lds_frag(Ks[cur], fj * 16, kk, lane), qf[kk], acc);
+        for (int kk = 0; kk < 2; ++kk) acc = mfma16<TE>(lds_frag(Ks[cur], fj * 16, kk, lane), qf[kk], acc);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int key = t * AT_TILE + fj * 16 + g * 4 + j;
-        s[fj][j] = key < Tn ? acc[j] * scale : -INFINITY;
-        tmax = fmaxf(tmax, s[fj][j]);
+        for (int j = 0; j < 4; ++j) {
+          const int key = t * AT_TILE + fj * 16 + g * 4 + j;
+          s[fj][j] = key < Tn ? acc[j] * scale : -INFINITY;
+          tmax = fmaxf(tmax, s[fj][j]);
+        }
       }
     }
     tmax = quad_max(tmax);
@@ -244,13 +249,18 @@ __global__ __launch_bounds__(256) void attn_fwd_tiled_kernel(const bf16_t* __res
     float psum = 0.f;
 #pragma unroll
     for (int fj = 0; fj < 4; ++fj) {
-      float ms[4] = {1.f, 1.f, 1.f, 1.f};
-      if (dp > 0.f) attn_drop4_keys(seed, bh, q, t * AT_TILE + fj * 16 + g * 4, Tn, dp, inv_keep, ms);
+      if (fj < nfj) {
+        float ms[4] = {1.f, 1.f, 1.f, 1.f};
+        if (dp > 0.f) attn_drop4_keys(seed, bh, q, t * AT_TILE + fj * 16 + g * 4, Tn, dp, inv_keep, ms);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float p = __expf(s[fj][j] - mn);
-        psum += p;                                    // the normaliser sums the probabilities BEFORE dropout
-        s[fj][j] = p * ms[j];
+        for (int j = 0; j < 4; ++j) {
+          const float p = __expf(s[fj][j] - mn);
+          psum += p;                                  // the normaliser sums the probabilities BEFORE dropout
+          s[fj][j] = p * ms[j];
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s[fj][j] = 0.f;
       }
     }
     l = l * alpha + quad_sum(psum);
@@ -258,9 +268,11 @@ __global__ __launch_bounds__(256) void attn_fwd_tiled_kernel(const bf16_t* __res
     for (int df = 0; df < 4; ++df) o[df] *= alpha;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
-      const frag8_t pf = pack_frag<TE>(s[2 * kb], s[2 * kb + 1]);
+      if (2 * kb < nfj) {
+        const frag8_t pf = pack_frag<TE>(s[2 * kb], s[2 * kb + 1]);
 #pragma unroll
-      for (int df = 0; df < 4; ++df) o[df] = mfma16<TE>(lds_frag_tr(Vs[cur], troff, df, kb), pf, o[df]);
+        for (int df = 0; df < 4; ++df) o[df] = mfma16<TE>(lds_frag_tr(Vs[cur], troff, df, kb), pf, o[df]);
+      }
     }
     }   // active
     if (t + 1 < ntile) {
@@ -327,31 +339,39 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_tiled_kernel(const bf16_t* __
       tile_load(rk, qb + H, gs, (t + 1) * AT_TILE, Tn);
       tile_load(rv, qb + 2 * H, gs, (t + 1) * AT_TILE, Tn);
     }
+    const int nfj = min(4, (Tn - t * AT_TILE + 15) >> 4);      // 16-key blocks with a valid key (uniform)
     if (active)
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
+      if (2 * kb < nfj) {
       float ds2[2][4];
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {
         const int fj = 2 * kb + hf;
-        f32x4 sa = {0.f, 0.f, 0.f, 0.f}, pa = {0.f, 0.f, 0.f, 0.f};
+        if (fj < nfj) {
+          f32x4 sa = {0.f, 0.f, 0.f, 0.f}, pa = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-          sa = mfma16<TE>(lds_frag(Ks[cur], fj * 16, kk, lane), qf[kk], sa);
-          pa = mfma16<TE>(lds_frag(Vs[cur], fj * 16, kk, lane), dof[kk], pa);
-        }
-        const int key0 = t * AT_TILE + fj * 16 + g * 4;
-        float ms[4] = {1.f, 1.f, 1.f, 1.f};
-        if (dp > 0.f) attn_drop4_keys(seed, bh, q, key0, Tn, dp, inv_keep, ms);
+          for (int kk = 0; kk < 2; ++kk) {
+            sa = mfma16<TE>(lds_frag(Ks[cur], fj * 16, kk, lane), qf[kk], sa);
+            pa = mfma16<TE>(lds_frag(Vs[cur], fj * 16, kk, lane), dof[kk], pa);
+          }
+          const int key0 = t * AT_TILE + fj * 16 + g * 4;
+          float ms[4] = {1.f, 1.f, 1.f, 1.f};
+          if (dp > 0.f) attn_drop4_keys(seed, bh, q, key0, Tn, dp, inv_keep, ms);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float p = (key0 + j < Tn && q < Tn) ? __expf(sa[j] * scale - l) : 0.f;
-          ds2[hf][j] = p * (pa[j] * ms[j] - dl) * scale;
+          for (int j = 0; j < 4; ++j) {
+            const float p = (key0 + j < Tn && q < Tn) ? __expf(sa[j] * scale - l) : 0.f;
+            ds2[hf][j] = p * (pa[j] * ms[j] - dl) * scale;
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) ds2[hf][j] = 0.f;
         }
       }
       const frag8_t pf = pack_frag<TE>(ds2[0], ds2[1]);
 #pragma unroll
       for (int df = 0; df < 4; ++df) o[df] = mfma16<TE>(lds_frag_tr(Ks[cur], troff, df, kb), pf, o[df]);
+      }
     }
     if (t + 1 < ntile) {
       tile_store(rk, Ks[cur ^ 1]);
@@ -418,30 +438,37 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_tiled_kernel(const bf16_t* __
       tile_load(ro, dob, H, (t + 1) * AT_TILE, Tn);
       row_load(t + 1);
     }
+    const int nfq = min(4, (Tn - t * AT_TILE + 15) >> 4);      // 16-query blocks with a valid row (uniform)
     if (active)
 #pragma unroll
     for (int qb2 = 0; qb2 < 2; ++qb2) {
+      if (2 * qb2 < nfq) {
       float pt2[2][4], ds2[2][4];
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {
         const int fq = 2 * qb2 + hf;
-        f32x4 sa = {0.f, 0.f, 0.f, 0.f}, pa = {0.f, 0.f, 0.f, 0.f};
+        if (fq < nfq) {
+          f32x4 sa = {0.f, 0.f, 0.f, 0.f}, pa = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-          sa = mfma16<TE>(lds_frag(Qs[cur], fq * 16, kk, lane), kf[kk], sa);
-          pa = mfma16<TE>(lds_frag(Os[cur], fq * 16, kk, lane), vf[kk], pa);
-        }
-        const float4 l4 = *reinterpret_cast<const float4*>(&lse_s[cur][fq * 16 + g * 4]);
-        const float4 d4 = *reinterpret_cast<const float4*>(&del_s[cur][fq * 16 + g * 4]);
-        const float la[4] = {l4.x, l4.y, l4.z, l4.w}, da[4] = {d4.x, d4.y, d4.z, d4.w};
-        const int q0 = t * AT_TILE + fq * 16 + g * 4;
-        float ms[4] = {1.f, 1.f, 1.f, 1.f};
-        if (dp > 0.f) attn_drop4_rows(seed, bh, q0, key, Tn, dp, inv_keep, ms);
+          for (int kk = 0; kk < 2; ++kk) {
+            sa = mfma16<TE>(lds_frag(Qs[cur], fq * 16, kk, lane), kf[kk], sa);
+            pa = mfma16<TE>(lds_frag(Os[cur], fq * 16, kk, lane), vf[kk], pa);
+          }
+          const float4 l4 = *reinterpret_cast<const float4*>(&lse_s[cur][fq * 16 + g * 4]);
+          const float4 d4 = *reinterpret_cast<const float4*>(&del_s[cur][fq * 16 + g * 4]);
+          const float la[4] = {l4.x, l4.y, l4.z, l4.w}, da[4] = {d4.x, d4.y, d4.z, d4.w};
+          const int q0 = t * AT_TILE + fq * 16 + g * 4;
+          float ms[4] = {1.f, 1.f, 1.f, 1.f};
+          if (dp > 0.f) attn_drop4_rows(seed, bh, q0, key, Tn, dp, inv_keep, ms);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float p = (q0 + j < Tn && key < Tn) ? __expf(sa[j] * scale - la[j]) : 0.f;
-          pt2[hf][j] = p * ms[j];
-          ds2[hf][j] = p * (pa[j] * ms[j] - da[j]) * scale;
+          for (int j = 0; j < 4; ++j) {
+            const float p = (q0 + j < Tn && key < Tn) ? __expf(sa[j] * scale - la[j]) : 0.f;
+            pt2[hf][j] = p * ms[j];
+            ds2[hf][j] = p * (pa[j] * ms[j] - da[j]) * scale;
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { pt2[hf][j] = 0.f; ds2[hf][j] = 0.f; }
         }
       }
       const frag8_t pf = pack_frag<TE>(pt2[0], pt2[1]);
@@ -450,6 +477,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_tiled_kernel(const bf16_t* __
       for (int df = 0; df < 4; ++df) {
         dv[df] = mfma16<TE>(lds_frag_tr(Os[cur], troff, df, qb2), pf, dv[df]);
         dk[df] = mfma16<TE>(lds_frag_tr(Qs[cur], troff, df, qb2), sf, dk[df]);
+      }
       }
     }
     if (t + 1 < ntile) {
