@@ -1,0 +1,78 @@
+"""Data-parallel step of the REAL engine on the GPU: two processes share the one device of the test box and
+all-reduce over gloo (RCCL refuses two ranks on one device; the reducer, its side stream and the bucket events are the
+same code path), then the result is compared with ONE process stepping on the joint batch.
+
+ref: PL ``accelerator: ddp`` (config/trainer/trainer.yaml:6-12): the gradient of the mean loss over the global batch is
+the average of the ranks' mean-loss gradients, so after one Adam step every replica holds the parameters of the
+single-process run."""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(dev, batch, seed_rank=None):
+    from oracle import w2v2_oracle as O
+    from w2v2_speaker_amd.config import W2V2Config, Wav2Vec2RegularisationConfig
+    from w2v2_speaker_amd.engine import Plan
+    from w2v2_speaker_amd.optim.schedule import OneCycle
+    from w2v2_speaker_amd.params import ParamStore
+    cfg = W2V2Config.tiny()
+    st = ParamStore(cfg, dev, torch.float32, head="aam", num_speakers=10)
+    st.init_weights(seed=3)
+    reg = Wav2Vec2RegularisationConfig(attention_dropout=0.0, feat_proj_dropout=0.0, hidden_dropout=0.0, layerdrop=0.0,
+                                       mask_time_prob=0.0)
+    plan = Plan(st, batch, 4000, train=True, reg=reg)
+    wav, label = O.synth_batch(4, 4000, 10, seed=11)          # the joint batch; rank r takes rows 2r, 2r+1
+    return st, plan, OneCycle(max_lr=1e-3, total_steps=10), wav.to(dev), label.to(dev)
+
+
+def _worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from w2v2_speaker_amd.trainer import SpeakerTrainer
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    st, plan, sched, wav, label = _setup(dev, 2)
+    tr = SpeakerTrainer(st, plan, sched)
+    for _ in range(2):
+        loss, _ = tr.train_step(wav[2 * rank:2 * rank + 2], label[2 * rank:2 * rank + 2])
+    torch.cuda.synchronize()
+    q.put((rank, st.flat[:st.n_train].cpu().numpy(), float(loss)))     # by value (no shared-memory handle)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_step_matches_single_process_on_joint_batch():
+    import torch.multiprocessing as mp
+    from w2v2_speaker_amd.trainer import SpeakerTrainer
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=300) for _ in procs), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    st, plan, sched, wav, label = _setup(torch.device("cuda", 0), 4)
+    tr = SpeakerTrainer(st, plan, sched)
+    for _ in range(2):
+        tr.train_step(wav, label)
+    torch.cuda.synchronize()
+    ref = st.flat[:st.n_train].cpu()
+    p0, p1 = torch.from_numpy(res[0][1]), torch.from_numpy(res[1][1])
+    assert torch.equal(p0, p1), "replicas diverged"
+    moved = float((ref - _fresh_params()).norm())
+    err = float((p0 - ref).norm())
+    print(f"two-rank vs joint batch: |dp| = {moved:.3e}, |p_ddp - p_joint| = {err:.3e}")
+    assert moved > 0 and err < 5e-4 * moved        # Adam normalises the update: compare against the step length
+
+
+def _fresh_params():
+    st, *_ = _setup(torch.device("cuda", 0), 1)
+    return st.flat[:st.n_train].cpu()
