@@ -177,6 +177,11 @@ def run(args):
         # nccl == RCCL on ROCm.  W2V2_DIST_BACKEND=gloo + W2V2_SHARE_GPU=1 exist only to rehearse the N > 1 control flow
         # (self-spawn, bucket events, side stream) on a ONE-GPU box, where RCCL refuses two ranks on one device
         backend = os.environ.get("W2V2_DIST_BACKEND", "nccl")
+        # An RCCL workgroup's LDS does not fit beside a 144 KiB GEMM workgroup, so every channel takes a CU away from
+        # the persistent GEMM grids for the length of a collective.  The single-round products (234 tiles) keep their
+        # one round as long as >= 234 of the 256 CUs stay free: cap the channels at 16 (376 MB per step at the
+        # bandwidth of 16 channels is still far shorter than the backward it hides under).  Override via the environment.
+        os.environ.setdefault("NCCL_MAX_NCHANNELS", "16")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
