@@ -767,7 +767,26 @@ __global__ __launch_bounds__(512) void gemm_bf16_glds3_kernel(const GemmArgs g) 
   const int nchunk = min(G, ntile - t0);
   if ((int)blockIdx.x >= nchunk) break;
   const int tile = t0 + xcd_remap(blockIdx.x, nchunk);
-  const int tm = tile / g.tiles_n, tn = tile - tm * g.tiles_n;
+  int tm, tn;
+  {
+    // Longest tiles first: with two-term weight columns (n >= n_ext_from) a tile of those columns runs twice the K
+    // steps.  In plain row-major order a workgroup of the fused QKV product (702 tiles, 3 rounds) can draw two double
+    // tiles and a single one (60 K steps against a mean of 44); enumerating all double tiles before the single ones
+    // bounds it at 48.  Tiles of one row panel stay adjacent inside each class (L2 reuse of the A rows).
+    const int tl = (g.k_ext > 0 && g.n_ext_from > 0) ? min(g.tiles_n, g.n_ext_from / BN) : 0;   // single-K columns
+    const int th = g.tiles_n - tl;
+    if (tl == 0 || th == 0) {
+      tm = tile / g.tiles_n;
+      tn = tile - tm * g.tiles_n;
+    } else if (tile < g.tiles_m * th) {
+      tm = tile / th;
+      tn = tl + (tile - tm * th);
+    } else {
+      const int t2 = tile - g.tiles_m * th;
+      tm = t2 / tl;
+      tn = t2 - tm * tl;
+    }
+  }
   const int m0 = tm * BM, n0 = tn * BN;
   const int z0 = z / g.batch_inner, z1 = z - z0 * g.batch_inner;
   // K steps of this tile: nk1 over (A, B) + for the tiles of the two-term weight columns nk - nk1 more over (A, B_lo)
