@@ -271,15 +271,15 @@ __device__ __forceinline__ void load_col8(const GemmArgs& g, const float* __rest
   }
 }
 
-template <typename TC, int EPI, int FM, int I0, bool DEFER = false>
+template <typename TC, int EPI, int FM, int I0, bool DEFER = false, int NR = 4>
 __device__ __forceinline__ void epilogue_direct4(const GemmArgs& g, TC* __restrict__ Cz, TC* __restrict__ auxz,
                                                  f32x4 (&acc)[FM][4], int m, int n, const float (&cv0)[8],
                                                  const float (&cv1)[8], uint4 (&pend)[8]) {
-  // row fragments I0 .. I0+3 of the wave tile (rows m + 16 i); four at a time bounds the aux staging registers
-  float ax[4][16];
+  // row fragments I0 .. I0+NR-1 of the wave tile (rows m + 16 i); NR at a time bounds the aux staging registers
+  float ax[NR][16];
   if constexpr (EPI == W2V2_EPI_GELU_BWD || EPI == W2V2_EPI_ADD) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NR; ++i) {
       const int mi = m + 16 * (I0 + i);
 #pragma unroll
       for (int e = 0; e < 16; ++e) ax[i][e] = 0.f;
@@ -301,7 +301,7 @@ __device__ __forceinline__ void epilogue_direct4(const GemmArgs& g, TC* __restri
     }
   }
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < NR; ++i) {
     const int mi = m + 16 * (I0 + i);
     if (mi >= g.M) continue;                           // (deferred: the flush repeats this test)
 #pragma unroll
@@ -320,15 +320,26 @@ __device__ __forceinline__ void epilogue_direct4(const GemmArgs& g, TC* __restri
     }
   }
 }
-// epilogue straight from the accumulators of a wave whose lane owns columns n .. n+15 of rows m + 16 i, i < FM
-template <typename TC, int EPI, int FM>
+// epilogue straight from the accumulators of a wave whose lane owns columns n .. n+15 of rows m + 16 i, i < FM.
+// NR = row fragments whose aux rows are staged together: 4 (64 VGPRs) hides their load latency best, the kernels at the
+// 256-register limit take 2 -- with 4 their tile-loop invariants spilled, and a kernel that touches scratch at all pays
+// ~8 us per dispatch (tools/probes/scratch_probe.hip)
+template <typename TC, int EPI, int FM, int NR = 4>
 __device__ __forceinline__ void epilogue_direct(const GemmArgs& g, TC* __restrict__ Cz, TC* __restrict__ auxz,
                                                 f32x4 (&acc)[FM][4], int m, int n, const float (&cv0)[8],
                                                 const float (&cv1)[8]) {
   if (n >= g.N) return;
   uint4 unused[8];
-  epilogue_direct4<TC, EPI, FM, 0>(g, Cz, auxz, acc, m, n, cv0, cv1, unused);
-  if constexpr (FM > 4) epilogue_direct4<TC, EPI, FM, 4>(g, Cz, auxz, acc, m, n, cv0, cv1, unused);
+  if constexpr (NR == 4) {
+    epilogue_direct4<TC, EPI, FM, 0>(g, Cz, auxz, acc, m, n, cv0, cv1, unused);
+    if constexpr (FM > 4) epilogue_direct4<TC, EPI, FM, 4>(g, Cz, auxz, acc, m, n, cv0, cv1, unused);
+  } else {
+    static_assert(NR == 2 && FM == 8, "two-row batches are wired for the 128-row wave tiles");
+    epilogue_direct4<TC, EPI, FM, 0, false, 2>(g, Cz, auxz, acc, m, n, cv0, cv1, unused);
+    epilogue_direct4<TC, EPI, FM, 2, false, 2>(g, Cz, auxz, acc, m, n, cv0, cv1, unused);
+    epilogue_direct4<TC, EPI, FM, 4, false, 2>(g, Cz, auxz, acc, m, n, cv0, cv1, unused);
+    epilogue_direct4<TC, EPI, FM, 6, false, 2>(g, Cz, auxz, acc, m, n, cv0, cv1, unused);
+  }
 }
 
 #define W2V2_EPI_DISPATCH(CALL)                                              \
@@ -1178,26 +1189,32 @@ __global__ __launch_bounds__(512) void gemm_ph_kernel(const GemmArgs g) {
     const int tm = tile / g.tiles_n, tn = tile - tm * g.tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
     // per-lane source pointers of the 8 pieces (K offset added at issue)
-    const bf16_t* src[4][2];
+    // element offsets from the operand base (32 bits: the largest operand, conv1's input, has 3.2e8 elements) -- as
+    // 64-bit pointers the eight sources cost 8 more VGPRs than this kernel has (it sits at the 256-register limit)
+    int soff[4][2];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const bool isa = q == 0 || q == 3;
       int col[2];
+      const bf16_t* ptr[2];
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const int row = piece_row(q, j) + r8;
         col[j] = (c8 ^ (isa ? swz(row) : swz_b(row))) << 3;
       }
       // the two pieces of a quarter are 8 (A) / 16 (B) rows apart
-      if (isa) tile_ptrs<2>(g.A, Ab, m0, BM, g.M, piece_row(q, 0) + r8, 8, col, src[q]);
-      else tile_ptrs<2>(g.B, Bb, n0, BN, g.N, piece_row(q, 0) + r8, 16, col, src[q]);
+      if (isa) tile_ptrs<2>(g.A, Ab, m0, BM, g.M, piece_row(q, 0) + r8, 8, col, ptr);
+      else tile_ptrs<2>(g.B, Bb, n0, BN, g.N, piece_row(q, 0) + r8, 16, col, ptr);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) soff[q][j] = (int)(ptr[j] - (isa ? Ab : Bb));
     }
     auto issue = [&](int q, int kt) {               // quarter q of K tile kt -> buffer kt & 1
-      bf16_t* base = smem + (kt & 1) * BUF + ((q == 0 || q == 3) ? 0 : BM * 64);
+      const bool isa = q == 0 || q == 3;
+      bf16_t* base = smem + (kt & 1) * BUF + (isa ? 0 : BM * 64);
 #pragma unroll
       for (int j = 0; j < 2; ++j)
-        __builtin_amdgcn_global_load_lds((gvoid_t*)(src[q][j] + kt * 64), (lvoid_t*)(base + piece_row(q, j) * 64), 16,
-                                         0, 0);
+        __builtin_amdgcn_global_load_lds((gvoid_t*)((isa ? Ab : Bb) + (soff[q][j] + kt * 64)),
+                                         (lvoid_t*)(base + piece_row(q, j) * 64), 16, 0, 0);
     };
     f32x4 acc[FM][FN];
 #pragma unroll
@@ -1302,11 +1319,15 @@ __global__ __launch_bounds__(512) void gemm_ph_kernel(const GemmArgs g) {
     TC* Cz = reinterpret_cast<TC*>(g.C) + z0 * g.c_s0 + z1 * g.c_s1;
     TC* auxz = g.aux ? reinterpret_cast<TC*>(g.aux) + z0 * g.aux_s0 + z1 * g.aux_s1 : nullptr;
     const float* bias = g.bias ? g.bias + z1 * g.bias_s1 : nullptr;
-    const int nc = n0 + wc * 64 + fk * 16;
+    // the output row / column of this lane are made opaque HERE: left to itself the compiler forms the epilogue's
+    // 64-bit row addresses before the main loop and, at the 256-register limit, spills them -- and a kernel that
+    // touches scratch at all pays ~8 us per dispatch (tools/probes/scratch_probe.hip)
+    int nc = n0 + wc * 64 + fk * 16, mr = m0 + wr * 128 + frow;
+    asm volatile("" : "+v"(nc), "+v"(mr));
     float cv0[8], cv1[8];
     load_col8(g, bias, nc, cv0);
     load_col8(g, bias, nc + 8, cv1);
-    W2V2_EPI_DISPATCH((epilogue_direct<TC, EPI, FM>(g, Cz, auxz, acc, m0 + wr * 128 + frow, nc, cv0, cv1)));
+    W2V2_EPI_DISPATCH((epilogue_direct<TC, EPI, FM, 2>(g, Cz, auxz, acc, mr, nc, cv0, cv1)));
   }   // tile loop
 }
 

@@ -97,7 +97,22 @@ __global__ __launch_bounds__(256, 4) void ln_bwd_kernel(const T* __restrict__ dy
   }
   for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
     const float mu = mean[row], rs = rstd[row];
-    float xh[LN_MAXC][8], g[LN_MAXC][8];
+    // 16-bit activations: the row of s is kept PACKED (4 instead of 8 VGPRs per chunk) and unpacked again in the
+    // second pass -- at 128 VGPRs (four workgroups per CU) the float copy spilled 5 registers, and a kernel that
+    // touches scratch at all pays ~8 us extra per dispatch on this stack (tools/probes/scratch_probe.hip)
+    constexpr bool PACK = sizeof(T) == 2;
+    uint4 sraw[PACK ? LN_MAXC : 1];
+    float xh[PACK ? 1 : LN_MAXC][8], g[LN_MAXC][8];
+    auto xhat = [&](int ci, int e) -> float {
+      if constexpr (PACK) {
+        const uint32_t w = e < 2 ? sraw[ci].x : e < 4 ? sraw[ci].y : e < 6 ? sraw[ci].z : sraw[ci].w;
+        float lo, hi;
+        unpack2<T>(w, lo, hi);
+        return ((e & 1 ? hi : lo) - mu) * rs;
+      } else {
+        return xh[ci][e];
+      }
+    };
     float c1 = 0.f, c2 = 0.f;
 #pragma unroll
     for (int ci = 0; ci < LN_MAXC; ++ci) {
@@ -107,13 +122,15 @@ __global__ __launch_bounds__(256, 4) void ln_bwd_kernel(const T* __restrict__ dy
         Vec8<T> vdy, vs;
         vdy.load(dy + off);
         vs.load(s + off);
+        if constexpr (PACK) sraw[ci] = *reinterpret_cast<const uint4*>(s + off);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          xh[ci][e] = (vs.v[e] - mu) * rs;
+          const float xv = (vs.v[e] - mu) * rs;
+          if constexpr (!PACK) xh[ci][e] = xv;
           g[ci][e] = vdy.v[e] * gm[ci][e];
           c1 += g[ci][e];
-          c2 += g[ci][e] * xh[ci][e];
-          ag[ci][e] += vdy.v[e] * xh[ci][e];
+          c2 += g[ci][e] * xv;
+          ag[ci][e] += vdy.v[e] * xv;
           ab[ci][e] += vdy.v[e];
         }
       }
@@ -127,7 +144,7 @@ __global__ __launch_bounds__(256, 4) void ln_bwd_kernel(const T* __restrict__ dy
         const int64_t off = (int64_t)row * H + ch * 8;
         Vec8<T> o, o2;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o.v[e] = rs * (g[ci][e] - c1 - xh[ci][e] * c2);
+        for (int e = 0; e < 8; ++e) o.v[e] = rs * (g[ci][e] - c1 - xhat(ci, e) * c2);
         if (d_r != nullptr) {
 #pragma unroll
           for (int e = 0; e < 8; e += 2) {
