@@ -236,7 +236,8 @@ __global__ __launch_bounds__(256, 2) void conv0_mfma_kernel(const float* __restr
   }
 }
 
-static bool conv0_mfma_ok(int C, int k) { return C % 128 == 0 && 3 * k <= 32 && getenv("W2V2_CONV0_VALU") == nullptr; }
+static const bool g_conv0_mfma = getenv("W2V2_CONV0_VALU") == nullptr;     // A/B switch
+static bool conv0_mfma_ok(int C, int k) { return C % 128 == 0 && 3 * k <= 32 && g_conv0_mfma; }
 
 static int conv0_check(const char* nm, int B, int N, int C, int k, int stride) {
   W2V2_REQUIRE(B > 0 && C > 0 && k > 0 && k <= C0_MAXK && stride > 0 && N >= k,

@@ -1353,6 +1353,13 @@ static void launch_ph(GemmArgs a, int M, int N, int batch, hipStream_t st) {
   hipLaunchKernelGGL((gemm_ph_kernel<TE, TC>), grid, dim3(512), lds, st, a);
 }
 
+static const bool g_w2v2_no_glds = getenv("W2V2_NO_GLDS") != nullptr;   // A/B switches for benchmarking
+static const bool g_w2v2_glds3 = getenv("W2V2_NO_GLDS3") == nullptr;
+static const bool g_w2v2_ph = getenv("W2V2_NO_GEMM_PH") == nullptr;
+static const bool g_w2v2_tile256 = getenv("W2V2_NO_GLDS4") == nullptr;          // 256x256 tiles at all
+static const bool g_w2v2_persistent = getenv("W2V2_G3_NONPERSISTENT") == nullptr;
+static const int g_w2v2_g3n = getenv("W2V2_G3N") ? atoi(getenv("W2V2_G3N")) : 512;  // smallest N of the 256x128 kernel
+
 static int g_w2v2_ncu = 0;
 static int device_cus() {
   if (g_w2v2_ncu == 0) {
@@ -1395,7 +1402,7 @@ static void launch_glds3(GemmArgs a, int M, int N, int batch, hipStream_t st) {
   }
   a.tiles_m = (int)cdiv(M, 256);
   a.tiles_n = (int)cdiv(N, 128);
-  const int ncu = getenv("W2V2_G3_NONPERSISTENT") ? (1 << 30) : device_cus();
+  const int ncu = g_w2v2_persistent ? device_cus() : (1 << 30);
   const int tiles = a.tiles_m * a.tiles_n;
   dim3 grid(tiles < ncu ? tiles : ncu, 1, batch);
   hipLaunchKernelGGL((gemm_bf16_glds3_kernel<TE, TC>), grid, dim3(512), lds, st, a);
@@ -1480,10 +1487,6 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
 }
 
 // ------------------------------------------------------------------------------ host dispatch
-static const bool g_w2v2_no_glds = getenv("W2V2_NO_GLDS") != nullptr;   // A/B switches for benchmarking
-static const bool g_w2v2_glds3 = getenv("W2V2_NO_GLDS3") == nullptr;
-static const bool g_w2v2_ph = getenv("W2V2_NO_GEMM_PH") == nullptr;
-
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 template <typename TE, int FM, int FN, typename TC>
@@ -1571,10 +1574,10 @@ extern "C" int w2v2_gemm(const w2v2_gemm_desc* d, void* stream) {
     // slightly faster on the 128x128 kernel at 2 workgroups per CU
     // (two-term weights exist on this kernel only: such a request takes it whatever the shape)
     const bool big = glds && split == 1 && !atomic &&
-                     (d->k_ext != 0 || (d->N >= (getenv("W2V2_G3N") ? atoi(getenv("W2V2_G3N")) : 512) && d->M >= 1024 && g_w2v2_glds3));
+                     (d->k_ext != 0 || (d->N >= g_w2v2_g3n && d->M >= 1024 && g_w2v2_glds3));
     // 256x256 tiles when they fill the chip: >= 85 % of the CU slots of the last round busy (FFN1, dH, conv stack)
     bool huge = false;
-    if (big && d->k_ext == 0 && d->N >= 512 && d->batch == 1 && !getenv("W2V2_NO_GLDS4")) {
+    if (big && d->k_ext == 0 && d->N >= 512 && d->batch == 1 && g_w2v2_tile256) {
       const int64_t t4 = cdiv(d->M, 256) * cdiv(d->N, 256), ncu = device_cus();
       huge = t4 >= ncu && (double)t4 / (double)(cdiv(t4, ncu) * ncu) >= 0.85 &&
              (double)d->N / (double)(cdiv(d->N, 256) * 256) >= 0.9;

@@ -620,7 +620,8 @@ extern "C" int w2v2_wgrad_grouped(const w2v2_wgrad_problem* probs, int n, int to
   // 256-row ring kernel unless every problem is narrower than one 256-row tile (or W2V2_WGRAD_V1 is set)
   int max_out = 0;
   for (int i = 0; i < n; ++i) max_out = probs[i].n_out > max_out ? probs[i].n_out : max_out;
-  const bool ring = max_out > 128 && getenv("W2V2_WGRAD_V1") == nullptr;
+  static const bool env_ring = getenv("W2V2_WGRAD_V1") == nullptr, env_ring4 = getenv("W2V2_NO_WGRAD4") == nullptr;   // A/B switches
+  const bool ring = max_out > 128 && env_ring;
   // 256x256 tiles when they alone fill >= 80 % of the CUs (e.g. the 8 problems of two w2v2-base blocks: 216 tiles)
   int64_t t4 = 0;
   for (int i = 0; i < n; ++i) t4 += cdiv(probs[i].n_out, 256) * cdiv(probs[i].n_in, 256);
@@ -636,7 +637,7 @@ extern "C" int w2v2_wgrad_grouped(const w2v2_wgrad_problem* probs, int n, int to
   int64_t t3 = 0;
   for (int i = 0; i < n; ++i) t3 += cdiv(probs[i].n_out, 256) * cdiv(probs[i].n_in, 128);
   const bool ring4 = ring && t4 * 10 >= (int64_t)ncu * 8 && cdiv(t4, ncu) * 17 <= cdiv(t3, ncu) * 10 &&
-                     getenv("W2V2_NO_WGRAD4") == nullptr;
+                     env_ring4;
   const int bm = ring ? 256 : 128;
   const int bn = ring4 ? 256 : 128;
   for (int i = 0; i < n; ++i) {
