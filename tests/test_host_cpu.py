@@ -270,3 +270,35 @@ def test_pl_format_checkpoint_round_trip_and_reheading(tmp_path):
     finally:
         C.W2V2Config.from_huggingface_id = orig
 
+
+
+def test_hot_kernels_use_no_scratch(tmp_path):
+    """A kernel that touches scratch (private segment) pays extra per dispatch on this stack (tools/probes/
+    scratch_probe.hip: 2.8 -> 10.5+ us isolated).  Guard: in the built library only the exact-f32 parity instantiations,
+    the f32-output ring GEMM (not launched by the training steps) and the A/B-only 256x256x32 kernel may spill."""
+    import re
+    import shutil
+    import subprocess
+    from w2v2_speaker_amd import _build
+    objdump, readelf = "/opt/rocm/lib/llvm/bin/llvm-objdump", "/opt/rocm/lib/llvm/bin/llvm-readelf"
+    if not (os.path.exists(objdump) and os.path.exists(readelf) and os.path.exists(_build.LIB)):
+        pytest.skip("needs the ROCm LLVM tools and a built libw2v2hip.so")
+    lib = tmp_path / "lib.so"
+    shutil.copy(_build.LIB, lib)
+    subprocess.run([objdump, "--offloading", str(lib)], cwd=tmp_path, capture_output=True, check=True)
+    allowed = re.compile(r"gemm_bf16_glds4_kernel|gemm_bf16_glds3_kernelI\w+fEv|ln_bwd_kernelIfE|gemm_f32_kernel")
+    spills, seen = [], 0
+    for f in tmp_path.glob("lib.so.*gfx950"):
+        notes = subprocess.run([readelf, "--notes", str(f)], capture_output=True, text=True, check=True).stdout
+        name = None
+        for line in notes.splitlines():
+            m = re.search(r"\.name:\s+(\S+)", line)
+            if m:
+                name = m.group(1)
+            m = re.search(r"\.private_segment_fixed_size:\s+(\d+)", line)
+            if m and name:
+                seen += 1
+                if int(m.group(1)) > 0 and not allowed.search(name):
+                    spills.append((name, int(m.group(1))))
+    assert seen > 100, "kernel metadata not found"
+    assert not spills, spills
