@@ -188,7 +188,7 @@ __device__ __forceinline__ void tile_store(const TileRegs& r, bf16_t* lds) {
 }
 
 template <typename TE>
-__global__ __launch_bounds__(256) void attn_fwd_tiled_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx,
+__global__ __launch_bounds__(256, 4) void attn_fwd_tiled_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx,
                                                              float* __restrict__ lse, int Tn, int heads, float scale,
                                                              float dp, float inv_keep, uint64_t seed) {
   __shared__ __attribute__((aligned(16))) bf16_t Ks[2][AT_TILE * 64];
@@ -384,7 +384,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_tiled_kernel(const bf16_t* __
 
 // dK, dV for 64 keys per workgroup, streaming query tiles (Q, dO, LSE, delta)
 template <typename TE>
-__global__ __launch_bounds__(256) void attn_bwd_kv_tiled_kernel(const bf16_t* __restrict__ qkv,
+__global__ __launch_bounds__(256, 3) void attn_bwd_kv_tiled_kernel(const bf16_t* __restrict__ qkv,
                                                                 const bf16_t* __restrict__ dctx,
                                                                 const float* __restrict__ lse,
                                                                 const float* __restrict__ delta,
