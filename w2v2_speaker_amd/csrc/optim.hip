@@ -18,26 +18,27 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
   }
   const int64_t nv = n >> 2;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nv; i += (int64_t)gridDim.x * blockDim.x) {
-    float4 pp = reinterpret_cast<float4*>(p)[i];
-    const float4 gg = reinterpret_cast<const float4*>(g)[i];
-    float4 mm = reinterpret_cast<float4*>(m)[i];
-    float4 vv = reinterpret_cast<float4*>(v)[i];
-    float* pa = &pp.x; const float* ga = &gg.x; float* ma = &mm.x; float* va = &vv.x;
+    // every array is touched once per step: streaming (non-temporal) accesses keep the 30 B/parameter out of the way
+    // of the L2 / Infinity Cache contents the next forward wants (the 16-bit operand copy written below)
+    f32x4_hw pp = __builtin_nontemporal_load(reinterpret_cast<const f32x4_hw*>(p) + i);
+    const f32x4_hw gg = __builtin_nontemporal_load(reinterpret_cast<const f32x4_hw*>(g) + i);
+    f32x4_hw mm = __builtin_nontemporal_load(reinterpret_cast<const f32x4_hw*>(m) + i);
+    f32x4_hw vv = __builtin_nontemporal_load(reinterpret_cast<const f32x4_hw*>(v) + i);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const float gr = ga[e] * gscale;
-      ma[e] = b1 * ma[e] + (1.0f - b1) * gr;
-      va[e] = b2 * va[e] + (1.0f - b2) * gr * gr;
-      const float denom = sqrtf(va[e]) * inv_sqrt_bc2 + eps;
-      pa[e] -= step_size * ma[e] / denom;
+      const float gr = gg[e] * gscale;
+      mm[e] = b1 * mm[e] + (1.0f - b1) * gr;
+      vv[e] = b2 * vv[e] + (1.0f - b2) * gr * gr;
+      const float denom = sqrtf(vv[e]) * inv_sqrt_bc2 + eps;
+      pp[e] -= step_size * mm[e] / denom;
     }
-    reinterpret_cast<float4*>(p)[i] = pp;
-    reinterpret_cast<float4*>(m)[i] = mm;
-    reinterpret_cast<float4*>(v)[i] = vv;
+    __builtin_nontemporal_store(pp, reinterpret_cast<f32x4_hw*>(p) + i);
+    __builtin_nontemporal_store(mm, reinterpret_cast<f32x4_hw*>(m) + i);
+    __builtin_nontemporal_store(vv, reinterpret_cast<f32x4_hw*>(v) + i);
     if (pb != nullptr) {
       uint2 w;
-      w.x = pack2<TB>(pp.x, pp.y);
-      w.y = pack2<TB>(pp.z, pp.w);
+      w.x = pack2<TB>(pp[0], pp[1]);
+      w.y = pack2<TB>(pp[2], pp[3]);
       reinterpret_cast<uint2*>(pb)[i] = w;
     }
   }
