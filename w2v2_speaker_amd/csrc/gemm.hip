@@ -1579,8 +1579,13 @@ extern "C" int w2v2_gemm(const w2v2_gemm_desc* d, void* stream) {
     bool huge = false;
     if (big && d->k_ext == 0 && d->N >= 512 && d->batch == 1 && g_w2v2_tile256) {
       const int64_t t4 = cdiv(d->M, 256) * cdiv(d->N, 256), ncu = device_cus();
+      // the phased kernel keeps its DMA sources as 32-bit element offsets from the operand base
+      auto extent = [](const w2v2_operand& o, int64_t rows, int64_t K) -> int64_t {
+        return (o.seg_len > 0 ? (rows / o.seg_len + 1) * o.seg_stride + o.seg_len * o.ld : rows * o.ld) + K;
+      };
+      const bool fits32 = extent(d->A, d->M, d->K) < (int64_t(1) << 31) && extent(d->B, d->N, d->K) < (int64_t(1) << 31);
       huge = t4 >= ncu && (double)t4 / (double)(cdiv(t4, ncu) * ncu) >= 0.85 &&
-             (double)d->N / (double)(cdiv(d->N, 256) * 256) >= 0.9;
+             (double)d->N / (double)(cdiv(d->N, 256) * 256) >= 0.9 && (fits32 || !g_w2v2_ph);
     }
     if (d->k_ext != 0)
       W2V2_REQUIRE(big && !huge && d->k_ext == d->K && d->n_ext_from >= 0 && d->n_ext_from % 128 == 0 &&
