@@ -302,3 +302,27 @@ def test_hot_kernels_use_no_scratch(tmp_path):
                     spills.append((name, int(m.group(1))))
     assert seen > 100, "kernel metadata not found"
     assert not spills, spills
+
+
+def test_committed_bench_lines_follow_the_contract():
+    """The JSON lines bench.py printed on the GPU box (committed under profiles/) carry every field the driver's
+    contract names; roofline.frac is achieved / peak; the ECAPA line has an HBM roofline per kernel family."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    line = json.load(open(os.path.join(root, "profiles", "r02_bench_line.json")))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in line, k
+    assert line["unit"] == "utterances/sec" and line["higher_is_better"] is True and line["vs_baseline"] is None
+    assert line["dtype"] == "f16" and line["data"] == "synthetic" and "workload" in line["config"]
+    assert "model" not in line["config"]
+    r = line["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 2500.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert isinstance(r["traffic"], int) and 0 < r["mfma_busy"] < 1
+    assert abs(line["value"] - line["config"]["global_batch"] / (line["ms_per_step"] * 1e-3)) < 0.01 * line["value"]
+    c = line["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+    e = json.load(open(os.path.join(root, "profiles", "r02_ecapa_bench_line.json")))
+    assert e["roofline"]["bound"] == "hbm" and e["roofline"]["unit"] == "GB/s" and e["roofline"]["peak"] == 8000.0
+    assert e["roofline"]["traffic"] > 0 and len(e["roofline_families"]) >= 3
