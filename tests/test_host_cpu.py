@@ -242,6 +242,8 @@ def test_pl_format_checkpoint_round_trip_and_reheading(tmp_path):
     from w2v2_speaker_amd.lightning_modules.speaker.wav2vec2_fc import Wav2vec2FCModule, Wav2vec2FCModuleConfig
     import dataclasses
     from w2v2_speaker_amd import config as C
+    from w2v2_speaker_amd.params import ParamStore
+    ParamStoreLegacy = ParamStore.legacy_key
     tiny = C.W2V2Config.tiny()
     orig = C.W2V2Config.from_huggingface_id
     C.W2V2Config.from_huggingface_id = staticmethod(lambda _id: tiny)       # keep the CPU test small
@@ -259,6 +261,18 @@ def test_pl_format_checkpoint_round_trip_and_reheading(tmp_path):
         ctor = lambda: AngularAdditiveMarginSoftMaxLoss(2, 2, margin=0.2, scale=30, device="cpu", act_dtype=torch.float32)
         ref_kw = dict(hyperparameters_to_save=None, num_speakers=7, loss_fn_constructor=ctor, validation_pairs=[],
                       test_pairs=[], evaluator=None)          # what ref: src/main.py:256-283 passes
+        # the file must carry the names of the reference's own stack (torch 1.9 weight_norm) -- its
+        # strict=False load would silently drop the parametrization names -- and torch-Adam-shaped optimizer states
+        keys = set(ck["state_dict"])
+        assert "wav2vec.model.encoder.pos_conv_embed.conv.weight_g" in keys
+        assert "wav2vec.model.encoder.pos_conv_embed.conv.weight_v" in keys
+        assert not any("parametrizations" in k for k in keys)
+        assert ck["pytorch-lightning_version"] == "1.4.5"
+        osd = ck["optimizer_states"][0]
+        assert set(osd) == {"state", "param_groups"} and osd["param_groups"][0]["params"] == list(range(len(keys)))
+        opt = torch.optim.Adam([torch.nn.Parameter(torch.zeros(tuple(v.shape))) for v in
+                                (ck["state_dict"][ParamStoreLegacy(k)] for k in a.store.reference_parameter_order())])
+        opt.load_state_dict(osd)                # what PL's restore does with it
         b = Wav2vec2FCModule.load_from_checkpoint(path, cfg=Wav2vec2FCModuleConfig(), init_seed=2, **ref_kw, **kw)
         assert b.steps == 123 and b.schedule_step == 123
         assert all(torch.equal(v, b.state_dict()[k]) for k, v in a.state_dict().items())
@@ -270,6 +284,70 @@ def test_pl_format_checkpoint_round_trip_and_reheading(tmp_path):
     finally:
         C.W2V2Config.from_huggingface_id = orig
 
+
+
+def test_checkpoint_keys_and_parameter_order_match_the_reference_stack(tmp_path):
+    """The reference's module is ``loss_fn`` + HF ``Wav2Vec2Model`` (under ``wav2vec.model.``) + ``fc_list``
+    (ref: wav2vec2_fc.py:101-228).  Key SET of a saved checkpoint == {HF state_dict keys with the torch-1.9 weight-norm
+    names} + the head, and ParamStore.reference_parameter_order() == HF ``named_parameters()`` order: the indices of
+    the torch-Adam state in ``optimizer_states`` then address the same tensors in the reference's optimiser.  An Adam
+    state survives save -> load (moments land at the right arena offsets)."""
+    import torch
+    from transformers import Wav2Vec2Config, Wav2Vec2Model
+    from w2v2_speaker_amd import config as C
+    from w2v2_speaker_amd.lightning_modules.speaker.wav2vec2_fc import Wav2vec2FCModule, Wav2vec2FCModuleConfig
+    from w2v2_speaker_amd.params import ParamStore, W2V_PREFIX
+    tiny = C.W2V2Config.tiny()
+    hf = Wav2Vec2Model(Wav2Vec2Config(
+        conv_dim=list(tiny.conv_dim), conv_kernel=list(tiny.conv_kernel), conv_stride=list(tiny.conv_stride),
+        hidden_size=tiny.hidden_size, num_hidden_layers=tiny.num_hidden_layers,
+        num_attention_heads=tiny.num_attention_heads, intermediate_size=tiny.intermediate_size,
+        num_conv_pos_embeddings=tiny.num_conv_pos_embeddings,
+        num_conv_pos_embedding_groups=tiny.num_conv_pos_embedding_groups))
+    hf_order = [W2V_PREFIX + n for n, _ in hf.named_parameters()]
+    hf_keys = {ParamStore.legacy_key(W2V_PREFIX + k) for k in hf.state_dict()}
+    orig = C.W2V2Config.from_huggingface_id
+    C.W2V2Config.from_huggingface_id = staticmethod(lambda _id: tiny)
+    try:
+        kw = dict(device="cpu", act_dtype=torch.float32)
+        m = Wav2vec2FCModule.from_config(Wav2vec2FCModuleConfig(reset_weights=True, hidden_fc_layers_out=[24]),
+                                         num_speakers=7, loss="ce", init_seed=1, **kw)
+        order = m.store.reference_parameter_order()
+        assert [n for n in order if n.startswith(W2V_PREFIX)] == hf_order
+        assert order[-4:] == ["fc_list.0.0.weight", "fc_list.0.0.bias", "fc_list.1.0.weight", "fc_list.1.0.bias"]
+        st = m.store
+        g = torch.Generator().manual_seed(3)
+        st.exp_avg = torch.randn(st.grad.shape, generator=g)
+        st.exp_avg_sq = torch.rand(st.grad.shape, generator=g)
+        st.step_head, st.step_body = 9, 5
+        path = str(tmp_path / "m.ckpt")
+        m.save_checkpoint(path)
+        ck = torch.load(path, weights_only=True)         # tensors / ints / containers only: loads without unpickling code
+        assert set(ck["state_dict"]) == hf_keys | {"fc_list.0.0.weight", "fc_list.0.0.bias", "fc_list.1.0.weight",
+                                                   "fc_list.1.0.bias"}
+        osd = ck["optimizer_states"][0]
+        for i, n in enumerate(order):                     # state i belongs to reference parameter i
+            if i in osd["state"]:
+                assert tuple(osd["state"][i]["exp_avg"].shape) == tuple(st.shapes[n])
+                assert osd["state"][i]["step"] == (9 if n.startswith("fc_list.") else 5)
+        frozen = [i for i, n in enumerate(order) if "feature_extractor" in n]
+        assert frozen and not any(i in osd["state"] for i in frozen)       # no gradient ever -> no Adam state (torch)
+        ctor_kw = dict(cfg=Wav2vec2FCModuleConfig(hidden_fc_layers_out=[24]), num_speakers=7,
+                       loss_fn_constructor=lambda: __import__("w2v2_speaker_amd.optim.loss", fromlist=["x"]).CrossEntropyLoss())
+        b = Wav2vec2FCModule.load_from_checkpoint(path, init_seed=2, **ctor_kw, **kw)
+        import math
+        for name, off in st.offsets.items():              # (the arena pads every tensor to 64 elements)
+            if off < st.n_train:
+                sl = slice(off, off + math.prod(st.shapes[name]))
+                assert torch.equal(b.store.exp_avg[sl], st.exp_avg[sl]), name
+                assert torch.equal(b.store.exp_avg_sq[sl], st.exp_avg_sq[sl]), name
+        assert (b.store.step_head, b.store.step_body) == (9, 5)
+        # a file written with the torch >= 2.1 names loads too
+        m.save_checkpoint(path, legacy_weight_norm_names=False)
+        c = Wav2vec2FCModule.load_from_checkpoint(path, init_seed=4, **ctor_kw, **kw)
+        assert all(torch.equal(v, c.state_dict()[k]) for k, v in m.state_dict().items())
+    finally:
+        C.W2V2Config.from_huggingface_id = orig
 
 
 def test_hot_kernels_use_no_scratch(tmp_path):

@@ -32,6 +32,21 @@ from ...optim.schedule import OneCycle
 from ...params import ParamStore
 from ...trainer import SpeakerTrainer
 
+from ...params import _WN_OLD as _WN_LEGACY
+
+
+def _load_checkpoint_file(path: str, trust_pickle: bool):
+    """Checkpoints and pretrained weight files hold tensors, ints, strings and containers of them: load with
+    ``weights_only=True`` (no arbitrary unpickling of a downloaded file).  A third-party checkpoint that pickles other
+    objects (e.g. an OmegaConf ``hyper_parameters`` node) needs the explicit opt-in ``trust_checkpoint_pickle=True``."""
+    try:
+        return torch.load(path, map_location="cpu", weights_only=True)
+    except Exception:
+        if not trust_pickle:
+            raise
+        return torch.load(path, map_location="cpu", weights_only=False)
+
+
 MAX_PLANS = 8      # static plans kept per module (LRU): evaluation over variable-length utterances builds one per length
 
 
@@ -173,7 +188,7 @@ class Wav2vec2FCModule:
                                 attentive_pool="attentive" in (cfg.stat_pooling_type, cfg.test_stat_pooling_type))
         self.store.init_weights(init_seed)
         if pretrained_state_dict is not None:
-            sd = (torch.load(pretrained_state_dict, map_location="cpu", weights_only=False)
+            sd = (torch.load(pretrained_state_dict, map_location="cpu", weights_only=True)      # plain tensors only
                   if isinstance(pretrained_state_dict, str) else pretrained_state_dict)
             self.store.load_state_dict({k: v for k, v in sd.items()}, strict=False, prefix_model=True)
         elif not cfg.reset_weights:
@@ -379,17 +394,30 @@ class Wav2vec2FCModule:
     def load_state_dict(self, sd, strict: bool = True):
         self.store.load_state_dict(sd, strict=strict, prefix_model=False)
 
-    def save_checkpoint(self, path: str) -> None:
-        """A file ``Trainer.save_checkpoint`` / ``load_from_checkpoint`` of the reference can exchange: a pickled
-        dict whose ``state_dict`` uses the reference's parameter and buffer names (``wav2vec.model.<HF name>``,
+    def save_checkpoint(self, path: str, legacy_weight_norm_names: bool = True) -> None:
+        """A PL-1.4-style checkpoint file (the reference pins pytorch-lightning 1.4.5): a pickled dict whose
+        ``state_dict`` uses the reference's parameter and buffer names (``wav2vec.model.<HF name>``,
         ``loss_fn.fc_weights`` / ``fc_list.{i}.0.*``, ``stat_pooling.pooling_layer.*`` incl. the BatchNorm running
-        statistics), plus the optimiser and schedule state a PL checkpoint carries (``optimizer_states``: Adam
-        moments and step counts as one flat arena each; ``lr_schedulers``: the schedule position)."""
-        torch.save({"state_dict": self.state_dict(), "global_step": self.schedule_step, "epoch": 0,
-                    "pytorch-lightning_version": "1.3.8",
-                    "optimizer_states": [self.store.optimizer_state()],
-                    "lr_schedulers": [{"last_epoch": self.schedule_step}],
-                    "freeze_schedule": {"steps": self.steps, "is_wav2vec_frozen": self._is_wav2vec_frozen},
+        statistics).  ``legacy_weight_norm_names`` (default) writes the pos-conv weight-norm pair as
+        ``...conv.weight_g`` / ``...conv.weight_v`` -- the names of the reference's own stack (torch 1.9 /
+        transformers ^4.8); its ``load_from_checkpoint(strict=False)`` would silently DROP the torch >= 2.1 names
+        ``parametrizations.weight.original0/1`` (load accepts both).  ``optimizer_states[0]`` is a
+        ``torch.optim.Adam.state_dict()`` in the reference's parameter order (ParamStore.torch_adam_state) and
+        ``lr_schedulers[0]`` the ``OneCycleLR`` fields a resume needs; the engine's own extras (fp16 loss-scale
+        record, freeze-schedule counters) travel under ``w2v2_amd``.  What is NOT claimed: torchmetrics / callback
+        states of a PL ``Trainer`` -- a ``Trainer`` resume restores weights, optimiser moments and schedule position."""
+        sd = self.state_dict()
+        if legacy_weight_norm_names:
+            sd = OrderedDict((ParamStore.legacy_key(k), v) for k, v in sd.items())
+        lr, beta1 = self.schedule.at(max(self.schedule_step - 1, 0))
+        z = lambda t: None if t is None else t.detach().clone().cpu()
+        torch.save({"state_dict": sd, "global_step": self.schedule_step, "epoch": 0,
+                    "pytorch-lightning_version": "1.4.5",
+                    "optimizer_states": [self.store.torch_adam_state(lr, (beta1, 0.999), 1e-8)],
+                    "lr_schedulers": [{"last_epoch": self.schedule_step, "_step_count": self.schedule_step + 1,
+                                       "total_steps": self.schedule.total_steps, "_last_lr": [lr]}],
+                    "w2v2_amd": {"loss_scaler": z(self.store.scaler), "steps": self.steps,
+                                 "is_wav2vec_frozen": self._is_wav2vec_frozen},
                     "hyper_parameters": {"num_speakers": self.num_speakers, "loss": self.loss}}, path)
 
     @classmethod
@@ -400,24 +428,31 @@ class Wav2vec2FCModule:
         missing ones keep their fresh initialisation.  Optimiser moments, the loss scale and the schedule position
         resume when the checkpoint has them and the arena still has the same size."""
         kwargs.setdefault("hyperparameters_to_save", None)
+        kwargs_trusted = bool(kwargs.pop("trust_checkpoint_pickle", False))
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")              # weights come from the checkpoint, not from "pretrained"
             module = cls(**kwargs)
-        ckpt = torch.load(checkpoint_path, map_location="cpu", weights_only=False)
+        ckpt = _load_checkpoint_file(checkpoint_path, kwargs_trusted)
         sd = ckpt["state_dict"] if "state_dict" in ckpt else ckpt
         if not strict:
             shapes = module.store.shapes
-            sd = {k: v for k, v in sd.items() if k not in shapes or tuple(v.shape) == tuple(shapes[k])}
+            canon = lambda k: next((k[: -len(o)] + n for o, n in _WN_LEGACY.items() if k.endswith(o)), k)
+            sd = {k: v for k, v in sd.items() if canon(k) not in shapes or tuple(v.shape) == tuple(shapes[canon(k)])}
         module.load_state_dict(sd, strict=strict)
         if isinstance(ckpt, dict):
             module.schedule_step = int(ckpt.get("global_step", 0))
-            fs = ckpt.get("freeze_schedule") or {}
+            fs = ckpt.get("w2v2_amd") or ckpt.get("freeze_schedule") or {}
             module.steps = int(fs.get("steps", module.schedule_step))
             module._is_wav2vec_frozen = bool(fs.get("is_wav2vec_frozen", False))
+            if module.store.scaler is not None and fs.get("loss_scaler") is not None:
+                module.store.scaler.copy_(torch.as_tensor(fs["loss_scaler"]).to(module.store.device))
             for ost in ckpt.get("optimizer_states") or []:
                 try:
-                    module.store.load_optimizer_state(ost)
-                except ValueError:
+                    if "param_groups" in ost:             # torch.optim.Adam.state_dict() (reference parameter order)
+                        module.store.load_torch_adam_state(ost)
+                    else:                                 # round-2 files: flat moment arenas
+                        module.store.load_optimizer_state(ost)
+                except (ValueError, IndexError):
                     if strict:
                         raise
         return module

@@ -125,6 +125,14 @@ class Gemm:
             self.kernel_name = "gemm_bf16_kernel" if lp else "gemm_f32_kernel"
 
     _prof = None
+    _log = None        # tools/gemm_instep.py: when a list, every launch appends its shape key (launch order)
+
+    def key(self) -> dict:
+        d = self.desc
+        return {"kind": "gemm", "M": d.M, "N": d.N, "K": d.K, "batch": d.batch, "epi": d.epilogue,
+                "two_term": int(d.k_ext != 0), "n_ext_from": d.n_ext_from, "aux": int(bool(d.aux)),
+                "kernel": self.kernel_name, "flops": self.flops + 2.0 * d.M * max(0, d.N - d.n_ext_from) * d.k_ext,
+                "alg_flops": self.flops, "bytes": self.bytes}
 
     @classmethod
     def profile_begin(cls, select) -> None:
@@ -150,6 +158,8 @@ class Gemm:
 
     def __call__(self) -> None:
         prof = Gemm._prof
+        if Gemm._log is not None:
+            Gemm._log.append(self.key())
         if prof is not None and prof["select"](self):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -194,6 +204,10 @@ class WgradGroup:
         self._fn = lib().w2v2_wgrad_grouped
 
     def __call__(self) -> None:
+        if Gemm._log is not None:
+            Gemm._log.append({"kind": "wgrad", "problems": self._n, "tokens": self._tokens, "flops": self.flops,
+                              "alg_flops": self.flops,
+                              "kernel": "wgrad_grouped_ring4_kernel" if self._n >= 8 else "wgrad_grouped_ring_kernel"})
         rc = self._fn(self._arr, self._n, self._tokens, self._tpad, self._dt, stream())
         if rc:
             _lib.check(rc, "wgrad_grouped")

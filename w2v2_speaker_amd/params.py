@@ -328,6 +328,97 @@ class ParamStore:
             sd[ASP_PREFIX + "tdnn.norm.norm.num_batches_tracked"] = torch.tensor(self.asp_batches_tracked)
         return sd
 
+    # ------------------------------------------------------------------ reference-facing names / order
+    def reference_parameter_order(self) -> List[str]:
+        """Arena parameter names in the order of the reference module's ``.parameters()`` -- the indices a torch
+        optimiser (and therefore a PL checkpoint's ``optimizer_states``) uses.  Registration order of
+        ref: src/lightning_modules/speaker/wav2vec2_fc.py:101-228: the base class creates ``loss_fn`` first
+        (speaker_recognition_module.py:62), then ``wav2vec`` (HF ``Wav2Vec2Model`` registration order, HF:1241-1262:
+        masked_spec_embed, feature_extractor, feature_projection, encoder{pos_conv_embed (bias, weight-norm g, v),
+        layer_norm, layers[l]{attention k/v/q/out, layer_norm, feed_forward, final_layer_norm}}), ``stat_pooling``
+        (attentive pooling only) and ``fc_list``.  tests/test_host_cpu.py checks the wav2vec2 part against HF."""
+        cfg, P = self.cfg, W2V_PREFIX
+        names = [n for n in self.shapes if n.startswith("loss_fn.")]
+        hf = ["masked_spec_embed"]
+        for i in range(len(cfg.conv_dim)):
+            hf.append(f"feature_extractor.conv_layers.{i}.conv.weight")
+            if i == 0:
+                hf += [f"feature_extractor.conv_layers.0.layer_norm.{w}" for w in ("weight", "bias")]
+        hf += [f"feature_projection.{m}.{w}" for m in ("layer_norm", "projection") for w in ("weight", "bias")]
+        hf += ["encoder.pos_conv_embed.conv.bias", "encoder.pos_conv_embed.conv.parametrizations.weight.original0",
+               "encoder.pos_conv_embed.conv.parametrizations.weight.original1",
+               "encoder.layer_norm.weight", "encoder.layer_norm.bias"]
+        for l in range(cfg.num_hidden_layers):
+            pre = f"encoder.layers.{l}."
+            for m in ("attention.k_proj", "attention.v_proj", "attention.q_proj", "attention.out_proj", "layer_norm",
+                      "feed_forward.intermediate_dense", "feed_forward.output_dense", "final_layer_norm"):
+                hf += [pre + m + ".weight", pre + m + ".bias"]
+        names += [P + n for n in hf]
+        names += [n for n in self.shapes if n.startswith("stat_pooling.")]
+        fc = sorted({int(n.split(".")[1]) for n in self.shapes if n.startswith("fc_list.")})
+        names += [f"fc_list.{i}.0.{w}" for i in fc for w in ("weight", "bias")]
+        assert sorted(names) == sorted(self.shapes), "reference_parameter_order does not cover the arena"
+        return names
+
+    @staticmethod
+    def legacy_key(name: str) -> str:
+        """State-dict key under the reference's own stack (torch 1.9 ``weight_norm``: ``weight_g`` / ``weight_v``;
+        torch >= 2.1 parametrizations call them ``parametrizations.weight.original0/1``)."""
+        for old, new in _WN_OLD.items():
+            if name.endswith(new):
+                return name[: -len(new)] + old
+        return name
+
+    def torch_adam_state(self, lr: float, betas=(0.9, 0.999), eps: float = 1e-8) -> Dict[str, object]:
+        """``torch.optim.Adam.state_dict()`` of the optimiser the reference builds over ``network.parameters()``
+        (ref: src/main.py:323): per-parameter ``step`` / ``exp_avg`` / ``exp_avg_sq`` views cut out of the flat moment
+        arenas, indexed in reference parameter order; parameters that never had a gradient (frozen CNN) have no
+        state entry, as in torch."""
+        order = self.reference_parameter_order()
+        state = {}
+        h = self.head_size()
+        for i, n in enumerate(order):
+            off = self.offsets[n]
+            if self.exp_avg is None or off >= self.n_train:
+                continue
+            cnt = 1
+            for d in self.shapes[n]:
+                cnt *= d
+            step = self.step_head if off < h else self.step_body
+            if step == 0:
+                continue
+            state[i] = {"step": step, "exp_avg": self.exp_avg[off:off + cnt].view(self.shapes[n]).detach().clone().cpu(),
+                        "exp_avg_sq": self.exp_avg_sq[off:off + cnt].view(self.shapes[n]).detach().clone().cpu()}
+        group = {"lr": lr, "betas": tuple(betas), "eps": eps, "weight_decay": 0, "amsgrad": False,
+                 "params": list(range(len(order)))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_torch_adam_state(self, osd: Dict[str, object]) -> None:
+        """Inverse of torch_adam_state(): scatter a torch Adam state dict (reference parameter order) into the flat
+        moment arenas.  Parameters without an entry keep zero moments."""
+        order = self.reference_parameter_order()
+        if self.exp_avg is None:
+            self.exp_avg = torch.zeros_like(self.grad)
+            self.exp_avg_sq = torch.zeros_like(self.grad)
+        h = self.head_size()
+        sh = sb = 0
+        for i, st in osd["state"].items():
+            n = order[int(i)]
+            off = self.offsets[n]
+            if off >= self.n_train:
+                continue
+            ea = torch.as_tensor(st["exp_avg"]).to(self.device, torch.float32).reshape(-1)
+            if tuple(torch.as_tensor(st["exp_avg"]).shape) != tuple(self.shapes[n]):
+                raise ValueError(f"optimizer state of {n}: shape {tuple(st['exp_avg'].shape)} != {self.shapes[n]}")
+            self.exp_avg[off:off + ea.numel()].copy_(ea)
+            self.exp_avg_sq[off:off + ea.numel()].copy_(torch.as_tensor(st["exp_avg_sq"]).to(self.device, torch.float32).reshape(-1))
+            if off < h:
+                sh = max(sh, int(st["step"]))
+            else:
+                sb = max(sb, int(st["step"]))
+        self.step_head, self.step_body = sh, sb
+        self.step_count = max(sh, sb)
+
     # ------------------------------------------------------------------ optimiser / schedule state (resume)
     def optimizer_state(self) -> Dict[str, object]:
         """What a PL checkpoint keeps under ``optimizer_states`` (torch Adam's exp_avg / exp_avg_sq / step) plus the
