@@ -109,9 +109,10 @@ def parse_args():
     ap.add_argument("--batch", type=int, default=66, help="utterances per GPU (paper batch size)")
     ap.add_argument("--seconds", type=float, default=3.0)
     ap.add_argument("--speakers", type=int, default=5994)
-    ap.add_argument("--dtype", default="f16", choices=["f16", "bf16", "f32"],
-                    help="f16 (default): the reference's fp16-AMP precision, embeddings within 1e-3 of the f32 reference; "
-                         "bf16: 8-bit significand option; f32: exact parity mode")
+    ap.add_argument("--dtype", default=None, choices=["f16", "bf16", "f32"],
+                    help="default = the reference's own precision for the model: f16 for wav2vec2 (fp16-AMP, embeddings "
+                         "within 1e-3 of the f32 reference), f32 for --model ecapa (`precision: 32`); bf16: 8-bit "
+                         "significand option; f32: exact mode")
     ap.add_argument("--pooling", default="mean+std", choices=["mean+std", "attentive", "first+cls"],
                     help="mean+std = the metric's workload; attentive = BASELINE configs[2]")
     ap.add_argument("--model", default="base", choices=["base", "large", "ecapa"],
@@ -122,7 +123,10 @@ def parse_args():
     ap.add_argument("--no-regularisation", action="store_true", help="dropout / LayerDrop / masks off")
     ap.add_argument("--unfreeze-cnn", action="store_true",
                     help="completely_freeze_feature_extractor=False ablation (127.2 GFLOP/utt)")
-    return ap.parse_args()
+    a = ap.parse_args()
+    if a.dtype is None:
+        a.dtype = "f32" if a.model == "ecapa" else "f16"
+    return a
 
 
 def _free_port() -> int:

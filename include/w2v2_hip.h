@@ -65,7 +65,12 @@ enum {
   W2V2_EPI_BIAS_GELU = 2, /* pre = alpha*acc + bias[n]; aux = pre (if aux); C = gelu(pre) */
   W2V2_EPI_GELU_BWD = 3,  /* C = alpha*acc * gelu'(aux[m][n])                           */
   W2V2_EPI_ADD = 4,       /* C = alpha*acc + aux[m][n]   (residual / gradient join)     */
-  W2V2_EPI_SCALE_RC = 5   /* C = alpha*acc * row_scale[m] * col_scale[n]  (AAM cosine)  */
+  W2V2_EPI_SCALE_RC = 5,  /* C = alpha*acc * row_scale[m] * col_scale[n]  (AAM cosine)  */
+  /* FFN pair of HF:565-572 with the activation derivative taken where the pre-activation is in f32 registers:
+   * the forward product stores gelu'(pre) instead of pre (same bytes), the backward product multiplies by it
+   * (1 VALU op per element instead of re-evaluating erf / exp on 30 M elements per layer) */
+  W2V2_EPI_BIAS_GELU_GRAD = 6, /* pre = alpha*acc + bias[n]; aux = gelu'(pre); C = gelu(pre)   */
+  W2V2_EPI_MUL = 7             /* C = alpha*acc * aux[m][n]                                    */
 };
 
 typedef struct {
@@ -99,6 +104,10 @@ typedef struct {
 } w2v2_gemm_desc;
 
 int w2v2_gemm(const w2v2_gemm_desc* d, void* stream);
+/* Tuning hook (tools/gemm_shapes.py, not used by the training path): force the tile family of plain K-contiguous
+ * 16-bit products -- 0 = the library's own dispatch, 1 = 128x128, 2 = 256x128 ring, 3 = 256x256x32 ring,
+ * 4 = 256x256x64 phased.  Returns the previous setting. */
+int w2v2_tune_gemm_kernel(int family);
 
 /* Grouped weight-gradient GEMM (the backward of HF:520-526,544,565-572 nn.Linear weights/biases):
  *   dW_p[o][i] = sum_t dY_p[t][o] * X_p[t][i]      dbias_p[o] = sum_t dY_p[t][o]   (dbias may be NULL)
@@ -185,6 +194,13 @@ int w2v2_gelu_bwd(const void* dy, const void* pre, void* dx, int64_t n, int dtyp
 int w2v2_add(const void* x, const void* a, void* y, int64_t n, int dtype, void* stream);
 /* out[n] += sum_m x[m][n]   (bias gradients; f32 atomics, caller zeroes). */
 int w2v2_colsum(const void* x, int64_t ld, float* out, int M, int N, int dtype, void* stream);
+/* base[off_r .. off_r + n_r) = 0 for the (off, n) pairs of the int64 device table: gradient zeroing of the tensors the
+ * backward ACCUMULATES into (LayerNorm gamma / beta, pos-conv bias, masked_spec_embed, LayerDrop-skipped layers) --
+ * the large gradients are written, not accumulated (w2v2_wgrad_grouped), so the reference's optimizer.zero_grad()
+ * (PL, torch.optim.Optimizer.zero_grad) does not have to touch them. */
+int w2v2_zero_ranges(float* base, const int64_t* table, int n_ranges, int blocks_per_range, void* stream);
+/* out[0] = mean of x[0..n): the scalar loss (ref: F.cross_entropy reduction="mean", aam_softmax.py:72). */
+int w2v2_mean(const float* x, float* out, int n, void* stream);
 /* f32 -> act dtype cast (bf16 weight copies), and strided 2-D copy/convert. */
 int w2v2_cast(const float* x, void* y, int64_t n, int dtype, void* stream);
 /* dst_i[C][R] = transpose(src_i[R][C]) for n matrices of one arena; table (device) holds per matrix
@@ -196,6 +212,10 @@ int w2v2_transpose_many(const void* src, void* dst, const int64_t* table, int n,
  * masked rows of dh (atomics), masked rows of dh zeroed in place. */
 int w2v2_mask_fill(void* h, const uint8_t* mask, const float* embed, int M, int H, int dtype,
                    void* stream);
+/* SpecAugment feature mask HF:1294-1304 (`mask_feature_prob`, ref: config/network/wav2vec2_fc.yaml:56): h[b][t][c] = 0
+ * where mask[b][c] (mask [B][H] bytes, 8-byte aligned, drawn on the host by the HF sampler AFTER the time mask).  The
+ * backward is the same call on the gradient. */
+int w2v2_mask_feature(void* h, const uint8_t* mask, int B, int T, int H, int dtype, void* stream);
 int w2v2_mask_fill_bwd(void* dh, const uint8_t* mask, float* d_embed, int M, int H, int dtype,
                        void* stream);
 /* CLS token (ref: src/models/wav2vec2.py:128-140): y[b][0][:] = c, y[b][1+t][:] = x[b][t][:]. */
@@ -249,7 +269,9 @@ int w2v2_attention_bwd(const void* qkv, const void* ctx, const void* dctx, const
  * mode 1: mean      -> [B,H]       mode 2: max -> [B,H]
  * mode 3: first     -> [B,H]       mode 4: last / "middle" (quirk Q2) -> [B,H]
  * mode 5: quantile  -> [B,5H] = the 0 / .25 / .5 / .75 / 1 quantiles over time, quantile-major
- *         (ref: src/layers/pooling.py:51-67, torch.quantile with linear interpolation) */
+ *         (ref: src/layers/pooling.py:51-67, torch.quantile with linear interpolation)
+ * mode 16 + t: frame t -> [B,H]  (IndexPool1D "random", ref: src/layers/pooling.py:125-126,150-154: the HOST draws t
+ *         with random.randint like the reference; NoPooling, :160-166, is the same call on the [B*T, 1, H] view) */
 int w2v2_pool_fwd(const void* x, float* out, int B, int T, int H, int mode, int dtype, void* stream);
 /* dx [B,T,H] act dtype from dout f32 and the forward output (std/mean reused; max needs x). */
 int w2v2_pool_bwd(const void* x, const float* out, const float* dout, void* dx, int B, int T, int H,
@@ -320,6 +342,8 @@ int w2v2_im2col_reflect(const void* x, int64_t ldx, void* col, int B, int T, int
                         void* stream);
 int w2v2_col2im_reflect(const void* dcol, void* dx, int64_t lddx, int B, int T, int Cin, int k, int dilation,
                         int accumulate, int dtype, void* stream);
+/* y[m][0..C) = a[m][0..C) + b[m][0..C) over row-strided views (Res2Net cumulative adds); b == NULL: y = a (a strided
+ * copy: the pass-through chunk of a Res2Net block, the SE input slice). */
 int w2v2_add_strided(const void* a, int64_t lda, const void* b, int64_t ldb, void* y, int64_t ldy, int M, int C,
                      int dtype, void* stream);
 /* squeeze-excitation gate g [B][C] f32: y = x * g;  dg = sum_t dout * x;  dx = dout * g + ds / T */
@@ -377,13 +401,18 @@ int w2v2_normalize_bwd(const float* g, const void* x, int64_t ldx, const float* 
  * (pb may be NULL).  grad_scale folds the 1/world_size of the data-parallel average.
  * scaler_state (may be NULL): the 4-float device record of w2v2_grad_scaler_*: gradients are divided by
  * state[0] and the whole step is skipped when state[1] != 0. */
+/* skip_slot (0 = off, 4 or 5): torch's GradScaler does not call optimizer.step() on an overflow, so Adam's step count
+ * must not advance on skipped steps.  With skip_slot set the kernel rebuilds both bias corrections from
+ * t = step - scaler_state[skip_slot] (the host's `step` counts every call; the 8-float record counts the skipped ones
+ * per parameter range: [4] head, [5] body -- see w2v2_grad_scaler_update) and ignores bias_corr1 / bias_corr2. */
 int w2v2_adam_step(float* p, const float* g, float* m, float* v, void* pb, int pb_dtype, int64_t n, float lr,
                    float beta1, float beta2, float eps, float bias_corr1, float bias_corr2,
-                   float grad_scale, const float* scaler_state, void* stream);
+                   float grad_scale, const float* scaler_state, int step, int skip_slot, void* stream);
 
 /* Dynamic loss scaling for fp16 activations = torch.cuda.amp.GradScaler, which PL `precision: 16` of the
  * reference's runs installs (ref: config/experiment/speaker_wav2vec2_aam.yaml:17).
- * state (device, 4 floats) = {scale, found_inf, growth_tracker, skipped_steps}; the heads multiply the loss
+ * state (device, 4 floats, or 8 with per-range skip counts) = {scale, found_inf, growth_tracker, skipped_steps
+ * [, skipped_head, skipped_body, 0, 0]}; the heads multiply the loss
  * gradient by state[0] (w2v2_aam_softmax_fwd_bwd / w2v2_bce_head_fwd_bwd `loss_scale`), so every gradient of the
  * step carries it.  check: state[1] = 1 if any of g[0..n) is non-finite.  update (after the optimiser step):
  * found_inf ? scale *= backoff : (every growth_interval clean steps scale *= growth); clears found_inf.
@@ -392,7 +421,10 @@ int w2v2_adam_step(float* p, const float* g, float* m, float* v, void* pb, int p
  * the residual plane of the two-term weights above (p = f32 master arena, lo = a 16-bit arena of the same layout). */
 int w2v2_weight_residual(const float* p, void* lo, const int64_t* table, int n_ranges, int dtype, void* stream);
 int w2v2_grad_scaler_check(const float* g, int64_t n, float* state, void* stream);
-int w2v2_grad_scaler_update(float* state, float growth, float backoff, int growth_interval, void* stream);
+/* skipped_ranges: bit 0 / bit 1 = on an overflow also count the skipped step in state[4] / state[5] (records of 8
+ * floats; pass 0 for the plain 4-float record). */
+int w2v2_grad_scaler_update(float* state, float growth, float backoff, int growth_interval, int skipped_ranges,
+                            void* stream);
 
 #ifdef __cplusplus
 }

@@ -76,3 +76,71 @@ def test_two_rank_step_matches_single_process_on_joint_batch():
 def _fresh_params():
     st, *_ = _setup(torch.device("cuda", 0), 1)
     return st.flat[:st.n_train].cpu()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# The benchmarked mode: fp16 activations under the dynamic loss scale, dropout, per-rank LayerDrop draws and
+# SpecAugment masks.  An overflow that happens on ONE rank only must make BOTH ranks skip the step and halve the scale
+# (the non-finite values travel through the SUM all-reduce into every replica's last bucket, which is what
+# w2v2_grad_scaler_check scans), and the replicas must stay bit-identical throughout.
+def _worker_fp16(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import w2v2_oracle as O
+    from w2v2_speaker_amd.config import W2V2Config, Wav2Vec2RegularisationConfig
+    from w2v2_speaker_amd.engine import Plan
+    from w2v2_speaker_amd.optim.schedule import OneCycle
+    from w2v2_speaker_amd.params import ParamStore
+    from w2v2_speaker_amd.trainer import SpeakerTrainer
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    cfg = W2V2Config.tiny()
+    st = ParamStore(cfg, dev, torch.float16, head="aam", num_speakers=10)
+    st.init_weights(seed=3)
+    st.scaler[0] = 1024.0
+    reg = Wav2Vec2RegularisationConfig(attention_dropout=0.1, feat_proj_dropout=0.1, hidden_dropout=0.1, layerdrop=0.4,
+                                       mask_time_prob=0.05, mask_time_length=2)
+    plan = Plan(st, 2, 4000, train=True, reg=reg, seed=7 + rank)
+    tr = SpeakerTrainer(st, plan, OneCycle(max_lr=1e-3, total_steps=10), layerdrop_seed=1234 + rank, mask_seed=7 + rank)
+    wav, label = O.synth_batch(4, 4000, 10, seed=11)
+    wav, label = wav.to(dev)[2 * rank:2 * rank + 2], label.to(dev)[2 * rank:2 * rank + 2]
+    head_fb = plan.head_forward_backward
+    record = []
+    skips = []
+    for step in range(5):
+        if step == 2 and rank == 1:
+            def poisoned(lbl):                     # an overflow on THIS rank only: inf in d(loss)/d(embedding)
+                out = head_fb(lbl)
+                plan.demb[0, 0] = float("inf")
+                return out
+            plan.head_forward_backward = poisoned
+        else:
+            plan.head_forward_backward = head_fb
+        tr.train_step(wav, label)
+        skips.append(tuple(plan._skip))
+        torch.cuda.synchronize()
+        record.append((float(st.scaler[0]), int(st.scaler[3])))
+    q.put((rank, st.flat[:st.n_train].cpu().numpy(), record, skips))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_fp16_step_with_overflow_on_one_rank_skips_on_both():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker_fp16, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=300) for _ in procs), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    (_, p0, rec0, sk0), (_, p1, rec1, sk1) = res
+    p0, p1 = torch.from_numpy(p0), torch.from_numpy(p1)
+    assert torch.isfinite(p0).all() and torch.equal(p0, p1), "replicas diverged or went non-finite"
+    assert rec0 == rec1, (rec0, rec1)                          # identical scale / skip history on both ranks
+    assert rec0[1] == (1024.0, 0) and rec0[2] == (512.0, 1) and rec0[4] == (512.0, 1), rec0
+    assert sk0 != sk1, "the ranks were meant to draw different LayerDrop patterns"

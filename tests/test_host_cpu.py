@@ -90,6 +90,35 @@ def test_base_param_count_matches_reference_log():
     assert trainable == 99_378_048                    # SURVEY 2.3 C1 (frozen feature extractor)
 
 
+def test_ecapa_param_count_matches_reference_log():
+    """ref: paper_results/auto_lr_find/ecapa/run.log:14-17 prints ``ECAPA_TDNN 20.8 M``, ``Classifier 232 K``, ``21.0 M
+    Trainable params`` for ``n_mels: 80`` (.hydra/config.yaml:88) and the 1211 speakers of VoxCeleb1.  speechbrain is
+    not installable here, so this does not pin the ECAPA arithmetic -- it pins the LAYER STRUCTURE of the restatement
+    (every conv / norm / SE / pooling tensor shape) against the one number the reference itself recorded, and the
+    engine's parameter arena against the restatement."""
+    from oracle.ecapa_oracle import EcapaConfig, param_shapes
+
+    def human(n):          # pytorch_lightning.utilities.model_summary.get_human_readable_count (1.4.x)
+        for div, unit in ((1e9, "B"), (1e6, "M"), (1e3, "K")):
+            if n >= div:
+                v = n / div
+                return f"{v:.1f} {unit}" if v < 100 and unit != "K" else f"{int(v)} {unit}"
+        return str(n)
+
+    shapes = param_shapes(EcapaConfig(input_size=80))
+    n = sum(int(np.prod(s)) for s in shapes.values())
+    assert n == 20_767_552 and human(n) == "20.8 M"
+    n_cls = 1211 * 192                                        # speechbrain Classifier: cosine weight [speakers, lin_neurons]
+    assert human(n_cls) == "232 K" and human(n + n_cls) == "21.0 M"
+    assert sum(int(np.prod(s)) for s in param_shapes(EcapaConfig(input_size=40)).values()) == 20_562_752
+    from w2v2_speaker_amd.ecapa import FE, EcapaStore
+    from w2v2_speaker_amd.ecapa import EcapaConfig as EngineConfig
+    st = EcapaStore(EngineConfig(input_mel_coefficients=80), "cpu", torch.float32, num_speakers=1211)
+    body = {k: v for k, v in st.shapes.items() if k.startswith(FE)}
+    assert sum(int(np.prod(s)) for s in body.values()) == n
+    assert {k[len(FE):] for k in body} == set(shapes)          # same speechbrain state-dict names
+
+
 def _ddp_worker(rank, world, port, q):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)

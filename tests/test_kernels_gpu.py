@@ -63,6 +63,16 @@ def _gemm_case(o, M, N, K, ta, tb, dtype, cdtype, epi="none", split=1, seed=0):
         kw.update(epilogue=o.EPI_GELU_BWD, aux=aux, ldaux=ldc)
         a = aux_host[:, :N].double()
         ref = ref * (0.5 * (1 + torch.erf(a / math.sqrt(2))) + a * torch.exp(-0.5 * a * a) / math.sqrt(2 * math.pi))
+    elif epi == "bias_gelu_grad":
+        aux = torch.zeros(M, ldc, dtype=cdtype, device=DEV)
+        kw.update(epilogue=o.EPI_BIAS_GELU_GRAD, bias=bias.to(DEV), aux=aux, ldaux=ldc)
+        x = ref + bias.double()
+        pre = 0.5 * (1 + torch.erf(x / math.sqrt(2))) + x * torch.exp(-0.5 * x * x) / math.sqrt(2 * math.pi)   # aux = gelu'
+        ref = gelu(x)
+    elif epi == "mul":
+        aux = aux_host.to(cdtype).to(DEV)
+        kw.update(epilogue=o.EPI_MUL, aux=aux, ldaux=ldc)
+        ref = ref * aux_host[:, :N].double()
     elif epi == "add":
         aux = aux_host.to(cdtype).to(DEV)
         kw.update(epilogue=o.EPI_ADD, aux=aux, ldaux=ldc)
@@ -77,7 +87,7 @@ def _gemm_case(o, M, N, K, ta, tb, dtype, cdtype, epi="none", split=1, seed=0):
     tol = 2e-5 if dtype == torch.float32 else (1.2e-2 if cdtype != torch.float32 else 2e-3)
     err = rel_l2(got, ref)
     assert err < tol, (M, N, K, ta, tb, dtype, cdtype, epi, split, err)
-    if epi == "bias_gelu":
+    if epi in ("bias_gelu", "bias_gelu_grad"):
         assert rel_l2(aux[:, :N].float().cpu().double(), pre) < tol
     assert float(C[:, N:].abs().max()) == 0.0 if ldc > N else True     # no out-of-bounds columns written
 
@@ -104,7 +114,7 @@ def test_gemm_bf16_identity_asymmetric(lp):
     assert torch.equal(C.cpu(), Bm.to(lp).float().t())
 
 
-@pytest.mark.parametrize("epi", ["bias", "bias_gelu", "gelu_bwd", "add", "scale_rc"])
+@pytest.mark.parametrize("epi", ["bias", "bias_gelu", "gelu_bwd", "add", "scale_rc", "bias_gelu_grad", "mul"])
 @pytest.mark.parametrize("lp", LP16)
 def test_gemm_epilogues(epi, lp):
     o = ops()
@@ -114,12 +124,14 @@ def test_gemm_epilogues(epi, lp):
 
 
 @pytest.mark.parametrize("M,N,K", [(9834, 3072, 768), (32768, 2048, 64), (16384, 2004, 192), (2100, 768, 256),
-                                   (9834, 768, 3072)])
-@pytest.mark.parametrize("epi", ["none", "bias_gelu", "gelu_bwd", "add"])
+                                   (9834, 768, 3072), (19734, 512, 1024), (2005, 1984, 128)])
+@pytest.mark.parametrize("epi", ["none", "bias_gelu", "gelu_bwd", "add", "bias_gelu_grad", "mul", "bias", "scale_rc"])
 @pytest.mark.parametrize("lp", LP16)
 def test_gemm_ring_kernels_at_full_size(M, N, K, epi, lp):
-    """The persistent LDS-DMA ring kernels only take products that fill the chip: 256x256 tiles (4-stage ring) for
-    the first three shapes, 256x128 (3-stage) for the last two.  Ragged M, ragged N (2004: scalar tail path), K of
+    """The persistent LDS-DMA ring kernels only take products that fill the chip: 256x256 tiles (phased kernel) for
+    the first two shapes and conv5's (19734 x 512), 256x128 (3-stage ring) for the others.  N % 64 == 0 shapes store
+    through the full-line register epilogue (lanes c, c ^ 8 swap halves), the others (2004, 1984 + ragged M) through the
+    per-lane one.  Ragged M, ragged N (2004: scalar tail path), K of
     only two ring steps, every fused epilogue; reference = f32 matmul of the same bf16-rounded operands."""
     o = ops()
     g = torch.Generator(device="cpu").manual_seed(M + N + K)
@@ -135,12 +147,30 @@ def test_gemm_ring_kernels_at_full_size(M, N, K, epi, lp):
         kw.update(epilogue=o.EPI_BIAS_GELU, bias=bias, aux=aux, ldaux=ldc)
         pre = ref + bias
         ref = torch.nn.functional.gelu(pre)
-    elif epi in ("gelu_bwd", "add"):
+    elif epi == "bias_gelu_grad":
+        bias = torch.randn(N, generator=g).to(DEV)
+        aux = torch.zeros(M, ldc, dtype=lp, device=DEV)
+        kw.update(epilogue=o.EPI_BIAS_GELU_GRAD, bias=bias, aux=aux, ldaux=ldc)
+        x = ref + bias
+        pre = 0.5 * (1 + torch.erf(x / math.sqrt(2))) + x * torch.exp(-0.5 * x * x) / math.sqrt(2 * math.pi)
+        ref = torch.nn.functional.gelu(x)
+    elif epi == "bias":
+        bias = torch.randn(N, generator=g).to(DEV)
+        kw.update(epilogue=o.EPI_BIAS, bias=bias)
+        ref = ref + bias
+    elif epi == "scale_rc":
+        rs, cs = torch.rand(M, generator=g).to(DEV) + 0.5, torch.rand(N, generator=g).to(DEV) + 0.5
+        kw.update(epilogue=o.EPI_SCALE_RC, row_scale=rs, col_scale=cs)
+        ref = ref * rs[:, None] * cs[None, :]
+    elif epi in ("gelu_bwd", "add", "mul"):
         aux = torch.randn(M, ldc, generator=g).to(lp).to(DEV)
         a = aux[:, :N].float()
         if epi == "add":
             kw.update(epilogue=o.EPI_ADD, aux=aux, ldaux=ldc)
             ref = ref + a
+        elif epi == "mul":
+            kw.update(epilogue=o.EPI_MUL, aux=aux, ldaux=ldc)
+            ref = ref * a
         else:
             kw.update(epilogue=o.EPI_GELU_BWD, aux=aux, ldaux=ldc)
             ref = ref * (0.5 * (1 + torch.erf(a / math.sqrt(2))) + a * torch.exp(-0.5 * a * a) / math.sqrt(2 * math.pi))
@@ -148,7 +178,7 @@ def test_gemm_ring_kernels_at_full_size(M, N, K, epi, lp):
     torch.cuda.synchronize()
     err = float((C[:, :N].float() - ref).norm() / ref.norm())
     assert err < 4e-3, (M, N, K, epi, err)
-    if epi == "bias_gelu":
+    if epi in ("bias_gelu", "bias_gelu_grad"):
         assert float((aux[:, :N].float() - pre).norm() / pre.norm()) < 4e-3
     if ldc > N:
         assert float(C[:, N:].abs().max()) == 0.0
@@ -1032,3 +1062,92 @@ def test_layernorm_bwd_deferred_fold_equals_immediate(lp):
     for w, g in zip(want, got):
         for a, b in zip(w, g):
             assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+def test_zero_ranges_and_mean_kernels():
+    o = ops()
+    x = torch.ones(100_003, device=DEV)
+    ranges = [(0, 5), (7, 1), (64, 4096), (4161, 3), (50_001, 49_999)]        # unaligned heads / tails, 1 element
+    tab = torch.tensor(ranges, dtype=torch.int64, device=DEV)
+    o.zero_ranges(x, tab, blocks_per_range=3)
+    ref = torch.ones(100_003)
+    for a, n in ranges:
+        ref[a:a + n] = 0
+    assert torch.equal(x.cpu(), ref)
+    v = torch.randn(66, device=DEV)
+    out = torch.empty((), device=DEV)
+    o.mean(v, out)
+    assert abs(float(out) - float(v.double().mean())) < 1e-6
+
+
+@pytest.mark.gpu
+def test_selective_zero_grad_equals_full_zero_under_layerdrop():
+    """ParamStore.zero_grad(skip_layers) clears only what the backward accumulates into (+ the LayerDrop-skipped
+    layers); the gradients of a step must be bit-identical to those after a full memset, whatever garbage the arena
+    held before (the step before used a different skip pattern)."""
+    from w2v2_speaker_amd.config import W2V2Config, Wav2Vec2RegularisationConfig
+    from w2v2_speaker_amd.engine import Plan
+    from w2v2_speaker_amd.optim.schedule import Constant
+    from w2v2_speaker_amd.params import ParamStore
+    from w2v2_speaker_amd.trainer import SpeakerTrainer
+    from oracle import w2v2_oracle as O
+    cfg = W2V2Config.tiny()
+    reg = Wav2Vec2RegularisationConfig(activation_dropout=0.0, attention_dropout=0.0, feat_proj_dropout=0.0,
+                                       hidden_dropout=0.0, layerdrop=0.0, mask_time_prob=0.0)
+    wav, label = O.synth_batch(3, 4000, 10, seed=11)
+    wav, label = wav.to(DEV), label.to(DEV)
+    grads = []
+    for selective in (False, True):
+        st = ParamStore(cfg, DEV, torch.float16, head="aam", num_speakers=10)
+        st.init_weights(5)
+        st.scaler[0] = 256.0
+        plan = Plan(st, 3, 4000, train=True, reg=reg)
+        tr = SpeakerTrainer(st, plan, Constant(0.0))
+        if not selective:
+            st.zero_grad = (lambda orig: (lambda skip_layers=None: orig(None)))(st.zero_grad)
+        for name, off in st.offsets.items():                         # garbage in every gradient tensor (the 64-element
+            if off < st.n_train:                                      # alignment gaps of the arena are never written)
+                st.grad[off:off + int(np.prod(st.shapes[name]))] = float("nan")
+        tr.train_step(wav, label, skip_layers=(0,))
+        tr.train_step(wav, label, skip_layers=(1,))                   # layer 0 now written, layer 1 must be zeroed
+        torch.cuda.synchronize()
+        grads.append(st.grad.clone())
+    assert torch.isfinite(grads[1]).all()
+    assert torch.equal(grads[0], grads[1])
+    lay1 = [s for n, s, e in st.grad_buckets() if n == "layer1"][0]
+    lay1e = [e for n, s, e in st.grad_buckets() if n == "layer1"][0]
+    assert float(grads[1][lay1:lay1e].abs().max()) == 0.0
+
+
+@pytest.mark.gpu
+def test_adam_step_count_does_not_advance_on_skipped_steps():
+    """torch's GradScaler does not call optimizer.step() when the gradients overflowed, so Adam's step count -- and its
+    bias corrections -- only count applied updates.  The host-side counter of the engine advances every call (it never
+    reads the device); with skip_slot the kernel subtracts the skipped count kept in the 8-float scaler record.
+    Sequence: overflow, overflow, clean, overflow, clean, clean  ==  three torch Adam steps."""
+    o = ops()
+    n = 4 * 300 + 2
+    pp = rnd(n, seed=1)
+    ref = torch.nn.Parameter(pp.clone())
+    opt = torch.optim.Adam([ref], lr=1e-2)
+    pd = pp.clone().to(DEV)
+    md, vd = torch.zeros_like(pd), torch.zeros_like(pd)
+    state = torch.tensor([64.0, 0, 0, 0, 0, 0, 0, 0], device=DEV)
+    for call, overflow in enumerate([True, True, False, True, False, False]):
+        gr = rnd(n, seed=20 + call)
+        scale = float(state[0])
+        gs = (gr * scale).to(DEV)
+        if overflow:
+            gs[call] = float("inf")
+        else:
+            ref.grad = gr.clone()
+            opt.step()
+        o.grad_scaler_check(gs, n, state)
+        o.adam_step(pd, gs, md, vd, None, n, 1e-2, 0.9, 0.999, 1e-8, call + 1, scaler=state, skip_slot=5)
+        o.grad_scaler_update(state, 2.0, 0.5, 1000, skipped_ranges=3)
+    torch.cuda.synchronize()
+    assert state.tolist()[:6] == [8.0, 0.0, 3.0, 3.0, 3.0, 3.0]
+    assert np.allclose(pd.cpu().numpy(), ref.detach().numpy(), atol=2e-6)
+    # without the correction the first applied update would use t = 3: (1 - 0.9^1) / (1 - 0.9^3) = 0.37x ... visible
+    assert float((pd.cpu() - pp).abs().max()) > 1e-3

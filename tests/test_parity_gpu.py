@@ -257,7 +257,7 @@ def _asp_weights(store, seed=5):
     return sd, od
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 def test_attentive_statistics_pooling_step_vs_unpinned_restatement(dtype):
     """SURVEY 8a row a10 / BASELINE configs[2]: wav2vec2 -> attentive statistics pooling (global context, BatchNorm
     with batch statistics) -> AAM.  Embedding, loss and EVERY gradient (encoder + the six pooling tensors) against
@@ -281,14 +281,17 @@ def test_attentive_statistics_pooling_step_vs_unpinned_restatement(dtype):
     loss_ref, _ = O.aam_softmax(emb_ref, sdg["loss_fn.fc_weights"], label)
     loss_ref.backward()
     tr = Plan(st, B, N, train=True, reg=_no_reg(), pooling="attentive")
+    if st.scaler is not None:
+        st.scaler[0] = 512.0
+    gs = _gscale(st)
     st.zero_grad()
     emb = tr.embed(wav.to(DEV))
     loss, _ = tr.head_forward_backward(label.to(DEV))
     tr.backward()
     torch.cuda.synchronize()
-    f32 = dtype == torch.float32
-    assert rel_l2(emb.cpu(), emb_ref.detach()) < (2e-5 if f32 else 3e-2)
-    assert abs(float(loss.detach()) - float(loss_ref.detach())) < (1e-4 if f32 else 3e-2) * abs(float(loss_ref.detach()))
+    f32, f16 = dtype == torch.float32, dtype == torch.float16
+    assert rel_l2(emb.cpu(), emb_ref.detach()) < (2e-5 if f32 else 4e-3 if f16 else 3e-2)
+    assert abs(float(loss.detach()) - float(loss_ref.detach())) < (1e-4 if f32 else 4e-3 if f16 else 3e-2) * abs(float(loss_ref.detach()))
     from w2v2_speaker_amd.asp import ASP_PREFIX
     names = {ASP_PREFIX + "tdnn.conv.conv.weight": aog["tdnn.conv.weight"], ASP_PREFIX + "tdnn.conv.conv.bias": aog["tdnn.conv.bias"],
              ASP_PREFIX + "tdnn.norm.norm.weight": aog["tdnn.norm.weight"], ASP_PREFIX + "tdnn.norm.norm.bias": aog["tdnn.norm.bias"],
@@ -301,7 +304,7 @@ def test_attentive_statistics_pooling_step_vs_unpinned_restatement(dtype):
     tol = 2e-3 if f32 else 0.12
     bad = []
     for name, v in names.items():
-        got, ref = st.g(name).double().cpu().reshape(v.grad.shape), v.grad.double()
+        got, ref = st.g(name).double().cpu().reshape(v.grad.shape) / gs, v.grad.double()
         assert torch.isfinite(got).all(), name
         if not f32 and not (name.startswith("loss_fn") or ".conv.conv." in name and "tdnn" not in name):
             # bf16: everything upstream of the BatchNorm backward (a projection orthogonal to {1, rhat} that leaves
@@ -319,7 +322,7 @@ def test_attentive_statistics_pooling_step_vs_unpinned_restatement(dtype):
     assert torch.isfinite(e2).all()
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 def test_paired_input_bce_step_vs_oracle(dtype):
     """SURVEY 8f row f4 (ref: wav2vec2_paired_input.py:163-207 + binary_cross_entropy.py): two waveforms per pair through
     conv stack + projection, [CLS] left [SEP] right [SEP] through the encoder, Linear(H,1) on token 0, BCE; logits,
@@ -343,6 +346,9 @@ def test_paired_input_bce_step_vs_oracle(dtype):
     loss_ref.backward()
     plan = Plan(st, B, N, train=True, reg=_no_reg(), pooling="first", paired=True)
     assert plan.T == 2 * plan.T0 + 3
+    if st.scaler is not None:
+        st.scaler[0] = 256.0
+    gs = _gscale(st)
     st.zero_grad()
     wav = torch.cat([wl[:, 0], wr[:, 0]], dim=0).to(DEV)            # [2B, N]: left utterances, then right
     plan.embed(wav)
@@ -357,7 +363,7 @@ def test_paired_input_bce_step_vs_oracle(dtype):
         name = n if n.startswith("linear") else "wav2vec.model." + n
         if v.grad is None or not st.is_trainable(name):
             continue
-        got, ref = st.g(name).double().cpu().reshape(v.grad.shape), v.grad.double()
+        got, ref = st.g(name).double().cpu().reshape(v.grad.shape) / gs, v.grad.double()
         err = float((got - ref).norm())
         if err > (2e-3 if f32 else 0.12) * float(ref.norm()) + (1e-6 if f32 else 5e-3) * gmax:
             bad.append((n, round(err, 6), round(float(ref.norm()), 6)))
@@ -407,20 +413,23 @@ def test_large_shape_5s_clips_vs_oracle():
         got = float(st.g(name).double().norm())
         assert abs(got - ref) <= 2e-3 * ref + 1e-6 * gmax, (n, got, ref)
     del tr
-    stb, _ = _store(cfg, ocfg, torch.bfloat16, "aam", C)
-    evb = Plan(stb, B, N, train=False)
-    eb = evb.embed(wav.to(DEV))
-    torch.cuda.synchronize()
-    assert rel_l2(eb.cpu(), emb_ref.detach()) < 3e-2
+    for lp, bound in ((torch.bfloat16, 3e-2), (torch.float16, 4e-3)):      # fp16 = the benchmarked mode
+        stb, _ = _store(cfg, ocfg, lp, "aam", C)
+        evb = Plan(stb, B, N, train=False)
+        eb = evb.embed(wav.to(DEV))
+        torch.cuda.synchronize()
+        assert rel_l2(eb.cpu(), emb_ref.detach()) < bound, (lp, rel_l2(eb.cpu(), emb_ref.detach()))
+        del evb, stb
 
 
-def test_full_batch_no_cross_utterance_mixing_and_determinism():
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_full_batch_no_cross_utterance_mixing_and_determinism(dtype):
     """Size-independent property at the BASELINE size (B = 66, 3 s): an utterance's embedding does not
     depend on its batch neighbours (the reference's own BatchGradientVerification check,
     ref: src/main.py:337-366), and two runs are bit-identical."""
     from w2v2_speaker_amd.engine import Plan
     cfg, ocfg = _cfgs("base")
-    st, _ = _store(cfg, ocfg, torch.bfloat16, None, 1)
+    st, _ = _store(cfg, ocfg, dtype, None, 1)
     wav, _ = O.synth_batch(66, 48000, 10, seed=1)
     wav = wav.to(DEV)
     big = Plan(st, 66, 48000, train=False)
@@ -435,6 +444,57 @@ def test_full_batch_no_cross_utterance_mixing_and_determinism():
         # every kernel reduces in a batch-independent order (no atomics on the forward path)
         assert torch.equal(ei, e1[i:i + 1]), (i, rel_l2(ei.cpu(), e1[i:i + 1].cpu()))
     assert torch.isfinite(e1).all()
+
+
+@pytest.mark.parametrize("pooling", ["mean+std", "attentive"])
+def test_b66_fp16_training_steps_of_the_benchmarked_configuration(pooling):
+    """BASELINE configs[1] (mean+std) and configs[2] (attentive) exactly as bench.py runs them: w2v2-base, B = 66, 3 s,
+    fp16 operands under the dynamic loss scale, dropout / LayerDrop / SpecAugment on, fused Adam.  Size-independent
+    properties: two trainers with the same seeds produce BIT-IDENTICAL gradient arenas and parameters (atomic-free
+    weight gradients, fixed-order LayerNorm folds; the attentive head's few atomic sums excepted), the loss is
+    finite, no step is skipped by the scaler at its default initial scale, the LayerDrop-skipped layers have
+    exactly-zero gradients."""
+    from w2v2_speaker_amd.config import Wav2Vec2RegularisationConfig
+    from w2v2_speaker_amd.engine import Plan
+    from w2v2_speaker_amd.optim.schedule import OneCycle
+    from w2v2_speaker_amd.params import ParamStore
+    from w2v2_speaker_amd.trainer import SpeakerTrainer
+    cfg, _ = _cfgs("base")
+    wav, label = O.synth_batch(66, 48000, 5994, seed=42133724)
+    wav, label = wav.to(DEV), label.to(DEV)
+    runs = []
+    for rep in range(2):
+        st = ParamStore(cfg, DEV, torch.float16, head="aam", num_speakers=5994, attentive_pool=pooling == "attentive")
+        st.init_weights(seed=20211)
+        plan = Plan(st, 66, 48000, train=True, reg=Wav2Vec2RegularisationConfig(), seed=7, pooling=pooling)
+        tr = SpeakerTrainer(st, plan, OneCycle(max_lr=5e-5, total_steps=10), layerdrop_seed=77, mask_seed=7)
+        buckets = {n: (s, e) for n, s, e in st.grad_buckets()}
+        enc = slice(buckets[f"layer{cfg.num_hidden_layers - 1}"][0], buckets["prologue"][0])     # the 12 layer buckets
+        losses, skips = [], []
+        for i in range(3):
+            loss, _ = tr.train_step(wav, label)
+            losses.append(float(loss))
+            skips.append(tuple(plan._skip))
+            if i == 0:
+                torch.cuda.synchronize()
+                g_first = st.grad[enc].clone()
+            for l in plan._skip:
+                s_, e_ = buckets[f"layer{l}"]
+                assert float(st.grad[s_:e_].abs().max()) == 0.0
+        torch.cuda.synchronize()
+        assert torch.isfinite(st.grad).all() and torch.isfinite(st.flat).all()
+        runs.append((g_first, losses, skips, float(st.scaler[0]), int(st.scaler[3])))
+        del tr, plan, st
+        torch.cuda.empty_cache()
+    (g0, l0, s0, sc0, sk0), (g1, l1, s1, sc1, sk1) = runs
+    # step 1 from identical states: the encoder buckets (grouped weight gradients, LayerNorm folds) are bitwise
+    # repeatable; the few atomically summed tensors outside them (masked_spec_embed, pos-conv bias) are not, so later
+    # steps may differ in the last bits
+    assert torch.equal(g0, g1) and float(g0.abs().max()) > 0
+    assert all(np.isfinite(l0 + l1)) and l0[0] == l1[0] and s0 == s1, (l0, l1)
+    assert max(abs(a - b) for a, b in zip(l0, l1)) < 1e-3
+    assert any(len(s) for s in s0), "pick a LayerDrop seed that skips a layer within three steps"
+    assert sk0 == 0 and sk1 == 0 and sc0 == 16384.0, "the default initial loss scale must not overflow at B = 66"
 
 
 def test_train_steps_reduce_loss_and_adam_matches_oracle():
@@ -677,3 +737,117 @@ def test_long_utterance_and_paired_model_run_on_the_tiled_attention():
     for n, s_, e_ in stp.grad_buckets():
         a, b = res[0][2][s_:e_], res[1][2][s_:e_]
         assert float((a - b).norm()) < 3e-2 * float(b.norm()) + 1e-6, n
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Options of in-scope rows that round 2 guarded off (VERDICT r2 missing 4): activation_dropout > 0 with its backward,
+# feature-axis SpecAugment (mask_feature_prob), IndexPool1D("random"), NoPooling.
+def test_activation_dropout_and_feature_mask_backward_by_directional_derivatives():
+    """ref: config/network/wav2vec2_fc.yaml:45,56 (activation_dropout, mask_feature_prob); HF:566-569, :1294-1304.
+    Dropout keep decisions are a pure function of (seed, step, site, element), so with everything else fixed the loss is
+    a deterministic differentiable function of the weights: in the exact-f32 mode the hand-written gradient must match
+    central differences along random directions.  Also: masked feature channels are exactly zero after the projection,
+    and the activation dropout really drops (a fraction ~p of FFN activations is zero)."""
+    from w2v2_speaker_amd.config import Wav2Vec2RegularisationConfig
+    from w2v2_speaker_amd.engine import Plan
+    cfg, ocfg = _cfgs("tiny")
+    B, N, C = 3, 4000, 10
+    st, _ = _store(cfg, ocfg, torch.float32, "aam", C)
+    reg = Wav2Vec2RegularisationConfig(activation_dropout=0.3, attention_dropout=0.0, feat_proj_dropout=0.0,
+                                       hidden_dropout=0.0, layerdrop=0.0, mask_time_prob=0.0, mask_feature_prob=0.2)
+    plan = Plan(st, B, N, train=True, reg=reg)
+    wav, label = O.synth_batch(B, N, C, seed=4)
+    wav, label = wav.to(DEV), label.to(DEV)
+    g = torch.Generator().manual_seed(1)
+    tmask = (torch.rand(B, plan.T0, generator=g) < 0.1).to(torch.uint8).to(DEV)
+    fmask = (torch.rand(B, cfg.hidden_size, generator=g) < 0.2).to(torch.uint8).to(DEV)
+
+    def loss_at():
+        plan.embed(wav, tmask, (), 5, fmask)
+        loss, _ = plan.head_forward_backward(label)
+        return float(loss)
+
+    st.zero_grad()
+    l0 = loss_at()
+    h0 = plan.h0.view(B, plan.T0, -1).float()
+    assert float((h0 * fmask[:, None, :].float()).abs().max()) == 0.0 and float(h0.abs().max()) > 0
+    hz = float((plan.lb[0].h == 0).float().mean())
+    assert 0.2 < hz < 0.4, hz
+    plan.backward()
+    torch.cuda.synchronize()
+    grad = st.grad.clone()
+    names = ["wav2vec.model.encoder.layers.0.feed_forward.intermediate_dense.weight",
+             "wav2vec.model.encoder.layers.1.feed_forward.output_dense.weight",
+             "wav2vec.model.feature_projection.projection.weight", "wav2vec.model.masked_spec_embed",
+             "wav2vec.model.encoder.layers.0.attention.q_proj.weight"]
+    for i, name in enumerate(names):
+        w = st.p(name)
+        v = torch.randn(w.shape, generator=torch.Generator().manual_seed(10 + i)).to(DEV)
+        v = v / v.norm() * w.norm() * 2e-3
+        w0 = w.clone()
+        w.copy_(w0 + v); st.sync_lowp(); lp = loss_at()
+        w.copy_(w0 - v); st.sync_lowp(); lm = loss_at()
+        w.copy_(w0); st.sync_lowp()
+        fd = (lp - lm) / 2
+        an = float((grad[st.offsets[name]:st.offsets[name] + w.numel()].view(w.shape) * v).sum())
+        assert abs(fd - an) <= 0.03 * max(abs(an), abs(fd)) + 2e-6, (name, fd, an)
+    assert abs(loss_at() - l0) < 1e-6            # same masks every time (counter-based dropout)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+def test_random_index_pooling_and_no_pooling(dtype):
+    """ref: src/layers/pooling.py:125-126,150-166 + speaker_recognition_module.py:246-267.  "random": the pooled
+    embedding is frame t* of the encoder output, t* drawn per forward call; its gradient lands on that frame only.
+    "none": every frame is an embedding; CE over B * T rows with the utterance label repeated per frame, checked against
+    torch on the engine's own embeddings; d(loss)/d(hidden) equals autograd's."""
+    from w2v2_speaker_amd.engine import Plan
+    cfg, ocfg = _cfgs("tiny")
+    B, N, C = 3, 4000, 10
+    f32 = dtype == torch.float32
+    wav, label = O.synth_batch(B, N, C, seed=9)
+    wav, label = wav.to(DEV), label.to(DEV)
+    st, _ = _store(cfg, ocfg, dtype, "aam", C, embed_dim=cfg.hidden_size)
+    if st.scaler is not None:
+        st.scaler[0] = 64.0
+    plan = Plan(st, B, N, train=True, reg=_no_reg(), pooling="random")
+    seen = set()
+    for _ in range(6):
+        emb = plan.embed(wav).clone()
+        t = plan._rand_idx
+        seen.add(t)
+        assert torch.equal(emb, plan.out[:, t, :].float())
+    assert len(seen) > 1 and all(0 <= t < plan.T for t in seen)
+    st.zero_grad()
+    plan.head_forward_backward(label)
+    demb = plan.demb.clone()
+    from w2v2_speaker_amd import ops
+    ops.pool_bwd(plan.out, plan.emb, demb, plan.G.view(B, plan.T, -1), ops.POOL_INDEX_BASE + plan._rand_idx)
+    G = plan.G.view(B, plan.T, -1).float()
+    assert torch.allclose(G[:, plan._rand_idx], demb, rtol=2e-3 if not f32 else 0, atol=0 if f32 else 1e-2 * float(demb.abs().max()))
+    G[:, plan._rand_idx] = 0
+    assert float(G.abs().max()) == 0.0
+    # ---- no pooling, CE head on every frame
+    st2, _ = _store(cfg, ocfg, dtype, "ce", C, embed_dim=cfg.hidden_size)
+    if st2.scaler is not None:
+        st2.scaler[0] = 64.0
+    p2 = Plan(st2, B, N, train=True, reg=_no_reg(), pooling="none")
+    emb = p2.embed(wav)
+    T = p2.T
+    assert emb.shape == (B * T, cfg.hidden_size) and torch.equal(emb.view(B, T, -1), p2.out.float())
+    st2.zero_grad()
+    loss, sm = p2.head_forward_backward(label)
+    gs = _gscale(st2)
+    e = emb.detach().clone().requires_grad_(True)
+    W, b = st2.p("fc_list.0.0.weight"), st2.p("fc_list.0.0.bias")
+    if not f32:
+        logits = e.to(dtype).float() @ W.to(dtype).float().t() + b
+    else:
+        logits = e @ W.t() + b
+    ref = torch.nn.functional.cross_entropy(logits, label.repeat_interleave(T))
+    ref.backward()
+    assert sm.shape == (B * T, C)
+    assert abs(float(loss) - float(ref)) < (1e-5 if f32 else 3e-3) * abs(float(ref))
+    assert rel_l2((p2.demb / gs).cpu(), e.grad.cpu()) < (1e-4 if f32 else 1e-2)
+    p2.backward()
+    torch.cuda.synchronize()
+    assert torch.isfinite(st2.grad).all() and float(st2.g("wav2vec.model.encoder.layers.0.attention.q_proj.weight").abs().max()) > 0

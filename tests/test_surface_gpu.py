@@ -396,7 +396,10 @@ def test_ecapa_and_paired_module_surfaces_train():
     g = torch.Generator().manual_seed(0)
     ecfg = EcapaTDNNModuleConfig(input_mel_coefficients=16, lin_neurons=24, channels=[64, 64, 64, 64, 192],
                                  attention_channels=16, res2net_scale=4, se_channels=16)
-    em = EcapaTdnnModule(ecfg, num_speakers=5, max_lr=2e-3, max_steps=50)
+    # the reference's constructor (ref: ecapa_tdnn.py:51-62, what src/main.py:256-285 passes)
+    from w2v2_speaker_amd.optim.loss import AngularAdditiveMarginSoftMaxLoss, BinaryCrossEntropyLoss
+    actor = lambda: AngularAdditiveMarginSoftMaxLoss(2, 2, margin=0.2, scale=30.0, device=DEV, act_dtype=torch.float32)
+    em = EcapaTdnnModule(None, ecfg, 5, actor, [], [], None, max_lr=2e-3, max_steps=50)
     feat = torch.randn(6, 40, 16, generator=g)
     batch = SpeakerClassificationDataBatch(6, [str(i) for i in range(6)], feat, torch.randint(0, 5, (6,), generator=g))
     losses = [float(em.training_step(batch)["loss"]) for _ in range(12)]
@@ -408,12 +411,24 @@ def test_ecapa_and_paired_module_surfaces_train():
     orig = C.W2V2Config.from_huggingface_id
     C.W2V2Config.from_huggingface_id = staticmethod(lambda _id: tiny)
     try:
-        pm = Wav2vec2PairedSpeakerModule(Wav2vec2PairedSpeakerModuleConfig(), max_lr=2e-3, max_steps=50)
+        # ref: wav2vec2_paired_input.py:65-71 (hyperparameters_to_save, cfg, loss_fn_constructor); fp16 by default
+        pm = Wav2vec2PairedSpeakerModule(None, Wav2vec2PairedSpeakerModuleConfig(), BinaryCrossEntropyLoss,
+                                         max_lr=2e-3, max_steps=50)
+        assert pm.store.act_dtype == torch.float16 and pm.store.scaler is not None
+        pm.store.scaler[0] = 256.0
         a, b = 0.3 * torch.randn(4, 4000, generator=g), 0.3 * torch.randn(4, 4000, generator=g)
         pb = PairedSpeakerClassificationDataBatch(4, list("abcd"), a, list("efgh"), b, torch.tensor([1, 0, 1, 0]))
         pl = [float(pm.training_step(pb)["loss"]) for _ in range(10)]
         assert np.isfinite(pl).all() and pl[-1] < pl[0]
         scores = pm(a, b)
         assert scores.shape == (4, 1) and torch.isfinite(scores).all()
+        # the loss mirror on its own: reference semantics (mean BCE-with-logits, sigmoid prediction), differentiable
+        lg = scores.detach().clone().float().requires_grad_(True)
+        lab = torch.tensor([1, 0, 1, 0], device=lg.device)
+        loss, pred = BinaryCrossEntropyLoss()(lg, lab)
+        loss.backward()
+        ref = torch.nn.functional.binary_cross_entropy_with_logits(lg.detach()[:, 0], lab.float())
+        assert abs(float(loss) - float(ref)) < 1e-5 and torch.allclose(pred, torch.sigmoid(lg.detach()[:, 0]), atol=1e-6)
+        assert torch.allclose(lg.grad[:, 0], (torch.sigmoid(lg.detach()[:, 0]) - lab.float()) / 4, atol=1e-6)
     finally:
         C.W2V2Config.from_huggingface_id = orig

@@ -39,6 +39,8 @@ SHAPES = [
 ]
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
 only = args[0] if args else None
+FAM = {0: "auto", 1: "128x128", 2: "256x128 ring", 3: "256x256x32 ring", 4: "256x256x64 phased"}
+fams = [int(x) for x in os.environ.get("FAMILIES", "0").split(",")]
 vs_lib = "--hipblaslt" in sys.argv
 
 _bA = torch.randn(66 * 2399, 1536, device=dev).to(dt)
@@ -59,21 +61,37 @@ for name, m, n, k, epi, has_aux, two in SHAPES:
     bias = torch.randn(n, device=dev) if epi in (EPI_BIAS, EPI_BIAS_GELU) else None
     g = ops.Gemm(m, n, k, A, Bw[0], Cm, lda=k, ldb=k, ldc=n, epilogue=epi, bias=bias, aux=aux, ldaux=n if has_aux else 0,
                  b_lo=Bw[1] if two is not None else None, n_ext_from=two or 0)
-    for _ in range(3):
-        g()
-    torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    ts = []
-    for _ in range(trials):
+    per_fam = {}
+    for fam in fams:
+        if fam and two is not None:
+            continue
+        ops.lib().w2v2_tune_gemm_kernel(0)
         for _ in range(3):
             blocker()
-        e0.record()
-        for _ in range(reps):
+        ops.lib().w2v2_tune_gemm_kernel(fam)
+        for _ in range(3):
             g()
-        e1.record()
         torch.cuda.synchronize()
-        ts.append(e0.elapsed_time(e1) * 1e3 / reps)
-    us = sorted(ts)[len(ts) // 2]
+        ts = []
+        for _ in range(trials):
+            ops.lib().w2v2_tune_gemm_kernel(0)
+            for _ in range(3):
+                blocker()
+            ops.lib().w2v2_tune_gemm_kernel(fam)
+            e0.record()
+            for _ in range(reps):
+                g()
+            e1.record()
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1) * 1e3 / reps)
+        per_fam[fam] = sorted(ts)[len(ts) // 2]
+    ops.lib().w2v2_tune_gemm_kernel(0)
+    if len(fams) > 1:
+        print(f"{name} M={m:7d} N={n:5d} K={k:5d} epi={epi}  " + "  ".join(f"[{FAM[f]}] {u:7.1f} us" for f, u in per_fam.items()),
+              flush=True)
+        continue
+    us = per_fam[fams[0]]
     ext = 2.0 * m * (n - two) * k if two is not None else 0.0
     lib = ""
     if vs_lib and two is None:

@@ -11,7 +11,7 @@ import os
 from . import _build
 
 F32, BF16, F16 = 0, 1, 2
-EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_GELU_BWD, EPI_ADD, EPI_SCALE_RC = range(6)
+EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_GELU_BWD, EPI_ADD, EPI_SCALE_RC, EPI_BIAS_GELU_GRAD, EPI_MUL = range(8)
 
 c_i32, c_i64, c_u64, c_f32, c_vp = C.c_int32, C.c_int64, C.c_uint64, C.c_float, C.c_void_p
 
@@ -45,6 +45,9 @@ _SIGS = {
     "w2v2_version": (c_i32, []),
     "w2v2_last_error": (C.c_char_p, []),
     "w2v2_gemm": (c_i32, [C.POINTER(GemmDesc), c_vp]),
+    "w2v2_tune_gemm_kernel": (c_i32, [c_i32]),
+    "w2v2_zero_ranges": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_vp]),
+    "w2v2_mean": (c_i32, [c_vp, c_vp, c_i32, c_vp]),
     "w2v2_wgrad_grouped": (c_i32, [C.POINTER(WgradProblem), c_i32, c_i32, c_i32, c_i32, c_vp]),
     "w2v2_conv0_workspace_floats": (c_i32, [c_i32, c_i32, c_i32, c_i32]),
     "w2v2_conv0_stats": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp]),
@@ -67,6 +70,7 @@ _SIGS = {
     "w2v2_colsum": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_i32, c_i32, c_vp]),
     "w2v2_cast": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_vp]),
     "w2v2_transpose_many": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
+    "w2v2_mask_feature": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "w2v2_mask_fill": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
     "w2v2_mask_fill_bwd": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
     "w2v2_prepend_token": (c_i32, [c_vp, c_vp, c_f32, c_i32, c_i32, c_i32, c_i32, c_vp]),
@@ -114,10 +118,10 @@ _SIGS = {
                                          c_i32, c_i64, c_f32, c_f32, c_vp, c_vp, c_i32, c_vp]),
     "w2v2_normalize_bwd": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "w2v2_adam_step": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32,
-                               c_f32, c_f32, c_vp, c_vp]),
+                               c_f32, c_f32, c_vp, c_i32, c_i32, c_vp]),
     "w2v2_weight_residual": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_vp]),
     "w2v2_grad_scaler_check": (c_i32, [c_vp, c_i64, c_vp, c_vp]),
-    "w2v2_grad_scaler_update": (c_i32, [c_vp, c_f32, c_f32, c_i32, c_vp]),
+    "w2v2_grad_scaler_update": (c_i32, [c_vp, c_f32, c_f32, c_i32, c_i32, c_vp]),
 }
 
 EXPORTS = tuple(_SIGS)

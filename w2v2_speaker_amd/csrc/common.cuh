@@ -173,6 +173,40 @@ template <> __device__ __forceinline__ float pair_sum_add<f16_t>(uint32_t w, uin
   return __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2_hw, w), __builtin_bit_cast(f16x2_hw, ones), acc, false);
 }
 
+// ---------------------------------------------------------------- full-line stores of MFMA-layout tiles
+// After a 16x16 MFMA a lane (c = lane & 15, q = lane >> 4) holds 16 consecutive output columns of row c as two 16-byte
+// halves P0 | P1; the four q-lanes of a row cover 128 contiguous bytes.  Stored as they are, one wave instruction writes
+// four scattered 16-byte pieces per row (4.6 TB/s chip-wide, tools/probes/store_pattern_probe.hip); when lanes c and
+// c ^ 8 swap one half each (v_mov_dpp row_ror:8) every instruction writes 8 rows x 128 contiguous bytes (5.8 TB/s):
+// lane c < 8 stores columns +0..7 of rows (c & 7) and (c & 7) + 8, lane c >= 8 columns +8..15 of the same two rows.
+__device__ __forceinline__ uint32_t dpp_ror8(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128 /* row_ror:8 */, 0xf, 0xf, false);
+}
+__device__ __forceinline__ uint4 dpp_ror8(uint4 v) {
+  return make_uint4(dpp_ror8(v.x), dpp_ror8(v.y), dpp_ror8(v.z), dpp_ror8(v.w));
+}
+__device__ __forceinline__ uint4 sel4(bool c, uint4 a, uint4 b) {
+  return make_uint4(c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z, c ? a.w : b.w);
+}
+// own halves (P0, P1) -> what this lane stores for rows (c & 7) and (c & 7) + 8
+__device__ __forceinline__ void halves_to_lines(bool lo, uint4 p0, uint4 p1, uint4& da, uint4& db) {
+  const uint4 y = dpp_ror8(sel4(lo, p1, p0));
+  da = sel4(lo, p0, y);
+  db = sel4(lo, y, p1);
+}
+// what this lane loaded from rows (c & 7) and (c & 7) + 8 -> its own halves (the same swap, inverted)
+__device__ __forceinline__ void lines_to_halves(bool lo, uint4 la, uint4 lb, uint4& p0, uint4& p1) {
+  const uint4 z = dpp_ror8(sel4(lo, lb, la));
+  p0 = sel4(lo, la, z);
+  p1 = sel4(lo, z, lb);
+}
+template <typename TC> __device__ __forceinline__ void unpack8(uint4 w, float* v) {
+  unpack2<TC>(w.x, v[0], v[1]); unpack2<TC>(w.y, v[2], v[3]); unpack2<TC>(w.z, v[4], v[5]); unpack2<TC>(w.w, v[6], v[7]);
+}
+template <typename TC> __device__ __forceinline__ uint4 pack8(const float* v) {
+  return make_uint4(pack2<TC>(v[0], v[1]), pack2<TC>(v[2], v[3]), pack2<TC>(v[4], v[5]), pack2<TC>(v[6], v[7]));
+}
+
 // ---------------------------------------------------------------- activation-dtype dispatch of the C entry points
 // `AT` names the storage type inside the statement; unknown codes fail with the entry point's name.
 #define W2V2_DISPATCH_ACT(DT, NAME, ...)                                       \
@@ -210,6 +244,22 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
   const float cdf = 0.5f * (1.0f + erf_fast(x * 0.70710678118654752f));
   const float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
   return cdf + x * pdf;
+}
+
+// GELU and its derivative from ONE evaluation of the erf polynomial and ONE exponential: exp(-(x / sqrt 2)^2) is both the
+// tail of erf and, times 1 / sqrt(2 pi), the normal density.  y is bit-identical to gelu_f(x).
+__device__ __forceinline__ void gelu_both_f(float x, float& y, float& dy) {
+  const float xs = x * 0.70710678118654752f;
+  const float ax = fabsf(xs);
+  const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
+  float poly = fmaf(1.061405429f, t, -1.453152027f);
+  poly = fmaf(poly, t, 1.421413741f);
+  poly = fmaf(poly, t, -0.284496736f);
+  poly = fmaf(poly, t, 0.254829592f);
+  const float ex = __expf(-ax * ax);
+  const float erfv = copysignf(1.0f - poly * t * ex, xs);
+  y = 0.5f * x * (1.0f + erfv);
+  dy = fmaf(x * 0.39894228040143268f, ex, 0.5f * (1.0f + erfv));
 }
 
 // ---------------------------------------------------------------- counter-based RNG (dropout)

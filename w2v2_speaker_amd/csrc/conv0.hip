@@ -127,11 +127,13 @@ __global__ __launch_bounds__(256, 2) void conv0_mfma_kernel(const float* __restr
   for (int cw0 = 0; cw0 < C; cw0 += 512) {           // uniform trip count: every wave takes part in the staging
     const int cw = cw0 + wave * 128;                 // this wave's 128 channels
     const bool active = cw < C;
-    // weight fragments: fragment j row rho <-> channel cw + (rho >> 2) * 32 + j * 4 + (rho & 3)
+    // weight fragments: fragment j row rho <-> channel cw + (j >> 2) * 64 + (rho >> 2) * 16 + (j & 3) * 4 + (rho & 3):
+    // after the MFMA a lane (frame r, quad kq) holds two runs of 16 consecutive channels, cw + u * 64 + kq * 16 + 0..15
+    // (u = 0, 1), and the four kq lanes of a frame cover one whole 128-byte line per run -- see the store below
     c0_bf16x8 wf[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const int ch = active ? cw + (r >> 2) * 32 + j * 4 + (r & 3) : 0;
+      const int ch = active ? cw + (j >> 2) * 64 + (r >> 2) * 16 + (j & 3) * 4 + (r & 3) : 0;
       const float* wp = w + (int64_t)ch * k;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
@@ -143,14 +145,15 @@ __global__ __launch_bounds__(256, 2) void conv0_mfma_kernel(const float* __restr
         wf[j][e] = __builtin_bit_cast(__bf16, v);
       }
     }
-    const int cl = active ? cw + kq * 32 : 0;        // this lane's 32 output channels
+    const int cl = active ? cw + kq * 16 : 0;        // this lane's 32 output channels: cl + (q >> 4) * 64 + (q & 15)
+    auto chq = [&](int q) -> int { return cl + (q >> 4) * 64 + (q & 15); };
     float ga[32], be[32];
     if constexpr (APPLY) {
 #pragma unroll
       for (int q = 0; q < 32; ++q) {
-        const float* st = mr + ((int64_t)b * C + cl + q) * 2;
-        ga[q] = gamma[cl + q] * st[1];
-        be[q] = beta[cl + q] - st[0] * ga[q];
+        const float* st = mr + ((int64_t)b * C + chq(q)) * 2;
+        ga[q] = gamma[chq(q)] * st[1];
+        be[q] = beta[chq(q)] - st[0] * ga[q];
       }
     }
     float s1[32], s2[32];
@@ -191,18 +194,23 @@ __global__ __launch_bounds__(256, 2) void conv0_mfma_kernel(const float* __restr
         for (int j = 0; j < 8; ++j)
           acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf, c0_f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
         if constexpr (APPLY) {
-          if (live) {
-            TO* dst = y + ((int64_t)b * L + l0 + f0 + r) * C + cl;
+          // full-line stores (common.cuh): lanes r and r ^ 8 swap one 16-byte half, then every instruction writes
+          // 8 frames x 128 contiguous bytes (the per-lane 64-byte runs of the first version left at 2.2 TB/s)
+          const bool lo = r < 8;
+          const int fa = f0 + (r & 7);
+          TO* dst = y + ((int64_t)b * L + l0 + fa) * C + cl + (lo ? 0 : 8);
 #pragma unroll
-            for (int h = 0; h < 4; ++h) {             // 8 channels = fragments 2h, 2h+1
-              Vec8<TO> o;
+          for (int u = 0; u < 2; ++u) {
+            float v[16];
 #pragma unroll
-              for (int e = 0; e < 8; ++e) {
-                const int q = h * 8 + e;
-                o.v[e] = gelu_f(fmaf(acc[q >> 2][q & 3], ga[q], be[q]));
-              }
-              o.store(dst + h * 8);
+            for (int e = 0; e < 16; ++e) {
+              const int q = u * 16 + e;
+              v[e] = gelu_f(fmaf(acc[q >> 2][q & 3], ga[q], be[q]));
             }
+            uint4 da, db;
+            halves_to_lines(lo, pack8<TO>(v), pack8<TO>(v + 8), da, db);
+            if (fa < nf) *reinterpret_cast<uint4*>(dst + u * 64) = da;
+            if (fa + 8 < nf) *reinterpret_cast<uint4*>(dst + (int64_t)8 * C + u * 64) = db;
           }
         } else {
 #pragma unroll
@@ -225,11 +233,11 @@ __global__ __launch_bounds__(256, 2) void conv0_mfma_kernel(const float* __restr
         }
       }
       if (r == 0 && active) {
-        float* pt = partial + (((int64_t)b * gridDim.x + blockIdx.x) * C + cl) * 2;
+        float* pt = partial + ((int64_t)b * gridDim.x + blockIdx.x) * C * 2;
 #pragma unroll
         for (int q = 0; q < 32; ++q) {
-          pt[2 * q] = s1[q];
-          pt[2 * q + 1] = s2[q];
+          pt[2 * chq(q)] = s1[q];
+          pt[2 * chq(q) + 1] = s2[q];
         }
       }
     }

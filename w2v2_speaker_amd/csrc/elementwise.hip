@@ -132,6 +132,54 @@ extern "C" int w2v2_colsum(const void* x, int64_t ld, float* out, int M, int N, 
   return 0;
 }
 
+// ------------------------------------------------------------------------------------- zero ranges / mean
+// The backward WRITES the large gradients (grouped weight-gradient launch: dW and dbias of every Linear) and ADDS only
+// into the small ones (LayerNorm gamma / beta folds, pos-conv bias, masked_spec_embed, ...).  Zeroing the whole 400 MB
+// gradient arena every step is therefore mostly wasted HBM writes; one launch over a table of (offset, count) ranges --
+// the accumulated tensors plus the slices of the layers LayerDrop skipped -- replaces the memset.
+__global__ __launch_bounds__(256) void zero_ranges_kernel(float* __restrict__ base, const int64_t* __restrict__ table) {
+  const int64_t off = table[2 * blockIdx.y], n = table[2 * blockIdx.y + 1];
+  float* p = base + off;
+  // head: up to the first 16-byte boundary; body: float4; tail
+  const int64_t head = min(n, (int64_t)((4 - ((reinterpret_cast<uintptr_t>(p) >> 2) & 3)) & 3));
+  const int64_t nv = (n - head) >> 2;
+  float4* pv = reinterpret_cast<float4*>(p + head);
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nv; i += (int64_t)gridDim.x * blockDim.x)
+    pv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (blockIdx.x == 0) {
+    if ((int64_t)threadIdx.x < head) p[threadIdx.x] = 0.f;
+    const int64_t t0 = head + (nv << 2);
+    if (t0 + threadIdx.x < n && threadIdx.x < 4) p[t0 + threadIdx.x] = 0.f;
+  }
+}
+
+extern "C" int w2v2_zero_ranges(float* base, const int64_t* table, int n_ranges, int blocks_per_range, void* stream) {
+  W2V2_REQUIRE(base && table && n_ranges >= 0 && blocks_per_range > 0, "zero_ranges: bad arguments");
+  if (n_ranges == 0) return 0;
+  hipLaunchKernelGGL(zero_ranges_kernel, dim3((unsigned)blocks_per_range, (unsigned)n_ranges), dim3(256), 0,
+                     as_stream(stream), base, table);
+  W2V2_CHECK_LAUNCH("zero_ranges");
+  return 0;
+}
+
+// out[0] = mean(x[0..n)) in a fixed order (one workgroup; n = batch size: the scalar loss of a step)
+__global__ __launch_bounds__(256) void mean_kernel(const float* __restrict__ x, float* __restrict__ out, int n) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) s += x[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = (red[0] + red[1] + red[2] + red[3]) / (float)n;
+}
+
+extern "C" int w2v2_mean(const float* x, float* out, int n, void* stream) {
+  W2V2_REQUIRE(x && out && n > 0, "mean: bad arguments");
+  hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(256), 0, as_stream(stream), x, out, n);
+  W2V2_CHECK_LAUNCH("mean");
+  return 0;
+}
+
 // ------------------------------------------------------------------------------------- cast
 template <typename T>
 __global__ void cast_kernel(const float* __restrict__ x, T* __restrict__ y, int64_t n) {
@@ -207,6 +255,36 @@ __global__ __launch_bounds__(256) void mask_fill_bwd_kernel(T* __restrict__ dh, 
     const int c = blockIdx.x * 64 + threadIdx.x;
     if (c < H && s != 0.f) unsafeAtomicAdd(d_embed + c, s);
   }
+}
+
+// feature-axis SpecAugment (HF:1294-1304): h[b][t][c] = 0 where mask[b][c]; the backward is the same call on dh
+template <typename T>
+__global__ void mask_feature_kernel(T* __restrict__ h, const uint8_t* __restrict__ mask, int B, int Tn, int H) {
+  const int nch = H >> 3;
+  const int64_t total = (int64_t)B * Tn * nch;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int ch = (int)(i % nch);
+    const int64_t row = i / nch;
+    const int b = (int)(row / Tn);
+    const uint2 mk = *reinterpret_cast<const uint2*>(mask + (int64_t)b * H + ch * 8);
+    if ((mk.x | mk.y) == 0) continue;                 // nothing masked in these 8 channels: row left untouched
+    Vec8<T> v;
+    v.load(h + row * H + ch * 8);
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (((k < 4 ? mk.x >> (8 * k) : mk.y >> (8 * (k - 4))) & 0xff) != 0) v.v[k] = 0.f;
+    v.store(h + row * H + ch * 8);
+  }
+}
+
+extern "C" int w2v2_mask_feature(void* h, const uint8_t* mask, int B, int T, int H, int dtype, void* stream) {
+  W2V2_REQUIRE(h && mask && H % 8 == 0 && (reinterpret_cast<uintptr_t>(mask) & 7) == 0, "mask_feature: bad arguments");
+  if (B <= 0 || T <= 0) return 0;
+  W2V2_DISPATCH_ACT(dtype, "mask_feature",
+    hipLaunchKernelGGL(mask_feature_kernel<AT>, dim3(ew_blocks((int64_t)B * T * (H >> 3))), dim3(256), 0,
+                       as_stream(stream), (AT*)h, mask, B, T, H););
+  W2V2_CHECK_LAUNCH("mask_feature");
+  return 0;
 }
 
 extern "C" int w2v2_mask_fill(void* h, const uint8_t* mask, const float* embed, int M, int H, int dtype, void* stream) {

@@ -99,8 +99,15 @@ __device__ __forceinline__ void epilogue_store4(const GemmArgs& g, TC* __restric
           pre[j] = v;
           v = gelu_f(v);
           break;
+        case W2V2_EPI_BIAS_GELU_GRAD:
+          v += bias[n];
+          gelu_both_f(v, v, pre[j]);
+          break;
         case W2V2_EPI_GELU_BWD:
           v *= gelu_grad_f(to_f32<TC>(aux_in[(int64_t)m * g.ldaux + n]));
+          break;
+        case W2V2_EPI_MUL:
+          v *= to_f32<TC>(aux_in[(int64_t)m * g.ldaux + n]);
           break;
         case W2V2_EPI_ADD:
           v += to_f32<TC>(aux_in[(int64_t)m * g.ldaux + n]);
@@ -137,7 +144,7 @@ __device__ __forceinline__ void epilogue_store4(const GemmArgs& g, TC* __restric
     for (int j = 0; j < 4; ++j)
       if (n0 + j < g.N) crow[n0 + j] = from_f32<TC>(out[j]);
   }
-  if (g.epilogue == W2V2_EPI_BIAS_GELU && aux_out != nullptr) {
+  if ((g.epilogue == W2V2_EPI_BIAS_GELU || g.epilogue == W2V2_EPI_BIAS_GELU_GRAD) && aux_out != nullptr) {
     TC* arow = aux_out + (int64_t)m * g.ldaux;
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -168,7 +175,9 @@ __device__ __forceinline__ void epilogue_row8_impl(const GemmArgs& g, TC* __rest
     float x = v[e] * g.alpha;
     if constexpr (EPI == W2V2_EPI_BIAS) { if (lead) x += cv[e]; }
     if constexpr (EPI == W2V2_EPI_BIAS_GELU) { x += cv[e]; pre[e] = x; x = gelu_f(x); }
+    if constexpr (EPI == W2V2_EPI_BIAS_GELU_GRAD) { x += cv[e]; gelu_both_f(x, x, pre[e]); }
     if constexpr (EPI == W2V2_EPI_GELU_BWD) x *= gelu_grad_f(ax[e]);
+    if constexpr (EPI == W2V2_EPI_MUL) x *= ax[e];
     if constexpr (EPI == W2V2_EPI_ADD) x += ax[e];
     if constexpr (EPI == W2V2_EPI_SCALE_RC) x *= rs * cv[e];
     v[e] = x;
@@ -193,7 +202,7 @@ __device__ __forceinline__ void epilogue_row8_impl(const GemmArgs& g, TC* __rest
 #pragma unroll
     for (int e = 0; e < 8; ++e) if (n + e < g.N) cp[e] = from_f32<TC>(v[e]);
   }
-  if constexpr (EPI == W2V2_EPI_BIAS_GELU) {
+  if constexpr (EPI == W2V2_EPI_BIAS_GELU || EPI == W2V2_EPI_BIAS_GELU_GRAD) {
     if (auxz != nullptr) {
       TC* ap = auxz + (int64_t)m * g.ldaux + n;
       if (full && g.aux_vec_ok) {
@@ -220,7 +229,7 @@ __device__ __forceinline__ void epilogue_pass(const GemmArgs& g, const float* __
   const int n = n0 + ch * 8;
   if (n >= g.N) return;
   float ax[NIT][8];
-  if constexpr (EPI == W2V2_EPI_GELU_BWD || EPI == W2V2_EPI_ADD) {
+  if constexpr (EPI == W2V2_EPI_GELU_BWD || EPI == W2V2_EPI_ADD || EPI == W2V2_EPI_MUL) {
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int r = (tid + NTHREADS * it) / CPR;
@@ -249,7 +258,7 @@ __device__ __forceinline__ void epilogue_pass(const GemmArgs& g, const float* __
     const float4 lo = *reinterpret_cast<const float4*>(stage + r * PITCH + ch * 8);
     const float4 hi = *reinterpret_cast<const float4*>(stage + r * PITCH + ch * 8 + 4);
     float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-    if constexpr (EPI == W2V2_EPI_GELU_BWD || EPI == W2V2_EPI_ADD)
+    if constexpr (EPI == W2V2_EPI_GELU_BWD || EPI == W2V2_EPI_ADD || EPI == W2V2_EPI_MUL)
       epilogue_row8_impl<TC, EPI>(g, Cz, auxz, m, n, v, cv, ax[it], lead);
     else
       epilogue_row8_impl<TC, EPI>(g, Cz, auxz, m, n, v, cv, cv, lead);
@@ -277,7 +286,7 @@ __device__ __forceinline__ void epilogue_direct4(const GemmArgs& g, TC* __restri
                                                  const float (&cv1)[8], uint4 (&pend)[8]) {
   // row fragments I0 .. I0+NR-1 of the wave tile (rows m + 16 i); NR at a time bounds the aux staging registers
   float ax[NR][16];
-  if constexpr (EPI == W2V2_EPI_GELU_BWD || EPI == W2V2_EPI_ADD) {
+  if constexpr (EPI == W2V2_EPI_GELU_BWD || EPI == W2V2_EPI_ADD || EPI == W2V2_EPI_MUL) {
 #pragma unroll
     for (int i = 0; i < NR; ++i) {
       const int mi = m + 16 * (I0 + i);
@@ -312,7 +321,7 @@ __device__ __forceinline__ void epilogue_direct4(const GemmArgs& g, TC* __restri
       for (int e = 0; e < 8; ++e) v[e] = acc[I0 + i][2 * h + (e >> 2)][e & 3];
       float a8[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) a8[e] = (EPI == W2V2_EPI_GELU_BWD || EPI == W2V2_EPI_ADD) ? ax[i][8 * h + e] : 0.f;
+      for (int e = 0; e < 8; ++e) a8[e] = (EPI == W2V2_EPI_GELU_BWD || EPI == W2V2_EPI_ADD || EPI == W2V2_EPI_MUL) ? ax[i][8 * h + e] : 0.f;
       if constexpr (DEFER && FM == 4)
         epilogue_row8_impl<TC, EPI, true>(g, Cz, auxz, mi, n + 8 * h, v, h ? cv1 : cv0, a8, true, &pend[i * 2 + h]);
       else
@@ -342,6 +351,96 @@ __device__ __forceinline__ void epilogue_direct(const GemmArgs& g, TC* __restric
   }
 }
 
+// ------------------------------------------------------------------------------ full-line register epilogue
+// In the layout above a lane (c = lane & 15, q = lane >> 4) holds, for row fragment i, the 16 columns nc .. nc + 15 of
+// row 16 i + c as two 16-byte halves P0 | P1.  Stored directly, one wave instruction writes, per row, FOUR SCATTERED
+// 16-byte pieces (q * 32 bytes apart): 4.6 TB/s over the whole chip (tools/probes/store_pattern_probe), 4.9 with 64-byte
+// runs, 5.8 when 8 lanes cover one whole 128-byte line.  So lanes c and c ^ 8 swap one half each (v_mov_dpp row_ror:8:
+// four moves per fragment and output plane): lanes c < 8 keep P0 and receive the partner's P0, lanes c >= 8 keep P1 and
+// receive the partner's P1 -- every lane then stores columns nc + (c < 8 ? 0 : 8) .. + 7 of rows 16 i + (c & 7) and + 8,
+// and one instruction writes 8 rows x 128 contiguous bytes.  aux rows are FETCHED in the same pattern (packed, four
+// fragments = 32 registers at a time, all loads of a batch in flight before the first use) and swapped back.
+// host-side eligibility (wave-uniform): 16-bit C (and aux), 16-byte aligned rows, every 64-column wave tile inside N
+__device__ __forceinline__ bool lines_ok(const GemmArgs& g) {
+  return g.c_vec_ok && !g.atomic && (g.N & 63) == 0 && (g.aux == nullptr || g.aux_vec_ok);
+}
+
+// mw = first row of the wave tile (no lane part), nc = this lane's first column; rows mw + 16 i + c, i < FM.
+// DEFER: the two 16-byte stores of fragment i are left in pend[2 i], pend[2 i + 1] (see lines_flush).
+template <typename TC, int EPI, int FM, bool DEFER = false>
+__device__ __forceinline__ void epilogue_lines(const GemmArgs& g, TC* __restrict__ Cz, TC* __restrict__ auxz,
+                                               f32x4 (&acc)[FM][4], int mw, int nc, int lane, const float (&cv0)[8],
+                                               const float (&cv1)[8], uint4* __restrict__ pend) {
+  static_assert(sizeof(TC) == 2, "16-bit outputs only");
+  constexpr bool READS_AUX = EPI == W2V2_EPI_GELU_BWD || EPI == W2V2_EPI_ADD || EPI == W2V2_EPI_MUL;
+  constexpr bool WRITES_AUX = EPI == W2V2_EPI_BIAS_GELU || EPI == W2V2_EPI_BIAS_GELU_GRAD;
+  if constexpr (!DEFER) {
+    if (nc >= g.N) return;                       // wave tile wholly past the last column (uniform: N % 64 == 0)
+  }
+  const int c = lane & 15;
+  const bool lo = c < 8;
+  const int ra = mw + (c & 7);                   // rows this lane stores / fetches: ra + 16 i, ra + 16 i + 8
+  const int ncs = nc + (lo ? 0 : 8);
+  const int mo = mw + c;                         // row of this lane's own values: mo + 16 i
+#pragma unroll
+  for (int i0 = 0; i0 < FM; i0 += 4) {
+    uint4 la[4], lb[4];
+    if constexpr (READS_AUX) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = ra + 16 * (i0 + i);
+        la[i] = lb[i] = make_uint4(0, 0, 0, 0);
+        if (r < g.M) la[i] = *reinterpret_cast<const uint4*>(auxz + (int64_t)r * g.ldaux + ncs);
+        if (r + 8 < g.M) lb[i] = *reinterpret_cast<const uint4*>(auxz + (int64_t)(r + 8) * g.ldaux + ncs);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float ax[16];
+      if constexpr (READS_AUX) {
+        uint4 a0, a1;
+        lines_to_halves(lo, la[i], lb[i], a0, a1);
+        unpack8<TC>(a0, ax);
+        unpack8<TC>(a1, ax + 8);
+      }
+      float rs = 1.0f;
+      if constexpr (EPI == W2V2_EPI_SCALE_RC) rs = (mo + 16 * (i0 + i) < g.M) ? g.row_scale[mo + 16 * (i0 + i)] : 0.f;
+      float v[16], pre[16];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        float x = acc[i0 + i][e >> 2][e & 3] * g.alpha;
+        const float cve = e < 8 ? cv0[e] : cv1[e - 8];
+        if constexpr (EPI == W2V2_EPI_BIAS) x += cve;
+        if constexpr (EPI == W2V2_EPI_BIAS_GELU) { x += cve; pre[e] = x; x = gelu_f(x); }
+        if constexpr (EPI == W2V2_EPI_BIAS_GELU_GRAD) { x += cve; gelu_both_f(x, x, pre[e]); }
+        if constexpr (EPI == W2V2_EPI_GELU_BWD) x *= gelu_grad_f(ax[e]);
+        if constexpr (EPI == W2V2_EPI_MUL) x *= ax[e];
+        if constexpr (EPI == W2V2_EPI_ADD) x += ax[e];
+        if constexpr (EPI == W2V2_EPI_SCALE_RC) x *= rs * cve;
+        v[e] = x;
+      }
+      uint4 da, db;
+      halves_to_lines(lo, pack8<TC>(v), pack8<TC>(v + 8), da, db);
+      const int r = ra + 16 * (i0 + i);
+      if constexpr (DEFER) {
+        pend[2 * (i0 + i)] = da;
+        pend[2 * (i0 + i) + 1] = db;
+      } else {
+        if (r < g.M) *reinterpret_cast<uint4*>(Cz + (int64_t)r * g.ldc + ncs) = da;
+        if (r + 8 < g.M) *reinterpret_cast<uint4*>(Cz + (int64_t)(r + 8) * g.ldc + ncs) = db;
+      }
+      if constexpr (WRITES_AUX) {
+        if (auxz != nullptr) {
+          uint4 xa, xb;
+          halves_to_lines(lo, pack8<TC>(pre), pack8<TC>(pre + 8), xa, xb);
+          if (r < g.M) *reinterpret_cast<uint4*>(auxz + (int64_t)r * g.ldaux + ncs) = xa;
+          if (r + 8 < g.M) *reinterpret_cast<uint4*>(auxz + (int64_t)(r + 8) * g.ldaux + ncs) = xb;
+        }
+      }
+    }
+  }
+}
+
 #define W2V2_EPI_DISPATCH(CALL)                                              \
   switch (g.epilogue) {                                                      \
     case W2V2_EPI_BIAS: { constexpr int EPI = W2V2_EPI_BIAS; CALL; } break;  \
@@ -349,6 +448,8 @@ __device__ __forceinline__ void epilogue_direct(const GemmArgs& g, TC* __restric
     case W2V2_EPI_GELU_BWD: { constexpr int EPI = W2V2_EPI_GELU_BWD; CALL; } break;   \
     case W2V2_EPI_ADD: { constexpr int EPI = W2V2_EPI_ADD; CALL; } break;    \
     case W2V2_EPI_SCALE_RC: { constexpr int EPI = W2V2_EPI_SCALE_RC; CALL; } break;   \
+    case W2V2_EPI_BIAS_GELU_GRAD: { constexpr int EPI = W2V2_EPI_BIAS_GELU_GRAD; CALL; } break; \
+    case W2V2_EPI_MUL: { constexpr int EPI = W2V2_EPI_MUL; CALL; } break;    \
     default: { constexpr int EPI = W2V2_EPI_NONE; CALL; } break;             \
   }
 
@@ -757,13 +858,14 @@ __global__ __launch_bounds__(512) void gemm_bf16_glds3_kernel(const GemmArgs g) 
   int pend_m = 0, pend_n = 0;
   TC* const Cdef = reinterpret_cast<TC*>(g.C) + (blockIdx.z / g.batch_inner) * g.c_s0 +
                    (blockIdx.z % g.batch_inner) * g.c_s1;
+  // pend[2 i], pend[2 i + 1] = rows pend_m + 16 i and + 8, columns pend_n .. pend_n + 7 (epilogue_lines)
   auto flush = [&](auto first, auto count) {
     if constexpr (sizeof(TC) == 2) {
 #pragma unroll
       for (int q = decltype(first)::value; q < decltype(first)::value + decltype(count)::value; ++q) {
-        const int mi = pend_m + 16 * (q >> 1);
+        const int mi = pend_m + 16 * (q >> 1) + 8 * (q & 1);
         if (mi < g.M)
-          *reinterpret_cast<uint4*>(Cdef + (int64_t)mi * g.ldc + pend_n + 8 * (q & 1)) = pend[q];
+          *reinterpret_cast<uint4*>(Cdef + (int64_t)mi * g.ldc + pend_n) = pend[q];
       }
     }
   };
@@ -947,11 +1049,17 @@ __global__ __launch_bounds__(512) void gemm_bf16_glds3_kernel(const GemmArgs g) 
   float cv0[8], cv1[8];
   load_col8(g, bias, nc, cv0);
   load_col8(g, bias, nc + 8, cv1);
-  if (sizeof(TC) == 2 && g.defer_ok) {
-    W2V2_EPI_DISPATCH((epilogue_direct4<TC, EPI, 4, 0, true>(g, Cz, auxz, acc, m0 + wm * 64 + frow, nc, cv0, cv1, pend)));
-    pending = true;
-    pend_m = m0 + wm * 64 + frow;
-    pend_n = nc;
+  if constexpr (sizeof(TC) == 2) {
+    if (g.defer_ok) {            // (the host grants defer_ok only where lines_ok holds)
+      W2V2_EPI_DISPATCH((epilogue_lines<TC, EPI, 4, true>(g, Cz, auxz, acc, m0 + wm * 64, nc, lane, cv0, cv1, pend)));
+      pending = true;
+      pend_m = m0 + wm * 64 + (frow & 7);
+      pend_n = nc + (frow < 8 ? 0 : 8);
+    } else if (lines_ok(g)) {
+      W2V2_EPI_DISPATCH((epilogue_lines<TC, EPI, 4>(g, Cz, auxz, acc, m0 + wm * 64, nc, lane, cv0, cv1, pend)));
+    } else {
+      W2V2_EPI_DISPATCH((epilogue_direct<TC, EPI, 4>(g, Cz, auxz, acc, m0 + wm * 64 + frow, nc, cv0, cv1)));
+    }
   } else {
     W2V2_EPI_DISPATCH((epilogue_direct<TC, EPI, 4>(g, Cz, auxz, acc, m0 + wm * 64 + frow, nc, cv0, cv1)));
   }
@@ -1108,7 +1216,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_glds4_kernel(const GemmArgs g) 
       float cv0[8], cv1[8];
     load_col8(g, bias, nc, cv0);
     load_col8(g, bias, nc + 8, cv1);
-    W2V2_EPI_DISPATCH((epilogue_direct<TC, EPI, FM>(g, Cz, auxz, acc, m0 + wm * 128 + frow, nc, cv0, cv1)));
+    if constexpr (sizeof(TC) == 2) {       // (the host sends 16-bit outputs here only where lines_ok holds)
+      W2V2_EPI_DISPATCH((epilogue_lines<TC, EPI, FM>(g, Cz, auxz, acc, m0 + wm * 128, nc, lane, cv0, cv1, nullptr)));
+    } else {
+      W2V2_EPI_DISPATCH((epilogue_direct<TC, EPI, FM>(g, Cz, auxz, acc, m0 + wm * 128 + frow, nc, cv0, cv1)));
+    }
   }   // tile loop
 }
 
@@ -1327,7 +1439,11 @@ __global__ __launch_bounds__(512) void gemm_ph_kernel(const GemmArgs g) {
     float cv0[8], cv1[8];
     load_col8(g, bias, nc, cv0);
     load_col8(g, bias, nc + 8, cv1);
-    W2V2_EPI_DISPATCH((epilogue_direct<TC, EPI, FM, 2>(g, Cz, auxz, acc, mr, nc, cv0, cv1)));
+    if constexpr (sizeof(TC) == 2) {       // (the host sends 16-bit outputs here only where lines_ok holds)
+      W2V2_EPI_DISPATCH((epilogue_lines<TC, EPI, FM>(g, Cz, auxz, acc, mr - frow, nc, lane, cv0, cv1, nullptr)));
+    } else {
+      W2V2_EPI_DISPATCH((epilogue_direct<TC, EPI, FM, 2>(g, Cz, auxz, acc, mr, nc, cv0, cv1)));
+    }
   }   // tile loop
 }
 
@@ -1486,6 +1602,146 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
     epilogue_store4<TC>(g, Cz, auxz, auxo, bias, m0 + ty * 4 + i, n0 + tx * 4, acc[i], split == 0);
 }
 
+// ------------------------------------------------------------------------------ exact f32 on the matrix cores
+// v_mfma_f32_32x32x2_f32: f32 operands, f32 accumulate, bit-for-bit a k-ordered fmaf chain (cdna_hip_programming.md 3,
+// "FP32-input MFMA") at the f32 vector RATE -- but issued by one instruction per 4096 multiply-adds instead of 64, with
+// one VGPR per operand, so an untuned LDS-tiled kernel already runs ~2.4x a VALU tile kernel (the 64x64x16 kernel above,
+// kept behind W2V2_F32_VALU for A/B).  This is the GEMM of the exact-f32 parity mode and of BASELINE configs[4]
+// (ECAPA-TDNN at the reference's `precision: 32`, "MFMA off" = no reduced-precision matrix path: the numerics ARE f32).
+//   128 x 128 x 16 block tile, 4 waves as 2 x 2, 64 x 64 per wave = 2 x 2 MFMA blocks (64 accumulator VGPRs);
+//   both operands are staged K-MAJOR in LDS ([k][row], pitch 132: a fragment is 32 consecutive rows of one k ->
+//   conflict-free ds_read_b32), the next K tile's global loads are in flight under the 32 MFMAs of the current one;
+//   operands swapped (D[n][m]) so a lane holds 4 consecutive n per accumulator quad -> the shared 4-wide epilogue.
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(const GemmArgs g) {
+  constexpr int BM = 128, BN = 128, BK = 16, P = 132;
+  __shared__ float As[2][BK][P];
+  __shared__ float Bs[2][BK][P];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tile = blockIdx.x;
+  const int tm = tile / g.tiles_n, tn = tile - tm * g.tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int z = blockIdx.z;
+  const int z0 = z / g.batch_inner, z1 = z - z0 * g.batch_inner;
+  const int split = blockIdx.y;
+  const int kbeg = split * g.k_per_split;
+  const int kend = min(g.K, kbeg + g.k_per_split);
+  const float* Ab = reinterpret_cast<const float*>(g.A.ptr) + z0 * g.a_s0 + z1 * g.a_s1;
+  const float* Bb = reinterpret_cast<const float*>(g.B.ptr) + z0 * g.b_s0 + z1 * g.b_s1;
+
+  // staging map: 2 x float4 per operand and thread.  K-contiguous operand (trans = 0): thread -> (row = c >> 2, 4 k);
+  // K-major operand (trans = 1): thread -> (k = c >> 5, 4 rows)
+  auto load_op = [&](const OpDev& o, const float* __restrict__ base, bool trans, int r0, int rbound, int k0,
+                     float4 (&reg)[2]) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int c = tid + 256 * j;
+      float v[4] = {0.f, 0.f, 0.f, 0.f};
+      if (!trans) {
+        const int row = c >> 2, k = k0 + (c & 3) * 4;
+        if (r0 + row < rbound && k < kend) {
+          const float* p = base + outer_off(o, r0 + row) + k;
+          if (o.vec_ok && k + 4 <= kend) {
+            const float4 t = *reinterpret_cast<const float4*>(p);
+            v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (k + e < kend) v[e] = p[e];
+          }
+        }
+      } else {
+        const int k = k0 + (c >> 5), row = (c & 31) * 4;
+        if (k < kend && r0 + row < rbound) {
+          const float* p = base + outer_off(o, k) + r0 + row;
+          if (o.vec_ok && r0 + row + 4 <= rbound) {
+            const float4 t = *reinterpret_cast<const float4*>(p);
+            v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (r0 + row + e < rbound) v[e] = p[e];
+          }
+        }
+      }
+      reg[j] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+  };
+  auto store_op = [&](float (&dst)[BK][P], bool trans, const float4 (&reg)[2]) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int c = tid + 256 * j;
+      if (!trans) {
+        const int row = c >> 2, k = (c & 3) * 4;
+        dst[k][row] = reg[j].x; dst[k + 1][row] = reg[j].y; dst[k + 2][row] = reg[j].z; dst[k + 3][row] = reg[j].w;
+      } else {
+        *reinterpret_cast<float4*>(&dst[c >> 5][(c & 31) * 4]) = reg[j];
+      }
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int nk = (kend - kbeg + BK - 1) / BK;
+  float4 ra[2], rb[2];
+  if (nk > 0) {
+    load_op(g.A, Ab, TA, m0, g.M, kbeg, ra);
+    load_op(g.B, Bb, TB, n0, g.N, kbeg, rb);
+    store_op(As[0], TA, ra);
+    store_op(Bs[0], TB, rb);
+  }
+  __syncthreads();
+  const int kl = lane >> 5, rl = lane & 31;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) {
+      load_op(g.A, Ab, TA, m0, g.M, kbeg + (kt + 1) * BK, ra);
+      load_op(g.B, Bb, TB, n0, g.N, kbeg + (kt + 1) * BK, rb);
+    }
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 2) {
+      float a[2], b[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) a[i] = As[cur][kk + kl][wm * 64 + i * 32 + rl];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) b[j] = Bs[cur][kk + kl][wn * 64 + j * 32 + rl];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[j], a[i], acc[i][j], 0, 0, 0);   // D[n][m]
+    }
+    if (kt + 1 < nk) {
+      store_op(As[cur ^ 1], TA, ra);
+      store_op(Bs[cur ^ 1], TB, rb);
+    }
+    __syncthreads();
+  }
+
+  float* Cz = reinterpret_cast<float*>(g.C) + z0 * g.c_s0 + z1 * g.c_s1;
+  const float* auxz = g.aux ? reinterpret_cast<const float*>(g.aux) + z0 * g.aux_s0 + z1 * g.aux_s1 : nullptr;
+  float* auxo = g.aux ? reinterpret_cast<float*>(g.aux) + z0 * g.aux_s0 + z1 * g.aux_s1 : nullptr;
+  const float* bias = g.bias ? g.bias + z1 * g.bias_s1 : nullptr;
+  // D[n][m]: lane l, register r: m = l & 31, n = 8 (r >> 2) + 4 (l >> 5) + (r & 3)
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float v4[4] = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+        epilogue_store4<float>(g, Cz, auxz, auxo, bias, m0 + wm * 64 + i * 32 + rl, n0 + wn * 64 + j * 32 + q * 8 + kl * 4,
+                               v4, split == 0);
+      }
+}
+
 // ------------------------------------------------------------------------------ host dispatch
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
@@ -1510,6 +1766,15 @@ static void launch_bf16(const GemmArgs& a, dim3 grid, hipStream_t st) {
 #undef W2V2_LAUNCH
 }
 
+// tuning hook (tools/gemm_shapes.py): force the kernel family of the K-contiguous 16-bit products.
+//   0 = dispatch below, 1 = 128x128 LDS-DMA, 2 = 256x128 ring, 3 = 256x256x32 ring, 4 = 256x256x64 phased
+static int g_w2v2_force = 0;
+extern "C" int w2v2_tune_gemm_kernel(int family) {
+  const int old = g_w2v2_force;
+  if (family >= 0 && family <= 4) g_w2v2_force = family;
+  return old;
+}
+
 extern "C" int w2v2_gemm(const w2v2_gemm_desc* d, void* stream) {
   W2V2_REQUIRE(d != nullptr, "w2v2_gemm: null descriptor");
   W2V2_REQUIRE(d->M > 0 && d->N > 0 && d->K >= 0 && d->batch > 0, "w2v2_gemm: bad shape M=%d N=%d K=%d batch=%d",
@@ -1519,7 +1784,7 @@ extern "C" int w2v2_gemm(const w2v2_gemm_desc* d, void* stream) {
                "w2v2_gemm: bad dtype_ab %d", d->dtype_ab);
   W2V2_REQUIRE(d->dtype_c == W2V2_F32 || d->dtype_c == d->dtype_ab, "w2v2_gemm: dtype_c %d must be f32 or dtype_ab (%d)",
                d->dtype_c, d->dtype_ab);
-  W2V2_REQUIRE(d->epilogue >= 0 && d->epilogue <= W2V2_EPI_SCALE_RC, "w2v2_gemm: bad epilogue %d", d->epilogue);
+  W2V2_REQUIRE(d->epilogue >= 0 && d->epilogue <= W2V2_EPI_MUL, "w2v2_gemm: bad epilogue %d", d->epilogue);
   const int split = d->split_k > 1 ? d->split_k : 1;
   const int atomic = (split > 1 || d->accumulate) ? 1 : 0;
   if (atomic) {
@@ -1527,9 +1792,10 @@ extern "C" int w2v2_gemm(const w2v2_gemm_desc* d, void* stream) {
     W2V2_REQUIRE(d->epilogue == W2V2_EPI_NONE || (split == 1) || d->epilogue == W2V2_EPI_BIAS,
                  "w2v2_gemm: split_k supports EPI_NONE/EPI_BIAS only");
   }
-  if (d->epilogue == W2V2_EPI_BIAS || d->epilogue == W2V2_EPI_BIAS_GELU)
+  if (d->epilogue == W2V2_EPI_BIAS || d->epilogue == W2V2_EPI_BIAS_GELU || d->epilogue == W2V2_EPI_BIAS_GELU_GRAD)
     W2V2_REQUIRE(d->bias != nullptr, "w2v2_gemm: bias epilogue without bias");
-  if (d->epilogue == W2V2_EPI_GELU_BWD || d->epilogue == W2V2_EPI_ADD)
+  if (d->epilogue == W2V2_EPI_GELU_BWD || d->epilogue == W2V2_EPI_ADD || d->epilogue == W2V2_EPI_MUL ||
+      d->epilogue == W2V2_EPI_BIAS_GELU_GRAD)
     W2V2_REQUIRE(d->aux != nullptr, "w2v2_gemm: epilogue %d needs aux", d->epilogue);
   if (d->epilogue == W2V2_EPI_SCALE_RC)
     W2V2_REQUIRE(d->row_scale && d->col_scale, "w2v2_gemm: EPI_SCALE_RC needs row/col scales");
@@ -1584,8 +1850,24 @@ extern "C" int w2v2_gemm(const w2v2_gemm_desc* d, void* stream) {
         return (o.seg_len > 0 ? (rows / o.seg_len + 1) * o.seg_stride + o.seg_len * o.ld : rows * o.ld) + K;
       };
       const bool fits32 = extent(d->A, d->M, d->K) < (int64_t(1) << 31) && extent(d->B, d->N, d->K) < (int64_t(1) << 31);
-      huge = t4 >= ncu && (double)t4 / (double)(cdiv(t4, ncu) * ncu) >= 0.85 &&
+      // measured per shape with tools/gemm_shapes.py (FAMILIES=0,1,2,3,4): a 256x256 tile step runs ~1.2x the flops
+      // per second of a 256x128 one (1.25 below), so the larger tile wins whenever its last-round fill is not worse by more than
+      // that (conv3: 620 tiles = 0.81 vs 0.97 -> 174 vs 183 us; conv5: 156 tiles = 0.61 vs 0.61 -> 41 vs 47 us;
+      // FFN2-shaped N = 768 products: 117 tiles = 0.46 vs 0.91 -> 73 vs 52 us stay on the 256x128 ring)
+      const int64_t t3 = cdiv(d->M, 256) * cdiv(d->N, 128);
+      const double fill4 = (double)t4 / (double)(cdiv(t4, ncu) * ncu), fill3 = (double)t3 / (double)(cdiv(t3, ncu) * ncu);
+      // 16-bit outputs of the 256x256 kernels go through the full-line register epilogue only
+      const bool lines = d->dtype_c == W2V2_F32 ||
+                         (a.c_vec_ok && (d->N % 64 == 0) && (d->aux == nullptr || a.aux_vec_ok));
+      huge = lines && fill4 * 1.25 >= fill3 && t4 * 2 >= ncu &&
              (double)d->N / (double)(cdiv(d->N, 256) * 256) >= 0.9 && (fits32 || !g_w2v2_ph);
+    }
+    bool big_ = big, force_ph = true;
+    if (g_w2v2_force != 0 && glds && split == 1 && !atomic && d->k_ext == 0 && d->batch == 1) {
+      big_ = g_w2v2_force >= 2;
+      huge = g_w2v2_force >= 3 && (d->dtype_c == W2V2_F32 ||
+                                   (a.c_vec_ok && (d->N % 64 == 0) && (d->aux == nullptr || a.aux_vec_ok)));
+      force_ph = g_w2v2_force == 4;
     }
     if (d->k_ext != 0)
       W2V2_REQUIRE(big && !huge && d->k_ext == d->K && d->n_ext_from >= 0 && d->n_ext_from % 128 == 0 &&
@@ -1595,15 +1877,16 @@ extern "C" int w2v2_gemm(const w2v2_gemm_desc* d, void* stream) {
     // TE = operand element type (selects the MFMA instruction), TC = float or TE
 #define W2V2_GEMM_LAUNCH(TE, TC)                                                                         \
     do {                                                                                                 \
-      if (huge && g_w2v2_ph) launch_ph<TE, TC>(a, d->M, d->N, d->batch, st);                              \
+      if (huge && g_w2v2_ph && force_ph) launch_ph<TE, TC>(a, d->M, d->N, d->batch, st);                  \
       else if (huge) launch_glds4<TE, TC>(a, d->M, d->N, d->batch, st);                                  \
-      else if (big) launch_glds3<TE, TC>(a, d->M, d->N, d->batch, st);                                   \
+      else if (big_) launch_glds3<TE, TC>(a, d->M, d->N, d->batch, st);                                  \
       else if (glds) { if (narrow) launch_glds<TE, 4, 2, TC>(a, grid, st); else launch_glds<TE, 4, 4, TC>(a, grid, st); } \
       else { if (narrow) launch_bf16<TE, 4, 2, TC>(a, grid, st); else launch_bf16<TE, 4, 4, TC>(a, grid, st); }         \
     } while (0)
-    if (big && !huge)
+    if (big_ && !huge)
       a.defer_ok = defer_env && d->dtype_c != W2V2_F32 && a.c_vec_ok && (d->N % 128 == 0) && !atomic &&
-                   d->epilogue != W2V2_EPI_BIAS_GELU;
+                   (d->aux == nullptr || a.aux_vec_ok) &&
+                   d->epilogue != W2V2_EPI_BIAS_GELU && d->epilogue != W2V2_EPI_BIAS_GELU_GRAD;
     if (d->dtype_ab == W2V2_BF16) {
       if (d->dtype_c == W2V2_F32) W2V2_GEMM_LAUNCH(bf16_t, float); else W2V2_GEMM_LAUNCH(bf16_t, bf16_t);
     } else {
@@ -1612,11 +1895,22 @@ extern "C" int w2v2_gemm(const w2v2_gemm_desc* d, void* stream) {
 #undef W2V2_GEMM_LAUNCH
   } else {
     W2V2_REQUIRE(d->dtype_c == W2V2_F32, "w2v2_gemm: f32 operands need an f32 C");
-    a.tiles_m = (int)cdiv(d->M, 64); a.tiles_n = (int)cdiv(d->N, 64);
+    static const bool f32_valu = getenv("W2V2_F32_VALU") != nullptr;      // A/B: the 64x64x16 VALU tile kernel
+    const int BT = f32_valu ? 64 : 128;
+    a.tiles_m = (int)cdiv(d->M, BT); a.tiles_n = (int)cdiv(d->N, BT);
     a.k_per_split = (int)(cdiv(cdiv(d->K, split), 16) * 16);
     if (a.k_per_split == 0) a.k_per_split = 16;
+    // f32 rows are 16-byte vectors of FOUR elements
+    auto vec4 = [&](const w2v2_operand& o) {
+      return aligned16(o.ptr) && (o.ld % 4 == 0) && (o.seg_stride % 4 == 0) && (o.stride0 % 4 == 0) && (o.stride1 % 4 == 0);
+    };
+    a.A.vec_ok = vec4(d->A); a.B.vec_ok = vec4(d->B);
     dim3 grid(a.tiles_m * a.tiles_n, split, d->batch);
-    hipLaunchKernelGGL(gemm_f32_kernel<float>, grid, dim3(256), 0, st, a);
+    if (f32_valu) hipLaunchKernelGGL(gemm_f32_kernel<float>, grid, dim3(256), 0, st, a);
+    else if (!a.A.trans && !a.B.trans) hipLaunchKernelGGL((gemm_f32_mfma_kernel<false, false>), grid, dim3(256), 0, st, a);
+    else if (!a.A.trans && a.B.trans) hipLaunchKernelGGL((gemm_f32_mfma_kernel<false, true>), grid, dim3(256), 0, st, a);
+    else if (a.A.trans && !a.B.trans) hipLaunchKernelGGL((gemm_f32_mfma_kernel<true, false>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((gemm_f32_mfma_kernel<true, true>), grid, dim3(256), 0, st, a);
   }
   W2V2_CHECK_LAUNCH("w2v2_gemm");
   return 0;

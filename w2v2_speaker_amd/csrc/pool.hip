@@ -120,6 +120,8 @@ __global__ void pool_select_kernel(const T* __restrict__ x, float* __restrict__ 
     for (int t = 1; t < Tn; ++t) r = fmaxf(r, to_f32<T>(xb[(int64_t)t * H]));
   } else if (mode == 3) {
     r = to_f32<T>(xb[0]);
+  } else if (mode >= 16) {                  // explicit frame index (IndexPool1D "random": the host draws it)
+    r = to_f32<T>(xb[(int64_t)(mode - 16) * H]);
   } else {
     r = to_f32<T>(xb[(int64_t)(Tn - 1) * H]);
   }
@@ -143,6 +145,8 @@ __global__ void pool_select_bwd_kernel(const T* __restrict__ x, const float* __r
     }
   } else if (mode == 4) {
     sel = Tn - 1;
+  } else if (mode >= 16) {
+    sel = mode - 16;
   }
   for (int t = 0; t < Tn; ++t) db[(int64_t)t * H] = from_f32<T>(t == sel ? dout[i] : 0.f);
 }
@@ -283,7 +287,8 @@ __global__ void pool_quantile_bwd_kernel(const T* __restrict__ x, const float* _
 }
 
 extern "C" int w2v2_pool_fwd(const void* x, float* out, int B, int T, int H, int mode, int dtype, void* stream) {
-  W2V2_REQUIRE(x && out && B > 0 && T > 0 && H > 0 && mode >= 0 && mode <= 5, "pool_fwd: bad arguments");
+  W2V2_REQUIRE(x && out && B > 0 && T > 0 && H > 0 && mode >= 0 && (mode <= 5 || (mode >= 16 && mode - 16 < T)),
+               "pool_fwd: bad arguments (mode %d, T %d)", mode, T);
   hipStream_t st = as_stream(stream);
   if (mode == 5) {
     dim3 grid((unsigned)cdiv((int64_t)B * H, 64));
@@ -305,7 +310,8 @@ extern "C" int w2v2_pool_fwd(const void* x, float* out, int B, int T, int H, int
 
 extern "C" int w2v2_pool_bwd(const void* x, const float* out, const float* dout, void* dx, int B, int T, int H,
                              int mode, int dtype, void* stream) {
-  W2V2_REQUIRE(x && out && dout && dx && B > 0 && T > 0 && H > 0 && mode >= 0 && mode <= 5, "pool_bwd: bad arguments");
+  W2V2_REQUIRE(x && out && dout && dx && B > 0 && T > 0 && H > 0 && mode >= 0 &&
+                   (mode <= 5 || (mode >= 16 && mode - 16 < T)), "pool_bwd: bad arguments (mode %d, T %d)", mode, T);
   hipStream_t st = as_stream(stream);
   if (mode == 5) {
     dim3 grid((unsigned)cdiv((int64_t)B * H, 64));

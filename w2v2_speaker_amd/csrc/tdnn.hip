@@ -343,9 +343,11 @@ __global__ void add_strided_kernel(const T* __restrict__ a, int64_t lda, const T
     const int64_t m = i / nch;
     Vec8<T> va, vb;
     va.load(a + m * lda + ch * 8);
-    vb.load(b + m * ldb + ch * 8);
+    if (b != nullptr) {                    // b == NULL: a strided copy (Res2Net pass-through chunk, SE input slice)
+      vb.load(b + m * ldb + ch * 8);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) va.v[e] += vb.v[e];
+      for (int e = 0; e < 8; ++e) va.v[e] += vb.v[e];
+    }
     va.store(y + m * ldy + ch * 8);
   }
 }
@@ -509,7 +511,7 @@ extern "C" int w2v2_col2im_reflect(const void* dcol, void* dx, int64_t lddx, int
 
 extern "C" int w2v2_add_strided(const void* a, int64_t lda, const void* b, int64_t ldb, void* y, int64_t ldy, int M,
                                 int C, int dtype, void* stream) {
-  W2V2_REQUIRE(a && b && y && M > 0 && C % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && ldy % 8 == 0,
+  W2V2_REQUIRE(a && y && M > 0 && C % 8 == 0 && lda % 8 == 0 && (b == nullptr || ldb % 8 == 0) && ldy % 8 == 0,
                "add_strided: bad arguments");
   const int nb = td_blocks((int64_t)M * (C >> 3));
   hipStream_t st = as_stream(stream);

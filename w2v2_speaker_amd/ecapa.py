@@ -147,7 +147,12 @@ class EcapaStore:
         self.version += 1
 
     def zero_grad(self) -> None:
-        self.grad.zero_()
+        if self.grad.is_cuda:
+            if getattr(self, "_ztab", None) is None:
+                self._ztab = torch.tensor([[0, self.grad.numel()]], dtype=torch.int64, device=self.device)
+            ops.zero_ranges(self.grad, self._ztab, blocks_per_range=1024)
+        else:
+            self.grad.zero_()
 
     def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = True) -> None:
         seen = set()
@@ -224,7 +229,7 @@ class _Tdnn:
         self.cin, self.cout, self.k, self.dil = cin, cout, k, dil
         M, K = B * T, k * cin
         self.M, self.K = M, K
-        self.wp = torch.empty(cout, K, dtype=adt, device=dev)                  # packed [cout][tap][cin] operand
+        self.wp, self.wpt = plan.weight_pair(cout, K)                          # packed [cout][tap][cin] operand (+ its transpose)
         self.col = plan.buf(M, K) if k > 1 else None
         self.a = torch.empty(M, cout, dtype=adt, device=dev)                   # pre-activation (saved)
         self.mean_rstd = torch.empty(cout, 2, dtype=f32, device=dev)
@@ -247,13 +252,12 @@ class _Tdnn:
             self.dcol = torch.empty(M, K, dtype=adt, device=dev) if k > 1 else None
             # bf16: the data-gradient product reads the packed weight TRANSPOSED ([K][cout], refreshed with the pack)
             # so that it is an NT product on the LDS-DMA ring kernels instead of a K-major-B one on the generic kernel
-            self.wpt = torch.empty(K, cout, dtype=adt, device=dev) if ops.is16(adt) else None
+            # (self.wpt: [K][cout] view of the plan's transposed-weight arena, refreshed by ONE batched-transpose launch
+            # for all TDNN blocks -- EcapaPlan._refresh)
             self._dx_gemm = {}
 
     def refresh(self) -> None:
         ops.pack_conv_weight(self.plan.store.p(self.pre + "conv.conv.weight"), self.wp)
-        if self.plan.train and self.wpt is not None:
-            self.wpt.copy_(self.wp.t())            # layout change only (buffer plumbing), no arithmetic
 
     def forward(self) -> None:
         st, pl = self.plan.store, self.plan
@@ -379,7 +383,7 @@ class _SERes2Net:
     def forward(self) -> None:
         w, C, M = self.w, self.C, self.M
         self.tdnn1.forward()
-        self.r2[:, :w].copy_(self.t1[:, :w])                                     # chunk 0 passes through
+        ops.copy_strided(self.t1, C, self.r2, C, M, w)                             # chunk 0 passes through
         for i in range(1, self.sc):
             if i >= 2:
                 ops.add_strided(self.t1[:, i * w:], C, self.r2[:, (i - 1) * w:], C, self.sums[i], w, M, w)
@@ -392,7 +396,7 @@ class _SERes2Net:
         """dout = gradient of the block output (view, row stride lddo); dx (+)= gradient of the block input."""
         w, C, M, sc = self.w, self.C, self.M, self.sc
         # residual branch: d(input) gets dout; SE branch: dout -> d_t2
-        self.d_se.copy_(dout[:, :C])
+        ops.copy_strided(dout, lddo, self.d_se, C, M, C)
         self.se.backward(self.d_se, self.d_t2)
         self.tdnn2.backward(self.d_t2, C, self.d_r2, C, False, defer_dw=True)
         # Res2Net, last slice first: the gradient of (x_i + y_{i-1}) lands in d_t1[:, i] and is carried to y_{i-1}
@@ -403,7 +407,7 @@ class _SERes2Net:
             else:
                 dy, ld = self.d_r2[:, i * w:], C
             self.chunks[i].backward(dy, ld, self.d_t1[:, i * w:(i + 1) * w], C, False, defer_dw=True)
-        self.d_t1[:, :w].copy_(self.d_r2[:, :w])
+        ops.copy_strided(self.d_r2, C, self.d_t1, C, M, w)
         self.tdnn1.backward(self.d_t1, C, dx, lddx, accumulate, defer_dw=True)
         # residual: dx += dout
         ops.add_strided(dx, lddx, dout, lddo, dx, lddx, M, C)
@@ -423,6 +427,11 @@ class EcapaPlan:
         C = cfg.channels
         nb = len(C) - 2                                                       # SE-Res2Net blocks
         assert all(c == C[1] for c in C[1:-1]) and C[-1] == nb * C[1], "MFA concatenates the SE-Res2Net outputs"
+        # packed conv weights of all TDNN blocks in one arena (+ a second one with their transposes for the 16-bit
+        # data-gradient products): the transposes are refreshed by one w2v2_transpose_many launch per optimiser step
+        self._wp_pool = torch.empty(store.n_total, dtype=adt, device=dev)
+        self._wpt_pool = torch.empty(store.n_total, dtype=adt, device=dev) if (train and ops.is16(adt)) else None
+        self._wp_off, self._t_rows = 0, []
         F_ = cfg.input_mel_coefficients
         self.feat = self.buf(M, F_)
         self.x0 = self.buf(M, C[0])
@@ -462,6 +471,18 @@ class EcapaPlan:
         self._version = -1
         self._wgs = None
 
+    def weight_pair(self, cout: int, K: int):
+        """([cout, K] packed-weight view, [K, cout] transposed view or None) out of the plan's two weight arenas."""
+        o, n = self._wp_off, cout * K
+        self._wp_off = o + (n + ALIGN - 1) // ALIGN * ALIGN
+        assert self._wp_off <= self._wp_pool.numel()
+        wp = self._wp_pool[o:o + n].view(cout, K)
+        wpt = None
+        if self._wpt_pool is not None:
+            wpt = self._wpt_pool[o:o + n].view(K, cout)
+            self._t_rows.append([o, o, cout, K])
+        return wp, wpt
+
     def buf(self, rows: int, cols: int) -> torch.Tensor:
         """[rows, cols] activation whose storage is zero-padded to a multiple of 64 rows (``_full``): legal K-major
         operand of the grouped weight-gradient kernels (csrc/wgrad.hip contract)."""
@@ -480,6 +501,10 @@ class EcapaPlan:
         if self._version != self.store.version:
             for t in self._tdnns():
                 t.refresh()
+            if self._wpt_pool is not None and self._t_rows:
+                if getattr(self, "_t_table", None) is None:
+                    self._t_table = torch.tensor(self._t_rows, dtype=torch.int64, device=self.dev)
+                ops.transpose_many(self._wp_pool, self._wpt_pool, self._t_table, self._t_table.shape[0])
             self._version = self.store.version
 
     def embed(self, feat: torch.Tensor) -> torch.Tensor:
@@ -487,7 +512,11 @@ class EcapaPlan:
         st, B, T = self.store, self.B, self.T
         assert feat.shape == (B, T, self.cfg.input_mel_coefficients) and feat.is_cuda
         self._refresh()
-        self.feat.copy_(feat.reshape(B * T, -1))
+        f2 = feat.reshape(B * T, -1)
+        if self.feat.dtype == torch.float32:        # (input plumbing: the filterbank frames into the plan's padded buffer)
+            ops.copy_strided(f2, f2.shape[1], self.feat, self.feat.stride(0), B * T, f2.shape[1])
+        else:
+            ops.cast(f2.contiguous(), self.feat)
         self.block0.forward()
         for b in self.blocks:
             b.forward()

@@ -19,7 +19,8 @@ import torch
 
 from . import ops
 from .config import W2V2Config, Wav2Vec2RegularisationConfig
-from .ops import (EPI_ADD, EPI_BIAS, EPI_BIAS_GELU, EPI_GELU_BWD, EPI_NONE, EPI_SCALE_RC, Gemm, POOL_MODES,
+from .ops import (EPI_ADD, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_GELU_GRAD, EPI_GELU_BWD, EPI_MUL, EPI_NONE, EPI_SCALE_RC, Gemm,
+                  POOL_MODES,
                   WgradGroup)
 from .params import W2V_PREFIX, ParamStore
 
@@ -86,7 +87,7 @@ class LayerBufs:
     ctx: torch.Tensor
     a: torch.Tensor        # out-proj output, overwritten with s1 = x + drop(a)
     x1: torch.Tensor
-    hpre: torch.Tensor
+    hpre: torch.Tensor     # gelu'(FFN pre-activation), written by the FFN1 epilogue (training plans)
     h: torch.Tensor
     f: torch.Tensor        # FFN output, overwritten with s2
     mean1: torch.Tensor
@@ -113,11 +114,15 @@ class Plan:
         self.Bc = 2 * batch if paired else batch
         assert not (paired and insert_cls_token)
         self.reg = reg if reg is not None else Wav2Vec2RegularisationConfig()
-        if train and self.reg.activation_dropout > 0:
-            raise NotImplementedError("activation_dropout > 0 has no backward here (the reference's default is 0.0, "
-                                      "config/network/wav2vec2_fc.yaml)")
+        # "random" (IndexPool1D, ref: src/layers/pooling.py:125-126,150-154): one frame index per forward call, drawn on
+        # the host with random.randint like the reference.  "none" (NoPooling, :160-166): no pooling, every frame is an
+        # embedding -- the head then sees B * T rows and the label of an utterance repeated for each of its frames
+        # (ref: speaker_recognition_module.py:246-267 _train_step_ce_loss_no_pooling)
+        pooling = pooling.lower() if pooling.lower() == "none" else pooling
         self.pooling, self.pool_mode = pooling, POOL_MODES.get(pooling, -1)
-        assert pooling == "attentive" or pooling in POOL_MODES, pooling
+        assert pooling in ("attentive", "random", "none") or pooling in POOL_MODES, pooling
+        self.no_pool = pooling == "none"
+        self._rand_idx = 0
         self.cls, self.cls_c = insert_cls_token, cls_token_constant
         self.margin, self.scale = aam_margin, aam_scale
         self.seed = seed
@@ -137,6 +142,7 @@ class Plan:
         self._pack_version = -1
         self._cnn_version = -1
         self._asp = {}
+        self.grouped = False
         self._alloc()
         self._build_gemms()
 
@@ -204,12 +210,13 @@ class Plan:
         if not self.fused:
             self.S = torch.zeros(B * heads * T, self.Tl, dtype=f32, device=self.dev)   # scores / dP scratch
         E = self.embed_dim
-        self.emb = self._e(B, E, dtype=f32)
+        self.head_rows = B * T if self.no_pool else B          # rows the head sees
+        self.emb = self._e(self.head_rows, E, dtype=f32)
         st = self.store
         self.head, self.fc = None, None
         if st.head == "bce":
             from .heads import BceHead
-            self.head = BceHead(B, E, w=st.p("linear.weight"), b=st.p("linear.bias"),
+            self.head = BceHead(self.head_rows, E, w=st.p("linear.weight"), b=st.p("linear.bias"),
                                 w_grad=st.g("linear.weight") if self.train else None,
                                 b_grad=st.g("linear.bias") if self.train else None, emb=self.emb, train=self.train,
                                 loss_scale=st.scaler)
@@ -218,11 +225,11 @@ class Plan:
             aam = st.head == "aam"
             nh = len(st.hidden_fc)
             # hidden Linear+ReLU layers between the pooled embedding and the head (ref: wav2vec2_fc.py:185-228)
-            self.fc = FcStack(st, B, E, st.hidden_fc, self.emb, self.train) if nh else None
+            self.fc = FcStack(st, self.head_rows, E, st.hidden_fc, self.emb, self.train) if nh else None
             head_in = self.fc.x[-1] if self.fc is not None else self.emb
             wname = "loss_fn.fc_weights" if aam else f"fc_list.{nh}.0.weight"
             bname = f"fc_list.{nh}.0.bias"
-            self.head = ClassifierHead(st.head, B, st.head_in_dim, st.num_speakers, w_master=st.p(wname),
+            self.head = ClassifierHead(st.head, self.head_rows, st.head_in_dim, st.num_speakers, w_master=st.p(wname),
                                        w_operand=st.w(wname), w_grad=st.g(wname) if self.train else None,
                                        bias=None if aam else st.p(bname),
                                        bias_grad=None if (aam or not self.train) else st.g(bname),
@@ -230,7 +237,7 @@ class Plan:
                                        scale=self.scale, loss_scale=st.scaler)
         if self.train:
             self.demb = (self.head.demb if (self.head is not None and getattr(self, "fc", None) is None)
-                         else self._e(B, E, dtype=f32))
+                         else self._e(self.head_rows, E, dtype=f32))
             self.G = self._ep(M, H)           # running activation gradient
             # Gradient scratch of one layer's backward: Gd = df (after the dropout mask of the FFN residual branch),
             # Gd1 = da (attention residual branch), DH, DQKV.  TWO sets, used by alternating layers: the grouped
@@ -310,9 +317,11 @@ class Plan:
             gl["out"] = Gemm(M, H, H, lb.ctx, mw(pre + "attention.out_proj.weight"), lb.a, lda=H, ldb=H, ldc=H,
                              epilogue=EPI_BIAS, bias=mp(pre + "attention.out_proj.bias"),
                              b_lo=st.w_lo(W2V_PREFIX + pre + "attention.out_proj.weight") if two else None)
+            # training: the epilogue leaves gelu'(pre) in lb.hpre (the f32 pre-activation is in registers there), the
+            # backward product "dh" just multiplies by it (w2v2_hip.h, W2V2_EPI_BIAS_GELU_GRAD / W2V2_EPI_MUL)
             gl["ffn1"] = Gemm(M, I, H, lb.x1, mw(pre + "feed_forward.intermediate_dense.weight"), lb.h, lda=H, ldb=H,
-                              ldc=I, epilogue=EPI_BIAS_GELU, bias=mp(pre + "feed_forward.intermediate_dense.bias"),
-                              aux=lb.hpre, ldaux=I)
+                              ldc=I, epilogue=EPI_BIAS_GELU_GRAD if lb.hpre is not None else EPI_BIAS_GELU,
+                              bias=mp(pre + "feed_forward.intermediate_dense.bias"), aux=lb.hpre, ldaux=I)
             gl["ffn2"] = Gemm(M, H, I, lb.h, mw(pre + "feed_forward.output_dense.weight"), lb.f, lda=I, ldb=I, ldc=H,
                               epilogue=EPI_BIAS, bias=mp(pre + "feed_forward.output_dense.bias"))
             if self.train:
@@ -346,7 +355,7 @@ class Plan:
                 gl["dW2"] = Gemm(H, I, M, gs["Gd"], lb.h, mg(pre + "feed_forward.output_dense.weight"), lda=H, ldb=I,
                                  ldc=I, transA=True, transB=True, split_k=sk(H, I), accumulate=True)
                 gl["dh"] = Gemm(M, I, H, gs["Gd"], W2, gs["DH"], lda=H, ldb=I if tb else H, ldc=I, transB=tb,
-                                epilogue=EPI_GELU_BWD, aux=lb.hpre, ldaux=I)
+                                epilogue=EPI_MUL, aux=lb.hpre, ldaux=I)
                 gl["dW1"] = Gemm(I, H, M, gs["DH"], lb.x1, mg(pre + "feed_forward.intermediate_dense.weight"), lda=I,
                                  ldb=H, ldc=H, transA=True, transB=True, split_k=sk(I, H), accumulate=True)
                 gl["dx1"] = Gemm(M, H, I, gs["DH"], W1, self.G, lda=I, ldb=H if tb else I, ldc=H, transB=tb,
@@ -430,10 +439,11 @@ class Plan:
 
     # ------------------------------------------------------------------------------------------ forward
     def forward(self, wav: torch.Tensor, mask: Optional[torch.Tensor] = None, skip_layers: Sequence[int] = (),
-                step: int = 0) -> torch.Tensor:
+                step: int = 0, feature_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
         """wav [B,N] (or [B,1,N]) f32 on the GPU -> last_hidden_state [B,T,H] (act dtype).
-        mask: [B,T0] uint8/bool SpecAugment time mask (training only).  Dropout is active iff the plan
-        was built with train=True and the regularisation probabilities are > 0."""
+        mask: [B,T0] uint8/bool SpecAugment time mask, feature_mask: [B,H] uint8/bool SpecAugment feature mask
+        (HF:1294-1304; training only).  Dropout is active iff the plan was built with train=True and the
+        regularisation probabilities are > 0."""
         cfg, st, reg = self.cfg, self.store, self.reg
         B, T, M, H = self.B, self.T, self.M, cfg.hidden_size
         if wav.dim() == 3:
@@ -443,7 +453,7 @@ class Plan:
         self._refresh_packs()
         self._wav = wav
         tr = self.train
-        self._step, self._skip, self._mask = step, tuple(skip_layers), None
+        self._step, self._skip, self._mask, self._fmask = step, tuple(skip_layers), None, None
         mp = st.mp
         ops.conv0_groupnorm_gelu(wav, mp("feature_extractor.conv_layers.0.conv.weight"),
                                  mp("feature_extractor.conv_layers.0.layer_norm.weight"),
@@ -471,6 +481,10 @@ class Plan:
         elif mask is not None:
             self._mask = mask.to(torch.uint8).contiguous().view(-1)
             ops.mask_fill(self.h0, self._mask, mp("masked_spec_embed"))
+        if feature_mask is not None:          # after the time mask, like HF's _mask_hidden_states
+            assert not (self.cls or self.paired)
+            self._fmask = feature_mask.to(torch.uint8).contiguous().view(-1)
+            ops.mask_feature(self.h0, self._fmask, B, self.T0)
         G, K = cfg.num_conv_pos_embedding_groups, cfg.num_conv_pos_embeddings
         ops.posconv_regroup(self.hx, self.xg, B, T, H, G, K, K // 2)
         self.g_pos()
@@ -503,20 +517,35 @@ class Plan:
                               lb.rstd1, cfg.layer_norm_eps, ph, self._sd("post_attn", l, step))
             gl["ffn1"]()
             if tr and reg.activation_dropout > 0:
+                # HF:566-569 intermediate_dropout.  The SAME keep decisions (same stream key, same element index) are
+                # applied to the saved gelu'(pre): the backward product "dh" multiplies by it, which is then exactly
+                # d(dropout(gelu(pre))) / d(pre) -- no separate dropout backward, no mask tensor
                 ops.dropout_(lb.h, reg.activation_dropout, self._sd("act", l, step))
+                ops.dropout_(lb.hpre, reg.activation_dropout, self._sd("act", l, step))
             gl["ffn2"]()
             ops.layernorm_fwd(lb.x1, lb.f, mp(pre + "final_layer_norm.weight"), mp(pre + "final_layer_norm.bias"),
                               xout, lb.mean2, lb.rstd2, cfg.layer_norm_eps, ph, self._sd("ffn", l, step))
         self.out = (self.X[cfg.num_hidden_layers] if self.all_x else self.X[cfg.num_hidden_layers % 2]).view(B, T, H)
         return self.out
 
-    def embed(self, wav, mask=None, skip_layers=(), step: int = 0) -> torch.Tensor:
+    def embed(self, wav, mask=None, skip_layers=(), step: int = 0, feature_mask=None) -> torch.Tensor:
         """ref: src/lightning_modules/speaker/wav2vec2_fc.py:414-431 -> pooled embedding [B,E] f32."""
-        out = self.forward(wav, mask, skip_layers, step)
+        out = self.forward(wav, mask, skip_layers, step, feature_mask)
         if self.pooling == "attentive":
             return self._asp_for(out).forward()
-        ops.pool_fwd(out, self.emb, self.pool_mode)
+        self._pool_fwd(out)
         return self.emb
+
+    def _pool_fwd(self, out: torch.Tensor) -> None:
+        B, T, H = out.shape
+        if self.no_pool:
+            ops.pool_fwd(out.view(B * T, 1, H), self.emb, POOL_MODES["first"])      # f32 copy of every frame
+        elif self.pooling == "random":
+            import random
+            self._rand_idx = random.randint(0, T - 1)                             # ref: pooling.py:150-154
+            ops.pool_fwd(out, self.emb, ops.POOL_INDEX_BASE + self._rand_idx)
+        else:
+            ops.pool_fwd(out, self.emb, self.pool_mode)
 
     def hidden_states(self) -> List[torch.Tensor]:
         """HF ``output_hidden_states`` of the last forward: [prologue output, layer 1, ..., layer L], each [B,T,H]."""
@@ -555,6 +584,8 @@ class Plan:
         """Loss head on self.emb (hidden FC layers, then heads.ClassifierHead): returns (loss scalar tensor,
         softmax [B,C]); a training plan also leaves d(loss)/d(pooled embedding) in self.demb and the head gradients
         in the flat buffer."""
+        if self.no_pool:                 # one prediction per frame: the utterance label for each of its T frames
+            label = torch.repeat_interleave(label, self.T)
         if self.fc is not None:
             self.fc.forward()
         out = self.head.forward_backward(label)
@@ -600,6 +631,10 @@ class Plan:
                 demb = self.demb
             if self.pooling == "attentive":   # its parameters share the head's gradient bucket
                 self._asp_cur.backward(demb)
+            elif self.no_pool:
+                ops.pool_bwd(self.out.view(B * T, 1, H), self.emb, demb, self.G.view(B * T, 1, H), POOL_MODES["first"])
+            elif self.pooling == "random":
+                ops.pool_bwd(self.out, self.emb, demb, self.G.view(B, T, H), ops.POOL_INDEX_BASE + self._rand_idx)
             else:
                 ops.pool_bwd(self.out, self.emb, demb, self.G.view(B, T, H), self.pool_mode)
         notify("head")
@@ -649,6 +684,8 @@ class Plan:
             g0 = self.G0
         else:
             g0 = self.G
+            if self._fmask is not None:
+                ops.mask_feature(g0, self._fmask, B, self.T0)
             if self._mask is not None:
                 ops.mask_fill_bwd(g0, self._mask, mg("masked_spec_embed"))
         if reg.feat_proj_dropout > 0:
@@ -685,7 +722,7 @@ class Plan:
         if not grouped:
             gl["dW2"]()
             ops.colsum(gs["Gd"], mg(pre + "feed_forward.output_dense.bias"), M, H)
-        gl["dh"]()                                          # DH = (df @ W2) * gelu'(hpre)
+        gl["dh"]()                                          # DH = (df @ W2) * gelu'(pre)   (lb.hpre holds gelu'(pre))
         if not grouped:
             gl["dW1"]()
             ops.colsum(gs["DH"], mg(pre + "feed_forward.intermediate_dense.bias"), M, cfg.intermediate_size)

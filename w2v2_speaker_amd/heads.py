@@ -42,8 +42,12 @@ class ClassifierHead:
             self.dcos_w = torch.zeros(B, self.ldc, dtype=act_dtype, device=dev)
             self.dcos_x = torch.zeros(B, self.ldc, dtype=act_dtype, device=dev) if aam else self.dcos_w
             self.rowdot = torch.empty(B, dtype=f32, device=dev)
-            self.coldot = torch.empty(Cn, dtype=f32, device=dev)
-            self.G1 = torch.empty(B, E, dtype=f32, device=dev)
+            # the two accumulators of a step (column dots of the AAM normalisation, d(emb) partial sums) share one
+            # buffer so that ONE zero_ranges launch clears both
+            self._zbuf = torch.empty(Cn + B * E, dtype=f32, device=dev)
+            self._ztab = torch.tensor([[0, Cn + B * E]], dtype=torch.int64, device=dev)
+            self.coldot = self._zbuf[:Cn]
+            self.G1 = self._zbuf[Cn:].view(B, E)
             self.demb = torch.empty(B, E, dtype=f32, device=dev)
             # d emb = dcos_w [B, C] . W [C, E]: 66 rows = ONE row of tiles, so the class dimension is cut into S chunks
             # (one batched launch + the ragged rest) whose f32 partials are then summed in a fixed order -- the single
@@ -77,19 +81,19 @@ class ClassifierHead:
             ops.row_invnorm(self.emb, self.inv_x, B, E)
             ops.row_invnorm(self.w_master, self.inv_w, Cn, E)
         self.g_fwd()
-        if tr and aam:
-            self.coldot.zero_()
+        if tr:
+            ops.zero_ranges(self._zbuf, self._ztab, blocks_per_range=16)
         ops.aam_softmax_fwd_bwd(self.logits, label, self.softmax, self.loss_rows,
                                 self.dcos_w if tr else None, (self.dcos_x if aam else None) if tr else None,
                                 self.inv_x if aam else None, self.inv_w if aam else None,
                                 self.rowdot if (tr and aam) else None, self.coldot if (tr and aam) else None,
                                 B, Cn, self.ldc, self.margin if aam else -1.0, self.scale, self.loss_scale if tr else None,
                                 self.correct)
-        loss = self.loss_rows.mean()
+        loss = torch.empty((), dtype=torch.float32, device=self.loss_rows.device)     # (allocator only: no kernel)
+        ops.mean(self.loss_rows, loss)
         if tr:
             for g in self.g_dx:
                 g()
-            self.G1.zero_()
             ops.colsum(self.dx_parts, self.G1.view(-1), self.dx_parts.shape[0], B * E)    # <= 128 rows: one writer
             if aam:
                 ops.normalize_bwd(self.G1, self.emb, self.inv_x, self.rowdot, self.demb, B, E)
@@ -126,7 +130,9 @@ class BceHead:
                              self.dlogit if tr else None, self.demb if tr else None,
                              self.w_grad.view(-1) if tr else None, self.b_grad if tr else None, self.B, self.E,
                              self.loss_scale if tr else None)
-        return self.loss_rows.mean(), self.prob
+        loss = torch.empty((), dtype=torch.float32, device=self.loss_rows.device)
+        ops.mean(self.loss_rows, loss)
+        return loss, self.prob
 
 
 

@@ -144,10 +144,6 @@ class Wav2vec2FCModule:
         if cfg.wav2vec_feature_encoder_only:
             # ref: :118-128 Wav2vecLiteWrapperModule (CNN only) -- not on the hot path
             raise NotImplementedError("wav2vec_feature_encoder_only (Wav2vecLiteWrapperModule) is outside the hot path")
-        if cfg.mask_feature_prob > 0:
-            raise NotImplementedError("feature-axis SpecAugment (reference default mask_feature_prob=0.0)")
-        if cfg.stat_pooling_type.lower() in ("none", "random"):
-            raise NotImplementedError(f"stat_pooling_type={cfg.stat_pooling_type!r} is not on the hot path")
         # ``final_channel_mask_prob`` is accepted and has NO effect, like in the reference: its EmbeddingMasker gates
         # the channel mask on ``timestep_mask_prob``, which Wav2vec2FCModule hard-wires to 0 (quirk Q3,
         # ref: src/layers/embedding_masking.py:79, wav2vec2_fc.py:162-169)
@@ -292,7 +288,10 @@ class Wav2vec2FCModule:
         x = self._prep_input(input_tensor).to(self.device, torch.float32)
         plan = self._plan(x.shape[0], x.shape[1], False)
         plan.embed(x)
-        return plan.speaker_embedding(self.cfg.embedding_layer_idx).clone()
+        emb = plan.speaker_embedding(self.cfg.embedding_layer_idx).clone()
+        if plan.no_pool:               # NoPooling: [B, T, features], like the reference (its fc layers act on the last dim)
+            emb = emb.view(plan.B, plan.T, -1)
+        return emb
 
     def _linear(self, x: torch.Tensor, i: int, relu: bool) -> torch.Tensor:
         W, b = self.store.p(f"fc_list.{i}.0.weight"), self.store.p(f"fc_list.{i}.0.bias")
@@ -306,11 +305,17 @@ class Wav2vec2FCModule:
         x = embedding_tensor.to(self.device)
         if x.dim() == 1:
             x = x[None]
+        lead = None
+        if x.dim() == 3:               # NoPooling: nn.Linear acts on the last dimension
+            lead = x.shape[:2]
+            x = x.reshape(-1, x.shape[-1])
         nh = len(self.cfg.hidden_fc_layers_out)
         for i in range(self.cfg.embedding_layer_idx + 1, nh):
             x = self._linear(x, i, relu=True)
         if self.loss == "ce" and self.cfg.embedding_layer_idx < nh:
             x = self._linear(x, nh, relu=False)
+        if lead is not None:
+            x = x.view(*lead, -1)
         return x.squeeze()
 
     def forward(self, input_tensor: torch.Tensor):
@@ -445,7 +450,8 @@ class Wav2vec2FCModule:
             module.steps = int(fs.get("steps", module.schedule_step))
             module._is_wav2vec_frozen = bool(fs.get("is_wav2vec_frozen", False))
             if module.store.scaler is not None and fs.get("loss_scaler") is not None:
-                module.store.scaler.copy_(torch.as_tensor(fs["loss_scaler"]).to(module.store.device))
+                rec = torch.as_tensor(fs["loss_scaler"]).to(module.store.device, torch.float32).reshape(-1)
+                module.store.scaler[:min(rec.numel(), module.store.scaler.numel())] = rec[:module.store.scaler.numel()]
             for ost in ckpt.get("optimizer_states") or []:
                 try:
                     if "param_groups" in ost:             # torch.optim.Adam.state_dict() (reference parameter order)

@@ -5,7 +5,7 @@ from __future__ import annotations
 
 import dataclasses
 from dataclasses import dataclass
-from typing import Dict, List, Optional, Tuple
+from typing import Callable, Dict, List, Optional, Tuple
 
 import torch
 
@@ -52,11 +52,24 @@ class PairedSpeakerClassificationDataBatch:
 
 
 class Wav2vec2PairedSpeakerModule:
-    def __init__(self, cfg: Wav2vec2PairedSpeakerModuleConfig, *, device="cuda",
-                 act_dtype: torch.dtype = torch.bfloat16, max_lr: float = 5e-5, max_steps: int = 100_000,
+    def __init__(self, hyperparameters_to_save, cfg: Wav2vec2PairedSpeakerModuleConfig,
+                 loss_fn_constructor: Optional[Callable[[], object]] = None, *, device="cuda",
+                 act_dtype: torch.dtype = torch.float16, max_lr: float = 5e-5, max_steps: int = 100_000,
                  process_group=None, init_seed: int = 20211):
+        """Positional arguments = ref: wav2vec2_paired_input.py:65-71.  ``loss_fn_constructor`` must build the
+        reference's ``BinaryCrossEntropyLoss`` (src/optim/loss/binary_cross_entropy.py; the only loss this module is
+        configured with, config/optim/loss/binary_cross_entropy.yaml) -- it is called once and checked; the arithmetic
+        runs in w2v2_bce_head_fwd_bwd.  Default precision: fp16 operands under the dynamic loss scale, like
+        Wav2vec2FCModule (the reference's ``precision: 16``)."""
         if cfg.wav2vec_initially_frozen or cfg.completely_freeze_feature_projector:
             raise NotImplementedError("initially-frozen network / frozen projector for the paired module")
+        if loss_fn_constructor is not None:
+            from ...optim.loss import BinaryCrossEntropyLoss
+            loss_fn = loss_fn_constructor()
+            if not isinstance(loss_fn, BinaryCrossEntropyLoss):
+                raise NotImplementedError(f"loss {type(loss_fn).__name__}: the paired module trains with "
+                                          "BinaryCrossEntropyLoss")
+        self.hyperparameters_to_save = hyperparameters_to_save
         self.cfg = cfg
         self.model_cfg = W2V2Config.from_huggingface_id(cfg.wav2vec_hunggingface_id)
         self.reg = Wav2Vec2RegularisationConfig(

@@ -12,11 +12,12 @@ from typing import Optional, Tuple
 import torch
 
 from . import _lib
-from ._lib import (BF16, EPI_ADD, EPI_BIAS, EPI_BIAS_GELU, EPI_GELU_BWD, EPI_NONE, EPI_SCALE_RC, F16, F32,
+from ._lib import (BF16, EPI_ADD, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_GELU_GRAD, EPI_GELU_BWD, EPI_MUL, EPI_NONE, EPI_SCALE_RC, F16, F32,
                    GemmDesc)
 
 POOL_MODES = {"mean+std": 0, "mean": 1, "max": 2, "first": 3, "first+cls": 3, "last": 4, "middle": 4, "quantile": 5}
 POOL_WIDTH = {0: 2, 5: 5}      # output features per input feature (default 1)
+POOL_INDEX_BASE = 16           # mode POOL_INDEX_BASE + t selects frame t (IndexPool1D "random")
 
 
 def lib():
@@ -115,9 +116,10 @@ class Gemm:
         fast = (lp and not transA and not transB and K % 64 == 0 and K >= 64 and lda % 8 == 0 and ldb % 8 == 0)
         if fast and split_k <= 1 and not accumulate and (b_lo is not None or (N >= 512 and M >= 1024)):
             self.kernel_name = "gemm_bf16_glds3_kernel"
-            t4 = -(-M // 256) * -(-N // 256)          # 256x256 tiling fills >= 85 % of the last round of 256 CUs
-            if (b_lo is None and N >= 512 and batch == 1 and t4 >= 256 and t4 / (-(-t4 // 256) * 256) >= 0.85 and N / (-(-N // 256) * 256) >= 0.9
-                    and not os.environ.get("W2V2_NO_GLDS4")):
+            t4, t3 = -(-M // 256) * -(-N // 256), -(-M // 256) * -(-N // 128)      # csrc/gemm.hip: 256x256 vs 256x128 tiles
+            fill = lambda t: t / (-(-t // 256) * 256)
+            if (b_lo is None and N >= 512 and batch == 1 and t4 * 2 >= 256 and fill(t4) * 1.25 >= fill(t3)
+                    and N / (-(-N // 256) * 256) >= 0.9 and not os.environ.get("W2V2_NO_GLDS4")):
                 self.kernel_name = "gemm_bf16_glds4_kernel" if os.environ.get("W2V2_NO_GEMM_PH") else "gemm_ph_kernel"
         elif fast:
             self.kernel_name = "gemm_bf16_glds_kernel"
@@ -356,6 +358,20 @@ def colsum(x: torch.Tensor, out: torch.Tensor, M: int, N: int, ld: Optional[int]
                "colsum")
 
 
+def zero_ranges(base: torch.Tensor, table: torch.Tensor, blocks_per_range: int = 8) -> None:
+    """base[off : off + n] = 0 for every (off, n) row of the int64 device table (f32 arena)."""
+    _dev(base, table)
+    assert base.dtype == torch.float32 and table.dtype == torch.int64
+    _lib.check(lib().w2v2_zero_ranges(base.data_ptr(), table.data_ptr(), table.shape[0], blocks_per_range, stream()),
+               "zero_ranges")
+
+
+def mean(x: torch.Tensor, out: torch.Tensor) -> None:
+    _dev(x, out)
+    assert x.dtype == torch.float32 and out.dtype == torch.float32
+    _lib.check(lib().w2v2_mean(x.data_ptr(), out.data_ptr(), x.numel(), stream()), "mean")
+
+
 def cast(x: torch.Tensor, y: torch.Tensor) -> None:
     _dev(x, y)
     _lib.check(lib().w2v2_cast(x.data_ptr(), y.data_ptr(), x.numel(), dt(y), stream()), "cast")
@@ -372,6 +388,14 @@ def mask_fill(h, mask_u8, embed) -> None:
     H = h.shape[-1]
     _lib.check(lib().w2v2_mask_fill(h.data_ptr(), mask_u8.data_ptr(), embed.data_ptr(), h.numel() // H, H, dt(h),
                                     stream()), "mask_fill")
+
+
+def mask_feature(h, mask_u8, B: int, T: int) -> None:
+    """h [B*T, H] (or [B, T, H]): channels c with mask_u8[b][c] != 0 are zeroed for every frame of utterance b."""
+    _dev(h, mask_u8)
+    H = h.shape[-1]
+    assert mask_u8.dtype == torch.uint8 and mask_u8.numel() == B * H
+    _lib.check(lib().w2v2_mask_feature(h.data_ptr(), mask_u8.data_ptr(), B, T, H, dt(h), stream()), "mask_feature")
 
 
 def mask_fill_bwd(dh, mask_u8, d_embed) -> None:
@@ -485,14 +509,16 @@ def normalize_bwd(g, x, inv, dot, dx, rows: int, cols: int, ldx: Optional[int] =
 
 # ------------------------------------------------------------------------------------------------ optimiser
 def adam_step(p, g, m, v, pb, n: int, lr: float, beta1: float, beta2: float, eps: float, step: int,
-              grad_scale: float = 1.0, scaler=None) -> None:
-    """scaler: the 4-float device record of the dynamic loss scale (see grad_scaler_*), or None."""
+              grad_scale: float = 1.0, scaler=None, skip_slot: int = 0) -> None:
+    """scaler: the device record of the dynamic loss scale (see grad_scaler_*), or None.  skip_slot (4 = head range,
+    5 = body range of an 8-float record): the kernel takes the bias corrections at step - scaler[skip_slot], i.e. the
+    number of optimiser steps that were NOT skipped for an overflow (torch GradScaler semantics)."""
     _dev(p, g, m, v, pb, scaler)
     bc1 = 1.0 - beta1 ** step
     bc2 = 1.0 - beta2 ** step
     _lib.check(lib().w2v2_adam_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), _p(pb),
                                     dt(pb) if pb is not None else BF16, n, lr, beta1, beta2, eps, bc1, bc2, grad_scale,
-                                    _p(scaler), stream()), "adam_step")
+                                    _p(scaler), step, skip_slot, stream()), "adam_step")
 
 
 def weight_residual(p, lo, table) -> None:
@@ -508,10 +534,13 @@ def grad_scaler_check(g, n: int, state) -> None:
     _lib.check(lib().w2v2_grad_scaler_check(g.data_ptr(), n, state.data_ptr(), stream()), "grad_scaler_check")
 
 
-def grad_scaler_update(state, growth: float = 2.0, backoff: float = 0.5, growth_interval: int = 2000) -> None:
-    """torch GradScaler.update() on the device record {scale, found_inf, growth_tracker, skipped_steps}."""
+def grad_scaler_update(state, growth: float = 2.0, backoff: float = 0.5, growth_interval: int = 2000,
+                       skipped_ranges: int = 0) -> None:
+    """torch GradScaler.update() on the device record {scale, found_inf, growth_tracker, skipped_steps [, skipped_head,
+    skipped_body, -, -]}; skipped_ranges bit 0 / 1: this step covered the head / body range (8-float records)."""
     _dev(state)
-    _lib.check(lib().w2v2_grad_scaler_update(state.data_ptr(), growth, backoff, growth_interval, stream()),
+    assert skipped_ranges == 0 or state.numel() >= 8
+    _lib.check(lib().w2v2_grad_scaler_update(state.data_ptr(), growth, backoff, growth_interval, skipped_ranges, stream()),
                "grad_scaler_update")
 
 
@@ -610,9 +639,14 @@ def col2im_reflect(dcol, dx, lddx: int, B: int, T: int, Cin: int, k: int, dilati
 
 
 def add_strided(a, lda: int, b, ldb: int, y, ldy: int, M: int, C: int) -> None:
+    """y = a + b over row-strided [M, C] views; b None: y = a (strided copy)."""
     _dev(a, b, y)
-    _lib.check(lib().w2v2_add_strided(a.data_ptr(), lda, b.data_ptr(), ldb, y.data_ptr(), ldy, M, C, dt(a), stream()),
+    _lib.check(lib().w2v2_add_strided(a.data_ptr(), lda, _p(b), ldb, y.data_ptr(), ldy, M, C, dt(a), stream()),
                "add_strided")
+
+
+def copy_strided(a, lda: int, y, ldy: int, M: int, C: int) -> None:
+    add_strided(a, lda, None, 0, y, ldy, M, C)
 
 
 def se_scale(x, g, y, B: int, T: int, C: int) -> None:

@@ -15,7 +15,7 @@ from __future__ import annotations
 import math
 import os
 from collections import OrderedDict
-from typing import Dict, List, Optional, Tuple
+from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
@@ -155,7 +155,9 @@ class ParamStore:
             self._lo_table = torch.tensor(rng, dtype=torch.int64, device=dev)
         # fp16 activations: dynamic loss scale, device record {scale, found_inf, growth_tracker, skipped_steps}
         # (torch GradScaler semantics -- the reference trains under PL precision 16; csrc/optim.hip)
-        self.scaler = (torch.tensor([init_loss_scale, 0.0, 0.0, 0.0], dtype=torch.float32, device=dev)
+        # {scale, found_inf, growth_tracker, skipped_steps, skipped optimiser steps of the head range, ... of the body
+        # range, -, -}: the last two feed Adam's bias correction (torch: a skipped step does not advance Adam's count)
+        self.scaler = (torch.tensor([init_loss_scale, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0], dtype=torch.float32, device=dev)
                        if act_dtype == torch.float16 else None)
         # pre-transposed bf16 copies of the 2-D weights whose data-gradient product dX = dY W is on the
         # training path (refreshed by one batched-transpose launch after every optimiser step)
@@ -377,6 +379,8 @@ class ParamStore:
         order = self.reference_parameter_order()
         state = {}
         h = self.head_size()
+        skipped = [int(x) for x in self.scaler[4:6].tolist()] if self.scaler is not None else [0, 0]
+        step_head, step_body = self.step_head - skipped[0], self.step_body - skipped[1]     # torch's counts
         for i, n in enumerate(order):
             off = self.offsets[n]
             if self.exp_avg is None or off >= self.n_train:
@@ -384,8 +388,8 @@ class ParamStore:
             cnt = 1
             for d in self.shapes[n]:
                 cnt *= d
-            step = self.step_head if off < h else self.step_body
-            if step == 0:
+            step = step_head if off < h else step_body
+            if step <= 0:
                 continue
             state[i] = {"step": step, "exp_avg": self.exp_avg[off:off + cnt].view(self.shapes[n]).detach().clone().cpu(),
                         "exp_avg_sq": self.exp_avg_sq[off:off + cnt].view(self.shapes[n]).detach().clone().cpu()}
@@ -418,6 +422,8 @@ class ParamStore:
                 sb = max(sb, int(st["step"]))
         self.step_head, self.step_body = sh, sb
         self.step_count = max(sh, sb)
+        if self.scaler is not None:
+            self.scaler[4:6] = 0.0            # the loaded counts are torch's (skipped steps already excluded)
 
     # ------------------------------------------------------------------ optimiser / schedule state (resume)
     def optimizer_state(self) -> Dict[str, object]:
@@ -436,7 +442,8 @@ class ParamStore:
         self.step_head, self.step_body = int(st.get("step_head", 0)), int(st.get("step_body", 0))
         self.step_count = max(self.step_head, self.step_body)
         if self.scaler is not None and st.get("loss_scaler") is not None:
-            self.scaler.copy_(torch.as_tensor(st["loss_scaler"]).to(self.device))
+            rec = torch.as_tensor(st["loss_scaler"]).to(self.device, torch.float32).reshape(-1)
+            self.scaler[:min(rec.numel(), self.scaler.numel())] = rec[:self.scaler.numel()]     # (4-float records of round 2)
 
     def init_weights(self, seed: int = 20211) -> None:
         """Random initialisation in the spirit of HF ``_init_weights`` (HF:1100-1140) and
@@ -477,8 +484,50 @@ class ParamStore:
         self.cnn_version += 1
 
     # ------------------------------------------------------------------ optimiser
-    def zero_grad(self) -> None:
-        self.grad.zero_()
+    def zero_grad(self, skip_layers: Optional[Sequence[int]] = None) -> None:
+        """``optimizer.zero_grad()`` of the step.  Without arguments: the whole gradient arena (400 MB on w2v2-base).
+        With this step's LayerDrop decisions (``skip_layers``, possibly empty) and the grouped weight-gradient path
+        (16-bit modes): only what the backward ACCUMULATES into -- LayerNorm gamma / beta, pos-conv bias and weight-norm
+        pair, masked_spec_embed, the head's small tensors -- plus the whole slice of every skipped layer.  The Linear
+        weights / biases of the encoder and the projection (99 % of the arena) are WRITTEN by w2v2_wgrad_grouped, the
+        AAM weight by the head's normalisation backward, so zeroing them first is wasted HBM traffic."""
+        if skip_layers is None or self.flat_lp_t is None or not self.freeze_cnn:
+            self.grad.zero_()
+            return
+        if getattr(self, "_zero_tables", None) is None:
+            self._zero_tables = self._build_zero_tables()
+        small, per_layer = self._zero_tables
+        if small.shape[0]:
+            ops.zero_ranges(self.grad, small, blocks_per_range=4)
+        for l in skip_layers:
+            ops.zero_ranges(self.grad, per_layer[l], blocks_per_range=512)
+
+    def _build_zero_tables(self):
+        """(table of the accumulated tensors' (offset, count) ranges, one single-row table per transformer layer)."""
+        P, H = W2V_PREFIX, self.cfg.hidden_size
+        written = set()
+        for l in range(self.cfg.num_hidden_layers):
+            pre = P + f"encoder.layers.{l}."
+            for m in ("attention.q_proj", "attention.k_proj", "attention.v_proj", "attention.out_proj",
+                      "feed_forward.intermediate_dense", "feed_forward.output_dense"):
+                written |= {pre + m + ".weight", pre + m + ".bias"}
+        written |= {P + "feature_projection.projection.weight", P + "feature_projection.projection.bias"}
+        if self.head == "aam":
+            written.add("loss_fn.fc_weights")
+        rng = []
+        for n, off in sorted(self.offsets.items(), key=lambda kv: kv[1]):
+            if off >= self.n_train or n in written:
+                continue
+            cnt = int(np.prod(self.shapes[n]))
+            if rng and rng[-1][0] + rng[-1][1] == off:
+                rng[-1][1] += cnt
+            else:
+                rng.append([off, cnt])
+        small = torch.tensor(rng, dtype=torch.int64, device=self.device).reshape(-1, 2)
+        buckets = {n: (s, e) for n, s, e in self.grad_buckets()}
+        per_layer = [torch.tensor([[buckets[f"layer{l}"][0], buckets[f"layer{l}"][1] - buckets[f"layer{l}"][0]]],
+                                  dtype=torch.int64, device=self.device) for l in range(self.cfg.num_hidden_layers)]
+        return small, per_layer
 
     def head_size(self) -> int:
         """Number of leading arena elements that belong to the classification head."""
@@ -515,16 +564,17 @@ class ParamStore:
             else:
                 lo = self.offsets[W2V_PREFIX + "encoder.layer_norm.weight"]
                 ops.grad_scaler_check(self.grad[lo:], n_train - lo, sc)
+        sh, sb = (4, 5) if sc is not None else (0, 0)         # record slots of the skipped-step counts (head / body)
         if head_only:
-            ops.adam_step(*a, lp, h, lr, beta1, beta2, eps, self.step_head, grad_scale, sc)
+            ops.adam_step(*a, lp, h, lr, beta1, beta2, eps, self.step_head, grad_scale, sc, sh)
         elif self.step_head == self.step_body or h == 0:
-            ops.adam_step(*a, lp, n_train, lr, beta1, beta2, eps, self.step_body, grad_scale, sc)
+            ops.adam_step(*a, lp, n_train, lr, beta1, beta2, eps, self.step_body, grad_scale, sc, sb)
         else:
-            ops.adam_step(*a, lp, h, lr, beta1, beta2, eps, self.step_head, grad_scale, sc)
+            ops.adam_step(*a, lp, h, lr, beta1, beta2, eps, self.step_head, grad_scale, sc, sh)
             ops.adam_step(*(t[h:] for t in a), lp[h:] if lp is not None else None, n_train - h, lr, beta1,
-                          beta2, eps, self.step_body, grad_scale, sc)
+                          beta2, eps, self.step_body, grad_scale, sc, sb)
         if sc is not None:
-            ops.grad_scaler_update(sc)
+            ops.grad_scaler_update(sc, skipped_ranges=1 if head_only else 3)
         self.sync_transposed()
         self.version += 1
         if not self.freeze_cnn:

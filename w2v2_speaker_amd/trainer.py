@@ -106,6 +106,15 @@ class SpeakerTrainer:
                                  plan.cfg.mask_time_min_masks, rng=self._mask_rng)
         return torch.from_numpy(m.astype(np.uint8)).to(plan.dev, non_blocking=True)
 
+    def sample_feature_mask(self) -> Optional[torch.Tensor]:
+        """HF:1294-1304: [B, hidden_size] mask of feature channels, drawn AFTER the time mask from the same stream."""
+        reg, plan = self.plan.reg, self.plan
+        if reg.mask_feature_prob <= 0 or plan.cls or plan.paired:
+            return None
+        m = compute_mask_indices((plan.B, plan.cfg.hidden_size), reg.mask_feature_prob, reg.mask_feature_length,
+                                 getattr(plan.cfg, "mask_feature_min_masks", 0), rng=self._mask_rng)
+        return torch.from_numpy(m.astype(np.uint8)).to(plan.dev, non_blocking=True)
+
     def train_step_frozen_encoder(self, frozen_plan: Plan, wav: torch.Tensor, label: torch.Tensor):
         """Step while the whole wav2vec2 network is frozen (ref: wav2vec2_fc.py:339-347 + PL ``freeze()`` =
         requires_grad False AND eval mode): eval-mode forward, head forward/backward, Adam on the head only."""
@@ -121,7 +130,7 @@ class SpeakerTrainer:
         return loss, softmax
 
     def train_step(self, wav: torch.Tensor, label: torch.Tensor, mask: Optional[torch.Tensor] = None,
-                   skip_layers: Optional[Sequence[int]] = None):
+                   skip_layers: Optional[Sequence[int]] = None, feature_mask: Optional[torch.Tensor] = None):
         """ref: speaker_recognition_module.py:207-220 (_train_step_ce_loss) + PL backward/optimizer step.
         Returns (loss, softmax) as device tensors; no host sync."""
         plan, store = self.plan, self.store
@@ -129,8 +138,10 @@ class SpeakerTrainer:
             skip_layers = self.sample_layerdrop()
         if mask is None:
             mask = self.sample_time_mask()
-        store.zero_grad()
-        plan.embed(wav, mask, skip_layers, self.step)
+        if feature_mask is None:
+            feature_mask = self.sample_feature_mask()
+        store.zero_grad(tuple(skip_layers) if plan.grouped else None)
+        plan.embed(wav, mask, skip_layers, self.step, feature_mask)
         loss, softmax = plan.head_forward_backward(label)
         plan.backward(on_bucket_ready=self.reducer.bucket_ready)
         self.reducer.wait()
