@@ -426,6 +426,22 @@ int w2v2_grad_scaler_check(const float* g, int64_t n, float* state, void* stream
 int w2v2_grad_scaler_update(float* state, float growth, float backoff, int growth_interval, int skipped_ranges,
                             void* stream);
 
+/* ------------------------------------------------------------------------------------ collective
+ * ref: config/trainer/trainer.yaml:6-12 (PL `accelerator: ddp`, one process per GPU): the SUM all-reduce of the gradient
+ * buckets is the only collective of a data-parallel step.  The repo's default binding issues it through
+ * torch.distributed ("nccl" == RCCL); these three calls run the same collective through the C ABI alone, on RCCL over
+ * xGMI (librccl.so resolved with dlopen at the first call -- no link-time dependency; W2V2_RCCL_LIB overrides the path).
+ *   rank 0: w2v2_comm_unique_id(id) -> ship the 128 bytes to every rank out of band (file, socket, launcher env)
+ *   every rank: w2v2_comm_init(&c, id, rank, world, device)             (collective: all ranks must call it)
+ *   per bucket: w2v2_allreduce_async(c, grad + off, n, comm_stream)     (in place, f32, enqueued on the given stream;
+ *               order the stream against the backward with events, like trainer.BucketAllReducer does)
+ *   w2v2_comm_destroy(c) */
+typedef struct w2v2_comm w2v2_comm;
+int w2v2_comm_unique_id(void* id_host_128);
+int w2v2_comm_init(w2v2_comm** comm, const void* id_host_128, int rank, int world, int device);
+int w2v2_allreduce_async(w2v2_comm* comm, float* buf, int64_t n, void* stream);
+int w2v2_comm_destroy(w2v2_comm* comm);
+
 #ifdef __cplusplus
 }
 #endif

@@ -144,3 +144,38 @@ def test_two_rank_fp16_step_with_overflow_on_one_rank_skips_on_both():
     assert rec0 == rec1, (rec0, rec1)                          # identical scale / skip history on both ranks
     assert rec0[1] == (1024.0, 0) and rec0[2] == (512.0, 1) and rec0[4] == (512.0, 1), rec0
     assert sk0 != sk1, "the ranks were meant to draw different LayerDrop patterns"
+
+
+def test_c_abi_collective_entry_points_on_rccl():
+    """include/w2v2_hip.h "collective": w2v2_comm_unique_id / w2v2_comm_init / w2v2_allreduce_async / w2v2_comm_destroy
+    resolve librccl.so at run time and run a real RCCL communicator.  The test box has ONE GPU (RCCL refuses two ranks
+    per device), so this is the world-size-1 communicator: the all-reduce must leave the buffer unchanged, on a side
+    stream, and the reducer built on it must drive a training step exactly like no reducer at all."""
+    from w2v2_speaker_amd.comm import CAbiBucketAllReducer, RcclComm
+    from w2v2_speaker_amd.trainer import SpeakerTrainer
+    uid = RcclComm.unique_id()
+    assert len(uid) == 128 and any(uid)
+    comm = RcclComm(0, 1, 0, uid)
+    x = torch.randn(1 << 20, device="cuda")
+    ref = x.clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    comm.all_reduce_(x, side)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    assert torch.equal(x, ref)
+    dev = torch.device("cuda", 0)
+    outs = []
+    for use in (False, True):
+        st, plan, sched, wav, label = _setup(dev, 4)
+        red = CAbiBucketAllReducer(st, comm) if use else None
+        tr = SpeakerTrainer(st, plan, sched, reducer=red)
+        if use:
+            red.world = 2                 # exercise the issue / wait path (a 1-rank SUM is the identity) ...
+            tr.world = 1                  # ... without the 1/world gradient scaling
+        for _ in range(2):
+            tr.train_step(wav, label)
+        torch.cuda.synchronize()
+        outs.append(st.flat[:st.n_train].clone())
+    assert torch.equal(outs[0], outs[1])
+    comm.destroy()

@@ -62,6 +62,21 @@ def test_tiny_eval_pools_and_cls():
     assert rel_l2(h, g["eval.cls.last_hidden"]) < 2e-5
 
 
+def test_base_second_golden_other_seed_batch8_5s():
+    """tests/golden/g10_base2.npz (reference run with other weights, B = 8, 5 s clips): pins the oracle at a second
+    operating point (T = 249)."""
+    g = load("g10_base2.npz")
+    cfg = O.OracleConfig.base()
+    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    sd = O.make_state_dict(cfg, 777)
+    wav, _ = O.synth_batch(8, 80000, 5994, seed=31337)
+    with torch.no_grad():
+        h = O.wav2vec2_forward(wav[:, 0], sd, cfg)
+        assert h.shape[1] == 249
+        assert rel_l2(h[:, ::16, ::16], g["eval.last_hidden.sample"]) < 1e-4
+        assert rel_l2(O.mean_std_pool(h), g["eval.mean+std"]) < 1e-4
+
+
 @pytest.mark.skipif(not os.path.exists(os.path.join(GOLDEN, "g2_base.npz")), reason="no base golden")
 def test_base_config_embeddings_and_grad_norms():
     g = load("g2_base.npz")

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libw2v2hip.so")
 SOURCES = ["api.hip", "gemm.hip", "wgrad.hip", "norm.hip", "elementwise.hip", "conv0.hip", "posconv.hip", "posconv_wgrad.hip",
-           "softmax.hip", "attention.hip", "pool.hip", "asp.hip", "tdnn.hip", "skinny.hip", "heads.hip", "optim.hip"]
+           "softmax.hip", "attention.hip", "pool.hip", "asp.hip", "tdnn.hip", "skinny.hip", "heads.hip", "optim.hip", "comm.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
 
 
@@ -47,6 +47,8 @@ def build_locked(force: bool = False, verbose: bool = False) -> str:
 def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
         return LIB
+    import time
+    t_start = time.time()
     hipcc = _hipcc()
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
@@ -59,20 +61,25 @@ def build(force: bool = False, verbose: bool = False) -> str:
                 and os.path.getmtime(obj) > max(os.path.getmtime(p) for p in [srcp] + hdrs)):
             return obj
         cmd = [hipcc] + FLAGS + ["-c", srcp, "-o", obj]
+        t_obj = time.time()
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{r.stderr[-4000:]}")
+        os.utime(obj, (t_obj, t_obj))
         if verbose:
             print("compiled", src)
         return obj
 
     with ThreadPoolExecutor(max_workers=min(6, os.cpu_count() or 1)) as ex:
         objs = list(ex.map(compile_one, SOURCES))
+    # the library's timestamp must not run ahead of a source that was edited WHILE the objects were compiling (a later
+    # needs_build() would then skip the rebuild): it gets the time at which this build STARTED reading the sources
     tmp = LIB + f".tmp{os.getpid()}"
-    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs,
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs + ["-ldl"],
                        capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stderr[-4000:]}")
+    os.utime(tmp, (t_start, t_start))
     os.replace(tmp, LIB)
     return LIB
 

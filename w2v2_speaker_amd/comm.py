@@ -1,0 +1,95 @@
+"""Gradient all-reduce through the C ABI alone (include/w2v2_hip.h "collective": w2v2_comm_* over librccl.so).
+
+ref: config/trainer/trainer.yaml:6-12 (PL ``accelerator: ddp``).  ``trainer.BucketAllReducer`` (torch.distributed "nccl"
+== RCCL) stays the default binding; ``CAbiBucketAllReducer`` is the same schedule -- contiguous gradient buckets,
+reduced on a side HIP stream as soon as backward finalises them -- for a host that has no torch.distributed process
+group: the 128-byte RCCL id travels through a ``torch.distributed.TCPStore`` (a plain key-value socket, no process
+group), a file, or whatever the launcher provides."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+from . import _lib
+
+
+class RcclComm:
+    """One RCCL communicator owned through the C ABI."""
+
+    def __init__(self, rank: int, world: int, device: int, unique_id: bytes):
+        assert len(unique_id) == 128
+        self.rank, self.world, self.device = rank, world, device
+        self._h = C.c_void_p()
+        buf = C.create_string_buffer(unique_id, 128)
+        _lib.check(_lib.load().w2v2_comm_init(C.byref(self._h), buf, rank, world, device), "comm_init")
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = C.create_string_buffer(128)
+        _lib.check(_lib.load().w2v2_comm_unique_id(buf), "comm_unique_id")
+        return buf.raw
+
+    @classmethod
+    def from_store(cls, rank: int, world: int, device: int, host: str = "127.0.0.1", port: int = 29555,
+                   timeout_s: float = 300.0) -> "RcclComm":
+        """Rendezvous over a TCPStore on (host, port): rank 0 creates the id, the others read it."""
+        from datetime import timedelta
+        from torch.distributed import TCPStore
+        store = TCPStore(host, port, world, is_master=(rank == 0), timeout=timedelta(seconds=timeout_s))
+        if rank == 0:
+            uid = cls.unique_id()
+            store.set("w2v2_rccl_id", uid)
+        else:
+            uid = bytes(store.get("w2v2_rccl_id"))
+        comm = cls(rank, world, device, uid)
+        comm._store = store            # keep the server alive until every rank has initialised
+        return comm
+
+    def all_reduce_(self, t: torch.Tensor, stream: Optional[torch.cuda.Stream] = None) -> None:
+        """SUM all-reduce of a contiguous f32 CUDA tensor, in place, enqueued on ``stream`` (default: current)."""
+        assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
+        s = (stream or torch.cuda.current_stream()).cuda_stream
+        _lib.check(_lib.load().w2v2_allreduce_async(self._h, t.data_ptr(), t.numel(), s), "allreduce_async")
+
+    def destroy(self) -> None:
+        if self._h:
+            _lib.check(_lib.load().w2v2_comm_destroy(self._h), "comm_destroy")
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+class CAbiBucketAllReducer:
+    """Drop-in for trainer.BucketAllReducer (same ``bucket_ready`` / ``wait`` / ``world`` / ``ranges`` / ``members``)
+    whose collective is w2v2_allreduce_async on a side HIP stream."""
+
+    def __init__(self, store, comm: RcclComm, bucket_merge: int = 2):
+        from .trainer import BucketAllReducer
+        self.comm, self.store, self.world = comm, store, comm.world
+        self.ranges, self.members = BucketAllReducer.merge_buckets(store.grad_buckets(), bucket_merge)
+        self.comm_stream = torch.cuda.Stream()
+        self._issued = False
+
+    def bucket_ready(self, name: str) -> None:
+        if self.world == 1 or name not in self.ranges:
+            return
+        s, e = self.ranges[name]
+        if e <= s:
+            return
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        self.comm_stream.wait_event(ev)
+        self.comm.all_reduce_(self.store.grad[s:e], self.comm_stream)
+        self._issued = True
+
+    def wait(self) -> None:
+        if self._issued:
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
+            self._issued = False

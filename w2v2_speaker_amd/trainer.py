@@ -32,12 +32,16 @@ class BucketAllReducer:
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.store = store
-        raw = store.grad_buckets()
-        # merge neighbouring layer buckets so each collective carries >= ~2 layers (xGMI rings are
-        # per-link bound: fewer, larger messages; SURVEY 5 "Distributed comm backend")
-        self.ranges = {}
-        self.members = {}          # firing bucket name -> raw buckets its collective covers (final when IT is final)
-        merged: List[Tuple[str, int, int]] = []
+        self.ranges, self.members = self.merge_buckets(store.grad_buckets(), bucket_merge)
+        self.comm_stream = torch.cuda.Stream() if store.device.type == "cuda" else None
+        self.works = []
+
+    @staticmethod
+    def merge_buckets(raw: List[Tuple[str, int, int]], bucket_merge: int):
+        """Merge neighbouring layer buckets so each collective carries >= ~2 layers (xGMI rings are per-link bound:
+        fewer, larger messages; SURVEY 5 "Distributed comm backend").  Returns (ranges: firing bucket -> (start, end),
+        members: firing bucket -> raw buckets its collective covers; it fires when the LAST member is final)."""
+        ranges, members = {}, {}
         i = 0
         while i < len(raw):
             n, s, e = raw[i]
@@ -46,13 +50,10 @@ class BucketAllReducer:
                 while j + 1 < len(raw) and raw[j + 1][0].startswith("layer") and (j - i + 1) < bucket_merge:
                     j += 1
                 e = raw[j][2]
-            merged.append((raw[j][0], s, e))      # fires when the LAST member is final
-            self.members[raw[j][0]] = [raw[k][0] for k in range(i, j + 1)]
+            ranges[raw[j][0]] = (s, e)
+            members[raw[j][0]] = [raw[k][0] for k in range(i, j + 1)]
             i = j + 1
-        for n, s, e in merged:
-            self.ranges[n] = (s, e)
-        self.comm_stream = torch.cuda.Stream() if store.device.type == "cuda" else None
-        self.works = []
+        return ranges, members
 
     def bucket_ready(self, name: str) -> None:
         if self.world == 1 or name not in self.ranges:
@@ -80,12 +81,14 @@ class BucketAllReducer:
 
 class SpeakerTrainer:
     def __init__(self, store: ParamStore, plan: Plan, schedule, process_group=None, beta2: float = 0.999,
-                 eps: float = 1e-8, layerdrop_seed: int = 1234, mask_seed: int = 7):
+                 eps: float = 1e-8, layerdrop_seed: int = 1234, mask_seed: int = 7, reducer=None):
+        """reducer: an object with bucket_ready(name) / wait() / world (default: BucketAllReducer over
+        torch.distributed; comm.CAbiBucketAllReducer runs the collective through the C ABI alone)."""
         assert plan.train
         self.store, self.plan, self.schedule = store, plan, schedule
         self.beta2, self.eps = beta2, eps
         self.step = 0
-        self.reducer = BucketAllReducer(store, process_group)
+        self.reducer = reducer if reducer is not None else BucketAllReducer(store, process_group)
         self.world = self.reducer.world
         self._ld_rng = np.random.RandomState(layerdrop_seed)
         self._mask_rng = np.random.RandomState(mask_seed)
