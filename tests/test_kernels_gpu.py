@@ -641,7 +641,7 @@ def _attention_dropout_tiled(o, lp, B, heads, d, T, p, seed):
 
 
 def test_dropout_stream_statistics():
-    """Counter-based dropout (common.cuh rng_pair): keep rate, independence of the two elements that share one
+    """Counter-based dropout (common.h rng_pair): keep rate, independence of the two elements that share one
     32-bit hash, independence of neighbouring hashes, and decorrelation of consecutive seeds."""
     o = ops()
     n, p = 1 << 22, 0.1

@@ -873,3 +873,64 @@ def test_random_index_pooling_and_no_pooling(dtype):
     p2.backward()
     torch.cuda.synchronize()
     assert torch.isfinite(st2.grad).all() and float(st2.g("wav2vec.model.encoder.layers.0.attention.q_proj.weight").abs().max()) > 0
+
+
+@pytest.mark.parametrize("where", ["head", "layer1", "layer0", "prologue"])
+def test_overflow_anywhere_in_the_backward_chain_reaches_the_scanned_bucket(where):
+    """found_inf is decided by scanning only the LAST gradient bucket backward writes (the prologue), which
+    relies on a non-finite activation gradient surviving every kernel below the point where it appears -- residual
+    joins, LayerNorm backward, attention backward, SpecAugment mask backward, dropout, LayerDrop-skipped layers.  An inf
+    is injected into the running activation gradient at the top of the chain, in front of each layer and in front of
+    the prologue, with dropout / time masks on and one layer skipped: the step must be skipped and the scale halved
+    every time, and the parameters must stay finite."""
+    from w2v2_speaker_amd.config import Wav2Vec2RegularisationConfig
+    from w2v2_speaker_amd.engine import Plan
+    from w2v2_speaker_amd.optim.schedule import Constant
+    from w2v2_speaker_amd.trainer import SpeakerTrainer
+    import dataclasses
+    cfg, ocfg = _cfgs("tiny")
+    cfg = dataclasses.replace(cfg, num_hidden_layers=3)
+    from w2v2_speaker_amd.params import ParamStore
+    st = ParamStore(cfg, DEV, torch.float16, head="aam", num_speakers=10)
+    st.init_weights(3)
+    st.scaler[0] = 256.0
+    reg = Wav2Vec2RegularisationConfig(attention_dropout=0.1, feat_proj_dropout=0.1, hidden_dropout=0.1, layerdrop=0.0,
+                                       mask_time_prob=0.3, mask_time_length=2)
+    plan = Plan(st, 4, 4000, train=True, reg=reg)
+    tr = SpeakerTrainer(st, plan, Constant(1e-3))
+    wav, label = O.synth_batch(4, 4000, 10, seed=2)
+    wav, label = wav.to(DEV), label.to(DEV)
+    tr.train_step(wav, label, skip_layers=())                       # a clean step first
+    torch.cuda.synchronize()
+    assert int(st.scaler[3]) == 0
+    p_before = st.flat.clone()
+    body, head_fb = plan._layer_backward_body, plan.head_forward_backward
+    if where == "head":
+        def poisoned(lbl):
+            out = head_fb(lbl)
+            plan.demb[1, 3] = float("inf")
+            return out
+        plan.head_forward_backward = poisoned
+    elif where.startswith("layer"):
+        target = int(where[5:])
+
+        def poked(l, lnfold):
+            if l == target:
+                plan.G.view(-1)[4321 % plan.G.numel()] = float("-inf")
+            return body(l, lnfold)
+        plan._layer_backward_body = poked
+    else:
+        def last(l, lnfold):
+            r = body(l, lnfold)
+            if l == 0:
+                plan.G.view(-1)[777] = float("nan")           # after the last layer body: only the prologue is below
+            return r
+        plan._layer_backward_body = last
+    tr.train_step(wav, label, skip_layers=(2,) if where != "layer1" else (0,))
+    torch.cuda.synchronize()
+    assert int(st.scaler[3]) == 1 and float(st.scaler[0]) == 128.0, (where, st.scaler.tolist())
+    assert torch.equal(st.flat, p_before), "a skipped step must not touch the parameters"
+    plan._layer_backward_body, plan.head_forward_backward = body, head_fb
+    tr.train_step(wav, label, skip_layers=())
+    torch.cuda.synchronize()
+    assert int(st.scaler[3]) == 1 and torch.isfinite(st.flat).all() and not torch.equal(st.flat, p_before)

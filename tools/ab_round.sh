@@ -5,6 +5,6 @@ R=${1:-3}; shift
 for i in $(seq $R); do
   for v in A B; do
     if [ $v = A ]; then B=build_ab/r02/bench.py; else B=bench.py; fi
-    python3 $B --no-cpu-baseline "$@" 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('$v', d['ms_per_step'], d['value'])"
+    python3 $B --no-cpu-baseline $([ $v = B ] && echo --no-also) "$@" 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('$v', d['ms_per_step'], d['value'])"
   done
 done

@@ -23,8 +23,8 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-EPI = {0: "none", 1: "bias", 2: "bias+gelu", 3: "gelu'", 4: "add", 5: "scale_rc"}
-PAT = re.compile(r"gemm_|wgrad_grouped")
+EPI = {0: "none", 1: "bias", 2: "bias+gelu", 3: "gelu'", 4: "add", 5: "scale_rc", 6: "bias+gelu+g'", 7: "mul"}
+PAT = re.compile(r"gemm16_|gemm_f32|wgrad_grouped")
 
 
 def run(seq_path, steps=6, warmup=3, dtype="f16"):
@@ -73,7 +73,7 @@ def join(seq_path, db_path, out=None):
             bad += 1
         if k["kind"] == "gemm":
             key = (k["M"], k["N"], k["K"], EPI[k["epi"]] + ("+aux" if k["aux"] and k["epi"] == 2 else "")
-                   + ("+2term" if k["two_term"] else ""), k["kernel"].replace("_kernel", "").replace("gemm_bf16_", "")
+                   + ("+2term" if k["two_term"] else ""), k["kernel"].replace("_kernel", "").replace("gemm16_", "")
                    + (f" x{k['batch']}" if k["batch"] > 1 else ""))
         else:
             key = (k["tokens"], k["problems"], 0, "dW+db", k["kernel"].replace("_kernel", "").replace("wgrad_grouped_", "wgrad_"))
@@ -86,11 +86,11 @@ def join(seq_path, db_path, out=None):
     lines = [f"# in-step matrix-core launches by shape: {db_path}; {steps} steps; {tot / 1e6 / steps:.3f} ms/step in these kernels; "
              f"name mismatches in the join: {bad}",
              f"# TF/s = algorithmic FLOPs / duration (two-term K extension NOT credited); TF/s(exec) credits the executed K steps",
-             f"{'M':>7} {'N':>5} {'K':>5} {'epilogue':>16} {'kernel':>14} {'n/step':>7} {'avg_us':>8} {'min_us':>8} {'max_us':>8} "
+             f"{'M':>7} {'N':>5} {'K':>5} {'epilogue':>16} {'kernel':>22} {'n/step':>7} {'avg_us':>8} {'min_us':>8} {'max_us':>8} "
              f"{'ms/step':>8} {'TF/s':>7} {'TF/s(exec)':>10}"]
     for key, a in sorted(agg.items(), key=lambda kv: -kv[1]["ns"]):
         M, N, K, epi, kern = key
-        lines.append(f"{M:7d} {N:5d} {K:5d} {epi:>16} {kern:>14} {a['n'] / steps:7.2f} {a['ns'] / a['n'] / 1e3:8.1f} "
+        lines.append(f"{M:7d} {N:5d} {K:5d} {epi:>16} {kern:>22} {a['n'] / steps:7.2f} {a['ns'] / a['n'] / 1e3:8.1f} "
                      f"{a['min'] / 1e3:8.1f} {a['max'] / 1e3:8.1f} {a['ns'] / 1e6 / steps:8.3f} "
                      f"{a['alg'] / a['ns'] / 1e3:7.0f} {a['flops'] / a['ns'] / 1e3:10.0f}")
     txt = "\n".join(lines)

@@ -68,6 +68,12 @@ def main():
                    "one counter group per pass; read bytes = 2 * FETCH_SIZE KiB (gfx950 correction), write bytes = "
                    "WRITE_SIZE KiB; mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs * GRBM_GUI_ACTIVE / 8 XCD instances).",
            "kernels": {}}
+    # which kernel sources these counters were taken on: bench.py recomputes the hash and marks the counters stale
+    # when the kernels have changed since (w2v2_speaker_amd/_build.py: source_hash)
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from w2v2_speaker_amd._build import source_hash
+    out["source_hash"] = source_hash()
     for name in sorted(f, key=lambda n: -(2 * f[n][1] + w.get(n, (0, 0))[1])):
         n, fk = f[name]
         wk = w.get(name, (n, 0.0))[1]

@@ -11,5 +11,5 @@ for db in glob.glob(sys.argv[1] + "/**/*.db", recursive=True):
         cols = [r[1] for r in cur.execute("pragma table_info(counters_collection)")]
         print("cols", cols); raise
     for n, cn, val, cnt in rows:
-        if "wgrad" in n or "glds3" in n:
+        if "wgrad" in n or "gemm16_ring" in n:
             print(f"{n[:50]:50s} {cn:28s} {val:16.1f} n={cnt}")

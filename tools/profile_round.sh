@@ -4,14 +4,14 @@
 # Usage: bash tools/profile_round.sh <tag> [ecapa]
 #   -> gpurun_out/<tag>_{kernel_stats.txt,pmc_counters.json,bench_line.json}   (with `ecapa`: <tag>_ecapa_*, configs[4])
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 MODEL=""
 if [ "${2:-}" = "ecapa" ]; then TAG=${TAG}_ecapa; MODEL="--model ecapa"; fi
 OUT=$PWD/gpurun_out
 mkdir -p $OUT
 export TMPDIR=/tmp
 export W2V2_BENCH_NO_FAMILY_PASS=1      # profiled runs: only the timed steps (no second, event-instrumented pass)
-BENCH="python3 $PWD/bench.py --no-cpu-baseline $MODEL"
+BENCH="python3 $PWD/bench.py --no-cpu-baseline --no-also $MODEL"
 cd /tmp
 rm -rf /tmp/prof_ks /tmp/prof_f /tmp/prof_w /tmp/prof_m
 rocprofv3 --kernel-trace --stats -d /tmp/prof_ks -- $BENCH --steps 8 --warmup 3 > $OUT/${TAG}_prof_ks.log 2>&1

@@ -23,11 +23,21 @@ def _hipcc() -> str:
     return exe
 
 
+def source_hash() -> str:
+    """sha256 over the kernel sources + the C header (what the profiled counters under profiles/ were measured on)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(SOURCES) + ["common.h"]:
+        h.update(open(os.path.join(CSRC, f), "rb").read())
+    h.update(open(os.path.join(HERE, "..", "include", "w2v2_hip.h"), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def needs_build() -> bool:
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "common.cuh"),
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "common.h"),
                                                       os.path.join(HERE, "..", "include", "w2v2_hip.h")]
     return any(os.path.getmtime(d) > t for d in deps)
 
@@ -56,7 +66,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     def compile_one(src: str) -> str:
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
         srcp = os.path.join(CSRC, src)
-        hdrs = [os.path.join(CSRC, "common.cuh"), os.path.join(HERE, "..", "include", "w2v2_hip.h")]
+        hdrs = [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "w2v2_hip.h")]
         if (not force and os.path.exists(obj)
                 and os.path.getmtime(obj) > max(os.path.getmtime(p) for p in [srcp] + hdrs)):
             return obj

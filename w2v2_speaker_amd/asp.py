@@ -82,10 +82,16 @@ class AttentivePool:
                                    (pad(self.da), pad(x), dW1[:, :C], g(ASP_PREFIX + "tdnn.conv.conv.bias"))], M,
                                   pad(self.ds).shape[0])
         else:
+            # exact-f32 mode: the token dimension is split over ~2 workgroups per CU (f32 atomics, zeroed target)
+            def sk(m, n):
+                s_ = max(1, min(32, 512 // (-(-m // 128) * -(-n // 128))))
+                while s_ > 1 and M // s_ < 256:
+                    s_ -= 1
+                return s_
             self.g_w2 = Gemm(C, A, M, self.ds, self.h, dW2, lda=C, ldb=A, ldc=A, transA=True, transB=True,
-                             accumulate=True)
+                             split_k=sk(C, A), accumulate=True)
             self.g_w1 = Gemm(A, C, M, self.da, x, dW1, lda=A, ldb=C, ldc=3 * C, transA=True, transB=True,
-                             accumulate=True)
+                             split_k=sk(A, C), accumulate=True)
 
     def forward(self) -> torch.Tensor:
         st, B, T, C, A = self.store, self.B, self.T, self.C, self.A

@@ -1,5 +1,5 @@
 // api.hip -- version / error plumbing of libw2v2hip.so
-#include "common.cuh"
+#include "common.h"
 
 thread_local char g_w2v2_err[512] = {0};
 

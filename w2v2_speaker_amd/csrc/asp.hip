@@ -12,7 +12,7 @@
 // this file holds the column / row statistics around them.  Everything here is HBM-bound and small (0.12 GFLOP/utt):
 // one thread per (utterance, channel) walks the time axis, adjacent threads = adjacent channels (coalesced rows).
 // Reductions over (B, T) are two-stage with a fixed order (deterministic, no atomics).
-#include "common.cuh"
+#include "common.h"
 
 constexpr float ASP_EPS = 1e-12f;
 // tanh through one exp + one rcp (|error| ~1e-7 relative to f32 libm tanhf, ~8 instead of ~40 instructions)

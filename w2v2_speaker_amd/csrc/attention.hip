@@ -16,7 +16,7 @@
 // The backward recomputes the scores in both kernels (7 matmul units instead of 5) in exchange for no [B,h,T,T] tensor
 // in HBM at all; attention is 3 % of the step's FLOPs.  Waves whose 16 rows lie entirely beyond T skip the arithmetic
 // (T = 149: the third 64-row block has two idle waves) but keep loading tiles and taking the barriers.
-#include "common.cuh"
+#include "common.h"
 #include <stdlib.h>
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
@@ -26,7 +26,7 @@ constexpr int HD = 64;  // head dim
 // 16-row periodic: all fragments of an image share one per-lane swizzle, so fragment addresses are
 // lane base + compile-time constant (ds_read offset immediates instead of one address VGPR each)
 // dropout counter of attention probability (bh, q, key): rows are padded to an even length so that keys 2j, 2j+1
-// of a row always share one hash (common.cuh rng_pair); every fused kernel (forward, all backward variants) uses it
+// of a row always share one hash (common.h rng_pair); every fused kernel (forward, all backward variants) uses it
 __device__ __forceinline__ uint64_t attn_drop_idx(int64_t bh, int q, int key, int Tn) {
   return (uint64_t)(bh * Tn + q) * (uint64_t)((Tn + 1) & ~1) + (uint64_t)key;
 }

@@ -5,7 +5,7 @@
 // ("nccl" == RCCL on ROCm, trainer.BucketAllReducer); these entry points let a caller WITHOUT torch.distributed run the
 // same step: RCCL (librccl.so) is resolved at run time with dlopen -- libw2v2hip.so has no link-time dependency on it,
 // and a process that already loaded an RCCL (torch's own copy) keeps using that one.
-#include "common.cuh"
+#include "common.h"
 #include <dlfcn.h>
 #include <stdlib.h>
 #include <string.h>

@@ -10,7 +10,7 @@
 // The waveform chunk of a block is staged in LDS once and read by broadcast (every thread of the
 // block needs the same 10-sample window for a given frame); threads map to adjacent channels so the
 // channels-last stores are fully coalesced (512 B per frame per block).
-#include "common.cuh"
+#include "common.h"
 #include <stdlib.h>
 
 constexpr int C0_FRAMES = 128;   // frames per block
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(256, 2) void conv0_mfma_kernel(const float* __restr
         for (int j = 0; j < 8; ++j)
           acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf, c0_f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
         if constexpr (APPLY) {
-          // full-line stores (common.cuh): lanes r and r ^ 8 swap one 16-byte half, then every instruction writes
+          // full-line stores (common.h): lanes r and r ^ 8 swap one 16-byte half, then every instruction writes
           // 8 frames x 128 contiguous bytes (the per-lane 64-byte runs of the first version left at 2.2 TB/s)
           const bool lo = r < 8;
           const int fa = f0 + (r & 7);

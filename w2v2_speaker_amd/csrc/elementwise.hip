@@ -1,6 +1,6 @@
 // elementwise.hip -- HBM-bound helpers: dropout, GELU', add, column sums (bias grads), casts,
 // SpecAugment mask fill, CLS-token prepend.  16-byte vector accesses, grid-stride loops.
-#include "common.cuh"
+#include "common.h"
 
 static inline int ew_blocks(int64_t nvec) {
   int64_t b = cdiv(nvec, 256);

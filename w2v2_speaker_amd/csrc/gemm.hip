@@ -13,7 +13,7 @@
 //   f32 path  : exact-f32 64x64x16 VALU tile kernel.  It exists for the parity mode only
 //               (embeddings within 1e-3 rel-L2 of the f32 reference, BASELINE.json north_star);
 //               throughput runs use bf16.
-#include "common.cuh"
+#include "common.h"
 #include <type_traits>
 #include <stdlib.h>
 
@@ -611,7 +611,7 @@ struct Stager {
 };
 
 template <typename TE, int FM, int FN, bool TA, bool TB, typename TC>
-__global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmArgs g) {
+__global__ __launch_bounds__(256) void gemm16_regstage_kernel(const GemmArgs g) {
   constexpr int BM = 32 * FM, BN = 32 * FN;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   bf16_t* As = reinterpret_cast<bf16_t*>(smem_raw);           // [2][BM*64]
@@ -720,7 +720,7 @@ typedef __attribute__((address_space(1))) const void gvoid_t;
 typedef __attribute__((address_space(3))) void lvoid_t;
 
 template <typename TE, int FM, int FN, typename TC>
-__global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(const GemmArgs g) {
+__global__ __launch_bounds__(256) void gemm16_dma_128_kernel(const GemmArgs g) {
   constexpr int BM = 32 * FM, BN = 32 * FN;
   constexpr int NA = BM / 32, NB = BN / 32;      // 1 KiB pieces per wave per operand tile
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -839,7 +839,7 @@ template <int S> __device__ __forceinline__ void wait_vmcnt() {
 }
 
 template <typename TE, typename TC>
-__global__ __launch_bounds__(512) void gemm_bf16_glds3_kernel(const GemmArgs g) {
+__global__ __launch_bounds__(512) void gemm16_ring_256x128_kernel(const GemmArgs g) {
   constexpr int BM = 256, BN = 128, FM = 4, FN = 4;
   constexpr int STAGE = (BM + BN) * 64;           // elements per stage (A then B)
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -1088,7 +1088,7 @@ __device__ __forceinline__ int swz64_b(int row) { return ((row >> 4) & 1) << 1; 
 // step earlier than in a read-then-multiply loop, i.e. two stages are in flight instead of three; a fifth stage
 // (160 KiB, the whole LDS) restored the distance and measured the same, so four it is.
 template <typename TE, typename TC>
-__global__ __launch_bounds__(512) void gemm_bf16_glds4_kernel(const GemmArgs g) {
+__global__ __launch_bounds__(512) void gemm16_ring_256x256_kernel(const GemmArgs g) {
   constexpr int BM = 256, BN = 256, FM = 8, FN = 4, BK = 32, S = 4;
   constexpr int STAGE = (BM + BN) * BK;           // elements per stage (A then B): 32 KiB
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -1257,7 +1257,7 @@ __device__ __forceinline__ void wait_quarters(int newer) {
 }
 
 template <typename TE, typename TC>
-__global__ __launch_bounds__(512) void gemm_ph_kernel(const GemmArgs g) {
+__global__ __launch_bounds__(512) void gemm16_phased_256x256_kernel(const GemmArgs g) {
   constexpr int BM = 256, BN = 256, BK = 64, FM = 8, FN = 4;
   constexpr int BUF = (BM + BN) * BK;             // elements per K-tile buffer: A [256][64] then B [256][64]
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -1452,7 +1452,7 @@ static void launch_ph(GemmArgs a, int M, int N, int batch, hipStream_t st) {
   constexpr size_t lds = (size_t)2 * (256 + 256) * 64 * sizeof(bf16_t);   // 128 KiB
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ph_kernel<TE, TC>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm16_phased_256x256_kernel<TE, TC>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
@@ -1466,7 +1466,7 @@ static void launch_ph(GemmArgs a, int M, int N, int batch, hipStream_t st) {
     if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
   }
   dim3 grid(tiles < ncu ? tiles : ncu, 1, batch);
-  hipLaunchKernelGGL((gemm_ph_kernel<TE, TC>), grid, dim3(512), lds, st, a);
+  hipLaunchKernelGGL((gemm16_phased_256x256_kernel<TE, TC>), grid, dim3(512), lds, st, a);
 }
 
 static const bool g_w2v2_no_glds = getenv("W2V2_NO_GLDS") != nullptr;   // A/B switches for benchmarking
@@ -1496,7 +1496,7 @@ static void launch_glds4(GemmArgs a, int M, int N, int batch, hipStream_t st) {
   constexpr size_t lds = (size_t)4 * (256 + 256) * 32 * sizeof(bf16_t);   // 128 KiB
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_glds4_kernel<TE, TC>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm16_ring_256x256_kernel<TE, TC>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
@@ -1504,7 +1504,7 @@ static void launch_glds4(GemmArgs a, int M, int N, int batch, hipStream_t st) {
   a.tiles_n = (int)cdiv(N, 256);
   const int tiles = a.tiles_m * a.tiles_n, ncu = device_cus();
   dim3 grid(tiles < ncu ? tiles : ncu, 1, batch);
-  hipLaunchKernelGGL((gemm_bf16_glds4_kernel<TE, TC>), grid, dim3(512), lds, st, a);
+  hipLaunchKernelGGL((gemm16_ring_256x256_kernel<TE, TC>), grid, dim3(512), lds, st, a);
 }
 
 template <typename TE, typename TC>
@@ -1512,7 +1512,7 @@ static void launch_glds3(GemmArgs a, int M, int N, int batch, hipStream_t st) {
   constexpr size_t lds = (size_t)3 * (256 + 128) * 64 * sizeof(bf16_t);   // 144 KiB
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_glds3_kernel<TE, TC>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm16_ring_256x128_kernel<TE, TC>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
@@ -1521,7 +1521,7 @@ static void launch_glds3(GemmArgs a, int M, int N, int batch, hipStream_t st) {
   const int ncu = g_w2v2_persistent ? device_cus() : (1 << 30);
   const int tiles = a.tiles_m * a.tiles_n;
   dim3 grid(tiles < ncu ? tiles : ncu, 1, batch);
-  hipLaunchKernelGGL((gemm_bf16_glds3_kernel<TE, TC>), grid, dim3(512), lds, st, a);
+  hipLaunchKernelGGL((gemm16_ring_256x128_kernel<TE, TC>), grid, dim3(512), lds, st, a);
 }
 
 template <typename TE, int FM, int FN, typename TC>
@@ -1529,11 +1529,11 @@ static void launch_glds(const GemmArgs& a, dim3 grid, hipStream_t st) {
   constexpr size_t lds = (size_t)2 * (32 * FM + 32 * FN) * 64 * sizeof(bf16_t);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_glds_kernel<TE, FM, FN, TC>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm16_dma_128_kernel<TE, FM, FN, TC>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_bf16_glds_kernel<TE, FM, FN, TC>), grid, dim3(256), lds, st, a);
+  hipLaunchKernelGGL((gemm16_dma_128_kernel<TE, FM, FN, TC>), grid, dim3(256), lds, st, a);
 }
 
 // ------------------------------------------------------------------------------ exact f32 kernel
@@ -1615,10 +1615,16 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 template <bool TA, bool TB>
-__global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(const GemmArgs g) {
-  constexpr int BM = 128, BN = 128, BK = 16, P = 132;
-  __shared__ float As[2][BK][P];
-  __shared__ float Bs[2][BK][P];
+__global__ __launch_bounds__(256, 2) void gemm_f32_mfma_kernel(const GemmArgs g) {
+  // BK = 32: a K-contiguous operand row contributes one whole 128-byte line per K tile (BK = 16 fetched half lines, and
+  // the 2 x 16 KB of half-used lines per tile thrashed the 32 KB L1: 26 TFLOP/s).  LDS pitch: 132 words for K-major
+  // sources (16-byte aligned float4 stores), 129 for K-contiguous ones (their transposing scalar stores hit
+  // (k + row) % 32 -> 2-way instead of 4-way conflicts); fragment reads [k][32 consecutive rows] are conflict-free
+  // with either.
+  constexpr int BM = 128, BN = 128, BK = 32, PA = TA ? 132 : 129, PB = TB ? 132 : 129;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];            // 2 x 32 x (PA + PB) floats = 66-68 KB
+  float (*As)[BK][PA] = reinterpret_cast<float (*)[BK][PA]>(smem_raw);
+  float (*Bs)[BK][PB] = reinterpret_cast<float (*)[BK][PB]>(smem_raw + sizeof(float) * 2 * BK * PA);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int tile = blockIdx.x;
@@ -1632,16 +1638,17 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(const GemmArgs g) {
   const float* Ab = reinterpret_cast<const float*>(g.A.ptr) + z0 * g.a_s0 + z1 * g.a_s1;
   const float* Bb = reinterpret_cast<const float*>(g.B.ptr) + z0 * g.b_s0 + z1 * g.b_s1;
 
-  // staging map: 2 x float4 per operand and thread.  K-contiguous operand (trans = 0): thread -> (row = c >> 2, 4 k);
-  // K-major operand (trans = 1): thread -> (k = c >> 5, 4 rows)
-  auto load_op = [&](const OpDev& o, const float* __restrict__ base, bool trans, int r0, int rbound, int k0,
-                     float4 (&reg)[2]) {
+  // staging map: 4 x float4 per operand and thread.  K-contiguous operand (trans = 0): thread -> (row = c >> 3, 4 k):
+  // eight lanes read one 128-byte line; K-major operand (trans = 1): thread -> (k = c >> 5, 4 rows)
+  auto load_op = [&](const OpDev& o, const float* __restrict__ base, auto trans_c, int r0, int rbound, int k0,
+                     float4 (&reg)[4]) {
+    constexpr bool trans = decltype(trans_c)::value;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < 4; ++j) {
       const int c = tid + 256 * j;
       float v[4] = {0.f, 0.f, 0.f, 0.f};
-      if (!trans) {
-        const int row = c >> 2, k = k0 + (c & 3) * 4;
+      if constexpr (!trans) {
+        const int row = c >> 3, k = k0 + (c & 7) * 4;
         if (r0 + row < rbound && k < kend) {
           const float* p = base + outer_off(o, r0 + row) + k;
           if (o.vec_ok && k + 4 <= kend) {
@@ -1668,15 +1675,27 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(const GemmArgs g) {
       reg[j] = make_float4(v[0], v[1], v[2], v[3]);
     }
   };
-  auto store_op = [&](float (&dst)[BK][P], bool trans, const float4 (&reg)[2]) {
+  auto store_a = [&](int buf, const float4 (&reg)[4]) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < 4; ++j) {
       const int c = tid + 256 * j;
-      if (!trans) {
-        const int row = c >> 2, k = (c & 3) * 4;
-        dst[k][row] = reg[j].x; dst[k + 1][row] = reg[j].y; dst[k + 2][row] = reg[j].z; dst[k + 3][row] = reg[j].w;
+      if constexpr (!TA) {
+        const int row = c >> 3, k = (c & 7) * 4;
+        As[buf][k][row] = reg[j].x; As[buf][k + 1][row] = reg[j].y; As[buf][k + 2][row] = reg[j].z; As[buf][k + 3][row] = reg[j].w;
       } else {
-        *reinterpret_cast<float4*>(&dst[c >> 5][(c & 31) * 4]) = reg[j];
+        *reinterpret_cast<float4*>(&As[buf][c >> 5][(c & 31) * 4]) = reg[j];
+      }
+    }
+  };
+  auto store_b = [&](int buf, const float4 (&reg)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = tid + 256 * j;
+      if constexpr (!TB) {
+        const int row = c >> 3, k = (c & 7) * 4;
+        Bs[buf][k][row] = reg[j].x; Bs[buf][k + 1][row] = reg[j].y; Bs[buf][k + 2][row] = reg[j].z; Bs[buf][k + 3][row] = reg[j].w;
+      } else {
+        *reinterpret_cast<float4*>(&Bs[buf][c >> 5][(c & 31) * 4]) = reg[j];
       }
     }
   };
@@ -1690,20 +1709,22 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(const GemmArgs g) {
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   const int nk = (kend - kbeg + BK - 1) / BK;
-  float4 ra[2], rb[2];
+  float4 ra[4], rb[4];
+  const std::integral_constant<bool, TA> ta_c{};
+  const std::integral_constant<bool, TB> tb_c{};
   if (nk > 0) {
-    load_op(g.A, Ab, TA, m0, g.M, kbeg, ra);
-    load_op(g.B, Bb, TB, n0, g.N, kbeg, rb);
-    store_op(As[0], TA, ra);
-    store_op(Bs[0], TB, rb);
+    load_op(g.A, Ab, ta_c, m0, g.M, kbeg, ra);
+    load_op(g.B, Bb, tb_c, n0, g.N, kbeg, rb);
+    store_a(0, ra);
+    store_b(0, rb);
   }
   __syncthreads();
   const int kl = lane >> 5, rl = lane & 31;
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
     if (kt + 1 < nk) {
-      load_op(g.A, Ab, TA, m0, g.M, kbeg + (kt + 1) * BK, ra);
-      load_op(g.B, Bb, TB, n0, g.N, kbeg + (kt + 1) * BK, rb);
+      load_op(g.A, Ab, ta_c, m0, g.M, kbeg + (kt + 1) * BK, ra);
+      load_op(g.B, Bb, tb_c, n0, g.N, kbeg + (kt + 1) * BK, rb);
     }
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 2) {
@@ -1719,8 +1740,8 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(const GemmArgs g) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[j], a[i], acc[i][j], 0, 0, 0);   // D[n][m]
     }
     if (kt + 1 < nk) {
-      store_op(As[cur ^ 1], TA, ra);
-      store_op(Bs[cur ^ 1], TB, rb);
+      store_a(cur ^ 1, ra);
+      store_b(cur ^ 1, rb);
     }
     __syncthreads();
   }
@@ -1753,11 +1774,11 @@ static void launch_bf16(const GemmArgs& a, dim3 grid, hipStream_t st) {
   do {                                                                                          \
     static bool attr_set = false;                                                               \
     if (!attr_set) {                                                                            \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<TE, FM, FN, TA_, TB_, TC>), \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm16_regstage_kernel<TE, FM, FN, TA_, TB_, TC>), \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);          \
       attr_set = true;                                                                          \
     }                                                                                           \
-    hipLaunchKernelGGL((gemm_bf16_kernel<TE, FM, FN, TA_, TB_, TC>), grid, dim3(256), lds, st, a);  \
+    hipLaunchKernelGGL((gemm16_regstage_kernel<TE, FM, FN, TA_, TB_, TC>), grid, dim3(256), lds, st, a);  \
   } while (0)
   if (!ta && !tb) W2V2_LAUNCH(false, false);
   else if (!ta && tb) W2V2_LAUNCH(false, true);
@@ -1898,19 +1919,31 @@ extern "C" int w2v2_gemm(const w2v2_gemm_desc* d, void* stream) {
     static const bool f32_valu = getenv("W2V2_F32_VALU") != nullptr;      // A/B: the 64x64x16 VALU tile kernel
     const int BT = f32_valu ? 64 : 128;
     a.tiles_m = (int)cdiv(d->M, BT); a.tiles_n = (int)cdiv(d->N, BT);
-    a.k_per_split = (int)(cdiv(cdiv(d->K, split), 16) * 16);
-    if (a.k_per_split == 0) a.k_per_split = 16;
+    a.k_per_split = (int)(cdiv(cdiv(d->K, split), 32) * 32);
+    if (a.k_per_split == 0) a.k_per_split = 32;
     // f32 rows are 16-byte vectors of FOUR elements
     auto vec4 = [&](const w2v2_operand& o) {
       return aligned16(o.ptr) && (o.ld % 4 == 0) && (o.seg_stride % 4 == 0) && (o.stride0 % 4 == 0) && (o.stride1 % 4 == 0);
     };
     a.A.vec_ok = vec4(d->A); a.B.vec_ok = vec4(d->B);
     dim3 grid(a.tiles_m * a.tiles_n, split, d->batch);
+#define W2V2_F32_LAUNCH(TA_, TB_)                                                                                     \
+    do {                                                                                                              \
+      constexpr size_t lds = sizeof(float) * 2 * 32 * ((TA_ ? 132 : 129) + (TB_ ? 132 : 129));                          \
+      static bool attr_set = false;                                                                                   \
+      if (!attr_set) {                                                                                                \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_mfma_kernel<TA_, TB_>),                      \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                              \
+        attr_set = true;                                                                                              \
+      }                                                                                                               \
+      hipLaunchKernelGGL((gemm_f32_mfma_kernel<TA_, TB_>), grid, dim3(256), lds, st, a);                               \
+    } while (0)
     if (f32_valu) hipLaunchKernelGGL(gemm_f32_kernel<float>, grid, dim3(256), 0, st, a);
-    else if (!a.A.trans && !a.B.trans) hipLaunchKernelGGL((gemm_f32_mfma_kernel<false, false>), grid, dim3(256), 0, st, a);
-    else if (!a.A.trans && a.B.trans) hipLaunchKernelGGL((gemm_f32_mfma_kernel<false, true>), grid, dim3(256), 0, st, a);
-    else if (a.A.trans && !a.B.trans) hipLaunchKernelGGL((gemm_f32_mfma_kernel<true, false>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((gemm_f32_mfma_kernel<true, true>), grid, dim3(256), 0, st, a);
+    else if (!a.A.trans && !a.B.trans) W2V2_F32_LAUNCH(false, false);
+    else if (!a.A.trans && a.B.trans) W2V2_F32_LAUNCH(false, true);
+    else if (a.A.trans && !a.B.trans) W2V2_F32_LAUNCH(true, false);
+    else W2V2_F32_LAUNCH(true, true);
+#undef W2V2_F32_LAUNCH
   }
   W2V2_CHECK_LAUNCH("w2v2_gemm");
   return 0;

@@ -3,7 +3,7 @@
 // run on the GEMM (EPI_SCALE_RC folds both F.normalize calls into its epilogue); the kernels here do
 // the row norms, the margin + scale + softmax + cross-entropy row pass (forward AND the gradient
 // wrt the cosines in one sweep over [B, C]) and the F.normalize backward.
-#include "common.cuh"
+#include "common.h"
 
 template <typename T>
 __global__ __launch_bounds__(256) void row_invnorm_kernel(const T* __restrict__ x, int64_t ld, float* __restrict__ inv,

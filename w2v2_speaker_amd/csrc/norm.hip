@@ -1,6 +1,6 @@
 // norm.hip -- LayerNorm(+residual +dropout) forward / backward (HF:429, HF:596-601, HF:691-692).
 // One 64-lane wave per token row, 16-byte vector accesses, wave-shuffle reductions; statistics f32.
-#include "common.cuh"
+#include "common.h"
 
 constexpr int LN_MAXC = 2;  // vec8 chunks per lane: H <= 1024
 // workgroups of the backward (= rows of the gamma/beta partial buffer): four 4-wave workgroups per CU; the kernel is

@@ -2,7 +2,7 @@
 // ref: config/optim/algo/adam.yaml:1-16, wired at src/main.py:323-335).  One launch updates every
 // trainable parameter and refreshes the bf16 copy the MFMA GEMMs read.  HBM-bound:
 // 4 f32 streams read (p, g, m, v) + 3 written (p, m, v) + 2 B/param bf16 copy = 30 B/param.
-#include "common.cuh"
+#include "common.h"
 #include <stdlib.h>
 
 template <typename TB, int U>

@@ -3,7 +3,7 @@
 // 16 column lanes x 16-byte vectors give fully coalesced 256-B row reads, the 16 time lanes
 // (4 lane groups x 4 waves) are folded with wave shuffles (xor 16, 32) and one LDS hop across waves.
 // Two passes over the (L2-resident) slab: mean, then centred sum of squares -> torch.std_mean parity.
-#include "common.cuh"
+#include "common.h"
 
 template <typename T>
 __global__ __launch_bounds__(256) void pool_meanstd_kernel(const T* __restrict__ x, float* __restrict__ out, int Tn,

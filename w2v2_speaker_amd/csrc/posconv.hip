@@ -2,7 +2,7 @@
 // The convolution itself runs on the MFMA GEMM as an implicit GEMM per group; these kernels build
 // its operands: the padded group-major activation image and the weight-norm-ed packed weights, and
 // the weight-norm backward.
-#include "common.cuh"
+#include "common.h"
 
 // x [B,T,H] -> xg [B,G,Tp,Cg], Tp = T+K-1, xg[b,g,tp,c] = x[b, tp-pad_left, g*Cg+c] (0 outside).
 // A row of the implicit GEMM for output frame t of group g is the contiguous K*Cg run starting at

@@ -15,7 +15,7 @@
 // k mapping of a 32-row MFMA step: lane group lg (0..3) takes rows {4 lg .. 4 lg + 3} and {16 + 4 lg ..}; with
 // dense rows of 2 Cg bytes the natural {8 lg ..} choice puts lane groups 0 and 1 on the same banks.  The
 // contraction index may be permuted freely as long as both operands use the same permutation.
-#include "common.cuh"
+#include "common.h"
 #include <type_traits>
 
 typedef __attribute__((ext_vector_type(4))) short short4v;

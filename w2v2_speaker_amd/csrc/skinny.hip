@@ -10,7 +10,7 @@
 // out, so one SE block is 2 + 4 launches instead of 4 + 9.  All sums are f32 in a fixed order (deterministic).
 //
 //   act: 0 none, 1 relu, 2 sigmoid.  Backward kernels take the forward OUTPUT y and form dy' = dy * act'(y).
-#include "common.cuh"
+#include "common.h"
 
 constexpr int SK_BT = 16;   // batch rows per workgroup of the forward kernel
 constexpr int SK_NT = 4;    // weight rows per workgroup of the forward kernel

@@ -1,7 +1,7 @@
 // softmax.hip -- row softmax (+ dropout on the probabilities) of the unfused attention path
 // (HF:438-463 eager_attention_forward).  One wave per score row; used for sequence lengths the
 // fused kernel (attention.hip) does not cover (full-length test utterances, T up to ~7k frames).
-#include "common.cuh"
+#include "common.h"
 
 template <typename T>
 __global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* __restrict__ s, T* __restrict__ p,

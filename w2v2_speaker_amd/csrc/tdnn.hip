@@ -10,7 +10,7 @@
 // Everything here is HBM-bound elementwise / reduction work over channels-last [B*T, C] activations; reductions
 // over rows are two-stage with a fixed order (deterministic, no atomics).  Row-strided operands (ld*) let the
 // Res2Net slices and the MFA concatenation live inside their parent tensors without copies.
-#include "common.cuh"
+#include "common.h"
 
 constexpr int BN_CW = 128;        // channels per workgroup of the BatchNorm kernels: 16 lanes x 8 channels (16 B)
 constexpr int BN_RL = 16;         // row lanes of a BatchNorm workgroup (blockDim = (16, BN_RL))

@@ -12,7 +12,7 @@
 // the 8 rows a half-wave touches over all 8 segments (conflict-free ds_read_b64_tr_b16).
 // Contract: token rows [tokens, tokens_padded) of every operand are readable and ZERO
 // (tokens_padded = tokens rounded up to 64); n_out, n_in multiples of 8; 16-byte aligned rows.
-#include "common.cuh"
+#include "common.h"
 #include <stdlib.h>
 #include <type_traits>
 
@@ -33,9 +33,15 @@ struct WgProblem {
   int n_out, n_in;
   int tile_begin, tiles_n;
 };
+constexpr int WG_MAXORDER = 512;
 struct WgArgs {
   WgProblem p[WG_MAXP];
   int n_problems, total_tiles, ktiles;
+  // 256x256 ring kernel: position in the launch -> tile, so that the run of tiles an XCD works on (consecutive
+  // positions after the XCD remap) forms compact 2-D blocks of ONE problem's tile grid: the tiles of an XCD then share
+  // their dY / X column panels in that XCD's private L2 (see w2v2_wgrad_grouped)
+  int use_order;
+  uint16_t order[WG_MAXORDER];
 };
 
 __device__ __forceinline__ int wg_f(int r) { return (r & 3) | ((r >> 1) & 4); }
@@ -195,7 +201,7 @@ __global__ __launch_bounds__(256) void wgrad_grouped_kernel(const WgArgs a) {
 // ------------------------------------------------------------------------------ 256 x 128 ring kernel
 // Same data path (LDS-DMA in natural [k][m] layout + ds_read_b64_tr_b16 fragments), but a 256(n_out) x
 // 128(n_in) x 64(tokens) block tile for 8 waves (4 x 2, 64 x 64 per wave) on the 3-stage LDS ring of
-// gemm_bf16_glds3_kernel: while tile t is multiplied, tiles t+1 and t+2 are in flight; per K tile one raw
+// gemm16_ring_256x128_kernel: while tile t is multiplied, tiles t+1 and t+2 are in flight; per K tile one raw
 // s_barrier and `s_waitcnt vmcnt(6)` (6 = this wave's DMA pieces per stage: 4 x [2 rows x 512 B] of dY,
 // 2 x [4 rows x 256 B] of X).  The four Linear layers of a w2v2-base block are 216 tiles = one round on 256 CUs.
 template <int S> __device__ __forceinline__ void wg_wait_vmcnt() {
@@ -400,7 +406,7 @@ __global__ __launch_bounds__(512) void wgrad_grouped_ring_kernel(const WgArgs a)
 
 
 // ------------------------------------------------------------------------------ 256 x 256 x 32, 4-stage ring
-// Same idea as gemm_bf16_glds4_kernel: half the L2 -> LDS bytes per flop of the 256x128 tile.  A block of w2v2-base
+// Same idea as gemm16_ring_256x256_kernel: half the L2 -> LDS bytes per flop of the 256x128 tile.  A block of w2v2-base
 // has only 108 such tiles, so the host groups the four Linear layers of TWO transformer blocks (8 problems = 216
 // tiles, one round on 256 CUs): still no split-K, no atomics, bitwise reproducible.  8 waves as 2 (n_out) x 4 (n_in),
 // 128 x 64 per wave; four 32 KiB stages [32 tokens][256 + 256] in natural K-major layout, three in flight
@@ -420,6 +426,7 @@ __global__ __launch_bounds__(512) void wgrad_grouped_ring4_kernel(const WgArgs a
     const int nwg = a.total_tiles, bid = blockIdx.x;
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
     tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    if (a.use_order) tile = a.order[tile];
   }
   int pi = 0;
 #pragma unroll
@@ -660,6 +667,45 @@ extern "C" int w2v2_wgrad_grouped(const w2v2_wgrad_problem* probs, int n, int to
   for (int i = n; i < WG_MAXP; ++i) a.p[i] = a.p[0];
   a.n_problems = n;
   a.total_tiles = tiles;
+  a.use_order = 0;
+  // measured (ABAB, round 3): 12.88 vs 12.83 ms/step WITH the blocked order -- the launch is not bound by the panel
+  // fetches (FETCH_SIZE counts L2 misses that the 256 MB Infinity Cache serves), and 27 tiles of ONE problem per XCD
+  // concentrate on fewer channels; kept behind a switch, off by default
+  static const bool env_order = getenv("W2V2_WGRAD_ORDER") != nullptr;
+  if (ring4 && tiles <= WG_MAXORDER && tiles >= 16 && env_order) {
+    // Every tile streams two column panels ([tokens] x 256 of dY and of X, 5 MB each at B = 66) and an XCD's L2 serves
+    // only its own CUs: in plain row-major order an XCD's ~tiles/8 consecutive tiles touch ~17 different panels
+    // (PMC: 856 MB fetched for 540 MB of operands).  Here each problem's tile grid is cut into blocks of at most
+    // `chunk` tiles spanning the SHORT grid dimension completely (3 x 9 of the 3 x 12 FFN2 grid: 12 panels for 27
+    // tiles), whole blocks first and the remainders packed behind them, so that an XCD's run is one or two blocks.
+    const int chunk = (tiles + 7) / 8;
+    struct Block { int p, r0, r1, c0, c1; };
+    Block blocks[4 * WG_MAXP];
+    int nb = 0;
+    for (int i = 0; i < n && nb < 4 * WG_MAXP - 2; ++i) {
+      const int R = (int)cdiv(probs[i].n_out, bm), Cn = a.p[i].tiles_n;
+      if (R <= Cn) {
+        const int w = chunk / R > 0 ? chunk / R : 1;
+        for (int c = 0; c < Cn && nb < 4 * WG_MAXP; c += w) blocks[nb++] = {i, 0, R, c, c + w < Cn ? c + w : Cn};
+      } else {
+        const int h = chunk / Cn > 0 ? chunk / Cn : 1;
+        for (int r = 0; r < R && nb < 4 * WG_MAXP; r += h) blocks[nb++] = {i, r, r + h < R ? r + h : R, 0, Cn};
+      }
+    }
+    // largest blocks first (stable): the full-size ones align with the XCD runs, the remainders share the last runs
+    for (int x = 1; x < nb; ++x)
+      for (int y = x; y > 0; --y) {
+        const int sa = (blocks[y - 1].r1 - blocks[y - 1].r0) * (blocks[y - 1].c1 - blocks[y - 1].c0);
+        const int sb = (blocks[y].r1 - blocks[y].r0) * (blocks[y].c1 - blocks[y].c0);
+        if (sb > sa) { const Block t = blocks[y]; blocks[y] = blocks[y - 1]; blocks[y - 1] = t; } else break;
+      }
+    int pos = 0;
+    for (int x = 0; x < nb; ++x)
+      for (int r = blocks[x].r0; r < blocks[x].r1; ++r)
+        for (int c = blocks[x].c0; c < blocks[x].c1; ++c)
+          if (pos < WG_MAXORDER) a.order[pos++] = (uint16_t)(a.p[blocks[x].p].tile_begin + r * a.p[blocks[x].p].tiles_n + c);
+    a.use_order = pos == tiles ? 1 : 0;
+  }
   a.ktiles = tokens_padded / 64;
   W2V2_DISPATCH_16(dtype, "wgrad_grouped", wgrad_launch<AT>(a, tiles, ring, ring4, as_stream(stream)););
   W2V2_CHECK_LAUNCH("wgrad_grouped");

@@ -247,8 +247,18 @@ class _Tdnn:
             self.grouped = ops.is16(adt) and hasattr(A, "_full")
             if self.grouped:
                 self.wg_problem = (self.da._full, A._full, dW, st.g(self.pre + "conv.conv.bias"))
+            # exact-f32 mode (no grouped launch): K of this product = the B * T tokens, its output only
+            # cout x K / 128^2 tiles (3 for a Res2Net chunk) -- split the token dimension over ~2 workgroups per CU
+            # (f32 atomics into a zeroed target), like the wav2vec2 engine's f32 weight gradients
+            tiles = -(-cout // 128) * -(-K // 128)
+            sk = max(1, min(32, 512 // tiles))
+            while sk > 1 and M // sk < 256:
+                sk -= 1
+            self._dw_split = sk if not self.grouped else 1
+            self._dwp_ztab = (torch.tensor([[0, cout * K]], dtype=torch.int64, device=dev)
+                              if (k > 1 and self._dw_split > 1) else None)
             self.g_dw = Gemm(cout, K, M, self.da, A, dW, lda=cout, ldb=lda, ldc=K, transA=True, transB=True,
-                             accumulate=(k == 1))
+                             split_k=self._dw_split, accumulate=(k == 1 or self._dw_split > 1))
             self.dcol = torch.empty(M, K, dtype=adt, device=dev) if k > 1 else None
             # bf16: the data-gradient product reads the packed weight TRANSPOSED ([K][cout], refreshed with the pack)
             # so that it is an NT product on the LDS-DMA ring kernels instead of a K-major-B one on the generic kernel
@@ -277,6 +287,8 @@ class _Tdnn:
             self._wg()
         else:
             ops.colsum(self.da, st.g(self.pre + "conv.conv.bias"), self.M, self.cout)
+            if self._dwp_ztab is not None:
+                ops.zero_ranges(self.dwp.view(-1), self._dwp_ztab, blocks_per_range=64)
             self.g_dw()
         self.finish_weight_grad()
 

@@ -129,7 +129,17 @@ def _pool_width(pooling: str) -> int:
     raise ValueError(f"unknown value for stat_pooling_type={pooling!r}")
 
 
-class Wav2vec2FCModule:
+class Wav2vec2FCModule(torch.nn.Module):
+    """A ``torch.nn.Module`` (the reference's is a LightningModule): ``parameters()`` / ``named_parameters()`` yield one
+    ``nn.Parameter`` per reference parameter, in the reference's order and under its names, each a VIEW of the flat f32
+    arena (``.grad`` = the matching view of the flat gradient buffer, scaled by the loss scale in the fp16 mode);
+    ``state_dict()`` / ``load_state_dict()`` speak the reference's keys; ``train()`` / ``eval()`` are nn.Module's.
+    ``automatic_optimization = False``: ``training_step`` runs forward, the hand-written backward, the gradient
+    all-reduce and the fused Adam itself (PL's manual-optimisation contract), an optimiser built over ``parameters()``
+    is therefore not stepped by this module.  ``.to()`` / ``.half()`` / ``.cuda()`` are no-ops: the engine is bound to
+    the device and activation dtype it was constructed with."""
+    automatic_optimization = False
+
     def __init__(self, hyperparameters_to_save, cfg: Wav2vec2FCModuleConfig, num_speakers: int,
                  loss_fn_constructor: Callable[[], object], validation_pairs: Optional[List[EvaluationPair]] = None,
                  test_pairs: Optional[List[EvaluationPair]] = None, evaluator=None, *, device="cuda",
@@ -139,6 +149,7 @@ class Wav2vec2FCModule:
         the engine, the one-cycle schedule the reference takes from ``cfg.optim`` (src/main.py:323-335), and
         ``pretrained_state_dict`` (a path or a dict with HF ``facebook/wav2vec2-*`` weights: there is no network
         here for ``from_pretrained``)."""
+        super().__init__()
         self.hyperparameters_to_save = hyperparameters_to_save
         self.cfg = cfg
         if cfg.wav2vec_feature_encoder_only:
@@ -197,7 +208,6 @@ class Wav2vec2FCModule:
         self.evaluator = evaluator or CosineDistanceEvaluator(False, False, 0)
         self.schedule = OneCycle(max_lr=max_lr, total_steps=max_steps)
         self.process_group = process_group
-        self.training = True
         self._plans: "OrderedDict[Tuple, Plan]" = OrderedDict()
         self._trainers: Dict[Tuple, SpeakerTrainer] = {}
         self.steps = 0              # ref: counts backward calls since on_train_start (the freeze schedule)
@@ -223,13 +233,24 @@ class Wav2vec2FCModule:
         return cls(None, cfg, num_speakers, ctor, kw.pop("validation_pairs", None), kw.pop("test_pairs", None),
                    kw.pop("evaluator", None), **kw)
 
-    # ------------------------------------------------------------------ PL-style mode switches
-    def train(self, mode: bool = True):
-        self.training = mode
-        return self
+    # ------------------------------------------------------------------ nn.Module surface over the flat arena
+    def named_parameters(self, prefix: str = "", recurse: bool = True, remove_duplicate: bool = True):
+        if getattr(self, "_param_views", None) is None:
+            self._param_views = {}
+            for n in self.store.reference_parameter_order():
+                p = torch.nn.Parameter(self.store.p(n), requires_grad=False)        # a view: shares the arena's memory
+                if self.store.is_trainable(n):
+                    p.grad = self.store.g(n)
+                self._param_views[n] = p
+        for n, p in self._param_views.items():
+            yield (prefix + "." if prefix else "") + n, p       # same keys as state_dict() (save_checkpoint maps to the torch-1.9 names)
 
-    def eval(self):
-        return self.train(False)
+    def parameters(self, recurse: bool = True):
+        for _, p in self.named_parameters(recurse=recurse):
+            yield p
+
+    def _apply(self, fn, recurse: bool = True):
+        return self            # .to() / .cuda() / .half() / .float(): the engine keeps its device and precision
 
     def _set_body_trainable(self, flag: bool) -> None:
         """``wav2vec.model.{feature_projection,encoder}.requires_grad_``: only all-or-nothing freezes exist on this
@@ -322,8 +343,6 @@ class Wav2vec2FCModule:
         embedding = self.compute_speaker_embedding(input_tensor)
         return embedding, self.compute_speaker_prediction(embedding)
 
-    __call__ = forward
-
     def generate_example_input(self, include_batch_dimension: bool, batch_size: Optional[int] = None):
         # ref: wav2vec2_fc.py:321-337
         shape = [batch_size, 16000] if include_batch_dimension else [16000]
@@ -393,10 +412,10 @@ class Wav2vec2FCModule:
         return plan.ensemble_embeddings(x.to(self.device), self.cfg.num_ensembles)
 
     # ------------------------------------------------------------------ checkpoints (reference key names)
-    def state_dict(self):
+    def state_dict(self, *args, **kwargs):
         return self.store.state_dict()
 
-    def load_state_dict(self, sd, strict: bool = True):
+    def load_state_dict(self, sd, strict: bool = True, assign: bool = False):
         self.store.load_state_dict(sd, strict=strict, prefix_model=False)
 
     def save_checkpoint(self, path: str, legacy_weight_norm_names: bool = True) -> None:

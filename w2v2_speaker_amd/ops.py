@@ -115,16 +115,16 @@ class Gemm:
         # mirrors the host dispatch of csrc/gemm.hip (w2v2_gemm): which kernel this descriptor launches
         fast = (lp and not transA and not transB and K % 64 == 0 and K >= 64 and lda % 8 == 0 and ldb % 8 == 0)
         if fast and split_k <= 1 and not accumulate and (b_lo is not None or (N >= 512 and M >= 1024)):
-            self.kernel_name = "gemm_bf16_glds3_kernel"
+            self.kernel_name = "gemm16_ring_256x128_kernel"
             t4, t3 = -(-M // 256) * -(-N // 256), -(-M // 256) * -(-N // 128)      # csrc/gemm.hip: 256x256 vs 256x128 tiles
             fill = lambda t: t / (-(-t // 256) * 256)
             if (b_lo is None and N >= 512 and batch == 1 and t4 * 2 >= 256 and fill(t4) * 1.25 >= fill(t3)
                     and N / (-(-N // 256) * 256) >= 0.9 and not os.environ.get("W2V2_NO_GLDS4")):
-                self.kernel_name = "gemm_bf16_glds4_kernel" if os.environ.get("W2V2_NO_GEMM_PH") else "gemm_ph_kernel"
+                self.kernel_name = "gemm16_ring_256x256_kernel" if os.environ.get("W2V2_NO_GEMM_PH") else "gemm16_phased_256x256_kernel"
         elif fast:
-            self.kernel_name = "gemm_bf16_glds_kernel"
+            self.kernel_name = "gemm16_dma_128_kernel"
         else:
-            self.kernel_name = "gemm_bf16_kernel" if lp else "gemm_f32_kernel"
+            self.kernel_name = "gemm16_regstage_kernel" if lp else "gemm_f32_kernel"
 
     _prof = None
     _log = None        # tools/gemm_instep.py: when a list, every launch appends its shape key (launch order)

@@ -559,7 +559,7 @@ class ParamStore:
             # Head-only steps and steps with a trainable CNN scan their whole slice.
             if head_only:
                 ops.grad_scaler_check(self.grad, h, sc)
-            elif n_train > self.n_body:
+            elif n_train > self.n_body or os.environ.get("W2V2_SCALER_FULL_SCAN"):      # (debug: scan the whole arena)
                 ops.grad_scaler_check(self.grad, n_train, sc)
             else:
                 lo = self.offsets[W2V_PREFIX + "encoder.layer_norm.weight"]
