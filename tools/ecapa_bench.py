@@ -28,7 +28,7 @@ import torch
 
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E ~8 TB/s
 MFMA_PEAK_TFLOPS = 2500.0
-PMC_FILE = os.path.join(ROOT, "profiles", "r02_ecapa_pmc_counters.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r03_ecapa_pmc_counters.json")
 
 
 FAMILY_KERNELS = {
@@ -113,7 +113,7 @@ def bench_ecapa(args, world, rank, dev, dist):
     ft.wrap("se_bwd_x", "se_gate", lambda d, g_, ds, dx, B, T, C: 2 * B * T * C * esz(d))
     ft.wrap("im2col_reflect", "im2col", lambda x, ldx, col, B, T, Cin, k, dil: (1 + k) * B * T * Cin * esz(x))
     ft.wrap("col2im_reflect", "im2col", lambda dcol, dx, lddx, B, T, Cin, k, dil, acc: (k + 1 + int(acc)) * B * T * Cin * esz(dx))
-    ft.wrap("add_strided", "res2net_add", lambda a, lda, b, ldb, y, ldy, M, C: 3 * M * C * esz(a))
+    ft.wrap("add_strided", "res2net_add", lambda a, lda, b, ldb, y, ldy, M, C: (3 if b is not None else 2) * M * C * esz(a))
 
     def sync():
         torch.cuda.synchronize()

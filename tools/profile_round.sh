@@ -22,6 +22,17 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/prof_w -- $BENCH --steps 2 --w
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d /tmp/prof_m -- $BENCH --steps 2 --warmup 1 > $OUT/${TAG}_prof_m.log 2>&1
 python3 $OLDPWD/tools/pmc_counters.py /tmp/prof_f /tmp/prof_w /tmp/prof_m > $OUT/${TAG}_pmc_counters.json 2> $OUT/${TAG}_pmc_err.log
 cd $OLDPWD
+# bench.py / tools/ecapa_bench.py read the counters from profiles/: refresh that copy BEFORE the line is produced, so the
+# line's traffic / mfma_busy fields come from counters taken on exactly these kernel sources (pmc_stale: false)
+cp $OUT/${TAG}_pmc_counters.json profiles/${TAG}_pmc_counters.json
+if [ -z "$MODEL" ]; then
+  # per-shape in-step table of the matrix-core launches (tools/gemm_instep.py)
+  cd /tmp; rm -rf /tmp/prof_is
+  rocprofv3 --kernel-trace -d /tmp/prof_is -- python3 $OLDPWD/tools/gemm_instep.py run $OUT/${TAG}_gemm_seq.json --steps 6 > $OUT/${TAG}_instep_run.log 2>&1
+  DBI=$(find /tmp/prof_is -name "*.db" | head -1)
+  python3 $OLDPWD/tools/gemm_instep.py join $OUT/${TAG}_gemm_seq.json $DBI $OUT/${TAG}_instep_by_shape.txt > $OUT/${TAG}_instep_join.log 2>&1
+  cd $OLDPWD
+fi
 unset W2V2_BENCH_NO_FAMILY_PASS
 python3 bench.py $MODEL > $OUT/${TAG}_bench_line.json 2> $OUT/${TAG}_bench_err.log
 tail -c 600 $OUT/${TAG}_bench_line.json
