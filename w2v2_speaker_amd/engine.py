@@ -150,10 +150,10 @@ class Plan:
     def _e(self, *shape, dtype=None) -> torch.Tensor:
         return torch.empty(*shape, dtype=dtype or self.adt, device=self.dev)
 
-    def _ep(self, rows: int, cols: int) -> torch.Tensor:
-        """[rows, cols] activation whose storage is padded with ZERO rows up to a multiple of 64: it can
-        be the K-major operand of the grouped weight-gradient GEMM (csrc/wgrad.hip contract)."""
-        rp = (rows + 63) // 64 * 64
+    def _ep(self, rows: int, cols: int, pad_rows: int = 0) -> torch.Tensor:
+        """[rows, cols] activation whose storage is padded with ZERO rows up to a multiple of 64 (at least
+        ``pad_rows``): it can be the K-major operand of the grouped weight-gradient GEMM (csrc/wgrad.hip contract)."""
+        rp = max((rows + 63) // 64 * 64, pad_rows)
         full = torch.zeros(rp, cols, dtype=self.adt, device=self.dev)
         v = full[:rows]
         v._w2v2_padded = full
@@ -177,7 +177,14 @@ class Plan:
             self.dwp = torch.zeros(max(C[i] * cfg.conv_kernel[i] * cins[i] for i in range(1, len(C))), dtype=f32,
                                    device=self.dev)
             self.sums0 = self._e(Bc, C[0], 2, dtype=f32)
-        self.ln_feat = self._ep(self.M0, C[-1])
+        # The projection's weight gradient is ONE small problem (768 x 512 outputs = 12 tiles) over all M0 tokens: alone
+        # in a grouped launch it ran on 12 CUs for 144 us.  Its token dimension is cut into PROJ_SLICES slices of
+        # proj_slice_len rows (a multiple of 64), each a problem of its own writing its own partial (96 workgroups),
+        # summed in a fixed order afterwards -- which needs the two operands zero-padded up to slices * slice_len rows
+        self.proj_slices = 8
+        self.proj_slice_len = -(-self.M0 // (self.proj_slices * 64)) * 64
+        proj_pad = self.proj_slices * self.proj_slice_len
+        self.ln_feat = self._ep(self.M0, C[-1], proj_pad)
         self.mean_f, self.rstd_f = self._e(self.M0, dtype=f32), self._e(self.M0, dtype=f32)
         self.h0 = self._e(self.M0, H)                          # projection output (pre-CLS)
         self.hx = self._e(M, H) if (self.cls or self.paired) else self.h0       # encoder input
@@ -238,7 +245,7 @@ class Plan:
         if self.train:
             self.demb = (self.head.demb if (self.head is not None and getattr(self, "fc", None) is None)
                          else self._e(self.head_rows, E, dtype=f32))
-            self.G = self._ep(M, H)           # running activation gradient
+            self.G = self._ep(M, H, 0 if (self.cls or self.paired) else proj_pad)           # running activation gradient
             # Gradient scratch of one layer's backward: Gd = df (after the dropout mask of the FFN residual branch),
             # Gd1 = da (attention residual branch), DH, DQKV.  TWO sets, used by alternating layers: the grouped
             # weight-gradient launch then covers a PAIR of layers (8 problems = 216 tiles of 256x256, one full round
@@ -251,7 +258,7 @@ class Plan:
             self.dwf = self._e(G, K * self.Cg, self.Cg, dtype=f32)
             self.pos_dot = self._e(129 * K, dtype=f32)
             self.dn = self._e(self.M0, C[-1])
-            self.G0 = self._ep(self.M0, H) if (self.cls or self.paired) else None
+            self.G0 = self._ep(self.M0, H, proj_pad) if (self.cls or self.paired) else None
             if self.fused:
                 self.delta = self._e(B * heads * T, dtype=f32)
             else:
@@ -342,7 +349,7 @@ class Plan:
                 self.grouped = st.flat_lp_t is not None      # bf16 mode: one grouped, atomic-free wgrad launch
                 if self.grouped:
                     pad = lambda t: t._w2v2_padded
-                    Mp = pad(self.G).shape[0]
+                    Mp = (M + 63) // 64 * 64
                     gl["wgrad_problems"] = [
                         (pad(gs["Gd"]), pad(lb.h), mg(pre + "feed_forward.output_dense.weight"),
                          mg(pre + "feed_forward.output_dense.bias")),
@@ -387,7 +394,7 @@ class Plan:
         # weight gradients of two consecutive layers (l, l-1; l counted down from the top) in one launch
         self.g_wgrad_pair = {}
         if self.train and getattr(self, "grouped", False) and not os.environ.get("W2V2_NO_WGRAD_PAIRS"):
-            Mp = self.G._w2v2_padded.shape[0]
+            Mp = (M + 63) // 64 * 64
             for l in range(L - 1, 0, -2):
                 self.g_wgrad_pair[l] = WgradGroup(self.g_layer[l]["wgrad_problems"] +
                                                   self.g_layer[l - 1]["wgrad_problems"], M, Mp)
@@ -405,10 +412,12 @@ class Plan:
                                  aux_strides=(0, Cg))
             g0 = self.G0 if (self.cls or self.paired) else self.G
             if st.flat_lp_t is not None:
-                self.g_proj_dw = WgradGroup([(g0._w2v2_padded, self.ln_feat._w2v2_padded,
-                                              mg("feature_projection.projection.weight"),
-                                              mg("feature_projection.projection.bias"))], self.M0,
-                                            g0._w2v2_padded.shape[0])
+                S, Ls, Cf = self.proj_slices, self.proj_slice_len, C[-1]
+                self.proj_parts = torch.zeros(S, H * Cf + H, dtype=torch.float32, device=self.dev)   # [slice][dW | db]
+                g0p, lnp = g0._w2v2_padded, self.ln_feat._w2v2_padded
+                assert g0p.shape[0] >= S * Ls and lnp.shape[0] >= S * Ls
+                self.g_proj_dw = WgradGroup([(g0p[i * Ls:], lnp[i * Ls:], self.proj_parts[i, :H * Cf].view(H, Cf),
+                                              self.proj_parts[i, H * Cf:]) for i in range(S)], Ls, Ls)
             else:
                 self.g_proj_dw = Gemm(H, C[-1], self.M0, g0, self.ln_feat, mg("feature_projection.projection.weight"),
                                       lda=H, ldb=C[-1], ldc=C[-1], transA=True, transB=True,
@@ -693,6 +702,11 @@ class Plan:
         self.g_proj_dw()
         if st.flat_lp_t is None:
             ops.colsum(g0, mg("feature_projection.projection.bias"), self.M0, H)
+        else:          # fixed-order sum of the slices' partials (one writer per column: no atomics race, reproducible)
+            S, Cf = self.proj_slices, cfg.conv_dim[-1]
+            ld = H * Cf + H
+            ops.colsum(self.proj_parts, mg("feature_projection.projection.weight").view(-1), S, H * Cf, ld)
+            ops.colsum(self.proj_parts[:, H * Cf:], mg("feature_projection.projection.bias"), S, H, ld)
         self.g_proj_dn()
         ops.layernorm_bwd(self.dn, self.conv[-1].view(self.M0, -1), self.mean_f, self.rstd_f,
                           mp("feature_projection.layer_norm.weight"), self.dn, None,

@@ -489,8 +489,8 @@ class ParamStore:
         With this step's LayerDrop decisions (``skip_layers``, possibly empty) and the grouped weight-gradient path
         (16-bit modes): only what the backward ACCUMULATES into -- LayerNorm gamma / beta, pos-conv bias and weight-norm
         pair, masked_spec_embed, the head's small tensors -- plus the whole slice of every skipped layer.  The Linear
-        weights / biases of the encoder and the projection (99 % of the arena) are WRITTEN by w2v2_wgrad_grouped, the
-        AAM weight by the head's normalisation backward, so zeroing them first is wasted HBM traffic."""
+        weights / biases of the encoder (99 % of the arena) are WRITTEN by w2v2_wgrad_grouped, the AAM weight by the
+        head's normalisation backward, so zeroing them first is wasted HBM traffic."""
         if skip_layers is None or self.flat_lp_t is None or not self.freeze_cnn:
             self.grad.zero_()
             return
@@ -511,7 +511,7 @@ class ParamStore:
             for m in ("attention.q_proj", "attention.k_proj", "attention.v_proj", "attention.out_proj",
                       "feed_forward.intermediate_dense", "feed_forward.output_dense"):
                 written |= {pre + m + ".weight", pre + m + ".bias"}
-        written |= {P + "feature_projection.projection.weight", P + "feature_projection.projection.bias"}
+        # (the projection's gradient is the fixed-order SUM of per-slice partials added into a zeroed target: not listed)
         if self.head == "aam":
             written.add("loss_fn.fc_weights")
         rng = []
