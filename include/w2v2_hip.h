@@ -124,6 +124,17 @@ typedef struct {
 } w2v2_wgrad_problem;
 int w2v2_wgrad_grouped(const w2v2_wgrad_problem* problems, int n, int tokens, int tokens_padded,
                        int dtype /* W2V2_BF16 or W2V2_F16: element type of dY and X */, void* stream);
+/* The same with a caller-owned scratch buffer that allows STREAM-K when the group has fewer 256x256 tiles than the chip
+ * has CUs (the two-transformer-block group of w2v2-base: 216 tiles on 256 CUs): one owner workgroup per tile runs the
+ * first K steps, the remaining CUs run the tails and hand their partial tiles over through the workspace; the owner adds
+ * them in a fixed order (bitwise reproducible; results differ from the plain launch only in the summation split).
+ * EXPERIMENTAL and off unless the environment has W2V2_WGRAD_STREAMK=1 (measured on MI355X: not faster than the plain
+ * launch); without it the call is w2v2_wgrad_grouped.  w2v2_wgrad_workspace_bytes() = the size this
+ * group needs (0: stream-K does not apply, pass NULL).  The buffer must be ZERO-INITIALISED ONCE (hipMemset /
+ * torch.zeros) and may be shared by all launches issued on one stream; 16-byte aligned. */
+int64_t w2v2_wgrad_workspace_bytes(const w2v2_wgrad_problem* problems, int n);
+int w2v2_wgrad_grouped_ws(const w2v2_wgrad_problem* problems, int n, int tokens, int tokens_padded, int dtype,
+                          void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------ conv feature extractor
  * Layer 0 of HF:382-419: Conv1d(1->C,k,stride,no bias) + GroupNorm(C groups == per-(b,c) over time,
