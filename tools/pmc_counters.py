@@ -12,7 +12,9 @@ Matrix-pipe utilisation: SQ_VALU_MFMA_BUSY_CYCLES counts the cycles a SIMD's mat
 v_mfma_f32_16x16x32: checked against the launches' MFMA counts), summed over the chip's 256 CUs x 4 SIMDs;
 GRBM_GUI_ACTIVE is the dispatch's duration in shader clocks, reported as the SUM over the 8 XCD instances (one row per
 dispatch in the rocpd database; GUI_ACTIVE / 8 / duration = 2.2 GHz, the clock under profiling).
-mfma_busy = MFMA_BUSY / (1024 SIMDs * GUI_ACTIVE / 8)."""
+mfma_busy = MFMA_BUSY / (1024 SIMDs * GUI_ACTIVE / 8).
+clock_ghz = GUI_ACTIVE / 8 / the dispatch's wall time in the same (profiled) pass: the chip clocks to its power budget
+(MI355X_MICROARCH.md "DVFS give-back"), so matrix-core kernels run below the 2.4 GHz the MFMA peak is quoted at."""
 import glob
 import json
 import re
@@ -58,12 +60,24 @@ def per_kernel(d, counter, how="sum"):
     return out
 
 
+def durations(d):
+    """kernel name -> summed wall time (ns) of its dispatches in this pass"""
+    db = glob.glob(d + "/**/*.db", recursive=True)[0]
+    cur = sqlite3.connect(db).cursor()
+    out = {}
+    for name, ns in cur.execute("select name, sum(end - start) from kernels group by name"):
+        name = re.sub(r"\(.*", "", demangle(name)).replace("void ", "")
+        out[name] = out.get(name, 0) + ns
+    return out
+
+
 def main():
     dF, dW, dM = sys.argv[1:4]
     f, w = per_kernel(dF, "FETCH_SIZE"), per_kernel(dW, "WRITE_SIZE")
     mf = per_kernel(dM, "SQ_VALU_MFMA_BUSY_CYCLES")
     sb = per_kernel(dM, "SQ_BUSY_CYCLES")
     ga = per_kernel(dM, "GRBM_GUI_ACTIVE")
+    dur = durations(dM)
     out = {"note": "rocprofv3 PMC passes of `python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline` (B=66, fp16 mode), "
                    "one counter group per pass; read bytes = 2 * FETCH_SIZE KiB (gfx950 correction), write bytes = "
                    "WRITE_SIZE KiB; mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs * GRBM_GUI_ACTIVE / 8 XCD instances).",
@@ -83,6 +97,8 @@ def main():
             rec["mfma_busy_cycles_per_launch"] = round(mf[name][1] / mf[name][0], 1)
             rec["gui_active_cycles_per_launch"] = round(ga[name][1] / ga[name][0] / N_XCD, 1)
             rec["mfma_busy"] = round(mf[name][1] / (N_SIMD * ga[name][1] / N_XCD), 4)
+            if dur.get(name, 0) > 0:
+                rec["clock_ghz"] = round(ga[name][1] / N_XCD / dur[name], 3)
             if name in sb and sb[name][1] > 0:
                 rec["sq_busy_cycles_per_launch"] = round(sb[name][1] / sb[name][0], 1)
         out["kernels"][name] = rec

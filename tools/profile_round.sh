@@ -16,7 +16,9 @@ cd /tmp
 rm -rf /tmp/prof_ks /tmp/prof_f /tmp/prof_w /tmp/prof_m
 rocprofv3 --kernel-trace --stats -d /tmp/prof_ks -- $BENCH --steps 8 --warmup 3 > $OUT/${TAG}_prof_ks.log 2>&1
 DB=$(find /tmp/prof_ks -name "*.db" | head -1)
-python3 $OLDPWD/tools/prof_summary.py $DB 11 > $OUT/${TAG}_kernel_stats.txt 2>&1
+# the last 8 steps only (steady state: start-up copies / fills / weight packing left out), delimited by the
+# once-per-step adam_kernel
+python3 $OLDPWD/tools/prof_summary.py $DB 8 --steady adam_kernel > $OUT/${TAG}_kernel_stats.txt 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/prof_f -- $BENCH --steps 2 --warmup 1 > $OUT/${TAG}_prof_f.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/prof_w -- $BENCH --steps 2 --warmup 1 > $OUT/${TAG}_prof_w.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d /tmp/prof_m -- $BENCH --steps 2 --warmup 1 > $OUT/${TAG}_prof_m.log 2>&1

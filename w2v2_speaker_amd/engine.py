@@ -509,7 +509,7 @@ class Plan:
             xin = self.X[l] if self.all_x else self.X[l % 2]
             xout = self.X[l + 1] if self.all_x else self.X[(l + 1) % 2]
             if l in self._skip:                 # LayerDrop (HF:698-709): the layer is the identity
-                xout.copy_(xin)
+                ops.copy_strided(xin, H, xout, H, xin.shape[0], H)
                 continue
             lb, gl = self.lb[l if tr else 0], self.g_layer[l]
             pre = f"encoder.layers.{l}."
