@@ -255,7 +255,8 @@ def run(args):
         trainer.train_step(wav, label)
     sync()
     skipped0 = int(store.scaler[3]) if store.scaler is not None else 0
-    ring = ("gemm16_ring_256x128_kernel", "gemm16_ring_256x256_kernel", "gemm16_phased_256x256_kernel")
+    ring = ("gemm16_ring_256x128_kernel", "gemm16_ring_256x256_kernel", "gemm16_phased_256x256_kernel",
+            "gemm16_quad_256x256_kernel")
     ops.Gemm.profile_begin(lambda g: g.kernel_name in ring)
     n_skip_layers = 0
     t0 = time.perf_counter()
@@ -310,7 +311,9 @@ def run(args):
                                               "out-proj, FFN2 forward + the N<=2304 data-gradient products",
                     "gemm16_ring_256x256_kernel": "256x256x32 4-stage LDS-DMA ring MFMA GEMM: conv1-3, FFN1 forward, dH",
                     "gemm16_phased_256x256_kernel": "256x256x64 phased LDS-DMA MFMA GEMM (two wave groups in anti-phase): conv1-3, "
-                                      "FFN1 forward, dH"}
+                                      "FFN1 forward, dH",
+                    "gemm16_quad_256x256_kernel": "256x256x64 4-wave register-staged MFMA GEMM (128x128 wave tiles, AGPR "
+                                                  "accumulators): conv1-3, FFN1 forward, dH"}
             pmc, pmc_stale = {}, None
             try:     # HBM bytes per launch and matrix-pipe busy fraction from the committed PMC passes of this command
                 # (separate rocprofv3 --pmc runs: a timed run cannot carry counters); stale = the kernel sources have
@@ -322,6 +325,17 @@ def run(args):
             except Exception:
                 pass
             tsym = {"f16": "_Float16", "bf16": "unsigned short"}.get(args.dtype, "")
+            # what the chip sustains on NOTHING BUT register-resident 16-bit MFMAs with random operands on all CUs
+            # (tools/probes/mfma_sustained_probe, committed output): the power-limited ceiling under `peak`
+            sustained = None
+            try:
+                for ln in open(os.path.join(ROOT, "profiles", "r03_mfma_sustained.txt")):
+                    f = ln.split()
+                    if len(f) == 5 and f[0] == "256" and f[1] == "1" and f[2] == "random":
+                        sustained = float(f[4])
+                        break
+            except Exception:
+                pass
 
             def entry(name, k):
                 ach = k["flops"] / (k["ms"] * 1e-3) / 1e12
@@ -332,6 +346,8 @@ def run(args):
                         # shader clock the kernel ran at in the profiled pass (GRBM_GUI_ACTIVE / wall time; the chip clocks
                         # to its power budget) and the fraction of the MFMA peak AT THAT CLOCK -- `frac` stays against
                         # the 2.4 GHz figure
+                        "peak_sustained_measured": sustained,
+                        "frac_of_sustained": round(ach / sustained, 4) if sustained else None,
                         "clock_ghz": rec.get("clock_ghz"),
                         "frac_at_clock": (round(ach / (MFMA_PEAK_TFLOPS * rec["clock_ghz"] / 2.4), 4)
                                           if rec.get("clock_ghz") else None),

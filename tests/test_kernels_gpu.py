@@ -184,6 +184,60 @@ def test_gemm_ring_kernels_at_full_size(M, N, K, epi, lp):
         assert float(C[:, N:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("M,N,K", [(9834, 3072, 768), (32768, 2048, 64), (19734, 512, 1024), (16384, 1024, 128)])
+@pytest.mark.parametrize("epi", ["none", "bias_gelu_grad", "mul", "add", "bias", "scale_rc"])
+@pytest.mark.parametrize("lp", LP16)
+def test_gemm_four_wave_register_staged_kernel(M, N, K, epi, lp):
+    """gemm16_quad_256x256_kernel (family 5 of w2v2_tune_gemm_kernel; W2V2_GEMM_QUAD=1 makes it the 256x256 kernel): one
+    wave per SIMD with 128x128 wave tiles, operands staged through registers, accumulators pinned in AGPRs.  It shares
+    the LDS image, the k-slot order and the epilogues with the phased 8-wave kernel, so every output must be BIT-EQUAL to
+    that kernel's (family 4) -- plus the f32 reference bound.  K = 64 is a single K tile (prologue only), ragged M."""
+    o = ops()
+    g = torch.Generator(device="cpu").manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g).to(lp).to(DEV)
+    Bm = (torch.randn(N, K, generator=g) / K ** 0.5).to(lp).to(DEV)
+    ref = A.float() @ Bm.float().t()
+    kw, aux_in = {}, None
+    if epi in ("bias", "bias_gelu_grad"):
+        bias = torch.randn(N, generator=g).to(DEV)
+        kw.update(epilogue=o.EPI_BIAS if epi == "bias" else o.EPI_BIAS_GELU_GRAD, bias=bias)
+        ref = ref + bias
+        if epi == "bias_gelu_grad":
+            ref = torch.nn.functional.gelu(ref)
+    elif epi == "scale_rc":
+        rs, cs = torch.rand(M, generator=g).to(DEV) + 0.5, torch.rand(N, generator=g).to(DEV) + 0.5
+        kw.update(epilogue=o.EPI_SCALE_RC, row_scale=rs, col_scale=cs)
+        ref = ref * rs[:, None] * cs[None, :]
+    elif epi in ("add", "mul"):
+        aux_in = torch.randn(M, N, generator=g).to(lp).to(DEV)
+        kw.update(epilogue=o.EPI_ADD if epi == "add" else o.EPI_MUL)
+        ref = ref + aux_in.float() if epi == "add" else ref * aux_in.float()
+    outs = {}
+    try:
+        for fam in (4, 5):
+            for cdt in (lp, torch.float32):
+                C = torch.full((M, N), float("nan"), dtype=cdt, device=DEV)
+                k2 = dict(kw)
+                if epi == "bias_gelu_grad":
+                    k2.update(aux=torch.full((M, N), float("nan"), dtype=cdt, device=DEV), ldaux=N)
+                elif aux_in is not None:
+                    k2.update(aux=aux_in.to(cdt), ldaux=N)
+                o.lib().w2v2_tune_gemm_kernel(fam)
+                o.gemm(M, N, K, A, Bm, C, lda=K, ldb=K, ldc=N, **k2)
+                torch.cuda.synchronize()
+                outs[(fam, cdt)] = (C, k2.get("aux") if epi == "bias_gelu_grad" else None)
+    finally:
+        o.lib().w2v2_tune_gemm_kernel(0)
+    for cdt in (lp, torch.float32):
+        C4, x4 = outs[(4, cdt)]
+        C5, x5 = outs[(5, cdt)]
+        assert torch.equal(C4, C5), (M, N, K, epi, cdt, float((C4.float() - C5.float()).abs().max()))
+        if x4 is not None:
+            assert torch.equal(x4, x5)
+        err = float((C5.float() - ref).norm() / ref.norm())
+        assert err < (4e-3 if cdt != torch.float32 else 2e-5 * K ** 0.5 + 1e-6), (M, N, K, epi, cdt, err)
+
+
 @pytest.mark.parametrize("M,N,K,nfrom", [(2100, 768, 256, 0), (9834, 2304, 768, 1536), (1500, 640, 64, 256)])
 def test_gemm_two_term_weights(M, N, K, nfrom):
     """fp16 products with two-term weights (w2v2_gemm_desc.k_ext): columns >= n_ext_from see W = hi + lo, i.e. the

@@ -148,6 +148,18 @@ template <> __device__ __forceinline__ f32x4_hw mfma16<f16_t>(frag8_t a, frag8_t
                                                 0);
 }
 
+// The same instruction with the accumulator PINNED in AGPRs and updated in place (gemm16_quad_256x256_kernel: 256
+// accumulator registers per wave = the whole AGPR file; left to the register allocator, the builtin form rotates the
+// tuples through v_accvgpr moves, ~500 per K tile).  Plain asm (not volatile, no memory clobber): the compiler still
+// schedules it, waits for the LDS reads that produce a / b, and keeps it in program order with its own accumulator only.
+template <typename T> __device__ __forceinline__ void mfma16_agpr(frag8_t a, frag8_t b, f32x4_hw& c);
+template <> __device__ __forceinline__ void mfma16_agpr<bf16_t>(frag8_t a, frag8_t b, f32x4_hw& c) {
+  asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+}
+template <> __device__ __forceinline__ void mfma16_agpr<f16_t>(frag8_t a, frag8_t b, f32x4_hw& c) {
+  asm("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+}
+
 // acc + lo + hi of one packed pair, as ONE v_dot2c_f32_{bf16,f16} against a (1, 1) pair: column sums of fragments
 // that are in registers anyway (bias gradients).  The (1, 1) operand must live in a VGPR: as a 32-bit literal
 // (what the compiler emits for a constant) the packed-16 operand of v_dot2c is not read as two halves on gfx950 and

@@ -1469,6 +1469,283 @@ static void launch_ph(GemmArgs a, int M, int N, int batch, hipStream_t st) {
   hipLaunchKernelGGL((gemm16_phased_256x256_kernel<TE, TC>), grid, dim3(512), lds, st, a);
 }
 
+// ------------------------------------------------------------------------------ 4-wave register-staged 256x256x64
+// ONE wave per SIMD, 128 x 128 per wave (2 x 2 waves): 0.25 ds_read_b128 per v_mfma_f32_16x16x32 instead of the 0.375 /
+// 0.5 of the 8-wave kernels above (their fragment reads + operand writes take the whole 128 B/clk LDS port for the 2048
+// MFMA cycles of a K tile: 192 + 64 KB; here 128 + 64 KB).  With a single instruction stream per SIMD an LDS-DMA piece
+// (~100 issue cycles each, 16 per K tile) would sit in front of the MFMAs (the round-2 4-wave kernel kept LDS-DMA and
+// lost 20 %), so the operands are staged global_load_dwordx4 -> 64 VGPRs -> ds_write_b128.  The 256 accumulators are
+// pinned in AGPRs by the asm form of the MFMA (mfma16_agpr); the main loop then uses 224 VGPRs with no spill.
+// A K tile is two phases of 64 MFMAs in 32 fenced slots of two MFMAs + at most two other instructions:
+//   phase 0: fragments of k-step 1 (16 ds_read) | 8 global loads A(K tile + 2) | staging of B(K tile + 1) -> other buffer
+//   barrier  (the only one per K tile)
+//   phase 1: fragments of the next K tile's k-step 0 | 8 global loads B(K tile + 2) | staging of A(K tile + 2)
+// OPT-IN (W2V2_GEMM_QUAD=1 / family 5 of w2v2_tune_gemm_kernel): bit-equal to the phased kernel on every epilogue, and
+// measured 0-10 % SLOWER than it (DESIGN.md section 4 has the per-shape table and the time attribution).
+// Same LDS image, swizzles, B row order and epilogues as gemm16_phased_256x256_kernel.
+template <typename TE, typename TC>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void gemm16_quad_256x256_kernel(const GemmArgs g) {
+  constexpr int BM = 256, BN = 256, BK = 64, FM = 8;
+  constexpr int BUF = (BM + BN) * BK;             // elements per K-tile buffer: A [256][64] then B [256][64]
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);
+
+  const int wave_s = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);   // 0..3
+  const int ntile = g.tiles_m * g.tiles_n;
+  const int G = gridDim.x;
+  const int z = blockIdx.z;
+  const int z0 = z / g.batch_inner, z1 = z - z0 * g.batch_inner;
+  const int nk = g.K >> 6;
+  const bf16_t* Ab = reinterpret_cast<const bf16_t*>(g.A.ptr) + z0 * g.a_s0 + z1 * g.a_s1;
+  const bf16_t* Bb = reinterpret_cast<const bf16_t*>(g.B.ptr) + z0 * g.b_s0 + z1 * g.b_s1;
+
+#pragma unroll 1
+  for (int t0 = 0; t0 < ntile; t0 += G) {
+    const int nchunk = min(G, ntile - t0);
+    if ((int)blockIdx.x >= nchunk) break;
+    const int tile = t0 + xcd_remap(blockIdx.x, nchunk);
+    // (divisors made opaque per tile: hoisted out of the tile loop, their reciprocals live in VGPRs across the main
+    // loop, where there is none to spare)
+    int tiles_n = g.tiles_n;
+    asm volatile("" : "+s"(tiles_n));
+    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    // the thread index is rebuilt per tile from the wave number (an SGPR) and the lane count, and made opaque:
+    // everything derived from it below is recomputed per tile (a few VALU instructions) instead of being kept alive --
+    // and spilled -- across the main loop and the pointer set-up; a kernel that touches scratch at all pays ~8 us per
+    // dispatch (tools/probes/scratch_probe.hip)
+    int tid;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(tid));
+    tid += wave_s * 64;
+    // staging: thread -> 16-byte chunk sc of rows srow + 32 u (u < 8) of each operand tile
+    const int srow = tid >> 3, sc = tid & 7;
+    int soa[8], sob[8];                              // 32-bit element offsets of the 16 source chunks (host: fits32)
+    {
+      // one row offset at a time (sched_barrier): the general form is a 64-bit division per row, and sixteen of them
+      // interleaved need more registers than the wave has
+      auto offs = [&](const OpDev& o, int t0r, int bound, int (&so)[8]) {
+        bool fast = t0r + 256 <= bound;
+        int64_t seg_base = 0;
+        int first = t0r;
+        int sl = (int)o.seg_len;                       // (row counts fit an int)
+        asm volatile("" : "+s"(sl));
+        if (sl > 0) {
+          const int q0 = t0r / sl, q1 = (t0r + 255) / sl;
+          fast = fast && q0 == q1;
+          seg_base = (int64_t)q0 * o.seg_stride;
+          first = t0r - q0 * sl;
+        }
+        if (fast) {
+          const int b0 = (int)(seg_base + (int64_t)(first + srow) * o.ld) + (sc << 3);
+          const int step = (int)(32 * o.ld);
+#pragma unroll
+          for (int u = 0; u < 8; ++u) so[u] = b0 + u * step;
+        } else {
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int r = min(t0r + srow + 32 * u, bound - 1);
+            int64_t off = (int64_t)r * o.ld;
+            if (sl > 0) {
+              const int q = r / sl;
+              off = (int64_t)q * o.seg_stride + (int64_t)(r - q * sl) * o.ld;
+            }
+            so[u] = (int)off + (sc << 3);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      };
+      offs(g.A, m0, g.M, soa);
+      offs(g.B, n0, g.N, sob);
+    }
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // 0..3
+    const int wr = wave >> 1, wc = wave & 1;
+    const int frow = lane & 15, fk = lane >> 4;
+    const int sw = swz(frow);
+    // fragment offsets (elements) inside a buffer for k-step 0 / 1; A fragment i: + i * 16 * 64, B fragment (h, j):
+    // + h * 64 * 64 + j * 4 * 64 (B rows are taken in the order (rho >> 2) * 16 + j * 4 + (rho & 3), see the phased kernel)
+    const int la0 = (wr * 128 + frow) * 64 + ((fk ^ sw) << 3);
+    const int la1 = (wr * 128 + frow) * 64 + (((4 + fk) ^ sw) << 3);
+    const int brow = (frow >> 2) * 16 + (frow & 3);
+    const int lb0 = BM * 64 + (wc * 128 + brow) * 64 + ((fk ^ sw) << 3);
+    const int lb1 = BM * 64 + (wc * 128 + brow) * 64 + (((4 + fk) ^ sw) << 3);
+    // LDS staging addresses: the swizzles depend on row bits 0..2 (A) / 0, 1, 4 (B) only, so one address per operand +
+    // immediates for the rows srow + 32 u
+    const int wa = (tid >> 3) * 64 + (((tid & 7) ^ swz(tid >> 3)) << 3);
+    const int wb = BM * 64 + (tid >> 3) * 64 + (((tid & 7) ^ swz_b(tid >> 3)) << 3);
+    f32x4 accL[FM][4], accR[FM][4];                  // columns wc * 128 + {0..63, 64..127}
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) accL[i][j] = accR[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // Registers of the main loop: fragments a[8] + b[8] + bn[8] (a[i] is re-read for the next k-step as soon as row i
+    // of the current one is done, the next B fragments need their own registers) = 96, staging ra[8] + rb[8] = 64.
+    // Staging life times (tile T in buffer T & 1, the barrier sits at the end of phase 0):
+    //   A(T): loaded at the start of phase 0 of K tile T - 2, written at the end of phase 1 of T - 2
+    //   B(T): loaded at the start of phase 1 of K tile T - 2, written at the end of phase 0 of T - 1
+    // -> both are ~1.8 phases in flight, both land in their buffer after the barrier that ends its last reads and before
+    //    the barrier in front of the first read of tile T (phase 1 of T - 1).
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+    u32x4 ra[8], rb[8];
+    frag8_t a[8], b[8], bn[8];
+#define W2V2_Q_GLOAD(dst_, base_, so_, kt_)                                                               \
+    _Pragma("unroll") for (int u = 0; u < 8; ++u)                                                         \
+      dst_[u] = *reinterpret_cast<const u32x4*>(base_ + (so_[u] + (kt_) * 64));
+#define W2V2_Q_LWRITE1(src_, buf_, w_, u_)                                                                \
+    *reinterpret_cast<u32x4*>(smem + (buf_) * BUF + w_ + (u_) * 32 * 64) = src_[u_];
+#define W2V2_Q_LWRITE(src_, buf_, w_)                                                                     \
+    W2V2_Q_LWRITE1(src_, buf_, w_, 0) W2V2_Q_LWRITE1(src_, buf_, w_, 1) W2V2_Q_LWRITE1(src_, buf_, w_, 2)  \
+    W2V2_Q_LWRITE1(src_, buf_, w_, 3) W2V2_Q_LWRITE1(src_, buf_, w_, 4) W2V2_Q_LWRITE1(src_, buf_, w_, 5)  \
+    W2V2_Q_LWRITE1(src_, buf_, w_, 6) W2V2_Q_LWRITE1(src_, buf_, w_, 7)
+#define W2V2_Q_RA(buf_, la_, i_) (*reinterpret_cast<const frag8_t*>(smem + (buf_) * BUF + la_ + (i_) * 16 * 64))
+#define W2V2_Q_RB(buf_, lb_, i_)                                                                          \
+    (*reinterpret_cast<const frag8_t*>(smem + (buf_) * BUF + lb_ + ((i_) >> 2) * 64 * 64 + ((i_) & 3) * 4 * 64))
+    // A phase is 32 slots of two MFMAs (row i_ of the wave tile x B fragments j_, 4 + j_) + at most two other
+    // instructions, each slot fenced by a sched_barrier: with ONE wave per SIMD whatever is issued in a bunch (the
+    // compiler's choice: all eight global loads with their address arithmetic in front of the first MFMA, four LDS
+    // writes back to back) is issue time the matrix pipe idles through -- measured on conv1: +89 us for the loads and
+    // +82 us for the writes on top of 479 us of MFMAs + prologue / epilogue (temporary variants with the loads / the
+    // writes / the fragment reads / the MFMAs compiled out); one at a time they fit in the 12 free cycles of an MFMA.
+#define W2V2_Q_SLOT(bc_, av_, i_, j_, OPS_)                                                               \
+    {                                                                          \
+      mfma16_agpr<TE>(bc_[j_], av_, accL[i_][j_]);                                                        \
+      mfma16_agpr<TE>(bc_[4 + (j_)], av_, accR[i_][j_]);                                                  \
+    }                                                                                                     \
+    OPS_                                                                                                  \
+    __builtin_amdgcn_sched_barrier(0);
+#define W2V2_Q_GL1(dst_, base_, so_, kt_, u_)                                                             \
+    dst_[u_] = *reinterpret_cast<const u32x4*>(base_ + (so_[u_] + (kt_) * 64));
+#define W2V2_Q_FA(rbuf_, la_, i_) a[i_] = W2V2_Q_RA(rbuf_, la_, i_);
+#define W2V2_Q_FA7(dst_, rbuf_, la_) dst_ = W2V2_Q_RA(rbuf_, la_, 7);
+#define W2V2_Q_FB(bnx_, rbuf_, lb_, i_) bnx_[i_] = W2V2_Q_RB(rbuf_, lb_, i_);
+    // one phase = 64 MFMAs of the current fragments (a[0..6], a7c_ x bc_) + the reads of the next ones: a[i] in place
+    // once row i is done, the last row's fragment and the B fragments into their second copies (a7n_, bnx_) -- so the
+    // last LDS instruction of a phase sits six MFMAs before its end and the lgkmcnt(0) in front of the barrier / of the
+    // next phase's first MFMA finds nothing to wait for; the 8 global loads of gdst_ in rows 0..3, the 8 LDS writes of
+    // wsrc_ in rows 4..6
+#define W2V2_Q_PHASE(bc_, bnx_, a7c_, a7n_, rbuf_, la_, lb_, gdst_, gbase_, gso_, gkt_, wsrc_, wbuf_, w_) \
+    W2V2_Q_SLOT(bc_, a[0], 0, 0, W2V2_Q_GL1(gdst_, gbase_, gso_, gkt_, 0))                                \
+    W2V2_Q_SLOT(bc_, a[0], 0, 1, W2V2_Q_FB(bnx_, rbuf_, lb_, 0))                                          \
+    W2V2_Q_SLOT(bc_, a[0], 0, 2, W2V2_Q_GL1(gdst_, gbase_, gso_, gkt_, 1))                                \
+    W2V2_Q_SLOT(bc_, a[0], 0, 3, W2V2_Q_FB(bnx_, rbuf_, lb_, 1))                                          \
+    W2V2_Q_SLOT(bc_, a[1], 1, 0, W2V2_Q_FA(rbuf_, la_, 0))                                                \
+    W2V2_Q_SLOT(bc_, a[1], 1, 1, W2V2_Q_GL1(gdst_, gbase_, gso_, gkt_, 2))                                \
+    W2V2_Q_SLOT(bc_, a[1], 1, 2, W2V2_Q_FB(bnx_, rbuf_, lb_, 2))                                          \
+    W2V2_Q_SLOT(bc_, a[1], 1, 3, W2V2_Q_GL1(gdst_, gbase_, gso_, gkt_, 3) W2V2_Q_FB(bnx_, rbuf_, lb_, 3)) \
+    W2V2_Q_SLOT(bc_, a[2], 2, 0, W2V2_Q_FA(rbuf_, la_, 1))                                                \
+    W2V2_Q_SLOT(bc_, a[2], 2, 1, W2V2_Q_GL1(gdst_, gbase_, gso_, gkt_, 4))                                \
+    W2V2_Q_SLOT(bc_, a[2], 2, 2, W2V2_Q_FB(bnx_, rbuf_, lb_, 4))                                          \
+    W2V2_Q_SLOT(bc_, a[2], 2, 3, W2V2_Q_GL1(gdst_, gbase_, gso_, gkt_, 5) W2V2_Q_FB(bnx_, rbuf_, lb_, 5)) \
+    W2V2_Q_SLOT(bc_, a[3], 3, 0, W2V2_Q_FA(rbuf_, la_, 2))                                                \
+    W2V2_Q_SLOT(bc_, a[3], 3, 1, W2V2_Q_GL1(gdst_, gbase_, gso_, gkt_, 6))                                \
+    W2V2_Q_SLOT(bc_, a[3], 3, 2, W2V2_Q_FB(bnx_, rbuf_, lb_, 6))                                          \
+    W2V2_Q_SLOT(bc_, a[3], 3, 3, W2V2_Q_GL1(gdst_, gbase_, gso_, gkt_, 7) W2V2_Q_FB(bnx_, rbuf_, lb_, 7)) \
+    W2V2_Q_SLOT(bc_, a[4], 4, 0, W2V2_Q_FA(rbuf_, la_, 3))                                                \
+    W2V2_Q_SLOT(bc_, a[4], 4, 1, W2V2_Q_LWRITE1(wsrc_, wbuf_, w_, 0))                                     \
+    W2V2_Q_SLOT(bc_, a[4], 4, 2, W2V2_Q_FA7(a7n_, rbuf_, la_))                                            \
+    W2V2_Q_SLOT(bc_, a[4], 4, 3, W2V2_Q_LWRITE1(wsrc_, wbuf_, w_, 1))                                     \
+    W2V2_Q_SLOT(bc_, a[5], 5, 0, W2V2_Q_FA(rbuf_, la_, 4))                                                \
+    W2V2_Q_SLOT(bc_, a[5], 5, 1, W2V2_Q_LWRITE1(wsrc_, wbuf_, w_, 2))                                     \
+    W2V2_Q_SLOT(bc_, a[5], 5, 2, W2V2_Q_LWRITE1(wsrc_, wbuf_, w_, 3))                                     \
+    W2V2_Q_SLOT(bc_, a[5], 5, 3, W2V2_Q_LWRITE1(wsrc_, wbuf_, w_, 4))                                     \
+    W2V2_Q_SLOT(bc_, a[6], 6, 0, W2V2_Q_FA(rbuf_, la_, 5))                                                \
+    W2V2_Q_SLOT(bc_, a[6], 6, 1, W2V2_Q_LWRITE1(wsrc_, wbuf_, w_, 5))                                     \
+    W2V2_Q_SLOT(bc_, a[6], 6, 2, W2V2_Q_LWRITE1(wsrc_, wbuf_, w_, 6))                                     \
+    W2V2_Q_SLOT(bc_, a[6], 6, 3, W2V2_Q_LWRITE1(wsrc_, wbuf_, w_, 7))                                     \
+    W2V2_Q_SLOT(bc_, a7c_, 7, 0, W2V2_Q_FA(rbuf_, la_, 6))                                                \
+    W2V2_Q_SLOT(bc_, a7c_, 7, 1, )                                                                        \
+    W2V2_Q_SLOT(bc_, a7c_, 7, 2, )                                                                        \
+    W2V2_Q_SLOT(bc_, a7c_, 7, 3, )
+    // ---- prologue: K tile 0 in buffer 0, A(1) in buffer 1, B(1) in rb, fragments of (tile 0, k-step 0)
+    const int k1 = min(1, nk - 1);
+    __builtin_amdgcn_s_barrier();                    // every wave has left the previous tile's buffers
+    {
+      u32x4 ta[8];                                   // A(1) travels with K tile 0 (one global latency, not two)
+      W2V2_Q_GLOAD(ra, Ab, soa, 0);
+      W2V2_Q_GLOAD(rb, Bb, sob, 0);
+      W2V2_Q_GLOAD(ta, Ab, soa, k1);
+      W2V2_Q_LWRITE(ra, 0, wa)
+      W2V2_Q_LWRITE(rb, 0, wb)
+      W2V2_Q_GLOAD(rb, Bb, sob, k1);                 // (first needed in row 4 of the first phase)
+      W2V2_Q_LWRITE(ta, 1, wa)
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { a[i] = W2V2_Q_RA(0, la0, i); b[i] = W2V2_Q_RB(0, lb0, i); }
+    frag8_t a7x = a[7], a7y = a[7];
+
+#pragma unroll 1
+    for (int kt = 0; kt < nk; ++kt) {
+      const int cur = kt & 1, oth = cur ^ 1;
+      const int kg = min(kt + 2, nk - 1);            // (the last two K tiles re-load the last one: never consumed)
+      // ---------------- phase 0: k-step 0 of tile kt; reads k-step 1; A(kt+2) -> ra; rb = B(kt+1) -> other buffer
+      W2V2_Q_PHASE(b, bn, a7x, a7y, cur, la1, lb1, ra, Ab, soa, kg, rb, oth, wb)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      // ---------------- phase 1: k-step 1 of tile kt; reads k-step 0 of tile kt+1; B(kt+2) -> rb; ra = A(kt+2) -> cur
+      W2V2_Q_PHASE(bn, b, a7y, a7x, oth, la0, lb0, rb, Bb, sob, kg, ra, cur, wa)
+    }
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the last MFMAs have written their AGPRs (asm: no hazard tracking)
+#undef W2V2_Q_SLOT
+#undef W2V2_Q_GL1
+#undef W2V2_Q_FA
+#undef W2V2_Q_FA7
+#undef W2V2_Q_FB
+#undef W2V2_Q_LWRITE1
+#undef W2V2_Q_PHASE
+#undef W2V2_Q_RA
+#undef W2V2_Q_RB
+#undef W2V2_Q_GLOAD
+#undef W2V2_Q_LWRITE
+
+    TC* Cz = reinterpret_cast<TC*>(g.C) + z0 * g.c_s0 + z1 * g.c_s1;
+    TC* auxz = g.aux ? reinterpret_cast<TC*>(g.aux) + z0 * g.aux_s0 + z1 * g.aux_s1 : nullptr;
+    const float* bias = g.bias ? g.bias + z1 * g.bias_s1 : nullptr;
+    int nc = n0 + wc * 128 + fk * 16, mr = m0 + wr * 128 + frow;
+    asm volatile("" : "+v"(nc), "+v"(mr));
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      float cv0[8], cv1[8];
+      load_col8(g, bias, nc + 64 * h, cv0);
+      load_col8(g, bias, nc + 64 * h + 8, cv1);
+      if constexpr (sizeof(TC) == 2) {       // (the host sends 16-bit outputs here only where lines_ok holds)
+        W2V2_EPI_DISPATCH((epilogue_lines<TC, EPI, FM>(g, Cz, auxz, h ? accR : accL, mr - frow, nc + 64 * h, lane, cv0, cv1,
+                                                       nullptr)));
+      } else {
+        W2V2_EPI_DISPATCH((epilogue_direct<TC, EPI, FM, 2>(g, Cz, auxz, h ? accR : accL, mr, nc + 64 * h, cv0, cv1)));
+      }
+    }
+  }   // tile loop
+}
+
+template <typename TE, typename TC>
+static void launch_quad(GemmArgs a, int M, int N, int batch, hipStream_t st) {
+  constexpr size_t lds = (size_t)2 * (256 + 256) * 64 * sizeof(bf16_t);   // 128 KiB
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm16_quad_256x256_kernel<TE, TC>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  a.tiles_m = (int)cdiv(M, 256);
+  a.tiles_n = (int)cdiv(N, 256);
+  const int tiles = a.tiles_m * a.tiles_n;
+  int ncu = 256;
+  {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
+  }
+  dim3 grid(tiles < ncu ? tiles : ncu, 1, batch);
+  hipLaunchKernelGGL((gemm16_quad_256x256_kernel<TE, TC>), grid, dim3(256), lds, st, a);
+}
+
 static const bool g_w2v2_no_glds = getenv("W2V2_NO_GLDS") != nullptr;   // A/B switches for benchmarking
 static const bool g_w2v2_glds3 = getenv("W2V2_NO_GLDS3") == nullptr;
 static const bool g_w2v2_ph = getenv("W2V2_NO_GEMM_PH") == nullptr;
@@ -1788,11 +2065,13 @@ static void launch_bf16(const GemmArgs& a, dim3 grid, hipStream_t st) {
 }
 
 // tuning hook (tools/gemm_shapes.py): force the kernel family of the K-contiguous 16-bit products.
-//   0 = dispatch below, 1 = 128x128 LDS-DMA, 2 = 256x128 ring, 3 = 256x256x32 ring, 4 = 256x256x64 phased
+//   0 = dispatch below, 1 = 128x128 LDS-DMA, 2 = 256x128 ring, 3 = 256x256x32 ring, 4 = 256x256x64 phased,
+//   5 = 256x256x64 4-wave register-staged
 static int g_w2v2_force = 0;
+static const bool g_w2v2_quad = getenv("W2V2_GEMM_QUAD") != nullptr;    // A/B: 4-wave kernel wherever the phased one runs
 extern "C" int w2v2_tune_gemm_kernel(int family) {
   const int old = g_w2v2_force;
-  if (family >= 0 && family <= 4) g_w2v2_force = family;
+  if (family >= 0 && family <= 5) g_w2v2_force = family;
   return old;
 }
 
@@ -1883,12 +2162,13 @@ extern "C" int w2v2_gemm(const w2v2_gemm_desc* d, void* stream) {
       huge = lines && fill4 * 1.25 >= fill3 && t4 * 2 >= ncu &&
              (double)d->N / (double)(cdiv(d->N, 256) * 256) >= 0.9 && (fits32 || !g_w2v2_ph);
     }
-    bool big_ = big, force_ph = true;
+    bool big_ = big, force_ph = true, quad = g_w2v2_quad;
     if (g_w2v2_force != 0 && glds && split == 1 && !atomic && d->k_ext == 0 && d->batch == 1) {
       big_ = g_w2v2_force >= 2;
       huge = g_w2v2_force >= 3 && (d->dtype_c == W2V2_F32 ||
                                    (a.c_vec_ok && (d->N % 64 == 0) && (d->aux == nullptr || a.aux_vec_ok)));
-      force_ph = g_w2v2_force == 4;
+      force_ph = g_w2v2_force >= 4;
+      quad = g_w2v2_force == 5;
     }
     if (d->k_ext != 0)
       W2V2_REQUIRE(big && !huge && d->k_ext == d->K && d->n_ext_from >= 0 && d->n_ext_from % 128 == 0 &&
@@ -1898,7 +2178,8 @@ extern "C" int w2v2_gemm(const w2v2_gemm_desc* d, void* stream) {
     // TE = operand element type (selects the MFMA instruction), TC = float or TE
 #define W2V2_GEMM_LAUNCH(TE, TC)                                                                         \
     do {                                                                                                 \
-      if (huge && g_w2v2_ph && force_ph) launch_ph<TE, TC>(a, d->M, d->N, d->batch, st);                  \
+      if (huge && g_w2v2_ph && force_ph && quad) launch_quad<TE, TC>(a, d->M, d->N, d->batch, st);        \
+      else if (huge && g_w2v2_ph && force_ph) launch_ph<TE, TC>(a, d->M, d->N, d->batch, st);             \
       else if (huge) launch_glds4<TE, TC>(a, d->M, d->N, d->batch, st);                                  \
       else if (big_) launch_glds3<TE, TC>(a, d->M, d->N, d->batch, st);                                  \
       else if (glds) { if (narrow) launch_glds<TE, 4, 2, TC>(a, grid, st); else launch_glds<TE, 4, 4, TC>(a, grid, st); } \

@@ -120,7 +120,9 @@ class Gemm:
             fill = lambda t: t / (-(-t // 256) * 256)
             if (b_lo is None and N >= 512 and batch == 1 and t4 * 2 >= 256 and fill(t4) * 1.25 >= fill(t3)
                     and N / (-(-N // 256) * 256) >= 0.9 and not os.environ.get("W2V2_NO_GLDS4")):
-                self.kernel_name = "gemm16_ring_256x256_kernel" if os.environ.get("W2V2_NO_GEMM_PH") else "gemm16_phased_256x256_kernel"
+                self.kernel_name = ("gemm16_ring_256x256_kernel" if os.environ.get("W2V2_NO_GEMM_PH") else
+                                    "gemm16_quad_256x256_kernel" if os.environ.get("W2V2_GEMM_QUAD") else
+                                    "gemm16_phased_256x256_kernel")
         elif fast:
             self.kernel_name = "gemm16_dma_128_kernel"
         else:
