@@ -343,14 +343,8 @@ def run(args):
                 return {"bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": rec.get("hbm_bytes_per_launch"),
                         "mfma_busy": rec.get("mfma_busy"),
-                        # shader clock the kernel ran at in the profiled pass (GRBM_GUI_ACTIVE / wall time; the chip clocks
-                        # to its power budget) and the fraction of the MFMA peak AT THAT CLOCK -- `frac` stays against
-                        # the 2.4 GHz figure
                         "peak_sustained_measured": sustained,
                         "frac_of_sustained": round(ach / sustained, 4) if sustained else None,
-                        "clock_ghz": rec.get("clock_ghz"),
-                        "frac_at_clock": (round(ach / (MFMA_PEAK_TFLOPS * rec["clock_ghz"] / 2.4), 4)
-                                          if rec.get("clock_ghz") else None),
                         "pmc_source": os.path.relpath(PMC_FILE, ROOT), "pmc_stale": pmc_stale,
                         "kernel": f"{name}<{args.dtype}> ({desc[name]})", "launches": k["launches"],
                         "ms_per_step": round(k["ms"] / args.steps, 3),

@@ -390,14 +390,16 @@ int w2v2_row_invnorm(const void* x, int64_t ld, float* inv, int rows, int cols, 
  * and for the backward, with g = dLoss/dcos (loss = mean over B):
  *   dcos_w[b][c] = g * inv_w[c]   (A operand of the embedding-gradient GEMM; inv_w NULL -> g)
  *   dcos_x[b][c] = g * inv_x[b]   (A operand of the weight-gradient GEMM;    inv_x NULL -> g)
- *   rowdot[b] = sum_c g*cos,  coldot[c] += sum_b g*cos (caller zeroes coldot); any may be NULL.
+ *   rowdot[b] = sum_c g*cos,  colprod[b][c] = g*cos ([B][C] f32, row stride C: the caller folds the rows in a fixed
+ *   order -- w2v2_colsum with B <= 128 has one writer per column -- into coldot[c] = sum_b g*cos for
+ *   w2v2_normalize_bwd; no atomics, so the head's weight gradient is bitwise reproducible); any may be NULL.
  * loss_scale (device pointer, may be NULL = 1): g is multiplied by *loss_scale (w2v2_grad_scaler_*); the loss
  * rows and the softmax are never scaled.  Labels outside [0, C) give loss = NaN for that row and zero gradients.
  * correct_rows [B] (may be NULL): 1 if argmax_c softmax[b][c] == label[b] else 0 -- the reference's train_acc
  * (ref: src/lightning_modules/speaker/speaker_recognition_module.py:296-307). */
 int w2v2_aam_softmax_fwd_bwd(const float* cos, const int64_t* label, float* softmax,
                              float* loss_rows, void* dcos_w, void* dcos_x, const float* inv_x,
-                             const float* inv_w, float* rowdot, float* coldot, int B, int C,
+                             const float* inv_w, float* rowdot, float* colprod, int B, int C,
                              int64_t ldc, float margin, float scale, const float* loss_scale,
                              float* correct_rows, int dtype, void* stream);
 /* F.normalize backward: dx = inv[r] * (g[r] - x[r] * inv[r] * dot[r]);  g, dx f32 (dx written or

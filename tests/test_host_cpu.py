@@ -419,24 +419,36 @@ def test_hot_kernels_use_no_scratch(tmp_path):
 
 
 def test_committed_bench_lines_follow_the_contract():
-    """The JSON lines bench.py printed on the GPU box (committed under profiles/) carry every field the driver's
-    contract names; roofline.frac is achieved / peak; the ECAPA line has an HBM roofline per kernel family."""
+    """The JSON lines bench.py printed on the GPU box (committed under profiles/, every round's) carry every field the
+    driver's contract names; roofline.frac is achieved / peak; the round-3 line says which PMC file its traffic / busy
+    figures come from, whether the kernels have changed since, what the matrix pipe sustains (measured) and the bf16
+    mode under `also`; the ECAPA line (configs[4]) is at the reference's f32 precision with an HBM roofline per family."""
     import json
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    line = json.load(open(os.path.join(root, "profiles", "r02_bench_line.json")))
-    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
-        assert k in line, k
-    assert line["unit"] == "utterances/sec" and line["higher_is_better"] is True and line["vs_baseline"] is None
-    assert line["dtype"] == "f16" and line["data"] == "synthetic" and "workload" in line["config"]
-    assert "model" not in line["config"]
-    r = line["roofline"]
-    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 2500.0
-    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
-    assert isinstance(r["traffic"], int) and 0 < r["mfma_busy"] < 1
-    assert abs(line["value"] - line["config"]["global_batch"] / (line["ms_per_step"] * 1e-3)) < 0.01 * line["value"]
-    c = line["cpu_baseline"]
-    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
-    e = json.load(open(os.path.join(root, "profiles", "r02_ecapa_bench_line.json")))
-    assert e["roofline"]["bound"] == "hbm" and e["roofline"]["unit"] == "GB/s" and e["roofline"]["peak"] == 8000.0
-    assert e["roofline"]["traffic"] > 0 and len(e["roofline_families"]) >= 3
+    for tag in ("r02", "r03"):
+        line = json.load(open(os.path.join(root, "profiles", f"{tag}_bench_line.json")))
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                  "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+            assert k in line, (tag, k)
+        assert line["unit"] == "utterances/sec" and line["higher_is_better"] is True and line["vs_baseline"] is None
+        assert line["dtype"] == "f16" and line["data"] == "synthetic" and "workload" in line["config"]
+        assert "model" not in line["config"]
+        r = line["roofline"]
+        assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 2500.0
+        assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+        assert isinstance(r["traffic"], int) and 0 < r["mfma_busy"] < 1
+        assert abs(line["value"] - line["config"]["global_batch"] / (line["ms_per_step"] * 1e-3)) < 0.01 * line["value"]
+        c = line["cpu_baseline"]
+        assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+        e = json.load(open(os.path.join(root, "profiles", f"{tag}_ecapa_bench_line.json")))
+        assert e["roofline"]["bound"] == "hbm" and e["roofline"]["unit"] == "GB/s" and e["roofline"]["peak"] == 8000.0
+        assert e["roofline"]["traffic"] > 0 and len(e["roofline_families"]) >= 3
+    # round 3: self-evidencing fields
+    assert r["pmc_source"] == "profiles/r03_pmc_counters.json" and r["pmc_stale"] is False
+    assert 1500.0 < r["peak_sustained_measured"] < 2500.0
+    assert abs(r["frac_of_sustained"] - r["achieved"] / r["peak_sustained_measured"]) < 1e-3
+    b16 = line["also"]["bf16"]
+    assert b16["unit"] == "utterances/sec" and abs(b16["value"] - 66 / (b16["ms_per_step"] * 1e-3)) < 0.01 * b16["value"]
+    assert e["dtype"] == "f32" and e["gemm_mfma"]["peak"] == 157.3 and "gemm_f32_mfma_kernel" in e["gemm_mfma"]["by_kernel"]
+    pmc = json.load(open(os.path.join(root, "profiles", "r03_pmc_counters.json")))
+    assert len(pmc["source_hash"]) == 16 and "gemm16_ring_256x128_kernel<_Float16, _Float16>" in pmc["kernels"]

@@ -1175,6 +1175,38 @@ def test_selective_zero_grad_equals_full_zero_under_layerdrop():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("lp", [torch.float16, torch.float32])
+def test_aam_head_gradients_are_bitwise_reproducible(lp):
+    """The AAM head's class-weight gradient needs coldot[c] = sum_b g * cos for the F.normalize backward.  It used to be
+    accumulated with f32 atomics from one workgroup per batch row (run-to-run differences in the last bit of
+    loss_fn.fc_weights' gradient, which made test_selective_zero_grad_... flaky); now the kernel stores the products and
+    a one-writer column sum folds them in a fixed order.  66 rows x 5994 classes (the benchmark's head), ten repeats of
+    the same head step on the same embedding: every gradient and d(emb) bit-equal."""
+    from w2v2_speaker_amd.config import W2V2Config
+    from w2v2_speaker_amd.engine import Plan
+    from w2v2_speaker_amd.params import ParamStore
+    cfg = W2V2Config.tiny()
+    st = ParamStore(cfg, DEV, lp, head="aam", num_speakers=5994)
+    st.init_weights(3)
+    plan = Plan(st, 66, 4000, train=True)
+    g = torch.Generator(device="cpu").manual_seed(5)
+    plan.emb.copy_(torch.randn(plan.emb.shape, generator=g).to(DEV))
+    label = torch.randint(0, 5994, (66,), generator=g).to(DEV)
+    ref = None
+    for _ in range(10):
+        st.grad.zero_()
+        loss, _ = plan.head_forward_backward(label)
+        torch.cuda.synchronize()
+        got = (st.g("loss_fn.fc_weights").clone(), plan.demb.clone(), loss.clone())
+        assert all(bool(torch.isfinite(t).all()) for t in got)
+        if ref is None:
+            ref = got
+        else:
+            assert all(torch.equal(a, b) for a, b in zip(ref, got))
+    assert float(ref[0].abs().max()) > 0
+
+
+@pytest.mark.gpu
 def test_adam_step_count_does_not_advance_on_skipped_steps():
     """torch's GradScaler does not call optimizer.step() when the gradients overflowed, so Adam's step count -- and its
     bias corrections -- only count applied updates.  The host-side counter of the engine advances every call (it never

@@ -187,18 +187,39 @@ __device__ __forceinline__ void tile_store(const TileRegs& r, bf16_t* lds) {
   }
 }
 
+// Workgroup -> (row tile, head, utterance).  The grid is ONE-dimensional and the index is remapped so that every XCD
+// (workgroup id % 8) owns a contiguous run of logical indices: the ceil(T / 64) row tiles of one (utterance, head) --
+// which all stream the SAME K / V (forward, dQ) or Q / dO (dK, dV) rows -- then sit on the same XCD at the same time and
+// share them in its L2.  With the 3-D grid (row tile fastest) they were dealt out to three different XCDs and each
+// fetched the operands from HBM itself: 121 / 152 / 155 MB per launch against ~60 algorithmic at T = 149 (PMC, round 2).
+struct AttnBlock { int tile, h, b; };
+__device__ __forceinline__ AttnBlock attn_block(int ntile_rows, int heads) {
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+  int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  if (heads < 0) { logical = bid; heads = -heads; }       // A/B switch (W2V2_ATTN_NO_XCD_REMAP): dispatch order
+  AttnBlock o;
+  o.tile = logical % ntile_rows;
+  const int bh = logical / ntile_rows;
+  o.h = bh % heads;
+  o.b = bh / heads;
+  return o;
+}
+
 template <typename TE>
 __global__ __launch_bounds__(256, 4) void attn_fwd_tiled_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx,
-                                                             float* __restrict__ lse, int Tn, int heads, float scale,
+                                                             float* __restrict__ lse, int Tn, int heads_s, float scale,
                                                              float dp, float inv_keep, uint64_t seed) {
   __shared__ __attribute__((aligned(16))) bf16_t Ks[2][AT_TILE * 64];
   __shared__ __attribute__((aligned(16))) bf16_t Vs[2][AT_TILE * 64];
-  const int b = blockIdx.z, h = blockIdx.y;
+  const AttnBlock blk = attn_block((Tn + 63) >> 6, heads_s);
+  const int heads = heads_s < 0 ? -heads_s : heads_s;
+  const int b = blk.b, h = blk.h, row_tile = blk.tile;
   const int H = heads * HD;
   const int64_t gs = 3 * (int64_t)H;
   const bf16_t* qb = qkv + (int64_t)b * Tn * gs + h * HD;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
-  const int q = blockIdx.x * 64 + wave * 16 + (lane & 15);
+  const int q = row_tile * 64 + wave * 16 + (lane & 15);
   const int64_t bh = (int64_t)b * heads + h;
   frag8_t qf[2];
   reg_frag(qf, qb, gs, q, Tn, lane);
@@ -214,7 +235,7 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_tiled_kernel(const bf16_t* __
   f32x4 o[4];
 #pragma unroll
   for (int df = 0; df < 4; ++df) o[df] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const bool active = blockIdx.x * 64 + wave * 16 < Tn;       // wave-uniform: any of this wave's 16 rows valid
+  const bool active = row_tile * 64 + wave * 16 < Tn;       // wave-uniform: any of this wave's 16 rows valid
 #pragma unroll 1
   for (int t = 0; t < ntile; ++t) {
     const int cur = t & 1;
@@ -297,18 +318,20 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_tiled_kernel(const bf16_t* __
                                                                 const bf16_t* __restrict__ dctx,
                                                                 const float* __restrict__ lse,
                                                                 bf16_t* __restrict__ dqkv, float* __restrict__ delta,
-                                                                int Tn, int heads, float scale, float dp,
+                                                                int Tn, int heads_s, float scale, float dp,
                                                                 float inv_keep, uint64_t seed) {
   __shared__ __attribute__((aligned(16))) bf16_t Ks[2][AT_TILE * 64];
   __shared__ __attribute__((aligned(16))) bf16_t Vs[2][AT_TILE * 64];
-  const int b = blockIdx.z, h = blockIdx.y;
+  const AttnBlock blk = attn_block((Tn + 63) >> 6, heads_s);
+  const int heads = heads_s < 0 ? -heads_s : heads_s;
+  const int b = blk.b, h = blk.h, row_tile = blk.tile;
   const int H = heads * HD;
   const int64_t gs = 3 * (int64_t)H;
   const bf16_t* qb = qkv + (int64_t)b * Tn * gs + h * HD;
   const bf16_t* dob = dctx + (int64_t)b * Tn * H + h * HD;
   const bf16_t* ob = ctx + (int64_t)b * Tn * H + h * HD;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
-  const int q = blockIdx.x * 64 + wave * 16 + (lane & 15);
+  const int q = row_tile * 64 + wave * 16 + (lane & 15);
   const int64_t bh = (int64_t)b * heads + h;
   frag8_t qf[2], dof[2], of[2];
   reg_frag(qf, qb, gs, q, Tn, lane);
@@ -331,7 +354,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_tiled_kernel(const bf16_t* __
   f32x4 o[4];
 #pragma unroll
   for (int df = 0; df < 4; ++df) o[df] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const bool active = blockIdx.x * 64 + wave * 16 < Tn;
+  const bool active = row_tile * 64 + wave * 16 < Tn;
 #pragma unroll 1
   for (int t = 0; t < ntile; ++t) {
     const int cur = t & 1;
@@ -388,19 +411,21 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_kv_tiled_kernel(const bf16_t*
                                                                 const bf16_t* __restrict__ dctx,
                                                                 const float* __restrict__ lse,
                                                                 const float* __restrict__ delta,
-                                                                bf16_t* __restrict__ dqkv, int Tn, int heads,
+                                                                bf16_t* __restrict__ dqkv, int Tn, int heads_s,
                                                                 float scale, float dp, float inv_keep, uint64_t seed) {
   __shared__ __attribute__((aligned(16))) bf16_t Qs[2][AT_TILE * 64];
   __shared__ __attribute__((aligned(16))) bf16_t Os[2][AT_TILE * 64];      // dO
   __shared__ __attribute__((aligned(16))) float lse_s[2][AT_TILE];
   __shared__ __attribute__((aligned(16))) float del_s[2][AT_TILE];
-  const int b = blockIdx.z, h = blockIdx.y;
+  const AttnBlock blk = attn_block((Tn + 63) >> 6, heads_s);
+  const int heads = heads_s < 0 ? -heads_s : heads_s;
+  const int b = blk.b, h = blk.h, row_tile = blk.tile;
   const int H = heads * HD;
   const int64_t gs = 3 * (int64_t)H;
   const bf16_t* qb = qkv + (int64_t)b * Tn * gs + h * HD;
   const bf16_t* dob = dctx + (int64_t)b * Tn * H + h * HD;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
-  const int key = blockIdx.x * 64 + wave * 16 + (lane & 15);
+  const int key = row_tile * 64 + wave * 16 + (lane & 15);
   const int64_t bh = (int64_t)b * heads + h;
   frag8_t kf[2], vf[2];
   reg_frag(kf, qb + H, gs, key, Tn, lane);
@@ -429,7 +454,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_kv_tiled_kernel(const bf16_t*
   f32x4 dv[4], dk[4];
 #pragma unroll
   for (int df = 0; df < 4; ++df) { dv[df] = f32x4{0.f, 0.f, 0.f, 0.f}; dk[df] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-  const bool active = blockIdx.x * 64 + wave * 16 < Tn;
+  const bool active = row_tile * 64 + wave * 16 < Tn;
 #pragma unroll 1
   for (int t = 0; t < ntile; ++t) {
     const int cur = t & 1;
@@ -504,14 +529,16 @@ static int attn_check(const char* nm, int B, int T, int heads, int d, int dtype,
   return 0;
 }
 
+static const bool g_attn_no_remap = getenv("W2V2_ATTN_NO_XCD_REMAP") != nullptr;
+
 template <typename TE>
 static int attention_fwd_t(const void* qkv, void* ctx, float* lse, int B, int T, int heads, float scale, float drop_p,
                            uint64_t seed, void* stream) {
   const float ik = 1.0f / (1.0f - drop_p);
   hipStream_t st = as_stream(stream);
-  dim3 grid((unsigned)cdiv(T, 64), heads, B);
+  dim3 grid((unsigned)(cdiv(T, 64) * heads * B));       // see attn_block
   hipLaunchKernelGGL((attn_fwd_tiled_kernel<TE>), grid, dim3(256), 0, st, (const bf16_t*)qkv, (bf16_t*)ctx, lse, T,
-                     heads, scale, drop_p, ik, seed);
+                     g_attn_no_remap ? -heads : heads, scale, drop_p, ik, seed);
   W2V2_CHECK_LAUNCH("attention_fwd");
   return 0;
 }
@@ -531,11 +558,12 @@ static int attention_bwd_t(const void* qkv, const void* ctx, const void* dctx, c
                            void* stream) {
   const float ik = 1.0f / (1.0f - drop_p);
   hipStream_t st = as_stream(stream);
-  dim3 grid((unsigned)cdiv(T, 64), heads, B);
+  dim3 grid((unsigned)(cdiv(T, 64) * heads * B));       // see attn_block
   hipLaunchKernelGGL((attn_bwd_dq_tiled_kernel<TE>), grid, dim3(256), 0, st, (const bf16_t*)qkv, (const bf16_t*)ctx,
-                     (const bf16_t*)dctx, lse, (bf16_t*)dqkv, delta, T, heads, scale, drop_p, ik, seed);
+                     (const bf16_t*)dctx, lse, (bf16_t*)dqkv, delta, T, g_attn_no_remap ? -heads : heads, scale, drop_p, ik,
+                     seed);
   hipLaunchKernelGGL((attn_bwd_kv_tiled_kernel<TE>), grid, dim3(256), 0, st, (const bf16_t*)qkv, (const bf16_t*)dctx,
-                     lse, (const float*)delta, (bf16_t*)dqkv, T, heads, scale, drop_p, ik, seed);
+                     lse, (const float*)delta, (bf16_t*)dqkv, T, g_attn_no_remap ? -heads : heads, scale, drop_p, ik, seed);
   W2V2_CHECK_LAUNCH("attention_bwd");
   return 0;
 }

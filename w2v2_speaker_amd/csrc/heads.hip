@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256) void aam_row_kernel(const float* __restrict__ 
                                                       T* __restrict__ dcos_w, T* __restrict__ dcos_x,
                                                       const float* __restrict__ inv_x,
                                                       const float* __restrict__ inv_w, float* __restrict__ rowdot,
-                                                      float* __restrict__ coldot, int B, int C, int64_t ldc,
+                                                      float* __restrict__ colprod, int B, int C, int64_t ldc,
                                                       float margin, float scale, const float* __restrict__ loss_scale,
                                                       float* __restrict__ correct_rows) {
   __shared__ float sh[4];
@@ -115,9 +115,9 @@ __global__ __launch_bounds__(256) void aam_row_kernel(const float* __restrict__ 
       // the two F.normalize scalings are folded into the operands of the two gradient GEMMs
       dcos_w[(int64_t)b * ldc + c] = from_f32<T>(inv_w ? g * inv_w[c] : g);
       if (dcos_x != nullptr) dcos_x[(int64_t)b * ldc + c] = from_f32<T>(inv_x ? g * inv_x[b] : g);
-      if (coldot != nullptr) {
+      if (colprod != nullptr) {
         rd = fmaf(g, cv, rd);
-        unsafeAtomicAdd(coldot + c, g * cv);
+        colprod[(int64_t)b * C + c] = g * cv;      // folded over b in a fixed order by the caller: no atomics
       }
     }
   }
@@ -129,13 +129,13 @@ __global__ __launch_bounds__(256) void aam_row_kernel(const float* __restrict__ 
 
 extern "C" int w2v2_aam_softmax_fwd_bwd(const float* cos, const int64_t* label, float* softmax, float* loss_rows,
                                         void* dcos_w, void* dcos_x, const float* inv_x, const float* inv_w,
-                                        float* rowdot, float* coldot, int B, int C, int64_t ldc, float margin,
+                                        float* rowdot, float* colprod, int B, int C, int64_t ldc, float margin,
                                         float scale, const float* loss_scale, float* correct_rows, int dtype,
                                         void* stream) {
   W2V2_REQUIRE(cos && label && softmax && loss_rows && B > 0 && C > 0 && ldc >= C, "aam_softmax: bad arguments");
   W2V2_DISPATCH_ACT(dtype, "aam_softmax",
     hipLaunchKernelGGL(aam_row_kernel<AT>, dim3(B), dim3(256), 0, as_stream(stream), cos, label, softmax,
-                       loss_rows, (AT*)dcos_w, (AT*)dcos_x, inv_x, inv_w, rowdot, coldot, B, C, ldc, margin,
+                       loss_rows, (AT*)dcos_w, (AT*)dcos_x, inv_x, inv_w, rowdot, colprod, B, C, ldc, margin,
                        scale, loss_scale, correct_rows););
   W2V2_CHECK_LAUNCH("aam_softmax");
   return 0;

@@ -48,6 +48,9 @@ class ClassifierHead:
             self._ztab = torch.tensor([[0, Cn + B * E]], dtype=torch.int64, device=dev)
             self.coldot = self._zbuf[:Cn]
             self.G1 = self._zbuf[Cn:].view(B, E)
+            # per-element g * cos of the AAM normalisation backward; folded over the batch in a fixed order (colsum with
+            # <= 128 rows has one writer per column): the class-weight gradient is bitwise reproducible
+            self.colprod = torch.empty(B, Cn, dtype=f32, device=dev) if aam else None
             self.demb = torch.empty(B, E, dtype=f32, device=dev)
             # d emb = dcos_w [B, C] . W [C, E]: 66 rows = ONE row of tiles, so the class dimension is cut into S chunks
             # (one batched launch + the ragged rest) whose f32 partials are then summed in a fixed order -- the single
@@ -86,7 +89,7 @@ class ClassifierHead:
         ops.aam_softmax_fwd_bwd(self.logits, label, self.softmax, self.loss_rows,
                                 self.dcos_w if tr else None, (self.dcos_x if aam else None) if tr else None,
                                 self.inv_x if aam else None, self.inv_w if aam else None,
-                                self.rowdot if (tr and aam) else None, self.coldot if (tr and aam) else None,
+                                self.rowdot if (tr and aam) else None, self.colprod if (tr and aam) else None,
                                 B, Cn, self.ldc, self.margin if aam else -1.0, self.scale, self.loss_scale if tr else None,
                                 self.correct)
         loss = torch.empty((), dtype=torch.float32, device=self.loss_rows.device)     # (allocator only: no kernel)
@@ -98,6 +101,7 @@ class ClassifierHead:
             if aam:
                 ops.normalize_bwd(self.G1, self.emb, self.inv_x, self.rowdot, self.demb, B, E)
                 self.g_dw()
+                ops.colsum(self.colprod, self.coldot, B, Cn)
                 ops.normalize_bwd(self.H1, self.w_master, self.inv_w, self.coldot, self.w_grad, Cn, E)
             else:
                 self.demb.copy_(self.G1)

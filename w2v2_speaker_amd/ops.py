@@ -126,7 +126,8 @@ class Gemm:
         elif fast:
             self.kernel_name = "gemm16_dma_128_kernel"
         else:
-            self.kernel_name = "gemm16_regstage_kernel" if lp else "gemm_f32_kernel"
+            self.kernel_name = ("gemm16_regstage_kernel" if lp else
+                                "gemm_f32_kernel" if os.environ.get("W2V2_F32_VALU") else "gemm_f32_mfma_kernel")
 
     _prof = None
     _log = None        # tools/gemm_instep.py: when a list, every launch appends its shape key (launch order)
@@ -505,15 +506,16 @@ def row_invnorm(x, inv, rows: int, cols: int, ld: Optional[int] = None) -> None:
                                       dt(x), stream()), "row_invnorm")
 
 
-def aam_softmax_fwd_bwd(cos, label, softmax, loss_rows, dcos_w, dcos_x, inv_x, inv_w, rowdot, coldot, B: int,
+def aam_softmax_fwd_bwd(cos, label, softmax, loss_rows, dcos_w, dcos_x, inv_x, inv_w, rowdot, colprod, B: int,
                         Cn: int, ldc: int, margin: float, scale: float, loss_scale=None, correct_rows=None) -> None:
     """loss_scale: device tensor whose first element multiplies the loss gradient (fp16 loss scaling), or None.
-    correct_rows [B] f32 (optional): 1 where the arg-max prediction equals the label (train_acc)."""
-    _dev(cos, label, softmax, loss_rows, dcos_w, dcos_x, inv_x, inv_w, rowdot, coldot, loss_scale, correct_rows)
+    correct_rows [B] f32 (optional): 1 where the arg-max prediction equals the label (train_acc).
+    colprod [B, Cn] f32 (optional): g * cos per element; colsum() over its rows gives the column dots."""
+    _dev(cos, label, softmax, loss_rows, dcos_w, dcos_x, inv_x, inv_w, rowdot, colprod, loss_scale, correct_rows)
     dty = dt(dcos_w) if dcos_w is not None else F32
     _lib.check(lib().w2v2_aam_softmax_fwd_bwd(cos.data_ptr(), label.data_ptr(), softmax.data_ptr(),
                                               loss_rows.data_ptr(), _p(dcos_w), _p(dcos_x), _p(inv_x), _p(inv_w),
-                                              _p(rowdot), _p(coldot), B, Cn, ldc, margin, scale, _p(loss_scale),
+                                              _p(rowdot), _p(colprod), B, Cn, ldc, margin, scale, _p(loss_scale),
                                               _p(correct_rows), dty, stream()),
                "aam_softmax")
 
