@@ -150,9 +150,11 @@ def bench_ecapa(args, world, rank, dev, dist):
     fwd = 2 * T * (cfg.input_mel_coefficients * cfg.kernel_sizes[0] * C[0]
                    + 3 * (2 * C[1] * C[1] + (cfg.res2net_scale - 1) * w * w * 3) + C[-1] * C[-1]
                    + C[-1] * cfg.attention_channels * 2) + 2 * (2 * C[-1] * cfg.lin_neurons + cfg.lin_neurons * 5994)
-    pmc = {}
-    try:
+    pmc, pmc_stale = {}, None
+    try:     # stale = the kernel sources have changed since the PMC passes were taken (hash recorded by pmc_counters.py)
+        from w2v2_speaker_amd._build import source_hash
         pmc = json.load(open(PMC_FILE))
+        pmc_stale = pmc.get("source_hash") != source_hash()
     except Exception:
         pass
 
@@ -173,6 +175,7 @@ def bench_ecapa(args, world, rank, dev, dist):
         ach = k["bytes"] / (k["ms"] * 1e-3) / 1e9
         return {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic(name),
+                "pmc_source": os.path.relpath(PMC_FILE, ROOT), "pmc_stale": pmc_stale,
                 "family": name, "launch_groups_per_step": k["launch_groups"] // psteps,
                 "ms_per_step": round(k["ms"] / psteps, 3),
                 "avg_us": round(1e3 * k["ms"] / k["launch_groups"], 2),

@@ -83,6 +83,21 @@ template <> __device__ __forceinline__ void unpack2<f16_t>(uint32_t w, float& lo
   hi = (float)h[1];
 }
 
+// WRITE-THROUGH 16-byte store (global_store_dwordx4 ... sc1) for the once-written outputs of a kernel.  A dependent
+// kernel boundary costs ~1.5-1.9 us + (bytes the predecessor left DIRTY in the eight L2s) / 6 TB/s
+// (MI355X_MICROARCH.md, "boundary").  Written through, the bytes leave L2 while the kernel still computes and nothing is
+// dirty at its end; the line is dropped from L2, which costs nothing here -- no kernel re-reads its own output.
+// Measured (same-box ABAB of two library builds, tools/ab_bench.sh): 12.39 -> 12.34 ms/step (-0.4 %); the 4.7 us mean gap
+// between kernels that tools/timeline_gaps.py shows under the tracer did NOT move (it is tracer + dispatch time: the
+// un-traced step is only ~0.4 ms longer than the sum of its 254 kernels = the ~1.5 us floor per boundary).
+// 16-byte stores cost the same either way; NARROWER sc1 stores are one fabric write each (2.7-12x per byte) and stay plain.
+// (asm: the compiler's hazard recogniser does not see the store read its data registers -> s_nop 1.)
+typedef __attribute__((ext_vector_type(4))) unsigned w2v2_u32x4;
+__device__ __forceinline__ void store16_wt(void* p, uint4 v) {
+  const w2v2_u32x4 d = {v.x, v.y, v.z, v.w};
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(d) : "memory");
+}
+
 // 8-element vector access (16 B for bf16, 32 B for f32); p must be 16-byte aligned.
 template <typename T> struct Vec8;
 template <> struct Vec8<float> {
@@ -92,8 +107,8 @@ template <> struct Vec8<float> {
     v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
   }
   __device__ __forceinline__ void store(float* p) const {
-    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
-    *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    store16_wt(p, make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])));
+    store16_wt(p + 4, make_uint4(__float_as_uint(v[4]), __float_as_uint(v[5]), __float_as_uint(v[6]), __float_as_uint(v[7])));
   }
 };
 template <> struct Vec8<bf16_t> {
@@ -111,7 +126,7 @@ template <> struct Vec8<bf16_t> {
     uint32_t w[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) w[i] = f32x2_to_bf16x2(v[2 * i], v[2 * i + 1]);
-    *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+    store16_wt(p, make_uint4(w[0], w[1], w[2], w[3]));
   }
 };
 
@@ -127,7 +142,7 @@ template <> struct Vec8<f16_t> {
     uint32_t w[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) w[i] = f32x2_to_f16x2(v[2 * i], v[2 * i + 1]);
-    *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+    store16_wt(p, make_uint4(w[0], w[1], w[2], w[3]));
   }
 };
 

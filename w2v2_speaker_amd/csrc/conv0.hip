@@ -209,8 +209,8 @@ __global__ __launch_bounds__(256, 2) void conv0_mfma_kernel(const float* __restr
             }
             uint4 da, db;
             halves_to_lines(lo, pack8<TO>(v), pack8<TO>(v + 8), da, db);
-            if (fa < nf) *reinterpret_cast<uint4*>(dst + u * 64) = da;
-            if (fa + 8 < nf) *reinterpret_cast<uint4*>(dst + (int64_t)8 * C + u * 64) = db;
+            if (fa < nf) store16_wt(dst + u * 64, da);
+            if (fa + 8 < nf) store16_wt(dst + (int64_t)8 * C + u * 64, db);
           }
         } else {
 #pragma unroll

@@ -374,7 +374,7 @@ __global__ __launch_bounds__(256) void transpose_many_kernel(const T* __restrict
 #pragma unroll
             for (int e = 0; e < 4; ++e)
               w[e] = (uint32_t)tile[rv + 2 * e][c] | ((uint32_t)tile[rv + 2 * e + 1][c] << 16);
-            *reinterpret_cast<uint4*>(dst + dof + (int64_t)(c0 + c) * R + r0 + rv) = make_uint4(w[0], w[1], w[2], w[3]);
+            store16_wt(dst + dof + (int64_t)(c0 + c) * R + r0 + rv, make_uint4(w[0], w[1], w[2], w[3]));
           }
         }
       }

@@ -426,15 +426,15 @@ __device__ __forceinline__ void epilogue_lines(const GemmArgs& g, TC* __restrict
         pend[2 * (i0 + i)] = da;
         pend[2 * (i0 + i) + 1] = db;
       } else {
-        if (r < g.M) *reinterpret_cast<uint4*>(Cz + (int64_t)r * g.ldc + ncs) = da;
-        if (r + 8 < g.M) *reinterpret_cast<uint4*>(Cz + (int64_t)(r + 8) * g.ldc + ncs) = db;
+        if (r < g.M) store16_wt(Cz + (int64_t)r * g.ldc + ncs, da);
+        if (r + 8 < g.M) store16_wt(Cz + (int64_t)(r + 8) * g.ldc + ncs, db);
       }
       if constexpr (WRITES_AUX) {
         if (auxz != nullptr) {
           uint4 xa, xb;
           halves_to_lines(lo, pack8<TC>(pre), pack8<TC>(pre + 8), xa, xb);
-          if (r < g.M) *reinterpret_cast<uint4*>(auxz + (int64_t)r * g.ldaux + ncs) = xa;
-          if (r + 8 < g.M) *reinterpret_cast<uint4*>(auxz + (int64_t)(r + 8) * g.ldaux + ncs) = xb;
+          if (r < g.M) store16_wt(auxz + (int64_t)r * g.ldaux + ncs, xa);
+          if (r + 8 < g.M) store16_wt(auxz + (int64_t)(r + 8) * g.ldaux + ncs, xb);
         }
       }
     }
@@ -865,7 +865,7 @@ __global__ __launch_bounds__(512) void gemm16_ring_256x128_kernel(const GemmArgs
       for (int q = decltype(first)::value; q < decltype(first)::value + decltype(count)::value; ++q) {
         const int mi = pend_m + 16 * (q >> 1) + 8 * (q & 1);
         if (mi < g.M)
-          *reinterpret_cast<uint4*>(Cdef + (int64_t)mi * g.ldc + pend_n) = pend[q];
+          store16_wt(Cdef + (int64_t)mi * g.ldc + pend_n, pend[q]);
       }
     }
   };

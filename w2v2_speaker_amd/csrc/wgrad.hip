@@ -199,8 +199,7 @@ __global__ __launch_bounds__(256) void wgrad_grouped_kernel(const WgArgs a) {
       const int r = c >> 5, ch = c & 31;
       const int m = m0 + pass * 64 + r, n = n0 + ch * 4;
       if (m < P.n_out && n + 4 <= P.n_in)
-        *reinterpret_cast<float4*>(P.dW + (int64_t)m * P.ld_dw + n) =
-            *reinterpret_cast<const float4*>(stagef + r * PITCH + ch * 4);
+        store16_wt(P.dW + (int64_t)m * P.ld_dw + n, *reinterpret_cast<const uint4*>(stagef + r * PITCH + ch * 4));
     }
   }
 }
@@ -405,8 +404,7 @@ __global__ __launch_bounds__(512) void wgrad_grouped_ring_kernel(const WgArgs a)
       const int r = c >> 5, ch = c & 31;
       const int m = m0 + pass * 128 + r, n = n0 + ch * 4;
       if (m < P.n_out && n + 4 <= P.n_in)
-        *reinterpret_cast<float4*>(P.dW + (int64_t)m * P.ld_dw + n) =
-            *reinterpret_cast<const float4*>(stagef + r * PITCH + ch * 4);
+        store16_wt(P.dW + (int64_t)m * P.ld_dw + n, *reinterpret_cast<const uint4*>(stagef + r * PITCH + ch * 4));
     }
   }
 }
@@ -679,8 +677,7 @@ __global__ __launch_bounds__(512) void wgrad_grouped_ring4_kernel(const WgArgs a
       const int r = c >> 6, ch = c & 63;
       const int m = m0 + pass * 64 + r, n = n0 + ch * 4;
       if (m < P.n_out && n + 4 <= P.n_in)
-        *reinterpret_cast<float4*>(P.dW + (int64_t)m * P.ld_dw + n) =
-            *reinterpret_cast<const float4*>(stagef + r * PITCH + ch * 4);
+        store16_wt(P.dW + (int64_t)m * P.ld_dw + n, *reinterpret_cast<const uint4*>(stagef + r * PITCH + ch * 4));
     }
   }
   }   // segment loop
