@@ -313,7 +313,7 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_tiled_kernel(const bf16_t* __
 
 // dQ (and delta[q] = sum_d dO O) for 64 queries per workgroup, streaming key tiles
 template <typename TE>
-__global__ __launch_bounds__(256) void attn_bwd_dq_tiled_kernel(const bf16_t* __restrict__ qkv,
+__global__ __launch_bounds__(256, 4) void attn_bwd_dq_tiled_kernel(const bf16_t* __restrict__ qkv,
                                                                 const bf16_t* __restrict__ ctx,
                                                                 const bf16_t* __restrict__ dctx,
                                                                 const float* __restrict__ lse,
