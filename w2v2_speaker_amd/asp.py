@@ -83,11 +83,8 @@ class AttentivePool:
                                   pad(self.ds).shape[0])
         else:
             # exact-f32 mode: the token dimension is split over ~2 workgroups per CU (f32 atomics, zeroed target)
-            def sk(m, n):
-                s_ = max(1, min(32, 512 // (-(-m // 128) * -(-n // 128))))
-                while s_ > 1 and M // s_ < 256:
-                    s_ -= 1
-                return s_
+            from .ecapa import f32_dw_split
+            sk = lambda m, n: f32_dw_split(m, n, M)
             self.g_w2 = Gemm(C, A, M, self.ds, self.h, dW2, lda=C, ldb=A, ldc=A, transA=True, transB=True,
                              split_k=sk(C, A), accumulate=True)
             self.g_w1 = Gemm(A, C, M, self.da, x, dW1, lda=A, ldb=C, ldc=3 * C, transA=True, transB=True,

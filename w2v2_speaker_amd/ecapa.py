@@ -219,6 +219,29 @@ def _cols(v: torch.Tensor, c0: int, c1: Optional[int] = None) -> torch.Tensor:
     return out
 
 
+
+def f32_dw_split(n_out: int, n_in: int, tokens: int, slots: int = 512) -> int:
+    """Split-K factor of an exact-f32 weight-gradient product dW[n_out, n_in] = dY^T X over `tokens` rows (f32 atomics
+    into a zeroed target).  The output is only n_out x n_in / 128^2 tiles -- 3 for a Res2Net chunk, 576 for the last
+    3072 x 3072 convolution -- on 512 workgroup slots (2 per CU).  Few tiles: fill the slots, at most 32 ways (more
+    splits of a 3-tile output lose to the contention of their atomics: 77 ways measured 139 us against 115 at 32).
+    More tiles than half the slots: the factor that minimises rounds / factor, i.e. the launch's quantisation loss
+    (576 tiles unsplit = 2 rounds, the second 12 % full: 5.83 ms; 8 ways = 9 full rounds of an eighth: 4.31 ms).
+    At least 256 tokens per split."""
+    tiles = -(-n_out // 128) * -(-n_in // 128)
+    if 2 * tiles <= slots:
+        sk = max(1, min(32, slots // tiles))
+    else:
+        sk, best = 1, None
+        for c in range(1, 17):
+            cost = -(-tiles * c // slots) / c * (1.0 + 0.004 * c)
+            if best is None or cost < best - 1e-9:
+                sk, best = c, cost
+    while sk > 1 and tokens // sk < 256:
+        sk -= 1
+    return sk
+
+
 class _Tdnn:
     """TDNNBlock = Conv1d("same", reflect, dilation) -> ReLU -> BatchNorm1d over one [M, Cin] view -> [M, Cout] view."""
 
@@ -250,11 +273,7 @@ class _Tdnn:
             # exact-f32 mode (no grouped launch): K of this product = the B * T tokens, its output only
             # cout x K / 128^2 tiles (3 for a Res2Net chunk) -- split the token dimension over ~2 workgroups per CU
             # (f32 atomics into a zeroed target), like the wav2vec2 engine's f32 weight gradients
-            tiles = -(-cout // 128) * -(-K // 128)
-            sk = max(1, min(32, 512 // tiles))
-            while sk > 1 and M // sk < 256:
-                sk -= 1
-            self._dw_split = sk if not self.grouped else 1
+            self._dw_split = f32_dw_split(cout, K, M) if not self.grouped else 1
             self._dwp_ztab = (torch.tensor([[0, cout * K]], dtype=torch.int64, device=dev)
                               if (k > 1 and self._dw_split > 1) else None)
             self.g_dw = Gemm(cout, K, M, self.da, A, dW, lda=cout, ldb=lda, ldc=K, transA=True, transB=True,
