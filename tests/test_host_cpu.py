@@ -452,3 +452,44 @@ def test_committed_bench_lines_follow_the_contract():
     assert e["dtype"] == "f32" and e["gemm_mfma"]["peak"] == 157.3 and "gemm_f32_mfma_kernel" in e["gemm_mfma"]["by_kernel"]
     pmc = json.load(open(os.path.join(root, "profiles", "r03_pmc_counters.json")))
     assert len(pmc["source_hash"]) == 16 and "gemm16_ring_256x128_kernel<_Float16, _Float16>" in pmc["kernels"]
+
+
+def test_f32_weight_gradient_split_factor():
+    """ecapa.f32_dw_split: few output tiles -> fill the 512 workgroup slots, at most 32 ways; more tiles than half the
+    slots -> the factor with the smallest quantisation loss; never fewer than 256 tokens per split."""
+    from w2v2_speaker_amd.ecapa import f32_dw_split
+    assert f32_dw_split(128, 384, 19800) == 32             # 3 tiles: capped (atomic contention beyond that)
+    assert f32_dw_split(1024, 1024, 19800) == 8            # 64 tiles x 8 = one full round
+    assert f32_dw_split(3072, 3072, 19800) == 8            # 576 tiles: 9 full rounds of an eighth instead of 1.125 -> 2
+    assert f32_dw_split(128, 3072, 19800) == 21
+    assert f32_dw_split(128, 384, 600) == 2                # 256 tokens per split at least
+    for n_out, n_in in ((128, 128), (1536, 3072), (4096, 4096), (200, 1024)):
+        sk = f32_dw_split(n_out, n_in, 19800)
+        assert 1 <= sk <= 32 and 19800 // sk >= 256
+
+
+def test_prof_summary_steady_state_window(tmp_path):
+    """tools/prof_summary.py --steady: only the launches between the (steps+1)-th last and the last launch of the named
+    once-per-step kernel are counted, so start-up work does not dilute the per-step table."""
+    import sqlite3
+    import subprocess
+    db = tmp_path / "t.db"
+    con = sqlite3.connect(db)
+    con.execute("create table kernels (name text, start integer, end integer)")
+    t = 0
+    rows = [("init_copy", 0, 10)] * 50                                         # start-up
+    for step in range(5):
+        for k in range(3):
+            rows.append(("gemm_kernel(args)", 1000 * (step + 1) + 10 * k, 1000 * (step + 1) + 10 * k + 8))
+        rows.append(("adam_kernel<float>(x)", 1000 * (step + 1) + 900, 1000 * (step + 1) + 950))
+    con.executemany("insert into kernels values (?, ?, ?)", rows)
+    con.commit()
+    con.close()
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "prof_summary.py"), str(db), "3", "--steady", "adam_kernel"],
+                         capture_output=True, text=True, check=True).stdout
+    assert "steady-state window: the last 3 steps" in out and "init_copy" not in out
+    line = [ln for ln in out.splitlines() if "gemm_kernel" in ln][0].split()
+    assert line[2] == "9"                                                      # 3 launches x 3 steps
+    whole = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "prof_summary.py"), str(db), "5"],
+                           capture_output=True, text=True, check=True).stdout
+    assert "init_copy" in whole
