@@ -108,6 +108,10 @@ int w2v2_gemm(const w2v2_gemm_desc* d, void* stream);
  * 16-bit products -- 0 = the library's own dispatch, 1 = 128x128, 2 = 256x128 ring, 3 = 256x256x32 ring,
  * 4 = 256x256x64 phased.  Returns the previous setting. */
 int w2v2_tune_gemm_kernel(int family);
+/* Tools only (tools/gemm_attrib.py): time-attribution / placement variants of the 256x256x64 phased kernel for fp16
+ * products -- bit 0 no DMA in the main loop, 1 no fragment reads, 2 no MFMAs, 3 no epilogue, 4 DMA pieces issued between
+ * the MFMAs.  Variants with bits 0-3 compute garbage by design.  Returns the previous setting; 0 = the product kernel. */
+int w2v2_tune_gemm_debug(int bits);
 
 /* Grouped weight-gradient GEMM (the backward of HF:520-526,544,565-572 nn.Linear weights/biases):
  *   dW_p[o][i] = sum_t dY_p[t][o] * X_p[t][i]      dbias_p[o] = sum_t dY_p[t][o]   (dbias may be NULL)

@@ -187,11 +187,12 @@ def test_gemm_ring_kernels_at_full_size(M, N, K, epi, lp):
 @pytest.mark.parametrize("M,N,K", [(9834, 3072, 768), (32768, 2048, 64), (19734, 512, 1024), (16384, 1024, 128)])
 @pytest.mark.parametrize("epi", ["none", "bias_gelu_grad", "mul", "add", "bias", "scale_rc"])
 @pytest.mark.parametrize("lp", LP16)
-def test_gemm_four_wave_register_staged_kernel(M, N, K, epi, lp):
-    """gemm16_quad_256x256_kernel (family 5 of w2v2_tune_gemm_kernel; W2V2_GEMM_QUAD=1 makes it the 256x256 kernel): one
-    wave per SIMD with 128x128 wave tiles, operands staged through registers, accumulators pinned in AGPRs.  It shares
-    the LDS image, the k-slot order and the epilogues with the phased 8-wave kernel, so every output must be BIT-EQUAL to
-    that kernel's (family 4) -- plus the f32 reference bound.  K = 64 is a single K tile (prologue only), ragged M."""
+def test_gemm_phased_kernel_bit_equal_to_ring_kernel(M, N, K, epi, lp):
+    """gemm16_phased_256x256_kernel (family 4 of w2v2_tune_gemm_kernel) against gemm16_ring_256x128_kernel (family 2): the
+    two large-tile kernels share the k-slot order of the MFMA chain and the register epilogues, so every output must be
+    BIT-EQUAL whichever tile family the dispatch picks -- plus the f32 reference bound.  K = 64 is a single K tile
+    (prologue only), ragged M.  (Round 3 ran this comparison against the 4-wave register-staged kernel, deleted in
+    round 4 after losing every A/B.)"""
     o = ops()
     g = torch.Generator(device="cpu").manual_seed(M + N + K)
     A = torch.randn(M, K, generator=g).to(lp).to(DEV)
@@ -214,7 +215,7 @@ def test_gemm_four_wave_register_staged_kernel(M, N, K, epi, lp):
         ref = ref + aux_in.float() if epi == "add" else ref * aux_in.float()
     outs = {}
     try:
-        for fam in (4, 5):
+        for fam in (4, 2):
             for cdt in (lp, torch.float32):
                 C = torch.full((M, N), float("nan"), dtype=cdt, device=DEV)
                 k2 = dict(kw)
@@ -230,7 +231,7 @@ def test_gemm_four_wave_register_staged_kernel(M, N, K, epi, lp):
         o.lib().w2v2_tune_gemm_kernel(0)
     for cdt in (lp, torch.float32):
         C4, x4 = outs[(4, cdt)]
-        C5, x5 = outs[(5, cdt)]
+        C5, x5 = outs[(2, cdt)]
         assert torch.equal(C4, C5), (M, N, K, epi, cdt, float((C4.float() - C5.float()).abs().max()))
         if x4 is not None:
             assert torch.equal(x4, x5)

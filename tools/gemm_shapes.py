@@ -3,7 +3,7 @@
 (bias, bias+GELU dual store, GELU' with aux read, residual add, two-term weight columns), fp16 operands.
 tools/gemm_bench.py times the plain product; the in-step launches carry 60-120 MB of epilogue traffic that it
 does not show.  Kernel choice follows the library's dispatch; the A/B environment switches
-of csrc/gemm.hip (W2V2_NO_GEMM_PH, W2V2_NO_GLDS4, W2V2_GEMM_FORCE=...) select alternatives per process.
+of csrc/gemm.hip (W2V2_NO_GEMM_PH, W2V2_NO_GLDS3, W2V2_NO_GLDS) select alternatives per process.
 
     python3 tools/gemm_shapes.py [filter] [--hipblaslt]
 """
@@ -39,7 +39,7 @@ SHAPES = [
 ]
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
 only = args[0] if args else None
-FAM = {0: "auto", 1: "128x128", 2: "256x128 ring", 3: "256x256x32 ring", 4: "256x256x64 phased", 5: "256x256x64 4-wave"}
+FAM = {0: "auto", 1: "128x128", 2: "256x128 ring", 4: "256x256x64 phased"}
 fams = [int(x) for x in os.environ.get("FAMILIES", "0").split(",")]
 vs_lib = "--hipblaslt" in sys.argv
 

@@ -77,6 +77,44 @@ void mfma_loop_agpr(const uint32_t* __restrict__ seed, float* __restrict__ out, 
   out[tid] = t;
 }
 
+
+// the same experiment on v_mfma_f32_32x32x16_f16 (round 4): twice the flops per instruction and per operand-register read
+// (8 + 8 operand registers feed 32768 flops instead of 16384), same nominal rate (one per 32 cycles and SIMD).  2 x 2
+// fragments, 4 accumulators of 16 registers.
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+__global__ __launch_bounds__(512) void mfma_loop32(const uint32_t* __restrict__ seed, float* __restrict__ out, int iters,
+                                                   int zero) {
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  f16x8 a[4], b[4];
+  uint32_t s = seed[tid % 4096] * 2654435761u + 12345u;
+  for (int i = 0; i < 4; ++i)
+    for (int e = 0; e < 8; ++e) {
+      s = s * 1664525u + 1013904223u;
+      a[i][e] = zero ? (_Float16)0.f : (_Float16)((float)(int)(s >> 8 & 0xffff) / 32768.f - 1.f);
+      s = s * 1664525u + 1013904223u;
+      b[i][e] = zero ? (_Float16)0.f : (_Float16)((float)(int)(s >> 8 & 0xffff) / 32768.f - 1.f);
+    }
+  f32x16 acc[2][2];
+  for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < 2; ++j)
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+#pragma unroll 1
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[(r & 1) * 2 + i], b[(r >> 1 & 1) * 2 + j], acc[i][j], 0, 0, 0);
+  }
+  float t = 0.f;
+  for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < 2; ++j)
+      for (int e = 0; e < 16; ++e) t += acc[i][j][e];
+  out[tid] = t;
+}
+
 int main() {
   uint32_t* seed;
   float* out;
@@ -120,5 +158,21 @@ int main() {
       const double flops = (double)cus * 4 * (double)iters * 64 * 16384.0;
       printf("%6d %10s %8s %10.3f %10.1f\n", cus, "1 (agpr)", zero ? "zeros" : "random", ms, flops / (ms * 1e-3) / 1e12);
     }
+  printf("# register-resident v_mfma_f32_32x32x16_f16 only (2 x 2 fragments, 4 accumulators)\n");
+  for (int zero = 0; zero < 2; ++zero)
+    for (int wps = 1; wps <= 2; ++wps)
+      for (int cus = 64; cus <= 256; cus += 64) {
+        const int iters = 60000 / wps;               // 32 MFMAs of 32768 flops per iteration and wave
+        hipLaunchKernelGGL(mfma_loop32, dim3(cus), dim3(256 * wps), 0, 0, seed, out, iters / 8, zero);
+        hipDeviceSynchronize();
+        hipEventRecord(e0, 0);
+        hipLaunchKernelGGL(mfma_loop32, dim3(cus), dim3(256 * wps), 0, 0, seed, out, iters, zero);
+        hipEventRecord(e1, 0);
+        hipEventSynchronize(e1);
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, e0, e1);
+        const double flops = (double)cus * 4 * wps * (double)iters * 32 * 32768.0;
+        printf("%6d %10d %8s %10.3f %10.1f\n", cus, wps, zero ? "zeros" : "random", ms, flops / (ms * 1e-3) / 1e12);
+      }
   return 0;
 }

@@ -11,8 +11,9 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libw2v2hip.so")
-SOURCES = ["api.hip", "gemm.hip", "wgrad.hip", "norm.hip", "elementwise.hip", "conv0.hip", "posconv.hip", "posconv_wgrad.hip",
+SOURCES = ["api.hip", "gemm.hip", "gemm_ring.hip", "gemm_phased.hip", "wgrad.hip", "norm.hip", "elementwise.hip", "conv0.hip", "posconv.hip", "posconv_wgrad.hip",
            "softmax.hip", "attention.hip", "pool.hip", "asp.hip", "tdnn.hip", "skinny.hip", "heads.hip", "optim.hip", "comm.hip"]
+HEADERS = ["common.h", "gemm_common.h"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
 
 
@@ -27,7 +28,7 @@ def source_hash() -> str:
     """sha256 over the kernel sources + the C header (what the profiled counters under profiles/ were measured on)."""
     import hashlib
     h = hashlib.sha256()
-    for f in sorted(SOURCES) + ["common.h"]:
+    for f in sorted(SOURCES) + HEADERS:
         h.update(open(os.path.join(CSRC, f), "rb").read())
     h.update(open(os.path.join(HERE, "..", "include", "w2v2_hip.h"), "rb").read())
     return h.hexdigest()[:16]
@@ -37,8 +38,7 @@ def needs_build() -> bool:
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "common.h"),
-                                                      os.path.join(HERE, "..", "include", "w2v2_hip.h")]
+    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.join(HERE, "..", "include", "w2v2_hip.h")]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
@@ -67,6 +67,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
         srcp = os.path.join(CSRC, src)
         hdrs = [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "w2v2_hip.h")]
+        if src.startswith("gemm"):
+            hdrs.append(os.path.join(CSRC, "gemm_common.h"))
         if (not force and os.path.exists(obj)
                 and os.path.getmtime(obj) > max(os.path.getmtime(p) for p in [srcp] + hdrs)):
             return obj
@@ -80,7 +82,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
             print("compiled", src)
         return obj
 
-    with ThreadPoolExecutor(max_workers=min(6, os.cpu_count() or 1)) as ex:
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
         objs = list(ex.map(compile_one, SOURCES))
     # the library's timestamp must not run ahead of a source that was edited WHILE the objects were compiling (a later
     # needs_build() would then skip the rebuild): it gets the time at which this build STARTED reading the sources

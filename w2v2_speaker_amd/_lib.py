@@ -46,6 +46,7 @@ _SIGS = {
     "w2v2_last_error": (C.c_char_p, []),
     "w2v2_gemm": (c_i32, [C.POINTER(GemmDesc), c_vp]),
     "w2v2_tune_gemm_kernel": (c_i32, [c_i32]),
+    "w2v2_tune_gemm_debug": (c_i32, [c_i32]),
     "w2v2_zero_ranges": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_vp]),
     "w2v2_mean": (c_i32, [c_vp, c_vp, c_i32, c_vp]),
     "w2v2_wgrad_grouped": (c_i32, [C.POINTER(WgradProblem), c_i32, c_i32, c_i32, c_i32, c_vp]),
@@ -157,6 +158,8 @@ def load():
             raise RuntimeError(f"libw2v2hip.so is missing or older than its sources and could not be built: {e}") from e
     lib = C.CDLL(path)
     for name, (res, args) in _SIGS.items():
+        if path == alt and not hasattr(lib, name):
+            continue                     # (tools only: an OLDER build under A/B may predate an entry point)
         fn = getattr(lib, name)          # AttributeError if the ABI symbol is missing
         fn.restype, fn.argtypes = res, args
     _lib = lib

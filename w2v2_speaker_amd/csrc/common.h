@@ -253,11 +253,13 @@ template <typename TC> __device__ __forceinline__ uint4 pack8(const float* v) {
 
 // ---------------------------------------------------------------- math
 // erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, i.e. f32 round-off class): 1 rcp + 1 exp + 7 fma
+// (the reciprocal is the hardware's v_rcp_f32, 1 ulp: `__frcp_rn` -- correctly rounded -- expands to the ten-instruction
+// IEEE division sequence, a third of the whole GELU epilogue)
 // instead of the ~40-instruction libm erff.  GELU is evaluated ~1e9 times per training step (conv layer 0,
 // FFN1 epilogue, its backward), always as a serial tail of a kernel.
 __device__ __forceinline__ float erf_fast(float x) {
   const float ax = fabsf(x);
-  const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
   float poly = fmaf(1.061405429f, t, -1.453152027f);
   poly = fmaf(poly, t, 1.421413741f);
   poly = fmaf(poly, t, -0.284496736f);
@@ -278,7 +280,7 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
 __device__ __forceinline__ void gelu_both_f(float x, float& y, float& dy) {
   const float xs = x * 0.70710678118654752f;
   const float ax = fabsf(xs);
-  const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
   float poly = fmaf(1.061405429f, t, -1.453152027f);
   poly = fmaf(poly, t, 1.421413741f);
   poly = fmaf(poly, t, -0.284496736f);

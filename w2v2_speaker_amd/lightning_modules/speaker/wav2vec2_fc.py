@@ -433,13 +433,25 @@ class Wav2vec2FCModule(torch.nn.Module):
         sd = self.state_dict()
         if legacy_weight_norm_names:
             sd = OrderedDict((ParamStore.legacy_key(k), v) for k, v in sd.items())
-        lr, beta1 = self.schedule.at(max(self.schedule_step - 1, 0))
+        # torch's groups hold the values of the NEXT optimiser step (OneCycleLR.step() writes them right after a step)
+        sch = self.schedule
+        lr, beta1 = sch.at(min(self.schedule_step, sch.total_steps - 1))
         z = lambda t: None if t is None else t.detach().clone().cpu()
+        initial_lr = sch.max_lr / sch.div_factor
+        # torch.optim.lr_scheduler.OneCycleLR.state_dict() (every key it reads back in load_state_dict / step)
+        sched_state = {"total_steps": sch.total_steps,
+                       "_schedule_phases": [
+                           {"end_step": float(sch.pct_start * sch.total_steps) - 1, "start_lr": "initial_lr", "end_lr": "max_lr",
+                            "start_momentum": "max_momentum", "end_momentum": "base_momentum"},
+                           {"end_step": sch.total_steps - 1, "start_lr": "max_lr", "end_lr": "min_lr",
+                            "start_momentum": "base_momentum", "end_momentum": "max_momentum"}],
+                       "_anneal_func_type": "cos", "cycle_momentum": True, "use_beta1": True, "base_lrs": [initial_lr],
+                       "last_epoch": self.schedule_step, "_step_count": self.schedule_step + 1, "_is_initial": False,
+                       "_get_lr_called_within_step": False, "_last_lr": [lr]}
         torch.save({"state_dict": sd, "global_step": self.schedule_step, "epoch": 0,
                     "pytorch-lightning_version": "1.4.5",
-                    "optimizer_states": [self.store.torch_adam_state(lr, (beta1, 0.999), 1e-8)],
-                    "lr_schedulers": [{"last_epoch": self.schedule_step, "_step_count": self.schedule_step + 1,
-                                       "total_steps": self.schedule.total_steps, "_last_lr": [lr]}],
+                    "optimizer_states": [self.store.torch_adam_state(lr, (beta1, 0.999), 1e-8, one_cycle=sch)],
+                    "lr_schedulers": [sched_state],
                     "w2v2_amd": {"loss_scaler": z(self.store.scaler), "steps": self.steps,
                                  "is_wav2vec_frozen": self._is_wav2vec_frozen},
                     "hyper_parameters": {"num_speakers": self.num_speakers, "loss": self.loss}}, path)

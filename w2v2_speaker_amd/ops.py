@@ -113,16 +113,21 @@ class Gemm:
         self.narrow = N <= 64
         self.out_is_act = is16(Cmat.dtype)
         # mirrors the host dispatch of csrc/gemm.hip (w2v2_gemm): which kernel this descriptor launches
-        fast = (lp and not transA and not transB and K % 64 == 0 and K >= 64 and lda % 8 == 0 and ldb % 8 == 0)
+        al16 = lambda t, ld, st: t is None or (t.data_ptr() % 16 == 0 and all(x % (16 // t.element_size()) == 0 for x in (ld, *st)))
+        fast = (lp and not transA and not transB and K % 64 == 0 and K >= 64 and al16(A, lda, a_strides + (a_seg[1],))
+                and al16(B, ldb, b_strides + (b_seg[1],)) and not os.environ.get("W2V2_NO_GLDS"))
         if fast and split_k <= 1 and not accumulate and (b_lo is not None or (N >= 512 and M >= 1024)):
             self.kernel_name = "gemm16_ring_256x128_kernel"
             t4, t3 = -(-M // 256) * -(-N // 256), -(-M // 256) * -(-N // 128)      # csrc/gemm.hip: 256x256 vs 256x128 tiles
-            fill = lambda t: t / (-(-t // 256) * 256)
-            if (b_lo is None and N >= 512 and batch == 1 and t4 * 2 >= 256 and fill(t4) * 1.25 >= fill(t3)
-                    and N / (-(-N // 256) * 256) >= 0.9 and not os.environ.get("W2V2_NO_GLDS4")):
-                self.kernel_name = ("gemm16_ring_256x256_kernel" if os.environ.get("W2V2_NO_GEMM_PH") else
-                                    "gemm16_quad_256x256_kernel" if os.environ.get("W2V2_GEMM_QUAD") else
-                                    "gemm16_phased_256x256_kernel")
+            ncu = max(1, 256 - int(os.environ.get("W2V2_RESERVE_CUS", "0") or 0))
+            fill = lambda t: t / (-(-t // ncu) * ncu)
+            # 16-bit outputs reach the 256x256 kernel only through its full-line epilogue (csrc/gemm.hip `lines`)
+            lines = (not is16(Cmat.dtype)) or (al16(Cmat, ldc, c_strides) and N % 64 == 0 and al16(aux, ldaux, aux_strides))
+            ext = lambda ld, seg, rows: ((rows // seg[0] + 1) * seg[1] + seg[0] * ld if seg[0] > 0 else rows * ld) + K
+            fits32 = ext(lda, a_seg, M) < 2 ** 31 and ext(ldb, b_seg, N) < 2 ** 31
+            if (b_lo is None and N >= 512 and batch == 1 and t4 * 2 >= ncu and fill(t4) * 1.25 >= fill(t3) and lines
+                    and fits32 and N / (-(-N // 256) * 256) >= 0.9 and not os.environ.get("W2V2_NO_GEMM_PH")):
+                self.kernel_name = "gemm16_phased_256x256_kernel"
         elif fast:
             self.kernel_name = "gemm16_dma_128_kernel"
         else:

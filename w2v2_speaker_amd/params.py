@@ -371,11 +371,14 @@ class ParamStore:
                 return name[: -len(new)] + old
         return name
 
-    def torch_adam_state(self, lr: float, betas=(0.9, 0.999), eps: float = 1e-8) -> Dict[str, object]:
+    def torch_adam_state(self, lr: float, betas=(0.9, 0.999), eps: float = 1e-8, one_cycle=None) -> Dict[str, object]:
         """``torch.optim.Adam.state_dict()`` of the optimiser the reference builds over ``network.parameters()``
         (ref: src/main.py:323): per-parameter ``step`` / ``exp_avg`` / ``exp_avg_sq`` views cut out of the flat moment
         arenas, indexed in reference parameter order; parameters that never had a gradient (frozen CNN) have no
-        state entry, as in torch."""
+        state entry, as in torch.  ``one_cycle`` (an ``optim.schedule.OneCycle``): the reference wraps this Adam in
+        ``OneCycleLR`` (ref: src/main.py:323-335), which keeps ``initial_lr / max_lr / min_lr / base_momentum /
+        max_momentum`` IN the optimiser's param group -- ``Optimizer.load_state_dict`` replaces the groups wholesale, so
+        a file without them breaks ``OneCycleLR.step()`` after a resume (KeyError: 'initial_lr')."""
         order = self.reference_parameter_order()
         state = {}
         h = self.head_size()
@@ -393,8 +396,12 @@ class ParamStore:
                 continue
             state[i] = {"step": step, "exp_avg": self.exp_avg[off:off + cnt].view(self.shapes[n]).detach().clone().cpu(),
                         "exp_avg_sq": self.exp_avg_sq[off:off + cnt].view(self.shapes[n]).detach().clone().cpu()}
-        group = {"lr": lr, "betas": tuple(betas), "eps": eps, "weight_decay": 0, "amsgrad": False,
-                 "params": list(range(len(order)))}
+        group = {"lr": lr, "betas": tuple(betas), "eps": eps, "weight_decay": 0, "amsgrad": False}
+        if one_cycle is not None:
+            initial_lr = one_cycle.max_lr / one_cycle.div_factor
+            group.update(initial_lr=initial_lr, max_lr=one_cycle.max_lr, min_lr=initial_lr / one_cycle.final_div_factor,
+                         max_momentum=one_cycle.max_momentum, base_momentum=one_cycle.base_momentum)
+        group["params"] = list(range(len(order)))
         return {"state": state, "param_groups": [group]}
 
     def load_torch_adam_state(self, osd: Dict[str, object]) -> None:
