@@ -109,8 +109,9 @@ int w2v2_gemm(const w2v2_gemm_desc* d, void* stream);
  * 4 = 256x256x64 phased.  Returns the previous setting. */
 int w2v2_tune_gemm_kernel(int family);
 /* Tools only (tools/gemm_attrib.py): time-attribution / placement variants of the 256x256x64 phased kernel for fp16
- * products -- bit 0 no DMA in the main loop, 1 no fragment reads, 2 no MFMAs, 3 no epilogue, 4 DMA pieces issued between
- * the MFMAs.  Variants with bits 0-3 compute garbage by design.  Returns the previous setting; 0 = the product kernel. */
+ * products -- bit 0 no DMA in the main loop, 1 no fragment reads, 2 no MFMAs, 3 no epilogue, bits 4-5 = DMA pieces of a
+ * phase issued between its MFMAs, bit 6 / 7 plain / write-through epilogue stores.  Variants with bits 0-3 compute
+ * garbage by design.  Returns the previous setting; 0 = the product kernel. */
 int w2v2_tune_gemm_debug(int bits);
 
 /* Grouped weight-gradient GEMM (the backward of HF:520-526,544,565-572 nn.Linear weights/biases):
@@ -128,17 +129,10 @@ typedef struct {
 } w2v2_wgrad_problem;
 int w2v2_wgrad_grouped(const w2v2_wgrad_problem* problems, int n, int tokens, int tokens_padded,
                        int dtype /* W2V2_BF16 or W2V2_F16: element type of dY and X */, void* stream);
-/* The same with a caller-owned scratch buffer that allows STREAM-K when the group has fewer 256x256 tiles than the chip
- * has CUs (the two-transformer-block group of w2v2-base: 216 tiles on 256 CUs): one owner workgroup per tile runs the
- * first K steps, the remaining CUs run the tails and hand their partial tiles over through the workspace; the owner adds
- * them in a fixed order (bitwise reproducible; results differ from the plain launch only in the summation split).
- * EXPERIMENTAL and off unless the environment has W2V2_WGRAD_STREAMK=1 (measured on MI355X: not faster than the plain
- * launch); without it the call is w2v2_wgrad_grouped.  w2v2_wgrad_workspace_bytes() = the size this
- * group needs (0: stream-K does not apply, pass NULL).  The buffer must be ZERO-INITIALISED ONCE (hipMemset /
- * torch.zeros) and may be shared by all launches issued on one stream; 16-byte aligned. */
-int64_t w2v2_wgrad_workspace_bytes(const w2v2_wgrad_problem* problems, int n);
-int w2v2_wgrad_grouped_ws(const w2v2_wgrad_problem* problems, int n, int tokens, int tokens_padded, int dtype,
-                          void* workspace, int64_t workspace_bytes, void* stream);
+/* Tools only (tools/gemm_shapes.py, tests): force the kernel of the grouped weight gradients -- 0 = the library's own
+ * choice, 1 = 128x128 two-stage, 2 = 256x128 ring, 3 = 256x256x32 ring, 4 = 256x256x64 phased (5 / 6: with one / both DMA
+ * pieces of a phase issued between its MFMAs).  Returns the previous value. */
+int w2v2_tune_wgrad_kernel(int family);
 
 /* ------------------------------------------------------------------------ conv feature extractor
  * Layer 0 of HF:382-419: Conv1d(1->C,k,stride,no bias) + GroupNorm(C groups == per-(b,c) over time,

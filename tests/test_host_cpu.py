@@ -315,6 +315,54 @@ def test_pl_format_checkpoint_round_trip_and_reheading(tmp_path):
 
 
 
+def test_checkpoint_resumes_on_torch_adam_and_one_cycle_lr(tmp_path):
+    """the reference wraps its Adam in ``OneCycleLR`` (ref: src/main.py:323-335), which keeps
+    ``initial_lr / max_lr / min_lr / base_momentum / max_momentum`` in the optimiser's param group;
+    ``Optimizer.load_state_dict`` replaces the groups wholesale, so a checkpoint without them dies in the first
+    ``OneCycleLR.step()`` after a resume (KeyError: 'initial_lr').  Here ``optimizer_states[0]`` / ``lr_schedulers[0]`` of a
+    saved file go into REAL torch objects, one optimiser + scheduler step runs, and the learning rate / beta1 follow
+    this repo's own schedule (which golden g8 pins against torch)."""
+    import torch
+    from w2v2_speaker_amd import config as C
+    from w2v2_speaker_amd.lightning_modules.speaker.wav2vec2_fc import Wav2vec2FCModule, Wav2vec2FCModuleConfig
+    from w2v2_speaker_amd.params import ParamStore
+    tiny = C.W2V2Config.tiny()
+    orig = C.W2V2Config.from_huggingface_id
+    C.W2V2Config.from_huggingface_id = staticmethod(lambda _id: tiny)
+    try:
+        m = Wav2vec2FCModule.from_config(Wav2vec2FCModuleConfig(reset_weights=True), num_speakers=7, init_seed=1,
+                                         device="cpu", act_dtype=torch.float32)
+        st, sch = m.store, m.schedule
+        g = torch.Generator().manual_seed(5)
+        st.exp_avg = torch.randn(st.grad.shape, generator=g)
+        st.exp_avg_sq = torch.rand(st.grad.shape, generator=g)
+        st.step_head = st.step_body = 7
+        m.steps = m.schedule_step = 7
+        path = str(tmp_path / "resume.ckpt")
+        m.save_checkpoint(path)
+        ck = torch.load(path, weights_only=True)
+        group = ck["optimizer_states"][0]["param_groups"][0]
+        assert {"initial_lr", "max_lr", "min_lr", "base_momentum", "max_momentum"} <= set(group)
+        assert group["lr"] == sch.at(7)[0] and group["betas"][0] == sch.at(7)[1]          # values of the NEXT step
+        params = [torch.nn.Parameter(torch.zeros(tuple(ck["state_dict"][ParamStore.legacy_key(k)].shape)))
+                  for k in st.reference_parameter_order()]
+        opt = torch.optim.Adam(params, lr=1.0)
+        sched = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=sch.max_lr, total_steps=sch.total_steps)
+        opt.load_state_dict(ck["optimizer_states"][0])            # what a PL resume does, in this order
+        sched.load_state_dict(ck["lr_schedulers"][0])
+        assert sched.last_epoch == 7 and opt.param_groups[0]["lr"] == sch.at(7)[0]
+        for q in params:
+            q.grad = torch.zeros_like(q)
+        opt.step()
+        sched.step()                                              # raised KeyError('initial_lr') before round 4
+        lr8, b8 = sch.at(8)
+        assert abs(opt.param_groups[0]["lr"] - lr8) <= 1e-12 * lr8 + 1e-18
+        assert abs(opt.param_groups[0]["betas"][0] - b8) <= 1e-12
+        assert sched.get_last_lr()[0] == opt.param_groups[0]["lr"]
+    finally:
+        C.W2V2Config.from_huggingface_id = orig
+
+
 def test_checkpoint_keys_and_parameter_order_match_the_reference_stack(tmp_path):
     """The reference's module is ``loss_fn`` + HF ``Wav2Vec2Model`` (under ``wav2vec.model.``) + ``fc_list``
     (ref: wav2vec2_fc.py:101-228).  Key SET of a saved checkpoint == {HF state_dict keys with the torch-1.9 weight-norm

@@ -1242,17 +1242,13 @@ def test_adam_step_count_does_not_advance_on_skipped_steps():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("lp", LP16)
-@pytest.mark.parametrize("tokens", [9834, 2 * 64 * 7 + 5])
-def test_grouped_weight_gradient_stream_k_two_block_group(lp, tokens, monkeypatch):
-    """w2v2_wgrad_grouped_ws with W2V2_WGRAD_STREAMK=1 (opt-in: measured not faster): the 8 problems
-    of two w2v2-base transformer blocks (216 tiles of 256x256 on 256 CUs) run as STREAM-K -- 216 owner workgroups run the
-    first K steps of their tile, 40 helpers the tails, pieces are combined through the workspace (write-through stores,
-    flag = launch epoch, agent-scope acquire).  Checked: every dW / dbias element against an f64 reference; bit-for-bit
-    equal over repeated launches WHILE another stream saturates HBM (uneven load is where a broken hand-off shows,
-    cdna_hip_programming.md Guideline 16); close to the plain launch (same operands, other summation split); tokens = 901
-    makes tiles of 30 K steps, so tails are shorter than a ring prologue."""
-    monkeypatch.setenv("W2V2_WGRAD_STREAMK", "1")
-    import ctypes as C
+@pytest.mark.parametrize("tokens", [9834, 2 * 64 * 7 + 5, 64])
+def test_grouped_weight_gradient_phased_kernel_two_block_group(lp, tokens):
+    """wgrad_grouped_phased_kernel (csrc/wgrad_phased.hip; family 4 of w2v2_tune_wgrad_kernel, the library's choice for the
+    two-block groups of the training step): the 8 problems of two w2v2-base transformer blocks = 216 tiles of 256x256.
+    Checked: every dW / dbias element against an f64 reference; BIT-EQUAL to the 256x256x32 ring kernel (family 3: same
+    k order per accumulator) and to itself over repeated launches while another stream saturates HBM; tokens = 901 is a
+    ragged token count (rows up to the padded count are zero by contract), tokens = 64 a single K tile (prologue only)."""
     from w2v2_speaker_amd import _lib
     o = ops()
     H, I = 768, 3072
@@ -1266,59 +1262,68 @@ def test_grouped_weight_gradient_stream_k_two_block_group(lp, tokens, monkeypatc
     probs = []
     for _ in range(2):
         probs += [(mk(H), mk(I)), (mk(I), mk(H)), (mk(H), mk(H)), (mk(3 * H), mk(H))]
-    outs = [(torch.full((dy.shape[1], x.shape[1]), float("nan"), device=DEV), torch.full((dy.shape[1],), float("nan"), device=DEV))
-            for dy, x in probs]
-    wg = o.WgradGroup([(dy, x, dw, db) for (dy, x), (dw, db) in zip(probs, outs)], tokens, Mp)
-    assert wg._ws is not None and wg._ws_bytes > 0, "this group must take the stream-K path"
-    wg()
-    torch.cuda.synchronize()
-    first = [(dw.clone(), db.clone()) for dw, db in outs]
-    for (dy, x), (dw, db) in zip(probs, first):
+    res = {}
+    try:
+        for fam in (4, 3):
+            outs = [(torch.full((dy.shape[1], x.shape[1]), float("nan"), device=DEV),
+                     torch.full((dy.shape[1],), float("nan"), device=DEV)) for dy, x in probs]
+            wg = o.WgradGroup([(dy, x, dw, db) for (dy, x), (dw, db) in zip(probs, outs)], tokens, Mp)
+            o.lib().w2v2_tune_wgrad_kernel(fam)
+            wg()
+            torch.cuda.synchronize()
+            res[fam] = (wg, outs, [(dw.clone(), db.clone()) for dw, db in outs])
+    finally:
+        o.lib().w2v2_tune_wgrad_kernel(0)
+    for (dy, x), (dw, db), (rw, rb) in zip(probs, res[4][2], res[3][2]):
         ref = dy[:tokens].double().t() @ x[:tokens].double()
         assert float((dw.double() - ref).norm() / ref.norm()) < 2e-6
         refb = dy[:tokens].double().sum(0)
         assert float((db.double() - refb).norm() / refb.norm()) < 2e-6
-    # plain (non-stream-K) launch of the same group: equal up to the summation split
-    arr = wg._arr
-    plain = [(torch.zeros_like(dw), torch.zeros_like(db)) for dw, db in outs]
-    arr2 = (_lib.WgradProblem * len(probs))()
-    for i, ((dy, x), (dw, db)) in enumerate(zip(probs, plain)):
-        q = arr2[i]
-        q.dY, q.ld_dy, q.X, q.ld_x = dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0)
-        q.dW, q.ld_dw, q.dbias, q.n_out, q.n_in = dw.data_ptr(), dw.stride(0), db.data_ptr(), dw.shape[0], dw.shape[1]
-    _lib.check(o.lib().w2v2_wgrad_grouped(arr2, len(probs), tokens, Mp, o.dt(probs[0][0]), o.stream()), "wgrad_grouped")
-    torch.cuda.synchronize()
-    for (dw, db), (pw, pb) in zip(first, plain):
-        assert float((dw - pw).abs().max()) <= 1e-4 * float(pw.abs().max())
-        assert float((db - pb).abs().max()) <= 1e-4 * float(pb.abs().max())
-    # A second group over OTHER operand values shares the workspace (ops.WgradGroup keeps one per device): launched
-    # alternately, a piece left over from the previous launch (stale L2 line, flag of an older epoch) would belong to the
-    # other operand set and show up as a wrong tile.  Meanwhile a second stream streams 1.5 GB back and forth: uneven
-    # load is where a broken hand-off shows.
-    probs2 = [((dy.float() * 0.5).to(lp), (x.float() * -1.0).to(lp)) for dy, x in probs]
-    outs2 = [(torch.full_like(dw, float("nan")), torch.full_like(db, float("nan"))) for dw, db in outs]
-    wg2 = o.WgradGroup([(dy, x, dw, db) for (dy, x), (dw, db) in zip(probs2, outs2)], tokens, Mp)
-    assert wg2._ws.data_ptr() == wg._ws.data_ptr()
-    hog_a = torch.empty(192 << 20, dtype=torch.float32, device=DEV)
+        assert torch.equal(dw, rw) and torch.equal(db, rb)
+    # repeatable under HBM load (the library's own dispatch must pick the phased kernel for this group: same bits)
+    wg, outs, first = res[4]
+    hog_a = torch.empty(128 << 20, dtype=torch.float32, device=DEV)
     hog_b = torch.empty_like(hog_a)
     side = torch.cuda.Stream()
-    for it in range(12):
-        for dw, db in outs + outs2:
+    for it in range(4):
+        for dw, db in outs:
             dw.fill_(float("nan")); db.fill_(float("nan"))
         with torch.cuda.stream(side):
             for _ in range(2 + it % 3):
                 hog_b.copy_(hog_a); hog_a.copy_(hog_b)
         wg()
-        wg2()
+        torch.cuda.synchronize()
+        for (dw, db), (fw, fb) in zip(outs, first):
+            assert torch.equal(dw, fw) and torch.equal(db, fb), it
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lp", LP16)
+def test_grouped_weight_gradient_phased_kernel_ragged_problems(lp):
+    """The phased kernel on tile grids with ragged edges: n_out / n_in that are multiples of 8 but not of 256 (columns
+    past the edge are clamped on the DMA side and never stored), a problem narrower than one tile, no bias pointer."""
+    o = ops()
+    tokens, Mp = 1000, 1024
+    g = torch.Generator(device="cpu").manual_seed(11)
+
+    def mk(c):
+        t = torch.zeros(Mp, c, dtype=lp, device=DEV)
+        t[:tokens] = (torch.randn(tokens, c, generator=g) * 0.5).to(lp).to(DEV)
+        return t
+    shapes = [(1536, 520, True), (264, 768, False), (1024, 1024, True), (72, 40, True), (512, 3072, True)]
+    probs = [(mk(no), mk(ni)) for no, ni, _ in shapes]
+    outs = [(torch.full((no, ni), float("nan"), device=DEV), torch.full((no,), float("nan"), device=DEV) if hb else None)
+            for no, ni, hb in shapes]
+    wg = o.WgradGroup([(dy, x, dw, db) for (dy, x), (dw, db) in zip(probs, outs)], tokens, Mp)
+    try:
+        o.lib().w2v2_tune_wgrad_kernel(4)
         wg()
         torch.cuda.synchronize()
-        for (dw, db), (fw, fb), (dw2, db2) in zip(outs, first, outs2):
-            assert torch.equal(dw, fw) and torch.equal(db, fb), it
-            # the second set is -0.5 x the first up to the matrix pipe's internal (sign-dependent) rounding: a stale
-            # piece of the OTHER set would be off by the size of the values themselves, not by 1e-6 of them
-            assert float((dw2 - fw * -0.5).abs().max()) <= 2e-6 * float(fw.abs().max()), it
-            assert float((db2 - fb * 0.5).abs().max()) <= 2e-6 * float(fb.abs().max()), it
-        if it == 0:
-            first2 = [(dw2.clone(), db2.clone()) for dw2, db2 in outs2]
-        for (dw2, db2), (f2w, f2b) in zip(outs2, first2):
-            assert torch.equal(dw2, f2w) and torch.equal(db2, f2b), it                    # and bitwise repeatable
+    finally:
+        o.lib().w2v2_tune_wgrad_kernel(0)
+    for (dy, x), (dw, db) in zip(probs, outs):
+        ref = dy[:tokens].double().t() @ x[:tokens].double()
+        assert float((dw.double() - ref).norm() / ref.norm()) < 2e-6
+        if db is not None:
+            refb = dy[:tokens].double().sum(0)
+            assert float((db.double() - refb).norm() / refb.norm()) < 2e-6

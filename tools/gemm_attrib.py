@@ -21,16 +21,13 @@ SHAPES = [
     ("ffn1 fwd", M, I, H, EPI_BIAS_GELU_GRAD, True),
     ("dh   bwd", M, I, H, EPI_MUL, True),
     ("plain   ", M, I, H, EPI_NONE, False),
-    ("ffn1 M/2", M // 2, I, H, EPI_BIAS_GELU_GRAD, True),
-    ("ffn1 M/4", M // 4, I, H, EPI_BIAS_GELU_GRAD, True),
-    ("dh   M/2", M // 2, I, H, EPI_MUL, True),
     ("conv1   ", 66 * 4799, 512, 1536, EPI_BIAS_GELU, False),
     ("conv3   ", 66 * 1199, 512, 1536, EPI_BIAS_GELU, False),
 ]
 NAMES = {0: "full", 1: "-dma", 2: "-reads", 4: "-mfma", 8: "-epi", 9: "-dma-epi", 11: "mfma only", 13: "reads only",
-         16: "dma in mfma", 24: "dma in mfma -epi", 32: "plain stores", 48: "dma in mfma + plain stores", 64: "wt stores", 80: "dma in mfma + wt stores"}
+         16: "1 of 2 dma pieces in mfma", 24: "1 of 2 in mfma -epi", 32: "both dma pieces in mfma", 40: "both in mfma -epi", 48: "dma in read segment", 64: "plain stores", 128: "wt stores"}
 only = sys.argv[1] if len(sys.argv) > 1 else None
-variants = [int(x) for x in os.environ.get("VARIANTS", "8,32,64,48,80").split(",")]
+variants = [int(x) for x in os.environ.get("VARIANTS", "48,32,8,40").split(",")]
 reps = int(os.environ.get("REPS", "20"))
 trials = int(os.environ.get("TRIALS", "5"))
 _bA = torch.randn(66 * 2399, 1536, device=dev).to(dt)
@@ -74,7 +71,7 @@ for name, m, n, k, epi, has_aux in SHAPES:
     g()
     ref = Cm.clone()
     for v in variants:
-        if v in (16, 32, 48, 64, 80):
+        if v in (16, 32, 48, 64, 128):
             Cm.zero_()
             lib.w2v2_tune_gemm_debug(v)
             g()

@@ -11,9 +11,9 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libw2v2hip.so")
-SOURCES = ["api.hip", "gemm.hip", "gemm_ring.hip", "gemm_phased.hip", "wgrad.hip", "norm.hip", "elementwise.hip", "conv0.hip", "posconv.hip", "posconv_wgrad.hip",
+SOURCES = ["api.hip", "gemm.hip", "gemm_ring.hip", "gemm_phased.hip", "wgrad.hip", "wgrad_phased.hip", "norm.hip", "elementwise.hip", "conv0.hip", "posconv.hip", "posconv_wgrad.hip",
            "softmax.hip", "attention.hip", "pool.hip", "asp.hip", "tdnn.hip", "skinny.hip", "heads.hip", "optim.hip", "comm.hip"]
-HEADERS = ["common.h", "gemm_common.h"]
+HEADERS = ["common.h", "gemm_common.h", "wgrad_common.h"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
 
 
@@ -69,6 +69,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
         hdrs = [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "w2v2_hip.h")]
         if src.startswith("gemm"):
             hdrs.append(os.path.join(CSRC, "gemm_common.h"))
+        if src.startswith("wgrad"):
+            hdrs.append(os.path.join(CSRC, "wgrad_common.h"))
         if (not force and os.path.exists(obj)
                 and os.path.getmtime(obj) > max(os.path.getmtime(p) for p in [srcp] + hdrs)):
             return obj

@@ -50,8 +50,7 @@ _SIGS = {
     "w2v2_zero_ranges": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_vp]),
     "w2v2_mean": (c_i32, [c_vp, c_vp, c_i32, c_vp]),
     "w2v2_wgrad_grouped": (c_i32, [C.POINTER(WgradProblem), c_i32, c_i32, c_i32, c_i32, c_vp]),
-    "w2v2_wgrad_workspace_bytes": (c_i64, [C.POINTER(WgradProblem), c_i32]),
-    "w2v2_wgrad_grouped_ws": (c_i32, [C.POINTER(WgradProblem), c_i32, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp]),
+    "w2v2_tune_wgrad_kernel": (c_i32, [c_i32]),
     "w2v2_conv0_workspace_floats": (c_i32, [c_i32, c_i32, c_i32, c_i32]),
     "w2v2_conv0_stats": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp]),
     "w2v2_conv0_stats_mfma": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp]),

@@ -661,6 +661,7 @@ extern "C" int w2v2_gemm(const w2v2_gemm_desc* d, void* stream) {
   static const bool defer_env = getenv("W2V2_NO_DEFER") == nullptr;   // A/B switch
   a.defer_ok = 0;
   a.wt_stores = 1;
+  a.late_dma = 0;
   const int cal = d->dtype_c == W2V2_F32 ? 4 : 8;     // elements per 16 bytes
   a.c_vec_ok = aligned16(d->C) && (d->ldc % cal == 0) && (d->c_stride0 % cal == 0) && (d->c_stride1 % cal == 0);
   a.aux_vec_ok = d->aux && aligned16(d->aux) && (d->ldaux % cal == 0) && (d->aux_stride0 % cal == 0) &&
@@ -726,6 +727,15 @@ extern "C" int w2v2_gemm(const w2v2_gemm_desc* d, void* stream) {
     {
       static const char* wt_env = getenv("W2V2_EPI_WT");
       a.wt_stores = wt_env ? (wt_env[0] != '0') : 1;
+    }
+    // Phased kernel, placement of the DMA pieces: in a phase's read segment (the product) or between its MFMAs
+    // (W2V2_PH_LATE=1, tools only).  Stand-alone, back to back, the heavy-epilogue products look faster with the pieces
+    // between the MFMAs (FFN1 80.3 -> 69.3 us, dH 67.4 -> 63.8; the main loop itself is unchanged, "-epi" columns of
+    // profiles/r04_gemm_attrib.txt) -- IN THE STEP the same choice measured +0.6 % (11.50 -> 11.57 ms, three ABAB rounds
+    // in one call): an artefact of timing one kernel against itself, not a property of the kernel.  Off.
+    {
+      static const char* late_env = getenv("W2V2_PH_LATE");
+      a.late_dma = late_env ? (late_env[0] != '0') : 0;
     }
 #define W2V2_GEMM_LAUNCH(TE, TC)                                                                         \
     do {                                                                                                 \

@@ -39,6 +39,7 @@ struct GemmArgs {
   int aux_vec_ok;  // 8-element vector access to aux legal
   int defer_ok;    // 256x128 ring kernel: stores of a tile may be issued under the next tile's main loop
   int wt_stores;   // full-line epilogue: 1 = write-through (sc1) stores, 0 = plain write-back stores (see w2v2_gemm)
+  int late_dma;    // phased kernel: DMA pieces of a phase issued between its MFMAs (host-side choice, see w2v2_gemm)
   // two-term weights (w2v2_hip.h): tiles with n0 >= n_ext_from run k_ext more K steps against B + b_lo_off
   int k_ext, n_ext_from;
   int64_t b_lo_off;

@@ -24,6 +24,20 @@ template <int N> __device__ __forceinline__ void wait_vm() {
   else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
   else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
 }
+// wait until all but the n most recently issued DMA pieces of this wave have landed
+__device__ __forceinline__ void wait_pieces(int n) {
+  switch (n) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+  }
+}
 // wait until all but the `newer` most recently issued quarters (2 DMA pieces each) of this wave have landed
 __device__ __forceinline__ void wait_quarters(int newer) {
   if (newer >= 4) wait_vm<8>();
@@ -35,8 +49,8 @@ __device__ __forceinline__ void wait_quarters(int newer) {
 
 // DBG (tools only, w2v2_tune_gemm_debug): time attribution / placement experiments on the SAME kernel body --
 //   1 = no DMA in the steady-state loop, 2 = no fragment reads, 4 = no MFMAs, 8 = no epilogue,
-//   16 = the two DMA pieces of a phase are issued BETWEEN its MFMAs instead of in its read segment,
-//   (host side) 32 = plain write-back epilogue stores, 64 = write-through ones, whatever w2v2_gemm chose
+//   16 / 32 = one / both of the two DMA pieces of a phase are issued BETWEEN its MFMAs instead of in its read segment,
+//   (host side) 64 = plain write-back epilogue stores, 128 = write-through ones, whatever w2v2_gemm chose
 template <typename TE, typename TC, int DBG = 0>
 __global__ __launch_bounds__(512) void gemm16_phased_256x256_kernel(const GemmArgs g) {
   constexpr int BM = 256, BN = 256, BK = 64, FM = 8, FN = 4;
@@ -123,7 +137,8 @@ __global__ __launch_bounds__(512) void gemm16_phased_256x256_kernel(const GemmAr
     if (wr == 1) __builtin_amdgcn_s_barrier();       // group 1 runs one barrier behind from here on
 
     frag8_t af[4][2], b0[2][2], b1[2][2];
-    constexpr bool NO_DMA = (DBG & 1) != 0, NO_READ = (DBG & 2) != 0, NO_MFMA = (DBG & 4) != 0, DMA_IN_MFMA = (DBG & 16) != 0;
+    constexpr bool NO_DMA = (DBG & 1) != 0, NO_READ = (DBG & 2) != 0, NO_MFMA = (DBG & 4) != 0;
+    constexpr int LATE = (DBG >> 4) & 3;             // DMA pieces of a phase (of 2) issued between its MFMAs instead of in its read segment
     if constexpr (NO_READ) {                           // (fragments defined once: the MFMAs keep real operands)
 #pragma unroll
       for (int j = 0; j < 2; ++j)
@@ -153,10 +168,17 @@ __global__ __launch_bounds__(512) void gemm16_phased_256x256_kernel(const GemmAr
             _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                  \
               acc[io_ + i][jo_ + j] = mfma16<TE>(bfr_[j][kk], af[i][kk], acc[io_ + i][jo_ + j]);          \
           }                                                                                                \
-          if constexpr (DMA_IN_MFMA && !NO_DMA) {                                                          \
+          if constexpr (LATE == 2 && !NO_DMA) {                                                            \
             if (i == 1 && (doq_)) {                                                                        \
               __builtin_amdgcn_sched_barrier(0);                                                           \
               issue1(q_, kq_, kk);                                                                         \
+              __builtin_amdgcn_sched_barrier(0);                                                           \
+            }                                                                                              \
+          }                                                                                                \
+          if constexpr (LATE == 1 && !NO_DMA) {                                                            \
+            if (kk == 0 && i == 3 && (doq_)) {                                                             \
+              __builtin_amdgcn_sched_barrier(0);                                                           \
+              issue1(q_, kq_, 1);                                                                          \
               __builtin_amdgcn_sched_barrier(0);                                                           \
             }                                                                                              \
           }                                                                                                \
@@ -166,7 +188,6 @@ __global__ __launch_bounds__(512) void gemm16_phased_256x256_kernel(const GemmAr
     for (int kt = 0; kt < nk; ++kt) {
       const bf16_t* bufp = smem + (kt & 1) * BUF;
       const bool more1 = kt + 1 < nk, more2 = kt + 2 < nk;
-      constexpr int LATE = DMA_IN_MFMA ? 1 : 0;      // this phase's quarter is issued after its wait: one fewer in flight
       // ---------------- phase 1: read B0 + A lo; issue QB1(kt+1); MFMA A lo x B0
       if constexpr (!NO_READ) {
 #pragma unroll
@@ -181,8 +202,8 @@ __global__ __launch_bounds__(512) void gemm16_phased_256x256_kernel(const GemmAr
           af[i][1] = *reinterpret_cast<const frag8_t*>(bufp + la1 + i * 16 * 64);
         }
       }
-      if constexpr (!NO_DMA && !DMA_IN_MFMA) { if (more1) issue(2, kt + 1); }
-      if constexpr (!NO_DMA) wait_quarters(1 + (more1 ? 3 - LATE : 0));            // QB1(kt) for phase 2
+      if constexpr (!NO_DMA) { if (more1) { if constexpr (LATE == 0) issue(2, kt + 1); else if constexpr (LATE == 1) issue1(2, kt + 1, 0); } }
+      if constexpr (!NO_DMA) wait_pieces(2 + (more1 ? 6 - LATE : 0));              // QB1(kt) for phase 2
       __builtin_amdgcn_s_barrier();
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
@@ -198,8 +219,8 @@ __global__ __launch_bounds__(512) void gemm16_phased_256x256_kernel(const GemmAr
           b1[j][1] = *reinterpret_cast<const frag8_t*>(bufp + lb1 + (2 + j) * 4 * 64);
         }
       }
-      if constexpr (!NO_DMA && !DMA_IN_MFMA) { if (more1) issue(3, kt + 1); }
-      if constexpr (!NO_DMA) wait_quarters(more1 ? 4 - LATE : 0);                  // QA1(kt) for phase 3
+      if constexpr (!NO_DMA) { if (more1) { if constexpr (LATE == 0) issue(3, kt + 1); else if constexpr (LATE == 1) issue1(3, kt + 1, 0); } }
+      if constexpr (!NO_DMA) wait_pieces(more1 ? 8 - LATE : 0);                    // QA1(kt) for phase 3
       __builtin_amdgcn_s_barrier();
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
@@ -215,7 +236,7 @@ __global__ __launch_bounds__(512) void gemm16_phased_256x256_kernel(const GemmAr
           af[i][1] = *reinterpret_cast<const frag8_t*>(bufp + la1 + (4 + i) * 16 * 64);
         }
       }
-      if constexpr (!NO_DMA && !DMA_IN_MFMA) { if (more2) issue(0, kt + 2); }
+      if constexpr (!NO_DMA) { if (more2) { if constexpr (LATE == 0) issue(0, kt + 2); else if constexpr (LATE == 1) issue1(0, kt + 2, 0); } }
       __builtin_amdgcn_s_barrier();
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
@@ -224,8 +245,8 @@ __global__ __launch_bounds__(512) void gemm16_phased_256x256_kernel(const GemmAr
       __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_s_barrier();
       // ---------------- phase 4: (operands in registers); issue QB0(kt+2); MFMA A hi x B0
-      if constexpr (!NO_DMA && !DMA_IN_MFMA) { if (more2) issue(1, kt + 2); }
-      if constexpr (!NO_DMA) { if (more1) wait_quarters(2 + (more2 ? 2 - LATE : 0)); } // QA0(kt+1), QB0(kt+1) for the next K tile's phase 1
+      if constexpr (!NO_DMA) { if (more2) { if constexpr (LATE == 0) issue(1, kt + 2); else if constexpr (LATE == 1) issue1(1, kt + 2, 0); } }
+      if constexpr (!NO_DMA) { if (more1) wait_pieces(4 + (more2 ? 4 - LATE : 0)); }   // QA0(kt+1), QB0(kt+1) for the next K tile's phase 1
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_setprio(1);
@@ -275,8 +296,9 @@ static void launch_ph(GemmArgs a, int M, int N, int batch, hipStream_t st) {
 }
 template <typename TE, typename TC>
 static void launch_ph_dbg(GemmArgs a, int M, int N, int batch, hipStream_t st) {
-  if (g_w2v2_dbg & 96) a.wt_stores = (g_w2v2_dbg & 64) ? 1 : 0;      // tools: bit 5 forces plain, bit 6 write-through stores
-  const int g_w2v2_dbg = ::g_w2v2_dbg & 31;
+  if (g_w2v2_dbg & 192) a.wt_stores = (g_w2v2_dbg & 128) ? 1 : 0;    // tools: bit 6 forces plain, bit 7 write-through stores
+  const int g_w2v2_dbg = ::g_w2v2_dbg & 63;
+  if (g_w2v2_dbg == 0 && a.late_dma) return launch_ph<TE, TC, 32>(a, M, N, batch, st);   // the product's second variant
   if constexpr (std::is_same<TE, f16_t>::value && std::is_same<TC, f16_t>::value) {
     switch (g_w2v2_dbg) {
       case 1: return launch_ph<TE, TC, 1>(a, M, N, batch, st);
@@ -288,6 +310,8 @@ static void launch_ph_dbg(GemmArgs a, int M, int N, int batch, hipStream_t st) {
       case 13: return launch_ph<TE, TC, 13>(a, M, N, batch, st);
       case 16: return launch_ph<TE, TC, 16>(a, M, N, batch, st);
       case 24: return launch_ph<TE, TC, 24>(a, M, N, batch, st);
+      case 48: return launch_ph<TE, TC, 0>(a, M, N, batch, st);    // tools: the read-segment placement whatever the host chose
+      case 40: return launch_ph<TE, TC, 40>(a, M, N, batch, st);
 
       default: break;
     }

@@ -12,44 +12,7 @@
 // the 8 rows a half-wave touches over all 8 segments (conflict-free ds_read_b64_tr_b16).
 // Contract: token rows [tokens, tokens_padded) of every operand are readable and ZERO
 // (tokens_padded = tokens rounded up to 64); n_out, n_in multiples of 8; 16-byte aligned rows.
-#include "common.h"
-#include <stdlib.h>
-#include <type_traits>
-
-typedef __attribute__((ext_vector_type(4))) short short4v;
-typedef __attribute__((ext_vector_type(4))) float f32x4;
-typedef __attribute__((address_space(1))) const void gvoid_t;
-typedef __attribute__((address_space(3))) void lvoid_t;
-typedef __attribute__((address_space(3))) short4v lds_s4_t;
-
-constexpr int WG_MAXP = 32;
-
-struct WgProblem {
-  const bf16_t* dY;
-  const bf16_t* X;
-  float* dW;
-  float* dbias;
-  int64_t ld_dy, ld_x, ld_dw;
-  int n_out, n_in;
-  int tile_begin, tiles_n;
-};
-constexpr int WG_MAXORDER = 512;
-struct WgArgs {
-  WgProblem p[WG_MAXP];
-  int n_problems, total_tiles, ktiles;
-  // 256x256 ring kernel: position in the launch -> tile, so that the run of tiles an XCD works on (consecutive
-  // positions after the XCD remap) forms compact 2-D blocks of ONE problem's tile grid: the tiles of an XCD then share
-  // their dY / X column panels in that XCD's private L2 (see w2v2_wgrad_grouped)
-  int use_order;
-  uint16_t order[WG_MAXORDER];
-  // stream-K (256x256 ring kernel): the launch's K steps are dealt out evenly to the workgroups; a tile whose steps span
-  // several workgroups is summed by the one that holds its first steps (see wgrad_grouped_ring4_kernel<TE, true>)
-  float4* sk_partials;          // [tiles][2 slots][SK_ROWS][512 lanes] float4
-  unsigned* sk_flags;           // [tiles][2 slots], == sk_epoch once the slot's partial is published
-  unsigned sk_epoch;
-  int sk_owner_steps;           // K steps (of 32 tokens) the owner of a tile runs itself; helpers run the rest
-};
-constexpr int SK_ROWS = 34;     // 32 accumulator quads + 2 quads of column sums per lane
+#include "wgrad_common.h"
 
 __device__ __forceinline__ int wg_f(int r) { return (r & 3) | ((r >> 1) & 4); }
 
@@ -416,12 +379,10 @@ __global__ __launch_bounds__(512) void wgrad_grouped_ring_kernel(const WgArgs a)
 // tiles, one round on 256 CUs): still no split-K, no atomics, bitwise reproducible.  8 waves as 2 (n_out) x 4 (n_in),
 // 128 x 64 per wave; four 32 KiB stages [32 tokens][256 + 256] in natural K-major layout, three in flight
 // (`s_waitcnt vmcnt(8)`, 4 DMA pieces per wave and stage); rolled ring loop (see gemm.hip on why).
-// SK = true, STREAM-K (owner / helper form): 216 tiles on 256 CUs leave 40 CUs idle for the whole launch (84 % fill)
-// and a tile is 308 K steps long.  The grid becomes one workgroup per CU: `tiles` owners that run the first q steps of
-// their tile and CUs - tiles helpers that run the tails; pieces travel as raw f32 accumulators (write-through stores,
-// flag = launch epoch), helpers never wait, owners wait only for their own tile's one or two pieces and add them in K
-// order -- fixed split, fixed order: bitwise reproducible (cdna_hip_programming.md Guideline 16 for the hand-off).
-template <typename TE, bool SK>
+// (Round 3 also carried a stream-K owner / helper form of this kernel for the 40 idle CUs of a 216-tile launch and a
+// blocked tile order: four variants, all correct, none faster -- DESIGN.md section 4 keeps the measurements; deleted in
+// round 4.)
+template <typename TE>
 __global__ __launch_bounds__(512) void wgrad_grouped_ring4_kernel(const WgArgs a) {
   constexpr int BM = 256, BN = 256, BK = 32;
   constexpr int STAGE = BK * (BM + BN);             // elements per stage: A [32][256] then B [32][256]
@@ -432,50 +393,14 @@ __global__ __launch_bounds__(512) void wgrad_grouped_ring4_kernel(const WgArgs a
   const int wm = wave >> 2, wn = wave & 3;
   const int nk_tile = a.ktiles * 2;                  // stages of 32 tokens per tile
 
-  // ---- SK: owners and helpers.  Workgroups 0 .. tiles-1 (27 per XCD, the plain launch's tile -> XCD map) OWN a tile and
-  // run its first sk_q K steps -- all of them in lockstep from K = 0, so the tiles of an XCD still share their dY / X
-  // column panels in that XCD's L2 like in the plain launch (a first version dealt out contiguous runs of the flattened
-  // (tile, K) space: every workgroup then sat at a different K offset, fetched its panels alone and the launch became
-  // HBM-bound, 405 vs 368 us).  The remaining gridDim - tiles workgroups (5 per XCD) are HELPERS: the tails
-  // [sk_q, nk) of all tiles, flattened, are dealt out evenly among them (a tail may be split between two helpers), each
-  // piece is published as soon as it is done, and the owner adds the one or two pieces of its tile in K order.
-  int sk_q = 0, sk_r = 0, sk_lo = 0, sk_hi = 0, nseg = 1;
-  bool helper = false;
-  if constexpr (SK) {
-    const int W = gridDim.x, T8 = a.total_tiles >> 3, xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
-    sk_q = a.sk_owner_steps;
-    sk_r = nk_tile - sk_q;
-    helper = loc >= T8;
-    if (helper) {
-      const int H8 = (W >> 3) - T8, h = xcd * H8 + (loc - T8), HS = a.total_tiles * sk_r;
-      const int qh = (HS + (W - a.total_tiles) - 1) / (W - a.total_tiles);
-      sk_lo = h * qh;
-      sk_hi = min(HS, sk_lo + qh);
-      if (sk_lo >= sk_hi) return;
-      nseg = (sk_hi - 1) / sk_r - sk_lo / sk_r + 1;              // tails touched
-    }
-  }
-#pragma unroll 1
-  for (int seg = 0; seg < nseg; ++seg) {
-  int tile, k_first = 0, nk = nk_tile, slot = 0;
-  if constexpr (SK) {
-    if (helper) {
-      tile = sk_lo / sk_r;
-      const int koff = sk_lo - tile * sk_r;
-      nk = min(sk_r - koff, sk_hi - sk_lo);
-      k_first = sk_q + koff;
-      slot = koff == 0 ? 0 : 1;
-      sk_lo += nk;
-    } else {
-      tile = (blockIdx.x & 7) * (a.total_tiles >> 3) + (blockIdx.x >> 3);
-      nk = sk_q;
-    }
-  } else {
+  int tile;
+  {
     const int nwg = a.total_tiles, bid = blockIdx.x;
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
     tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-    if (a.use_order) tile = a.order[tile];
   }
+  const int nk = nk_tile;
+  constexpr int k_first = 0;
   int pi = 0;
 #pragma unroll
   for (int i = 1; i < WG_MAXP; ++i)
@@ -591,57 +516,6 @@ __global__ __launch_bounds__(512) void wgrad_grouped_ring4_kernel(const WgArgs a
   }
 #undef W2V2_TR4
 
-  if constexpr (SK) {
-    if (helper) {
-      // ---- publish this piece (raw accumulators, lane-major: every lane of the owner reads back its own elements)
-      // WRITE-THROUGH (sc1) 16-byte stores: a piece is 272 KB, 1.4 MB per helper -- published with plain stores + an
-      // agent-scope release every buffer_wbl2 has to flush the XCD-wide dirty set (measured: +100 us per launch);
-      // write-through stores leave nothing dirty, so the drained vmcnt + the barrier are the release
-      // (MI355X_MICROARCH.md "publish-large", cdna_hip_programming.md Guideline 16 R1)
-      float4* dst = a.sk_partials + ((size_t)(tile * 2 + slot) * SK_ROWS) * 512 + tid;
-      auto st_sc1 = [](float4* p, f32x4 v) {
-        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
-      };
-#pragma unroll
-      for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) st_sc1(dst + (size_t)(i * 4 + j) * 512, acc[i][j]);
-      st_sc1(dst + (size_t)32 * 512, f32x4{bsum[0], bsum[1], bsum[2], bsum[3]});
-      st_sc1(dst + (size_t)33 * 512, f32x4{bsum[4], bsum[5], bsum[6], bsum[7]});
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      if (tid == 0)
-        __hip_atomic_store(a.sk_flags + tile * 2 + slot, a.sk_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      continue;                                      // (the next segment's loop starts with a barrier)
-    }
-    // number of helper pieces of this tile: two iff a helper boundary falls strictly inside its tail
-    const int HSn = a.total_tiles * sk_r, Hn = gridDim.x - a.total_tiles;
-    const int qhn = (HSn + Hn - 1) / Hn;
-    const int pieces = (sk_r == 0) ? 1 : 2 + (((tile * sk_r) / qhn != (tile * sk_r + sk_r - 1) / qhn) ? 1 : 0);
-    // ---- owner: add the earlier pieces in K order
-#pragma unroll 1
-    for (int p = 0; p < pieces - 1; ++p) {
-      if (tid == 0) {
-        const unsigned* f = a.sk_flags + tile * 2 + p;
-        int spins = 0;
-        while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.sk_epoch && ++spins < (1 << 24))
-          __builtin_amdgcn_s_sleep(4);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      }
-      __syncthreads();
-      const float4* src = a.sk_partials + ((size_t)(tile * 2 + p) * SK_ROWS) * 512 + tid;
-#pragma unroll
-      for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float4 v = src[(size_t)(i * 4 + j) * 512];
-          acc[i][j][0] += v.x; acc[i][j][1] += v.y; acc[i][j][2] += v.z; acc[i][j][3] += v.w;
-        }
-      const float4 b0 = src[(size_t)32 * 512], b1 = src[(size_t)33 * 512];
-      bsum[0] += b0.x; bsum[1] += b0.y; bsum[2] += b0.z; bsum[3] += b0.w;
-      bsum[4] += b1.x; bsum[5] += b1.y; bsum[6] += b1.z; bsum[7] += b1.w;
-    }
-  }
   if (do_bias) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -680,23 +554,19 @@ __global__ __launch_bounds__(512) void wgrad_grouped_ring4_kernel(const WgArgs a
         store16_wt(P.dW + (int64_t)m * P.ld_dw + n, *reinterpret_cast<const uint4*>(stagef + r * PITCH + ch * 4));
     }
   }
-  }   // segment loop
 }
 
 template <typename TE>
-static void wgrad_launch(const WgArgs& a, int tiles, bool ring, bool ring4, int sk_grid, hipStream_t st) {
+static void wgrad_launch(const WgArgs& a, int tiles, bool ring, bool ring4, hipStream_t st) {
   if (ring4) {
     constexpr size_t lds = (size_t)4 * 32 * (256 + 256) * sizeof(bf16_t);   // 128 KiB
     static bool attr_set = false;
     if (!attr_set) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_grouped_ring4_kernel<TE, false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_grouped_ring4_kernel<TE, true>),
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_grouped_ring4_kernel<TE>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       attr_set = true;
     }
-    if (sk_grid > 0) hipLaunchKernelGGL((wgrad_grouped_ring4_kernel<TE, true>), dim3(sk_grid), dim3(512), lds, st, a);
-    else hipLaunchKernelGGL((wgrad_grouped_ring4_kernel<TE, false>), dim3(tiles), dim3(512), lds, st, a);
+    hipLaunchKernelGGL((wgrad_grouped_ring4_kernel<TE>), dim3(tiles), dim3(512), lds, st, a);
   } else if (ring) {
     constexpr size_t lds = (size_t)3 * 64 * (256 + 128) * sizeof(bf16_t);   // 144 KiB
     static bool attr_set = false;
@@ -718,38 +588,15 @@ static void wgrad_launch(const WgArgs& a, int tiles, bool ring, bool ring4, int 
   }
 }
 
-// ---- stream-K workspace: [flags: tiles x 2 x u32, padded to 4 KiB][partials: tiles x 2 x SK_ROWS x 512 x float4]
-static int wgrad_cus() {
-  int ncu = 256, dev = 0;
-  (void)hipGetDevice(&dev);
-  if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
-  return ncu;
-}
-static int64_t sk_tiles256(const w2v2_wgrad_problem* probs, int n) {
-  int64_t t4 = 0;
-  for (int i = 0; i < n; ++i) t4 += cdiv(probs[i].n_out, 256) * cdiv(probs[i].n_in, 256);
-  return t4;
-}
-static int64_t sk_flag_bytes(int64_t tiles) { return cdiv(tiles * 2 * (int64_t)sizeof(unsigned), 4096) * 4096; }
-// OPT-IN (W2V2_WGRAD_STREAMK=1, read per call so a test can flip it): measured on MI355X the stream-K launch is not
-// faster than the plain one -- see DESIGN.md section 4 "stream-K for the grouped weight gradients"
-static bool wgrad_sk_enabled() { const char* e = getenv("W2V2_WGRAD_STREAMK"); return e != nullptr && e[0] == '1'; }
-
-extern "C" int64_t w2v2_wgrad_workspace_bytes(const w2v2_wgrad_problem* probs, int n) {
-  if (probs == nullptr || n <= 0 || n > WG_MAXP) return 0;
-  const int64_t t4 = sk_tiles256(probs, n), ncu = wgrad_cus();
-  // only where it can pay and where the owner / helper split is XCD-symmetric (see w2v2_wgrad_grouped_ws)
-  if (!(t4 < ncu && t4 * 2 >= ncu && t4 % 8 == 0 && ncu % 8 == 0)) return 0;
-  return sk_flag_bytes(t4) + t4 * 2 * (int64_t)SK_ROWS * 512 * (int64_t)sizeof(float4);
+static int g_wgrad_force = 0;
+extern "C" int w2v2_tune_wgrad_kernel(int family) {
+  const int old = g_wgrad_force;
+  if (family >= 0 && family <= 6) g_wgrad_force = family;
+  return old;
 }
 
 extern "C" int w2v2_wgrad_grouped(const w2v2_wgrad_problem* probs, int n, int tokens, int tokens_padded, int dtype,
                                   void* stream) {
-  return w2v2_wgrad_grouped_ws(probs, n, tokens, tokens_padded, dtype, nullptr, 0, stream);
-}
-
-extern "C" int w2v2_wgrad_grouped_ws(const w2v2_wgrad_problem* probs, int n, int tokens, int tokens_padded, int dtype,
-                                     void* workspace, int64_t workspace_bytes, void* stream) {
   W2V2_REQUIRE(probs && n > 0 && n <= WG_MAXP, "wgrad_grouped: need 1..%d problems", WG_MAXP);
   W2V2_REQUIRE(tokens > 0 && tokens_padded >= tokens && tokens_padded % 64 == 0,
                "wgrad_grouped: tokens_padded must be tokens rounded up to a multiple of 64");
@@ -759,7 +606,9 @@ extern "C" int w2v2_wgrad_grouped_ws(const w2v2_wgrad_problem* probs, int n, int
   int max_out = 0;
   for (int i = 0; i < n; ++i) max_out = probs[i].n_out > max_out ? probs[i].n_out : max_out;
   static const bool env_ring = getenv("W2V2_WGRAD_V1") == nullptr, env_ring4 = getenv("W2V2_NO_WGRAD4") == nullptr;   // A/B switches
-  const bool ring = max_out > 128 && env_ring;
+  static const bool env_phased = getenv("W2V2_NO_WGRAD_PH") == nullptr;
+  const int force = g_wgrad_force;                   // tools / tests: 1 = 128x128, 2 = 256x128 ring, 3 = 256x256x32 ring, 4 = phased
+  const bool ring = force ? force >= 2 : (max_out > 128 && env_ring);
   // 256x256 tiles when they alone fill >= 80 % of the CUs (e.g. the 8 problems of two w2v2-base blocks: 216 tiles)
   int64_t t4 = 0;
   for (int i = 0; i < n; ++i) t4 += cdiv(probs[i].n_out, 256) * cdiv(probs[i].n_in, 256);
@@ -774,8 +623,11 @@ extern "C" int w2v2_wgrad_grouped_ws(const w2v2_wgrad_problem* probs, int n, int
   // half of a 256x256 tile empty, so a mixed group can need MORE time on the large tiles)
   int64_t t3 = 0;
   for (int i = 0; i < n; ++i) t3 += cdiv(probs[i].n_out, 256) * cdiv(probs[i].n_in, 128);
-  const bool ring4 = ring && t4 * 10 >= (int64_t)ncu * 8 && cdiv(t4, ncu) * 17 <= cdiv(t3, ncu) * 10 &&
-                     env_ring4;
+  const bool ring4 = force ? force >= 3
+                           : (ring && t4 * 10 >= (int64_t)ncu * 8 && cdiv(t4, ncu) * 17 <= cdiv(t3, ncu) * 10 && env_ring4);
+  // the same 256x256 tiles on the phased kernel (wgrad_phased.hip): bit-equal results, anti-phase wave groups
+  const bool phased = force ? force >= 4 : (ring4 && env_phased);
+  const int late = force >= 4 ? force - 4 : 0;
   const int bm = ring ? 256 : 128;
   const int bn = ring4 ? 256 : 128;
   for (int i = 0; i < n; ++i) {
@@ -798,75 +650,10 @@ extern "C" int w2v2_wgrad_grouped_ws(const w2v2_wgrad_problem* probs, int n, int
   for (int i = n; i < WG_MAXP; ++i) a.p[i] = a.p[0];
   a.n_problems = n;
   a.total_tiles = tiles;
-  a.use_order = 0;
-  // measured (ABAB, round 3): 12.88 vs 12.83 ms/step WITH the blocked order -- the launch is not bound by the panel
-  // fetches (FETCH_SIZE counts L2 misses that the 256 MB Infinity Cache serves), and 27 tiles of ONE problem per XCD
-  // concentrate on fewer channels; kept behind a switch, off by default
-  static const bool env_order = getenv("W2V2_WGRAD_ORDER") != nullptr;
-  if (ring4 && tiles <= WG_MAXORDER && tiles >= 16 && env_order) {
-    // Every tile streams two column panels ([tokens] x 256 of dY and of X, 5 MB each at B = 66) and an XCD's L2 serves
-    // only its own CUs: in plain row-major order an XCD's ~tiles/8 consecutive tiles touch ~17 different panels
-    // (PMC: 856 MB fetched for 540 MB of operands).  Here each problem's tile grid is cut into blocks of at most
-    // `chunk` tiles spanning the SHORT grid dimension completely (3 x 9 of the 3 x 12 FFN2 grid: 12 panels for 27
-    // tiles), whole blocks first and the remainders packed behind them, so that an XCD's run is one or two blocks.
-    const int chunk = (tiles + 7) / 8;
-    struct Block { int p, r0, r1, c0, c1; };
-    Block blocks[4 * WG_MAXP];
-    int nb = 0;
-    for (int i = 0; i < n && nb < 4 * WG_MAXP - 2; ++i) {
-      const int R = (int)cdiv(probs[i].n_out, bm), Cn = a.p[i].tiles_n;
-      if (R <= Cn) {
-        const int w = chunk / R > 0 ? chunk / R : 1;
-        for (int c = 0; c < Cn && nb < 4 * WG_MAXP; c += w) blocks[nb++] = {i, 0, R, c, c + w < Cn ? c + w : Cn};
-      } else {
-        const int h = chunk / Cn > 0 ? chunk / Cn : 1;
-        for (int r = 0; r < R && nb < 4 * WG_MAXP; r += h) blocks[nb++] = {i, r, r + h < R ? r + h : R, 0, Cn};
-      }
-    }
-    // largest blocks first (stable): the full-size ones align with the XCD runs, the remainders share the last runs
-    for (int x = 1; x < nb; ++x)
-      for (int y = x; y > 0; --y) {
-        const int sa = (blocks[y - 1].r1 - blocks[y - 1].r0) * (blocks[y - 1].c1 - blocks[y - 1].c0);
-        const int sb = (blocks[y].r1 - blocks[y].r0) * (blocks[y].c1 - blocks[y].c0);
-        if (sb > sa) { const Block t = blocks[y]; blocks[y] = blocks[y - 1]; blocks[y - 1] = t; } else break;
-      }
-    int pos = 0;
-    for (int x = 0; x < nb; ++x)
-      for (int r = blocks[x].r0; r < blocks[x].r1; ++r)
-        for (int c = blocks[x].c0; c < blocks[x].c1; ++c)
-          if (pos < WG_MAXORDER) a.order[pos++] = (uint16_t)(a.p[blocks[x].p].tile_begin + r * a.p[blocks[x].p].tiles_n + c);
-    a.use_order = pos == tiles ? 1 : 0;
-  }
   a.ktiles = tokens_padded / 64;
-  // stream-K (256x256 kernel, caller-provided zero-initialised workspace): fewer tiles than CUs but at least half as
-  // many, a multiple of 8 (so every XCD gets the same number of owners and helpers).  Owners run the first q K steps of
-  // their tile, the CUs - tiles helpers share the tails; q = the even split + a margin that pays for the helpers'
-  // per-piece costs (ring prologue, 272 KB publish): a fifth of the even tail, or W2V2_WGRAD_SK_MARGIN steps.  The epoch makes a stale
-  // flag of an earlier launch unequal to this launch's value, so the flags never need resetting.
-  int sk_grid = 0;
-  a.sk_partials = nullptr; a.sk_flags = nullptr; a.sk_epoch = 0; a.sk_owner_steps = 0;
-  if (ring4 && workspace != nullptr && !a.use_order && wgrad_sk_enabled()) {
-    const int64_t need = w2v2_wgrad_workspace_bytes(probs, n);
-    if (need > 0 && workspace_bytes >= need && (reinterpret_cast<uintptr_t>(workspace) & 15) == 0) {
-      static const int margin_env = getenv("W2V2_WGRAD_SK_MARGIN") ? atoi(getenv("W2V2_WGRAD_SK_MARGIN")) : -1;
-      const int nk_tile = a.ktiles * 2;
-      const int q0 = (int)cdiv((int64_t)tiles * nk_tile, ncu);
-      const int q_m = q0 + (margin_env >= 0 ? margin_env : (nk_tile - q0) / 5);
-      const int q = q_m < nk_tile ? q_m : nk_tile;
-      const int r = nk_tile - q, H = ncu - tiles;
-      // a tail must fit into one helper's share (then it is split between at most two helpers = two slots)
-      if (r > 0 && cdiv((int64_t)tiles * r, H) >= r) {
-        static unsigned epoch = 0;
-        if (++epoch == 0) epoch = 1;
-        a.sk_flags = reinterpret_cast<unsigned*>(workspace);
-        a.sk_partials = reinterpret_cast<float4*>(reinterpret_cast<char*>(workspace) + sk_flag_bytes(tiles));
-        a.sk_epoch = epoch;
-        a.sk_owner_steps = q;
-        sk_grid = ncu;
-      }
-    }
-  }
-  W2V2_DISPATCH_16(dtype, "wgrad_grouped", wgrad_launch<AT>(a, tiles, ring, ring4, sk_grid, as_stream(stream)););
+  W2V2_REQUIRE(dtype == W2V2_BF16 || dtype == W2V2_F16, "wgrad_grouped: needs a 16-bit activation dtype (got %d)", dtype);
+  if (phased) w2v2_launch_wgrad_phased(a, dtype, tiles, late, as_stream(stream));
+  else W2V2_DISPATCH_16(dtype, "wgrad_grouped", wgrad_launch<AT>(a, tiles, ring, ring4, as_stream(stream)););
   W2V2_CHECK_LAUNCH("wgrad_grouped");
   return 0;
 }

@@ -211,30 +211,14 @@ class WgradGroup:
         self._arr, self._keep, self._n = arr, keep, n
         self._tokens, self._tpad = tokens, tokens_padded
         self._dt = dt(problems[0][0])
-        self._fn = lib().w2v2_wgrad_grouped_ws
-        # stream-K scratch (w2v2_wgrad_grouped_ws; opt-in with W2V2_WGRAD_STREAMK=1 -- measured not faster than the plain
-        # launch): one zero-initialised buffer per device, shared by every group -- all launches go
-        # to the plan's one stream, so they never overlap
-        self._ws, self._ws_bytes = None, 0
-        need = 0
-        if problems[0][0].is_cuda and os.environ.get("W2V2_WGRAD_STREAMK", "0")[:1] == "1":
-            need = int(lib().w2v2_wgrad_workspace_bytes(arr, n))
-        if need > 0:
-            key = str(problems[0][0].device)
-            cur = WgradGroup._workspaces.get(key)
-            if cur is None or cur.numel() < need:
-                cur = torch.zeros(need, dtype=torch.uint8, device=problems[0][0].device)
-                WgradGroup._workspaces[key] = cur
-            self._ws, self._ws_bytes = cur, need
-
-    _workspaces = {}
+        self._fn = lib().w2v2_wgrad_grouped
 
     def __call__(self) -> None:
         if Gemm._log is not None:
             Gemm._log.append({"kind": "wgrad", "problems": self._n, "tokens": self._tokens, "flops": self.flops,
                               "alg_flops": self.flops,
                               "kernel": "wgrad_grouped_ring4_kernel" if self._n >= 8 else "wgrad_grouped_ring_kernel"})
-        rc = self._fn(self._arr, self._n, self._tokens, self._tpad, self._dt, _p(self._ws), self._ws_bytes, stream())
+        rc = self._fn(self._arr, self._n, self._tokens, self._tpad, self._dt, stream())
         if rc:
             _lib.check(rc, "wgrad_grouped")
 
