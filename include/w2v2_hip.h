@@ -399,7 +399,7 @@ int w2v2_aam_softmax_fwd_bwd(const float* cos, const int64_t* label, float* soft
                              float* loss_rows, void* dcos_w, void* dcos_x, const float* inv_x,
                              const float* inv_w, float* rowdot, float* colprod, int B, int C,
                              int64_t ldc, float margin, float scale, const float* loss_scale,
-                             float* correct_rows, int dtype, void* stream);
+                             float* correct_rows, int easy_margin /* ref: aam_softmax.py:60-61 */, int dtype, void* stream);
 /* F.normalize backward: dx = inv[r] * (g[r] - x[r] * inv[r] * dot[r]);  g, dx f32 (dx written or
  * added), x f32 or act dtype. */
 int w2v2_normalize_bwd(const float* g, const void* x, int64_t ldx, const float* inv,

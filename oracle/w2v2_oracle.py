@@ -351,8 +351,8 @@ def attentive_stat_pool(x_bth: Tensor, asp: StateDict, bn_eps: float = 1e-5) -> 
 
 # --------------------------------------------------------------------------- heads
 def aam_softmax(x: Tensor, fc_weights: Tensor, label: Tensor, margin: float = 0.2,
-                scale: float = 30.0) -> Tuple[Tensor, Tensor]:
-    """ref: src/optim/loss/aam_softmax.py:50-74 (easy_margin=False) -> (loss, softmax[B,C])."""
+                scale: float = 30.0, easy_margin: bool = False) -> Tuple[Tensor, Tensor]:
+    """ref: src/optim/loss/aam_softmax.py:50-74 (both branches of easy_margin, :60-63) -> (loss, softmax[B,C])."""
     cos_m, sin_m = math.cos(margin), math.sin(margin)
     th = math.cos(math.pi - margin)
     mm = math.sin(math.pi - margin) * margin
@@ -361,7 +361,7 @@ def aam_softmax(x: Tensor, fc_weights: Tensor, label: Tensor, margin: float = 0.
     cosine = xn @ wn.t()
     sine = torch.sqrt((1.0 - cosine * cosine).clamp(0, 1))
     phi = cosine * cos_m - sine * sin_m
-    phi = torch.where((cosine - th) > 0, phi, cosine - mm)
+    phi = torch.where(cosine > 0, phi, cosine) if easy_margin else torch.where((cosine - th) > 0, phi, cosine - mm)
     one_hot = torch.zeros_like(cosine)
     one_hot.scatter_(1, label.view(-1, 1), 1)
     output = (one_hot * phi + (1.0 - one_hot) * cosine) * scale

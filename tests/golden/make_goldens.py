@@ -282,6 +282,19 @@ def golden_aam():
         k = f"m{margin}_s{scale}."
         g[k + "loss"], g[k + "softmax"] = loss, pred
         g[k + "dx"], g[k + "dW"] = xi.grad, fn.fc_weights.grad
+    # easy_margin=True (ref: aam_softmax.py:60-61): phi where cos > 0, the cosine itself elsewhere.  Rows 0 / 2 sit at
+    # cos ~ -1 (the `cosine` branch), row 1 at cos = +1, the random rows on both sides of 0.
+    fn = AngularAdditiveMarginSoftMaxLoss(D, C, margin=0.2, scale=30.0, easy_margin=True)
+    with torch.no_grad():
+        fn.fc_weights.copy_(W)
+    xi = x.clone().requires_grad_(True)
+    loss, pred = fn(xi, label)
+    loss.backward()
+    g["easy_m0.2_s30.0.loss"], g["easy_m0.2_s30.0.softmax"] = loss, pred
+    g["easy_m0.2_s30.0.dx"], g["easy_m0.2_s30.0.dW"] = xi.grad, fn.fc_weights.grad
+    with torch.no_grad():
+        xn = torch.nn.functional.normalize(x) @ torch.nn.functional.normalize(W).t()
+        g["easy.label_cos"] = xn.gather(1, label.view(-1, 1))[:, 0]
     g.update(x=x, W=W, label=label)
     np.savez_compressed(os.path.join(OUT, "g4_aam.npz"), **to_np(g))
     print("g4_aam ok")

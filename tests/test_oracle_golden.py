@@ -126,6 +126,25 @@ def test_aam_known_answers():
         assert np.allclose(W.grad.numpy(), g[k + "dW"], atol=1e-5, equal_nan=True)
 
 
+def test_aam_easy_margin_known_answers():
+    """ref: src/optim/loss/aam_softmax.py:60-61 (`easy_margin=True`: phi where cos > 0, the cosine itself elsewhere);
+    golden rows cover both branches (label cosines -1, +1, -0.999, and six within +-0.2 of zero on both sides)."""
+    g = load("g4_aam.npz")
+    assert (g["easy.label_cos"] > 0).sum() >= 3 and (g["easy.label_cos"] <= 0).sum() >= 3
+    x = T(g["x"]).requires_grad_(True)
+    W = T(g["W"]).requires_grad_(True)
+    loss, sm = O.aam_softmax(x, W, T(g["label"]), 0.2, 30.0, easy_margin=True)
+    loss.backward()
+    k = "easy_m0.2_s30.0."
+    assert abs(float(loss) - float(g[k + "loss"])) < 1e-5
+    assert np.allclose(sm.detach().numpy(), g[k + "softmax"], atol=1e-6)
+    assert np.allclose(x.grad.numpy(), g[k + "dx"], atol=1e-5, equal_nan=True)
+    assert np.allclose(W.grad.numpy(), g[k + "dW"], atol=1e-5, equal_nan=True)
+    # and it differs from the default branch on exactly these inputs
+    l2, _ = O.aam_softmax(T(g["x"]), T(g["W"]), T(g["label"]), 0.2, 30.0)
+    assert abs(float(l2) - float(loss)) > 1e-3
+
+
 def test_pooling_goldens_incl_edges():
     g = load("g5_pool.npz")
     for name in ("small", "t1", "long"):

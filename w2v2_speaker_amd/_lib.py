@@ -117,7 +117,7 @@ _SIGS = {
     "w2v2_asp_context_bwd": (c_i32, [c_vp] * 7 + [c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "w2v2_row_invnorm": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_i32, c_i32, c_vp]),
     "w2v2_aam_softmax_fwd_bwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32,
-                                         c_i32, c_i64, c_f32, c_f32, c_vp, c_vp, c_i32, c_vp]),
+                                         c_i32, c_i64, c_f32, c_f32, c_vp, c_vp, c_i32, c_i32, c_vp]),
     "w2v2_normalize_bwd": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "w2v2_adam_step": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32,
                                c_f32, c_f32, c_vp, c_i32, c_i32, c_vp]),

@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256) void aam_row_kernel(const float* __restrict__ 
                                                       const float* __restrict__ inv_w, float* __restrict__ rowdot,
                                                       float* __restrict__ colprod, int B, int C, int64_t ldc,
                                                       float margin, float scale, const float* __restrict__ loss_scale,
-                                                      float* __restrict__ correct_rows) {
+                                                      float* __restrict__ correct_rows, int easy_margin) {
   __shared__ float sh[4];
   __shared__ int shi[4];
   const int b = blockIdx.x;
@@ -69,10 +69,12 @@ __global__ __launch_bounds__(256) void aam_row_kernel(const float* __restrict__ 
       const float mm = sinf(3.14159265358979323846f - margin) * margin;
       const float sine = sqrtf(fminf(fmaxf(1.0f - cy * cy, 0.f), 1.f));
       float phi = cy * cos_m - sine * sin_m;
-      if (cy - th > 0.f) {
+      // ref: aam_softmax.py:60-63 -- easy_margin: phi where cos > 0, else the cosine itself; otherwise phi where
+      // cos > cos(pi - m), else cos - sin(pi - m) * m
+      if (easy_margin ? (cy > 0.f) : (cy - th > 0.f)) {
         dphi = cos_m + sin_m * cy / fmaxf(sine, 1e-12f);
       } else {
-        phi = cy - mm;
+        phi = easy_margin ? cy : cy - mm;
         dphi = 1.0f;
       }
       zy = phi * scale;
@@ -130,13 +132,13 @@ __global__ __launch_bounds__(256) void aam_row_kernel(const float* __restrict__ 
 extern "C" int w2v2_aam_softmax_fwd_bwd(const float* cos, const int64_t* label, float* softmax, float* loss_rows,
                                         void* dcos_w, void* dcos_x, const float* inv_x, const float* inv_w,
                                         float* rowdot, float* colprod, int B, int C, int64_t ldc, float margin,
-                                        float scale, const float* loss_scale, float* correct_rows, int dtype,
-                                        void* stream) {
+                                        float scale, const float* loss_scale, float* correct_rows, int easy_margin,
+                                        int dtype, void* stream) {
   W2V2_REQUIRE(cos && label && softmax && loss_rows && B > 0 && C > 0 && ldc >= C, "aam_softmax: bad arguments");
   W2V2_DISPATCH_ACT(dtype, "aam_softmax",
     hipLaunchKernelGGL(aam_row_kernel<AT>, dim3(B), dim3(256), 0, as_stream(stream), cos, label, softmax,
                        loss_rows, (AT*)dcos_w, (AT*)dcos_x, inv_x, inv_w, rowdot, colprod, B, C, ldc, margin,
-                       scale, loss_scale, correct_rows););
+                       scale, loss_scale, correct_rows, easy_margin););
   W2V2_CHECK_LAUNCH("aam_softmax");
   return 0;
 }

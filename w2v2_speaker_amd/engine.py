@@ -537,6 +537,35 @@ class Plan:
         self.out = (self.X[cfg.num_hidden_layers] if self.all_x else self.X[cfg.num_hidden_layers % 2]).view(B, T, H)
         return self.out
 
+    def conv_features(self, wav: torch.Tensor) -> torch.Tensor:
+        """The conv feature extractor alone (HF:382-419; ref: src/models/wav2vec2.py:163-169,
+        ``Wav2vecLiteWrapperModule.forward``): wav [B,N] f32 -> [B, L, 512] (act dtype, channels-last; the reference
+        returns the transpose).  Same kernels as the first stage of forward()."""
+        cfg, st = self.cfg, self.store
+        if wav.dim() == 3:
+            wav = wav[:, 0, :]
+        wav = wav.contiguous()
+        assert wav.shape == (self.Bc, self.N) and wav.dtype == torch.float32 and wav.is_cuda
+        self._refresh_packs()
+        self._wav = wav
+        mp = st.mp
+        ops.conv0_groupnorm_gelu(wav, mp("feature_extractor.conv_layers.0.conv.weight"),
+                                 mp("feature_extractor.conv_layers.0.layer_norm.weight"),
+                                 mp("feature_extractor.conv_layers.0.layer_norm.bias"), self.conv[0], self.stats0,
+                                 cfg.conv_kernel[0], cfg.conv_stride[0])
+        for g in self.g_conv:
+            g()
+        return self.conv[-1]
+
+    def conv_backward(self, dfeat: torch.Tensor) -> None:
+        """Backward of conv_features(): dfeat [B, L, 512] = d(loss)/d(features); the gradients of the seven conv layers
+        and the layer-0 GroupNorm are ACCUMULATED in the arena.  Needs a plan built with train=True over a store with
+        ``freeze_cnn=False``."""
+        if not self.train or self.store.freeze_cnn:
+            raise RuntimeError("conv_backward needs Plan(train=True) over ParamStore(freeze_cnn=False)")
+        self.dn.view(-1).copy_(dfeat.to(self.adt).contiguous().view(-1))
+        self._backward_cnn()
+
     def embed(self, wav, mask=None, skip_layers=(), step: int = 0, feature_mask=None) -> torch.Tensor:
         """ref: src/lightning_modules/speaker/wav2vec2_fc.py:414-431 -> pooled embedding [B,E] f32."""
         out = self.forward(wav, mask, skip_layers, step, feature_mask)

@@ -16,11 +16,12 @@ class ClassifierHead:
     def __init__(self, kind: str, batch: int, embed_dim: int, classes: int, *, w_master: torch.Tensor,
                  w_operand: torch.Tensor, w_grad: Optional[torch.Tensor], bias: Optional[torch.Tensor] = None,
                  bias_grad: Optional[torch.Tensor] = None, emb: torch.Tensor, act_dtype: torch.dtype,
-                 train: bool, margin: float = 0.2, scale: float = 30.0, loss_scale: Optional[torch.Tensor] = None):
+                 train: bool, margin: float = 0.2, scale: float = 30.0, loss_scale: Optional[torch.Tensor] = None,
+                 easy_margin: bool = False):
         assert kind in ("aam", "ce")
         self.loss_scale = loss_scale          # device record of the dynamic loss scale (fp16 activations) or None
         self.kind, self.B, self.E, self.C, self.train = kind, batch, embed_dim, classes, train
-        self.margin, self.scale = margin, scale
+        self.margin, self.scale, self.easy_margin = margin, scale, bool(easy_margin)
         self.w_master, self.w_grad, self.bias, self.bias_grad, self.emb = w_master, w_grad, bias, bias_grad, emb
         dev, f32 = emb.device, torch.float32
         B, E, Cn = batch, embed_dim, classes
@@ -91,7 +92,7 @@ class ClassifierHead:
                                 self.inv_x if aam else None, self.inv_w if aam else None,
                                 self.rowdot if (tr and aam) else None, self.colprod if (tr and aam) else None,
                                 B, Cn, self.ldc, self.margin if aam else -1.0, self.scale, self.loss_scale if tr else None,
-                                self.correct)
+                                self.correct, easy_margin=self.easy_margin)
         loss = torch.empty((), dtype=torch.float32, device=self.loss_rows.device)     # (allocator only: no kernel)
         ops.mean(self.loss_rows, loss)
         if tr:

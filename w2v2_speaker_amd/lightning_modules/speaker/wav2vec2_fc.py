@@ -153,8 +153,11 @@ class Wav2vec2FCModule(torch.nn.Module):
         self.hyperparameters_to_save = hyperparameters_to_save
         self.cfg = cfg
         if cfg.wav2vec_feature_encoder_only:
-            # ref: :118-128 Wav2vecLiteWrapperModule (CNN only) -- not on the hot path
-            raise NotImplementedError("wav2vec_feature_encoder_only (Wav2vecLiteWrapperModule) is outside the hot path")
+            # ref: :114-128 swaps in Wav2vecLiteWrapperModule (CNN only).  The wrapper itself is mirrored
+            # (models.wav2vec2.Wav2vecLiteWrapperModule, forward + conv backward); the speaker module over it is not:
+            # no experiment of the reference sets this flag (config/network/wav2vec2_fc.yaml:12 `false`)
+            raise NotImplementedError("wav2vec_feature_encoder_only=True: use models.wav2vec2.Wav2vecLiteWrapperModule "
+                                      "directly; the speaker module over the CNN-only encoder is not built")
         # ``final_channel_mask_prob`` is accepted and has NO effect, like in the reference: its EmbeddingMasker gates
         # the channel mask on ``timestep_mask_prob``, which Wav2vec2FCModule hard-wires to 0 (quirk Q3,
         # ref: src/layers/embedding_masking.py:79, wav2vec2_fc.py:162-169)

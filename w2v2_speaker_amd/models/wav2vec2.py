@@ -135,3 +135,65 @@ class Wav2Vec2WrapperModule(torch.nn.Module):
         self.store.load_state_dict(sd, strict=False)
         for p in self._plans.values():
             p._pack_version = -1
+
+
+class _ConvFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, wav, anchor, module):
+        plan = module._plan(wav.shape[0], wav.shape[-1], module.training and not module.store.freeze_cnn)
+        ctx.plan = plan
+        return plan.conv_features(wav).clone()
+
+    @staticmethod
+    def backward(ctx, dout):
+        ctx.plan.conv_backward(dout)
+        return None, torch.zeros((), device=dout.device), None
+
+
+class Wav2vecLiteWrapperModule(torch.nn.Module):
+    """Mirror of ref: src/models/wav2vec2.py:149-169 -- the wav2vec2 CONV FEATURE EXTRACTOR only
+    (``wav2vec_feature_encoder_only``): ``forward(wav [B,N]) -> [B, 512, num_frames]``, on the engine's conv kernels
+    (layer 0 fused conv + GroupNorm + GELU, layers 1-6 implicit-GEMM convs).  Gradients of a backward pass are
+    accumulated in ``store.grad`` like in Wav2Vec2WrapperModule (the store must be built with ``freeze_cnn=False`` to
+    train the CNN; with the default frozen store the module is forward-only)."""
+    num_features = 512
+
+    def __init__(self, wav2vec2_huggingface_id: str, reset_weights: bool, *, store: Optional[ParamStore] = None,
+                 device="cuda", act_dtype: torch.dtype = torch.float16, init_seed: int = 20211, pretrained_state_dict=None,
+                 freeze_cnn: bool = False):
+        super().__init__()
+        self.cfg = W2V2Config.from_huggingface_id(wav2vec2_huggingface_id)
+        self.num_features = self.cfg.conv_dim[-1]
+        self.store = store if store is not None else ParamStore(self.cfg, device, act_dtype, head=None,
+                                                                freeze_cnn=freeze_cnn)
+        if store is None:
+            self.store.init_weights(init_seed)
+            if pretrained_state_dict is not None:
+                sd = (torch.load(pretrained_state_dict, map_location="cpu", weights_only=False)
+                      if isinstance(pretrained_state_dict, str) else pretrained_state_dict)
+                self.store.load_state_dict(dict(sd), strict=False, prefix_model=True)
+            elif not reset_weights:
+                warnings.warn("Wav2vecLiteWrapperModule: reset_weights=False asks for pretrained weights but no "
+                              "pretrained_state_dict was given (no network access): RANDOM initialisation", stacklevel=2)
+        self._plans: "OrderedDict[Tuple[int, int, bool], Plan]" = OrderedDict()
+        self._anchor = torch.nn.Parameter(torch.zeros((), device=self.store.device))
+        self.model = ModelHandle(self.store)
+
+    @property
+    def num_embedding_features(self):
+        return self.num_features
+
+    def _plan(self, batch: int, n_samples: int, train: bool) -> Plan:
+        key = (batch, n_samples, train)
+        if key not in self._plans:
+            self._plans[key] = Plan(self.store, batch, n_samples, train=train, reg=Wav2Vec2RegularisationConfig())
+            while len(self._plans) > MAX_PLANS:
+                self._plans.popitem(last=False)
+        self._plans.move_to_end(key)
+        return self._plans[key]
+
+    def forward(self, wav_input: torch.Tensor) -> torch.Tensor:
+        # wav_input has shape [BATCH_SIZE, NUM_SAMPLES]
+        feat = _ConvFn.apply(wav_input.to(self.store.device, torch.float32), self._anchor, self)
+        # return an embedding with shape [BATCH_SIZE, NUM_FEATURES, NUM_FRAMES]
+        return feat.transpose(1, 2)

@@ -496,7 +496,8 @@ def row_invnorm(x, inv, rows: int, cols: int, ld: Optional[int] = None) -> None:
 
 
 def aam_softmax_fwd_bwd(cos, label, softmax, loss_rows, dcos_w, dcos_x, inv_x, inv_w, rowdot, colprod, B: int,
-                        Cn: int, ldc: int, margin: float, scale: float, loss_scale=None, correct_rows=None) -> None:
+                        Cn: int, ldc: int, margin: float, scale: float, loss_scale=None, correct_rows=None,
+                        easy_margin: bool = False) -> None:
     """loss_scale: device tensor whose first element multiplies the loss gradient (fp16 loss scaling), or None.
     correct_rows [B] f32 (optional): 1 where the arg-max prediction equals the label (train_acc).
     colprod [B, Cn] f32 (optional): g * cos per element; colsum() over its rows gives the column dots."""
@@ -505,7 +506,7 @@ def aam_softmax_fwd_bwd(cos, label, softmax, loss_rows, dcos_w, dcos_x, inv_x, i
     _lib.check(lib().w2v2_aam_softmax_fwd_bwd(cos.data_ptr(), label.data_ptr(), softmax.data_ptr(),
                                               loss_rows.data_ptr(), _p(dcos_w), _p(dcos_x), _p(inv_x), _p(inv_w),
                                               _p(rowdot), _p(colprod), B, Cn, ldc, margin, scale, _p(loss_scale),
-                                              _p(correct_rows), dty, stream()),
+                                              _p(correct_rows), int(easy_margin), dty, stream()),
                "aam_softmax")
 
 

@@ -33,8 +33,6 @@ class AngularAdditiveMarginSoftMaxLoss(torch.nn.Module):
     def __init__(self, input_features, output_features, margin=0.3, scale=15, easy_margin=False, *,
                  device="cuda", act_dtype: torch.dtype = torch.bfloat16):
         super().__init__()
-        if easy_margin:
-            raise NotImplementedError("easy_margin=True is not on the reference's hot path")
         self.margin, self.scale, self.input_features = margin, scale, input_features
         self.easy_margin = easy_margin
         w = torch.empty(output_features, input_features, device=device)
@@ -55,7 +53,8 @@ class AngularAdditiveMarginSoftMaxLoss(torch.nn.Module):
             emb = torch.empty(batch, E, dtype=torch.float32, device=device)
             head = ClassifierHead("aam", batch, E, C, w_master=self.fc_weights.data, w_operand=wlp,
                                   w_grad=torch.zeros_like(self.fc_weights.data), emb=emb,
-                                  act_dtype=self.act_dtype, train=train, margin=self.margin, scale=self.scale)
+                                  act_dtype=self.act_dtype, train=train, margin=self.margin, scale=self.scale,
+                                  easy_margin=self.easy_margin)
             self._heads[key] = (head, wlp)
         head, wlp = self._heads[key]
         if wlp is not self.fc_weights.data:
