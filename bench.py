@@ -34,7 +34,7 @@ import numpy as np
 import torch
 
 MFMA_PEAK_TFLOPS = 2500.0      # /opt/skills/guides/MI355X_MICROARCH.md: dense bf16 / fp16 MFMA peak
-PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_counters.json")   # tools/profile_round.sh -> tools/pmc_counters.py
+PMC_FILE = os.path.join(ROOT, "profiles", "r04_pmc_counters.json")   # tools/profile_round.sh -> tools/pmc_counters.py
 
 
 def synth_batch(batch, n_samples, num_speakers, seed, device):
@@ -120,7 +120,8 @@ def parse_args():
                          "(24 layers, H=1024; use --seconds 5 --batch 32); ecapa = configs[4] (ECAPA-TDNN on 300 x 40 "
                          "filterbank frames, HBM-roofline entry)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-also", action="store_true", help="skip the short bf16-mode leg reported under `also`")
+    ap.add_argument("--no-also", action="store_true",
+                    help="skip the short legs reported under `also` (bf16 mode + BASELINE configs[2], [3], [4])")
     ap.add_argument("--no-regularisation", action="store_true", help="dropout / LayerDrop / masks off")
     ap.add_argument("--unfreeze-cnn", action="store_true",
                     help="completely_freeze_feature_extractor=False ablation (127.2 GFLOP/utt)")
@@ -244,6 +245,10 @@ def run(args):
     trainer = SpeakerTrainer(store, plan, OneCycle(max_lr=5e-5, total_steps=max(total, 10)),
                              layerdrop_seed=1234 + rank, mask_seed=7 + rank)
     wav, label = synth_batch(args.batch, n_samples, args.speakers, seed=42133724 + rank, device=dev)
+    if world > 1:
+        # what PL's DDP wrapper does when it wraps the module: every replica starts from rank 0's state,
+        # whatever the ranks initialised or loaded themselves
+        trainer.reducer.broadcast_parameters(0)
 
     def sync():
         torch.cuda.synchronize()
@@ -255,8 +260,7 @@ def run(args):
         trainer.train_step(wav, label)
     sync()
     skipped0 = int(store.scaler[3]) if store.scaler is not None else 0
-    ring = ("gemm16_ring_256x128_kernel", "gemm16_ring_256x256_kernel", "gemm16_phased_256x256_kernel",
-            "gemm16_quad_256x256_kernel")
+    ring = ("gemm16_ring_256x128_kernel", "gemm16_phased_256x256_kernel")
     ops.Gemm.profile_begin(lambda g: g.kernel_name in ring)
     n_skip_layers = 0
     t0 = time.perf_counter()
@@ -309,11 +313,8 @@ def run(args):
         if prof["launches"]:
             desc = {"gemm16_ring_256x128_kernel": "256x128x64 3-stage LDS-DMA ring MFMA GEMM: conv4-6, projection, QKV, "
                                               "out-proj, FFN2 forward + the N<=2304 data-gradient products",
-                    "gemm16_ring_256x256_kernel": "256x256x32 4-stage LDS-DMA ring MFMA GEMM: conv1-3, FFN1 forward, dH",
                     "gemm16_phased_256x256_kernel": "256x256x64 phased LDS-DMA MFMA GEMM (two wave groups in anti-phase): conv1-3, "
-                                      "FFN1 forward, dH",
-                    "gemm16_quad_256x256_kernel": "256x256x64 4-wave register-staged MFMA GEMM (128x128 wave tiles, AGPR "
-                                                  "accumulators): conv1-3, FFN1 forward, dH"}
+                                      "FFN1 forward, dH"}
             pmc, pmc_stale = {}, None
             try:     # HBM bytes per launch and matrix-pipe busy fraction from the committed PMC passes of this command
                 # (separate rocprofv3 --pmc runs: a timed run cannot carry counters); stale = the kernel sources have
@@ -329,10 +330,10 @@ def run(args):
             # (tools/probes/mfma_sustained_probe, committed output): the power-limited ceiling under `peak`
             sustained = None
             try:
-                for ln in open(os.path.join(ROOT, "profiles", "r03_mfma_sustained.txt")):
+                for ln in open(os.path.join(ROOT, "profiles", "r04_mfma_sustained.txt")):
                     f = ln.split()
                     if len(f) == 5 and f[0] == "256" and f[1] == "1" and f[2] == "random":
-                        sustained = float(f[4])
+                        sustained = float(f[4])       # first block of the file = v_mfma_f32_16x16x32_f16 (the kernels' shape)
                         break
             except Exception:
                 pass
@@ -356,30 +357,60 @@ def run(args):
             if len(ranked) > 1:
                 out["roofline_second_kernel"] = entry(*ranked[1])
         if world == 1 and args.dtype == "f16" and args.model == "base" and not args.no_also:
-            # BASELINE configs[1] says "bf16"; the line above is fp16 because only fp16 operands keep the embedding
-            # within the 1e-3 rel-L2 target (tests/test_parity_gpu.py: fp16 7.7e-4 / 9e-4 on the two reference goldens,
-            # bf16 8.4e-3).  The bf16 mode of the same engine, same workload, measured here for the record:
+            # Short legs of the same engine on the other BASELINE configurations, so that the driver's line carries them
+            # (5 timed steps each after 2 warm-up steps; `value` above is untouched by them):
+            #   bf16          configs[1] says "bf16"; the headline is fp16 because only fp16 operands keep the embedding
+            #                 within the 1e-3 rel-L2 target (tests/test_parity_gpu.py; profiles/r04_parity.json)
+            #   attentive_b66 configs[2]: w2v2-base + attentive statistics pooling, the per-GPU share of the DDP job
+            #   large_5s_b32  configs[3]: wav2vec2-large geometry (24 layers, H = 1024), 5 s clips, 32 utterances per GPU
+            #   ecapa_f32_b66 configs[4]: ECAPA-TDNN, with its per-family HBM roofline (tools/ecapa_bench.py)
             del trainer, plan, store
             torch.cuda.empty_cache()
-            st2 = ParamStore(cfg, dev, torch.bfloat16, head="aam", num_speakers=args.speakers, freeze_cnn=not args.unfreeze_cnn,
-                             attentive_pool=args.pooling == "attentive",
-                             embed_dim=cfg.hidden_size * (1 if args.pooling == "first+cls" else 2))
-            st2.init_weights(seed=20211)
-            pl2 = Plan(st2, args.batch, n_samples, train=True, reg=reg, seed=7, pooling=args.pooling,
-                       insert_cls_token=args.pooling == "first+cls")
-            tr2 = SpeakerTrainer(st2, pl2, OneCycle(max_lr=5e-5, total_steps=40), layerdrop_seed=1234, mask_seed=7)
-            for _ in range(3):
-                tr2.train_step(wav, label)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(10):
-                tr2.train_step(wav, label)
-            torch.cuda.synchronize()
-            dt2 = (time.perf_counter() - t1) / 10
-            out["also"] = {"bf16": {"ms_per_step": round(1e3 * dt2, 3), "value": round(args.batch / dt2, 2),
-                                    "unit": "utterances/sec", "steps": 10,
-                                    "embedding_rel_l2_vs_reference": "8.4e-3 (bound 3e-2 asserted; fp16: < 1e-3 asserted) "
-                                                                     "-- tests/test_parity_gpu.py"}}
+
+            def leg(model, pooling, seconds, batch, adt, note):
+                c = W2V2Config.from_huggingface_id("facebook/wav2vec2-" + model)
+                ns = int(round(seconds * 16000))
+                st2 = ParamStore(c, dev, adt, head="aam", num_speakers=args.speakers, freeze_cnn=True,
+                                 attentive_pool=pooling == "attentive", embed_dim=c.hidden_size * 2)
+                st2.init_weights(seed=20211)
+                pl2 = Plan(st2, batch, ns, train=True, reg=reg, seed=7, pooling=pooling)
+                tr2 = SpeakerTrainer(st2, pl2, OneCycle(max_lr=5e-5, total_steps=40), layerdrop_seed=1234, mask_seed=7)
+                w2, l2 = synth_batch(batch, ns, args.speakers, seed=42133724, device=dev)
+                for _ in range(2):
+                    tr2.train_step(w2, l2)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(5):
+                    ls, _ = tr2.train_step(w2, l2)
+                torch.cuda.synchronize()
+                dt2 = (time.perf_counter() - t1) / 5
+                fl2 = c.flops_per_utt(ns, args.speakers)["train_frozen_cnn"]
+                res = {"ms_per_step": round(1e3 * dt2, 3), "value": round(batch / dt2, 2), "unit": "utterances/sec",
+                       "steps": 5, "warmup": 2, "model_tflops": round(fl2 * batch / dt2 / 1e12, 1),
+                       "final_loss": round(float(ls), 4),
+                       "workload": f"wav2vec2-{model} + AAM-softmax({args.speakers}), {pooling} pooling, {seconds:g} s "
+                                   f"synthetic audio, bs={batch}, {str(adt).split('.')[-1]}, fwd+bwd+Adam -- {note}"}
+                del tr2, pl2, st2
+                torch.cuda.empty_cache()
+                return res
+            also = {}
+            also["bf16"] = leg("base", "mean+std", args.seconds, args.batch, torch.bfloat16,
+                               "BASELINE configs[1] in the bf16 mode (embedding rel-L2 vs the reference 8.4e-3, bound "
+                               "3e-2 asserted; fp16: < 1e-3 asserted)")
+            also["attentive_b66"] = leg("base", "attentive", 3.0, 66, torch.float16, "BASELINE configs[2], per-GPU share")
+            also["large_5s_b32"] = leg("large", "mean+std", 5.0, 32, torch.float16, "BASELINE configs[3], per-GPU share")
+            try:
+                from types import SimpleNamespace
+                from tools.ecapa_bench import bench_ecapa
+                e = bench_ecapa(SimpleNamespace(batch=66, frames=300, steps=5, warmup=2, dtype="f32"), 1, 0, dev, None,
+                                emit=False)
+                also["ecapa_f32_b66"] = {k: e[k] for k in ("ms_per_step", "value", "unit", "steps", "warmup", "dtype", "mfma",
+                                                          "model_tflops_per_gpu", "roofline", "roofline_families",
+                                                          "gemm_mfma") if k in e}
+                also["ecapa_f32_b66"]["workload"] = e["config"]["workload"]
+            except Exception as ex:                    # a side leg must never cost the headline line
+                also["ecapa_f32_b66"] = {"error": repr(ex)}
+            out["also"] = also
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

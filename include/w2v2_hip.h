@@ -446,11 +446,17 @@ int w2v2_grad_scaler_update(float* state, float growth, float backoff, int growt
  *   every rank: w2v2_comm_init(&c, id, rank, world, device)             (collective: all ranks must call it)
  *   per bucket: w2v2_allreduce_async(c, grad + off, n, comm_stream)     (in place, f32, enqueued on the given stream;
  *               order the stream against the backward with events, like trainer.BucketAllReducer does)
- *   w2v2_comm_destroy(c) */
+ *   at start-up / after loading a checkpoint on one rank: w2v2_broadcast_async(c, buf, nbytes, root, stream) of the
+ *               parameter arena, the optimiser moments and the loss-scale record (in place, any dtype: bytes) -- what
+ *               PL's DDP wrapper does implicitly when it wraps the module (identical replicas)
+ *   w2v2_comm_destroy(c)
+ * Multi-rank operation of these entry points is covered by construction + a world-size-1 communicator on the 1-GPU test
+ * boxes; the first check on an N-GPU node is tools/scale_sweep.sh (2 ranks against torch.distributed, bitwise). */
 typedef struct w2v2_comm w2v2_comm;
 int w2v2_comm_unique_id(void* id_host_128);
 int w2v2_comm_init(w2v2_comm** comm, const void* id_host_128, int rank, int world, int device);
 int w2v2_allreduce_async(w2v2_comm* comm, float* buf, int64_t n, void* stream);
+int w2v2_broadcast_async(w2v2_comm* comm, void* buf, int64_t nbytes, int root, void* stream);
 int w2v2_comm_destroy(w2v2_comm* comm);
 
 #ifdef __cplusplus

@@ -164,6 +164,15 @@ def test_c_abi_collective_entry_points_on_rccl():
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
     assert torch.equal(x, ref)
+    # w2v2_broadcast_async (start-up broadcast of the replica state): root 0 of a one-rank communicator, any dtype
+    h = torch.randn(4097, device="cuda").to(torch.float16)
+    href = h.clone()
+    comm.broadcast_(h, 0, side)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    assert torch.equal(h, href)
+    with pytest.raises(RuntimeError):
+        comm.broadcast_(h, 3)                                  # root outside the communicator
     dev = torch.device("cuda", 0)
     outs = []
     for use in (False, True):
@@ -173,6 +182,9 @@ def test_c_abi_collective_entry_points_on_rccl():
         if use:
             red.world = 2                 # exercise the issue / wait path (a 1-rank SUM is the identity) ...
             tr.world = 1                  # ... without the 1/world gradient scaling
+            before = st.flat.clone()
+            red.broadcast_parameters(0)   # one rank: every state tensor comes back unchanged, operand copies rebuilt
+            assert torch.equal(st.flat, before)
         for _ in range(2):
             tr.train_step(wav, label)
         torch.cuda.synchronize()

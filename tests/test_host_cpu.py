@@ -153,6 +153,60 @@ def test_bucketed_allreduce_two_ranks_gloo():
     assert all(ok and same for _, ok, same in res), res
 
 
+def _bcast_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from w2v2_speaker_amd.config import W2V2Config
+    from w2v2_speaker_amd.params import ParamStore
+    from w2v2_speaker_amd.trainer import BucketAllReducer
+    st = ParamStore(W2V2Config.tiny(), "cpu", torch.float32, head="aam", num_speakers=10)
+    st.init_weights(seed=1000 + rank)                      # every rank starts DIFFERENT ("load on rank 0" situation)
+    g = torch.Generator().manual_seed(50 + rank)
+    st.exp_avg = torch.randn(st.n_train, generator=g)
+    st.exp_avg_sq = torch.rand(st.n_train, generator=g)
+    red = BucketAllReducer(st, bucket_merge=2)
+    before = st.flat.clone()
+    v0 = st.version
+    red.broadcast_parameters(root=0)
+    ref = ParamStore(W2V2Config.tiny(), "cpu", torch.float32, head="aam", num_speakers=10)
+    ref.init_weights(seed=1000)
+    g0 = torch.Generator().manual_seed(50)
+    m0 = torch.randn(st.n_train, generator=g0)
+    s0 = torch.rand(st.n_train, generator=g0)
+    ok = (torch.equal(st.flat, ref.flat) and torch.equal(st.exp_avg, m0) and torch.equal(st.exp_avg_sq, s0)
+          and st.version > v0 and (rank == 0 or not torch.equal(before, st.flat)))
+    # a rank whose state differs in KIND (no moments) must be refused, not silently mis-paired
+    refused = None
+    if world == 2:
+        if rank == 1:
+            st.exp_avg = st.exp_avg_sq = None
+        try:
+            red.broadcast_parameters(root=0)
+            refused = False
+        except RuntimeError:
+            refused = True
+    q.put((rank, bool(ok), refused))
+    dist.destroy_process_group()
+
+
+def test_broadcast_parameters_two_ranks_gloo():
+    """SURVEY C2 / ref: config/trainer/trainer.yaml:6-12 -- PL's DDP wrapper broadcasts rank 0's module state at start-up;
+    here ``BucketAllReducer.broadcast_parameters``: two ranks with DIFFERENT initial weights and moments end up with rank
+    0's, bit for bit; ranks that disagree on which state tensors exist get an error on every rank."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_bcast_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(ok and refused for _, ok, refused in res), res
+
+
 def _check_schedule(L, skip, pair_uppers, members):
     """Invariants of engine.encoder_backward_schedule against the bucketing of trainer.BucketAllReducer."""
     from w2v2_speaker_amd.engine import encoder_backward_schedule

@@ -28,7 +28,7 @@ import torch
 
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E ~8 TB/s
 MFMA_PEAK_TFLOPS = 2500.0
-PMC_FILE = os.path.join(ROOT, "profiles", "r03_ecapa_pmc_counters.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r04_ecapa_pmc_counters.json")
 
 
 FAMILY_KERNELS = {
@@ -75,7 +75,8 @@ class _FamilyTimer:
         return out
 
 
-def bench_ecapa(args, world, rank, dev, dist):
+def bench_ecapa(args, world, rank, dev, dist, emit=True):
+    """emit=False: return the line's dict instead of printing it (bench.py `also.ecapa_f32_b66`)."""
     from w2v2_speaker_amd import ops
     from w2v2_speaker_amd.ecapa import EcapaConfig, EcapaPlan, EcapaStore, EcapaTrainer
     from w2v2_speaker_amd.optim.schedule import OneCycle
@@ -186,6 +187,9 @@ def bench_ecapa(args, world, rank, dev, dist):
            "value": round(utt / elapsed, 1), "unit": "utterances/sec", "n_gpus": world, "steps": args.steps,
            "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None, "dtype": dtype,
+           "mfma": ("f32 exact: products on v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate, bit-for-bit an fmaf chain, f32 "
+                    "vector RATE) -- BASELINE configs[4] 'MFMA off' read as 'no reduced-precision matrix path'"
+                    if dtype == "f32" else "bf16 operands on v_mfma_f32_16x16x32_bf16, f32 accumulation"),
            "data": f"synthetic ({NB} distinct minibatches, round-robin)",
            "config": {"workload": f"ECAPA-TDNN (C=1024, 5 blocks, attentive statistics pooling, 192-d) + AAM-softmax(5994), "
                                   f"[{args.batch}, {frames}, 40] synthetic filterbank frames per GPU, fwd+bwd+"
@@ -206,6 +210,8 @@ def bench_ecapa(args, world, rank, dev, dist):
                             "by_kernel": {k: {"ms_per_step": round(v["ms"] / psteps, 3), "launches_per_step": v["launches"] // psteps,
                                               "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1)}
                                           for k, v in sorted(gp["by_kernel"].items(), key=lambda kv: -kv[1]["ms"])}}
+    if not emit:
+        return out
     print(json.dumps(out), flush=True)
 
 

@@ -125,6 +125,7 @@ _SIGS = {
     "w2v2_comm_unique_id": (c_i32, [c_vp]),
     "w2v2_comm_init": (c_i32, [C.POINTER(c_vp), c_vp, c_i32, c_i32, c_i32]),
     "w2v2_allreduce_async": (c_i32, [c_vp, c_vp, c_i64, c_vp]),
+    "w2v2_broadcast_async": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_vp]),
     "w2v2_comm_destroy": (c_i32, [c_vp]),
     "w2v2_grad_scaler_check": (c_i32, [c_vp, c_i64, c_vp, c_vp]),
     "w2v2_grad_scaler_update": (c_i32, [c_vp, c_f32, c_f32, c_i32, c_i32, c_vp]),

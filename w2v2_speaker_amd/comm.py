@@ -54,12 +54,22 @@ class RcclComm:
         s = (stream or torch.cuda.current_stream()).cuda_stream
         _lib.check(_lib.load().w2v2_allreduce_async(self._h, t.data_ptr(), t.numel(), s), "allreduce_async")
 
+    def broadcast_(self, t: torch.Tensor, root: int = 0, stream: Optional[torch.cuda.Stream] = None) -> None:
+        """Broadcast a contiguous CUDA tensor (any dtype: bytes) from ``root``, in place, enqueued on ``stream``."""
+        assert t.is_cuda and t.is_contiguous()
+        s = (stream or torch.cuda.current_stream()).cuda_stream
+        _lib.check(_lib.load().w2v2_broadcast_async(self._h, t.data_ptr(), t.numel() * t.element_size(), root, s),
+                   "broadcast_async")
+
     def destroy(self) -> None:
         if self._h:
             _lib.check(_lib.load().w2v2_comm_destroy(self._h), "comm_destroy")
             self._h = C.c_void_p()
 
     def __del__(self):
+        import sys
+        if sys is None or sys.is_finalizing():       # interpreter teardown: RCCL may already be unloaded (ADVICE r3)
+            return
         try:
             self.destroy()
         except Exception:
@@ -88,6 +98,15 @@ class CAbiBucketAllReducer:
         self.comm_stream.wait_event(ev)
         self.comm.all_reduce_(self.store.grad[s:e], self.comm_stream)
         self._issued = True
+
+    def broadcast_parameters(self, root: int = 0) -> None:
+        """Same contract as trainer.BucketAllReducer.broadcast_parameters, through w2v2_broadcast_async."""
+        if self.world == 1:
+            return
+        for t in self.store.replica_state():
+            self.comm.broadcast_(t, root)
+        torch.cuda.current_stream().synchronize()
+        self.store.sync_lowp()
 
     def wait(self) -> None:
         if self._issued:

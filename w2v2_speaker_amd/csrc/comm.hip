@@ -16,6 +16,7 @@ typedef void* Comm;                              // ncclComm_t
 typedef int (*GetUniqueIdFn)(UniqueId*);
 typedef int (*CommInitRankFn)(Comm*, int, UniqueId, int);
 typedef int (*AllReduceFn)(const void*, void*, size_t, int, int, Comm, hipStream_t);
+typedef int (*BroadcastFn)(const void*, void*, size_t, int, int, Comm, hipStream_t);
 typedef int (*CommDestroyFn)(Comm);
 typedef const char* (*GetErrorStringFn)(int);
 
@@ -24,6 +25,7 @@ struct Rccl {
   GetUniqueIdFn get_unique_id = nullptr;
   CommInitRankFn comm_init_rank = nullptr;
   AllReduceFn all_reduce = nullptr;
+  BroadcastFn broadcast = nullptr;
   CommDestroyFn comm_destroy = nullptr;
   GetErrorStringFn error_string = nullptr;
 };
@@ -53,6 +55,7 @@ int rccl_load() {
   g_rccl.get_unique_id = (GetUniqueIdFn)dlsym(h, "ncclGetUniqueId");
   g_rccl.comm_init_rank = (CommInitRankFn)dlsym(h, "ncclCommInitRank");
   g_rccl.all_reduce = (AllReduceFn)dlsym(h, "ncclAllReduce");
+  g_rccl.broadcast = (BroadcastFn)dlsym(h, "ncclBroadcast");
   g_rccl.comm_destroy = (CommDestroyFn)dlsym(h, "ncclCommDestroy");
   g_rccl.error_string = (GetErrorStringFn)dlsym(h, "ncclGetErrorString");
   if (!g_rccl.get_unique_id || !g_rccl.comm_init_rank || !g_rccl.all_reduce || !g_rccl.comm_destroy)
@@ -82,14 +85,24 @@ extern "C" int w2v2_comm_init(w2v2_comm** out, const void* id_host_128, int rank
   W2V2_REQUIRE(out != nullptr && id_host_128 != nullptr && world >= 1 && rank >= 0 && rank < world && device >= 0,
                "comm_init: bad arguments (rank %d of %d, device %d)", rank, world, device);
   if (rccl_load()) return -1;
+  // the communicator is bound to `device`; the caller's current device is restored
+  int prev = -1;
+  (void)hipGetDevice(&prev);
   if (hipSetDevice(device) != hipSuccess) W2V2_FAIL("comm_init: hipSetDevice(%d) failed", device);
+  w2v2_comm* w = (w2v2_comm*)malloc(sizeof(w2v2_comm));       // before the collective: nothing to unwind on failure
+  if (w == nullptr) {
+    if (prev >= 0) (void)hipSetDevice(prev);
+    W2V2_FAIL("comm_init: out of memory");
+  }
   UniqueId id;
   memcpy(&id, id_host_128, sizeof(id));
   Comm c = nullptr;
   const int rc = g_rccl.comm_init_rank(&c, world, id, rank);
-  if (rc != 0) W2V2_FAIL("comm_init: ncclCommInitRank: %s", rccl_err(rc));
-  w2v2_comm* w = (w2v2_comm*)malloc(sizeof(w2v2_comm));
-  if (w == nullptr) W2V2_FAIL("comm_init: out of memory");
+  if (prev >= 0) (void)hipSetDevice(prev);
+  if (rc != 0) {
+    free(w);
+    W2V2_FAIL("comm_init: ncclCommInitRank: %s", rccl_err(rc));
+  }
   w->comm = c; w->rank = rank; w->world = world; w->device = device;
   *out = w;
   return 0;
@@ -100,6 +113,16 @@ extern "C" int w2v2_allreduce_async(w2v2_comm* comm, float* buf, int64_t n, void
   if (n == 0) return 0;
   const int rc = g_rccl.all_reduce(buf, buf, (size_t)n, /*ncclFloat32*/ 7, /*ncclSum*/ 0, comm->comm, as_stream(stream));
   if (rc != 0) W2V2_FAIL("allreduce_async: ncclAllReduce: %s", rccl_err(rc));
+  return 0;
+}
+
+extern "C" int w2v2_broadcast_async(w2v2_comm* comm, void* buf, int64_t nbytes, int root, void* stream) {
+  W2V2_REQUIRE(comm != nullptr && buf != nullptr && nbytes >= 0 && root >= 0 && root < comm->world,
+               "broadcast_async: bad arguments (root %d)", root);
+  if (nbytes == 0) return 0;
+  W2V2_REQUIRE(g_rccl.broadcast != nullptr, "broadcast_async: librccl.so lacks ncclBroadcast");
+  const int rc = g_rccl.broadcast(buf, buf, (size_t)nbytes, /*ncclUint8*/ 1, root, comm->comm, as_stream(stream));
+  if (rc != 0) W2V2_FAIL("broadcast_async: ncclBroadcast: %s", rccl_err(rc));
   return 0;
 }
 

@@ -483,6 +483,16 @@ class ParamStore:
             v.pow(2).sum(dim=(0, 1), keepdim=True).sqrt())
         self.sync_lowp()
 
+    def replica_state(self) -> List[torch.Tensor]:
+        """Every tensor a data-parallel replica must share with rank 0 before the first step (f32 master arena incl.
+        the frozen CNN and the BatchNorm buffers that live in it, Adam moments when they exist, the loss-scale record):
+        what ``broadcast_parameters`` of the reducers sends.  The 16-bit operand copies are derived (sync_lowp)."""
+        ts = [self.flat]
+        for t in (self.exp_avg, self.exp_avg_sq, self.scaler):
+            if t is not None:
+                ts.append(t)
+        return ts
+
     def sync_lowp(self) -> None:
         if self.flat_lp is not None:
             ops.cast(self.flat, self.flat_lp)

@@ -71,6 +71,27 @@ class BucketAllReducer:
         with torch.cuda.stream(self.comm_stream):
             self.works.append(self.dist.all_reduce(view, op=self.dist.ReduceOp.SUM, group=self.pg, async_op=True))
 
+    def broadcast_parameters(self, root: int = 0) -> None:
+        """Start-up broadcast (ref: config/trainer/trainer.yaml:6-12 -- PL's DDP wrapper broadcasts the
+        module state of rank 0 when it wraps the model): master parameters, optimiser moments and the loss-scale record
+        of ``root`` replace every other rank's, then the 16-bit operand copies are rebuilt.  Call it once after
+        construction / after loading a checkpoint on rank 0 only; without it the replicas are identical only if every
+        rank seeded / loaded identically.  Ranks that have no Adam moments yet must not differ from root in that
+        respect (a collective: same tensors on every rank)."""
+        if self.world == 1:
+            return
+        counts = torch.tensor([len(self.store.replica_state())], device=self.store.flat.device, dtype=torch.int64)
+        lo, hi = counts.clone(), counts.clone()
+        self.dist.all_reduce(lo, op=self.dist.ReduceOp.MIN, group=self.pg)
+        self.dist.all_reduce(hi, op=self.dist.ReduceOp.MAX, group=self.pg)
+        if int(lo) != int(hi):
+            raise RuntimeError("broadcast_parameters: ranks disagree on which state tensors exist (optimiser moments / "
+                               "loss scale); create or load them on every rank first")
+        src = self.dist.get_global_rank(self.pg, root) if self.pg is not None else root
+        for t in self.store.replica_state():
+            self.dist.broadcast(t, src=src, group=self.pg)
+        self.store.sync_lowp()
+
     def wait(self) -> None:
         for w in self.works:
             w.wait()                      # makes the current (compute) stream wait for the collective
