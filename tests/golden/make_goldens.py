@@ -261,6 +261,29 @@ def golden_base2():
     print("g10_base2: emb norm", float(g["eval.mean+std"].norm()), "T", h.shape[1])
 
 
+# ----------------------------------------------------------------------------- G11 base config at the benchmark's batch size
+def golden_base66():
+    """BASELINE configs[1] at ITS OWN size: 66 utterances of 3 s through the reference's
+    ``Wav2Vec2WrapperModule`` (eval mode) + mean+std pooling, the weights of g2_base (seed 20211), the batch bench.py
+    steps on (``synth_batch(66, 48000, 5994, seed=42133724)``: rows 0 / 1 are g2_base's two utterances).  Stored:
+    the [66, 1536] embeddings (f32, 400 KB) and a strided sample of the hidden states."""
+    cfg = O.OracleConfig.base()
+    B, N = 66, 48000
+    w, _ = build_reference_wrapper(cfg, seed=20211)
+    wav, _ = O.synth_batch(B, N, 5994, seed=42133724)
+    x = torch.squeeze(wav)
+    w.eval()
+    embs, samples = [], []
+    with torch.no_grad():
+        for i in range(0, B, 6):                   # (chunks of 6: the reference's forward is batch-independent in eval)
+            h = w(x[i:i + 6]).transpose(2, 1)
+            embs.append(MeanStdStatPool1D(1)(h))
+            samples.append(h[:, ::32, ::32].contiguous())
+    g = {"eval.mean+std": torch.cat(embs), "eval.last_hidden.sample": torch.cat(samples)}
+    np.savez_compressed(os.path.join(OUT, "g11_base66.npz"), **to_np(g))
+    print("g11_base66: emb norm", float(g["eval.mean+std"].norm()), "rows", g["eval.mean+std"].shape)
+
+
 # ----------------------------------------------------------------------------- G4 AAM known answers
 def golden_aam():
     g = {}
@@ -392,7 +415,7 @@ def golden_bce():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["tiny", "base", "aam", "pool", "eval", "optim", "bce", "base2"]
+    which = sys.argv[1:] or ["tiny", "base", "aam", "pool", "eval", "optim", "bce", "base2", "base66"]
     for wname in which:
-        {"tiny": golden_tiny, "base": golden_base, "aam": golden_aam, "pool": golden_pool,
+        {"tiny": golden_tiny, "base": golden_base, "aam": golden_aam, "base66": golden_base66, "pool": golden_pool,
          "eval": golden_eval, "optim": golden_optim, "bce": golden_bce, "base2": golden_base2}[wname]()

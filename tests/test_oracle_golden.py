@@ -109,6 +109,21 @@ def test_base_config_embeddings_and_grad_norms():
         assert np.allclose(head.numpy(), g["gradhead." + n], rtol=5e-3, atol=2e-3 * ref / np.sqrt(grads[n].numel()) + floor), n
 
 
+def test_base66_golden_rows_agree_with_oracle_and_with_the_b2_golden():
+    """tests/golden/g11_base66.npz (the reference at BASELINE configs[1]'s own batch): rows 0 / 1 are the two utterances
+    of g2_base (same seed, same weights) -- the two reference runs must agree -- and the oracle reproduces a row from
+    the middle of the batch (utterance 40; one utterance keeps the CPU suite short)."""
+    g, g2 = load("g11_base66.npz"), load("g2_base.npz")
+    assert g["eval.mean+std"].shape == (66, 1536)
+    assert np.allclose(g["eval.mean+std"][:2], g2["eval.mean+std"], atol=2e-5)
+    cfg = O.OracleConfig.base()
+    sd = O.make_state_dict(cfg, 20211)
+    wav, _ = O.synth_batch(66, 48000, 5994, seed=42133724)
+    with torch.no_grad():
+        e = O.speaker_embedding(wav[40:41], sd, cfg, "mean+std")
+    assert rel_l2(e.numpy(), g["eval.mean+std"][40:41]) < 1e-4
+
+
 def test_aam_known_answers():
     g = load("g4_aam.npz")
     for margin, scale in ((0.2, 30.0), (0.3, 15.0)):

@@ -207,7 +207,34 @@ def test_base_second_golden_other_seed_batch8_5s(dtype):
     print(f"second base golden {dtype}: embedding rel-L2 {err:.3e}, sampled hidden states {hs:.3e}")
     assert err < {torch.float32: 1e-4, **EMB_BOUND}[dtype], err
     per_utt = (e.cpu() - T(g["eval.mean+std"])).norm(dim=1) / T(g["eval.mean+std"]).norm(dim=1)
-    assert float(per_utt.max()) < 1.3 * {torch.float32: 1e-4, **EMB_BOUND}[dtype], per_utt      # every utterance, not the mean
+    # every utterance, not the mean (measured, profiles/r04_parity.json: fp16 worst utterance 9.3e-4 here, 8.5e-4 of 66 at B = 66)
+    assert float(per_utt.max()) < {torch.float32: 1e-4, **EMB_BOUND}[dtype], per_utt
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
+def test_base_b66_embeddings_vs_reference_golden_at_benchmark_size(dtype):
+    """BASELINE configs[1] compared with the REFERENCE at its own size: the 66 utterances bench.py
+    steps on, 3 s each, eval embeddings of the reference's wrapper + mean+std pooling (tests/golden/g11_base66.npz,
+    make_goldens.py `base66`).  Bounds: f32 1e-4; fp16 (the benchmarked mode) 1e-3 over the batch AND for every single
+    utterance; bf16 3e-2.  The measured values are kept in profiles/r04_parity.json (tools/parity_report.py)."""
+    from w2v2_speaker_amd.engine import Plan
+    g = load("g11_base66.npz")
+    cfg, ocfg = _cfgs("base")
+    st, _ = _store(cfg, ocfg, dtype, None, 1)
+    wav, _ = O.synth_batch(66, 48000, 5994, seed=42133724)
+    ev = Plan(st, 66, 48000, train=False)
+    e = ev.embed(wav.to(DEV))
+    torch.cuda.synchronize()
+    ref = T(g["eval.mean+std"])
+    bound = {torch.float32: 1e-4, **EMB_BOUND}[dtype]
+    err = rel_l2(e.cpu(), ref)
+    per_utt = (e.cpu() - ref).norm(dim=1) / ref.norm(dim=1)
+    print(f"B=66 golden {dtype}: embedding rel-L2 {err:.3e}, per utterance max {float(per_utt.max()):.3e} "
+          f"median {float(per_utt.median()):.3e}")
+    assert err < bound, err
+    assert float(per_utt.max()) < bound, per_utt
+    assert rel_l2(ev.out[:, ::32, ::32].float().cpu(), g["eval.last_hidden.sample"]) < {torch.float32: 1e-4, torch.float16: 3e-3,
+                                                                                       torch.bfloat16: 3e-2}[dtype]
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
