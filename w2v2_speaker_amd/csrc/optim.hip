@@ -21,8 +21,11 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     // ones of this parameter range, so the bias corrections are rebuilt here from t = step - skipped.
     if (skip_slot > 0) {
       const float t = fmaxf((float)step - scaler[skip_slot], 1.0f);
-      step_size = lr / (1.0f - __powf(b1, t));
-      inv_sqrt_bc2 = rsqrtf(1.0f - __powf(b2, t));
+      // double pow: at small t, 1 - 0.999^t ~ 1e-3 and the ~1-ulp error of the f32 exp2 / log2 path would be 5e-5..1e-4
+      // relative in the correction; once per thread, invisible next to the 30 B/parameter stream.  The
+      // host's bias_corr1 / bias_corr2 arguments are NOT used on this path.
+      step_size = (float)((double)lr / (1.0 - pow((double)b1, (double)t)));
+      inv_sqrt_bc2 = (float)(1.0 / sqrt(1.0 - pow((double)b2, (double)t)));
     }
   }
   const int64_t nv = n >> 2;
@@ -177,7 +180,8 @@ extern "C" int w2v2_adam_step(float* p, const float* g, float* m, float* v, void
   W2V2_REQUIRE(bias_corr1 > 0.f && bias_corr2 > 0.f, "adam_step: bias corrections must be > 0");
   if (n == 0) return 0;
   // A/B knobs (tools): W2V2_ADAM_U = vectors per thread and pass (1, 2, 4), W2V2_ADAM_BLOCKS = grid cap
-  static const int env_u = getenv("W2V2_ADAM_U") ? atoi(getenv("W2V2_ADAM_U")) : 2;   // 2: 495 vs 549 us over the 99.4 M-parameter arena
+  static const int env_u_raw = getenv("W2V2_ADAM_U") ? atoi(getenv("W2V2_ADAM_U")) : 2;   // 2: 495 vs 549 us over the 99.4 M-parameter arena
+  static const int env_u = env_u_raw >= 4 ? 4 : (env_u_raw >= 2 ? 2 : 1);
   static const int env_nb = getenv("W2V2_ADAM_BLOCKS") ? atoi(getenv("W2V2_ADAM_BLOCKS")) : 8192;
   int64_t nb = cdiv(n >> 2, 256 * env_u);
   if (nb > env_nb) nb = env_nb;

@@ -212,12 +212,22 @@ class WgradGroup:
         self._tokens, self._tpad = tokens, tokens_padded
         self._dt = dt(problems[0][0])
         self._fn = lib().w2v2_wgrad_grouped
+        # mirrors the host's choice in csrc/wgrad.hip (for the in-step profile labels): 256x256 tiles when they alone
+        # fill >= 80 % of the CUs and cost fewer rounds than 256x128 tiles -- then the phased kernel
+        cd = lambda a, b: -(-a // b)
+        t4 = sum(cd(dw.shape[0], 256) * cd(dw.shape[1], 256) for _, _, dw, _ in problems)
+        t3 = sum(cd(dw.shape[0], 256) * cd(dw.shape[1], 128) for _, _, dw, _ in problems)
+        big = max(dw.shape[0] for _, _, dw, _ in problems) > 128
+        tiles256 = big and t4 * 10 >= 256 * 8 and cd(t4, 256) * 17 <= cd(t3, 256) * 10
+        self.kernel_name = ("wgrad_grouped_phased_kernel" if tiles256 and not os.environ.get("W2V2_NO_WGRAD_PH") else
+                            "wgrad_grouped_ring4_kernel" if tiles256 else
+                            "wgrad_grouped_ring_kernel" if big else "wgrad_grouped_kernel")
 
     def __call__(self) -> None:
         if Gemm._log is not None:
             Gemm._log.append({"kind": "wgrad", "problems": self._n, "tokens": self._tokens, "flops": self.flops,
                               "alg_flops": self.flops,
-                              "kernel": "wgrad_grouped_ring4_kernel" if self._n >= 8 else "wgrad_grouped_ring_kernel"})
+                              "kernel": self.kernel_name})
         rc = self._fn(self._arr, self._n, self._tokens, self._tpad, self._dt, stream())
         if rc:
             _lib.check(rc, "wgrad_grouped")
