@@ -340,7 +340,7 @@ def run(args):
 
             def entry(name, k):
                 ach = k["flops"] / (k["ms"] * 1e-3) / 1e12
-                rec = pmc.get(f"{name}<{tsym}, {tsym}>", {})
+                rec = pmc.get(f"{name}<{tsym}, {tsym}>") or pmc.get(f"{name}<{tsym}, {tsym}, 0>") or {}
                 return {"bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": rec.get("hbm_bytes_per_launch"),
                         "mfma_busy": rec.get("mfma_busy"),

@@ -231,7 +231,8 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_tiled_kernel(const bf16_t* __
   tile_store(rk, Ks[0]);
   tile_store(rv, Vs[0]);
   __syncthreads();
-  float m = -INFINITY, l = 0.f;
+  float m = -INFINITY, l = 0.f;                       // running maximum in the log2 domain
+  const float scale2 = scale * 1.4426950408889634f;
   f32x4 o[4];
 #pragma unroll
   for (int df = 0; df < 4; ++df) o[df] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -249,23 +250,34 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_tiled_kernel(const bf16_t* __
     if (active) {
     float s[4][4];
     float tmax = -INFINITY;
+    // scores in the LOG2 domain (scale * log2(e) folded into one multiply, v_exp_f32 is 2^x); the key < T test only
+    // where a tile can hold an invalid key at all -- the last one (uniform branch: two copies of the score loop)
+    const bool partial = (t + 1) * AT_TILE > Tn;
 #pragma unroll
     for (int fj = 0; fj < 4; ++fj) {
       if (fj < nfj) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) acc = mfma16<TE>(lds_frag(Ks[cur], fj * 16, kk, lane), qf[kk], acc);
+        if (partial) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int key = t * AT_TILE + fj * 16 + g * 4 + j;
-          s[fj][j] = key < Tn ? acc[j] * scale : -INFINITY;
-          tmax = fmaxf(tmax, s[fj][j]);
+          for (int j = 0; j < 4; ++j) {
+            const int key = t * AT_TILE + fj * 16 + g * 4 + j;
+            s[fj][j] = key < Tn ? acc[j] * scale2 : -INFINITY;
+            tmax = fmaxf(tmax, s[fj][j]);
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            s[fj][j] = acc[j] * scale2;
+            tmax = fmaxf(tmax, s[fj][j]);
+          }
         }
       }
     }
     tmax = quad_max(tmax);
     const float mn = fmaxf(m, tmax);                  // finite: every tile holds at least one valid key
-    const float alpha = __expf(m - mn);               // first tile: exp(-inf) = 0
+    const float alpha = __builtin_amdgcn_exp2f(m - mn);   // first tile: 2^(-inf) = 0
     m = mn;
     float psum = 0.f;
 #pragma unroll
@@ -275,7 +287,7 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_tiled_kernel(const bf16_t* __
         if (dp > 0.f) attn_drop4_keys(seed, bh, q, t * AT_TILE + fj * 16 + g * 4, Tn, dp, inv_keep, ms);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const float p = __expf(s[fj][j] - mn);
+          const float p = __builtin_amdgcn_exp2f(s[fj][j] - mn);
           psum += p;                                  // the normaliser sums the probabilities BEFORE dropout
           s[fj][j] = p * ms[j];
         }
@@ -307,7 +319,7 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_tiled_kernel(const bf16_t* __
 #pragma unroll
     for (int df = 0; df < 4; ++df) o[df] *= inv;
     store_row4x4<TE>(ctx + ((int64_t)b * Tn + q) * H + h * HD + g * 4, o);
-    if (g == 0) lse[bh * Tn + q] = m + __logf(l);
+    if (g == 0) lse[bh * Tn + q] = m * 0.6931471805599453f + __logf(l);
   }
 }
 
@@ -342,7 +354,11 @@ __global__ __launch_bounds__(256, 4) void attn_bwd_dq_tiled_kernel(const bf16_t*
   for (int kk = 0; kk < 2; ++kk) dl += frag_dot<TE>(dof[kk], of[kk]);
   dl = quad_sum(dl);
   if (g == 0 && q < Tn) delta[bh * Tn + q] = dl;
-  const float l = q < Tn ? lse[bh * Tn + q] : 0.f;
+  // P = exp(s * scale - lse) = 2^(s * scale2 - l2).  Rows beyond T need no mask: their q, dO are zero, so p = 1 and
+  // dS = p * (0 - 0) = 0.  Keys beyond T (last tile only, uniform branch) keep theirs: p = exp(-lse) is unbounded
+  // there and would meet a zero K row as inf * 0 after the 16-bit pack.
+  const float l2 = q < Tn ? lse[bh * Tn + q] * 1.4426950408889634f : 0.f;
+  const float scale2 = scale * 1.4426950408889634f;
   const TrOff troff = tr_offsets(lane);
   const int ntile = (Tn + AT_TILE - 1) / AT_TILE;
   TileRegs rk, rv;
@@ -381,10 +397,18 @@ __global__ __launch_bounds__(256, 4) void attn_bwd_dq_tiled_kernel(const bf16_t*
           const int key0 = t * AT_TILE + fj * 16 + g * 4;
           float ms[4] = {1.f, 1.f, 1.f, 1.f};
           if (dp > 0.f) attn_drop4_keys(seed, bh, q, key0, Tn, dp, inv_keep, ms);
+          if ((t + 1) * AT_TILE > Tn) {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const float p = (key0 + j < Tn && q < Tn) ? __expf(sa[j] * scale - l) : 0.f;
-            ds2[hf][j] = p * (pa[j] * ms[j] - dl) * scale;
+            for (int j = 0; j < 4; ++j) {
+              const float p = key0 + j < Tn ? __builtin_amdgcn_exp2f(fmaf(sa[j], scale2, -l2)) : 0.f;
+              ds2[hf][j] = p * (pa[j] * ms[j] - dl) * scale;
+            }
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const float p = __builtin_amdgcn_exp2f(fmaf(sa[j], scale2, -l2));
+              ds2[hf][j] = p * (pa[j] * ms[j] - dl) * scale;
+            }
           }
         } else {
 #pragma unroll
@@ -437,7 +461,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_kv_tiled_kernel(const bf16_t*
   auto row_load = [&](int t) {
     if (threadIdx.x < AT_TILE) {
       const int r = t * AT_TILE + threadIdx.x;
-      rl = r < Tn ? lse[bh * Tn + r] : 0.f;
+      rl = r < Tn ? lse[bh * Tn + r] * 1.4426950408889634f : 0.f;      // log2 domain, see below
       rd = r < Tn ? delta[bh * Tn + r] : 0.f;
     }
   };
@@ -455,6 +479,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_kv_tiled_kernel(const bf16_t*
 #pragma unroll
   for (int df = 0; df < 4; ++df) { dv[df] = f32x4{0.f, 0.f, 0.f, 0.f}; dk[df] = f32x4{0.f, 0.f, 0.f, 0.f}; }
   const bool active = row_tile * 64 + wave * 16 < Tn;
+  const float scale2 = scale * 1.4426950408889634f;
 #pragma unroll 1
   for (int t = 0; t < ntile; ++t) {
     const int cur = t & 1;
@@ -485,9 +510,12 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_kv_tiled_kernel(const bf16_t*
           const int q0 = t * AT_TILE + fq * 16 + g * 4;
           float ms[4] = {1.f, 1.f, 1.f, 1.f};
           if (dp > 0.f) attn_drop4_rows(seed, bh, q0, key, Tn, dp, inv_keep, ms);
+          // P = 2^(s * scale2 - lse2).  No mask at all: a query row beyond T has zero Q, dO, lse, delta -> p = 1 and both
+          // products meet its zero dO / Q row; a key beyond T is a COLUMN of dK / dV that is never stored and that no
+          // valid column reads
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            const float p = (q0 + j < Tn && key < Tn) ? __expf(sa[j] * scale - la[j]) : 0.f;
+            const float p = __builtin_amdgcn_exp2f(fmaf(sa[j], scale2, -la[j]));
             pt2[hf][j] = p * ms[j];
             ds2[hf][j] = p * (pa[j] * ms[j] - da[j]) * scale;
           }
