@@ -461,7 +461,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_kv_tiled_kernel(const bf16_t*
   auto row_load = [&](int t) {
     if (threadIdx.x < AT_TILE) {
       const int r = t * AT_TILE + threadIdx.x;
-      rl = r < Tn ? lse[bh * Tn + r] * 1.4426950408889634f : 0.f;      // log2 domain, see below
+      rl = r < Tn ? lse[bh * Tn + r] : 0.f;
       rd = r < Tn ? delta[bh * Tn + r] : 0.f;
     }
   };
@@ -479,7 +479,6 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_kv_tiled_kernel(const bf16_t*
 #pragma unroll
   for (int df = 0; df < 4; ++df) { dv[df] = f32x4{0.f, 0.f, 0.f, 0.f}; dk[df] = f32x4{0.f, 0.f, 0.f, 0.f}; }
   const bool active = row_tile * 64 + wave * 16 < Tn;
-  const float scale2 = scale * 1.4426950408889634f;
 #pragma unroll 1
   for (int t = 0; t < ntile; ++t) {
     const int cur = t & 1;
@@ -510,12 +509,11 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_kv_tiled_kernel(const bf16_t*
           const int q0 = t * AT_TILE + fq * 16 + g * 4;
           float ms[4] = {1.f, 1.f, 1.f, 1.f};
           if (dp > 0.f) attn_drop4_rows(seed, bh, q0, key, Tn, dp, inv_keep, ms);
-          // P = 2^(s * scale2 - lse2).  No mask at all: a query row beyond T has zero Q, dO, lse, delta -> p = 1 and both
-          // products meet its zero dO / Q row; a key beyond T is a COLUMN of dK / dV that is never stored and that no
-          // valid column reads
+          // (this kernel sits at its register limit -- 168 for three workgroups per CU: the log2-domain / unmasked form
+          // of the other two kernels spills 10 registers here, and scratch costs more than the three instructions)
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            const float p = __builtin_amdgcn_exp2f(fmaf(sa[j], scale2, -la[j]));
+            const float p = (q0 + j < Tn && key < Tn) ? __expf(sa[j] * scale - la[j]) : 0.f;
             pt2[hf][j] = p * ms[j];
             ds2[hf][j] = p * (pa[j] * ms[j] - da[j]) * scale;
           }
