@@ -113,6 +113,9 @@ int w2v2_tune_gemm_kernel(int family);
  * phase issued between its MFMAs, bit 6 / 7 plain / write-through epilogue stores.  Variants with bits 0-3 compute
  * garbage by design.  Returns the previous setting; 0 = the product kernel. */
 int w2v2_tune_gemm_debug(int bits);
+/* Tools only: force the block tile of the exact-f32 MFMA GEMM (csrc/gemm_f32.hip) -- 0 = the library's choice (largest
+ * tile whose grid fills the chip), 1 = 128x128, 2 = 64x128, 3 = 128x64, 4 = 64x64.  Returns the previous setting. */
+int w2v2_tune_gemm_f32_tile(int tile);
 
 /* Grouped weight-gradient GEMM (the backward of HF:520-526,544,565-572 nn.Linear weights/biases):
  *   dW_p[o][i] = sum_t dY_p[t][o] * X_p[t][i]      dbias_p[o] = sum_t dY_p[t][o]   (dbias may be NULL)
@@ -341,10 +344,14 @@ int w2v2_bn_workspace_floats(int M, int C);
 int w2v2_bn_fwd(const void* a, int64_t lda, float* workspace, float* mean_rstd, float* running, const float* gamma,
                 const float* beta, void* y, int64_t ldy, int M, int C, float eps, float momentum, int relu, int train,
                 int dtype, void* stream);
-/* dy -> da (through BatchNorm and the optional relu); writes dgamma[C], dbeta[C] */
+/* dy -> da (through BatchNorm and the optional relu); writes dgamma[C], dbeta[C].  colsum_partial (may be NULL):
+ * [w2v2_bn_colsum_rows(M)][C] f32, WRITTEN with the column sums of da over each row block -- the bias gradient of the
+ * convolution in front of the BatchNorm (TDNNBlock = conv -> ReLU -> BatchNorm) is their sum: a w2v2_colsum over
+ * M / 256 rows instead of a second pass over the M rows of da. */
+int w2v2_bn_colsum_rows(int M);
 int w2v2_bn_bwd(const void* dy, int64_t lddy, const void* a, int64_t lda, const float* mean_rstd, const float* gamma,
                 float* workspace, float* dgamma, float* dbeta, void* da, int64_t ldda, int M, int C, int relu,
-                int dtype, void* stream);
+                float* colsum_partial, int dtype, void* stream);
 /* Conv1d(padding="same", padding_mode="reflect", dilation d, odd k) as im2col + GEMM:
  * col[(b,t)][j*Cin + c] = x[b][reflect(t + (j - (k-1)/2) d)][c]; col2im is its exact adjoint (gather, deterministic) */
 int w2v2_im2col_reflect(const void* x, int64_t ldx, void* col, int B, int T, int Cin, int k, int dilation, int dtype,

@@ -194,9 +194,14 @@ def test_batchnorm_kernels_vs_torch(dtype, M, C, ld, relu):
     assert rel_l2(running[:C].cpu().double(), bn.running_mean) < 1e-5
     assert rel_l2(running[C:].cpu().double(), bn.running_var) < 1e-5
     dgam, dbet = torch.empty(C, device=dev), torch.empty(C, device=dev)
-    ops.bn_bwd(dyd, ld, ad, ld, mr, gd, work, dgam, dbet, da, ld, M, C, relu)
+    csp = torch.full((ops.bn_colsum_rows(M), C), float("nan"), device=dev)
+    ops.bn_bwd(dyd, ld, ad, ld, mr, gd, work, dgam, dbet, da, ld, M, C, relu, colsum_partial=csp)
     gtol = 2e-5 if dtype == torch.float32 else 8e-3
     assert rel_l2(da[:, :C].cpu().double(), ar.grad) < gtol
+    # fused column sums of da (the bias gradient of the convolution in front): per row block, of the STORED values
+    cs_ref = da[:, :C].float().cpu().double().sum(0)
+    ctol = 1e-4 if dtype == torch.float32 else 1e-2        # (16-bit: the sums are taken BEFORE the values are rounded for the store)
+    assert float((csp.cpu().double().sum(0) - cs_ref).abs().max()) <= ctol * float(da[:, :C].float().abs().sum(0).max().cpu()) + 1e-6
     assert rel_l2(dgam.cpu().double(), bn.weight.grad) < 1e-4 and rel_l2(dbet.cpu().double(), bn.bias.grad) < 1e-4
     bn.eval()
     ye = bn(torch.relu(ar) if relu else ar)

@@ -108,7 +108,7 @@ def bench_ecapa(args, world, rank, dev, dist, emit=True):
     esz = lambda t: t.element_size()
     ft = _FamilyTimer(ops)
     ft.wrap("bn_fwd", "batchnorm", lambda a, lda, work, mr, run, ga, be, y, ldy, M, C, *r: 3 * M * C * esz(a))
-    ft.wrap("bn_bwd", "batchnorm", lambda dy, lddy, a, lda, mr, ga, work, dga, dbe, da, ldda, M, C, *r: 5 * M * C * esz(a))
+    ft.wrap("bn_bwd", "batchnorm", lambda dy, lddy, a, lda, mr, ga, work, dga, dbe, da, ldda, M, C, *r, **kw: 5 * M * C * esz(a))
     ft.wrap("se_scale", "se_gate", lambda x, g_, y, B, T, C: 2 * B * T * C * esz(x))
     ft.wrap("se_bwd_gate", "se_gate", lambda d, x, dg, B, T, C: 2 * B * T * C * esz(x))
     ft.wrap("se_bwd_x", "se_gate", lambda d, g_, ds, dx, B, T, C: 2 * B * T * C * esz(d))

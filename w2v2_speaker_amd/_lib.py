@@ -47,6 +47,7 @@ _SIGS = {
     "w2v2_gemm": (c_i32, [C.POINTER(GemmDesc), c_vp]),
     "w2v2_tune_gemm_kernel": (c_i32, [c_i32]),
     "w2v2_tune_gemm_debug": (c_i32, [c_i32]),
+    "w2v2_tune_gemm_f32_tile": (c_i32, [c_i32]),
     "w2v2_zero_ranges": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_vp]),
     "w2v2_mean": (c_i32, [c_vp, c_vp, c_i32, c_vp]),
     "w2v2_wgrad_grouped": (c_i32, [C.POINTER(WgradProblem), c_i32, c_i32, c_i32, c_i32, c_vp]),
@@ -96,7 +97,8 @@ _SIGS = {
     "w2v2_skinny_linear_bwd_x": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "w2v2_skinny_linear_bwd_w": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "w2v2_bn_bwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32,
-                            c_i32, c_vp]),
+                            c_vp, c_i32, c_vp]),
+    "w2v2_bn_colsum_rows": (c_i32, [c_i32]),
     "w2v2_im2col_reflect": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "w2v2_col2im_reflect": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "w2v2_add_strided": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp]),

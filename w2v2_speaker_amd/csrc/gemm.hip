@@ -11,9 +11,7 @@
 //               LDS image: [row][64 k] bf16, 128-B rows, 16-B chunks XOR-swizzled by
 //               (row ^ row>>3) & 7 -> conflict-free ds_read_b128 fragment reads and ds_write_b128
 //               staging writes, <= 2-way on the transposing ds_write_b64.
-//   f32 path  : exact-f32 64x64x16 VALU tile kernel.  It exists for the parity mode only
-//               (embeddings within 1e-3 rel-L2 of the f32 reference, BASELINE.json north_star);
-//               throughput runs use bf16.
+//   f32 path  : gemm_f32.hip (exact f32 on the f32-input MFMA; the round-1 VALU tile kernel was deleted in round 4).
 #include "gemm_common.h"
 
 // ------------------------------------------------------------------------------ bf16 MFMA kernel
@@ -352,233 +350,6 @@ static void launch_glds(const GemmArgs& a, dim3 grid, hipStream_t st) {
   hipLaunchKernelGGL((gemm16_dma_128_kernel<TE, FM, FN, TC>), grid, dim3(256), lds, st, a);
 }
 
-// ------------------------------------------------------------------------------ exact f32 kernel
-template <typename TC>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
-  __shared__ float As[16][68];
-  __shared__ float Bs[16][68];
-  const int tid = threadIdx.x;
-  const int tx = tid & 15, ty = tid >> 4;  // 16 x 16 threads, 4x4 outputs each
-  const int tile = blockIdx.x;
-  const int tm = tile / g.tiles_n, tn = tile - tm * g.tiles_n;
-  const int m0 = tm * 64, n0 = tn * 64;
-  const int z = blockIdx.z;
-  const int z0 = z / g.batch_inner, z1 = z - z0 * g.batch_inner;
-  const int split = blockIdx.y;
-  const int kbeg = split * g.k_per_split;
-  const int kend = min(g.K, kbeg + g.k_per_split);
-  const float* Ab = reinterpret_cast<const float*>(g.A.ptr) + z0 * g.a_s0 + z1 * g.a_s1;
-  const float* Bb = reinterpret_cast<const float*>(g.B.ptr) + z0 * g.b_s0 + z1 * g.b_s1;
-
-  float acc[4][4] = {};
-  for (int k0 = kbeg; k0 < kend; k0 += 16) {
-    // each thread stages 4 elements of A and of B; index so that the contiguous (inner) dimension
-    // of the operand runs over consecutive threads
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int idx = tid + 256 * e;  // 0..1023
-      {
-        int r, k;
-        if (g.A.trans) { r = idx & 63; k = idx >> 6; } else { k = idx & 15; r = idx >> 4; }
-        float v = 0.f;
-        if (m0 + r < g.M && k0 + k < kend)
-          v = g.A.trans ? Ab[outer_off(g.A, k0 + k) + m0 + r] : Ab[outer_off(g.A, m0 + r) + k0 + k];
-        As[k][r] = v;
-      }
-      {
-        int r, k;
-        if (g.B.trans) { r = idx & 63; k = idx >> 6; } else { k = idx & 15; r = idx >> 4; }
-        float v = 0.f;
-        if (n0 + r < g.N && k0 + k < kend)
-          v = g.B.trans ? Bb[outer_off(g.B, k0 + k) + n0 + r] : Bb[outer_off(g.B, n0 + r) + k0 + k];
-        Bs[k][r] = v;
-      }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      float a[4], b[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) a[i] = As[k][ty * 4 + i];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) b[j] = Bs[k][tx * 4 + j];
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
-    }
-    __syncthreads();
-  }
-  TC* Cz = reinterpret_cast<TC*>(g.C) + z0 * g.c_s0 + z1 * g.c_s1;
-  const TC* auxz = g.aux ? reinterpret_cast<const TC*>(g.aux) + z0 * g.aux_s0 + z1 * g.aux_s1 : nullptr;
-  TC* auxo = g.aux ? reinterpret_cast<TC*>(g.aux) + z0 * g.aux_s0 + z1 * g.aux_s1 : nullptr;
-  const float* bias = g.bias ? g.bias + z1 * g.bias_s1 : nullptr;
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-    epilogue_store4<TC>(g, Cz, auxz, auxo, bias, m0 + ty * 4 + i, n0 + tx * 4, acc[i], split == 0);
-}
-
-// ------------------------------------------------------------------------------ exact f32 on the matrix cores
-// v_mfma_f32_32x32x2_f32: f32 operands, f32 accumulate, bit-for-bit a k-ordered fmaf chain (cdna_hip_programming.md 3,
-// "FP32-input MFMA") at the f32 vector RATE -- but issued by one instruction per 4096 multiply-adds instead of 64, with
-// one VGPR per operand, so an untuned LDS-tiled kernel already runs ~2.4x a VALU tile kernel (the 64x64x16 kernel above,
-// kept behind W2V2_F32_VALU for A/B).  This is the GEMM of the exact-f32 parity mode and of BASELINE configs[4]
-// (ECAPA-TDNN at the reference's `precision: 32`, "MFMA off" = no reduced-precision matrix path: the numerics ARE f32).
-//   128 x 128 x 16 block tile, 4 waves as 2 x 2, 64 x 64 per wave = 2 x 2 MFMA blocks (64 accumulator VGPRs);
-//   both operands are staged K-MAJOR in LDS ([k][row], pitch 132: a fragment is 32 consecutive rows of one k ->
-//   conflict-free ds_read_b32), the next K tile's global loads are in flight under the 32 MFMAs of the current one;
-//   operands swapped (D[n][m]) so a lane holds 4 consecutive n per accumulator quad -> the shared 4-wide epilogue.
-typedef __attribute__((ext_vector_type(16))) float f32x16;
-
-template <bool TA, bool TB>
-__global__ __launch_bounds__(256, 2) void gemm_f32_mfma_kernel(const GemmArgs g) {
-  // BK = 32: a K-contiguous operand row contributes one whole 128-byte line per K tile (BK = 16 fetched half lines, and
-  // the 2 x 16 KB of half-used lines per tile thrashed the 32 KB L1: 26 TFLOP/s).  LDS pitch: 132 words for K-major
-  // sources (16-byte aligned float4 stores), 129 for K-contiguous ones (their transposing scalar stores hit
-  // (k + row) % 32 -> 2-way instead of 4-way conflicts); fragment reads [k][32 consecutive rows] are conflict-free
-  // with either.
-  constexpr int BM = 128, BN = 128, BK = 32, PA = TA ? 132 : 129, PB = TB ? 132 : 129;
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];            // 2 x 32 x (PA + PB) floats = 66-68 KB
-  float (*As)[BK][PA] = reinterpret_cast<float (*)[BK][PA]>(smem_raw);
-  float (*Bs)[BK][PB] = reinterpret_cast<float (*)[BK][PB]>(smem_raw + sizeof(float) * 2 * BK * PA);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int tile = blockIdx.x;
-  const int tm = tile / g.tiles_n, tn = tile - tm * g.tiles_n;
-  const int m0 = tm * BM, n0 = tn * BN;
-  const int z = blockIdx.z;
-  const int z0 = z / g.batch_inner, z1 = z - z0 * g.batch_inner;
-  const int split = blockIdx.y;
-  const int kbeg = split * g.k_per_split;
-  const int kend = min(g.K, kbeg + g.k_per_split);
-  const float* Ab = reinterpret_cast<const float*>(g.A.ptr) + z0 * g.a_s0 + z1 * g.a_s1;
-  const float* Bb = reinterpret_cast<const float*>(g.B.ptr) + z0 * g.b_s0 + z1 * g.b_s1;
-
-  // staging map: 4 x float4 per operand and thread.  K-contiguous operand (trans = 0): thread -> (row = c >> 3, 4 k):
-  // eight lanes read one 128-byte line; K-major operand (trans = 1): thread -> (k = c >> 5, 4 rows)
-  auto load_op = [&](const OpDev& o, const float* __restrict__ base, auto trans_c, int r0, int rbound, int k0,
-                     float4 (&reg)[4]) {
-    constexpr bool trans = decltype(trans_c)::value;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int c = tid + 256 * j;
-      float v[4] = {0.f, 0.f, 0.f, 0.f};
-      if constexpr (!trans) {
-        const int row = c >> 3, k = k0 + (c & 7) * 4;
-        if (r0 + row < rbound && k < kend) {
-          const float* p = base + outer_off(o, r0 + row) + k;
-          if (o.vec_ok && k + 4 <= kend) {
-            const float4 t = *reinterpret_cast<const float4*>(p);
-            v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-          } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) if (k + e < kend) v[e] = p[e];
-          }
-        }
-      } else {
-        const int k = k0 + (c >> 5), row = (c & 31) * 4;
-        if (k < kend && r0 + row < rbound) {
-          const float* p = base + outer_off(o, k) + r0 + row;
-          if (o.vec_ok && r0 + row + 4 <= rbound) {
-            const float4 t = *reinterpret_cast<const float4*>(p);
-            v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-          } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) if (r0 + row + e < rbound) v[e] = p[e];
-          }
-        }
-      }
-      reg[j] = make_float4(v[0], v[1], v[2], v[3]);
-    }
-  };
-  auto store_a = [&](int buf, const float4 (&reg)[4]) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int c = tid + 256 * j;
-      if constexpr (!TA) {
-        const int row = c >> 3, k = (c & 7) * 4;
-        As[buf][k][row] = reg[j].x; As[buf][k + 1][row] = reg[j].y; As[buf][k + 2][row] = reg[j].z; As[buf][k + 3][row] = reg[j].w;
-      } else {
-        *reinterpret_cast<float4*>(&As[buf][c >> 5][(c & 31) * 4]) = reg[j];
-      }
-    }
-  };
-  auto store_b = [&](int buf, const float4 (&reg)[4]) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int c = tid + 256 * j;
-      if constexpr (!TB) {
-        const int row = c >> 3, k = (c & 7) * 4;
-        Bs[buf][k][row] = reg[j].x; Bs[buf][k + 1][row] = reg[j].y; Bs[buf][k + 2][row] = reg[j].z; Bs[buf][k + 3][row] = reg[j].w;
-      } else {
-        *reinterpret_cast<float4*>(&Bs[buf][c >> 5][(c & 31) * 4]) = reg[j];
-      }
-    }
-  };
-
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-  const int nk = (kend - kbeg + BK - 1) / BK;
-  float4 ra[4], rb[4];
-  const std::integral_constant<bool, TA> ta_c{};
-  const std::integral_constant<bool, TB> tb_c{};
-  if (nk > 0) {
-    load_op(g.A, Ab, ta_c, m0, g.M, kbeg, ra);
-    load_op(g.B, Bb, tb_c, n0, g.N, kbeg, rb);
-    store_a(0, ra);
-    store_b(0, rb);
-  }
-  __syncthreads();
-  const int kl = lane >> 5, rl = lane & 31;
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) {
-      load_op(g.A, Ab, ta_c, m0, g.M, kbeg + (kt + 1) * BK, ra);
-      load_op(g.B, Bb, tb_c, n0, g.N, kbeg + (kt + 1) * BK, rb);
-    }
-#pragma unroll
-    for (int kk = 0; kk < BK; kk += 2) {
-      float a[2], b[2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) a[i] = As[cur][kk + kl][wm * 64 + i * 32 + rl];
-#pragma unroll
-      for (int j = 0; j < 2; ++j) b[j] = Bs[cur][kk + kl][wn * 64 + j * 32 + rl];
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[j], a[i], acc[i][j], 0, 0, 0);   // D[n][m]
-    }
-    if (kt + 1 < nk) {
-      store_a(cur ^ 1, ra);
-      store_b(cur ^ 1, rb);
-    }
-    __syncthreads();
-  }
-
-  float* Cz = reinterpret_cast<float*>(g.C) + z0 * g.c_s0 + z1 * g.c_s1;
-  const float* auxz = g.aux ? reinterpret_cast<const float*>(g.aux) + z0 * g.aux_s0 + z1 * g.aux_s1 : nullptr;
-  float* auxo = g.aux ? reinterpret_cast<float*>(g.aux) + z0 * g.aux_s0 + z1 * g.aux_s1 : nullptr;
-  const float* bias = g.bias ? g.bias + z1 * g.bias_s1 : nullptr;
-  // D[n][m]: lane l, register r: m = l & 31, n = 8 (r >> 2) + 4 (l >> 5) + (r & 3)
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float v4[4] = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-        epilogue_store4<float>(g, Cz, auxz, auxo, bias, m0 + wm * 64 + i * 32 + rl, n0 + wn * 64 + j * 32 + q * 8 + kl * 4,
-                               v4, split == 0);
-      }
-}
-
 // ------------------------------------------------------------------------------ host dispatch
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
@@ -756,34 +527,12 @@ extern "C" int w2v2_gemm(const w2v2_gemm_desc* d, void* stream) {
 #undef W2V2_GEMM_LAUNCH
   } else {
     W2V2_REQUIRE(d->dtype_c == W2V2_F32, "w2v2_gemm: f32 operands need an f32 C");
-    static const bool f32_valu = getenv("W2V2_F32_VALU") != nullptr;      // A/B: the 64x64x16 VALU tile kernel
-    const int BT = f32_valu ? 64 : 128;
-    a.tiles_m = (int)cdiv(d->M, BT); a.tiles_n = (int)cdiv(d->N, BT);
-    a.k_per_split = (int)(cdiv(cdiv(d->K, split), 32) * 32);
-    if (a.k_per_split == 0) a.k_per_split = 32;
     // f32 rows are 16-byte vectors of FOUR elements
     auto vec4 = [&](const w2v2_operand& o) {
       return aligned16(o.ptr) && (o.ld % 4 == 0) && (o.seg_stride % 4 == 0) && (o.stride0 % 4 == 0) && (o.stride1 % 4 == 0);
     };
     a.A.vec_ok = vec4(d->A); a.B.vec_ok = vec4(d->B);
-    dim3 grid(a.tiles_m * a.tiles_n, split, d->batch);
-#define W2V2_F32_LAUNCH(TA_, TB_)                                                                                     \
-    do {                                                                                                              \
-      constexpr size_t lds = sizeof(float) * 2 * 32 * ((TA_ ? 132 : 129) + (TB_ ? 132 : 129));                          \
-      static bool attr_set = false;                                                                                   \
-      if (!attr_set) {                                                                                                \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_mfma_kernel<TA_, TB_>),                      \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                              \
-        attr_set = true;                                                                                              \
-      }                                                                                                               \
-      hipLaunchKernelGGL((gemm_f32_mfma_kernel<TA_, TB_>), grid, dim3(256), lds, st, a);                               \
-    } while (0)
-    if (f32_valu) hipLaunchKernelGGL(gemm_f32_kernel<float>, grid, dim3(256), 0, st, a);
-    else if (!a.A.trans && !a.B.trans) W2V2_F32_LAUNCH(false, false);
-    else if (!a.A.trans && a.B.trans) W2V2_F32_LAUNCH(false, true);
-    else if (a.A.trans && !a.B.trans) W2V2_F32_LAUNCH(true, false);
-    else W2V2_F32_LAUNCH(true, true);
-#undef W2V2_F32_LAUNCH
+    w2v2_launch_gemm_f32(a, d->M, d->N, d->K, split, d->batch, st);       // gemm_f32.hip
   }
   W2V2_CHECK_LAUNCH("w2v2_gemm");
   return 0;

@@ -1,0 +1,233 @@
+// gemm_f32.hip -- exact-f32 GEMM on the matrix cores (the exact-f32 parity mode of the wav2vec2 engine and BASELINE
+// configs[4]: ECAPA-TDNN at the reference's `precision: 32`, "MFMA off" = no reduced-precision matrix path: the numerics
+// ARE f32).  See gemm_common.h for the family map; w2v2_gemm (gemm.hip) sends every f32-operand descriptor here.
+//
+// v_mfma_f32_32x32x2_f32: f32 operands, f32 accumulate, bit-for-bit a k-ordered fmaf chain (cdna_hip_programming.md 3,
+// "FP32-input MFMA") at the f32 vector RATE (157 TFLOP/s) -- issued by one instruction per 4096 multiply-adds instead of
+// 64, with one VGPR per operand.
+//   BM x BN x 32 block tile, BM, BN in {128, 64}: 4 waves as 2 x 2, (BM/2) x (BN/2) per wave = FI x FJ MFMA blocks of
+//   32 x 32.  Both operands are staged K-MAJOR in LDS ([k][row]: a fragment is 32 consecutive rows of one k ->
+//   conflict-free ds_read_b32), double-buffered; the next K tile's global loads are issued before the 16 k-steps of the
+//   current one and stored to the other buffer behind them.  Operands swapped (D[n][m]) so a lane holds 4 consecutive n
+//   per accumulator quad.
+//   Tile choice (host): the largest tile whose grid still fills the 512 workgroup slots (2 per CU) -- the 128-channel
+//   Res2Net convolutions of ECAPA (N = 128, 3-tile weight gradients) ran 128 x 128 tiles on 30 % of the chip.
+//   BK = 32: a K-contiguous operand row contributes one whole 128-byte line per K tile.  LDS pitch: BM + 4 words for
+//   K-major sources (16-byte aligned float4 stores), BM + 1 for K-contiguous ones (their transposing scalar stores hit
+//   (k + row) % 32 -> 2-way instead of 4-way conflicts); fragment reads are conflict-free with either.
+#include "gemm_common.h"
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+template <bool TA, bool TB, int BM, int BN>
+__global__ __launch_bounds__(256, 2) void gemm_f32_mfma_kernel(const GemmArgs g) {
+  constexpr int BK = 32, PA = BM + (TA ? 4 : 1), PB = BN + (TB ? 4 : 1);
+  constexpr int FI = BM / 64, FJ = BN / 64;          // 32 x 32 MFMA blocks per wave
+  constexpr int NA = BM / 32, NB = BN / 32;          // float4 per thread and operand tile
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float (*As)[BK][PA] = reinterpret_cast<float (*)[BK][PA]>(smem_raw);
+  float (*Bs)[BK][PB] = reinterpret_cast<float (*)[BK][PB]>(smem_raw + sizeof(float) * 2 * BK * PA);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tile = blockIdx.x;
+  const int tm = tile / g.tiles_n, tn = tile - tm * g.tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int z = blockIdx.z;
+  const int z0 = z / g.batch_inner, z1 = z - z0 * g.batch_inner;
+  const int split = blockIdx.y;
+  const int kbeg = split * g.k_per_split;
+  const int kend = min(g.K, kbeg + g.k_per_split);
+  const float* Ab = reinterpret_cast<const float*>(g.A.ptr) + z0 * g.a_s0 + z1 * g.a_s1;
+  const float* Bb = reinterpret_cast<const float*>(g.B.ptr) + z0 * g.b_s0 + z1 * g.b_s1;
+
+  // staging map: NV x float4 per operand and thread.  K-contiguous operand (trans = 0): thread -> (row = c >> 3, 4 k):
+  // eight lanes read one 128-byte line; K-major operand (trans = 1): thread -> (k = c / (R / 4), 4 rows)
+  auto load_vec = [&](const OpDev& o, const float* __restrict__ base, auto trans_c, auto rows_c, int r0, int rbound, int k0,
+                      int j) -> float4 {
+    constexpr bool trans = decltype(trans_c)::value;
+    constexpr int R = decltype(rows_c)::value;
+    const int c = tid + 256 * j;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (!trans) {
+      const int row = c >> 3, k = k0 + (c & 7) * 4;
+      if (r0 + row < rbound && k < kend) {
+        const float* p = base + outer_off(o, r0 + row) + k;
+        if (o.vec_ok && k + 4 <= kend) {
+          const float4 t = *reinterpret_cast<const float4*>(p);
+          v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) if (k + e < kend) v[e] = p[e];
+        }
+      }
+    } else {
+      const int k = k0 + c / (R / 4), row = (c % (R / 4)) * 4;
+      if (k < kend && r0 + row < rbound) {
+        const float* p = base + outer_off(o, k) + r0 + row;
+        if (o.vec_ok && r0 + row + 4 <= rbound) {
+          const float4 t = *reinterpret_cast<const float4*>(p);
+          v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) if (r0 + row + e < rbound) v[e] = p[e];
+        }
+      }
+    }
+    return make_float4(v[0], v[1], v[2], v[3]);
+  };
+  auto store_a1 = [&](int buf, float4 r, int j) {
+    const int c = tid + 256 * j;
+    if constexpr (!TA) {
+      const int row = c >> 3, k = (c & 7) * 4;
+      As[buf][k][row] = r.x; As[buf][k + 1][row] = r.y; As[buf][k + 2][row] = r.z; As[buf][k + 3][row] = r.w;
+    } else {
+      *reinterpret_cast<float4*>(&As[buf][c / (BM / 4)][(c % (BM / 4)) * 4]) = r;
+    }
+  };
+  auto store_b1 = [&](int buf, float4 r, int j) {
+    const int c = tid + 256 * j;
+    if constexpr (!TB) {
+      const int row = c >> 3, k = (c & 7) * 4;
+      Bs[buf][k][row] = r.x; Bs[buf][k + 1][row] = r.y; Bs[buf][k + 2][row] = r.z; Bs[buf][k + 3][row] = r.w;
+    } else {
+      *reinterpret_cast<float4*>(&Bs[buf][c / (BN / 4)][(c % (BN / 4)) * 4]) = r;
+    }
+  };
+
+  f32x16 acc[FI][FJ];
+#pragma unroll
+  for (int i = 0; i < FI; ++i)
+#pragma unroll
+    for (int j = 0; j < FJ; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int nk = (kend - kbeg + BK - 1) / BK;
+  float4 ra[NA], rb[NB];
+  const std::integral_constant<bool, TA> ta_c{};
+  const std::integral_constant<bool, TB> tb_c{};
+  const std::integral_constant<int, BM> bm_c{};
+  const std::integral_constant<int, BN> bn_c{};
+  if (nk > 0) {
+#pragma unroll
+    for (int j = 0; j < NA; ++j) ra[j] = load_vec(g.A, Ab, ta_c, bm_c, m0, g.M, kbeg, j);
+#pragma unroll
+    for (int j = 0; j < NB; ++j) rb[j] = load_vec(g.B, Bb, tb_c, bn_c, n0, g.N, kbeg, j);
+#pragma unroll
+    for (int j = 0; j < NA; ++j) store_a1(0, ra[j], j);
+#pragma unroll
+    for (int j = 0; j < NB; ++j) store_b1(0, rb[j], j);
+  }
+  __syncthreads();
+  const int kl = lane >> 5, rl = lane & 31;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    const bool more = kt + 1 < nk;
+    if (more) {
+#pragma unroll
+      for (int j = 0; j < NA; ++j) ra[j] = load_vec(g.A, Ab, ta_c, bm_c, m0, g.M, kbeg + (kt + 1) * BK, j);
+#pragma unroll
+      for (int j = 0; j < NB; ++j) rb[j] = load_vec(g.B, Bb, tb_c, bn_c, n0, g.N, kbeg + (kt + 1) * BK, j);
+    }
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 2) {
+      float a[FI], b[FJ];
+#pragma unroll
+      for (int i = 0; i < FI; ++i) a[i] = As[cur][kk + kl][wm * (BM / 2) + i * 32 + rl];
+#pragma unroll
+      for (int j = 0; j < FJ; ++j) b[j] = Bs[cur][kk + kl][wn * (BN / 2) + j * 32 + rl];
+#pragma unroll
+      for (int i = 0; i < FI; ++i)
+#pragma unroll
+        for (int j = 0; j < FJ; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[j], a[i], acc[i][j], 0, 0, 0);   // D[n][m]
+    }
+    // (round 4 tried spreading these stores over the second half of the k-steps: the `vmcnt` wait in front of the first
+    // one then sits in the MIDDLE of the MFMA stream and stops its issue -- 19800 x 1024 x 1024: 435 -> 518 us; behind the
+    // last MFMA the wait overlaps the matrix pipe draining)
+    if (more) {
+#pragma unroll
+      for (int j = 0; j < NA; ++j) store_a1(cur ^ 1, ra[j], j);
+#pragma unroll
+      for (int j = 0; j < NB; ++j) store_b1(cur ^ 1, rb[j], j);
+    }
+    __syncthreads();
+  }
+
+  float* Cz = reinterpret_cast<float*>(g.C) + z0 * g.c_s0 + z1 * g.c_s1;
+  const float* auxz = g.aux ? reinterpret_cast<const float*>(g.aux) + z0 * g.aux_s0 + z1 * g.aux_s1 : nullptr;
+  float* auxo = g.aux ? reinterpret_cast<float*>(g.aux) + z0 * g.aux_s0 + z1 * g.aux_s1 : nullptr;
+  const float* bias = g.bias ? g.bias + z1 * g.bias_s1 : nullptr;
+  // D[n][m]: lane l, register r: m = l & 31, n = 8 (r >> 2) + 4 (l >> 5) + (r & 3)
+#pragma unroll
+  for (int i = 0; i < FI; ++i)
+#pragma unroll
+    for (int j = 0; j < FJ; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float v4[4] = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+        epilogue_store4<float>(g, Cz, auxz, auxo, bias, m0 + wm * (BM / 2) + i * 32 + rl,
+                               n0 + wn * (BN / 2) + j * 32 + q * 8 + kl * 4, v4, split == 0);
+      }
+}
+
+template <bool TA, bool TB, int BM, int BN>
+static void launch_f32(GemmArgs a, int M, int N, int split, int batch, hipStream_t st) {
+  constexpr size_t lds = sizeof(float) * 2 * 32 * ((BM + (TA ? 4 : 1)) + (BN + (TB ? 4 : 1)));
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_mfma_kernel<TA, TB, BM, BN>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  a.tiles_m = (int)cdiv(M, BM);
+  a.tiles_n = (int)cdiv(N, BN);
+  dim3 grid(a.tiles_m * a.tiles_n, split, batch);
+  hipLaunchKernelGGL((gemm_f32_mfma_kernel<TA, TB, BM, BN>), grid, dim3(256), lds, st, a);
+}
+
+template <int BM, int BN>
+static void launch_f32_layout(const GemmArgs& a, int M, int N, int split, int batch, hipStream_t st) {
+  if (!a.A.trans && !a.B.trans) launch_f32<false, false, BM, BN>(a, M, N, split, batch, st);
+  else if (!a.A.trans && a.B.trans) launch_f32<false, true, BM, BN>(a, M, N, split, batch, st);
+  else if (a.A.trans && !a.B.trans) launch_f32<true, false, BM, BN>(a, M, N, split, batch, st);
+  else launch_f32<true, true, BM, BN>(a, M, N, split, batch, st);
+}
+
+static int g_f32_tile_force = 0;      // tools: 0 = the choice below, 1 = 128x128, 2 = 64x128, 3 = 128x64, 4 = 64x64
+extern "C" int w2v2_tune_gemm_f32_tile(int t) {
+  const int old = g_f32_tile_force;
+  if (t >= 0 && t <= 4) g_f32_tile_force = t;
+  return old;
+}
+
+void w2v2_launch_gemm_f32(GemmArgs a, int M, int N, int K, int split, int batch, hipStream_t st) {
+  a.k_per_split = (int)(cdiv(cdiv(K, split), 32) * 32);
+  if (a.k_per_split == 0) a.k_per_split = 32;
+  // Tile choice: the chip holds 2 workgroups of the 128 x 128 tile per CU.  Take the largest tile (fewest LDS reads and
+  // global loads per MFMA) whose grid fills >= 60 % of those slots; when none does, the smallest one.  (A round-counting
+  // cost model that also moved the 2.4-round 19800 x 1024 x 1024 products to 64 x 128 tiles measured SLOWER, 463 vs 423 us:
+  // the half-size tile's in-loop rate is ~0.8 of the full one's, more than the rounds it saves.)
+  const int64_t slots = 2 * (int64_t)w2v2_gemm_device_cus();
+  auto wgs = [&](int bm, int bn) { return cdiv(M, bm) * cdiv(N, bn) * (int64_t)split * batch; };
+  int bm = 128, bn = 128;
+  if (M <= 64) bm = 64;
+  if (N <= 64) bn = 64;
+  if (wgs(bm, bn) * 10 < slots * 6) {
+    // halve the dimension with the longer tile side first (keeps the tile closer to square), M on ties
+    if (bm == 128 && (bn == 64 || wgs(64, bn) * 10 >= slots * 6 || M >= N)) bm = 64;
+    else if (bn == 128) bn = 64;
+    if (wgs(bm, bn) * 10 < slots * 6) { if (bm == 128) bm = 64; else if (bn == 128) bn = 64; }
+  }
+  switch (g_f32_tile_force) {
+    case 1: bm = 128; bn = 128; break;
+    case 2: bm = 64; bn = 128; break;
+    case 3: bm = 128; bn = 64; break;
+    case 4: bm = 64; bn = 64; break;
+    default: break;
+  }
+  if (bm == 128 && bn == 128) launch_f32_layout<128, 128>(a, M, N, split, batch, st);
+  else if (bm == 64 && bn == 128) launch_f32_layout<64, 128>(a, M, N, split, batch, st);
+  else if (bm == 128 && bn == 64) launch_f32_layout<128, 64>(a, M, N, split, batch, st);
+  else launch_f32_layout<64, 64>(a, M, N, split, batch, st);
+}

@@ -213,8 +213,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                                                            const float* __restrict__ partial, int nblk,
                                                            float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                            T* __restrict__ da, int64_t ldda, int M, int C, int relu,
-                                                           float invM) {
+                                                           float invM, float* __restrict__ cs_partial) {
   __shared__ double fold[4][BN_CW][2];
+  __shared__ float csred[BN_RL][BN_CW];          // column sums of da over this workgroup's rows (cs_partial != NULL)
   __shared__ float cf[5][BN_CW];                 // mean, rstd, gamma*rstd, sum dy / M, sum dy xhat / M
   const int tid = threadIdx.y * 16 + threadIdx.x;
   const int c = tid & (BN_CW - 1), cc = blockIdx.x * BN_CW + c;
@@ -234,9 +235,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
   }
   __syncthreads();
   const int cl = threadIdx.x * 8, cg = blockIdx.x * BN_CW + cl;
-  if (cg >= C) return;
-  const int m0 = blockIdx.y * BN_AROWS, m1 = min(M, m0 + BN_AROWS);
-  float mu[8], rs[8], gr[8], m1s[8], m2s[8];
+  if (cg >= C && cs_partial == nullptr) return;
+  const int m0 = blockIdx.y * BN_AROWS, m1 = (cg < C) ? min(M, m0 + BN_AROWS) : m0;
+  float mu[8], rs[8], gr[8], m1s[8], m2s[8], cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     mu[e] = cf[0][cl + e]; rs[e] = cf[1][cl + e]; gr[e] = cf[2][cl + e]; m1s[e] = cf[3][cl + e]; m2s[e] = cf[4][cl + e];
@@ -259,9 +260,23 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
           const float rh = (r - mu[e]) * rs[e];
           const float dr = gr[e] * (d[u].v[e] - m1s[e] - rh * m2s[e]);
           d[u].v[e] = (relu && !(av > 0.f)) ? 0.f : dr;
+          cs[e] += d[u].v[e];
         }
         d[u].store(da + (int64_t)(m + u * BN_RL) * ldda + cg);
       }
+  }
+  // column sums of da (= the bias gradient of the convolution in front of this BatchNorm) while the values are in
+  // registers: per row-block partials, folded by the caller (w2v2_colsum over nblk rows instead of M)
+  if (cs_partial != nullptr) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) csred[threadIdx.y][cl + e] = cs[e];
+    __syncthreads();
+    if (tid < BN_CW && cc < C) {
+      float t = 0.f;
+#pragma unroll
+      for (int y = 0; y < BN_RL; ++y) t += csred[y][c];
+      cs_partial[(int64_t)blockIdx.y * C + cc] = t;
+    }
   }
 }
 
@@ -440,6 +455,7 @@ __global__ void act_bwd_kernel(const float* __restrict__ dy, const float* __rest
 static int td_blocks(int64_t n) { return (int)(cdiv(n, 256) > 8192 ? 8192 : (cdiv(n, 256) < 1 ? 1 : cdiv(n, 256))); }
 
 extern "C" int w2v2_bn_workspace_floats(int M, int C) { return (int)cdiv(M, 128) * C * 2; }
+extern "C" int w2v2_bn_colsum_rows(int M) { return (int)cdiv(M, BN_AROWS); }
 
 extern "C" int w2v2_bn_fwd(const void* a, int64_t lda, float* workspace, float* mean_rstd, float* running,
                            const float* gamma, const float* beta, void* y, int64_t ldy, int M, int C, float eps,
@@ -464,7 +480,7 @@ extern "C" int w2v2_bn_fwd(const void* a, int64_t lda, float* workspace, float* 
 
 extern "C" int w2v2_bn_bwd(const void* dy, int64_t lddy, const void* a, int64_t lda, const float* mean_rstd,
                            const float* gamma, float* workspace, float* dgamma, float* dbeta, void* da, int64_t ldda,
-                           int M, int C, int relu, int dtype, void* stream) {
+                           int M, int C, int relu, float* colsum_partial, int dtype, void* stream) {
   W2V2_REQUIRE(dy && a && mean_rstd && gamma && workspace && dgamma && dbeta && da && M > 0 && C > 0 && C % 8 == 0 &&
                    lda % 8 == 0 && lddy % 8 == 0 && ldda % 8 == 0, "bn_bwd: bad arguments (C and strides multiples of 8)");
   const int nblk = (int)cdiv(M, bn_rows_host(C));
@@ -474,7 +490,7 @@ extern "C" int w2v2_bn_bwd(const void* dy, int64_t lddy, const void* a, int64_t 
   hipLaunchKernelGGL(bn_bwd_partial_kernel<T_>, gp, blk, 0, st, (const T_*)dy, lddy, (const T_*)a, lda, mean_rstd,  \
                      workspace, M, C, relu);                                                                        \
   hipLaunchKernelGGL(bn_bwd_apply_kernel<T_>, ga, blk, 0, st, (const T_*)dy, lddy, (const T_*)a, lda, mean_rstd,    \
-                     gamma, workspace, nblk, dgamma, dbeta, (T_*)da, ldda, M, C, relu, 1.0f / (float)M)
+                     gamma, workspace, nblk, dgamma, dbeta, (T_*)da, ldda, M, C, relu, 1.0f / (float)M, colsum_partial)
   W2V2_DISPATCH_ACT(dtype, "bn_bwd", TD_BNB(AT););
 #undef TD_BNB
   W2V2_CHECK_LAUNCH("bn_bwd");

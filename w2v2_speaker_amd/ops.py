@@ -131,8 +131,7 @@ class Gemm:
         elif fast:
             self.kernel_name = "gemm16_dma_128_kernel"
         else:
-            self.kernel_name = ("gemm16_regstage_kernel" if lp else
-                                "gemm_f32_kernel" if os.environ.get("W2V2_F32_VALU") else "gemm_f32_mfma_kernel")
+            self.kernel_name = "gemm16_regstage_kernel" if lp else "gemm_f32_mfma_kernel"
 
     _prof = None
     _log = None        # tools/gemm_instep.py: when a list, every launch appends its shape key (launch order)
@@ -638,12 +637,17 @@ def bn_fwd(a, lda: int, work, mean_rstd, running, gamma, beta, y, ldy: int, M: i
                                  stream()), "bn_fwd")
 
 
+def bn_colsum_rows(M: int) -> int:
+    return int(lib().w2v2_bn_colsum_rows(M))
+
+
 def bn_bwd(dy, lddy: int, a, lda: int, mean_rstd, gamma, work, dgamma, dbeta, da, ldda: int, M: int, C: int,
-           relu: bool) -> None:
-    _dev(dy, a, mean_rstd, gamma, work, dgamma, dbeta, da)
+           relu: bool, colsum_partial=None) -> None:
+    """colsum_partial [bn_colsum_rows(M), C] f32 (optional): written with the per-row-block column sums of da."""
+    _dev(dy, a, mean_rstd, gamma, work, dgamma, dbeta, da, colsum_partial)
     _lib.check(lib().w2v2_bn_bwd(dy.data_ptr(), lddy, a.data_ptr(), lda, mean_rstd.data_ptr(), gamma.data_ptr(),
                                  work.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), da.data_ptr(), ldda, M, C,
-                                 int(relu), dt(a), stream()), "bn_bwd")
+                                 int(relu), _p(colsum_partial), dt(a), stream()), "bn_bwd")
 
 
 def im2col_reflect(x, ldx: int, col, B: int, T: int, Cin: int, k: int, dilation: int) -> None:
