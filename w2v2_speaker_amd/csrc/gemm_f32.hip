@@ -159,6 +159,44 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma_kernel(const GemmArgs g)
   float* auxo = g.aux ? reinterpret_cast<float*>(g.aux) + z0 * g.aux_s0 + z1 * g.aux_s1 : nullptr;
   const float* bias = g.bias ? g.bias + z1 * g.bias_s1 : nullptr;
   // D[n][m]: lane l, register r: m = l & 31, n = 8 (r >> 2) + 4 (l >> 5) + (r & 3)
+  if (g.atomic && (g.epilogue == W2V2_EPI_NONE || g.epilogue == W2V2_EPI_BIAS)) {
+    // Split-K / accumulating products (the token-long weight gradients of ECAPA: 8..32 partial tiles per output tile)
+    // ADD into C.  Straight from the accumulator layout one atomic instruction touches 32 different ROWS = 64 cache
+    // lines, and the L2 atomic units then are the bottleneck of the whole launch (round 4, ECAPA step: 1024 x 1024 x
+    // 19800 split 8 ways 553 us with these atomics, 392 us with plain stores instead).  So each 32-row block goes
+    // through LDS (the operand images are dead) and comes back with the lanes ALONG a row: one instruction = 64 (or
+    // 2 x 32) consecutive columns = 4 lines.
+    constexpr int WN = BN / 2, SP = WN + 1;
+    static_assert(4 * 32 * SP * sizeof(float) <= sizeof(float) * 2 * 32 * (PA + PB), "staging fits the operand images");
+    float* stage = reinterpret_cast<float*>(smem_raw) + wave * (32 * SP);
+    const bool add_bias = g.epilogue == W2V2_EPI_BIAS && split == 0 && bias != nullptr;
+#pragma unroll
+    for (int i = 0; i < FI; ++i) {
+#pragma unroll
+      for (int j = 0; j < FJ; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) stage[rl * SP + j * 32 + 8 * (r >> 2) + 4 * kl + (r & 3)] = acc[i][j][r] * g.alpha;
+      __syncthreads();
+      const int mb = m0 + wm * (BM / 2) + i * 32;
+      if constexpr (WN == 64) {
+        const int n = n0 + wn * WN + lane;
+        const float bv = (add_bias && n < g.N) ? bias[n] : 0.f;
+#pragma unroll 8
+        for (int rr = 0; rr < 32; ++rr)
+          if (mb + rr < g.M && n < g.N) unsafeAtomicAdd(Cz + (int64_t)(mb + rr) * g.ldc + n, stage[rr * SP + lane] + bv);
+      } else {
+        const int n = n0 + wn * WN + (lane & 31);
+        const float bv = (add_bias && n < g.N) ? bias[n] : 0.f;
+#pragma unroll 8
+        for (int r2 = 0; r2 < 16; ++r2) {
+          const int rr = 2 * r2 + (lane >> 5);
+          if (mb + rr < g.M && n < g.N) unsafeAtomicAdd(Cz + (int64_t)(mb + rr) * g.ldc + n, stage[rr * SP + (lane & 31)] + bv);
+        }
+      }
+      __syncthreads();
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < FI; ++i)
 #pragma unroll
