@@ -209,3 +209,57 @@ def test_batchnorm_kernels_vs_torch(dtype, M, C, ld, relu):
     ops.bn_fwd(ad, ld, None, mr, running, gd, bd, y, ld, M, C, 1e-5, 0.1, relu, False)
     assert rel_l2(y[:, :C].cpu().double(), ye.detach()) < tol
     assert torch.equal(running, run0)
+
+
+def test_ecapa_full_size_f32_step_every_weight_gradient_and_running_statistics():
+    """BASELINE configs[4] at ITS OWN size under -m gpu: C = 1024, 66 utterances x 300 frames, f32 --
+    the geometry whose token-long weight gradients take the split-K path with f32 atomics (3072 x 3072 x 19800 eight
+    ways, the 128-channel Res2Net chunks 32 ways on 64 x 64 tiles) that the tiny geometry never reaches.  One training
+    step: finite loss / embedding; the weight gradient of EVERY TDNN block against an f64 product of the operands the
+    plan itself stored (da^T x conv input), its bias gradient (the column sums the BatchNorm backward leaves) against
+    the f64 column sum of da; BatchNorm running statistics against torch's update rule on the stored pre-activations."""
+    from w2v2_speaker_amd.ecapa import BN_EPS, BN_MOMENTUM, FE, EcapaConfig, EcapaPlan, EcapaStore
+    cfg = EcapaConfig()
+    assert cfg.channels[1] == 1024
+    st = EcapaStore(cfg, DEV, torch.float32, num_speakers=5994)
+    st.init_weights(1)
+    B, T = 66, 300
+    plan = EcapaPlan(st, B, T, train=True)
+    g = torch.Generator().manual_seed(11)
+    feat = torch.randn(B, T, cfg.input_mel_coefficients, generator=g).to(DEV)
+    label = torch.randint(0, 5994, (B,), generator=g).to(DEV)
+    tdnns = plan._tdnns()
+    run0 = {t.pre: t.running.clone() for t in tdnns}
+    st.zero_grad()
+    emb = plan.embed(feat)
+    loss, _ = plan.head_forward_backward(label)
+    plan.backward()
+    torch.cuda.synchronize()
+    assert math.isfinite(float(loss)) and 5.0 < float(loss) < 25.0 and bool(torch.isfinite(emb).all())
+    assert bool(torch.isfinite(st.grad).all())
+    M = B * T
+    worst = 0.0
+    for t in tdnns:
+        A = t.col if t.k > 1 else t.x[:, :t.cin]
+        ref = t.da.double().t() @ A.double()                                   # [cout, K] (K = tap-major, cin-minor)
+        if t.k > 1:
+            got = t.dwp
+        else:
+            got = st.g(t.pre + "conv.conv.weight").view(t.cout, t.cin)
+        err = float((got.double() - ref).norm() / ref.norm())
+        worst = max(worst, err)
+        assert err < 2e-5, (t.pre, t.cout, t.K, err)
+        if t.k > 1:      # and the packed gradient reached the arena in torch's [cout][cin][tap] layout
+            arena = st.g(t.pre + "conv.conv.weight").view(t.cout, t.cin, t.k)
+            assert float((arena.permute(0, 2, 1).reshape(t.cout, t.K).double() - ref).norm() / ref.norm()) < 2e-5, t.pre
+        db_ref = t.da.double().sum(0)
+        assert float((st.g(t.pre + "conv.conv.bias").double() - db_ref).norm() / db_ref.norm().clamp_min(1e-30)) < 1e-4, t.pre
+        # running statistics: torch BatchNorm1d(momentum) on relu(a): mean, UNBIASED variance
+        r = torch.relu(t.a.double())
+        mean, var = r.mean(0), r.var(0, unbiased=True)
+        C = t.cout
+        exp_mean = (1 - BN_MOMENTUM) * run0[t.pre][:C].double() + BN_MOMENTUM * mean
+        exp_var = (1 - BN_MOMENTUM) * run0[t.pre][C:].double() + BN_MOMENTUM * var
+        assert float((t.running[:C].double() - exp_mean).abs().max()) < 1e-5 * float(exp_mean.abs().max() + 1), t.pre
+        assert float((t.running[C:].double() - exp_var).abs().max()) < 1e-5 * float(exp_var.abs().max() + 1), t.pre
+    print(f"full-size ECAPA f32: loss {float(loss):.4f}, worst weight-gradient rel-L2 vs f64 {worst:.2e} over {len(tdnns)} blocks")
