@@ -465,6 +465,11 @@ int w2v2_comm_init(w2v2_comm** comm, const void* id_host_128, int rank, int worl
 int w2v2_allreduce_async(w2v2_comm* comm, float* buf, int64_t n, void* stream);
 int w2v2_broadcast_async(w2v2_comm* comm, void* buf, int64_t nbytes, int root, void* stream);
 int w2v2_comm_destroy(w2v2_comm* comm);
+/* Tools only (tools/overlap_rehearsal.py): a stand-in for the RCCL channels of one bucket's all-reduce on a 1-GPU box --
+ * `channels` workgroups holding `lds_bytes` of LDS each stream the n floats of `buf` through themselves in place (values
+ * unchanged), paced to `gbps` GB/s in total (0 = unpaced).  Measures what the collective's residency costs the compute
+ * stream; moves nothing between GPUs. */
+int w2v2_traffic_probe(float* buf, int64_t n, int channels, int lds_bytes, float gbps, void* stream);
 
 #ifdef __cplusplus
 }

@@ -129,6 +129,7 @@ _SIGS = {
     "w2v2_allreduce_async": (c_i32, [c_vp, c_vp, c_i64, c_vp]),
     "w2v2_broadcast_async": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_vp]),
     "w2v2_comm_destroy": (c_i32, [c_vp]),
+    "w2v2_traffic_probe": (c_i32, [c_vp, c_i64, c_i32, c_i32, c_f32, c_vp]),
     "w2v2_grad_scaler_check": (c_i32, [c_vp, c_i64, c_vp, c_vp]),
     "w2v2_grad_scaler_update": (c_i32, [c_vp, c_f32, c_f32, c_i32, c_i32, c_vp]),
 }

@@ -133,3 +133,53 @@ extern "C" int w2v2_comm_destroy(w2v2_comm* comm) {
   if (rc != 0) W2V2_FAIL("comm_destroy: ncclCommDestroy: %s", rccl_err(rc));
   return 0;
 }
+
+// ------------------------------------------------------------------------------------------ overlap rehearsal (tools)
+// A stand-in for the RCCL channels of a gradient all-reduce on a ONE-GPU box (tools/overlap_rehearsal.py): `channels`
+// workgroups of 256 threads, each holding `lds_bytes` of LDS (an RCCL channel's footprint: it cannot share a CU with a
+// 128-144 KiB GEMM workgroup), stream `bytes` of a bucket through themselves (read the slice, add, write it back: the HBM
+// side of a ring step) -- PACED to `gbps` GB/s over all channels (s_memtime wall clock), so that the stand-in occupies its
+// CUs for as long as a collective of that size would on xGMI.  What it measures is the compute-side cost of the
+// collective's residency; it moves no data between GPUs.
+__global__ __launch_bounds__(256) void traffic_probe_kernel(float* __restrict__ buf, int64_t n, int64_t chunk,
+                                                            int64_t cycles_per_chunk) {
+  extern __shared__ char probe_lds[];
+  if (threadIdx.x == 0) probe_lds[0] = 0;                       // (keeps the dynamic LDS allocation)
+  const int64_t per = (n + gridDim.x - 1) / gridDim.x;
+  const int64_t lo = blockIdx.x * per, hi = lo + per < n ? lo + per : n;
+  const uint64_t t0 = __builtin_amdgcn_s_memrealtime();          // constant 100 MHz counter
+  int64_t done = 0;
+  for (int64_t c0 = lo; c0 < hi; c0 += chunk, ++done) {
+    const int64_t c1 = c0 + chunk < hi ? c0 + chunk : hi;
+    for (int64_t i = c0 + threadIdx.x * 4; i + 3 < c1; i += 256 * 4) {
+      float4 v = *reinterpret_cast<const float4*>(buf + i);
+      v.x += 0.f; v.y += 0.f; v.z += 0.f; v.w += 0.f;
+      *reinterpret_cast<float4*>(buf + i) = v;
+    }
+    if (cycles_per_chunk > 0) {
+      const uint64_t due = t0 + (uint64_t)((done + 1) * cycles_per_chunk);
+      while (__builtin_amdgcn_s_memrealtime() < due) __builtin_amdgcn_s_sleep(8);
+    }
+  }
+}
+
+extern "C" int w2v2_traffic_probe(float* buf, int64_t n, int channels, int lds_bytes, float gbps, void* stream) {
+  W2V2_REQUIRE(buf != nullptr && n >= 0 && channels > 0 && channels <= 1024 && lds_bytes >= 0 && lds_bytes <= 160 * 1024,
+               "traffic_probe: bad arguments");
+  if (n == 0) return 0;
+  W2V2_REQUIRE((reinterpret_cast<uintptr_t>(buf) & 15) == 0, "traffic_probe: 16-byte aligned buffer");
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&traffic_probe_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024);
+    attr_set = true;
+  }
+  const int64_t chunk = 16384;                                  // floats per pacing step (64 KiB)
+  // s_memrealtime counts at a fixed 100 MHz; one pacing step of every channel = channels * 64 KiB of the bucket
+  int64_t cycles = 0;
+  if (gbps > 0.f) cycles = (int64_t)(1e8 * (double)channels * (double)chunk * 4.0 / ((double)gbps * 1e9));    // gbps = bucket bytes per second
+  hipLaunchKernelGGL(traffic_probe_kernel, dim3((unsigned)channels), dim3(256), (size_t)(lds_bytes > 16 ? lds_bytes : 16),
+                     as_stream(stream), buf, n, chunk, cycles);
+  W2V2_CHECK_LAUNCH("traffic_probe");
+  return 0;
+}
