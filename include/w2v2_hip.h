@@ -251,6 +251,15 @@ int w2v2_posconv_regroup(const void* x, void* xg, int B, int T, int H, int G, in
  * Cg = H/G in {16, 32, 48, 64}, K a multiple of 16.  (ref: the autograd of HF:360-368 `self.conv`.) */
 int w2v2_posconv_wgrad(const void* dY, const void* xg, float* dwf, int B, int T, int H, int G, int K,
                        int dtype /* W2V2_BF16 or W2V2_F16 */, void* stream);
+/* The grouped positional convolution itself (HF:326-379) and its data gradient as a DIRECT convolution with the padded
+ * image of one (utterance, group) resident in LDS (csrc/posconv_direct.hip; w2v2-base geometry: Cg = 48, K = 128):
+ *   out[b, t, g*Cg + co] = epi( sum_{tap, ci} xg[b, g, t + tap, ci] * w[g][co][tap*Cg + ci] )
+ * xg = posconv_regroup(x, pad_left) [B][G][T+K-1][Cg]; w = the packed (weight-normed) weights [G][Cg][K*Cg] of
+ * w2v2_weightnorm_pack (forward: wf; data gradient: wb over the regrouped dY).  mode 0: epi = GELU(. + bias[g*Cg+co]),
+ * aux (may be NULL) receives the pre-activation; mode 1: epi = . + aux (aux may alias out).  16-bit activations;
+ * bit-equal to the implicit GEMM of w2v2_gemm over the same operands.  Other geometries: use the implicit GEMM. */
+int w2v2_posconv_direct(const void* xg, const void* w, void* out, void* aux, const float* bias, int B, int T, int G,
+                        int Cg, int K, int64_t ldc, int mode, int dtype, void* stream);
 int w2v2_weightnorm_pack(const float* g, const float* v, float* sumsq /*[129*K]*/, void* wf,
                          void* wb, int H, int G, int K, int dtype, void* stream);
 int w2v2_weightnorm_bwd(const float* g, const float* v, const float* sumsq, const float* dwf,

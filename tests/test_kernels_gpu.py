@@ -1058,6 +1058,58 @@ def test_transpose_many_vector_and_scalar_paths(lp):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("B,T", [(3, 149), (2, 301), (5, 37), (1, 160), (2, 161)])
+@pytest.mark.parametrize("lp", LP16)
+def test_posconv_direct_convolution_bit_equal_to_implicit_gemm(B, T, lp):
+    """csrc/posconv_direct.hip (image of one (utterance, group) resident in LDS, weights streamed): forward (bias + GELU,
+    pre-activation saved) and data-gradient (+ aux, in place) modes at the w2v2-base geometry (16 groups x 48 channels,
+    128 taps) against (a) an f64 grouped convolution and (b) the implicit GEMM of w2v2_gemm over the SAME operands --
+    bit for bit (same k order per accumulator).  T = 301 / 161: two frame blocks per utterance; T = 37: shorter than
+    the kernel's halo."""
+    o = ops()
+    G, Cg, K = 16, 48, 128
+    H, Tp, M = G * Cg, T + K - 1, B * T
+    g = torch.Generator(device="cpu").manual_seed(B * 1000 + T)
+    x = (torch.randn(B, T, H, generator=g)).to(lp)
+    wf = (torch.randn(G, Cg, K * Cg, generator=g) / (K * Cg) ** 0.5).to(lp)       # [g][co][tap*Cg + ci]
+    bias = torch.randn(H, generator=g)
+    res = (torch.randn(M, H, generator=g)).to(lp)
+    xd, wd, bd = x.to(DEV), wf.to(DEV), bias.to(DEV)
+    xg = torch.zeros(B, G, Tp, Cg, dtype=lp, device=DEV)
+    o.posconv_regroup(xd.view(M, H), xg, B, T, H, G, K, K // 2)
+    # f64 reference: out[b, t, g*Cg + co] = sum_{tap, ci} xpad[b, t + tap, g*Cg + ci] * w[g][co][tap][ci]
+    xp = torch.nn.functional.pad(x.double().transpose(1, 2), (K // 2, K - 1 - K // 2))          # [B, H, Tp]
+    w4 = wf.double().view(G, Cg, K, Cg).permute(0, 1, 3, 2).reshape(H, Cg, K)                      # torch layout [H][ci][tap]
+    ref = torch.nn.functional.conv1d(xp, w4, groups=G).transpose(1, 2).reshape(M, H)              # [M, H]
+    # (a) + (b), forward
+    out_d, pre_d = torch.full((M, H), float("nan"), dtype=lp, device=DEV), torch.full((M, H), float("nan"), dtype=lp, device=DEV)
+    o.posconv_direct(xg, wd, out_d, pre_d, bd, B, T, G, Cg, K, H, 0)
+    out_g, pre_g = torch.zeros(M, H, dtype=lp, device=DEV), torch.zeros(M, H, dtype=lp, device=DEV)
+    o.gemm(M, Cg, K * Cg, xg, wd, out_g, lda=Cg, ldb=K * Cg, ldc=H, a_seg=(T, G * Tp * Cg), batch=G, batch_inner=G,
+           a_strides=(0, Tp * Cg), b_strides=(0, Cg * K * Cg), c_strides=(0, Cg), epilogue=o.EPI_BIAS_GELU, bias=bd,
+           bias_stride1=Cg, aux=pre_g, ldaux=H, aux_strides=(0, Cg))
+    torch.cuda.synchronize()
+    tol = 4e-3 if lp == torch.float16 else 2e-2
+    assert rel_l2(pre_d.float().cpu(), ref + bias.double()) < tol
+    assert rel_l2(out_d.float().cpu(), torch.nn.functional.gelu(ref + bias.double())) < tol
+    assert torch.equal(out_d, out_g) and torch.equal(pre_d, pre_g)
+    # eval mode: no pre-activation buffer
+    out_e = torch.zeros(M, H, dtype=lp, device=DEV)
+    o.posconv_direct(xg, wd, out_e, None, bd, B, T, G, Cg, K, H, 0)
+    torch.cuda.synchronize()
+    assert torch.equal(out_e, out_d)
+    # data-gradient mode: in place + aux
+    acc_d, acc_g = res.to(DEV).clone(), res.to(DEV).clone()
+    o.posconv_direct(xg, wd, acc_d, acc_d, None, B, T, G, Cg, K, H, 1)
+    o.gemm(M, Cg, K * Cg, xg, wd, acc_g, lda=Cg, ldb=K * Cg, ldc=H, a_seg=(T, G * Tp * Cg), batch=G, batch_inner=G,
+           a_strides=(0, Tp * Cg), b_strides=(0, Cg * K * Cg), c_strides=(0, Cg), epilogue=o.EPI_ADD, aux=acc_g, ldaux=H,
+           aux_strides=(0, Cg))
+    torch.cuda.synchronize()
+    assert rel_l2(acc_d.float().cpu(), ref + res.double()) < tol
+    assert torch.equal(acc_d, acc_g)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("B,T,G,Cg,K", [(3, 149, 16, 48, 128), (2, 249, 16, 64, 128), (2, 37, 4, 16, 16),
                                          (2, 170, 2, 32, 32)])
 @pytest.mark.parametrize("lp", LP16)

@@ -190,6 +190,9 @@ class Plan:
         self.hx = self._e(M, H) if (self.cls or self.paired) else self.h0       # encoder input
         G, K = cfg.num_conv_pos_embedding_groups, cfg.num_conv_pos_embeddings
         self.Cg, self.Tp = H // G, T + K - 1
+        # the direct convolution kernel is built for the w2v2-base geometry (48 channels per group, 128 taps); everything
+        # else (wav2vec2-large: 64 channels per group; the exact-f32 mode) runs the implicit GEMM
+        self.pos_direct = (ops.is16(self.adt) and self.Cg == 48 and K == 128 and not os.environ.get("W2V2_NO_POSCONV_DIRECT"))
         self.xg = self._e(B, G, self.Tp, self.Cg)
         self.posw_f, self.posw_b = self._e(G, self.Cg, K * self.Cg), self._e(G, self.Cg, K * self.Cg)
         self.pos_sumsq = self._e(129 * K, dtype=f32)
@@ -496,7 +499,11 @@ class Plan:
             ops.mask_feature(self.h0, self._fmask, B, self.T0)
         G, K = cfg.num_conv_pos_embedding_groups, cfg.num_conv_pos_embeddings
         ops.posconv_regroup(self.hx, self.xg, B, T, H, G, K, K // 2)
-        self.g_pos()
+        if self.pos_direct:      # image-resident direct convolution (csrc/posconv_direct.hip), bit-equal to the GEMM
+            ops.posconv_direct(self.xg, self.posw_f, self.pos, self.pos_pre, mp("encoder.pos_conv_embed.conv.bias"), B, T, G,
+                               self.Cg, K, H, 0)
+        else:
+            self.g_pos()
         x = self.X[0]
         ops.layernorm_fwd(self.hx, self.pos, mp("encoder.layer_norm.weight"), mp("encoder.layer_norm.bias"), x,
                           self.mean0, self.rstd0, cfg.layer_norm_eps)
@@ -711,7 +718,10 @@ class Plan:
                            self.dwf, self.pos_dot, mg("encoder.pos_conv_embed.conv.parametrizations.weight.original0"),
                            mg("encoder.pos_conv_embed.conv.parametrizations.weight.original1"), H, G_, K)
         ops.posconv_regroup(self.P1, self.dyg, B, T, H, G_, K, K - 1 - K // 2)
-        self.g_pos_dx()                                         # G = conv^T(P1) + G
+        if self.pos_direct:
+            ops.posconv_direct(self.dyg, self.posw_b, self.G, self.G, None, B, T, G_, self.Cg, K, H, 1)
+        else:
+            self.g_pos_dx()                                     # G = conv^T(P1) + G
         if self.cls:
             self.G0.view(B, self.T0, H).copy_(self.G.view(B, T, H)[:, 1:, :])    # the CLS row has no input
             g0 = self.G0

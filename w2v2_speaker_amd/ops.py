@@ -437,6 +437,18 @@ def posconv_wgrad(dY, xg, dwf, B: int, T: int, H: int, G: int, K: int) -> None:
                "posconv_wgrad")
 
 
+def posconv_direct(xg, w, out, aux, bias, B: int, T: int, G: int, Cg: int, K: int, ldc: int, mode: int) -> None:
+    """Direct grouped pos-conv / its data gradient (include/w2v2_hip.h w2v2_posconv_direct): mode 0 = GELU(conv + bias)
+    (+ pre-activation into aux), mode 1 = conv + aux."""
+    _dev(xg, w, out, aux, bias)
+    assert is16(xg.dtype) and w.dtype == xg.dtype and out.dtype == xg.dtype
+    _lib.check(lib().w2v2_posconv_direct(xg.data_ptr(), w.data_ptr(), out.data_ptr(), _p(aux), _p(bias), B, T, G, Cg, K,
+                                         ldc, mode, dt(xg), stream()), "posconv_direct")
+    if Gemm._log is not None:
+        Gemm._log.append({"kind": "posconv", "flops": 2.0 * B * T * G * Cg * K * Cg, "alg_flops": 2.0 * B * T * G * Cg * K * Cg,
+                          "kernel": "posconv_direct_kernel", "M": B * T, "N": Cg, "K": K * Cg, "mode": mode})
+
+
 def posconv_regroup(x, xg, B: int, T: int, H: int, G: int, K: int, pad_left: int) -> None:
     _dev(x, xg)
     _lib.check(lib().w2v2_posconv_regroup(x.data_ptr(), xg.data_ptr(), B, T, H, G, K, pad_left, dt(x), stream()),
