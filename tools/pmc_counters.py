@@ -75,6 +75,7 @@ def durations(d):
 
 def main():
     dF, dW, dM = sys.argv[1:4]
+    dV = sys.argv[4] if len(sys.argv) > 4 else None          # optional 4th pass: --pmc SQ_INSTS_VALU SQ_WAVES
     f, w = per_kernel(dF, "FETCH_SIZE"), per_kernel(dW, "WRITE_SIZE")
     mf = per_kernel(dM, "SQ_VALU_MFMA_BUSY_CYCLES")
     sb = per_kernel(dM, "SQ_BUSY_CYCLES")
@@ -104,6 +105,17 @@ def main():
             if name in sb and sb[name][1] > 0:
                 rec["sq_busy_cycles_per_launch"] = round(sb[name][1] / sb[name][0], 1)
         out["kernels"][name] = rec
+    if dV is not None:
+        # VALU wave-instructions per launch (SQ_INSTS_VALU, summed over the chip); for the attention kernels also per
+        # attention score: a launch evaluates B * heads * T^2 scores (w2v2-base bench: 66 * 12 * 149^2), each wave
+        # instruction covers 64 lanes -> instructions per score = 64 * SQ_INSTS_VALU / scores
+        va = per_kernel(dV, "SQ_INSTS_VALU")
+        scores = 66 * 12 * 149 * 149
+        for name, (n, tot) in va.items():
+            rec = out["kernels"].setdefault(name, {"launches": n})
+            rec["valu_wave_insts_per_launch"] = round(tot / n, 1)
+            if name.startswith("attn_"):
+                rec["valu_lane_insts_per_score"] = round(64.0 * tot / n / scores, 2)
     json.dump(out, sys.stdout, indent=1)
 
 

@@ -13,7 +13,7 @@ export TMPDIR=/tmp
 export W2V2_BENCH_NO_FAMILY_PASS=1      # profiled runs: only the timed steps (no second, event-instrumented pass)
 BENCH="python3 $PWD/bench.py --no-cpu-baseline --no-also $MODEL"
 cd /tmp
-rm -rf /tmp/prof_ks /tmp/prof_f /tmp/prof_w /tmp/prof_m
+rm -rf /tmp/prof_ks /tmp/prof_f /tmp/prof_w /tmp/prof_m /tmp/prof_v
 rocprofv3 --kernel-trace --stats -d /tmp/prof_ks -- $BENCH --steps 8 --warmup 3 > $OUT/${TAG}_prof_ks.log 2>&1
 DB=$(find /tmp/prof_ks -name "*.db" | head -1)
 # the last 8 steps only (steady state: start-up copies / fills / weight packing left out), delimited by the
@@ -22,7 +22,9 @@ python3 $OLDPWD/tools/prof_summary.py $DB 8 --steady adam_kernel > $OUT/${TAG}_k
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/prof_f -- $BENCH --steps 2 --warmup 1 > $OUT/${TAG}_prof_f.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/prof_w -- $BENCH --steps 2 --warmup 1 > $OUT/${TAG}_prof_w.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d /tmp/prof_m -- $BENCH --steps 2 --warmup 1 > $OUT/${TAG}_prof_m.log 2>&1
-python3 $OLDPWD/tools/pmc_counters.py /tmp/prof_f /tmp/prof_w /tmp/prof_m > $OUT/${TAG}_pmc_counters.json 2> $OUT/${TAG}_pmc_err.log
+rm -rf /tmp/prof_v
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU -d /tmp/prof_v -- $BENCH --steps 2 --warmup 1 > $OUT/${TAG}_prof_v.log 2>&1
+python3 $OLDPWD/tools/pmc_counters.py /tmp/prof_f /tmp/prof_w /tmp/prof_m /tmp/prof_v > $OUT/${TAG}_pmc_counters.json 2> $OUT/${TAG}_pmc_err.log
 cd $OLDPWD
 # bench.py / tools/ecapa_bench.py read the counters from profiles/: refresh that copy BEFORE the line is produced, so the
 # line's traffic / mfma_busy fields come from counters taken on exactly these kernel sources (pmc_stale: false)
