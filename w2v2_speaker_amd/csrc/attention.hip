@@ -18,6 +18,7 @@
 // (T = 149: the third 64-row block has two idle waves) but keep loading tiles and taking the barriers.
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
@@ -26,15 +27,20 @@ constexpr int HD = 64;  // head dim
 // 16-row periodic: all fragments of an image share one per-lane swizzle, so fragment addresses are
 // lane base + compile-time constant (ds_read offset immediates instead of one address VGPR each)
 // dropout counter of attention probability (bh, q, key): rows are padded to an even length so that keys 2j, 2j+1
-// of a row always share one hash (common.h rng_pair); every fused kernel (forward, all backward variants) uses it
+// of a row always share one hash (common.h rng_pair); every fused kernel (forward, both backward kernels) uses it
 __device__ __forceinline__ uint64_t attn_drop_idx(int64_t bh, int q, int key, int Tn) {
   return (uint64_t)(bh * Tn + q) * (uint64_t)((Tn + 1) & ~1) + (uint64_t)key;
 }
-// keep-scales of 4 consecutive keys key0 .. key0+3 (key0 % 4 == 0) of query row q: two hashes
-__device__ __forceinline__ void attn_drop4_keys(uint64_t seed, int64_t bh, int q, int key0, int Tn, float dp,
-                                                float inv_keep, float (&ms)[4]) {
-  const uint32_t k = rng_key(seed), thr = drop_thr16(dp);
-  const uint64_t pi = attn_drop_idx(bh, q, key0, Tn) >> 1;
+// pair index of key 0 of query row q (attn_drop_idx(bh, q, 0, Tn) >> 1): a per-lane constant of the forward and dQ
+// kernels, so a hash costs one 64-bit add instead of one 64-bit multiply
+__device__ __forceinline__ uint64_t attn_row_pair0(int64_t bh, int q, int Tn) {
+  return (uint64_t)(bh * Tn + q) * (uint64_t)(((Tn + 1) & ~1) >> 1);
+}
+// keep-scales of 4 consecutive keys of a query row: two hashes.  row0 = pair index of the row's key k0 (k0 % 4 == 0,
+// lane-dependent), key0_rel = distance of the first of the 4 keys from k0, a wave-uniform multiple of 4 -> one 64-bit add
+__device__ __forceinline__ void attn_drop4_keys(uint32_t k, uint32_t thr, uint64_t row0, int key0_rel, float inv_keep,
+                                                float (&ms)[4]) {
+  const uint64_t pi = row0 + (uint64_t)(uint32_t)(key0_rel >> 1);
   const uint32_t h0 = rng_pair(k, pi), h1 = rng_pair(k, pi + 1);
   ms[0] = (h0 & 0xffffu) >= thr ? inv_keep : 0.f;
   ms[1] = (h0 >> 16) >= thr ? inv_keep : 0.f;
@@ -106,13 +112,24 @@ __device__ __forceinline__ void reg_frag(frag8_t f[2], const bf16_t* g, int64_t 
     f[kk] = as_frag(v);
   }
 }
+// reductions over the four lanes {c, c+16, c+32, c+48} that share a row: gfx950 row / half swaps in the VALU
+// (v_permlane16_swap: rows 1 <-> 0 and 3 <-> 2 of the two operands; v_permlane32_swap: upper half <-> lower half)
+// instead of two ds_bpermute round trips with their per-call lane-index arithmetic
 __device__ __forceinline__ float quad_max(float v) {
-  v = fmaxf(v, __shfl_xor(v, 16, 64));
-  return fmaxf(v, __shfl_xor(v, 32, 64));
+  const uint32_t u = __float_as_uint(v);
+  auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  v = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+  const uint32_t w = __float_as_uint(v);
+  auto b = __builtin_amdgcn_permlane32_swap(w, w, false, false);
+  return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
 }
 __device__ __forceinline__ float quad_sum(float v) {
-  v += __shfl_xor(v, 16, 64);
-  return v + __shfl_xor(v, 32, 64);
+  const uint32_t u = __float_as_uint(v);
+  auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  const uint32_t w = __float_as_uint(v);
+  auto b = __builtin_amdgcn_permlane32_swap(w, w, false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
 
 template <typename TE>
@@ -233,6 +250,9 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_tiled_kernel(const bf16_t* __
   __syncthreads();
   float m = -INFINITY, l = 0.f;                       // running maximum in the log2 domain
   const float scale2 = scale * 1.4426950408889634f;
+  const uint32_t thr = drop_thr16(dp);
+  const uint32_t rkey = rng_key(seed);
+  const uint64_t row0 = attn_row_pair0(bh, q, Tn) + (uint64_t)(g * 2);     // + the lane's 4 keys of a 16-key block
   f32x4 o[4];
 #pragma unroll
   for (int df = 0; df < 4; ++df) o[df] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -248,65 +268,66 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_tiled_kernel(const bf16_t* __
     // outright -- at T = 149 that is two of the twelve blocks a query tile walks
     const int nfj = min(4, (Tn - t * AT_TILE + 15) >> 4);
     if (active) {
-    float s[4][4];
-    float tmax = -INFINITY;
-    // scores in the LOG2 domain (scale * log2(e) folded into one multiply, v_exp_f32 is 2^x); the key < T test only
-    // where a tile can hold an invalid key at all -- the last one (uniform branch: two copies of the score loop)
-    const bool partial = (t + 1) * AT_TILE > Tn;
+      // One body, two instantiations: FULL = a tile with four valid 16-key blocks and no key past T (every tile but the
+      // last): straight-line code, no per-block branches, no masks
+      auto body = [&](auto full_c, auto drop_c) {
+        constexpr bool FULL = decltype(full_c)::value, DROP = decltype(drop_c)::value;
+        float s[4][4];
+        float tmax = -INFINITY;
+        // scores in the LOG2 domain (scale * log2(e) folded into one multiply, v_exp_f32 is 2^x)
 #pragma unroll
-    for (int fj = 0; fj < 4; ++fj) {
-      if (fj < nfj) {
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int fj = 0; fj < 4; ++fj) {
+          if (FULL || fj < nfj) {
+            f32x4 acc = mfma16<TE>(lds_frag(Ks[cur], fj * 16, 0, lane), qf[0], f32x4{0.f, 0.f, 0.f, 0.f});
+            acc = mfma16<TE>(lds_frag(Ks[cur], fj * 16, 1, lane), qf[1], acc);
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) acc = mfma16<TE>(lds_frag(Ks[cur], fj * 16, kk, lane), qf[kk], acc);
-        if (partial) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int key = t * AT_TILE + fj * 16 + g * 4 + j;
-            s[fj][j] = key < Tn ? acc[j] * scale2 : -INFINITY;
-            tmax = fmaxf(tmax, s[fj][j]);
-          }
-        } else {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            s[fj][j] = acc[j] * scale2;
-            tmax = fmaxf(tmax, s[fj][j]);
+            for (int j = 0; j < 4; ++j) {
+              float v = acc[j] * scale2;
+              if constexpr (!FULL) v = (t * AT_TILE + fj * 16 + g * 4 + j < Tn) ? v : -INFINITY;
+              s[fj][j] = v;
+              tmax = fmaxf(tmax, v);
+            }
           }
         }
-      }
-    }
-    tmax = quad_max(tmax);
-    const float mn = fmaxf(m, tmax);                  // finite: every tile holds at least one valid key
-    const float alpha = __builtin_amdgcn_exp2f(m - mn);   // first tile: 2^(-inf) = 0
-    m = mn;
-    float psum = 0.f;
+        tmax = quad_max(tmax);
+        const float mn = fmaxf(m, tmax);                  // finite: every tile holds at least one valid key
+        const float alpha = __builtin_amdgcn_exp2f(m - mn);   // first tile: 2^(-inf) = 0
+        m = mn;
+        float psum = 0.f;
 #pragma unroll
-    for (int fj = 0; fj < 4; ++fj) {
-      if (fj < nfj) {
-        float ms[4] = {1.f, 1.f, 1.f, 1.f};
-        if (dp > 0.f) attn_drop4_keys(seed, bh, q, t * AT_TILE + fj * 16 + g * 4, Tn, dp, inv_keep, ms);
+        for (int fj = 0; fj < 4; ++fj) {
+          if (FULL || fj < nfj) {
+            float ms[4];
+            if constexpr (DROP) attn_drop4_keys(rkey, thr, row0, t * AT_TILE + fj * 16, inv_keep, ms);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float p = __builtin_amdgcn_exp2f(s[fj][j] - mn);
-          psum += p;                                  // the normaliser sums the probabilities BEFORE dropout
-          s[fj][j] = p * ms[j];
+            for (int j = 0; j < 4; ++j) {
+              const float p = __builtin_amdgcn_exp2f(s[fj][j] - mn);
+              psum += p;                                  // the normaliser sums the probabilities BEFORE dropout
+              s[fj][j] = DROP ? p * ms[j] : p;
+            }
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s[fj][j] = 0.f;
+          }
         }
+        l = l * alpha + quad_sum(psum);
+#pragma unroll
+        for (int df = 0; df < 4; ++df) o[df] *= alpha;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+          if (FULL || 2 * kb < nfj) {
+            const frag8_t pf = pack_frag<TE>(s[2 * kb], s[2 * kb + 1]);
+#pragma unroll
+            for (int df = 0; df < 4; ++df) o[df] = mfma16<TE>(lds_frag_tr(Vs[cur], troff, df, kb), pf, o[df]);
+          }
+        }
+      };
+      const bool full = (t + 1) * AT_TILE <= Tn;
+      if (dp > 0.f) {
+        if (full) body(std::true_type{}, std::true_type{}); else body(std::false_type{}, std::true_type{});
       } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) s[fj][j] = 0.f;
+        if (full) body(std::true_type{}, std::false_type{}); else body(std::false_type{}, std::false_type{});
       }
-    }
-    l = l * alpha + quad_sum(psum);
-#pragma unroll
-    for (int df = 0; df < 4; ++df) o[df] *= alpha;
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-      if (2 * kb < nfj) {
-        const frag8_t pf = pack_frag<TE>(s[2 * kb], s[2 * kb + 1]);
-#pragma unroll
-        for (int df = 0; df < 4; ++df) o[df] = mfma16<TE>(lds_frag_tr(Vs[cur], troff, df, kb), pf, o[df]);
-      }
-    }
     }   // active
     if (t + 1 < ntile) {
       tile_store(rk, Ks[cur ^ 1]);                    // last read in iteration t-1, behind that iteration's barrier
@@ -357,6 +378,9 @@ __global__ __launch_bounds__(256, 4) void attn_bwd_dq_tiled_kernel(const bf16_t*
   // P = exp(s * scale - lse) = 2^(s * scale2 - l2).  Rows beyond T need no mask: their q, dO are zero, so p = 1 and
   // dS = p * (0 - 0) = 0.  Keys beyond T (last tile only, uniform branch) keep theirs: p = exp(-lse) is unbounded
   // there and would meet a zero K row as inf * 0 after the 16-bit pack.
+  const uint32_t thr = drop_thr16(dp);
+  const uint32_t rkey = rng_key(seed);
+  const uint64_t row0 = attn_row_pair0(bh, q, Tn) + (uint64_t)(g * 2);     // + the lane's 4 keys of a 16-key block
   const float l2 = q < Tn ? lse[bh * Tn + q] * 1.4426950408889634f : 0.f;
   const float scale2 = scale * 1.4426950408889634f;
   const TrOff troff = tr_offsets(lane);
@@ -396,7 +420,7 @@ __global__ __launch_bounds__(256, 4) void attn_bwd_dq_tiled_kernel(const bf16_t*
           }
           const int key0 = t * AT_TILE + fj * 16 + g * 4;
           float ms[4] = {1.f, 1.f, 1.f, 1.f};
-          if (dp > 0.f) attn_drop4_keys(seed, bh, q, key0, Tn, dp, inv_keep, ms);
+          if (dp > 0.f) attn_drop4_keys(rkey, thr, row0, t * AT_TILE + fj * 16, inv_keep, ms);
           if ((t + 1) * AT_TILE > Tn) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
