@@ -1,11 +1,12 @@
 // norm.hip -- LayerNorm(+residual +dropout) forward / backward (HF:429, HF:596-601, HF:691-692).
 // One 64-lane wave per token row, 16-byte vector accesses, wave-shuffle reductions; statistics f32.
 #include "common.h"
+#include <stdlib.h>
 
 constexpr int LN_MAXC = 2;  // vec8 chunks per lane: H <= 1024
-// workgroups of the backward (= rows of the gamma/beta partial buffer): four 4-wave workgroups per CU; the kernel is
-// held to 128 VGPRs so that all of them are resident
-constexpr int LN_BWD_BLOCKS = 1024;
+// workgroups of the backward (= rows of the gamma/beta partial buffer): three 4-wave workgroups per CU -- the 16-bit
+// kernel holds two packed rows (current + prefetched) in 151 VGPRs
+constexpr int LN_BWD_BLOCKS = 768;
 
 template <typename T>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, T* __restrict__ r,
@@ -181,6 +182,135 @@ __global__ __launch_bounds__(256, 4) void ln_bwd_kernel(const T* __restrict__ dy
   }
 }
 
+// 16-bit activations: same arithmetic and the same per-block partial layout as ln_bwd_kernel, with the NEXT row's
+// dy / s (and its mean / rstd) requested before the current row's two wave reductions: a wave walks only 2-3 rows at
+// M = 9834, so without the prefetch every row is one exposed HBM round trip.  Both rows stay PACKED (4 VGPRs per
+// 16-byte chunk); dy * gamma is recomputed in the second pass instead of kept (16 VGPRs).
+template <typename T>
+__global__ __launch_bounds__(256, 3) void ln_bwd16_kernel(const T* __restrict__ dy, const T* __restrict__ s,
+                                                       const float* __restrict__ mean,
+                                                       const float* __restrict__ rstd,
+                                                       const float* __restrict__ gamma, T* __restrict__ ds,
+                                                       T* __restrict__ d_r, float* __restrict__ dgamma,
+                                                       float* __restrict__ dbeta, float* __restrict__ partial,
+                                                       int M, int H, float p, uint64_t seed) {
+  static_assert(sizeof(T) == 2, "16-bit activations only");
+  __shared__ float red[4][LN_MAXC * 64 * 8];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nch = H >> 3;
+  const float inv_keep = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
+  float ag[LN_MAXC][8] = {}, ab[LN_MAXC][8] = {};
+  float gm[LN_MAXC][8];
+  bool have[LN_MAXC];
+#pragma unroll
+  for (int ci = 0; ci < LN_MAXC; ++ci) {
+    have[ci] = lane + 64 * ci < nch;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) gm[ci][e] = 0.f;
+    if (have[ci]) {
+      Vec8<float> g;
+      g.load(gamma + (lane + 64 * ci) * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) gm[ci][e] = g.v[e];
+    }
+  }
+  const int stride = gridDim.x * 4;
+  int row = blockIdx.x * 4 + wave;
+  uint4 rdy[LN_MAXC], rs_[LN_MAXC], ndy[LN_MAXC], ns[LN_MAXC];
+  float mu = 0.f, rs = 0.f, nmu = 0.f, nrs = 0.f;
+  auto fetch = [&](int r, uint4 (&a)[LN_MAXC], uint4 (&b)[LN_MAXC], float& m_, float& r_) {
+    m_ = mean[r];
+    r_ = rstd[r];
+#pragma unroll
+    for (int ci = 0; ci < LN_MAXC; ++ci) {
+      a[ci] = uint4{0u, 0u, 0u, 0u};
+      b[ci] = uint4{0u, 0u, 0u, 0u};
+      if (have[ci]) {
+        const int64_t off = (int64_t)r * H + (lane + 64 * ci) * 8;
+        a[ci] = *reinterpret_cast<const uint4*>(dy + off);
+        b[ci] = *reinterpret_cast<const uint4*>(s + off);
+      }
+    }
+  };
+  auto word = [](const uint4& v, int i) -> uint32_t { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; };
+  if (row < M) fetch(row, rdy, rs_, mu, rs);
+  for (; row < M; row += stride) {
+    const int nrow = row + stride;
+    if (nrow < M) fetch(nrow, ndy, ns, nmu, nrs);
+    float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+    for (int ci = 0; ci < LN_MAXC; ++ci)
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        float d0, d1, x0, x1;
+        unpack2<T>(word(rdy[ci], w), d0, d1);
+        unpack2<T>(word(rs_[ci], w), x0, x1);
+        x0 = (x0 - mu) * rs;
+        x1 = (x1 - mu) * rs;
+        const float g0 = d0 * gm[ci][2 * w], g1 = d1 * gm[ci][2 * w + 1];
+        c1 += g0;
+        c2 += g0 * x0;
+        c1 += g1;
+        c2 += g1 * x1;
+        ag[ci][2 * w] += d0 * x0;
+        ag[ci][2 * w + 1] += d1 * x1;
+        ab[ci][2 * w] += d0;
+        ab[ci][2 * w + 1] += d1;
+      }
+    // (chunks a lane does not own hold dy = 0: they add nothing above; their x-hat is finite garbage times 0)
+    c1 = wave_sum(c1) / (float)H;
+    c2 = wave_sum(c2) / (float)H;
+#pragma unroll
+    for (int ci = 0; ci < LN_MAXC; ++ci) {
+      if (have[ci]) {
+        const int64_t off = (int64_t)row * H + (lane + 64 * ci) * 8;
+        uint32_t ow[4], ow2[4];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          float d0, d1, x0, x1;
+          unpack2<T>(word(rdy[ci], w), d0, d1);
+          unpack2<T>(word(rs_[ci], w), x0, x1);
+          x0 = (x0 - mu) * rs;
+          x1 = (x1 - mu) * rs;
+          const float o0 = rs * (d0 * gm[ci][2 * w] - c1 - x0 * c2);
+          const float o1 = rs * (d1 * gm[ci][2 * w + 1] - c1 - x1 * c2);
+          ow[w] = pack2<T>(o0, o1);
+          if (d_r != nullptr) {
+            float s0 = 1.f, s1 = 1.f;
+            if (p > 0.f) drop_scale2(seed, (uint64_t)(off + 2 * w), p, inv_keep, s0, s1);
+            ow2[w] = pack2<T>(o0 * s0, o1 * s1);
+          }
+        }
+        store16_wt(ds + off, uint4{ow[0], ow[1], ow[2], ow[3]});
+        if (d_r != nullptr) store16_wt(d_r + off, uint4{ow2[0], ow2[1], ow2[2], ow2[3]});
+      }
+    }
+#pragma unroll
+    for (int ci = 0; ci < LN_MAXC; ++ci) { rdy[ci] = ndy[ci]; rs_[ci] = ns[ci]; }
+    mu = nmu;
+    rs = nrs;
+  }
+  if (dgamma == nullptr && partial == nullptr) return;
+  for (int pass = 0; pass < 2; ++pass) {
+    __syncthreads();
+#pragma unroll
+    for (int ci = 0; ci < LN_MAXC; ++ci)
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        red[wave][(ci * 64 + lane) * 8 + e] = pass == 0 ? ag[ci][e] : ab[ci][e];
+    __syncthreads();
+    for (int i = threadIdx.x; i < LN_MAXC * 64 * 8; i += 256) {
+      const int ci = i / 512, rem = i - ci * 512, ln = rem >> 3, e = rem & 7;
+      const int col = (ln + 64 * ci) * 8 + e;
+      if (col < H) {
+        const float v = red[0][i] + red[1][i] + red[2][i] + red[3][i];
+        if (partial != nullptr) partial[((int64_t)blockIdx.x * 2 + pass) * H + col] = v;   // folded by ln_bwd_finalize
+        else unsafeAtomicAdd((pass == 0 ? dgamma : dbeta) + col, v);
+      }
+    }
+  }
+}
+
 // fold the per-block column partials in a fixed order (deterministic) and add them to dgamma / dbeta:
 // 32 columns x 8 block lanes per workgroup, each lane sums every 8th block (independent loads, unrolled),
 // then a fixed-order LDS fold over the 8 lanes
@@ -281,10 +411,18 @@ extern "C" int w2v2_layernorm_bwd(const void* dy, const void* s, const float* me
   const int nb = (int)(cdiv(M, 4) < LN_BWD_BLOCKS ? cdiv(M, 4) : LN_BWD_BLOCKS);
   // dgamma == NULL with a workspace: leave the per-block partials in it for w2v2_layernorm_bwd_fold
   float* partial = workspace;
-  W2V2_DISPATCH_ACT(dtype, "layernorm_bwd",
-    hipLaunchKernelGGL(ln_bwd_kernel<AT>, dim3(nb), dim3(256), 0, as_stream(stream), (const AT*)dy,
-                       (const AT*)s, mean, rstd, gamma, (AT*)ds, (AT*)d_r, dgamma, dbeta, partial, M, H,
-                       drop_p, seed););
+  static const bool no_prefetch = getenv("W2V2_NO_LN_PREFETCH") != nullptr;       // A/B switch
+  if (dtype == W2V2_F32 || no_prefetch) {
+    W2V2_DISPATCH_ACT(dtype, "layernorm_bwd",
+      hipLaunchKernelGGL(ln_bwd_kernel<AT>, dim3(nb), dim3(256), 0, as_stream(stream), (const AT*)dy,
+                         (const AT*)s, mean, rstd, gamma, (AT*)ds, (AT*)d_r, dgamma, dbeta, partial, M, H,
+                         drop_p, seed););
+  } else {
+    W2V2_DISPATCH_16(dtype, "layernorm_bwd",
+      hipLaunchKernelGGL(ln_bwd16_kernel<AT>, dim3(nb), dim3(256), 0, as_stream(stream), (const AT*)dy,
+                         (const AT*)s, mean, rstd, gamma, (AT*)ds, (AT*)d_r, dgamma, dbeta, partial, M, H,
+                         drop_p, seed););
+  }
   if (partial != nullptr && dgamma != nullptr)
     hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3((unsigned)cdiv(2 * H, 32)), dim3(256), 0, as_stream(stream),
                        partial, dgamma, dbeta, nb, H);
