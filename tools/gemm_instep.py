@@ -24,7 +24,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 EPI = {0: "none", 1: "bias", 2: "bias+gelu", 3: "gelu'", 4: "add", 5: "scale_rc", 6: "bias+gelu+g'", 7: "mul"}
-PAT = re.compile(r"gemm16_|gemm_f32|wgrad_grouped")
+PAT = re.compile(r"gemm16_|gemm_f32|wgrad_grouped|posconv_direct")
 
 
 def run(seq_path, steps=6, warmup=3, dtype="f16"):
@@ -75,6 +75,8 @@ def join(seq_path, db_path, out=None):
             key = (k["M"], k["N"], k["K"], EPI[k["epi"]] + ("+aux" if k["aux"] and k["epi"] == 2 else "")
                    + ("+2term" if k["two_term"] else ""), k["kernel"].replace("_kernel", "").replace("gemm16_", "")
                    + (f" x{k['batch']}" if k["batch"] > 1 else ""))
+        elif k["kind"] == "posconv":
+            key = (k["M"], k["N"], k["K"], "bias+gelu+aux" if k["mode"] == 0 else "add", "posconv_direct x16")
         else:
             key = (k["tokens"], k["problems"], 0, "dW+db", k["kernel"].replace("_kernel", "").replace("wgrad_grouped_", "wgrad_"))
         a = agg.setdefault(key, {"n": 0, "ns": 0, "min": 1 << 62, "max": 0, "flops": 0.0, "alg": 0.0})
