@@ -49,12 +49,13 @@ __device__ __forceinline__ void attn_drop4_keys(uint32_t k, uint32_t thr, uint64
 }
 // keep-scales of key column `key` (parity == lane parity) for 4 consecutive query rows q0 .. q0+3: the two lanes
 // of a key pair hash two rows each and swap (one hash serves keys 2j and 2j+1 of a row)
-__device__ __forceinline__ void attn_drop4_rows(uint64_t seed, int64_t bh, int q0, int key, int Tn, float dp,
+// col0 = pair index of (query row 0 of this (utterance, head), this lane's key) = attn_drop_idx(bh, 0, key, Tn) >> 1, a
+// per-lane constant; a row adds q * Tp2 (Tp2 = padded row length / 2: 24-bit operands, full-rate multiply)
+__device__ __forceinline__ void attn_drop4_rows(uint32_t k, uint32_t thr, uint64_t col0, uint32_t Tp2, int q0, int odd,
                                                 float inv_keep, float (&ms)[4]) {
-  const uint32_t k = rng_key(seed), thr = drop_thr16(dp);
-  const int odd = key & 1;
-  const uint32_t h0 = rng_pair(k, attn_drop_idx(bh, q0 + 2 * odd, key, Tn) >> 1);
-  const uint32_t h1 = rng_pair(k, attn_drop_idx(bh, q0 + 2 * odd + 1, key, Tn) >> 1);
+  const uint32_t qa = (uint32_t)(q0 + 2 * odd);
+  const uint32_t h0 = rng_pair(k, col0 + (uint64_t)__umul24(qa, Tp2));
+  const uint32_t h1 = rng_pair(k, col0 + (uint64_t)__umul24(qa + 1u, Tp2));
   const uint32_t p0 = __shfl_xor(h0, 1, 64), p1 = __shfl_xor(h1, 1, 64);
   const uint32_t r0 = odd ? p0 : h0, r1 = odd ? p1 : h1, r2 = odd ? h0 : p0, r3 = odd ? h1 : p1;
   const int sh = odd * 16;
@@ -485,7 +486,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_kv_tiled_kernel(const bf16_t*
   auto row_load = [&](int t) {
     if (threadIdx.x < AT_TILE) {
       const int r = t * AT_TILE + threadIdx.x;
-      rl = r < Tn ? lse[bh * Tn + r] : 0.f;
+      rl = r < Tn ? lse[bh * Tn + r] * 1.4426950408889634f : 0.f;
       rd = r < Tn ? delta[bh * Tn + r] : 0.f;
     }
   };
@@ -503,6 +504,10 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_kv_tiled_kernel(const bf16_t*
 #pragma unroll
   for (int df = 0; df < 4; ++df) { dv[df] = f32x4{0.f, 0.f, 0.f, 0.f}; dk[df] = f32x4{0.f, 0.f, 0.f, 0.f}; }
   const bool active = row_tile * 64 + wave * 16 < Tn;
+  const uint32_t rkey = rng_key(seed), thr = drop_thr16(dp);
+  const uint64_t col0 = attn_drop_idx(bh, 0, key, Tn) >> 1;
+  const uint32_t Tp2 = (uint32_t)(((Tn + 1) & ~1) >> 1);
+  const float scale2 = scale * 1.4426950408889634f;
 #pragma unroll 1
   for (int t = 0; t < ntile; ++t) {
     const int cur = t & 1;
@@ -532,12 +537,12 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_kv_tiled_kernel(const bf16_t*
           const float la[4] = {l4.x, l4.y, l4.z, l4.w}, da[4] = {d4.x, d4.y, d4.z, d4.w};
           const int q0 = t * AT_TILE + fq * 16 + g * 4;
           float ms[4] = {1.f, 1.f, 1.f, 1.f};
-          if (dp > 0.f) attn_drop4_rows(seed, bh, q0, key, Tn, dp, inv_keep, ms);
-          // (this kernel sits at its register limit -- 168 for three workgroups per CU: the log2-domain / unmasked form
-          // of the other two kernels spills 10 registers here, and scratch costs more than the three instructions)
+          if (dp > 0.f) attn_drop4_rows(rkey, thr, col0, Tp2, q0, key & 1, inv_keep, ms);
+          // log2 domain (lse_s holds lse * log2 e).  Query rows beyond T need no mask (their q and dO rows are zero: p = 1
+          // meets dO = 0 and dP - delta = 0); key columns beyond T keep theirs (p = 2^-lse is unbounded there)
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            const float p = (q0 + j < Tn && key < Tn) ? __expf(sa[j] * scale - la[j]) : 0.f;
+            const float p = key < Tn ? __builtin_amdgcn_exp2f(fmaf(sa[j], scale2, -la[j])) : 0.f;
             pt2[hf][j] = p * ms[j];
             ds2[hf][j] = p * (pa[j] * ms[j] - da[j]) * scale;
           }
