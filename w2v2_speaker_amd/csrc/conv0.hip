@@ -4,6 +4,8 @@
 //   pass 1 (stats): conv, per-block partial sum / sum-of-squares per (b, chunk, c), then a tiny
 //                   finalize kernel folds the partials in a FIXED order (f64) -> {mean, rstd}:
 //                   bitwise deterministic and independent of the batch an utterance sits in.
+//                   (16-bit activations, k = 10: no convolution at all -- window moments of the waveform,
+//                   see conv0_gram_kernel below.)
 //   pass 2 (apply): conv again (10 MAC per output, cheaper than a 9.8 MB/utt round trip),
 //                   normalise, GELU, store channels-last in the activation dtype.
 // HBM-bound: algorithmic bytes/utt = 2 x 192 KB waveform reads + L*C*sizeof(T) output (9.83 MB bf16).
@@ -247,6 +249,88 @@ __global__ __launch_bounds__(256, 2) void conv0_mfma_kernel(const float* __restr
 static const bool g_conv0_mfma = getenv("W2V2_CONV0_VALU") == nullptr;     // A/B switch
 static bool conv0_mfma_ok(int C, int k) { return C % 128 == 0 && 3 * k <= 32 && g_conv0_mfma; }
 
+// ------------------------------------------------------------------------------ statistics without the convolution
+// The convolution is linear in the waveform, so the per-(utterance, channel) statistics GroupNorm needs are quadratic
+// forms of TEN-sample window moments that do not depend on the channel:
+//     sum_t y[t,c]   = sum_j w[c,j] S[j],                 S[j]     = sum_t x[t*stride + j]
+//     sum_t y[t,c]^2 = sum_j sum_j' w[c,j] w[c,j'] R[j,j'],   R[j,j'] = sum_t x[t*stride + j] x[t*stride + j']
+// 65 numbers per utterance (k = 10) instead of a [L, C] convolution (5120 MACs per frame -> 55): the statistics
+// pass drops from 100 us to a few.  Products of two f32 are exact in f64 and everything is accumulated in f64 in a fixed
+// order (per thread over its frames, the 64 lanes in lane order, blocks in order): deterministic, independent of the
+// batch, and more accurate than summing the split-bf16 convolution itself.
+template <int K>
+__global__ __launch_bounds__(64) void conv0_gram_kernel(const float* __restrict__ wav, double* __restrict__ partial,
+                                                        int N, int L, int stride, int fpb) {
+  constexpr int NR = K * (K + 1) / 2, NV = K + NR;
+  extern __shared__ float xs[];                      // the block's samples: (fpb - 1) * stride + K floats
+  __shared__ double red[NV][65];                     // (pitch 65: the fold below reads a row per lane)
+  const int b = blockIdx.y;
+  const int f0 = blockIdx.x * fpb;                   // frames [f0, f0 + nf) of utterance b; one wave per block
+  const int nf = min(fpb, L - f0);
+  const float* src = wav + (int64_t)b * N + (int64_t)f0 * stride;
+  const int nsamp = nf > 0 ? (nf - 1) * stride + K : 0;
+  for (int i = threadIdx.x; i < nsamp; i += 64) xs[i] = src[i];
+  __syncthreads();
+  double acc[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) acc[i] = 0.0;
+  for (int f = threadIdx.x; f < nf; f += 64) {       // lanes `stride` floats apart: conflict-free LDS reads for odd strides
+    float x[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) x[j] = xs[f * stride + j];
+    int idx = K;
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      acc[j] += (double)x[j];
+#pragma unroll
+      for (int j2 = j; j2 < K; ++j2) acc[idx++] += (double)x[j] * (double)x[j2];
+    }
+  }
+  // fold over the 64 lanes in lane order through LDS (a shuffle tree costs 2 x 6 ds_bpermute per value: 780 per wave)
+#pragma unroll
+  for (int i = 0; i < NV; ++i) red[i][threadIdx.x] = acc[i];
+  __syncthreads();
+  for (int i = threadIdx.x; i < NV; i += 64) {
+    double v = 0.0;
+    for (int j = 0; j < 64; ++j) v += red[i][j];
+    partial[((int64_t)b * gridDim.x + blockIdx.x) * NV + i] = v;
+  }
+}
+
+template <int K>
+__global__ __launch_bounds__(256) void conv0_gram_finalize_kernel(const double* __restrict__ partial,
+                                                                  const float* __restrict__ w, float* __restrict__ mr,
+                                                                  int C, int nblk, int L, float eps) {
+  constexpr int NR = K * (K + 1) / 2, NV = K + NR;
+  __shared__ double G[NV];
+  const int b = blockIdx.x;
+  if (threadIdx.x < NV) {
+    double v = 0.0;
+    for (int j = 0; j < nblk; ++j) v += partial[((int64_t)b * nblk + j) * NV + threadIdx.x];
+    G[threadIdx.x] = v;
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    double wr[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) wr[j] = (double)w[c * K + j];
+    double s1 = 0.0, s2 = 0.0;
+    int idx = K;
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      s1 += wr[j] * G[j];
+#pragma unroll
+      for (int j2 = j; j2 < K; ++j2) s2 += (j2 == j ? 1.0 : 2.0) * wr[j] * wr[j2] * G[idx++];
+    }
+    const double mu = s1 / (double)L;
+    const double var = s2 / (double)L - mu * mu;
+    mr[((int64_t)b * C + c) * 2] = (float)mu;
+    mr[((int64_t)b * C + c) * 2 + 1] = (float)(1.0 / sqrt((var > 0.0 ? var : 0.0) + (double)eps));
+  }
+}
+constexpr int C0_GRAM_FRAMES = 640;     // frames per workgroup of the window-moment kernel
+
+extern "C" int w2v2_conv0_workspace_floats(int N, int C, int k, int stride);
 static int conv0_check(const char* nm, int B, int N, int C, int k, int stride) {
   W2V2_REQUIRE(B > 0 && C > 0 && k > 0 && k <= C0_MAXK && stride > 0 && N >= k,
                "%s: bad shape B=%d N=%d C=%d k=%d stride=%d", nm, B, N, C, k, stride);
@@ -278,6 +362,21 @@ extern "C" int w2v2_conv0_stats_mfma(const float* wav, const float* w, float* pa
   if (conv0_check("conv0_stats_mfma", B, N, C, k, stride)) return -1;
   W2V2_REQUIRE(wav && w && partial && mean_rstd, "conv0_stats_mfma: null pointer");
   const int L = (N - k) / stride + 1;
+  static const bool no_gram = getenv("W2V2_CONV0_NO_GRAM") != nullptr;        // A/B switch
+  if (k == 10 && !no_gram) {
+    // statistics from the window moments of the waveform (see conv0_gram_kernel); the workspace (>= 8 floats per frame)
+    // holds the f64 partials: 130 floats per block of C0_GRAM_FRAMES frames
+    const int nblk = (int)cdiv(L, C0_GRAM_FRAMES);
+    double* gp = reinterpret_cast<double*>(partial);
+    const size_t lds = ((size_t)(C0_GRAM_FRAMES - 1) * stride + 10) * sizeof(float);
+    W2V2_REQUIRE(lds <= 64 * 1024, "conv0_stats_mfma: stride %d too large for the window-moment kernel", stride);
+    hipLaunchKernelGGL((conv0_gram_kernel<10>), dim3((unsigned)nblk, B), dim3(64), lds, as_stream(stream), wav, gp, N, L,
+                       stride, C0_GRAM_FRAMES);
+    hipLaunchKernelGGL((conv0_gram_finalize_kernel<10>), dim3(B), dim3(256), 0, as_stream(stream), (const double*)gp, w,
+                       mean_rstd, C, nblk, L, eps);
+    W2V2_CHECK_LAUNCH("conv0_stats_mfma");
+    return 0;
+  }
   const int nchunk = (int)cdiv(cdiv(L, C0_FRAMES), C0_CPB);      // one partial per workgroup (C0_CPB chunks)
   dim3 grid((unsigned)nchunk, B);
   const size_t lds2 = (2 * ((size_t)(C0_FRAMES - 1) * stride + k) + 8) * sizeof(bf16_t);

@@ -247,7 +247,7 @@ def conv0_groupnorm_gelu(wav: torch.Tensor, w: torch.Tensor, gamma: torch.Tensor
     Cc = w.shape[0]
     mr = work[work.numel() - B * Cc * 2:]
     L = lib()
-    # bf16 activations: conv on the matrix cores (split-bf16, ~2^-16), statistics from the same arithmetic
+    # 16-bit activations: conv on the matrix cores (split-bf16, ~2^-16); statistics from the waveform's window moments
     stats = L.w2v2_conv0_stats_mfma if is16(out.dtype) else L.w2v2_conv0_stats
     _lib.check(stats(wav.data_ptr(), w.data_ptr(), work.data_ptr(), mr.data_ptr(), B, N, Cc, k, stride,
                      eps, stream()), "conv0_stats")
