@@ -358,7 +358,7 @@ def run(args):
                 out["roofline_second_kernel"] = entry(*ranked[1])
         if world == 1 and args.dtype == "f16" and args.model == "base" and not args.no_also:
             # Short legs of the same engine on the other BASELINE configurations, so that the driver's line carries them
-            # (5 timed steps each after 2 warm-up steps; `value` above is untouched by them):
+            # (10 timed steps each after the headline's warm-up count; `value` above is untouched by them):
             #   bf16          configs[1] says "bf16"; the headline is fp16 because only fp16 operands keep the embedding
             #                 within the 1e-3 rel-L2 target (tests/test_parity_gpu.py; profiles/r04_parity.json)
             #   attentive_b66 configs[2]: w2v2-base + attentive statistics pooling, the per-GPU share of the DDP job
@@ -376,17 +376,22 @@ def run(args):
                 pl2 = Plan(st2, batch, ns, train=True, reg=reg, seed=7, pooling=pooling)
                 tr2 = SpeakerTrainer(st2, pl2, OneCycle(max_lr=5e-5, total_steps=40), layerdrop_seed=1234, mask_seed=7)
                 w2, l2 = synth_batch(batch, ns, args.speakers, seed=42133724, device=dev)
-                for _ in range(2):
+                # (LayerDrop draws decide how many layers a step runs: few steps = a noisy figure -- the leg reports the
+                # layers it skipped, and runs the warm-up draws of the headline run first so both see the same sequence)
+                for _ in range(args.warmup):
                     tr2.train_step(w2, l2)
                 torch.cuda.synchronize()
+                nst, nskip = 10, 0
                 t1 = time.perf_counter()
-                for _ in range(5):
+                for _ in range(nst):
                     ls, _ = tr2.train_step(w2, l2)
+                    nskip += len(pl2._skip)
                 torch.cuda.synchronize()
-                dt2 = (time.perf_counter() - t1) / 5
+                dt2 = (time.perf_counter() - t1) / nst
                 fl2 = c.flops_per_utt(ns, args.speakers)["train_frozen_cnn"]
                 res = {"ms_per_step": round(1e3 * dt2, 3), "value": round(batch / dt2, 2), "unit": "utterances/sec",
-                       "steps": 5, "warmup": 2, "model_tflops": round(fl2 * batch / dt2 / 1e12, 1),
+                       "steps": nst, "warmup": args.warmup, "layerdrop_skipped_layers_per_step": round(nskip / nst, 2),
+                       "model_tflops": round(fl2 * batch / dt2 / 1e12, 1),
                        "final_loss": round(float(ls), 4),
                        "workload": f"wav2vec2-{model} + AAM-softmax({args.speakers}), {pooling} pooling, {seconds:g} s "
                                    f"synthetic audio, bs={batch}, {str(adt).split('.')[-1]}, fwd+bwd+Adam -- {note}"}
