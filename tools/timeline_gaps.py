@@ -19,3 +19,27 @@ print(f"step: {len(step)} launches, wall {(t1 - t0) / 1e3:.1f} us, kernels {busy
 print(f"gaps: mean {sum(g for g, _, _ in gaps) / len(gaps) / 1e3:.2f} us; > 5 us: {sum(1 for g, _, _ in gaps if g > 5000)}")
 for g, p, q in sorted(gaps, reverse=True)[:12]:
     print(f"  {g / 1e3:7.1f} us  after {p}  before {q}")
+
+# mean gap by the kernel that precedes it (which kernels leave the chip idle behind them)
+import re
+by = {}
+for g, p, q in gaps:
+    k = re.sub(r"^_Z\d+|I[Dt].*|<.*|\(.*", "", p)
+    d = by.setdefault(k, [0, 0])
+    d[0] += g; d[1] += 1
+print("mean gap BEHIND a kernel (us), count, total (us):")
+for k, (t, n) in sorted(by.items(), key=lambda kv: -kv[1][0])[:14]:
+    print(f"  {k[:44]:44s} {t / n / 1e3:6.2f} {n:4d} {t / 1e3:8.1f}")
+
+bq, pairs = {}, {}
+for g, p, q in gaps:
+    kp = re.sub(r"^_Z\d+|I[Dt].*|<.*|\(.*", "", p)[:28]
+    kq = re.sub(r"^_Z\d+|I[Dt].*|<.*|\(.*", "", q)[:28]
+    d = bq.setdefault(kq, [0, 0]); d[0] += g; d[1] += 1
+    d = pairs.setdefault((kp, kq), [0, 0]); d[0] += g; d[1] += 1
+print("mean gap IN FRONT OF a kernel (us), count, total (us):")
+for k, (t, n) in sorted(bq.items(), key=lambda kv: -kv[1][0])[:12]:
+    print(f"  {k:44s} {t / n / 1e3:6.2f} {n:4d} {t / 1e3:8.1f}")
+print("by (previous, next) pair:")
+for (kp, kq), (t, n) in sorted(pairs.items(), key=lambda kv: -kv[1][0])[:24]:
+    print(f"  {kp:28s} -> {kq:28s} {t / n / 1e3:6.2f} {n:4d} {t / 1e3:8.1f}")

@@ -133,14 +133,25 @@ __device__ __forceinline__ float quad_sum(float v) {
   return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
 
+// One output row (64 columns) is held by the four lanes g = 0..3 of a row: lane g has columns df * 16 + g * 4 .. + 3 of
+// each 16-column block df -- four 8-byte pieces.  Lanes g and g ^ 1 exchange one piece per block pair
+// (v_permlane16_swap: odd 16-lane rows of the first operand <-> even rows of the second): the even lane then owns columns
+// g * 4 .. + 7 of block 2p, the odd lane columns (g - 1) * 4 .. + 7 of block 2p + 1 -- two 16-byte write-through stores
+// per lane instead of four 8-byte write-back ones.  (A kernel that leaves tens of MB of dirty lines in L2 pays ~2.4 us of
+// write-back at its end, tools/probes/launch_gap_probe.hip; narrower sc1 stores are one fabric write each.)
+// Every lane must call this (the swap is a cross-lane operation); `valid` guards the stores.
 template <typename TE>
-__device__ __forceinline__ void store_row4x4(bf16_t* dst, const f32x4 (&o)[4]) {
+__device__ __forceinline__ void store_row4x4(bf16_t* row, int g, bool valid, const f32x4 (&o)[4]) {
+  const bool odd = (g & 1) != 0;
 #pragma unroll
-  for (int df = 0; df < 4; ++df) {
-    uint2 w;
-    w.x = pack2<TE>(o[df][0], o[df][1]);
-    w.y = pack2<TE>(o[df][2], o[df][3]);
-    *reinterpret_cast<uint2*>(dst + df * 16) = w;
+  for (int p = 0; p < 2; ++p) {
+    const uint32_t ax = pack2<TE>(o[2 * p][0], o[2 * p][1]), ay = pack2<TE>(o[2 * p][2], o[2 * p][3]);
+    const uint32_t bx = pack2<TE>(o[2 * p + 1][0], o[2 * p + 1][1]), by = pack2<TE>(o[2 * p + 1][2], o[2 * p + 1][3]);
+    const auto sx = __builtin_amdgcn_permlane16_swap(ax, bx, false, false);
+    const auto sy = __builtin_amdgcn_permlane16_swap(ay, by, false, false);
+    // even lane: {own A, partner's A} = block 2p, 8 columns from g * 4; odd lane: {partner's B, own B} = block 2p + 1
+    const uint4 w = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+    if (valid) store16_wt(row + (2 * p + (odd ? 1 : 0)) * 16 + (g & 2) * 4, w);
   }
 }
 
@@ -336,13 +347,11 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_tiled_kernel(const bf16_t* __
     }
     __syncthreads();
   }
-  if (q < Tn) {
-    const float inv = 1.0f / l;
+  const float inv = q < Tn ? 1.0f / l : 0.f;
 #pragma unroll
-    for (int df = 0; df < 4; ++df) o[df] *= inv;
-    store_row4x4<TE>(ctx + ((int64_t)b * Tn + q) * H + h * HD + g * 4, o);
-    if (g == 0) lse[bh * Tn + q] = m * 0.6931471805599453f + __logf(l);
-  }
+  for (int df = 0; df < 4; ++df) o[df] *= inv;
+  store_row4x4<TE>(ctx + ((int64_t)b * Tn + q) * H + h * HD, g, q < Tn, o);
+  if (q < Tn && g == 0) lse[bh * Tn + q] = m * 0.6931471805599453f + __logf(l);
 }
 
 // dQ (and delta[q] = sum_d dO O) for 64 queries per workgroup, streaming key tiles
@@ -451,7 +460,7 @@ __global__ __launch_bounds__(256, 4) void attn_bwd_dq_tiled_kernel(const bf16_t*
     }
     __syncthreads();
   }
-  if (q < Tn) store_row4x4<TE>(dqkv + ((int64_t)b * Tn + q) * gs + h * HD + g * 4, o);
+  store_row4x4<TE>(dqkv + ((int64_t)b * Tn + q) * gs + h * HD, g, q < Tn, o);
 }
 
 // dK, dV for 64 keys per workgroup, streaming query tiles (Q, dO, LSE, delta)
@@ -567,11 +576,9 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_kv_tiled_kernel(const bf16_t*
     }
     __syncthreads();
   }
-  if (key < Tn) {
-    bf16_t* dstk = dqkv + ((int64_t)b * Tn + key) * gs + H + h * HD + g * 4;
-    store_row4x4<TE>(dstk, dk);
-    store_row4x4<TE>(dstk + H, dv);
-  }
+  bf16_t* dstk = dqkv + ((int64_t)b * Tn + key) * gs + H + h * HD;
+  store_row4x4<TE>(dstk, g, key < Tn, dk);
+  store_row4x4<TE>(dstk + H, g, key < Tn, dv);
 }
 
 // ------------------------------------------------------------------------------------- host
