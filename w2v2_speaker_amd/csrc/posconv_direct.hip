@@ -117,13 +117,17 @@ __global__ __launch_bounds__(256) void posconv_direct_kernel(const bf16_t* __res
     }
   }
 
-  // ---- epilogue: lane (fr, kg) holds channels 16 j + 4 kg .. + 3 of frame 16 (w + 4 i) + fr
+  // ---- epilogue: lane (fr, kg) holds channels 16 j + 4 kg .. + 3 of frame 16 (w + 4 i) + fr.  Lanes kg and kg ^ 1
+  // exchange one 8-byte piece per block pair (v_permlane16_swap, see attention.hip store_row4x4), so every store is a
+  // 16-byte write-through one: blocks 0 / 1 go to the even / odd lane, block 2 (its partner piece is a dummy) to the even one
+  const bool odd = (kg & 1) != 0;
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
-    if (i >= nmf) continue;
+    if (i >= nmf) continue;                          // (wave-uniform)
     const int t = t0 + (wave + 4 * i) * 16 + fr;
-    if (t >= Tn) continue;
-    const int64_t rowoff = ((int64_t)b * Tn + t) * ldc + g * PD_CG;
+    const bool valid = t < Tn;                       // (the same for the two lanes of a pair: it depends on fr only)
+    const int64_t rowoff = ((int64_t)b * Tn + (valid ? t : 0)) * ldc + g * PD_CG;
+    uint2 ow[3], pw[3];
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
       const int n = j * 16 + kg * 4;
@@ -135,12 +139,8 @@ __global__ __launch_bounds__(256) void posconv_direct_kernel(const bf16_t* __res
           pre[e] = v[e] + bias[g * PD_CG + n + e];
           v[e] = gelu_f(pre[e]);
         }
-        if (aux != nullptr) {
-          uint2 pw;
-          pw.x = pack2<TE>(pre[0], pre[1]);
-          pw.y = pack2<TE>(pre[2], pre[3]);
-          *reinterpret_cast<uint2*>(aux + rowoff + n) = pw;
-        }
+        pw[j].x = pack2<TE>(pre[0], pre[1]);
+        pw[j].y = pack2<TE>(pre[2], pre[3]);
       } else {
         const uint2 a2 = *reinterpret_cast<const uint2*>(aux + rowoff + n);
         float a0, a1, a2f, a3;
@@ -148,11 +148,23 @@ __global__ __launch_bounds__(256) void posconv_direct_kernel(const bf16_t* __res
         unpack2<TE>(a2.y, a2f, a3);
         v[0] += a0; v[1] += a1; v[2] += a2f; v[3] += a3;
       }
-      uint2 ow;
-      ow.x = pack2<TE>(v[0], v[1]);
-      ow.y = pack2<TE>(v[2], v[3]);
-      *reinterpret_cast<uint2*>(out + rowoff + n) = ow;
+      ow[j].x = pack2<TE>(v[0], v[1]);
+      ow[j].y = pack2<TE>(v[2], v[3]);
     }
+    auto store48 = [&](bf16_t* dst, const uint2 (&w)[3]) {
+      const auto sx = __builtin_amdgcn_permlane16_swap(w[0].x, w[1].x, false, false);
+      const auto sy = __builtin_amdgcn_permlane16_swap(w[0].y, w[1].y, false, false);
+      const auto tx = __builtin_amdgcn_permlane16_swap(w[2].x, 0u, false, false);
+      const auto ty = __builtin_amdgcn_permlane16_swap(w[2].y, 0u, false, false);
+      if (valid) {
+        store16_wt(dst + rowoff + (odd ? 16 : 0) + (kg & 2) * 4, make_uint4(sx[0], sy[0], sx[1], sy[1]));
+        if (!odd) store16_wt(dst + rowoff + 32 + (kg & 2) * 4, make_uint4(tx[0], ty[0], tx[1], ty[1]));
+      }
+    };
+    if constexpr (MODE == 0) {
+      if (aux != nullptr) store48(aux, pw);
+    }
+    store48(out, ow);
   }
 }
 
