@@ -14,8 +14,9 @@ WORLD_SIZE in the environment) or plainly as above, in which case this process s
 before it has touched a GPU itself -- and waits for them.  One rank per GPU over RCCL (torch.distributed "nccl").
 
 Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel of the step (largest total time among the
-MFMA GEMM kernels): algorithmic FLOPs of its launches divided by their HIP-event-measured durations inside the timed
-region; `traffic` / `mfma_busy` come from the committed rocprofv3 PMC passes of the same command under profiles/.
+MFMA GEMM kernels): algorithmic FLOPs of its launches divided by their durations inside the timed region, measured with
+HIP events that carry the dispatch's own begin / end timestamps (w2v2_gemm_timed -> hipExtLaunchKernelGGL: the duration
+rocprofv3 reports for the kernel); `traffic` / `mfma_busy` come from the committed rocprofv3 PMC passes of the same command under profiles/.
 `cpu_baseline` times the CPU oracle (oracle/w2v2_oracle.py, kind "port") on the host cores with the protocol of
 BASELINE.md section 3 (config 1: bs 8, CE head).
 """

@@ -104,6 +104,13 @@ typedef struct {
 } w2v2_gemm_desc;
 
 int w2v2_gemm(const w2v2_gemm_desc* d, void* stream);
+/* Measurement hook (bench.py `roofline`): the same launch, timed by the dispatch's own begin / end timestamps
+ * (hipExtLaunchKernelGGL with a start / stop event owned by the library, slot = index into its event pool) -- what
+ * rocprofv3 reports for the kernel, without the ~3 us of dispatch time that two hipEventRecord calls around a launch
+ * include.  Only products that run on the 256x128 ring or the phased 256x256 kernel (error otherwise).
+ * w2v2_timer_read waits for slots [first_slot, first_slot + n) and writes their durations in milliseconds. */
+int w2v2_gemm_timed(const w2v2_gemm_desc* d, void* stream, int slot);
+int w2v2_timer_read(int first_slot, int n, float* ms_out);
 /* Tuning hook (tools/gemm_shapes.py, not used by the training path): force the tile family of plain K-contiguous
  * 16-bit products -- 0 = the library's own dispatch, 1 = 128x128, 2 = 256x128 ring, 3 = 256x256x32 ring,
  * 4 = 256x256x64 phased.  Returns the previous setting. */

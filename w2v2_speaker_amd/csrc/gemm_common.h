@@ -7,6 +7,7 @@
 // (one file per kernel family keeps a rebuild after an edit to ~1 minute instead of four)
 #pragma once
 #include "common.h"
+#include <hip/hip_ext.h>
 #include <type_traits>
 #include <stdlib.h>
 
@@ -522,6 +523,21 @@ typedef __attribute__((address_space(1))) const void gvoid_t;
 typedef __attribute__((address_space(3))) void lvoid_t;
 
 // CUs the persistent grids may fill (W2V2_RESERVE_CUS keeps some out for RCCL's channels); gemm.hip
+// Kernel-timestamp timing of single launches (w2v2_gemm_timed): when a slot's events are pending, the launch helpers of
+// the two dominant kernels hand them to hipExtLaunchKernelGGL, which stamps the dispatch's own begin / end (what
+// rocprofv3 reports) instead of bracketing the launch with two stream events (+3 us of dispatch time per launch).
+struct W2v2PendingTimer { hipEvent_t start, stop; bool armed; };
+W2v2PendingTimer& w2v2_pending_timer();
+#define W2V2_LAUNCH_MAYBE_TIMED(KERNEL, GRID, BLOCK, LDS, STREAM, ARGS)                                         \
+  do {                                                                                                          \
+    W2v2PendingTimer& pt_ = w2v2_pending_timer();                                                               \
+    if (pt_.armed) {                                                                                            \
+      pt_.armed = false;                                                                                        \
+      hipExtLaunchKernelGGL(KERNEL, GRID, BLOCK, LDS, STREAM, pt_.start, pt_.stop, 0, ARGS);                    \
+    } else {                                                                                                    \
+      hipLaunchKernelGGL(KERNEL, GRID, BLOCK, LDS, STREAM, ARGS);                                               \
+    }                                                                                                           \
+  } while (0)
 int w2v2_gemm_device_cus();
 // cross-file launchers: dtype_ab / dtype_c are the W2V2_* codes (16-bit operands; C 16-bit of the same type or f32)
 void w2v2_launch_ring_256x128(const GemmArgs& a, int dtype_ab, int dtype_c, int M, int N, int batch, bool persistent,

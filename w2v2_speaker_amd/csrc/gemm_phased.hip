@@ -292,7 +292,7 @@ static void launch_ph(GemmArgs a, int M, int N, int batch, hipStream_t st) {
   const int tiles = a.tiles_m * a.tiles_n;
   const int ncu = w2v2_gemm_device_cus();
   dim3 grid(tiles < ncu ? tiles : ncu, 1, batch);
-  hipLaunchKernelGGL((gemm16_phased_256x256_kernel<TE, TC, DBG>), grid, dim3(512), lds, st, a);
+  W2V2_LAUNCH_MAYBE_TIMED((gemm16_phased_256x256_kernel<TE, TC, DBG>), grid, dim3(512), lds, st, a);
 }
 template <typename TE, typename TC>
 static void launch_ph_dbg(GemmArgs a, int M, int N, int batch, hipStream_t st) {

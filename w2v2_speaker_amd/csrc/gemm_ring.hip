@@ -261,7 +261,7 @@ static void launch_ring(GemmArgs a, int M, int N, int batch, bool persistent, hi
   const int ncu = persistent ? w2v2_gemm_device_cus() : (1 << 30);
   const int tiles = a.tiles_m * a.tiles_n;
   dim3 grid(tiles < ncu ? tiles : ncu, 1, batch);
-  hipLaunchKernelGGL((gemm16_ring_256x128_kernel<TE, TC>), grid, dim3(512), lds, st, a);
+  W2V2_LAUNCH_MAYBE_TIMED((gemm16_ring_256x128_kernel<TE, TC>), grid, dim3(512), lds, st, a);
 }
 
 void w2v2_launch_ring_256x128(const GemmArgs& a, int dtype_ab, int dtype_c, int M, int N, int batch, bool persistent,
