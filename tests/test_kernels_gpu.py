@@ -239,6 +239,44 @@ def test_gemm_phased_kernel_bit_equal_to_ring_kernel(M, N, K, epi, lp):
         assert err < (4e-3 if cdt != torch.float32 else 2e-5 * K ** 0.5 + 1e-6), (M, N, K, epi, cdt, err)
 
 
+@pytest.mark.gpu
+def test_gemm_timed_launch_reports_the_kernel_duration():
+    """bench.py's roofline hook (w2v2_gemm_timed / w2v2_timer_read): same result as the plain launch, a duration of the
+    right magnitude for both hooked kernels (256x128 ring, phased 256x256), and a loud error for a product that runs on
+    a kernel family without the hook."""
+    import ctypes
+    o = ops()
+    L = o.lib()
+    g = torch.Generator(device="cpu").manual_seed(5)
+    for slot, (M, N, K, name) in enumerate([(9834, 768, 768, "gemm16_ring_256x128_kernel"),
+                                            (9834, 3072, 768, "gemm16_phased_256x256_kernel")]):
+        A = torch.randn(M, K, generator=g).to(torch.float16).to(DEV)
+        Bm = (torch.randn(N, K, generator=g) / K ** 0.5).to(torch.float16).to(DEV)
+        C0 = torch.zeros(M, N, dtype=torch.float16, device=DEV)
+        C1 = torch.zeros_like(C0)
+        g0 = o.Gemm(M, N, K, A, Bm, C0, lda=K, ldb=K, ldc=N)
+        g1 = o.Gemm(M, N, K, A, Bm, C1, lda=K, ldb=K, ldc=N)
+        assert g1.kernel_name == name
+        g0()
+        for _ in range(3):                                   # (warm: the first launch of a kernel loads its code object)
+            assert L.w2v2_gemm_timed(g1._ref, o.stream(), slot) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(C0, C1)
+        ms = (ctypes.c_float * 1)()
+        assert L.w2v2_timer_read(slot, 1, ctypes.cast(ms, ctypes.c_void_p)) == 0
+        tf = 2.0 * M * N * K / (ms[0] * 1e-3) / 1e12
+        assert 100.0 < tf < 2500.0, (name, ms[0], tf)        # a kernel duration, not a host-side interval
+    # a skinny product runs on the register-staged kernel: no hook -> error, nothing silently bracketed
+    A = torch.randn(66, 106, generator=g).to(torch.float16).to(DEV)
+    Bm = torch.randn(1536, 106, generator=g).to(torch.float16).to(DEV)
+    C = torch.zeros(66, 1536, dtype=torch.float32, device=DEV)
+    gs = o.Gemm(66, 1536, 106, A, Bm, C, lda=106, ldb=106, ldc=1536)
+    assert L.w2v2_gemm_timed(gs._ref, o.stream(), 7) != 0
+    assert b"does not run on" in L.w2v2_last_error()
+    assert L.w2v2_timer_read(0, 100000, None) != 0
+
+
+
 @pytest.mark.parametrize("M,N,K,nfrom", [(2100, 768, 256, 0), (9834, 2304, 768, 1536), (1500, 640, 64, 256)])
 def test_gemm_two_term_weights(M, N, K, nfrom):
     """fp16 products with two-term weights (w2v2_gemm_desc.k_ext): columns >= n_ext_from see W = hi + lo, i.e. the
@@ -345,7 +383,7 @@ def test_conv0_groupnorm_gelu(dtype):
     assert rel_l2(out.float().cpu(), ref) < (2e-6 if dtype == torch.float32 else 4e-3)
 
 
-@pytest.mark.parametrize("C,N", [(128, 4000), (512, 3333), (640, 1291)])
+@pytest.mark.parametrize("C,N", [(128, 4000), (512, 3333), (640, 1291), (128, 161234)])   # (last: 51 window-moment blocks)
 @pytest.mark.parametrize("lp", LP16)
 def test_conv0_matrix_core_path(C, N, lp):
     """bf16 outputs with C % 128 == 0 take the split-bf16 MFMA convolution (conv0.hip): f32-class statistics
