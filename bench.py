@@ -30,6 +30,9 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# kernel arguments in device memory (w2v2_speaker_amd/__init__.py explains; -3 % step time): set here as well, before
+# torch can initialise the HIP runtime in this process or in the ranks it spawns
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
 
 import numpy as np
 import torch
