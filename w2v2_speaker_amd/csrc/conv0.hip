@@ -370,6 +370,8 @@ extern "C" int w2v2_conv0_stats_mfma(const float* wav, const float* w, float* pa
     double* gp = reinterpret_cast<double*>(partial);
     const size_t lds = ((size_t)(C0_GRAM_FRAMES - 1) * stride + 10) * sizeof(float);
     W2V2_REQUIRE(lds <= 64 * 1024, "conv0_stats_mfma: stride %d too large for the window-moment kernel", stride);
+    W2V2_REQUIRE((int64_t)nblk * 130 <= (int64_t)w2v2_conv0_workspace_floats(N, C, k, stride),
+                 "conv0_stats_mfma: workspace too small for %d window-moment blocks", nblk);
     hipLaunchKernelGGL((conv0_gram_kernel<10>), dim3((unsigned)nblk, B), dim3(64), lds, as_stream(stream), wav, gp, N, L,
                        stride, C0_GRAM_FRAMES);
     hipLaunchKernelGGL((conv0_gram_finalize_kernel<10>), dim3(B), dim3(256), 0, as_stream(stream), (const double*)gp, w,
