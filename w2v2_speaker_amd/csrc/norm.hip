@@ -13,7 +13,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, T*
                                                      const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, T* __restrict__ y,
                                                      float* __restrict__ mean_o, float* __restrict__ rstd_o,
-                                                     int M, int H, float eps, float p, uint64_t seed) {
+                                                     int M, int H, float eps, float p, uint64_t seed, int rounded_sum) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int row = blockIdx.x * 4 + wave;
   if (row >= M) return;
@@ -38,10 +38,15 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, T*
           vx.v[e] += vr.v[e] * s0;
           vx.v[e + 1] += vr.v[e + 1] * s1;
         }
-        vx.store(r + off);  // pre-norm sum saved for backward
-        // keep the stored (possibly bf16-rounded) value so fwd and bwd see the same s
+        vx.store(r + off);  // pre-norm sum saved for backward (rounded to the activation format)
+        // The statistics and y come from the UNROUNDED f32 sum: one rounding fewer on the forward path per LayerNorm
+        // (24 per encoder pass).  The backward rebuilds x-hat from the stored 16-bit sum with these statistics -- a
+        // 2^-12 relative inconsistency, below the rounding of the gradients it multiplies.  W2V2_LN_ROUNDED_SUM=1
+        // restores the old behaviour (statistics and y from the rounded sum).
+        if (rounded_sum) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) vx.v[e] = to_f32<T>(from_f32<T>(vx.v[e]));
+          for (int e = 0; e < 8; ++e) vx.v[e] = to_f32<T>(from_f32<T>(vx.v[e]));
+        }
       }
 #pragma unroll
       for (int e = 0; e < 8; ++e) { s[ci][e] = vx.v[e]; sum += vx.v[e]; }
@@ -390,10 +395,11 @@ extern "C" int w2v2_layernorm_fwd(const void* x, void* r, const float* gamma, co
   W2V2_REQUIRE(H % 8 == 0 && H <= 8 * 64 * LN_MAXC, "layernorm_fwd: H=%d unsupported (need H%%8==0, H<=1024)", H);
   W2V2_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "layernorm_fwd: bad dropout p");
   if (M <= 0) return 0;
+  static const bool rounded_sum = getenv("W2V2_LN_ROUNDED_SUM") != nullptr;      // A/B switch (parity experiments)
   dim3 grid((unsigned)cdiv(M, 4));
   W2V2_DISPATCH_ACT(dtype, "layernorm_fwd",
     hipLaunchKernelGGL(ln_fwd_kernel<AT>, grid, dim3(256), 0, as_stream(stream), (const AT*)x,
-                       (AT*)r, gamma, beta, (AT*)y, mean, rstd, M, H, eps, drop_p, seed););
+                       (AT*)r, gamma, beta, (AT*)y, mean, rstd, M, H, eps, drop_p, seed, (int)rounded_sum););
   W2V2_CHECK_LAUNCH("layernorm_fwd");
   return 0;
 }
