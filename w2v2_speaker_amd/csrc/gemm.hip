@@ -405,11 +405,12 @@ extern "C" int w2v2_gemm_timed(const w2v2_gemm_desc* d, void* stream, int slot) 
   pt.stop = g_timer_slots[slot].second;
   pt.armed = true;
   const int rc = w2v2_gemm(d, stream);
-  if (pt.armed) {              // the product went to a kernel family without the hook: bracket it with stream events
-    pt.armed = false;
+  const bool unused = pt.armed;
+  pt.armed = false;
+  if (rc != 0) return rc;      // (w2v2_gemm's own message stays in w2v2_last_error)
+  if (unused)                  // the product went to a kernel family without the hook: nothing was timed
     W2V2_FAIL("w2v2_gemm_timed: this product does not run on the 256x128 ring or the phased 256x256 kernel");
-  }
-  return rc;
+  return 0;
 }
 extern "C" int w2v2_timer_read(int first_slot, int n, float* ms_out) {
   W2V2_REQUIRE(first_slot >= 0 && n >= 0 && first_slot + n <= (int)g_timer_slots.size() && ms_out, "w2v2_timer_read: bad range");
