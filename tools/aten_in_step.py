@@ -21,12 +21,13 @@ from w2v2_speaker_amd.trainer import SpeakerTrainer
 
 STEPS = int(os.environ.get("STEPS", "4"))
 dev = torch.device("cuda:0")
-cfg = W2V2Config.from_huggingface_id("facebook/wav2vec2-base")
+MODEL, BATCH, NS = os.environ.get("MODEL", "base"), int(os.environ.get("BATCH", "66")), int(os.environ.get("SAMPLES", "48000"))
+cfg = W2V2Config.from_huggingface_id("facebook/wav2vec2-" + MODEL)      # MODEL=large BATCH=32 SAMPLES=80000: configs[3]
 store = ParamStore(cfg, dev, torch.float16, head="aam", num_speakers=5994, freeze_cnn=True, embed_dim=2 * cfg.hidden_size)
 store.init_weights(seed=20211)
-plan = Plan(store, 66, 48000, train=True, reg=Wav2Vec2RegularisationConfig(), seed=7, pooling="mean+std")
+plan = Plan(store, BATCH, NS, train=True, reg=Wav2Vec2RegularisationConfig(), seed=7, pooling="mean+std")
 tr = SpeakerTrainer(store, plan, OneCycle(max_lr=5e-5, total_steps=100), layerdrop_seed=1234, mask_seed=7)
-wav, label = synth_batch(66, 48000, 5994, seed=42133724, device=dev)
+wav, label = synth_batch(BATCH, NS, 5994, seed=42133724, device=dev)
 for _ in range(3):
     tr.train_step(wav, label)
 torch.cuda.synchronize()
