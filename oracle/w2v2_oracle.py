@@ -4,8 +4,8 @@ TEST INFRASTRUCTURE ONLY -- see ``oracle/__init__.py``.  This file is our own
 restatement of the arithmetic the reference dispatches through HuggingFace
 ``Wav2Vec2Model`` / torch; it is pinned against the real reference (imported in
 the authoring container) by ``tests/golden/make_goldens.py`` -> ``tests/golden/*.npz``
-and by ``tests/test_oracle_vs_reference.py`` (skipped where /root/reference is
-absent).  Gradients come from torch autograd over these functions.
+(committed fixtures); ``tests/test_oracle_golden.py`` checks this file against them on CPU,
+wherever it runs.  Gradients come from torch autograd over these functions.
 
 Citations: ``ref:`` = /root/reference/, ``HF:`` = transformers 5.15.0
 ``models/wav2vec2/modeling_wav2vec2.py`` (the reference pins ^4.8.2).

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Kernel-level A/B inside ONE gpurun call: average duration of the kernels matching <pattern> in the default bench
-# step, A = w2v2_speaker_amd/lib_ab_old.so, B = the in-tree library (alternating, <rounds> times).
+# step, A = tools/ab/lib_ab_old.so, B = the in-tree library (alternating, <rounds> times).
 # Usage: bash tools/ab_prof.sh <pattern> [rounds] [bench.py args...]
 PAT=$1; R=${2:-2}; shift; shift
 export TMPDIR=/tmp W2V2_BENCH_NO_FAMILY_PASS=1
@@ -8,7 +8,7 @@ ROOT=$PWD
 cd /tmp
 for i in $(seq $R); do
   for v in A B; do
-    if [ $v = A ]; then export W2V2_LIB_AB=$ROOT/w2v2_speaker_amd/lib_ab_old.so; else unset W2V2_LIB_AB; fi
+    if [ $v = A ]; then export W2V2_LIB_AB=$ROOT/tools/ab/lib_ab_old.so; else unset W2V2_LIB_AB; fi
     rm -rf /tmp/abp
     rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/abp -o r -- python3 $ROOT/bench.py --no-cpu-baseline --no-also --steps 20 --warmup 4 "$@" > /tmp/abp.log 2>&1
     F=$(find /tmp/abp -name "r_kernel_stats.csv" | head -1)
