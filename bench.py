@@ -252,7 +252,7 @@ def run(args):
     if world > 1:
         # what PL's DDP wrapper does when it wraps the module: every replica starts from rank 0's state,
         # whatever the ranks initialised or loaded themselves
-        trainer.reducer.broadcast_parameters(0)
+        trainer.broadcast_state(0)
 
     def sync():
         torch.cuda.synchronize()

@@ -268,7 +268,8 @@ int w2v2_posconv_wgrad(const void* dY, const void* xg, float* dwf, int B, int T,
  * xg = posconv_regroup(x, pad_left) [B][G][T+K-1][Cg]; w = the packed (weight-normed) weights [G][Cg][K*Cg] of
  * w2v2_weightnorm_pack (forward: wf; data gradient: wb over the regrouped dY).  mode 0: epi = GELU(. + bias[g*Cg+co]),
  * aux (may be NULL) receives the pre-activation; mode 1: epi = . + aux (aux may alias out).  16-bit activations;
- * bit-equal to the implicit GEMM of w2v2_gemm over the same operands.  Other geometries: use the implicit GEMM. */
+ * bit-equal to the implicit GEMM of w2v2_gemm over the same operands.  Other geometries: use the implicit GEMM.
+ * Contract: ldc a multiple of 8 elements; xg, w, out and aux 16-byte aligned (else an error is returned). */
 int w2v2_posconv_direct(const void* xg, const void* w, void* out, void* aux, const float* bias, int B, int T, int G,
                         int Cg, int K, int64_t ldc, int mode, int dtype, void* stream);
 int w2v2_weightnorm_pack(const float* g, const float* v, float* sumsq /*[129*K]*/, void* wf,

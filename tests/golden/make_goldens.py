@@ -414,8 +414,83 @@ def golden_bce():
     print("g9_bce: loss", float(loss))
 
 
+# ----------------------------------------------------------------------------- G12 the "eval EER" half of the metric
+def golden_eer(mix=None):
+    """a structured synthetic trial set (w2v2_speaker_amd/data/synthetic.py: 8 speakers x 4
+    utterances of 3 s, speaker "voice" + fresh noise) through the reference's wrapper (eval mode, the g2_base weights)
+    + mean+std pooling, then through the reference's OWN evaluator (CosineDistanceEvaluator(False, False, 0).evaluate:
+    ref src/evaluation/speaker/speaker_recognition_evaluator.py:46-115, cosine_distance.py:107-132) on all 496 pairs.
+    Stored: the [32, 1536] reference embeddings, the [0,1] scores the reference feeds calculate_eer, its EER / minDCF."""
+    from src.evaluation.speaker.cosine_distance import CosineDistanceEvaluator
+    from src.evaluation.speaker.speaker_recognition_evaluator import EvaluationPair, EmbeddingSample
+    from w2v2_speaker_amd.data.synthetic import TRIAL_SET_DEFAULT, synth_trial_set
+    kw = dict(TRIAL_SET_DEFAULT)
+    if mix is not None:
+        kw["mix"] = mix
+    wav, spk, keys, trials = synth_trial_set(**kw)
+    cfg = O.OracleConfig.base()
+    w, _ = build_reference_wrapper(cfg, seed=20211)
+    w.eval()
+    x = torch.from_numpy(wav)
+    embs = []
+    with torch.no_grad():
+        for i in range(0, x.shape[0], 8):
+            embs.append(MeanStdStatPool1D(1)(w(x[i:i + 8]).transpose(2, 1)))
+    emb = torch.cat(embs)
+    pairs = [EvaluationPair(bool(same), keys[i], keys[j]) for same, i, j in trials]
+    samples = [EmbeddingSample(k, e) for k, e in zip(keys, emb)]
+    ev = CosineDistanceEvaluator(False, False, 0)
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        res = ev.evaluate(pairs, samples)
+    scores = np.clip((np.array(ev._compute_prediction_scores(
+        [(samples[i], samples[j]) for _, i, j in trials])) + 1) / 2, 0, 1)
+    g = {"embedding": emb, "speaker": spk, "trials": np.array(trials, dtype=np.int64), "scores": scores,
+         "eer": res["eer"], "eer_threshold": res["eer_threshold"], "mdc": res["mdc"], "mdc_threshold": res["mdc_threshold"],
+         "params": np.array([kw["n_speakers"], kw["utts_per_speaker"], kw["n_samples"], kw["seed"]], dtype=np.int64),
+         "mix": np.float64(kw["mix"])}
+    if mix is None:
+        np.savez_compressed(os.path.join(OUT, "g12_eer.npz"), **to_np(g))
+    tgt = scores[np.array([t[0] for t in trials]) == 1]
+    non = scores[np.array([t[0] for t in trials]) == 0]
+    print(f"g12_eer (mix {kw['mix']}): eer {res['eer']:.5f} mdc {res['mdc']:.4f}; target scores {tgt.mean():.4f}+-{tgt.std():.4f} "
+          f"non-target {non.mean():.4f}+-{non.std():.4f}")
+    return res
+
+
+# ----------------------------------------------------------------------------- G13 evaluation-length utterance, G14 third weight seed
+def golden_long():
+    """the reference tests on whole utterances at batch size 1 (ref: src/main.py:506-514,
+    speaker_recognition_module.py:462-500).  One 20 s utterance (N = 320000 -> T = 999) through the reference wrapper,
+    eval mode, the g2_base weights: embedding + a strided sample of the hidden states."""
+    cfg = O.OracleConfig.base()
+    w, _ = build_reference_wrapper(cfg, seed=20211)
+    wav, _ = O.synth_batch(1, 320000, 5994, seed=90017)
+    w.eval()
+    with torch.no_grad():
+        h = w(wav[:, 0, :]).transpose(2, 1)
+        g = {"eval.mean+std": MeanStdStatPool1D(1)(h), "eval.last_hidden.sample": h[:, ::37, ::16].contiguous()}
+    np.savez_compressed(os.path.join(OUT, "g13_long.npz"), **to_np(g))
+    print("g13_long: emb norm", float(g["eval.mean+std"].norm()), "T", h.shape[1])
+
+
+def golden_seed3():
+    """a THIRD weight seed for the fp16 embedding bound (the margin under 1e-3 is a few percent, and
+    every golden so far used seeds 20211 / 777): weights 4099, utterances 60611, B = 6, 4 s clips (T = 199)."""
+    cfg = O.OracleConfig.base()
+    w, _ = build_reference_wrapper(cfg, seed=4099)
+    wav, _ = O.synth_batch(6, 64000, 5994, seed=60611)
+    w.eval()
+    with torch.no_grad():
+        h = w(torch.squeeze(wav)).transpose(2, 1)
+        g = {"eval.mean+std": MeanStdStatPool1D(1)(h), "eval.last_hidden.sample": h[:, ::16, ::16].contiguous()}
+    np.savez_compressed(os.path.join(OUT, "g14_seed3.npz"), **to_np(g))
+    print("g14_seed3: emb norm", float(g["eval.mean+std"].norm()), "T", h.shape[1])
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["tiny", "base", "aam", "pool", "eval", "optim", "bce", "base2", "base66"]
+    which = sys.argv[1:] or ["tiny", "base", "aam", "pool", "eval", "optim", "bce", "base2", "base66", "eer", "long", "seed3"]
     for wname in which:
         {"tiny": golden_tiny, "base": golden_base, "aam": golden_aam, "base66": golden_base66, "pool": golden_pool,
-         "eval": golden_eval, "optim": golden_optim, "bce": golden_bce, "base2": golden_base2}[wname]()
+         "eval": golden_eval, "optim": golden_optim, "bce": golden_bce, "base2": golden_base2, "eer": golden_eer,
+         "long": golden_long, "seed3": golden_seed3}[wname]()

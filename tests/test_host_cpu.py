@@ -168,14 +168,20 @@ def _bcast_worker(rank, world, port, q):
     red = BucketAllReducer(st, bucket_merge=2)
     before = st.flat.clone()
     v0 = st.version
-    red.broadcast_parameters(root=0)
+    # ONLY rank 0 has "loaded a checkpoint": its Adam step counts and schedule position are advanced (the
+    # host half of the optimiser state must travel with the moments, else the other ranks run bias-correction t = 1 and
+    # schedule.at(0) on step-N moments)
+    if rank == 0:
+        st.set_step_counts(41, 37)
+    got = red.broadcast_parameters(root=0, host_counters=[1234 if rank == 0 else 0, 77 if rank == 0 else 5])
+    host_ok = (st.step_head, st.step_body, st.step_count) == (41, 37, 41) and got == [1234, 77]
     ref = ParamStore(W2V2Config.tiny(), "cpu", torch.float32, head="aam", num_speakers=10)
     ref.init_weights(seed=1000)
     g0 = torch.Generator().manual_seed(50)
     m0 = torch.randn(st.n_train, generator=g0)
     s0 = torch.rand(st.n_train, generator=g0)
     ok = (torch.equal(st.flat, ref.flat) and torch.equal(st.exp_avg, m0) and torch.equal(st.exp_avg_sq, s0)
-          and st.version > v0 and (rank == 0 or not torch.equal(before, st.flat)))
+          and st.version > v0 and (rank == 0 or not torch.equal(before, st.flat)) and host_ok)
     # a rank whose state differs in KIND (no moments) must be refused, not silently mis-paired
     refused = None
     if world == 2:

@@ -124,6 +124,62 @@ def test_base66_golden_rows_agree_with_oracle_and_with_the_b2_golden():
     assert rel_l2(e.numpy(), g["eval.mean+std"][40:41]) < 1e-4
 
 
+def test_eer_trial_set_golden_reference_scores_reproduced_by_the_mirror_and_the_oracle():
+    """tests/golden/g12_eer.npz (make_goldens.py `eer`): the structured synthetic trial set through the REFERENCE's wrapper
+    and its own CosineDistanceEvaluator.  (a) the trial set regenerates from its seed; (b) the package's evaluator and
+    `score_trials` reproduce the reference's scores / EER / minDCF from the reference's embeddings; (c) the oracle
+    reproduces the reference embedding of four utterances (two speakers; all 32 would take a minute)."""
+    from w2v2_speaker_amd.data.synthetic import TRIAL_SET_DEFAULT, score_trials, synth_trial_set
+    from w2v2_speaker_amd.eval_metrics import calculate_eer, calculate_mdc
+    from w2v2_speaker_amd.evaluation.speaker.cosine_distance import (CosineDistanceEvaluator, EmbeddingSample,
+                                                                     EvaluationPair)
+    g = load("g12_eer.npz")
+    S, U, N, seed = (int(v) for v in g["params"])
+    assert (S, U, N, seed, float(g["mix"])) == tuple(TRIAL_SET_DEFAULT[k] for k in
+                                                     ("n_speakers", "utts_per_speaker", "n_samples", "seed", "mix"))
+    wav, spk, keys, trials = synth_trial_set()
+    assert np.array_equal(spk, g["speaker"]) and np.array_equal(np.array(trials), g["trials"])
+    assert len(trials) == 496 and sum(t[0] for t in trials) == 48
+    emb = g["embedding"]
+    gt, sc = score_trials(emb, trials)
+    assert np.allclose(sc, g["scores"], atol=2e-7)
+    eer, _ = calculate_eer(gt, sc)
+    mdc, _ = calculate_mdc(gt, sc)
+    assert abs(eer - float(g["eer"])) < 1e-6 and abs(mdc - float(g["mdc"])) < 1e-6
+    assert 0.05 < eer < 0.25                      # a trial set on which the EER can move
+    res = CosineDistanceEvaluator(False, False, 0).evaluate(
+        [EvaluationPair(bool(s), keys[i], keys[j]) for s, i, j in trials],
+        [EmbeddingSample(k, T(e)) for k, e in zip(keys, emb)])
+    assert abs(res["eer"] - float(g["eer"])) < 1e-6 and abs(res["mdc"] - float(g["mdc"])) < 1e-6
+    cfg = O.OracleConfig.base()
+    sd = O.make_state_dict(cfg, 20211)
+    rows = [0, 1, 12, 31]
+    with torch.no_grad():
+        e = O.speaker_embedding(T(wav[rows])[:, None, :], sd, cfg, "mean+std")
+    assert rel_l2(e.numpy(), emb[rows]) < 1e-4
+
+
+def test_evaluation_length_utterance_and_third_weight_seed_goldens():
+    """g13_long (one 20 s utterance, T = 999, batch 1: how the reference tests, ref src/main.py:506-514) and g14_seed3
+    (weights 4099, 6 x 4 s): two more operating points the oracle is pinned at."""
+    cfg = O.OracleConfig.base()
+    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    g = load("g13_long.npz")
+    wav, _ = O.synth_batch(1, 320000, 5994, seed=90017)
+    with torch.no_grad():
+        h = O.wav2vec2_forward(wav[:, 0], O.make_state_dict(cfg, 20211), cfg)
+    assert h.shape[1] == 999
+    assert rel_l2(h[:, ::37, ::16], g["eval.last_hidden.sample"]) < 1e-4
+    assert rel_l2(O.mean_std_pool(h), g["eval.mean+std"]) < 1e-4
+    g = load("g14_seed3.npz")
+    wav, _ = O.synth_batch(6, 64000, 5994, seed=60611)
+    with torch.no_grad():
+        h = O.wav2vec2_forward(wav[:2, 0], O.make_state_dict(cfg, 4099), cfg)
+    assert h.shape[1] == 199
+    assert rel_l2(h[:, ::16, ::16], g["eval.last_hidden.sample"][:2]) < 1e-4
+    assert rel_l2(O.mean_std_pool(h), g["eval.mean+std"][:2]) < 1e-4
+
+
 def test_aam_known_answers():
     g = load("g4_aam.npz")
     for margin, scale in ((0.2, 30.0), (0.3, 15.0)):

@@ -237,6 +237,99 @@ def test_base_b66_embeddings_vs_reference_golden_at_benchmark_size(dtype):
                                                                                        torch.bfloat16: 3e-2}[dtype]
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+def test_eer_on_the_synthetic_trial_set_hip_vs_reference(dtype):
+    """The "eval EER" half of the metric at the benchmarked size and precision (VERDICT r4 missing 3): the 32 utterances of
+    w2v2_speaker_amd.data.synthetic.synth_trial_set through the HIP engine (eval, mean+std), scored on all 496 pairs like
+    the reference's evaluator (ref: speaker_recognition_evaluator.py:46-115), against tests/golden/g12_eer.npz = the
+    REFERENCE's embeddings / scores / EER for the same waveforms (reference EER 0.104: target and non-target scores
+    overlap, so the figure reacts to embedding errors).  Bounds: embeddings as everywhere (f32 1e-4, fp16 1e-3 per
+    utterance); every trial score within 1e-6 (f32) / 5e-5 (fp16: scores live in 0.998..1, the target / non-target gap is
+    7e-4); EER equal (f32) / within one target trial = 1/48 (fp16), minDCF within 0.05."""
+    from w2v2_speaker_amd.data.synthetic import score_trials, synth_trial_set
+    from w2v2_speaker_amd.engine import Plan
+    from w2v2_speaker_amd.eval_metrics import calculate_eer, calculate_mdc
+    g = load("g12_eer.npz")
+    wav, spk, keys, trials = synth_trial_set()
+    cfg, ocfg = _cfgs("base")
+    st, _ = _store(cfg, ocfg, dtype, None, 1)
+    ev = Plan(st, wav.shape[0], wav.shape[1], train=False)
+    e = ev.embed(T(wav).to(DEV)).cpu()
+    torch.cuda.synchronize()
+    ref = T(g["embedding"])
+    per_utt = (e - ref).norm(dim=1) / ref.norm(dim=1)
+    f32 = dtype == torch.float32
+    assert float(per_utt.max()) < (1e-4 if f32 else 1e-3), per_utt
+    gt, sc = score_trials(e.numpy(), trials)
+    dsc = float(np.abs(np.array(sc) - g["scores"]).max())
+    eer, _ = calculate_eer(gt, sc)
+    mdc, _ = calculate_mdc(gt, sc)
+    print(f"EER trial set {dtype}: hip {eer:.5f} reference {float(g['eer']):.5f}; minDCF {mdc:.4f} vs {float(g['mdc']):.4f}; "
+          f"max |score diff| {dsc:.2e}; embedding per-utterance max {float(per_utt.max()):.2e}")
+    assert dsc < (1e-6 if f32 else 5e-5), dsc
+    assert abs(eer - float(g["eer"])) <= (1e-6 if f32 else 1.0 / 48 + 1e-6), (eer, float(g["eer"]))
+    assert abs(mdc - float(g["mdc"])) <= (1e-6 if f32 else 0.05), (mdc, float(g["mdc"]))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
+def test_evaluation_length_utterance_and_third_weight_seed_vs_reference(dtype):
+    """Two more reference goldens for the embedding bound (the fp16 margin under 1e-3 is a few percent):
+    g13_long = ONE 20 s utterance at batch size 1 (T = 999; the reference tests on whole utterances, ref src/main.py:506-514)
+    and g14_seed3 = a third weight seed (4099), 6 x 4 s (T = 199).  fp16 < 1e-3 for every utterance."""
+    from w2v2_speaker_amd.engine import Plan
+    cfg, ocfg = _cfgs("base")
+    bound = {torch.float32: 1e-4, **EMB_BOUND}[dtype]
+    hb = {torch.float32: 1e-4, torch.float16: 3e-3, torch.bfloat16: 3e-2}[dtype]
+    g = load("g13_long.npz")
+    st, _ = _store(cfg, ocfg, dtype, None, 1)
+    wav, _ = O.synth_batch(1, 320000, 5994, seed=90017)
+    ev = Plan(st, 1, 320000, train=False)
+    assert ev.T == 999
+    e = ev.embed(wav.to(DEV)).cpu()
+    err_long = rel_l2(e, g["eval.mean+std"])
+    assert rel_l2(ev.out[:, ::37, ::16].float().cpu(), g["eval.last_hidden.sample"]) < hb
+    del ev, st
+    g = load("g14_seed3.npz")
+    st, _ = _store(cfg, ocfg, dtype, None, 1, seed=4099)
+    wav, _ = O.synth_batch(6, 64000, 5994, seed=60611)
+    ev = Plan(st, 6, 64000, train=False)
+    assert ev.T == 199
+    e = ev.embed(wav.to(DEV)).cpu()
+    ref = T(g["eval.mean+std"])
+    per_utt = (e - ref).norm(dim=1) / ref.norm(dim=1)
+    print(f"long utterance {dtype}: rel-L2 {err_long:.3e}; third seed: per utterance max {float(per_utt.max()):.3e} "
+          f"batch {rel_l2(e, ref):.3e}")
+    assert err_long < bound, err_long
+    assert float(per_utt.max()) < bound, per_utt
+    assert rel_l2(ev.out[:, ::16, ::16].float().cpu(), g["eval.last_hidden.sample"]) < hb
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+def test_base_ce_head_1211_vs_reference_golden(dtype):
+    """BASELINE configs[0]'s head at its real size: w2v2-base + Linear(1536 -> 1211) + cross-entropy
+    (ref: wav2vec2_fc.py:199-210, cross_entropy.py:27-31) on the train-mode embedding of g2_base (injected mask, dropouts
+    off): loss and the softmax probability of every label against the reference (`ce.loss`, `ce.softmax.label`)."""
+    from w2v2_speaker_amd.engine import Plan
+    g = load("g2_base.npz")
+    cfg, ocfg = _cfgs("base")
+    st, _ = _store(cfg, ocfg, dtype, "ce", 1211)
+    wav, label = O.synth_batch(2, 48000, 5994, seed=42133724)
+    lab = (label % 1211).to(DEV)
+    if st.scaler is not None:
+        st.scaler[0] = 256.0
+    plan = Plan(st, 2, 48000, train=True, reg=_no_reg())
+    st.zero_grad()
+    emb = plan.embed(wav.to(DEV), T(g["mask"]).to(DEV))
+    loss, sm = plan.head_forward_backward(lab)
+    torch.cuda.synchronize()
+    f32 = dtype == torch.float32
+    assert rel_l2(emb.cpu(), g["train.embedding"]) < (1e-4 if f32 else 1e-3)
+    assert abs(float(loss) - float(g["ce.loss"])) < (1e-4 if f32 else 3e-3) * abs(float(g["ce.loss"]))
+    got = sm.cpu().gather(1, (label % 1211).view(-1, 1))
+    assert rel_l2(got, g["ce.softmax.label"]) < (1e-3 if f32 else 2e-2)
+
+
+
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 def test_base_16bit_fused_attention_vs_reference_and_vs_unfused(dtype):
     from w2v2_speaker_amd.engine import Plan

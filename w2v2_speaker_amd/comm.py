@@ -99,14 +99,38 @@ class CAbiBucketAllReducer:
         self.comm.all_reduce_(self.store.grad[s:e], self.comm_stream)
         self._issued = True
 
-    def broadcast_parameters(self, root: int = 0) -> None:
-        """Same contract as trainer.BucketAllReducer.broadcast_parameters, through w2v2_broadcast_async."""
+    def broadcast_parameters(self, root: int = 0, host_counters=None):
+        """Same contract as trainer.BucketAllReducer.broadcast_parameters (device state + the host-side step counters),
+        through w2v2_broadcast_async.  Everything is enqueued on the communicator's own stream (the one the gradient
+        all-reduces use), ordered against the compute stream on both sides; before any broadcast the ranks check,
+        through one tiny all-reduce, that they agree on how many state tensors and bytes there are -- mismatched
+        ncclBroadcast sequences would hang instead of failing."""
+        extra = [int(c) for c in (host_counters or ())]
         if self.world == 1:
-            return
-        for t in self.store.replica_state():
-            self.comm.broadcast_(t, root)
-        torch.cuda.current_stream().synchronize()
+            return extra
+        ts = self.store.replica_state()
+        dev = self.store.flat.device
+        cur = torch.cuda.current_stream()
+        self.comm_stream.wait_stream(cur)
+        nbytes = sum(t.numel() * t.element_size() for t in ts)
+        sig = [float(len(ts)), float(len(extra)), float(nbytes % 8191), float(nbytes // 8191 % 8191)]
+        chk = torch.tensor(sig + [v * v for v in sig], device=dev, dtype=torch.float32)     # small integers: exact in f32
+        self.comm.all_reduce_(chk, self.comm_stream)
+        self.comm_stream.synchronize()
+        c = chk.tolist()
+        if any(abs(self.world * c[4 + i] - c[i] * c[i]) > 0.5 for i in range(4)):          # n * sum(x^2) == (sum x)^2 iff all equal
+            raise RuntimeError("broadcast_parameters: ranks disagree on which state tensors exist (optimiser moments / "
+                               "loss scale / host counters); create or load them on every rank first")
+        for t in ts:
+            self.comm.broadcast_(t, root, self.comm_stream)
+        host = torch.tensor([self.store.step_head, self.store.step_body] + extra, device=dev, dtype=torch.int64)
+        self.comm.broadcast_(host, root, self.comm_stream)
+        cur.wait_stream(self.comm_stream)
+        self.comm_stream.synchronize()
+        host = [int(v) for v in host.tolist()]
+        self.store.set_step_counts(host[0], host[1])
         self.store.sync_lowp()
+        return host[2:]
 
     def wait(self) -> None:
         if self._issued:

@@ -174,7 +174,9 @@ extern "C" int w2v2_posconv_direct(const void* xg, const void* w, void* out, voi
   W2V2_REQUIRE(Cg == PD_CG && K == 128, "posconv_direct: built for 48 channels per group and 128 taps (w2v2-base); got "
                "Cg=%d K=%d -- use the implicit GEMM", Cg, K);
   W2V2_REQUIRE(mode == 0 ? bias != nullptr : (mode == 1 && aux != nullptr), "posconv_direct: mode 0 needs bias, mode 1 aux");
-  W2V2_REQUIRE(ldc % 4 == 0 && ldc >= G * Cg, "posconv_direct: ldc must be a multiple of 4 and >= G * Cg");
+  W2V2_REQUIRE(ldc % 8 == 0 && ldc >= G * Cg, "posconv_direct: ldc must be a multiple of 8 and >= G * Cg");
+  W2V2_REQUIRE(((uintptr_t)xg | (uintptr_t)w | (uintptr_t)out | (uintptr_t)aux) % 16 == 0,
+               "posconv_direct: xg, w, out and aux must be 16-byte aligned (16-byte epilogue stores, LDS-DMA source rows)");
   W2V2_REQUIRE(dtype == W2V2_BF16 || dtype == W2V2_F16, "posconv_direct: needs a 16-bit activation dtype (got %d)", dtype);
   const int mblocks = (int)cdiv(T, PD_MB);
   const int64_t xg_elems = (int64_t)B * G * (T + K - 1) * Cg;

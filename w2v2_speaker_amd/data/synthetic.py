@@ -1,0 +1,56 @@
+"""Synthetic speaker-verification trial set for the "eval EER" half of the metric ("eval EER on a fixed
+synthetic trial list").  VoxCeleb is not available offline, so the trial list the reference scores
+(ref: src/evaluation/speaker/speaker_recognition_evaluator.py:46-115 on `veri_test2.txt` pairs) is replaced by a
+structured one that any host can regenerate bit for bit from its seed (numpy PCG64, no torch RNG):
+
+  * ``n_speakers`` speakers, each a fixed unit-variance noise waveform v_s[n] (the speaker's "template");
+  * utterance u of speaker s = ``mix`` * v_s + sqrt(1 - mix^2) * fresh white noise, normalised per utterance exactly as
+    the reference's ``InputNormalizer2D`` does (ref: src/data/preprocess/input_normalisation.py:54-67).  With random
+    (untrained) weights the network is no speaker model: what makes two utterances score high is that their waveforms
+    are close, so ``mix`` sets the difficulty -- 0.9 puts the reference's own EER at 0.11 (0.97: 0, 0.7: 0.42), i.e.
+    target and non-target scores overlap and the EER reacts to embedding errors.  Only IEEE adds / multiplies /
+    one sqrt in a fixed order (float64, rounded once to f32): every host regenerates the same samples;
+  * trials = ALL pairs of distinct utterances, target iff same speaker (8 x 4 utterances: 496 trials, 48 targets).
+
+The same waveforms go through the reference (tests/golden/make_goldens.py `eer` -> tests/golden/g12_eer.npz holds ITS
+embeddings, scores and EER) and through the HIP path (tests/test_parity_gpu.py, bench.py `eer` field)."""
+from __future__ import annotations
+
+from typing import List, Tuple
+
+import numpy as np
+
+TRIAL_SET_DEFAULT = dict(n_speakers=8, utts_per_speaker=4, n_samples=48000, mix=0.9, seed=52001)
+
+
+def synth_trial_set(n_speakers: int = 8, utts_per_speaker: int = 4, n_samples: int = 48000, mix: float = 0.9,
+                    seed: int = 52001) -> Tuple[np.ndarray, np.ndarray, List[str], List[Tuple[int, int, int]]]:
+    """-> (wav [S*U, n_samples] f32 normalised, speaker [S*U] int64, keys, trials [(same, i, j)] over all i < j)."""
+    g = np.random.Generator(np.random.PCG64(seed))
+    voices = g.standard_normal((n_speakers, n_samples))
+    wav = np.empty((n_speakers * utts_per_speaker, n_samples), dtype=np.float32)
+    spk = np.empty(n_speakers * utts_per_speaker, dtype=np.int64)
+    keys = []
+    a, b = float(mix), float(np.sqrt(1.0 - mix * mix))
+    for s in range(n_speakers):
+        for u in range(utts_per_speaker):
+            x = a * voices[s] + b * g.standard_normal(n_samples)
+            mean = x.sum() / n_samples
+            var = ((x - mean) ** 2).sum() / (n_samples - 1)    # unbiased, like torch.std_mean in the reference
+            i = s * utts_per_speaker + u
+            wav[i] = ((x - mean) / (np.sqrt(var) + 1e-5)).astype(np.float32)
+            spk[i] = s
+            keys.append(f"id{s:05d}/synth/{u:05d}")
+    n = len(keys)
+    trials = [(int(spk[i] == spk[j]), i, j) for i in range(n) for j in range(i + 1, n)]
+    return wav, spk, keys, trials
+
+
+def score_trials(emb, trials) -> Tuple[List[int], List[float]]:
+    """Cosine score of every trial mapped to [0, 1] as the reference's evaluator does before the EER
+    (ref: speaker_recognition_evaluator.py:81 ``clip((s + 1) / 2, 0, 1)``) -> (ground truth, scores)."""
+    e = np.asarray(emb, dtype=np.float64)
+    en = e / np.maximum(np.linalg.norm(e, axis=1, keepdims=True), 1e-8)
+    gt = [t[0] for t in trials]
+    sc = [float(np.clip((en[i] @ en[j] + 1.0) / 2.0, 0.0, 1.0)) for _, i, j in trials]
+    return gt, sc

@@ -352,6 +352,16 @@ class Wav2vec2FCModule(torch.nn.Module):
         return torch.rand(size=shape)
 
     # ------------------------------------------------------------------ steps
+    def broadcast_state(self, root: int = 0) -> None:
+        """What PL's DDP does at ``trainer.fit`` plus the host half of a resume: every rank takes ``root``'s
+        parameters, Adam moments, loss scale, Adam step counts, schedule position and freeze counter -- so a checkpoint
+        loaded on rank 0 only leaves the replicas identical (under PL every rank restores the checkpoint itself)."""
+        from ...trainer import BucketAllReducer
+        red = BucketAllReducer(self.store, self.process_group)
+        got = red.broadcast_parameters(root, [self.schedule_step, self.steps, int(self._is_wav2vec_frozen)])
+        self.schedule_step, self.steps = got[0], got[1]
+        self._is_wav2vec_frozen = bool(got[2])
+
     def training_step(self, batch: SpeakerClassificationDataBatch, batch_idx: int = 0,
                       optimizer_idx: Optional[int] = None):
         """forward + backward (+ all-reduce) + fused Adam; returns {"loss", "prediction", "train_acc"} (device

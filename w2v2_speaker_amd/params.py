@@ -483,6 +483,12 @@ class ParamStore:
             v.pow(2).sum(dim=(0, 1), keepdim=True).sqrt())
         self.sync_lowp()
 
+    def set_step_counts(self, step_head: int, step_body: int) -> None:
+        """Host-side half of the optimiser state (Adam's bias corrections): set by a resume and by the start-up
+        broadcast of the reducers, which sends rank 0's counts along with its moments."""
+        self.step_head, self.step_body = int(step_head), int(step_body)
+        self.step_count = max(self.step_head, self.step_body)
+
     def replica_state(self) -> List[torch.Tensor]:
         """Every tensor a data-parallel replica must share with rank 0 before the first step (f32 master arena incl.
         the frozen CNN and the BatchNorm buffers that live in it, Adam moments when they exist, the loss-scale record):

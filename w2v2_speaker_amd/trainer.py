@@ -71,26 +71,34 @@ class BucketAllReducer:
         with torch.cuda.stream(self.comm_stream):
             self.works.append(self.dist.all_reduce(view, op=self.dist.ReduceOp.SUM, group=self.pg, async_op=True))
 
-    def broadcast_parameters(self, root: int = 0) -> None:
+    def broadcast_parameters(self, root: int = 0, host_counters: Optional[Sequence[int]] = None) -> List[int]:
         """Start-up broadcast (ref: config/trainer/trainer.yaml:6-12 -- PL's DDP wrapper broadcasts the
         module state of rank 0 when it wraps the model): master parameters, optimiser moments and the loss-scale record
-        of ``root`` replace every other rank's, then the 16-bit operand copies are rebuilt.  Call it once after
-        construction / after loading a checkpoint on rank 0 only; without it the replicas are identical only if every
-        rank seeded / loaded identically.  Ranks that have no Adam moments yet must not differ from root in that
-        respect (a collective: same tensors on every rank)."""
+        of ``root`` replace every other rank's, then the 16-bit operand copies are rebuilt.  The HOST side of the
+        optimiser state travels with them: the store's Adam step counts (bias corrections) and whatever
+        ``host_counters`` the caller adds (schedule position, freeze counter) -- returned as ``root`` had them, so that
+        a checkpoint loaded on rank 0 only leaves every replica at the same step.  Ranks that have no Adam moments yet
+        must not differ from root in that respect (a collective: same tensors on every rank)."""
+        extra = [int(c) for c in (host_counters or ())]
         if self.world == 1:
-            return
-        counts = torch.tensor([len(self.store.replica_state())], device=self.store.flat.device, dtype=torch.int64)
+            return extra
+        dev = self.store.flat.device
+        counts = torch.tensor([len(self.store.replica_state()), len(extra)], device=dev, dtype=torch.int64)
         lo, hi = counts.clone(), counts.clone()
         self.dist.all_reduce(lo, op=self.dist.ReduceOp.MIN, group=self.pg)
         self.dist.all_reduce(hi, op=self.dist.ReduceOp.MAX, group=self.pg)
-        if int(lo) != int(hi):
+        if not torch.equal(lo, hi):
             raise RuntimeError("broadcast_parameters: ranks disagree on which state tensors exist (optimiser moments / "
-                               "loss scale); create or load them on every rank first")
+                               "loss scale / host counters); create or load them on every rank first")
         src = self.dist.get_global_rank(self.pg, root) if self.pg is not None else root
         for t in self.store.replica_state():
             self.dist.broadcast(t, src=src, group=self.pg)
+        host = torch.tensor([self.store.step_head, self.store.step_body] + extra, device=dev, dtype=torch.int64)
+        self.dist.broadcast(host, src=src, group=self.pg)
+        host = [int(v) for v in host.tolist()]
+        self.store.set_step_counts(host[0], host[1])
         self.store.sync_lowp()
+        return host[2:]
 
     def wait(self) -> None:
         for w in self.works:
@@ -113,6 +121,14 @@ class SpeakerTrainer:
         self.world = self.reducer.world
         self._ld_rng = np.random.RandomState(layerdrop_seed)
         self._mask_rng = np.random.RandomState(mask_seed)
+
+    def broadcast_state(self, root: int = 0, host_counters: Optional[Sequence[int]] = None) -> List[int]:
+        """Every replica takes ``root``'s parameters, moments, loss scale AND step position (this trainer's ``step`` =
+        the lr / beta1 schedule index, the store's Adam step counts, plus the caller's ``host_counters``, returned as
+        root had them).  What a rank-0-only checkpoint load needs before the first step."""
+        got = self.reducer.broadcast_parameters(root, [self.step] + [int(c) for c in (host_counters or ())])
+        self.step = got[0]
+        return got[1:]
 
     def sample_layerdrop(self) -> Tuple[int, ...]:
         """HF:698-709: each layer is skipped with probability ``layerdrop`` (host RNG)."""
