@@ -103,38 +103,13 @@ def param_shapes(cfg: OracleConfig) -> Dict[str, Tuple[int, ...]]:
     return shp
 
 
-def _name_seed(name: str, seed: int) -> int:
-    h = 1469598103934665603
-    for ch in (name + f"#{seed}").encode():
-        h = ((h ^ ch) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
-    return h
-
-
 def synth_tensor(name: str, shape: Sequence[int], seed: int) -> Tensor:
-    """Deterministic name-keyed PCG64 tensor: both the golden script and the GPU box
-    regenerate identical weights, so no 378 MB checkpoint is ever committed."""
-    g = np.random.Generator(np.random.PCG64(_name_seed(name, seed)))
-    shape = tuple(shape)
-    leaf = name.rsplit(".", 1)[-1]
-    if name == "masked_spec_embed":
-        a = g.random(shape)                                     # HF:1253 uniform_()
-    elif name.endswith("parametrizations.weight.original0"):
-        a = 1.0 + 0.25 * g.standard_normal(shape)               # weight-norm gain g
-    elif "layer_norm" in name and leaf == "weight":
-        a = 1.0 + 0.1 * g.standard_normal(shape)
-    elif leaf == "bias":
-        a = 0.1 * g.standard_normal(shape)
-    elif name.startswith("feature_extractor") and leaf == "weight":
-        fan_in = shape[1] * shape[2]
-        a = math.sqrt(2.0 / fan_in) * 1.3 * g.standard_normal(shape)   # keep variance through GELU
-    elif name.endswith("original1"):
-        fan_in = shape[1] * shape[2]
-        a = math.sqrt(1.0 / fan_in) * g.standard_normal(shape)
-    elif len(shape) == 2:
-        a = math.sqrt(1.0 / shape[1]) * g.standard_normal(shape)
-    else:
-        a = g.standard_normal(shape)
-    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
+    """Deterministic name-keyed PCG64 tensor: both the golden script and the GPU box regenerate identical weights, so
+    no 378 MB checkpoint is ever committed.  The generator itself is plain numpy and lives with the other
+    synthetic-data helpers of the package (w2v2_speaker_amd/data/synthetic.py: bench.py's EER leg needs the goldens'
+    weights and must not import this directory); no arithmetic of the path is shared that way."""
+    from w2v2_speaker_amd.data.synthetic import synth_weight
+    return torch.from_numpy(synth_weight(name, shape, seed))
 
 
 def make_state_dict(cfg: OracleConfig, seed: int = 20211) -> StateDict:

@@ -263,3 +263,49 @@ def test_ecapa_full_size_f32_step_every_weight_gradient_and_running_statistics()
         assert float((t.running[:C].double() - exp_mean).abs().max()) < 1e-5 * float(exp_mean.abs().max() + 1), t.pre
         assert float((t.running[C:].double() - exp_var).abs().max()) < 1e-5 * float(exp_var.abs().max() + 1), t.pre
     print(f"full-size ECAPA f32: loss {float(loss):.4f}, worst weight-gradient rel-L2 vs f64 {worst:.2e} over {len(tdnns)} blocks")
+
+
+import os as _os
+import numpy as _np
+from conftest import GOLDEN as _GOLDEN
+_SB_DIR = _os.environ.get("W2V2_SB_GOLDEN_DIR", _GOLDEN)
+
+
+@pytest.mark.skipif(not _os.path.exists(_os.path.join(_SB_DIR, "g15_sb_ecapa_tiny.npz")),
+                    reason="no speechbrain golden (tests/golden/make_sb_goldens.py needs speechbrain): row a19 stays unpinned")
+def test_ecapa_vs_speechbrain_golden():
+    """SURVEY 8a row a19 against the REAL speechbrain ECAPA_TDNN (g15_sb_ecapa_tiny.npz, the tiny widths; ref:
+    src/lightning_modules/speaker/ecapa_tdnn.py:75-85): stages, embedding and every parameter gradient of the HIP path
+    (exact-f32 mode) for the golden's upstream gradient on the embedding."""
+    from w2v2_speaker_amd.ecapa import FE, EcapaConfig, EcapaPlan, EcapaStore
+    g = _np.load(_os.path.join(_SB_DIR, "g15_sb_ecapa_tiny.npz"), allow_pickle=False)
+    cfg, ocfg = EcapaConfig.tiny(), E.EcapaConfig.tiny()
+    st = EcapaStore(cfg, DEV, torch.float32, num_speakers=9)
+    sd = E.make_state_dict(ocfg, 20211)
+    sd["loss_fn.fc_weights"] = O.synth_tensor("loss_fn.fc_weights", (9, cfg.lin_neurons), 20211)
+    st.load_state_dict(sd)
+    feat = torch.from_numpy(g["feat"])
+    B, T = feat.shape[:2]
+    plan = EcapaPlan(st, B, T, train=True)
+    st.zero_grad()
+    emb = plan.embed(feat.to(DEV))
+    plan.head.demb.copy_(torch.from_numpy(g["upstream"]).to(DEV))          # the golden's loss is <embedding, upstream>
+    plan.backward()
+    torch.cuda.synchronize()
+    assert rel_l2(plan.x0.float().cpu().view(B, T, -1), g["stage.block0"]) < 2e-5
+    C1 = cfg.channels[1]
+    for i in (1, 2, 3):
+        assert rel_l2(plan.cat[:, (i - 1) * C1:i * C1].float().cpu().view(B, T, C1), g[f"stage.block{i}"]) < 5e-5, i
+    assert rel_l2(plan.mfa_out.float().cpu().view(B, T, -1), g["stage.mfa"]) < 5e-5
+    assert rel_l2(plan.pooled.cpu(), g["stage.asp"]) < 5e-5
+    assert rel_l2(emb.cpu(), g["embedding"]) < 1e-4
+    gmax = max(float(_np.linalg.norm(g[k])) for k in g.files if k.startswith("grad."))
+    bad = []
+    for k in g.files:
+        if not k.startswith("grad."):
+            continue
+        got = st.g(FE + k[len("grad."):]).double().cpu().numpy().reshape(g[k].shape)
+        err = float(_np.linalg.norm(got - g[k]))
+        if err > 3e-3 * float(_np.linalg.norm(g[k])) + 2e-6 * gmax:
+            bad.append((k, err))
+    assert not bad, bad[:8]

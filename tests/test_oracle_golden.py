@@ -265,3 +265,56 @@ def test_one_cycle_and_adam():
         assert abs(lr - g["lr"][i]) < 1e-12 and abs(b1 - g["beta1"][i]) < 1e-9, i
         O.adam_step(p, T(g["grads"][i]), m, v, i + 1, lr, b1)
         assert np.allclose(p.numpy(), g["params"][i], atol=1e-7), i
+
+
+# --------------------------------------------------------------------------- speechbrain goldens (rows a10 / a19), when present
+SB_DIR = os.environ.get("W2V2_SB_GOLDEN_DIR", GOLDEN)
+_have_sb = all(os.path.exists(os.path.join(SB_DIR, f)) for f in
+               ("g15_sb_asp.npz", "g15_sb_ecapa_tiny.npz", "g15_sb_seres2net.npz"))
+
+
+@pytest.mark.skipif(not _have_sb, reason="no speechbrain goldens: run tests/golden/make_sb_goldens.py where speechbrain "
+                                         "imports (absent here: rows a10 / a19 stay parity-unpinned)")
+def test_speechbrain_goldens_pin_the_asp_and_ecapa_restatements():
+    """tests/golden/g15_sb_*.npz come from the REAL speechbrain classes (make_sb_goldens.py): the oracle's restatement of
+    attentive statistics pooling (ref: src/layers/pooling.py:87-106), of ECAPA-TDNN (ref: ecapa_tdnn.py:75-85) and of one
+    full-width SE-Res2Net block must reproduce their outputs and every gradient."""
+    from oracle import ecapa_oracle as E
+    sbl = lambda n: np.load(os.path.join(SB_DIR, n), allow_pickle=False)
+    g = sbl("g15_sb_asp.npz")
+    x = T(g["x"]).requires_grad_(True)
+    names = {"tdnn.conv.weight": "tdnn.conv.conv.weight", "tdnn.conv.bias": "tdnn.conv.conv.bias",
+             "tdnn.norm.weight": "tdnn.norm.norm.weight", "tdnn.norm.bias": "tdnn.norm.norm.bias",
+             "conv.weight": "conv.conv.weight", "conv.bias": "conv.conv.bias"}
+    asp = {k: T(g["param." + v]).clone().requires_grad_(True) for k, v in names.items()}
+    y = O.attentive_stat_pool(x, asp)
+    (y * T(g["upstream"])).sum().backward()
+    assert rel_l2(y.detach(), g["out"]) < 2e-5
+    assert rel_l2(x.grad, g["dx"]) < 2e-4
+    for k, v in names.items():
+        assert rel_l2(asp[k].grad, g["grad." + v]) < 5e-4, v
+    g = sbl("g15_sb_ecapa_tiny.npz")
+    cfg = E.EcapaConfig.tiny()
+    sd = {k: v.clone().requires_grad_(True) for k, v in E.make_state_dict(cfg, 20211).items()}
+    feat = T(g["feat"]).requires_grad_(True)
+    emb, st = E.ecapa_forward(feat, sd, cfg, return_stages=True)
+    (emb * T(g["upstream"])).sum().backward()
+    for k in ("block0", "block1", "block2", "block3", "mfa", "asp"):
+        assert rel_l2(st[k].detach(), g["stage." + k]) < 5e-5, k
+    assert rel_l2(emb.detach(), g["embedding"]) < 1e-4
+    assert rel_l2(feat.grad, g["dfeat"]) < 2e-3
+    gmax = max(float(np.linalg.norm(g["grad." + n])) for n in sd)
+    for n, v in sd.items():
+        ref = g["grad." + n]
+        assert float(np.linalg.norm(v.grad.numpy() - ref)) <= 2e-3 * float(np.linalg.norm(ref)) + 1e-6 * gmax, n
+    g = sbl("g15_sb_seres2net.npz")
+    cfg = E.EcapaConfig()
+    full = {k: v.clone().requires_grad_(True) for k, v in E.make_state_dict(cfg, 20211).items() if k.startswith("blocks.1.")}
+    x = T(g["x"]).requires_grad_(True)
+    y = E.se_res2net_block(x, full, "blocks.1.", cfg, cfg.dilations[1])
+    (y * T(g["upstream"])).sum().backward()
+    assert rel_l2(y.detach(), g["out"]) < 5e-5
+    assert rel_l2(x.grad, g["dx"]) < 2e-3
+    for k, v in full.items():
+        ref = g["grad." + k[len("blocks.1."):]]
+        assert float(np.linalg.norm(v.grad.numpy() - ref)) <= 2e-3 * float(np.linalg.norm(ref)) + 1e-5, k

@@ -1054,3 +1054,42 @@ def test_overflow_anywhere_in_the_backward_chain_reaches_the_scanned_bucket(wher
     tr.train_step(wav, label, skip_layers=())
     torch.cuda.synchronize()
     assert int(st.scaler[3]) == 1 and torch.isfinite(st.flat).all() and not torch.equal(st.flat, p_before)
+
+
+SB_DIR = os.environ.get("W2V2_SB_GOLDEN_DIR", GOLDEN)
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(SB_DIR, "g15_sb_asp.npz")),
+                    reason="no speechbrain golden (tests/golden/make_sb_goldens.py needs speechbrain): row a10 stays unpinned")
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+def test_attentive_pooling_vs_speechbrain_golden(dtype):
+    """SURVEY 8a row a10 against the REAL speechbrain AttentiveStatisticsPooling(768) (g15_sb_asp.npz: C = 768, T = 149,
+    B = 4, training mode; ref: src/layers/pooling.py:87-106): output, input gradient and the six parameter gradients of the
+    HIP kernels (csrc/asp.hip + asp.py) for the golden's upstream gradient."""
+    from w2v2_speaker_amd.asp import ASP_PREFIX, AttentivePool
+    from w2v2_speaker_amd.config import W2V2Config
+    from w2v2_speaker_amd.params import ParamStore
+    g = np.load(os.path.join(SB_DIR, "g15_sb_asp.npz"), allow_pickle=False)
+    B, Tn, C = g["x"].shape
+    st = ParamStore(W2V2Config(), DEV, dtype, head="aam", num_speakers=10, attentive_pool=True)
+    st.init_weights(seed=1)
+    st.load_state_dict({ASP_PREFIX + k[len("param."):]: T(g[k]) for k in g.files if k.startswith("param.")}, strict=False)
+    rows = (B * Tn + 63) // 64 * 64
+    full = torch.zeros(rows, C, dtype=st.act_dtype, device=DEV)
+    x = full[:B * Tn]
+    x._w2v2_padded = full
+    x.copy_(T(g["x"]).view(B * Tn, C).to(DEV))
+    emb = torch.empty(B, 2 * C, dtype=torch.float32, device=DEV)
+    dx = torch.zeros(B * Tn, C, dtype=st.act_dtype, device=DEV)
+    pool = AttentivePool(st, x, emb, dx, B, Tn, True)
+    st.zero_grad()
+    pool.forward()
+    pool.backward(T(g["upstream"]).to(DEV))
+    torch.cuda.synchronize()
+    f32 = dtype == torch.float32
+    assert rel_l2(emb.cpu(), g["out"]) < (2e-5 if f32 else 3e-3)
+    assert rel_l2(dx.float().cpu().view(B, Tn, C), g["dx"]) < (1e-3 if f32 else 3e-2)
+    for k in g.files:
+        if k.startswith("grad."):
+            got = st.g(ASP_PREFIX + k[len("grad."):]).cpu().reshape(g[k].shape)
+            assert rel_l2(got, g[k]) < (2e-3 if f32 else 5e-2), k

@@ -118,7 +118,8 @@ class CAbiBucketAllReducer:
         self.comm.all_reduce_(chk, self.comm_stream)
         self.comm_stream.synchronize()
         c = chk.tolist()
-        if any(abs(self.world * c[4 + i] - c[i] * c[i]) > 0.5 for i in range(4)):          # n * sum(x^2) == (sum x)^2 iff all equal
+        n = self.comm.world                                                                # ranks that actually summed
+        if any(abs(n * c[4 + i] - c[i] * c[i]) > 0.5 for i in range(4)):                   # n * sum(x^2) == (sum x)^2 iff all equal
             raise RuntimeError("broadcast_parameters: ranks disagree on which state tensors exist (optimiser moments / "
                                "loss scale / host counters); create or load them on every rank first")
         for t in ts:

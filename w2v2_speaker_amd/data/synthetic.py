@@ -16,7 +16,8 @@ The same waveforms go through the reference (tests/golden/make_goldens.py `eer` 
 embeddings, scores and EER) and through the HIP path (tests/test_parity_gpu.py, bench.py `eer` field)."""
 from __future__ import annotations
 
-from typing import List, Tuple
+import math
+from typing import Dict, List, Sequence, Tuple
 
 import numpy as np
 
@@ -54,3 +55,50 @@ def score_trials(emb, trials) -> Tuple[List[int], List[float]]:
     gt = [t[0] for t in trials]
     sc = [float(np.clip((en[i] @ en[j] + 1.0) / 2.0, 0.0, 1.0)) for _, i, j in trials]
     return gt, sc
+
+
+# --------------------------------------------------------------------------- synthetic weights (no checkpoint offline)
+def _name_seed(name: str, seed: int) -> int:
+    h = 1469598103934665603
+    for ch in (name + f"#{seed}").encode():
+        h = ((h ^ ch) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+def synth_weight(name: str, shape: Sequence[int], seed: int) -> np.ndarray:
+    """Deterministic name-keyed PCG64 parameter (f32): the golden script (tests/golden/make_goldens.py, which loads these
+    weights into the REFERENCE's model), the CPU oracle and the GPU box regenerate identical weights from (name, seed),
+    so no 378 MB checkpoint is ever committed.  ``name`` = the HF state-dict key without the
+    ``wav2vec.model.`` prefix, or ``loss_fn.fc_weights`` / ``fc_list.*``."""
+    g = np.random.Generator(np.random.PCG64(_name_seed(name, seed)))
+    shape = tuple(shape)
+    leaf = name.rsplit(".", 1)[-1]
+    if name == "masked_spec_embed":
+        a = g.random(shape)                                     # HF:1253 uniform_()
+    elif name.endswith("parametrizations.weight.original0"):
+        a = 1.0 + 0.25 * g.standard_normal(shape)               # weight-norm gain g
+    elif "layer_norm" in name and leaf == "weight":
+        a = 1.0 + 0.1 * g.standard_normal(shape)
+    elif leaf == "bias":
+        a = 0.1 * g.standard_normal(shape)
+    elif name.startswith("feature_extractor") and leaf == "weight":
+        fan_in = shape[1] * shape[2]
+        a = math.sqrt(2.0 / fan_in) * 1.3 * g.standard_normal(shape)   # keep variance through GELU
+    elif name.endswith("original1"):
+        fan_in = shape[1] * shape[2]
+        a = math.sqrt(1.0 / fan_in) * g.standard_normal(shape)
+    elif len(shape) == 2:
+        a = math.sqrt(1.0 / shape[1]) * g.standard_normal(shape)
+    else:
+        a = g.standard_normal(shape)
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def synth_state_dict(shapes: Dict[str, Sequence[int]], seed: int, prefix: str = "wav2vec.model.") -> Dict[str, np.ndarray]:
+    """``shapes`` as ``ParamStore.shapes`` has them (reference-style keys): every parameter drawn from ``synth_weight``
+    under its HF name (``prefix`` stripped) -- the weights the reference goldens were generated with."""
+    out = {}
+    for n, shp in shapes.items():
+        key = n[len(prefix):] if n.startswith(prefix) else n
+        out[n] = synth_weight(key, shp, seed)
+    return out
