@@ -252,8 +252,9 @@ int w2v2_prepend_token(const void* x, void* y, float c, int B, int T, int H, int
  * weightnorm_bwd: from the packed weight gradient dwf[G][tap][ci][co] (f32; = the GEMM
  *   dwf_g[(tap,ci)][co] = sum_t xg_g[t][(tap,ci)] * dy_g[t][co], large dimension as M) -> dg[K],
  *   dv[H][H/G][K] (written, not added).
- * `sumsq` / `dot` are f32 scratch of 129*K floats: [0,K) the per-tap result, the rest per-block
- * partials that are folded in a fixed order (bitwise reproducible packed weights). */
+ * `sumsq` / `dot` are f32 scratch of w2v2_weightnorm_scratch_floats(H, G, K) = (1 + H)*K floats: [0,K) the per-tap
+ * result, the rest per-block partials (one block per output channel) that are folded in a fixed order (bitwise
+ * reproducible packed weights). */
 int w2v2_posconv_regroup(const void* x, void* xg, int B, int T, int H, int G, int K, int pad_left,
                          int dtype, void* stream);
 /* Weight gradient of the grouped positional conv as a correlation on the matrix cores (replaces the implicit-GEMM
@@ -272,10 +273,11 @@ int w2v2_posconv_wgrad(const void* dY, const void* xg, float* dwf, int B, int T,
  * Contract: ldc a multiple of 8 elements; xg, w, out and aux 16-byte aligned (else an error is returned). */
 int w2v2_posconv_direct(const void* xg, const void* w, void* out, void* aux, const float* bias, int B, int T, int G,
                         int Cg, int K, int64_t ldc, int mode, int dtype, void* stream);
-int w2v2_weightnorm_pack(const float* g, const float* v, float* sumsq /*[129*K]*/, void* wf,
+int64_t w2v2_weightnorm_scratch_floats(int H, int G, int K);
+int w2v2_weightnorm_pack(const float* g, const float* v, float* sumsq /*[(1+H)*K]*/, void* wf,
                          void* wb, int H, int G, int K, int dtype, void* stream);
 int w2v2_weightnorm_bwd(const float* g, const float* v, const float* sumsq, const float* dwf,
-                        float* dot /*[129*K]*/, float* dg, float* dv, int H, int G, int K,
+                        float* dot /*[(1+H)*K]*/, float* dg, float* dv, int H, int G, int K,
                         void* stream);
 
 /* ------------------------------------------------------------------------------------ attention
@@ -433,6 +435,13 @@ int w2v2_aam_softmax_fwd_bwd(const float* cos, const int64_t* label, float* soft
 int w2v2_normalize_bwd(const float* g, const void* x, int64_t ldx, const float* inv,
                        const float* dot, float* dx, int rows, int cols, int x_dtype, int add,
                        void* stream);
+/* Class-weight gradient of the AAM head in one launch (ref: the autograd of src/optim/loss/aam_softmax.py:55 through
+ * F.normalize(W)): dW[c][e] = inv_w[c] * (sum_b dcos_x[b][c] * emb[b][e] - W[c][e] * inv_w[c] * sum_b colprod[b][c]).
+ * dcos_x [B][ldc] and emb [B][E] in `dtype` (the head's 16-bit operands, or f32), colprod [B][C] f32 = g * cos per element
+ * (w2v2_aam_softmax_fwd_bwd), W [C][E] f32 master weights, dW [C][E] f32 WRITTEN.  E % 8 == 0, 16-byte aligned operands;
+ * fixed summation order. */
+int w2v2_aam_dw(const void* dcos_x, int64_t ldc, const void* emb, const float* colprod, const float* W,
+                const float* inv_w, float* dW, int B, int C, int E, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------ optimiser
  * torch.optim.Adam (ref: config/optim/algo/adam.yaml, src/main.py:323-335) over one flat f32

@@ -570,7 +570,7 @@ def test_posconv_forward_backward(dtype):
     xg = torch.zeros(B, G, Tp, Cg, dtype=dtype, device=DEV)
     o.posconv_regroup(xd, xg, B, T, H, G, K, K // 2)
     wf, wb = torch.zeros(G, Cg, K * Cg, dtype=dtype, device=DEV), torch.zeros(G, Cg, K * Cg, dtype=dtype, device=DEV)
-    sumsq = torch.zeros(129 * K, device=DEV)
+    sumsq = o.weightnorm_scratch(H, G, K, DEV)
     o.weightnorm_pack(g.to(DEV), v.to(DEV), sumsq, wf, wb, H, G, K)
     y = torch.zeros(B * T, H, dtype=dtype, device=DEV)
     ypre = torch.zeros(B * T, H, dtype=dtype, device=DEV)
@@ -588,7 +588,7 @@ def test_posconv_forward_backward(dtype):
     o.gemm(K * Cg, Cg, M, xg, P1, dwf, lda=Cg, ldb=H, ldc=Cg, transA=True, transB=True,
            a_seg=(T, G * Tp * Cg), batch=G, batch_inner=G, a_strides=(0, Tp * Cg), b_strides=(0, Cg),
            c_strides=(0, K * Cg * Cg))
-    dot, dg, dv = torch.zeros(129 * K, device=DEV), torch.zeros(K, device=DEV), torch.zeros(H, Cg, K, device=DEV)
+    dot, dg, dv = o.weightnorm_scratch(H, G, K, DEV), torch.zeros(K, device=DEV), torch.zeros(H, Cg, K, device=DEV)
     o.weightnorm_bwd(g.to(DEV), v.to(DEV), sumsq, dwf, dot, dg, dv, H, G, K)
     dyg = torch.zeros(B, G, Tp, Cg, dtype=dtype, device=DEV)
     o.posconv_regroup(P1, dyg, B, T, H, G, K, K - 1 - K // 2)

@@ -82,6 +82,7 @@ _SIGS = {
     "w2v2_posconv_regroup": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "w2v2_posconv_direct": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i64, c_i32, c_i32, c_vp]),
     "w2v2_posconv_wgrad": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    "w2v2_weightnorm_scratch_floats": (c_i64, [c_i32, c_i32, c_i32]),
     "w2v2_weightnorm_pack": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "w2v2_weightnorm_bwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
     "w2v2_softmax_fwd": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, c_i64, c_f32, c_u64, c_i32, c_vp]),
@@ -123,6 +124,7 @@ _SIGS = {
     "w2v2_row_invnorm": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_i32, c_i32, c_vp]),
     "w2v2_aam_softmax_fwd_bwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32,
                                          c_i32, c_i64, c_f32, c_f32, c_vp, c_vp, c_i32, c_i32, c_vp]),
+    "w2v2_aam_dw": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "w2v2_normalize_bwd": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "w2v2_adam_step": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32,
                                c_f32, c_f32, c_vp, c_i32, c_i32, c_vp]),

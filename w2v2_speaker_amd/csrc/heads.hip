@@ -4,6 +4,7 @@
 // the row norms, the margin + scale + softmax + cross-entropy row pass (forward AND the gradient
 // wrt the cosines in one sweep over [B, C]) and the F.normalize backward.
 #include "common.h"
+#include <stdlib.h>
 
 template <typename T>
 __global__ __launch_bounds__(256) void row_invnorm_kernel(const T* __restrict__ x, int64_t ld, float* __restrict__ inv,
@@ -13,7 +14,22 @@ __global__ __launch_bounds__(256) void row_invnorm_kernel(const T* __restrict__ 
   if (row >= rows) return;
   const T* xr = x + (int64_t)row * ld;
   float s = 0.f;
-  for (int c = lane; c < cols; c += 64) { const float v = to_f32<T>(xr[c]); s = fmaf(v, v, s); }
+  if constexpr (sizeof(T) == 4) {
+    if ((cols & 3) == 0 && (ld & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
+      // 16-byte loads, all of a lane's loads independent (the AAM class weights: 37 MB per step)
+      const float4* x4 = reinterpret_cast<const float4*>(xr);
+      float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+      for (int c = lane; c < (cols >> 2); c += 64) {
+        const float4 v = x4[c];
+        s = fmaf(v.x, v.x, s); s1 = fmaf(v.y, v.y, s1); s2 = fmaf(v.z, v.z, s2); s3 = fmaf(v.w, v.w, s3);
+      }
+      s = (s + s1) + (s2 + s3);
+    } else {
+      for (int c = lane; c < cols; c += 64) { const float v = to_f32<T>(xr[c]); s = fmaf(v, v, s); }
+    }
+  } else {
+    for (int c = lane; c < cols; c += 64) { const float v = to_f32<T>(xr[c]); s = fmaf(v, v, s); }
+  }
   s = wave_sum(s);
   if (lane == 0) inv[row] = 1.0f / fmaxf(sqrtf(s), 1e-12f);   // F.normalize eps
 }
@@ -167,6 +183,153 @@ extern "C" int w2v2_normalize_bwd(const float* g, const void* x, int64_t ldx, co
     hipLaunchKernelGGL(normalize_bwd_kernel<AT>, dim3(nb), dim3(256), 0, as_stream(stream), g, (const AT*)x,
                        ldx, inv, dot, dx, rows, cols, add););
   W2V2_CHECK_LAUNCH("normalize_bwd");
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------ AAM class-weight gradient
+// dW of the AAM head in ONE launch (round 5; was: a [C x E x B] product on the generic register-staged GEMM into an f32
+// scratch, a column sum, and the normalisation backward = 67 us for a memory-sized job):
+//   H1[c][e] = sum_b dcos_x[b][c] * emb[b][e]            (the B = 66 rows are the contraction: an outer-product stream)
+//   dot[c]   = sum_b colprod[b][c]                       (fixed order: bitwise reproducible)
+//   dW[c][e] = inv_w[c] * (H1[c][e] - W[c][e] * inv_w[c] * dot[c])         (F.normalize backward, see normalize_bwd)
+// A workgroup owns CB classes x all E columns (thread = columns tid + 256 j), accumulators in registers, the batch rows
+// staged through LDS 64 at a time.  ref: the autograd of src/optim/loss/aam_softmax.py:55 (F.linear of normalised operands).
+// Round 5, second form: a workgroup owns 16 classes x 512 columns; the batch rows it contracts over are staged through
+// LDS 64 at a time (one burst of 16-byte loads, then no global access in the inner loop), a thread keeps 4 columns x 8
+// classes in registers (packed f32 FMAs).  The first form re-read every embedding row from L2 per 6-row chunk and was
+// bound by those round trips (65 us).
+constexpr int ADW_CB = 16, ADW_EC = 512, ADW_BC = 36;   // 36 staged rows = 39 KiB of LDS: four workgroups per CU, so
+// that one's W / dW streaming (74 MB per launch: the HBM floor is 12 us) runs under another's FMAs
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+template <typename T>
+__global__ __launch_bounds__(256) void aam_dw_kernel(const T* __restrict__ dcos_x, int64_t ldc, const T* __restrict__ emb,
+                                                     const float* __restrict__ colprod, const float* __restrict__ W,
+                                                     const float* __restrict__ inv_w, float* __restrict__ dW, int B,
+                                                     int Cn, int E, int chunk) {
+  extern __shared__ __attribute__((aligned(16))) char adw_raw[];
+  T* es = reinterpret_cast<T*>(adw_raw);                                        // [ADW_BC][ADW_EC]
+  float* dc = reinterpret_cast<float*>(adw_raw + (size_t)ADW_BC * ADW_EC * sizeof(T));   // [ADW_BC][ADW_CB]
+  float* cdp = dc + ADW_BC * ADW_CB;                                            // [16][ADW_CB]
+  float* cd = cdp + 16 * ADW_CB;                                                // [ADW_CB]
+  const int c0 = blockIdx.x * ADW_CB, ecol0 = blockIdx.y * ADW_EC, tid = threadIdx.x;
+  const int q = tid & 127, h = tid >> 7;            // column quad, class half (wave-uniform)
+  const int e0 = ecol0 + 4 * q;
+  f32x2_t acc[4][4];                                // [column][class pair of this half]
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[j][k] = f32x2_t{0.f, 0.f};
+  {     // column dots: thread -> (class k = tid % CB, batch lane tid / CB); lanes folded in a fixed order
+    const int k = tid % ADW_CB, bl = tid / ADW_CB;
+    float s = 0.f;
+    if (c0 + k < Cn)
+      for (int b = bl; b < B; b += 256 / ADW_CB) s += colprod[(int64_t)b * Cn + c0 + k];
+    cdp[bl * ADW_CB + k] = s;
+  }
+  constexpr int VPR = ADW_EC * sizeof(T) / 16;      // 16-byte vectors per staged row
+  constexpr int EPV = 16 / sizeof(T);               // elements per vector
+  for (int b0 = 0; b0 < B; b0 += chunk) {          // chunk <= ADW_BC rows, equal parts of B (host)
+    const int nb = min(chunk, B - b0);
+    __syncthreads();
+    // (all loads of a pass in flight before the first LDS store: written as load-store pairs the fill was a chain of
+    // sixteen L2 round trips per thread)
+    for (int i0 = tid; i0 < nb * VPR; i0 += 256 * 8) {
+      uint4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + 256 * u, r = i / VPR, vcol = i - r * VPR;
+        v[u] = make_uint4(0, 0, 0, 0);
+        if (i < nb * VPR && ecol0 + vcol * EPV < E)
+          v[u] = *reinterpret_cast<const uint4*>(emb + (int64_t)(b0 + r) * E + ecol0 + vcol * EPV);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + 256 * u, r = i / VPR, vcol = i - r * VPR;
+        if (i < nb * VPR) *reinterpret_cast<uint4*>(es + (int64_t)r * ADW_EC + vcol * EPV) = v[u];
+      }
+    }
+    {
+      constexpr int NDV = (ADW_BC * ADW_CB + 255) / 256;
+      float dv[NDV];
+#pragma unroll
+      for (int u = 0; u < NDV; ++u) {
+        const int i = tid + 256 * u, r = i / ADW_CB, k = i - r * ADW_CB;
+        dv[u] = (r < nb && c0 + k < Cn) ? to_f32<T>(dcos_x[(int64_t)(b0 + r) * ldc + c0 + k]) : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < NDV; ++u)
+        if (tid + 256 * u < ADW_BC * ADW_CB) dc[tid + 256 * u] = dv[u];
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int r = 0; r < nb; ++r) {
+      float x[4];
+      if constexpr (sizeof(T) == 2) {
+        const uint2 w = *reinterpret_cast<const uint2*>(es + r * ADW_EC + 4 * q);
+        unpack2<T>(w.x, x[0], x[1]);
+        unpack2<T>(w.y, x[2], x[3]);
+      } else {
+        const float4 w = *reinterpret_cast<const float4*>(es + r * ADW_EC + 4 * q);
+        x[0] = w.x; x[1] = w.y; x[2] = w.z; x[3] = w.w;
+      }
+      const float4 d0 = *reinterpret_cast<const float4*>(dc + r * ADW_CB + h * 8);
+      const float4 d1 = *reinterpret_cast<const float4*>(dc + r * ADW_CB + h * 8 + 4);
+      const f32x2_t d[4] = {{d0.x, d0.y}, {d0.z, d0.w}, {d1.x, d1.y}, {d1.z, d1.w}};
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[j][k] = __builtin_elementwise_fma(d[k], f32x2_t{x[j], x[j]}, acc[j][k]);
+    }
+  }
+  __syncthreads();
+  if (tid < ADW_CB) {
+    float s = 0.f;
+    for (int l = 0; l < 256 / ADW_CB; ++l) s += cdp[l * ADW_CB + tid];
+    cd[tid] = s;
+  }
+  __syncthreads();
+  if (e0 >= E) return;
+  // the eight W rows of this thread in flight together (a per-class load -> use -> store chain was eight HBM round trips)
+  float4 wv[8];
+  float ivv[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int c = min(c0 + h * 8 + k, Cn - 1);
+    wv[k] = *reinterpret_cast<const float4*>(W + (int64_t)c * E + e0);
+    ivv[k] = inv_w[c];
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int c = c0 + h * 8 + k;
+    const float iv = ivv[k], sc = iv * cd[h * 8 + k];
+    const float w4[4] = {wv[k].x, wv[k].y, wv[k].z, wv[k].w};
+    float o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = iv * (acc[j][k >> 1][k & 1] - w4[j] * sc);
+    if (c < Cn) *reinterpret_cast<float4*>(dW + (int64_t)c * E + e0) = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+extern "C" int w2v2_aam_dw(const void* dcos_x, int64_t ldc, const void* emb, const float* colprod, const float* W,
+                           const float* inv_w, float* dW, int B, int Cn, int E, int dtype, void* stream) {
+  W2V2_REQUIRE(dcos_x && emb && colprod && W && inv_w && dW && B > 0 && Cn > 0 && E > 0 && ldc >= Cn, "aam_dw: bad arguments");
+  W2V2_REQUIRE(E % 8 == 0 && ((uintptr_t)emb | (uintptr_t)W | (uintptr_t)dW) % 16 == 0,
+               "aam_dw: embedding dim %d must be a multiple of 8 and the operands 16-byte aligned (else: the GEMM path)", E);
+  dim3 grid((unsigned)cdiv(Cn, ADW_CB), (unsigned)cdiv(E, ADW_EC));
+  hipStream_t st = as_stream(stream);
+  W2V2_DISPATCH_ACT(dtype, "aam_dw", {
+    const size_t lds = (size_t)ADW_BC * ADW_EC * sizeof(AT) + (size_t)(ADW_BC * ADW_CB + 16 * ADW_CB + ADW_CB) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&aam_dw_kernel<AT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds);
+      attr_set = true;
+    }
+    const int nchunk = (int)cdiv(B, ADW_BC), chunk = (int)cdiv(B, nchunk);
+    hipLaunchKernelGGL(aam_dw_kernel<AT>, grid, dim3(256), lds, st, (const AT*)dcos_x, ldc, (const AT*)emb, colprod, W, inv_w,
+                       dW, B, Cn, E, chunk);
+  });
+  W2V2_CHECK_LAUNCH("aam_dw");
   return 0;
 }
 

@@ -195,7 +195,7 @@ class Plan:
         self.pos_direct = (ops.is16(self.adt) and self.Cg == 48 and K == 128 and not os.environ.get("W2V2_NO_POSCONV_DIRECT"))
         self.xg = self._e(B, G, self.Tp, self.Cg)
         self.posw_f, self.posw_b = self._e(G, self.Cg, K * self.Cg), self._e(G, self.Cg, K * self.Cg)
-        self.pos_sumsq = self._e(129 * K, dtype=f32)
+        self.pos_sumsq = ops.weightnorm_scratch(H, G, K, self.dev)
         self.pos = self._e(M, H)                               # GELU(posconv) -> overwritten with s0
         self.pos_pre = self._e(M, H) if self.train else None
         self.mean0, self.rstd0 = self._e(M, dtype=f32), self._e(M, dtype=f32)
@@ -259,7 +259,7 @@ class Plan:
             self.P1 = self._e(M, H)
             self.dyg = self._e(B, G, self.Tp, self.Cg)
             self.dwf = self._e(G, K * self.Cg, self.Cg, dtype=f32)
-            self.pos_dot = self._e(129 * K, dtype=f32)
+            self.pos_dot = ops.weightnorm_scratch(H, G, K, self.dev)
             self.dn = self._e(self.M0, C[-1])
             self.G0 = self._ep(self.M0, H, proj_pad) if (self.cls or self.paired) else None
             if self.fused:

@@ -65,11 +65,14 @@ class ClassifierHead:
             if rest:
                 self.g_dx.append(Gemm(B, E, rest, self.dcos_w.view(-1)[S * Kc:], w_operand.view(-1)[S * Kc * E:],
                                       self.dx_parts[S], lda=self.ldc, ldb=E, ldc=E, transB=True))
-            if aam:
+            # AAM class-weight gradient: product, column dots and the F.normalize backward in ONE launch (csrc/heads.hip
+            # aam_dw_kernel) when E % 8 == 0; other embeddings keep the three-launch GEMM path
+            self.fused_dw = aam and E % 8 == 0
+            if aam and not self.fused_dw:
                 self.H1 = torch.empty(Cn, E, dtype=f32, device=dev)
                 self.g_dw = Gemm(Cn, E, B, self.dcos_x, self.emb_lp, self.H1, lda=self.ldc, ldb=E, ldc=E,
                                  transA=True, transB=True)
-            else:
+            elif not aam:
                 self.g_dw = Gemm(Cn, E, B, self.dcos_x, self.emb_lp, w_grad, lda=self.ldc, ldb=E, ldc=E,
                                  transA=True, transB=True, accumulate=True)
 
@@ -101,9 +104,13 @@ class ClassifierHead:
             ops.colsum(self.dx_parts, self.G1.view(-1), self.dx_parts.shape[0], B * E)    # <= 128 rows: one writer
             if aam:
                 ops.normalize_bwd(self.G1, self.emb, self.inv_x, self.rowdot, self.demb, B, E)
-                self.g_dw()
-                ops.colsum(self.colprod, self.coldot, B, Cn)
-                ops.normalize_bwd(self.H1, self.w_master, self.inv_w, self.coldot, self.w_grad, Cn, E)
+                if self.fused_dw:
+                    ops.aam_dw(self.dcos_x, self.emb_lp, self.colprod, self.w_master, self.inv_w, self.w_grad, B, Cn, E,
+                               self.ldc)
+                else:
+                    self.g_dw()
+                    ops.colsum(self.colprod, self.coldot, B, Cn)
+                    ops.normalize_bwd(self.H1, self.w_master, self.inv_w, self.coldot, self.w_grad, Cn, E)
             else:
                 self.demb.copy_(self.G1)
                 self.g_dw()

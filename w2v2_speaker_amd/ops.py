@@ -467,6 +467,11 @@ def posconv_regroup(x, xg, B: int, T: int, H: int, G: int, K: int, pad_left: int
                "posconv_regroup")
 
 
+def weightnorm_scratch(H: int, G: int, K: int, device) -> torch.Tensor:
+    """f32 scratch of weightnorm_pack (``sumsq``) / weightnorm_bwd (``dot``): per-tap result + per-block partials."""
+    return torch.empty(int(lib().w2v2_weightnorm_scratch_floats(H, G, K)), dtype=torch.float32, device=device)
+
+
 def weightnorm_pack(g, v, sumsq, wf, wb, H: int, G: int, K: int) -> None:
     _dev(g, v, sumsq, wf, wb)
     _lib.check(lib().w2v2_weightnorm_pack(g.data_ptr(), v.data_ptr(), sumsq.data_ptr(), wf.data_ptr(),
@@ -548,6 +553,14 @@ def normalize_bwd(g, x, inv, dot, dx, rows: int, cols: int, ldx: Optional[int] =
     _lib.check(lib().w2v2_normalize_bwd(g.data_ptr(), x.data_ptr(), ldx if ldx is not None else cols, inv.data_ptr(),
                                         dot.data_ptr(), dx.data_ptr(), rows, cols, dt(x), int(add_to), stream()),
                "normalize_bwd")
+
+
+def aam_dw(dcos_x, emb, colprod, w_master, inv_w, dw, B: int, Cn: int, E: int, ldc: int) -> None:
+    """Class-weight gradient of the AAM head (product + column dots + F.normalize backward) in one launch."""
+    _dev(dcos_x, emb, colprod, w_master, inv_w, dw)
+    assert emb.dtype == dcos_x.dtype and dw.dtype == torch.float32 and w_master.dtype == torch.float32
+    _lib.check(lib().w2v2_aam_dw(dcos_x.data_ptr(), ldc, emb.data_ptr(), colprod.data_ptr(), w_master.data_ptr(),
+                                 inv_w.data_ptr(), dw.data_ptr(), B, Cn, E, dt(emb), stream()), "aam_dw")
 
 
 # ------------------------------------------------------------------------------------------------ optimiser

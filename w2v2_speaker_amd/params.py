@@ -521,7 +521,7 @@ class ParamStore:
             self._zero_tables = self._build_zero_tables()
         small, per_layer = self._zero_tables
         if small.shape[0]:
-            ops.zero_ranges(self.grad, small, blocks_per_range=4)
+            ops.zero_ranges(self.grad, small, blocks_per_range=16)
         for l in skip_layers:
             ops.zero_ranges(self.grad, per_layer[l], blocks_per_range=512)
 
@@ -537,6 +537,10 @@ class ParamStore:
         # (the projection's gradient is the fixed-order SUM of per-slice partials added into a zeroed target: not listed)
         if self.head == "aam":
             written.add("loss_fn.fc_weights")
+        # the weight-norm backward WRITES both halves of the pos-conv weight pair (csrc/posconv.hip wn_bwd_*): 19 MB that
+        # round 4 zeroed first, on 4 workgroups (39 us)
+        written |= {P + "encoder.pos_conv_embed.conv.parametrizations.weight.original0",
+                    P + "encoder.pos_conv_embed.conv.parametrizations.weight.original1"}
         rng = []
         for n, off in sorted(self.offsets.items(), key=lambda kv: kv[1]):
             if off >= self.n_train or n in written:
