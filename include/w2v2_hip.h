@@ -213,6 +213,9 @@ int w2v2_layernorm_bwd_fold(const w2v2_ln_fold* entries, int n, int M, int H, vo
 int w2v2_dropout(const void* x, void* y, int64_t n, float p, uint64_t seed, int dtype, void* stream);
 /* dx = dy * gelu'(pre)  (exact erf GELU, ACT2FN["gelu"]). */
 int w2v2_gelu_bwd(const void* dy, const void* pre, void* dx, int64_t n, int dtype, void* stream);
+/* dx[m][n] = dy * gelu'(pre) over a dense [M][N] matrix and colsum[n] += sum_m dx[m][n] (f32 atomics, caller zeroes):
+ * GELU backward of the positional convolution fused with its bias gradient (HF:360-368).  N % 8 == 0, 16-byte aligned. */
+int w2v2_gelu_bwd_colsum(const void* dy, const void* pre, void* dx, float* colsum, int M, int N, int dtype, void* stream);
 /* y = x + a (gradient joins). */
 int w2v2_add(const void* x, const void* a, void* y, int64_t n, int dtype, void* stream);
 /* out[n] += sum_m x[m][n]   (bias gradients; f32 atomics, caller zeroes). */

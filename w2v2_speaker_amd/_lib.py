@@ -70,6 +70,7 @@ _SIGS = {
                                    c_f32, c_u64, c_i32, c_vp]),
     "w2v2_layernorm_bwd_fold": (c_i32, [C.POINTER(LnFold), c_i32, c_i32, c_i32, c_vp]),
     "w2v2_dropout": (c_i32, [c_vp, c_vp, c_i64, c_f32, c_u64, c_i32, c_vp]),
+    "w2v2_gelu_bwd_colsum": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
     "w2v2_gelu_bwd": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, c_vp]),
     "w2v2_add": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, c_vp]),
     "w2v2_colsum": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_i32, c_i32, c_vp]),

@@ -317,26 +317,28 @@ __global__ __launch_bounds__(256, 3) void ln_bwd16_kernel(const T* __restrict__ 
 }
 
 // fold the per-block column partials in a fixed order (deterministic) and add them to dgamma / dbeta:
-// 32 columns x 8 block lanes per workgroup, each lane sums every 8th block (independent loads, unrolled),
-// then a fixed-order LDS fold over the 8 lanes
-__global__ __launch_bounds__(256) void ln_bwd_finalize_kernel(const float* __restrict__ partial,
-                                                              float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                              int nblk, int H) {
-  __shared__ float red[8][32];
+// 32 columns x 32 block lanes per workgroup (round 5: 1024 threads; with 8 lanes a thread walked 96 partial rows and a
+// four-LayerNorm fold took 11.6 us), each lane sums every 32nd block (independent loads, unrolled), then a fixed-order
+// LDS fold over the 32 lanes
+constexpr int LN_FOLD_LANES = 32;
+__global__ __launch_bounds__(1024) void ln_bwd_finalize_kernel(const float* __restrict__ partial,
+                                                               float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                               int nblk, int H) {
+  __shared__ float red[LN_FOLD_LANES][32];
   const int cl = threadIdx.x & 31, bl = threadIdx.x >> 5;
   const int i = blockIdx.x * 32 + cl;                 // index into [2][H]
   float s = 0.f;
   if (i < 2 * H) {
     const int pass = i / H, col = i - pass * H;
 #pragma unroll 8
-    for (int b = bl; b < nblk; b += 8) s += partial[((int64_t)b * 2 + pass) * H + col];
+    for (int b = bl; b < nblk; b += LN_FOLD_LANES) s += partial[((int64_t)b * 2 + pass) * H + col];
   }
   red[bl][cl] = s;
   __syncthreads();
   if (bl == 0 && i < 2 * H) {
     float t = 0.f;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) t += red[k][cl];
+    for (int k = 0; k < LN_FOLD_LANES; ++k) t += red[k][cl];
     const int pass = i / H, col = i - pass * H;
     float* dst = (pass == 0 ? dgamma : dbeta) + col;
     *dst += t;
@@ -350,8 +352,8 @@ struct LnFoldArgs {
   float* dgamma[8];
   float* dbeta[8];
 };
-__global__ __launch_bounds__(256) void ln_bwd_finalize_many_kernel(const LnFoldArgs a, int nblk, int H) {
-  __shared__ float red[8][32];
+__global__ __launch_bounds__(1024) void ln_bwd_finalize_many_kernel(const LnFoldArgs a, int nblk, int H) {
+  __shared__ float red[LN_FOLD_LANES][32];
   const float* __restrict__ partial = a.partial[blockIdx.y];
   const int cl = threadIdx.x & 31, bl = threadIdx.x >> 5;
   const int i = blockIdx.x * 32 + cl;                 // index into [2][H]
@@ -359,14 +361,14 @@ __global__ __launch_bounds__(256) void ln_bwd_finalize_many_kernel(const LnFoldA
   if (i < 2 * H) {
     const int pass = i / H, col = i - pass * H;
 #pragma unroll 8
-    for (int b = bl; b < nblk; b += 8) s += partial[((int64_t)b * 2 + pass) * H + col];
+    for (int b = bl; b < nblk; b += LN_FOLD_LANES) s += partial[((int64_t)b * 2 + pass) * H + col];
   }
   red[bl][cl] = s;
   __syncthreads();
   if (bl == 0 && i < 2 * H) {
     float t = 0.f;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) t += red[k][cl];
+    for (int k = 0; k < LN_FOLD_LANES; ++k) t += red[k][cl];
     const int pass = i / H, col = i - pass * H;
     float* dst = (pass == 0 ? a.dgamma[blockIdx.y] : a.dbeta[blockIdx.y]) + col;
     *dst += t;
@@ -382,7 +384,7 @@ extern "C" int w2v2_layernorm_bwd_fold(const w2v2_ln_fold* e, int n, int M, int 
     a.partial[i] = e[i].partial; a.dgamma[i] = e[i].dgamma; a.dbeta[i] = e[i].dbeta;
   }
   const int nb = (int)(cdiv(M, 4) < LN_BWD_BLOCKS ? cdiv(M, 4) : LN_BWD_BLOCKS);
-  hipLaunchKernelGGL(ln_bwd_finalize_many_kernel, dim3((unsigned)cdiv(2 * H, 32), n), dim3(256), 0, as_stream(stream),
+  hipLaunchKernelGGL(ln_bwd_finalize_many_kernel, dim3((unsigned)cdiv(2 * H, 32), n), dim3(32 * LN_FOLD_LANES), 0, as_stream(stream),
                      a, nb, H);
   W2V2_CHECK_LAUNCH("layernorm_bwd_fold");
   return 0;
@@ -430,7 +432,7 @@ extern "C" int w2v2_layernorm_bwd(const void* dy, const void* s, const float* me
                          drop_p, seed););
   }
   if (partial != nullptr && dgamma != nullptr)
-    hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3((unsigned)cdiv(2 * H, 32)), dim3(256), 0, as_stream(stream),
+    hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3((unsigned)cdiv(2 * H, 32)), dim3(32 * LN_FOLD_LANES), 0, as_stream(stream),
                        partial, dgamma, dbeta, nb, H);
   W2V2_CHECK_LAUNCH("layernorm_bwd");
   return 0;

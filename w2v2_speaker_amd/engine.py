@@ -706,8 +706,11 @@ class Plan:
             ops.dropout_(self.G, ph, self._sd("prologue", 0, step))
         ops.layernorm_bwd(self.G, self.pos, self.mean0, self.rstd0, mp("encoder.layer_norm.weight"), self.G, None,
                           mg("encoder.layer_norm.weight"), mg("encoder.layer_norm.bias"))
-        ops.gelu_bwd(self.G, self.pos_pre, self.P1)
-        ops.colsum(self.P1, mg("encoder.pos_conv_embed.conv.bias"), M, H)
+        if H % 8 == 0:
+            ops.gelu_bwd_colsum(self.G, self.pos_pre, self.P1, mg("encoder.pos_conv_embed.conv.bias"), M, H)
+        else:
+            ops.gelu_bwd(self.G, self.pos_pre, self.P1)
+            ops.colsum(self.P1, mg("encoder.pos_conv_embed.conv.bias"), M, H)
         G_, K = cfg.num_conv_pos_embedding_groups, cfg.num_conv_pos_embeddings
         if ops.is16(self.P1.dtype) and not os.environ.get("W2V2_POS_DW_GEMM"):
             ops.posconv_wgrad(self.P1, self.xg, self.dwf, B, T, H, G_, K)      # correlation kernel (posconv_wgrad.hip)

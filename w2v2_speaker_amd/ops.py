@@ -375,6 +375,13 @@ def gelu_bwd(dy, pre, dx) -> None:
                "gelu_bwd")
 
 
+def gelu_bwd_colsum(dy, pre, dx, colsum_out, M: int, N: int) -> None:
+    """dx = dy * gelu'(pre) over [M, N] and colsum_out[n] += sum_m dx[m, n] in one pass."""
+    _dev(dy, pre, dx, colsum_out)
+    _lib.check(lib().w2v2_gelu_bwd_colsum(dy.data_ptr(), pre.data_ptr(), dx.data_ptr(), colsum_out.data_ptr(), M, N,
+                                          dt(dy), stream()), "gelu_bwd_colsum")
+
+
 def add(x, a, y) -> None:
     _dev(x, a, y)
     _lib.check(lib().w2v2_add(x.data_ptr(), a.data_ptr(), y.data_ptr(), x.numel(), dt(x), stream()), "add")
