@@ -68,7 +68,11 @@ def test_param_arena_layout_and_buckets():
     assert b[0][0] == "head" and b[0][1] == 0 and b[-1][2] == st.n_train
     for (n0, s0, e0), (n1, s1, e1) in zip(b, b[1:]):
         assert e0 == s1 and e0 > s0
-    assert [n for n, _, _ in b] == ["head", "layer1", "layer0", "prologue"]
+    assert [n for n, _, _ in b] == ["head", "layer1", "layer0", "prologue", "projection"]
+    # the late, unhideable slice is the small one (projection + masked embed + feature LayerNorm), the pos-conv pair
+    # rides in the bucket that is final before the pos-conv data gradient runs
+    bk = {n: (s, e) for n, s, e in b}
+    assert bk["projection"][1] - bk["projection"][0] < bk["prologue"][1] - bk["prologue"][0]
     # state-dict round trip incl. the old weight_g / weight_v naming
     sd = {k: torch.randn(v) for k, v in st.shapes.items()}
     old = {k.replace("parametrizations.weight.original0", "weight_g").replace("parametrizations.weight.original1", "weight_v"): v

@@ -755,7 +755,7 @@ def test_gradient_buckets_are_final_when_notified_under_layerdrop(dtype):
                     snaps.append((name, s, e, st.grad[s:e].clone()))
         plan.backward(on_bucket_ready=rec)
         torch.cuda.synchronize()
-        assert order == ["head"] + [f"layer{l}" for l in range(5, -1, -1)] + ["prologue"], order
+        assert order == ["head"] + [f"layer{l}" for l in range(5, -1, -1)] + ["prologue", "projection"], order
         for name, s, e, snap in snaps:
             assert torch.equal(snap, st.grad[s:e]), (skip, name)
         for l in skip:                                   # LayerDrop: zero gradient

@@ -662,7 +662,7 @@ class Plan:
                  dhidden: Optional[torch.Tensor] = None) -> None:
         """Backward of embed(): demb [B,E] f32 (default self.demb from the head) -> parameter gradients
         accumulated into store.grad.  on_bucket_ready(name) fires as soon as a gradient bucket
-        ('head', 'layer11', ..., 'layer0', 'prologue') is final, for the overlapped all-reduce."""
+        ('head', 'layer11', ..., 'layer0', 'prologue', 'projection') is final, for the overlapped all-reduce."""
         assert self.train, "backward needs a training plan"
         cfg, st, reg = self.cfg, self.store, self.reg
         B, T, M, H = self.B, self.T, self.M, cfg.hidden_size
@@ -720,6 +720,7 @@ class Plan:
                            mp("encoder.pos_conv_embed.conv.parametrizations.weight.original1"), self.pos_sumsq,
                            self.dwf, self.pos_dot, mg("encoder.pos_conv_embed.conv.parametrizations.weight.original0"),
                            mg("encoder.pos_conv_embed.conv.parametrizations.weight.original1"), H, G_, K)
+        notify("prologue")            # encoder LayerNorm, pos-conv bias and weight-norm pair are final (params.grad_buckets)
         ops.posconv_regroup(self.P1, self.dyg, B, T, H, G_, K, K - 1 - K // 2)
         if self.pos_direct:
             ops.posconv_direct(self.dyg, self.posw_b, self.G, self.G, None, B, T, G_, self.Cg, K, H, 1)
@@ -753,7 +754,7 @@ class Plan:
         ops.layernorm_bwd(self.dn, self.conv[-1].view(self.M0, -1), self.mean_f, self.rstd_f,
                           mp("feature_projection.layer_norm.weight"), self.dn, None,
                           mg("feature_projection.layer_norm.weight"), mg("feature_projection.layer_norm.bias"))
-        notify("prologue")
+        notify("projection")
         if not st.freeze_cnn:
             if not st.cnn_runtime_frozen:         # feature_extractor.requires_grad_(False) at run time: zero gradient
                 self._backward_cnn()

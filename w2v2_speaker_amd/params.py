@@ -268,7 +268,12 @@ class ParamStore:
         L = self.cfg.num_hidden_layers
         for l in reversed(range(L)):
             marks.append((f"layer{l}", self.offsets[W2V_PREFIX + f"encoder.layers.{l}.final_layer_norm.weight"]))
+        # the encoder prologue in two buckets: encoder LayerNorm + the pos-conv bias / weight-norm pair (19 of its 20 MB)
+        # are final as soon as the weight-norm backward has run, ~0.15 ms before backward ends; only the projection /
+        # masked-embed / feature-LayerNorm rest (1.6 MB) is final at the very end -- the slice whose all-reduce nothing can
+        # hide (profiles/r05_exposed_tail.txt)
         marks.append(("prologue", self.offsets[W2V_PREFIX + "encoder.layer_norm.weight"]))
+        marks.append(("projection", self.offsets[W2V_PREFIX + "masked_spec_embed"]))
         if not self.freeze_cnn:
             marks.append(("cnn", self.offsets[W2V_PREFIX + f"feature_extractor.conv_layers.{len(self.cfg.conv_dim) - 1}.conv.weight"]))
         out = []
