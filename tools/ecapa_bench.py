@@ -28,7 +28,9 @@ import torch
 
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E ~8 TB/s
 MFMA_PEAK_TFLOPS = 2500.0
-PMC_FILE = os.path.join(ROOT, "profiles", "r04_ecapa_pmc_counters.json")
+import glob as _glob
+PMC_FILE = (sorted(_glob.glob(os.path.join(ROOT, "profiles", "r0?_ecapa_pmc_counters.json"))) or
+            [os.path.join(ROOT, "profiles", "r04_ecapa_pmc_counters.json")])[-1]       # newest committed PMC pass
 
 
 FAMILY_KERNELS = {

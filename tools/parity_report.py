@@ -123,13 +123,59 @@ def base66(dtype):
     return out
 
 
+def long_utt(dtype):
+    from w2v2_speaker_amd.engine import Plan
+    g = load("g13_long.npz")
+    cfg, ocfg = _cfgs("base")
+    st, _ = _store(cfg, ocfg, dtype, None, 1)
+    wav, _ = O.synth_batch(1, 320000, 5994, seed=90017)
+    ev = Plan(st, 1, 320000, train=False)
+    e = ev.embed(wav.to(DEV))
+    torch.cuda.synchronize()
+    return {"eval_embedding": per_utt(e, g["eval.mean+std"]),
+            "hidden_states_sample_rel_l2": rel_l2(ev.out[:, ::37, ::16].float().cpu(), g["eval.last_hidden.sample"])}
+
+
+def seed3(dtype):
+    from w2v2_speaker_amd.engine import Plan
+    g = load("g14_seed3.npz")
+    cfg, ocfg = _cfgs("base")
+    st, _ = _store(cfg, ocfg, dtype, None, 1, seed=4099)
+    wav, _ = O.synth_batch(6, 64000, 5994, seed=60611)
+    ev = Plan(st, 6, 64000, train=False)
+    return {"eval_embedding": per_utt(ev.embed(wav.to(DEV)), g["eval.mean+std"])}
+
+
+def eer(dtype):
+    from w2v2_speaker_amd.data.synthetic import score_trials, synth_trial_set
+    from w2v2_speaker_amd.engine import Plan
+    from w2v2_speaker_amd.eval_metrics import calculate_eer, calculate_mdc
+    g = load("g12_eer.npz")
+    wav, _spk, _keys, trials = synth_trial_set()
+    cfg, ocfg = _cfgs("base")
+    st, _ = _store(cfg, ocfg, dtype, None, 1)
+    ev = Plan(st, wav.shape[0], wav.shape[1], train=False)
+    e = ev.embed(T(wav).to(DEV))
+    torch.cuda.synchronize()
+    gt, sc = score_trials(e.float().cpu().numpy(), trials)
+    er, _ = calculate_eer(gt, sc)
+    md, _ = calculate_mdc(gt, sc)
+    return {"eval_embedding": per_utt(e, g["embedding"]), "eer_hip": float(er), "eer_reference": float(g["eer"]),
+            "min_dcf_hip": float(md), "min_dcf_reference": float(g["mdc"]),
+            "max_abs_score_diff": float(np.abs(np.array(sc) - g["scores"]).max()), "trials": len(trials)}
+
+
 def main():
     rep = {"what": "HIP path vs reference-generated goldens (tests/golden, make_goldens.py); rel-L2 = ||got - ref|| / ||ref||",
            "device": torch.cuda.get_device_name(0), "goldens": {}}
     for name, fn, desc in (("g1_tiny", tiny, "tiny geometry, B=2: train forward + loss + every gradient, eval embedding"),
                            ("g2_base", base, "w2v2-base, B=2, 3 s: eval / train embedding, AAM loss, gradient norms"),
                            ("g10_base2", base2, "w2v2-base, other seed, B=8, 5 s: eval embedding"),
-                           ("g11_base66", base66, "w2v2-base, B=66, 3 s (BASELINE configs[1] at its own size): eval embedding")):
+                           ("g11_base66", base66, "w2v2-base, B=66, 3 s (BASELINE configs[1] at its own size): eval embedding"),
+                           ("g12_eer", eer, "w2v2-base, 32 synthetic trial utterances (8 speakers x 4), 496 trials: embedding, "
+                                            "scores, EER / minDCF against the reference's own evaluator"),
+                           ("g13_long", long_utt, "w2v2-base, ONE 20 s utterance at batch size 1 (T = 999): eval embedding"),
+                           ("g14_seed3", seed3, "w2v2-base, third weight seed, B=6, 4 s (T = 199): eval embedding")):
         rep["goldens"][name] = {"description": desc}
         for mode, dt in MODES.items():
             rep["goldens"][name][mode] = fn(dt)
