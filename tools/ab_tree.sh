@@ -6,6 +6,6 @@ R=${1:-3}; shift
 for i in $(seq $R); do
   for v in A B; do
     if [ $v = A ]; then B=tools/ab/tree/bench.py; else B=bench.py; fi
-    python3 $B --no-cpu-baseline --no-also --no-eer "$@" 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('$v', d['ms_per_step'], d.get('ms_per_step_median'), d['value'])"
+    python3 $B --no-cpu-baseline --no-also $(grep -q -- "--no-eer" $B && echo --no-eer) "$@" 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('$v', d['ms_per_step'], d.get('ms_per_step_median'), d['value'])"
   done
 done
