@@ -1417,3 +1417,59 @@ def test_grouped_weight_gradient_phased_kernel_ragged_problems(lp):
         if db is not None:
             refb = dy[:tokens].double().sum(0)
             assert float((db.double() - refb).norm() / refb.norm()) < 2e-6
+
+
+# ----------------------------------------------------------------------------------------------- round-5 small kernels
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("B,C,E", [(66, 5994, 1536), (7, 37, 192), (150, 1211, 768), (3, 16, 520)])
+def test_fused_aam_class_weight_gradient_vs_torch(B, C, E, dtype):
+    """w2v2_aam_dw (csrc/heads.hip): dW[c][e] = inv_w[c] * (sum_b dcos[b][c] emb[b][e] - W[c][e] inv_w[c] sum_b colprod[b][c])
+    = the autograd of F.linear(F.normalize(x), F.normalize(W)) wrt W (ref: src/optim/loss/aam_softmax.py:55) for a given
+    d(loss)/d(cos); ragged class / column / batch-chunk counts (B > 36 = several staged passes), every operand dtype."""
+    o = ops()
+    ldc = (C + 7) // 8 * 8
+    dcos = rnd(B, ldc, seed=1, scale=1e-2).to(dtype)
+    emb = rnd(B, E, seed=2).to(dtype)
+    W = rnd(C, E, seed=3)
+    colprod = rnd(B, C, seed=4, scale=1e-2)
+    inv_w = 1.0 / W.norm(dim=1)
+    dW = torch.full((C, E), float("nan"), device=DEV)
+    o.aam_dw(dcos.to(DEV), emb.to(DEV), colprod.to(DEV), W.to(DEV), inv_w.to(DEV), dW, B, C, E, ldc)
+    torch.cuda.synchronize()
+    H1 = dcos[:, :C].double().t() @ emb.double()
+    dot = colprod.double().sum(0)
+    ref = inv_w.double()[:, None] * (H1 - W.double() * (inv_w.double() * dot)[:, None])
+    assert torch.isfinite(dW).all()
+    assert rel_l2(dW.cpu(), ref) < 2e-6
+    # and it is the autograd of the normalised linear map when dcos / colprod come from an upstream gradient G
+    if dtype == torch.float32 and B <= 66:
+        Wr = W.double().clone().requires_grad_(True)
+        x = rnd(B, E, seed=2).double()
+        G = rnd(B, C, seed=9, scale=1e-2).double()
+        cos = torch.nn.functional.normalize(x) @ torch.nn.functional.normalize(Wr).t()
+        (cos * G).sum().backward()
+        inv_x = 1.0 / x.norm(dim=1)
+        dcx = torch.zeros(B, ldc)
+        dcx[:, :C] = (G * inv_x[:, None]).float()              # d(loss)/d(cos) * inv_x: what the row kernel hands over
+        dW2 = torch.empty(C, E, device=DEV)
+        o.aam_dw(dcx.to(DEV), x.float().to(DEV), (G * cos.detach()).float().to(DEV), W.to(DEV), inv_w.to(DEV), dW2, B, C, E, ldc)
+        torch.cuda.synchronize()
+        assert rel_l2(dW2.cpu(), Wr.grad) < 1e-5
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M,N", [(9834, 768), (301, 64), (17, 1024)])
+def test_gelu_backward_with_column_sums_in_one_pass(M, N, dtype):
+    """w2v2_gelu_bwd_colsum == w2v2_gelu_bwd followed by w2v2_colsum of the stored product (the pos-conv bias gradient)."""
+    o = ops()
+    dy, pre = rnd(M, N, seed=1).to(dtype).to(DEV), rnd(M, N, seed=2, scale=1.5).to(dtype).to(DEV)
+    dx_a, dx_b = torch.empty_like(dy), torch.empty_like(dy)
+    cs_a, cs_b = torch.full((N,), 0.25, device=DEV), torch.full((N,), 0.25, device=DEV)      # accumulates into its target
+    o.gelu_bwd_colsum(dy, pre, dx_a, cs_a, M, N)
+    o.gelu_bwd(dy, pre, dx_b)
+    o.colsum(dx_b, cs_b, M, N)
+    torch.cuda.synchronize()
+    assert torch.equal(dx_a, dx_b)
+    ref = 0.25 + dx_b.double().sum(0)
+    assert float((cs_a.double() - ref).abs().max()) < 1e-4 * float(dx_b.double().abs().sum(0).max()) + 1e-6
+    assert float((cs_b.double() - ref).abs().max()) < 1e-4 * float(dx_b.double().abs().sum(0).max()) + 1e-6
