@@ -45,6 +45,7 @@ _SIGS = {
     "w2v2_version": (c_i32, []),
     "w2v2_last_error": (C.c_char_p, []),
     "w2v2_gemm": (c_i32, [C.POINTER(GemmDesc), c_vp]),
+    "w2v2_gemm_kernel_of": (c_i32, [c_vp]),
     "w2v2_gemm_timed": (c_i32, [C.POINTER(GemmDesc), c_vp, c_i32]),
     "w2v2_timer_read": (c_i32, [c_i32, c_i32, c_vp]),
     "w2v2_tune_gemm_kernel": (c_i32, [c_i32]),

@@ -393,6 +393,17 @@ W2v2PendingTimer& w2v2_pending_timer() {
 }
 static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_timer_slots;
 extern "C" int w2v2_gemm(const w2v2_gemm_desc* d, void* stream);
+// Which kernel family w2v2_gemm sends a descriptor to, decided by the dispatch code ITSELF (a dry run: validation +
+// decision, no launch): 4 = phased 256x256, 2 = 256x128 ring, 1 = 128-row LDS-DMA kernel, 3 = register-staged, 9 = exact
+// f32; < 0 = the descriptor is rejected.  Profilers label launches with it instead of mirroring the heuristics.
+static thread_local int g_gemm_dry = 0, g_gemm_family = 0;
+extern "C" int w2v2_gemm_kernel_of(const w2v2_gemm_desc* d) {
+  g_gemm_dry = 1;
+  g_gemm_family = 0;
+  const int rc = w2v2_gemm(d, nullptr);
+  g_gemm_dry = 0;
+  return rc != 0 ? -1 : g_gemm_family;
+}
 extern "C" int w2v2_gemm_timed(const w2v2_gemm_desc* d, void* stream, int slot) {
   W2V2_REQUIRE(slot >= 0 && slot < (1 << 16), "w2v2_gemm_timed: slot %d out of range", slot);
   while ((int)g_timer_slots.size() <= slot) {
@@ -545,6 +556,8 @@ extern "C" int w2v2_gemm(const w2v2_gemm_desc* d, void* stream) {
       static const char* late_env = getenv("W2V2_PH_LATE");
       a.late_dma = late_env ? (late_env[0] != '0') : 0;
     }
+    g_gemm_family = huge ? 4 : big_ ? 2 : glds ? 1 : 3;
+    if (g_gemm_dry) return 0;                     // w2v2_gemm_kernel_of: the dispatch decision only, nothing launched
 #define W2V2_GEMM_LAUNCH(TE, TC)                                                                         \
     do {                                                                                                 \
       if (huge) w2v2_launch_phased_256x256(a, d->dtype_ab, d->dtype_c, d->M, d->N, d->batch, st);        \
@@ -569,6 +582,8 @@ extern "C" int w2v2_gemm(const w2v2_gemm_desc* d, void* stream) {
       return aligned16(o.ptr) && (o.ld % 4 == 0) && (o.seg_stride % 4 == 0) && (o.stride0 % 4 == 0) && (o.stride1 % 4 == 0);
     };
     a.A.vec_ok = vec4(d->A); a.B.vec_ok = vec4(d->B);
+    g_gemm_family = 9;
+    if (g_gemm_dry) return 0;
     w2v2_launch_gemm_f32(a, d->M, d->N, d->K, split, d->batch, st);       // gemm_f32.hip
   }
   W2V2_CHECK_LAUNCH("w2v2_gemm");

@@ -612,12 +612,13 @@ extern "C" int w2v2_wgrad_grouped(const w2v2_wgrad_problem* probs, int n, int to
   // 256x256 tiles when they alone fill >= 80 % of the CUs (e.g. the 8 problems of two w2v2-base blocks: 216 tiles)
   int64_t t4 = 0;
   for (int i = 0; i < n; ++i) t4 += cdiv(probs[i].n_out, 256) * cdiv(probs[i].n_in, 256);
-  int ncu = 256;
-  {
-    int dev = 0;
+  static int ncu_cached = 0;                         // (one device per process: queried once, not on every launch)
+  if (ncu_cached == 0) {
+    int dev = 0, v = 0;
     (void)hipGetDevice(&dev);
-    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
+    ncu_cached = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
   }
+  const int ncu = ncu_cached;
   // ... and when their rounds over the chip cost less than the rounds of 256x128 tiles (a 256x256 tile takes ~1.7x
   // the time of a 256x128 one; problems narrower than 256 rows -- the 128-channel Res2Net TDNNs of ECAPA -- leave
   // half of a 256x256 tile empty, so a mixed group can need MORE time on the large tiles)

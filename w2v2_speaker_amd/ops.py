@@ -112,26 +112,12 @@ class Gemm:
         self.kernel_class = ("mfma16" if lp else "f32") + "_" + ("t" if transA else "n") + ("n" if transB else "t")
         self.narrow = N <= 64
         self.out_is_act = is16(Cmat.dtype)
-        # mirrors the host dispatch of csrc/gemm.hip (w2v2_gemm): which kernel this descriptor launches
-        al16 = lambda t, ld, st: t is None or (t.data_ptr() % 16 == 0 and all(x % (16 // t.element_size()) == 0 for x in (ld, *st)))
-        fast = (lp and not transA and not transB and K % 64 == 0 and K >= 64 and al16(A, lda, a_strides + (a_seg[1],))
-                and al16(B, ldb, b_strides + (b_seg[1],)) and not os.environ.get("W2V2_NO_GLDS"))
-        if fast and split_k <= 1 and not accumulate and (b_lo is not None or (N >= 512 and M >= 1024)):
-            self.kernel_name = "gemm16_ring_256x128_kernel"
-            t4, t3 = -(-M // 256) * -(-N // 256), -(-M // 256) * -(-N // 128)      # csrc/gemm.hip: 256x256 vs 256x128 tiles
-            ncu = max(1, 256 - int(os.environ.get("W2V2_RESERVE_CUS", "0") or 0))
-            fill = lambda t: t / (-(-t // ncu) * ncu)
-            # 16-bit outputs reach the 256x256 kernel only through its full-line epilogue (csrc/gemm.hip `lines`)
-            lines = (not is16(Cmat.dtype)) or (al16(Cmat, ldc, c_strides) and N % 64 == 0 and al16(aux, ldaux, aux_strides))
-            ext = lambda ld, seg, rows: ((rows // seg[0] + 1) * seg[1] + seg[0] * ld if seg[0] > 0 else rows * ld) + K
-            fits32 = ext(lda, a_seg, M) < 2 ** 31 and ext(ldb, b_seg, N) < 2 ** 31
-            if (b_lo is None and N >= 512 and batch == 1 and t4 * 2 >= ncu and fill(t4) * 1.25 >= fill(t3) and lines
-                    and fits32 and N / (-(-N // 256) * 256) >= 0.9 and not os.environ.get("W2V2_NO_GEMM_PH")):
-                self.kernel_name = "gemm16_phased_256x256_kernel"
-        elif fast:
-            self.kernel_name = "gemm16_dma_128_kernel"
-        else:
-            self.kernel_name = "gemm16_regstage_kernel" if lp else "gemm_f32_mfma_kernel"
+        # which kernel this descriptor launches: asked of the library's own dispatch (a dry run of w2v2_gemm, round 5 --
+        # the Python mirror of its heuristics could disagree with an env-tuned or differently sized device)
+        fam = lib().w2v2_gemm_kernel_of(self._ref)
+        self.kernel_name = {4: "gemm16_phased_256x256_kernel", 2: "gemm16_ring_256x128_kernel", 1: "gemm16_dma_128_kernel",
+                            3: "gemm16_regstage_kernel", 9: "gemm_f32_mfma_kernel"}.get(fam, "gemm16_regstage_kernel" if lp
+                                                                                       else "gemm_f32_mfma_kernel")
 
     _prof = None
     _TIMED_KERNELS = ("gemm16_ring_256x128_kernel", "gemm16_phased_256x256_kernel")
