@@ -488,9 +488,24 @@ def golden_seed3():
     print("g14_seed3: emb norm", float(g["eval.mean+std"].norm()), "T", h.shape[1])
 
 
+def golden_seeds():
+    """How wide is the fp16 margin across WEIGHT seeds (every golden so far used three seeds)?  Five
+    more weight seeds x 4 utterances of 3 s through the reference wrapper (eval, mean+std): g16_seeds.npz holds the five
+    [4, 1536] embedding blocks; weights / utterances regenerate from (seed, 7000 + seed)."""
+    cfg = O.OracleConfig.base()
+    g = {"seeds": np.array([101, 202, 303, 404, 505], dtype=np.int64)}
+    for sd_ in g["seeds"].tolist():
+        w, _ = build_reference_wrapper(cfg, seed=sd_)
+        wav, _ = O.synth_batch(4, 48000, 5994, seed=7000 + sd_)
+        w.eval()
+        with torch.no_grad():
+            g[f"eval.mean+std.{sd_}"] = MeanStdStatPool1D(1)(w(torch.squeeze(wav)).transpose(2, 1))
+        print("g16_seeds: seed", sd_, "emb norm", float(g[f"eval.mean+std.{sd_}"].norm()))
+    np.savez_compressed(os.path.join(OUT, "g16_seeds.npz"), **to_np(g))
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["tiny", "base", "aam", "pool", "eval", "optim", "bce", "base2", "base66", "eer", "long", "seed3"]
+    which = sys.argv[1:] or ["tiny", "base", "aam", "pool", "eval", "optim", "bce", "base2", "base66", "eer", "long", "seed3", "seeds"]
     for wname in which:
         {"tiny": golden_tiny, "base": golden_base, "aam": golden_aam, "base66": golden_base66, "pool": golden_pool,
          "eval": golden_eval, "optim": golden_optim, "bce": golden_bce, "base2": golden_base2, "eer": golden_eer,
-         "long": golden_long, "seed3": golden_seed3}[wname]()
+         "long": golden_long, "seed3": golden_seed3, "seeds": golden_seeds}[wname]()

@@ -180,6 +180,20 @@ def test_evaluation_length_utterance_and_third_weight_seed_goldens():
     assert rel_l2(O.mean_std_pool(h), g["eval.mean+std"][:2]) < 1e-4
 
 
+def test_five_more_weight_seeds_golden_first_seed_reproduced_by_the_oracle():
+    """g16_seeds.npz (five more weight seeds through the reference): the oracle reproduces the first utterance of the first
+    and of the last seed (one utterance each keeps the CPU suite short)."""
+    g = load("g16_seeds.npz")
+    cfg = O.OracleConfig.base()
+    seeds = g["seeds"].tolist()
+    assert len(seeds) == 5
+    for sd_ in (seeds[0], seeds[-1]):
+        wav, _ = O.synth_batch(4, 48000, 5994, seed=7000 + sd_)
+        with torch.no_grad():
+            e = O.speaker_embedding(wav[:1], O.make_state_dict(cfg, sd_), cfg, "mean+std")
+        assert rel_l2(e.numpy(), g[f"eval.mean+std.{sd_}"][:1]) < 1e-4, sd_
+
+
 def test_aam_known_answers():
     g = load("g4_aam.npz")
     for margin, scale in ((0.2, 30.0), (0.3, 15.0)):

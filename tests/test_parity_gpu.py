@@ -305,6 +305,28 @@ def test_evaluation_length_utterance_and_third_weight_seed_vs_reference(dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+def test_five_more_weight_seeds_per_utterance_bound(dtype):
+    """How wide the fp16 margin is across WEIGHT seeds: five more reference goldens
+    (tests/golden/g16_seeds.npz, make_goldens.py `seeds`: seeds 101 .. 505, 4 utterances of 3 s each), every utterance
+    inside the 1e-3 bound of the benchmarked fp16 mode (f32 mode: 1e-4).  The measured maximum is printed."""
+    from w2v2_speaker_amd.engine import Plan
+    g = load("g16_seeds.npz")
+    cfg, ocfg = _cfgs("base")
+    worst = 0.0
+    for sd_ in g["seeds"].tolist():
+        st, _ = _store(cfg, ocfg, dtype, None, 1, seed=sd_)
+        wav, _ = O.synth_batch(4, 48000, 5994, seed=7000 + sd_)
+        ev = Plan(st, 4, 48000, train=False)
+        e = ev.embed(wav.to(DEV)).cpu()
+        ref = T(g[f"eval.mean+std.{sd_}"])
+        per_utt = (e - ref).norm(dim=1) / ref.norm(dim=1)
+        worst = max(worst, float(per_utt.max()))
+        assert float(per_utt.max()) < (1e-4 if dtype == torch.float32 else 1e-3), (sd_, per_utt)
+        del ev, st
+    print(f"five more weight seeds {dtype}: worst utterance rel-L2 {worst:.3e}")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
 def test_base_ce_head_1211_vs_reference_golden(dtype):
     """BASELINE configs[0]'s head at its real size: w2v2-base + Linear(1536 -> 1211) + cross-entropy
     (ref: wav2vec2_fc.py:199-210, cross_entropy.py:27-31) on the train-mode embedding of g2_base (injected mask, dropouts
