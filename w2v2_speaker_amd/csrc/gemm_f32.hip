@@ -19,14 +19,17 @@
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
+// (round 5 tried a single-buffered image, 33 KiB = 3 workgroups per CU, two barriers per K tile: 20.40 vs 20.32 ms over the
+// ECAPA step's products -- no gain, removed)
 template <bool TA, bool TB, int BM, int BN>
 __global__ __launch_bounds__(256, 2) void gemm_f32_mfma_kernel(const GemmArgs g) {
+  constexpr int NBUF = 2;
   constexpr int BK = 32, PA = BM + (TA ? 4 : 1), PB = BN + (TB ? 4 : 1);
   constexpr int FI = BM / 64, FJ = BN / 64;          // 32 x 32 MFMA blocks per wave
   constexpr int NA = BM / 32, NB = BN / 32;          // float4 per thread and operand tile
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float (*As)[BK][PA] = reinterpret_cast<float (*)[BK][PA]>(smem_raw);
-  float (*Bs)[BK][PB] = reinterpret_cast<float (*)[BK][PB]>(smem_raw + sizeof(float) * 2 * BK * PA);
+  float (*Bs)[BK][PB] = reinterpret_cast<float (*)[BK][PB]>(smem_raw + sizeof(float) * NBUF * BK * PA);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int tile = blockIdx.x;
@@ -103,16 +106,48 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma_kernel(const GemmArgs g)
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   const int nk = (kend - kbeg + BK - 1) / BK;
+  // Interior tiles of plain (unsegmented, 16-byte aligned) operands: the per-thread source pointers are formed ONCE and
+  // advance by a constant per K tile.  The general load_vec above re-derives row offsets, bounds and the vector / scalar
+  // choice for each of its 8 loads in every K tile (~500 mostly scalar instructions in front of the 64 MFMAs of a wave,
+  // round 5: the in-order wave cannot issue MFMAs meanwhile); it stays for edge tiles, segmented operands and K tails.
+  const bool fast_tile = g.A.vec_ok && g.B.vec_ok && g.A.seg_len <= 0 && g.B.seg_len <= 0 && m0 + BM <= g.M &&
+                         n0 + BN <= g.N;
+  const float* pa[NA];
+  const float* pb[NB];
+  int64_t adv_a = 0, adv_b = 0;
+  if (fast_tile) {
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+      const int c = tid + 256 * j;
+      if constexpr (!TA) pa[j] = Ab + (int64_t)(m0 + (c >> 3)) * g.A.ld + kbeg + (c & 7) * 4;
+      else pa[j] = Ab + (int64_t)(kbeg + c / (BM / 4)) * g.A.ld + m0 + (c % (BM / 4)) * 4;
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const int c = tid + 256 * j;
+      if constexpr (!TB) pb[j] = Bb + (int64_t)(n0 + (c >> 3)) * g.B.ld + kbeg + (c & 7) * 4;
+      else pb[j] = Bb + (int64_t)(kbeg + c / (BN / 4)) * g.B.ld + n0 + (c % (BN / 4)) * 4;
+    }
+    adv_a = TA ? (int64_t)BK * g.A.ld : BK;
+    adv_b = TB ? (int64_t)BK * g.B.ld : BK;
+  }
   float4 ra[NA], rb[NB];
-  const std::integral_constant<bool, TA> ta_c{};
-  const std::integral_constant<bool, TB> tb_c{};
-  const std::integral_constant<int, BM> bm_c{};
-  const std::integral_constant<int, BN> bn_c{};
+  auto load_tile = [&](int kt) {
+    const int k0 = kbeg + kt * BK;
+    if (fast_tile && k0 + BK <= kend) {
+#pragma unroll
+      for (int j = 0; j < NA; ++j) ra[j] = *reinterpret_cast<const float4*>(pa[j] + (int64_t)kt * adv_a);
+#pragma unroll
+      for (int j = 0; j < NB; ++j) rb[j] = *reinterpret_cast<const float4*>(pb[j] + (int64_t)kt * adv_b);
+    } else {
+#pragma unroll
+      for (int j = 0; j < NA; ++j) ra[j] = load_vec(g.A, Ab, std::integral_constant<bool, TA>{}, std::integral_constant<int, BM>{}, m0, g.M, k0, j);
+#pragma unroll
+      for (int j = 0; j < NB; ++j) rb[j] = load_vec(g.B, Bb, std::integral_constant<bool, TB>{}, std::integral_constant<int, BN>{}, n0, g.N, k0, j);
+    }
+  };
   if (nk > 0) {
-#pragma unroll
-    for (int j = 0; j < NA; ++j) ra[j] = load_vec(g.A, Ab, ta_c, bm_c, m0, g.M, kbeg, j);
-#pragma unroll
-    for (int j = 0; j < NB; ++j) rb[j] = load_vec(g.B, Bb, tb_c, bn_c, n0, g.N, kbeg, j);
+    load_tile(0);
 #pragma unroll
     for (int j = 0; j < NA; ++j) store_a1(0, ra[j], j);
 #pragma unroll
@@ -123,24 +158,29 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma_kernel(const GemmArgs g)
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
     const bool more = kt + 1 < nk;
-    if (more) {
+    if (more) load_tile(kt + 1);
+    // Fragments of k-step kk + 2 are requested BEFORE the MFMAs of step kk issue (two register sets, the scheduler fenced
+    // so that it cannot fold them back into one): left alone the compiler reuses one set, so every step's ds_reads
+    // queue behind the previous step's last MFMA issue and their latency sits in front of the next four MFMAs
+    float af[2][FI], bf[2][FJ];
+    auto frag = [&](int set, int kk) {
 #pragma unroll
-      for (int j = 0; j < NA; ++j) ra[j] = load_vec(g.A, Ab, ta_c, bm_c, m0, g.M, kbeg + (kt + 1) * BK, j);
+      for (int i = 0; i < FI; ++i) af[set][i] = As[cur][kk + kl][wm * (BM / 2) + i * 32 + rl];
 #pragma unroll
-      for (int j = 0; j < NB; ++j) rb[j] = load_vec(g.B, Bb, tb_c, bn_c, n0, g.N, kbeg + (kt + 1) * BK, j);
-    }
+      for (int j = 0; j < FJ; ++j) bf[set][j] = Bs[cur][kk + kl][wn * (BN / 2) + j * 32 + rl];
+    };
+    frag(0, 0);
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 2) {
-      float a[FI], b[FJ];
-#pragma unroll
-      for (int i = 0; i < FI; ++i) a[i] = As[cur][kk + kl][wm * (BM / 2) + i * 32 + rl];
-#pragma unroll
-      for (int j = 0; j < FJ; ++j) b[j] = Bs[cur][kk + kl][wn * (BN / 2) + j * 32 + rl];
+      const int set = (kk >> 1) & 1;
+      if (kk + 2 < BK) frag(set ^ 1, kk + 2);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int i = 0; i < FI; ++i)
 #pragma unroll
         for (int j = 0; j < FJ; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[j], a[i], acc[i][j], 0, 0, 0);   // D[n][m]
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[set][j], af[set][i], acc[i][j], 0, 0, 0);   // D[n][m]
+      __builtin_amdgcn_sched_barrier(0);
     }
     // (round 4 tried spreading these stores over the second half of the k-steps: the `vmcnt` wait in front of the first
     // one then sits in the MIDDLE of the MFMA stream and stops its issue -- 19800 x 1024 x 1024: 435 -> 518 us; behind the
@@ -167,7 +207,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma_kernel(const GemmArgs g)
     // through LDS (the operand images are dead) and comes back with the lanes ALONG a row: one instruction = 64 (or
     // 2 x 32) consecutive columns = 4 lines.
     constexpr int WN = BN / 2, SP = WN + 1;
-    static_assert(4 * 32 * SP * sizeof(float) <= sizeof(float) * 2 * 32 * (PA + PB), "staging fits the operand images");
+    static_assert(4 * 32 * SP * sizeof(float) <= sizeof(float) * NBUF * 32 * (PA + PB), "staging fits the operand images");
     float* stage = reinterpret_cast<float*>(smem_raw) + wave * (32 * SP);
     const bool add_bias = g.epilogue == W2V2_EPI_BIAS && split == 0 && bias != nullptr;
 #pragma unroll
