@@ -34,6 +34,10 @@ def rec(self):
     return orig(self)
 
 
+# F32_TILE=1..4 forces the f32 tile (1 = 128x128, 2 = 64x128, 3 = 128x64, 4 = 64x64) for every product (w2v2_tune_gemm_f32_tile)
+if os.environ.get("F32_TILE"):
+    from w2v2_speaker_amd import _lib
+    _lib.load().w2v2_tune_gemm_f32_tile(int(os.environ["F32_TILE"]))
 ops.Gemm.__call__ = rec
 tr.train_step(feats, labels)
 torch.cuda.synchronize()

@@ -282,20 +282,27 @@ extern "C" int w2v2_tune_gemm_f32_tile(int t) {
 void w2v2_launch_gemm_f32(GemmArgs a, int M, int N, int K, int split, int batch, hipStream_t st) {
   a.k_per_split = (int)(cdiv(cdiv(K, split), 32) * 32);
   if (a.k_per_split == 0) a.k_per_split = 32;
-  // Tile choice: the chip holds 2 workgroups of the 128 x 128 tile per CU.  Take the largest tile (fewest LDS reads and
-  // global loads per MFMA) whose grid fills >= 60 % of those slots; when none does, the smallest one.  (A round-counting
-  // cost model that also moved the 2.4-round 19800 x 1024 x 1024 products to 64 x 128 tiles measured SLOWER, 463 vs 423 us:
-  // the half-size tile's in-loop rate is ~0.8 of the full one's, more than the rounds it saves.)
-  const int64_t slots = 2 * (int64_t)w2v2_gemm_device_cus();
+  // Tile choice, from every product of the ECAPA step timed on each tile (tools/ecapa_gemm_shapes.py F32_TILE=1..4,
+  // round 5: best-per-shape 19.3 ms against 20.2 for the round-4 rule "largest tile that fills 60 % of the slots"):
+  //   * 128 x 128 (2 workgroups per CU = 512 slots, the fastest main loop) when the grid is at least ~0.9 of a round AND
+  //     its last round is not too empty (rounds / exact rounds <= 1.12: 19800 x 1024 x 1024 = 2.42 rounds loses 19 % to
+  //     the third round and runs faster on 64 x 64 tiles, 4 per CU, 4.84 rounds) AND the K loop is long enough to pay
+  //     for the big tile's prologue and epilogue (K > 256);
+  //   * else the 64-row / 64-column tile along the shorter side if THAT fills its 768 slots the same way;
+  //   * else 64 x 64: skinny and short-K products (N = 128 Res2Net convolutions, K = 128 .. 200) are bound by the
+  //     global-load latency of a 12-trip K loop, which only more resident workgroups hide (41.7 -> 30.6 us).
+  const int64_t cus = w2v2_gemm_device_cus();
   auto wgs = [&](int bm, int bn) { return cdiv(M, bm) * cdiv(N, bn) * (int64_t)split * batch; };
-  int bm = 128, bn = 128;
-  if (M <= 64) bm = 64;
-  if (N <= 64) bn = 64;
-  if (wgs(bm, bn) * 10 < slots * 6) {
-    // halve the dimension with the longer tile side first (keeps the tile closer to square), M on ties
-    if (bm == 128 && (bn == 64 || wgs(64, bn) * 10 >= slots * 6 || M >= N)) bm = 64;
-    else if (bn == 128) bn = 64;
-    if (wgs(bm, bn) * 10 < slots * 6) { if (bm == 128) bm = 64; else if (bn == 128) bn = 64; }
+  auto fits = [&](int bm, int bn, int per_cu) {
+    const double exact = (double)wgs(bm, bn) / (double)(per_cu * cus);
+    return exact >= 0.9 && (double)cdiv(wgs(bm, bn), per_cu * cus) / exact <= 1.12;
+  };
+  int bm = 64, bn = 64;
+  const int64_t kper = cdiv(K, split);
+  if (M > 64 && N > 64 && kper > 256) {
+    if (fits(128, 128, 2)) { bm = 128; bn = 128; }
+    else if (M >= N && fits(64, 128, 3)) { bm = 64; bn = 128; }
+    else if (M < N && fits(128, 64, 3)) { bm = 128; bn = 64; }
   }
   switch (g_f32_tile_force) {
     case 1: bm = 128; bn = 128; break;
