@@ -40,9 +40,12 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, T*
         }
         vx.store(r + off);  // pre-norm sum saved for backward (rounded to the activation format)
         // The statistics and y come from the UNROUNDED f32 sum: one rounding fewer on the forward path per LayerNorm
-        // (24 per encoder pass).  The backward rebuilds x-hat from the stored 16-bit sum with these statistics -- a
-        // 2^-12 relative inconsistency, below the rounding of the gradients it multiplies.  W2V2_LN_ROUNDED_SUM=1
-        // restores the old behaviour (statistics and y from the rounded sum).
+        // (24 per encoder pass).  The backward rebuilds x-hat from the stored 16-bit sum with these statistics: the
+        // stored sum carries a rounding of 2^-12 |s| in fp16 and 2^-9 |s| in bf16, so x-hat (= (s - mean) * rstd) is off
+        // by up to 2^-12 resp. 2^-9 times |s| * rstd -- in fp16 below the rounding of the gradients it multiplies; in
+        // bf16 the same size as the rounding every other bf16 activation of the backward already carries (the bf16
+        // gradient bounds of tests/test_parity_gpu.py, 12 %, are measured WITH it).  W2V2_LN_ROUNDED_SUM=1 restores
+        // the old behaviour (statistics and y from the rounded sum).
         if (rounded_sum) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) vx.v[e] = to_f32<T>(from_f32<T>(vx.v[e]));
