@@ -3,6 +3,7 @@
 //   gemm.hip        host dispatch (w2v2_gemm), the register-staged generic kernel, the 128x128 LDS-DMA kernel, exact f32
 //   gemm_ring.hip   256x128x64 three-stage LDS-DMA ring (N <= 2304 products, two-term weights, deferred stores)
 //   gemm_phased.hip 256x256x64 phased kernel (anti-phase wave groups: FFN1, dH, conv stack)
+//   gemm_duo.hip    256x128x32 ring for two four-wave workgroups per CU (one's epilogue under the other's main loop)
 //   gemm_f32.hip    exact-f32 products on v_mfma_f32_32x32x2_f32 (parity mode, ECAPA-TDNN at `precision: 32`)
 // (one file per kernel family keeps a rebuild after an edit to ~1 minute instead of four)
 #pragma once
@@ -528,14 +529,14 @@ typedef __attribute__((address_space(3))) void lvoid_t;
 // rocprofv3 reports) instead of bracketing the launch with two stream events (+3 us of dispatch time per launch).
 struct W2v2PendingTimer { hipEvent_t start, stop; bool armed; };
 W2v2PendingTimer& w2v2_pending_timer();
-#define W2V2_LAUNCH_MAYBE_TIMED(KERNEL, GRID, BLOCK, LDS, STREAM, ARGS)                                         \
+#define W2V2_LAUNCH_MAYBE_TIMED(KERNEL, GRID, BLOCK, LDS, STREAM, ...)                                          \
   do {                                                                                                          \
     W2v2PendingTimer& pt_ = w2v2_pending_timer();                                                               \
     if (pt_.armed) {                                                                                            \
       pt_.armed = false;                                                                                        \
-      hipExtLaunchKernelGGL(KERNEL, GRID, BLOCK, LDS, STREAM, pt_.start, pt_.stop, 0, ARGS);                    \
+      hipExtLaunchKernelGGL(KERNEL, GRID, BLOCK, LDS, STREAM, pt_.start, pt_.stop, 0, __VA_ARGS__);             \
     } else {                                                                                                    \
-      hipLaunchKernelGGL(KERNEL, GRID, BLOCK, LDS, STREAM, ARGS);                                               \
+      hipLaunchKernelGGL(KERNEL, GRID, BLOCK, LDS, STREAM, __VA_ARGS__);                                        \
     }                                                                                                           \
   } while (0)
 int w2v2_gemm_device_cus();
@@ -543,5 +544,6 @@ int w2v2_gemm_device_cus();
 void w2v2_launch_ring_256x128(const GemmArgs& a, int dtype_ab, int dtype_c, int M, int N, int batch, bool persistent,
                               hipStream_t st);
 void w2v2_launch_phased_256x256(const GemmArgs& a, int dtype_ab, int dtype_c, int M, int N, int batch, hipStream_t st);
+void w2v2_launch_duo_256x128(const GemmArgs& a, int dtype_ab, int dtype_c, int M, int N, int batch, hipStream_t st);
 // gemm_f32.hip: exact-f32 products (f32 operands, f32 C); split = split-K factor (atomics), chooses its own tile
 void w2v2_launch_gemm_f32(GemmArgs a, int M, int N, int K, int split, int batch, hipStream_t st);
