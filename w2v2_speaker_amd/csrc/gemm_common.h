@@ -3,7 +3,6 @@
 //   gemm.hip        host dispatch (w2v2_gemm), the register-staged generic kernel, the 128x128 LDS-DMA kernel, exact f32
 //   gemm_ring.hip   256x128x64 three-stage LDS-DMA ring (N <= 2304 products, two-term weights, deferred stores)
 //   gemm_phased.hip 256x256x64 phased kernel (anti-phase wave groups: FFN1, dH, conv stack)
-//   gemm_duo.hip    256x128x32 ring for two four-wave workgroups per CU (one's epilogue under the other's main loop)
 //   gemm_f32.hip    exact-f32 products on v_mfma_f32_32x32x2_f32 (parity mode, ECAPA-TDNN at `precision: 32`)
 // (one file per kernel family keeps a rebuild after an edit to ~1 minute instead of four)
 #pragma once
@@ -46,6 +45,12 @@ struct GemmArgs {
   // two-term weights (w2v2_hip.h): tiles with n0 >= n_ext_from run k_ext more K steps against B + b_lo_off
   int k_ext, n_ext_from;
   int64_t b_lo_off;
+  // split-K pairs (phased kernel, gemm_phased.hip): two workgroups share a 256x256 tile, each runs half of its K tiles;
+  // slot s of the grid publishes into ks_scratch[s][seq & 1][16][512] (16-byte vectors) and raises ks_flags[32 s] (one
+  // 128-byte line per slot: word 0 = (seq << 4) | XCC id, word 16 = seq once its L2 is written back -- the cross-XCD path)
+  float* ks_scratch;
+  unsigned* ks_flags;
+  int ks_cross;    // tools: pair workgroups b and b ^ 1 (two XCDs) instead of b and b ^ 8: exercises the fence path
 };
 
 __device__ __forceinline__ int64_t outer_off(const OpDev& o, int64_t idx) {
@@ -544,6 +549,7 @@ int w2v2_gemm_device_cus();
 void w2v2_launch_ring_256x128(const GemmArgs& a, int dtype_ab, int dtype_c, int M, int N, int batch, bool persistent,
                               hipStream_t st);
 void w2v2_launch_phased_256x256(const GemmArgs& a, int dtype_ab, int dtype_c, int M, int N, int batch, hipStream_t st);
-void w2v2_launch_duo_256x128(const GemmArgs& a, int dtype_ab, int dtype_c, int M, int N, int batch, hipStream_t st);
+// the same kernel over split-K pairs (16-bit C, full-line epilogue, batch 1); != 0: w2v2_last_error holds the reason
+int w2v2_launch_phased_ksplit(const GemmArgs& a, int dtype_ab, int M, int N, hipStream_t st);
 // gemm_f32.hip: exact-f32 products (f32 operands, f32 C); split = split-K factor (atomics), chooses its own tile
 void w2v2_launch_gemm_f32(GemmArgs a, int M, int N, int K, int split, int batch, hipStream_t st);
