@@ -112,24 +112,12 @@ int w2v2_gemm(const w2v2_gemm_desc* d, void* stream);
 int w2v2_gemm_timed(const w2v2_gemm_desc* d, void* stream, int slot);
 int w2v2_timer_read(int first_slot, int n, float* ms_out);
 /* The kernel family w2v2_gemm sends this descriptor to, from a dry run of the dispatch itself (nothing is launched):
- * 4 = phased 256x256, 6 = phased 256x256 over split-K pairs, 2 = 256x128 ring, 1 = 128-row LDS-DMA, 3 = register-staged,
- * 9 = exact f32; < 0 = rejected. */
+ * 4 = phased 256x256, 2 = 256x128 ring, 1 = 128-row LDS-DMA, 3 = register-staged, 9 = exact f32; < 0 = rejected. */
 int w2v2_gemm_kernel_of(const w2v2_gemm_desc* d);
 /* Tuning hook (tools/gemm_shapes.py, not used by the training path): force the tile family of plain K-contiguous
- * 16-bit products -- 0 = the library's own dispatch, 1 = 128x128, 2 = 256x128 ring, 4 = 256x256x64 phased,
- * 6 = 256x256x64 phased over split-K pairs (where the product is eligible: 16-bit C, N % 256 == 0, K >= 512).  Returns the
- * previous setting. */
+ * 16-bit products -- 0 = the library's own dispatch, 1 = 128x128, 2 = 256x128 ring, 3 = 256x256x32 ring,
+ * 4 = 256x256x64 phased.  Returns the previous setting. */
 int w2v2_tune_gemm_kernel(int family);
-/* Tests / tools: pair the workgroups of the split-K kernel ACROSS XCDs (slots b, b ^ 1 instead of b, b ^ 8), which forces
- * the release-fence / second-flag / acquire-fence exchange that the kernel falls back to when two partners do not share
- * an L2 -- never the case with the hardware's round-robin placement, so this is the only way to run that path.  Returns
- * the previous setting. */
-int w2v2_tune_gemm_ks_cross(int on);
-/* Tools (tools/ksplit_stamps.py): select the time-stamping variant of the fp16 split-K kernel, and read the 100 MHz
- * s_memrealtime stamps its last launch on `stream` left per grid slot -- out[256][6] = kernel start, main loop end,
- * payload published, partner's flag seen, partner's payload added, epilogue stores drained (0 for idle slots). */
-int w2v2_tune_gemm_ks_stamps(int on);
-int w2v2_tune_gemm_ks_read_stamps(void* stream, unsigned long long* out);
 /* Tools only (tools/gemm_attrib.py): time-attribution / placement variants of the 256x256x64 phased kernel for fp16
  * products -- bit 0 no DMA in the main loop, 1 no fragment reads, 2 no MFMAs, 3 no epilogue, bits 4-5 = DMA pieces of a
  * phase issued between its MFMAs, bit 6 / 7 plain / write-through epilogue stores.  Variants with bits 0-3 compute

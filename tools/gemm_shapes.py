@@ -39,7 +39,7 @@ SHAPES = [
 ]
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
 only = args[0] if args else None
-FAM = {0: "auto", 1: "128x128", 2: "256x128 ring", 4: "256x256x64 phased", 6: "phased split-K pairs"}
+FAM = {0: "auto", 1: "128x128", 2: "256x128 ring", 4: "256x256x64 phased"}
 fams = [int(x) for x in os.environ.get("FAMILIES", "0").split(",")]
 vs_lib = "--hipblaslt" in sys.argv
 

@@ -50,9 +50,6 @@ _SIGS = {
     "w2v2_timer_read": (c_i32, [c_i32, c_i32, c_vp]),
     "w2v2_tune_gemm_kernel": (c_i32, [c_i32]),
     "w2v2_tune_gemm_debug": (c_i32, [c_i32]),
-    "w2v2_tune_gemm_ks_cross": (c_i32, [c_i32]),
-    "w2v2_tune_gemm_ks_stamps": (c_i32, [c_i32]),
-    "w2v2_tune_gemm_ks_read_stamps": (c_i32, [c_vp, c_vp]),
     "w2v2_tune_gemm_f32_tile": (c_i32, [c_i32]),
     "w2v2_zero_ranges": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_vp]),
     "w2v2_mean": (c_i32, [c_vp, c_vp, c_i32, c_vp]),

@@ -381,7 +381,7 @@ static void launch_bf16(const GemmArgs& a, dim3 grid, hipStream_t st) {
 static int g_w2v2_force = 0;
 extern "C" int w2v2_tune_gemm_kernel(int family) {
   const int old = g_w2v2_force;
-  if (family == 0 || family == 1 || family == 2 || family == 4 || family == 6) g_w2v2_force = family;
+  if (family == 0 || family == 1 || family == 2 || family == 4) g_w2v2_force = family;
   return old;
 }
 
@@ -522,23 +522,7 @@ extern "C" int w2v2_gemm(const w2v2_gemm_desc* d, void* stream) {
       huge = lines && fill4 * 1.25 >= fill3 && t4 * 2 >= ncu &&
              (double)d->N / (double)(cdiv(d->N, 256) * 256) >= 0.9 && fits32;
     }
-    // Split-K pairs on the phased kernel (family 6): products whose 256x256 tiles cannot fill the chip but whose K loop is
-    // long enough to pay for the pair exchange -- per round the 256x128 ring spends nk x 0.91 us, a pair nk / 2 x 1.36 us +
-    // ~6 us (profiles/r05_splitk_exchange_probe.txt), so from K = 2304 on (FFN2, the FFN1 and QKV data gradients).  The
-    // rule looks at N and K only, never at M: the K halves are summed in a different order than one pass over K, and an
-    // utterance must embed to the same bits whatever batch it arrives in.
-    static const bool ks_env = getenv("W2V2_NO_KSPLIT") == nullptr;      // A/B switch
-    auto ks_ok = [&]() {
-      auto extent = [](const w2v2_operand& o, int64_t rows, int64_t K) -> int64_t {
-        return (o.seg_len > 0 ? (rows / o.seg_len + 1) * o.seg_stride + o.seg_len * o.ld : rows * o.ld) + K;
-      };
-      return glds && split == 1 && !atomic && d->k_ext == 0 && d->batch == 1 && d->dtype_c != W2V2_F32 && a.c_vec_ok &&
-             (d->N % 256 == 0) && (d->aux == nullptr || a.aux_vec_ok) && d->K >= 512 &&
-             extent(d->A, d->M, d->K) < (int64_t(1) << 31) && extent(d->B, d->N, d->K) < (int64_t(1) << 31);
-    };
-    bool ksplit = ks_env && g_w2v2_force == 0 && !huge && ks_ok() && d->K >= 2304 && d->N <= 1024;
     bool big_ = big;
-    if (g_w2v2_force == 6) ksplit = ks_ok();
     if (g_w2v2_force != 0 && glds && split == 1 && !atomic && d->k_ext == 0 && d->batch == 1) {
       auto extent = [](const w2v2_operand& o, int64_t rows, int64_t K) -> int64_t {
         return (o.seg_len > 0 ? (rows / o.seg_len + 1) * o.seg_stride + o.seg_len * o.ld : rows * o.ld) + K;
@@ -572,13 +556,8 @@ extern "C" int w2v2_gemm(const w2v2_gemm_desc* d, void* stream) {
       static const char* late_env = getenv("W2V2_PH_LATE");
       a.late_dma = late_env ? (late_env[0] != '0') : 0;
     }
-    g_gemm_family = ksplit ? 6 : huge ? 4 : big_ ? 2 : glds ? 1 : 3;
+    g_gemm_family = huge ? 4 : big_ ? 2 : glds ? 1 : 3;
     if (g_gemm_dry) return 0;                     // w2v2_gemm_kernel_of: the dispatch decision only, nothing launched
-    if (ksplit) {
-      if (w2v2_launch_phased_ksplit(a, d->dtype_ab, d->M, d->N, st) != 0) return -1;
-      W2V2_CHECK_LAUNCH("w2v2_gemm");
-      return 0;
-    }
 #define W2V2_GEMM_LAUNCH(TE, TC)                                                                         \
     do {                                                                                                 \
       if (huge) w2v2_launch_phased_256x256(a, d->dtype_ab, d->dtype_c, d->M, d->N, d->batch, st);        \

@@ -45,12 +45,6 @@ struct GemmArgs {
   // two-term weights (w2v2_hip.h): tiles with n0 >= n_ext_from run k_ext more K steps against B + b_lo_off
   int k_ext, n_ext_from;
   int64_t b_lo_off;
-  // split-K pairs (phased kernel, gemm_phased.hip): two workgroups share a 256x256 tile, each runs half of its K tiles;
-  // slot s of the grid publishes into ks_scratch[s][seq & 1][16][512] (16-byte vectors) and raises ks_flags[32 s] (one
-  // 128-byte line per slot: word 0 = (seq << 4) | XCC id, word 16 = seq once its L2 is written back -- the cross-XCD path)
-  float* ks_scratch;
-  unsigned* ks_flags;
-  int ks_cross;    // tools: pair workgroups b and b ^ 1 (two XCDs) instead of b and b ^ 8: exercises the fence path
 };
 
 __device__ __forceinline__ int64_t outer_off(const OpDev& o, int64_t idx) {
@@ -534,14 +528,14 @@ typedef __attribute__((address_space(3))) void lvoid_t;
 // rocprofv3 reports) instead of bracketing the launch with two stream events (+3 us of dispatch time per launch).
 struct W2v2PendingTimer { hipEvent_t start, stop; bool armed; };
 W2v2PendingTimer& w2v2_pending_timer();
-#define W2V2_LAUNCH_MAYBE_TIMED(KERNEL, GRID, BLOCK, LDS, STREAM, ...)                                          \
+#define W2V2_LAUNCH_MAYBE_TIMED(KERNEL, GRID, BLOCK, LDS, STREAM, ARGS)                                         \
   do {                                                                                                          \
     W2v2PendingTimer& pt_ = w2v2_pending_timer();                                                               \
     if (pt_.armed) {                                                                                            \
       pt_.armed = false;                                                                                        \
-      hipExtLaunchKernelGGL(KERNEL, GRID, BLOCK, LDS, STREAM, pt_.start, pt_.stop, 0, __VA_ARGS__);             \
+      hipExtLaunchKernelGGL(KERNEL, GRID, BLOCK, LDS, STREAM, pt_.start, pt_.stop, 0, ARGS);                    \
     } else {                                                                                                    \
-      hipLaunchKernelGGL(KERNEL, GRID, BLOCK, LDS, STREAM, __VA_ARGS__);                                        \
+      hipLaunchKernelGGL(KERNEL, GRID, BLOCK, LDS, STREAM, ARGS);                                               \
     }                                                                                                           \
   } while (0)
 int w2v2_gemm_device_cus();
@@ -549,7 +543,5 @@ int w2v2_gemm_device_cus();
 void w2v2_launch_ring_256x128(const GemmArgs& a, int dtype_ab, int dtype_c, int M, int N, int batch, bool persistent,
                               hipStream_t st);
 void w2v2_launch_phased_256x256(const GemmArgs& a, int dtype_ab, int dtype_c, int M, int N, int batch, hipStream_t st);
-// the same kernel over split-K pairs (16-bit C, full-line epilogue, batch 1); != 0: w2v2_last_error holds the reason
-int w2v2_launch_phased_ksplit(const GemmArgs& a, int dtype_ab, int M, int N, hipStream_t st);
 // gemm_f32.hip: exact-f32 products (f32 operands, f32 C); split = split-K factor (atomics), chooses its own tile
 void w2v2_launch_gemm_f32(GemmArgs a, int M, int N, int K, int split, int batch, hipStream_t st);

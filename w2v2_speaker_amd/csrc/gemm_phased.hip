@@ -51,34 +51,7 @@ __device__ __forceinline__ void wait_quarters(int newer) {
 //   1 = no DMA in the steady-state loop, 2 = no fragment reads, 4 = no MFMAs, 8 = no epilogue,
 //   16 / 32 = one / both of the two DMA pieces of a phase are issued BETWEEN its MFMAs instead of in its read segment,
 //   (host side) 64 = plain write-back epilogue stores, 128 = write-through ones, whatever w2v2_gemm chose
-// KSPLIT: split-K PAIRS for the products whose 256x256 tiles cannot fill the chip (N = 768, K >= 2304: 117 tiles).  Two
-// workgroups take one tile and half of its K tiles each; at the end each keeps one 64-row half of every wave tile,
-// publishes the accumulators of the other half (64 registers per lane, 128 KiB per workgroup, plain 16-byte stores in
-// lane order), raises a flag, and adds what its partner published for the half it keeps; the epilogue then runs on 64
-// values per lane on each side.  The pair is (slot s, slot s ^ 8) of the grid: blockIdx.x round-robins over the XCDs, so
-// both normally share an L2 and the payload never leaves it (tools/probes/splitk_exchange_probe.hip,
-// profiles/r05_splitk_exchange_probe.txt: 5.4-5.8 us for the whole exchange, against 9 us with write-through stores and
-// 70 us with release / acquire fences).  Placement is not architecturally guaranteed, so the flag carries the XCC id: when
-// the partners sit on different XCDs both fall back to release fence -> second flag -> acquire fence (never seen in
-// practice; `ks_cross` pairs s with s ^ 1 to test it).  Flags are per-slot sequence numbers that live in device memory
-// across launches (a slot and its partner always publish equally often), so a launch needs no reset and replays from a
-// graph; payload buffers alternate with the sequence number: a partner cannot publish round n + 1 into the buffer this
-// workgroup is still reading, because it first has to see this workgroup's flag of round n.
-__device__ __forceinline__ unsigned ks_load_u32(const unsigned* p) {
-  unsigned v;
-  asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
-  return v;
-}
-__device__ __forceinline__ void ks_store_u32(unsigned* p, unsigned v) {
-  asm volatile("global_store_dword %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
-}
-__device__ __forceinline__ f32x4 ks_load16(const f32x4* p) {          // skips this CU's L1 (the line may be two rounds old there)
-  f32x4 v;
-  asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
-  return v;
-}
-
-template <typename TE, typename TC, int DBG = 0, bool KSPLIT = false>
+template <typename TE, typename TC, int DBG = 0>
 __global__ __launch_bounds__(512) void gemm16_phased_256x256_kernel(const GemmArgs g) {
   constexpr int BM = 256, BN = 256, BK = 64, FM = 8, FN = 4;
   constexpr int BUF = (BM + BN) * BK;             // elements per K-tile buffer: A [256][64] then B [256][64]
@@ -93,6 +66,7 @@ __global__ __launch_bounds__(512) void gemm16_phased_256x256_kernel(const GemmAr
   const int G = gridDim.x;
   const int z = blockIdx.z;
   const int z0 = z / g.batch_inner, z1 = z - z0 * g.batch_inner;
+  const int nk = g.K >> 6;
   const bf16_t* Ab = reinterpret_cast<const bf16_t*>(g.A.ptr) + z0 * g.a_s0 + z1 * g.a_s1;
   const bf16_t* Bb = reinterpret_cast<const bf16_t*>(g.B.ptr) + z0 * g.b_s0 + z1 * g.b_s1;
   const int c8 = lane & 7, r8 = lane >> 3;
@@ -114,44 +88,13 @@ __global__ __launch_bounds__(512) void gemm16_phased_256x256_kernel(const GemmAr
     return p * 16 + (q == 2 ? 8 : 0);
   };
 
-  // split-K pairs: slot = blockIdx.x (bits 0 and 3 swapped under ks_cross), XCD = slot & 7, pair slot = (slot >> 4) within
-  // the XCD, K half = (slot >> 3) & 1; the grid holds 8 * L pair slots and walks the tiles in rounds of that many
-  int ks_slot = 0, ks_half = 0, ks_kt0 = 0;
-  unsigned ks_seq = 0, ks_xcc = 0;
-  unsigned long long ks_t[6] = {0, 0, 0, 0, 0, 0};      // DBG & 64 (tools): s_memrealtime stamps of the last round
-  if constexpr (KSPLIT && (DBG & 64) != 0) ks_t[0] = __builtin_amdgcn_s_memrealtime();
-  if constexpr (KSPLIT) {
-    const int b = blockIdx.x;
-    ks_slot = g.ks_cross ? ((b & ~9) | ((b & 1) << 3) | ((b >> 3) & 1)) : b;
-    ks_half = (ks_slot >> 3) & 1;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(ks_xcc));
-    ks_xcc &= 15;
-    ks_seq = ks_load_u32(g.ks_flags + ks_slot * 32) >> 4;      // this slot's own count (only this slot ever writes it)
-    ks_seq = __builtin_amdgcn_readfirstlane(ks_seq);
-  }
-  const int nk_all = g.K >> 6;
-  const int step_tiles = KSPLIT ? (G >> 1) : G;
 #pragma unroll 1
-  for (int t0 = 0; t0 < ntile; t0 += step_tiles) {
-    int tile;
-    if constexpr (KSPLIT) {
-      const int nchunk = min(step_tiles, ntile - t0);
-      const int pq = nchunk >> 3, pr = nchunk & 7, x = ks_slot & 7, pl = ks_slot >> 4;
-      if (pl >= pq + (x < pr ? 1 : 0)) break;                   // (the partner, slot ^ 8, leaves with it)
-      tile = t0 + (x < pr ? x * (pq + 1) : pr * (pq + 1) + (x - pr) * pq) + pl;
-    } else {
-      const int nchunk = min(G, ntile - t0);
-      if ((int)blockIdx.x >= nchunk) break;
-      tile = t0 + xcd_remap(blockIdx.x, nchunk);
-    }
+  for (int t0 = 0; t0 < ntile; t0 += G) {
+    const int nchunk = min(G, ntile - t0);
+    if ((int)blockIdx.x >= nchunk) break;
+    const int tile = t0 + xcd_remap(blockIdx.x, nchunk);
     const int tm = tile / g.tiles_n, tn = tile - tm * g.tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
-    int nk = nk_all;
-    if constexpr (KSPLIT) {                                      // K tiles [kt0, kt0 + nk) of this half
-      const int nk0 = (nk_all + 1) >> 1;
-      ks_kt0 = ks_half ? nk0 : 0;
-      nk = ks_half ? nk_all - nk0 : nk0;
-    }
     // per-lane source pointers of the 8 pieces (K offset added at issue)
     // element offsets from the operand base (32 bits: the largest operand, conv1's input, has 3.2e8 elements) -- as
     // 64-bit pointers the eight sources cost 8 more VGPRs than this kernel has (it sits at the 256-register limit)
@@ -170,7 +113,7 @@ __global__ __launch_bounds__(512) void gemm16_phased_256x256_kernel(const GemmAr
       if (isa) tile_ptrs<2>(g.A, Ab, m0, BM, g.M, piece_row(q, 0) + r8, 8, col, ptr);
       else tile_ptrs<2>(g.B, Bb, n0, BN, g.N, piece_row(q, 0) + r8, 16, col, ptr);
 #pragma unroll
-      for (int j = 0; j < 2; ++j) soff[q][j] = (int)(ptr[j] - (isa ? Ab : Bb)) + ks_kt0 * 64;
+      for (int j = 0; j < 2; ++j) soff[q][j] = (int)(ptr[j] - (isa ? Ab : Bb));
     }
     auto issue = [&](int q, int kt) {               // quarter q of K tile kt -> buffer kt & 1
       const bool isa = q == 0 || q == 3;
@@ -326,72 +269,7 @@ __global__ __launch_bounds__(512) void gemm16_phased_256x256_kernel(const GemmAr
     float cv0[8], cv1[8];
     load_col8(g, bias, nc, cv0);
     load_col8(g, bias, nc + 8, cv1);
-    if constexpr (KSPLIT) {
-      // ---- exchange: keep row fragments [4 half, 4 half + 4) of the wave tile, publish the other four
-      if constexpr ((DBG & 64) != 0) ks_t[1] = __builtin_amdgcn_s_memrealtime();
-      if (ks_half) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < FN; ++j) { const f32x4 t = acc[i][j]; acc[i][j] = acc[i + 4][j]; acc[i + 4][j] = t; }
-      }
-      ++ks_seq;
-      const size_t per_buf = (size_t)16 * 512;
-      f32x4* mine = reinterpret_cast<f32x4*>(g.ks_scratch) + ((size_t)ks_slot * 2 + (ks_seq & 1)) * per_buf + tid;
-      const f32x4* theirs = reinterpret_cast<const f32x4*>(g.ks_scratch) + ((size_t)(ks_slot ^ 8) * 2 + (ks_seq & 1)) * per_buf + tid;
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < FN; ++j) mine[(i * FN + j) * 512] = acc[4 + i][j];
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's payload is in L2
-      __syncthreads();                                           // ... every wave's
-      if constexpr ((DBG & 64) != 0) ks_t[2] = __builtin_amdgcn_s_memrealtime();
-      unsigned* my_flag = g.ks_flags + ks_slot * 32;
-      const unsigned* their_flag = g.ks_flags + (ks_slot ^ 8) * 32;
-      volatile unsigned* lds_word = reinterpret_cast<volatile unsigned*>(smem_raw);   // (the operand buffers are dead)
-      if (tid == 0) {
-        ks_store_u32(my_flag, (ks_seq << 4) | ks_xcc);
-        unsigned v;
-        while (((v = ks_load_u32(their_flag)) >> 4) != ks_seq) __builtin_amdgcn_s_sleep(1);
-        lds_word[0] = v & 15;
-      }
-      __syncthreads();
-      const unsigned their_xcc = lds_word[0];
-      if constexpr ((DBG & 64) != 0) ks_t[3] = __builtin_amdgcn_s_memrealtime();
-      if (their_xcc != ks_xcc) {                                 // two L2s: write back, second flag, invalidate
-        __threadfence();
-        __syncthreads();
-        if (tid == 0) {
-          ks_store_u32(my_flag + 16, ks_seq);
-          while (ks_load_u32(their_flag + 16) != ks_seq) __builtin_amdgcn_s_sleep(1);
-        }
-        __syncthreads();
-        __threadfence();
-      }
-      f32x4 r[16];
-#pragma unroll
-      for (int v = 0; v < 16; ++v) r[v] = ks_load16(theirs + v * 512);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-      for (int v = 0; v < 16; ++v) asm volatile("" : "+v"(r[v]));          // (uses stay behind the wait)
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < FN; ++j) acc[i][j] += r[i * FN + j];
-      if constexpr ((DBG & 64) != 0) ks_t[4] = __builtin_amdgcn_s_memrealtime();
-      __syncthreads();                                           // lds_word is operand space again in the next round
-      f32x4 (&keep)[4][FN] = *reinterpret_cast<f32x4 (*)[4][FN]>(&acc[0][0]);
-      W2V2_EPI_DISPATCH((epilogue_lines<TC, EPI, 4>(g, Cz, auxz, keep, mr - frow + ks_half * 64, nc, lane, cv0, cv1, nullptr)));
-      if constexpr ((DBG & 64) != 0) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        ks_t[5] = __builtin_amdgcn_s_memrealtime();
-        if (tid == 0) {
-          unsigned long long* dst = reinterpret_cast<unsigned long long*>(g.ks_flags + ks_slot * 32 + 2);
-#pragma unroll
-          for (int q = 0; q < 6; ++q) dst[q] = ks_t[q];
-        }
-      }
-    } else if constexpr (sizeof(TC) == 2) {       // (the host sends 16-bit outputs here only where lines_ok holds)
+    if constexpr (sizeof(TC) == 2) {       // (the host sends 16-bit outputs here only where lines_ok holds)
       W2V2_EPI_DISPATCH((epilogue_lines<TC, EPI, FM>(g, Cz, auxz, acc, mr - frow, nc, lane, cv0, cv1, nullptr)));
     } else {
       W2V2_EPI_DISPATCH((epilogue_direct<TC, EPI, FM, 2>(g, Cz, auxz, acc, mr, nc, cv0, cv1)));
@@ -448,88 +326,6 @@ void w2v2_launch_phased_256x256(const GemmArgs& a, int dtype_ab, int dtype_c, in
     if (dtype_c == W2V2_F32) launch_ph_dbg<f16_t, float>(a, M, N, batch, st);
     else launch_ph_dbg<f16_t, f16_t>(a, M, N, batch, st);
   }
-}
-
-// ------------------------------------------------------------------------------ split-K pairs: exchange space and launch
-// One exchange space per (device, stream): 256 slots x 2 buffers x 128 KiB of payload + one 128-byte flag line per slot.
-// Launches of one stream are ordered, so they share it; two streams never do.  Allocated at the first launch (never
-// inside a graph capture: warm the product up once before capturing, as for every lazily initialised library object).
-#include <map>
-#include <mutex>
-namespace {
-struct KsSpace { float* scratch; unsigned* flags; };
-constexpr int KS_SLOTS = 256;
-int ks_space(hipStream_t st, KsSpace* out) {
-  static std::mutex mu;
-  static std::map<std::pair<int, hipStream_t>, KsSpace> spaces;
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) W2V2_FAIL("w2v2_gemm (split-K pairs): hipGetDevice failed");
-  std::lock_guard<std::mutex> lock(mu);
-  auto it = spaces.find({dev, st});
-  if (it == spaces.end()) {
-    KsSpace sp{nullptr, nullptr};
-    const size_t payload = (size_t)KS_SLOTS * 2 * 16 * 512 * 16, flags = (size_t)KS_SLOTS * 128;
-    if (hipMalloc(&sp.scratch, payload) != hipSuccess || hipMalloc(&sp.flags, flags) != hipSuccess ||
-        hipMemsetAsync(sp.flags, 0, flags, st) != hipSuccess)
-      W2V2_FAIL("w2v2_gemm (split-K pairs): cannot allocate the %zu MB exchange space", (payload + flags) >> 20);
-    it = spaces.emplace(std::make_pair(dev, st), sp).first;
-  }
-  *out = it->second;
-  return 0;
-}
-static int g_w2v2_ks_cross = 0;          // tools / tests: pair slots across XCDs (the fence path)
-template <typename TE, int DBG = 0>
-int launch_ks(GemmArgs a, int M, int N, hipStream_t st) {
-  constexpr size_t lds = (size_t)2 * (256 + 256) * 64 * sizeof(bf16_t);   // 128 KiB
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm16_phased_256x256_kernel<TE, TE, DBG, true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
-  KsSpace sp;
-  if (ks_space(st, &sp) != 0) return -1;
-  a.ks_scratch = sp.scratch;
-  a.ks_flags = sp.flags;
-  a.ks_cross = g_w2v2_ks_cross;
-  a.tiles_m = (int)cdiv(M, 256);
-  a.tiles_n = (int)cdiv(N, 256);
-  const int tiles = a.tiles_m * a.tiles_n;
-  // 16 workgroups per pair slot of the eight XCDs; never more workgroups than CUs (every pair must be resident)
-  int L = w2v2_gemm_device_cus() / 16;
-  if (L > KS_SLOTS / 16) L = KS_SLOTS / 16;
-  if (L < 1) L = 1;
-  if ((int)cdiv(tiles, 8) < L) L = (int)cdiv(tiles, 8);
-  W2V2_LAUNCH_MAYBE_TIMED((gemm16_phased_256x256_kernel<TE, TE, DBG, true>), dim3(16 * L), dim3(512), lds, st, a);
-  return 0;
-}
-}  // namespace
-static int g_w2v2_ks_stamps = 0;         // tools: the stamping variant (fp16)
-int w2v2_launch_phased_ksplit(const GemmArgs& a, int dtype_ab, int M, int N, hipStream_t st) {
-  if (dtype_ab == W2V2_BF16) return launch_ks<bf16_t>(a, M, N, st);
-  return g_w2v2_ks_stamps ? launch_ks<f16_t, 64>(a, M, N, st) : launch_ks<f16_t>(a, M, N, st);
-}
-// tools (tools/ksplit_stamps.py): run the stamping variant of the fp16 split-K kernel / read the 100 MHz stamps of the
-// last launch on `stream` (kernel start, main loop end, payload published, partner's flag seen, partner's payload added,
-// epilogue stores drained) for each of the 256 slots; returns the previous setting / 0.
-extern "C" int w2v2_tune_gemm_ks_stamps(int on) {
-  const int old = g_w2v2_ks_stamps;
-  g_w2v2_ks_stamps = on ? 1 : 0;
-  return old;
-}
-extern "C" int w2v2_tune_gemm_ks_read_stamps(void* stream, unsigned long long* out) {
-  KsSpace sp;
-  if (ks_space(as_stream(stream), &sp) != 0) return -1;
-  if (hipStreamSynchronize(as_stream(stream)) != hipSuccess) W2V2_FAIL("w2v2_tune_gemm_ks_read_stamps: sync failed");
-  for (int s = 0; s < KS_SLOTS; ++s)
-    if (hipMemcpy(out + s * 6, sp.flags + s * 32 + 2, 48, hipMemcpyDeviceToHost) != hipSuccess)
-      W2V2_FAIL("w2v2_tune_gemm_ks_read_stamps: copy failed");
-  return 0;
-}
-extern "C" int w2v2_tune_gemm_ks_cross(int on) {
-  const int old = g_w2v2_ks_cross;
-  g_w2v2_ks_cross = on ? 1 : 0;
-  return old;
 }
 
 extern "C" int w2v2_tune_gemm_debug(int bits) {
