@@ -374,10 +374,11 @@ int w2v2_bn_fwd(const void* a, int64_t lda, float* workspace, float* mean_rstd, 
                 const float* beta, void* y, int64_t ldy, int M, int C, float eps, float momentum, int relu, int train,
                 int dtype, void* stream);
 /* dy -> da (through BatchNorm and the optional relu); writes dgamma[C], dbeta[C].  colsum_partial (may be NULL):
- * [w2v2_bn_colsum_rows(M)][C] f32, WRITTEN with the column sums of da over each row block -- the bias gradient of the
+ * [w2v2_bn_colsum_rows(M, C)][C] f32, WRITTEN with the column sums of da over each row block -- the bias gradient of the
  * convolution in front of the BatchNorm (TDNNBlock = conv -> ReLU -> BatchNorm) is their sum: a w2v2_colsum over
- * M / 256 rows instead of a second pass over the M rows of da. */
-int w2v2_bn_colsum_rows(int M);
+ * M / 256 rows (M / 64 for the narrow Res2Net slices, whose row blocks are shorter so that they fill the chip) instead of
+ * a second pass over the M rows of da. */
+int w2v2_bn_colsum_rows(int M, int C);
 int w2v2_bn_bwd(const void* dy, int64_t lddy, const void* a, int64_t lda, const float* mean_rstd, const float* gamma,
                 float* workspace, float* dgamma, float* dbeta, void* da, int64_t ldda, int M, int C, int relu,
                 float* colsum_partial, int dtype, void* stream);

@@ -194,7 +194,7 @@ def test_batchnorm_kernels_vs_torch(dtype, M, C, ld, relu):
     assert rel_l2(running[:C].cpu().double(), bn.running_mean) < 1e-5
     assert rel_l2(running[C:].cpu().double(), bn.running_var) < 1e-5
     dgam, dbet = torch.empty(C, device=dev), torch.empty(C, device=dev)
-    csp = torch.full((ops.bn_colsum_rows(M), C), float("nan"), device=dev)
+    csp = torch.full((ops.bn_colsum_rows(M, C), C), float("nan"), device=dev)
     ops.bn_bwd(dyd, ld, ad, ld, mr, gd, work, dgam, dbet, da, ld, M, C, relu, colsum_partial=csp)
     gtol = 2e-5 if dtype == torch.float32 else 8e-3
     assert rel_l2(da[:, :C].cpu().double(), ar.grad) < gtol

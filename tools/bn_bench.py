@@ -44,7 +44,7 @@ for name, C, ld in (("128-ch slice of 1024", 128, 1024), ("1024 wide", 1024, 102
     running = torch.zeros(2 * C, device=dev)
     gamma, beta = torch.ones(C, device=dev), torch.zeros(C, device=dev)
     dg, db = torch.empty(C, device=dev), torch.empty(C, device=dev)
-    cs = torch.empty(o.bn_colsum_rows(M), C, device=dev)
+    cs = torch.empty(o.bn_colsum_rows(M, C), C, device=dev)
     f = timed(lambda: o.bn_fwd(a, ld, work, mr, running, gamma, beta, y, ld, M, C, 1e-5, 0.1, True, True))
     b = timed(lambda: o.bn_bwd(dy, ld, a, ld, mr, gamma, work, dg, db, da, ld, M, C, True, cs))
     t = M * C * 4 / 1e3          # KB -> us * GB/s

@@ -14,7 +14,7 @@
 
 constexpr int BN_CW = 128;        // channels per workgroup of the BatchNorm kernels: 16 lanes x 8 channels (16 B)
 constexpr int BN_RL = 16;         // row lanes of a BatchNorm workgroup (blockDim = (16, BN_RL))
-constexpr int BN_AROWS = 256;     // rows one workgroup of the apply kernels walks
+constexpr int BN_AROWS = 256;     // rows one workgroup of the apply kernels walks (64 where that leaves CUs idle: bn_arows)
 constexpr int BN_UN = 4;          // rows in flight per thread (memory-level parallelism of the row walks)
 
 // ------------------------------------------------------------------------------------------ BatchNorm (+ReLU)
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ a, 
                                                        float* __restrict__ mean_rstd, float* __restrict__ running,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        T* __restrict__ y, int64_t ldy, int M, int C, int relu,
-                                                       float eps, float momentum, int mode) {
+                                                       float eps, float momentum, int mode, int arows) {
   __shared__ double fold[4][BN_CW][2];
   __shared__ float cf[4][BN_CW];                 // mean, rstd, gamma, beta of the strip
   const int tid = threadIdx.y * 16 + threadIdx.x;
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ a, 
   __syncthreads();
   const int cl = threadIdx.x * 8, cg = blockIdx.x * BN_CW + cl;
   if (cg >= C) return;
-  const int m0 = blockIdx.y * BN_AROWS, m1 = min(M, m0 + BN_AROWS);
+  const int m0 = blockIdx.y * arows, m1 = min(M, m0 + arows);
   float mus[8], rs[8], ga[8], be[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) { mus[e] = cf[0][cl + e]; rs[e] = cf[1][cl + e]; ga[e] = cf[2][cl + e]; be[e] = cf[3][cl + e]; }
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                                                            const float* __restrict__ partial, int nblk,
                                                            float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                            T* __restrict__ da, int64_t ldda, int M, int C, int relu,
-                                                           float invM, float* __restrict__ cs_partial) {
+                                                           float invM, float* __restrict__ cs_partial, int arows) {
   __shared__ double fold[4][BN_CW][2];
   __shared__ float csred[BN_RL][BN_CW];          // column sums of da over this workgroup's rows (cs_partial != NULL)
   __shared__ float cf[5][BN_CW];                 // mean, rstd, gamma*rstd, sum dy / M, sum dy xhat / M
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
   __syncthreads();
   const int cl = threadIdx.x * 8, cg = blockIdx.x * BN_CW + cl;
   if (cg >= C && cs_partial == nullptr) return;
-  const int m0 = blockIdx.y * BN_AROWS, m1 = (cg < C) ? min(M, m0 + BN_AROWS) : m0;
+  const int m0 = blockIdx.y * arows, m1 = (cg < C) ? min(M, m0 + arows) : m0;
   float mu[8], rs[8], gr[8], m1s[8], m2s[8], cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
@@ -455,7 +455,11 @@ __global__ void act_bwd_kernel(const float* __restrict__ dy, const float* __rest
 static int td_blocks(int64_t n) { return (int)(cdiv(n, 256) > 8192 ? 8192 : (cdiv(n, 256) < 1 ? 1 : cdiv(n, 256))); }
 
 extern "C" int w2v2_bn_workspace_floats(int M, int C) { return (int)cdiv(M, 128) * C * 2; }
-extern "C" int w2v2_bn_colsum_rows(int M) { return (int)cdiv(M, BN_AROWS); }
+// Rows per workgroup of the apply kernels: 256, or 64 where 256 would leave most CUs without a workgroup -- the 128-channel
+// Res2Net slices of the ECAPA path are ONE strip wide: 78 workgroups of 256 rows at M = 19800 ran a 10 MB pass in 17-19 us
+// (four dependent load rounds behind the statistics fold on 78 of 256 CUs), 310 workgroups of 64 rows do one round each.
+static int bn_arows(int M, int C) { return cdiv(C, BN_CW) * cdiv(M, BN_AROWS) >= 256 ? BN_AROWS : 64; }
+extern "C" int w2v2_bn_colsum_rows(int M, int C) { return (int)cdiv(M, bn_arows(M, C)); }
 
 extern "C" int w2v2_bn_fwd(const void* a, int64_t lda, float* workspace, float* mean_rstd, float* running,
                            const float* gamma, const float* beta, void* y, int64_t ldy, int M, int C, float eps,
@@ -465,13 +469,14 @@ extern "C" int w2v2_bn_fwd(const void* a, int64_t lda, float* workspace, float* 
   W2V2_REQUIRE(train ? workspace != nullptr : running != nullptr,
                "bn_fwd: training needs the workspace, evaluation the running statistics");
   const int nblk = (int)cdiv(M, bn_rows_host(C));
-  const dim3 blk(16, BN_RL), gp((unsigned)cdiv(C, BN_CW), nblk), ga((unsigned)cdiv(C, BN_CW), (unsigned)cdiv(M, BN_AROWS));
+  const int arows = bn_arows(M, C);
+  const dim3 blk(16, BN_RL), gp((unsigned)cdiv(C, BN_CW), nblk), ga((unsigned)cdiv(C, BN_CW), (unsigned)cdiv(M, arows));
   hipStream_t st = as_stream(stream);
 #define TD_BNF(T_)                                                                                                   \
   if (train)                                                                                                         \
     hipLaunchKernelGGL(bn_partial_kernel<T_>, gp, blk, 0, st, (const T_*)a, lda, workspace, M, C, relu);             \
   hipLaunchKernelGGL(bn_apply_kernel<T_>, ga, blk, 0, st, (const T_*)a, lda, workspace, nblk, mean_rstd, running,    \
-                     gamma, beta, (T_*)y, ldy, M, C, relu, eps, momentum, train)
+                     gamma, beta, (T_*)y, ldy, M, C, relu, eps, momentum, train, arows)
   W2V2_DISPATCH_ACT(dtype, "bn_fwd", TD_BNF(AT););
 #undef TD_BNF
   W2V2_CHECK_LAUNCH("bn_fwd");
@@ -484,13 +489,14 @@ extern "C" int w2v2_bn_bwd(const void* dy, int64_t lddy, const void* a, int64_t 
   W2V2_REQUIRE(dy && a && mean_rstd && gamma && workspace && dgamma && dbeta && da && M > 0 && C > 0 && C % 8 == 0 &&
                    lda % 8 == 0 && lddy % 8 == 0 && ldda % 8 == 0, "bn_bwd: bad arguments (C and strides multiples of 8)");
   const int nblk = (int)cdiv(M, bn_rows_host(C));
-  const dim3 blk(16, BN_RL), gp((unsigned)cdiv(C, BN_CW), nblk), ga((unsigned)cdiv(C, BN_CW), (unsigned)cdiv(M, BN_AROWS));
+  const int arows = bn_arows(M, C);
+  const dim3 blk(16, BN_RL), gp((unsigned)cdiv(C, BN_CW), nblk), ga((unsigned)cdiv(C, BN_CW), (unsigned)cdiv(M, arows));
   hipStream_t st = as_stream(stream);
 #define TD_BNB(T_)                                                                                                  \
   hipLaunchKernelGGL(bn_bwd_partial_kernel<T_>, gp, blk, 0, st, (const T_*)dy, lddy, (const T_*)a, lda, mean_rstd,  \
                      workspace, M, C, relu);                                                                        \
   hipLaunchKernelGGL(bn_bwd_apply_kernel<T_>, ga, blk, 0, st, (const T_*)dy, lddy, (const T_*)a, lda, mean_rstd,    \
-                     gamma, workspace, nblk, dgamma, dbeta, (T_*)da, ldda, M, C, relu, 1.0f / (float)M, colsum_partial)
+                     gamma, workspace, nblk, dgamma, dbeta, (T_*)da, ldda, M, C, relu, 1.0f / (float)M, colsum_partial, arows)
   W2V2_DISPATCH_ACT(dtype, "bn_bwd", TD_BNB(AT););
 #undef TD_BNB
   W2V2_CHECK_LAUNCH("bn_bwd");

@@ -263,7 +263,7 @@ class _Tdnn:
                           bias=st.p(self.pre + "conv.conv.bias"))
         if plan.train:
             self.da = plan.buf(M, cout)
-            self.cs_part = torch.empty(ops.bn_colsum_rows(M), cout, dtype=f32, device=dev)   # bias-gradient partials
+            self.cs_part = torch.empty(ops.bn_colsum_rows(M, cout), cout, dtype=f32, device=dev)   # bias-gradient partials
             self.dwp = torch.zeros(cout, K, dtype=f32, device=dev) if k > 1 else None
             dW = self.dwp if k > 1 else st.g(self.pre + "conv.conv.weight").view(cout, cin)
             # bf16: weight + bias gradient through the grouped, atomic-free wgrad kernels (K-major operands: da and the

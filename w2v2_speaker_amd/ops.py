@@ -667,13 +667,13 @@ def bn_fwd(a, lda: int, work, mean_rstd, running, gamma, beta, y, ldy: int, M: i
                                  stream()), "bn_fwd")
 
 
-def bn_colsum_rows(M: int) -> int:
-    return int(lib().w2v2_bn_colsum_rows(M))
+def bn_colsum_rows(M: int, C: int) -> int:
+    return int(lib().w2v2_bn_colsum_rows(M, C))
 
 
 def bn_bwd(dy, lddy: int, a, lda: int, mean_rstd, gamma, work, dgamma, dbeta, da, ldda: int, M: int, C: int,
            relu: bool, colsum_partial=None) -> None:
-    """colsum_partial [bn_colsum_rows(M), C] f32 (optional): written with the per-row-block column sums of da."""
+    """colsum_partial [bn_colsum_rows(M, C), C] f32 (optional): written with the per-row-block column sums of da."""
     _dev(dy, a, mean_rstd, gamma, work, dgamma, dbeta, da, colsum_partial)
     _lib.check(lib().w2v2_bn_bwd(dy.data_ptr(), lddy, a.data_ptr(), lda, mean_rstd.data_ptr(), gamma.data_ptr(),
                                  work.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), da.data_ptr(), ldda, M, C,
