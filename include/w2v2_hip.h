@@ -382,10 +382,19 @@ int w2v2_bn_colsum_rows(int M, int C);
 int w2v2_bn_bwd(const void* dy, int64_t lddy, const void* a, int64_t lda, const float* mean_rstd, const float* gamma,
                 float* workspace, float* dgamma, float* dbeta, void* da, int64_t ldda, int M, int C, int relu,
                 float* colsum_partial, int dtype, void* stream);
+/* The same with the output gradient given as dy + dy2 (same shape, own row strides; both kernels add them as they read):
+ * a Res2Net chunk's output feeds the next chunk and the block's concatenation, so its gradient has two sources. */
+int w2v2_bn_bwd_sum(const void* dy, int64_t lddy, const void* dy2, int64_t lddy2, const void* a, int64_t lda,
+                    const float* mean_rstd, const float* gamma, float* workspace, float* dgamma, float* dbeta, void* da,
+                    int64_t ldda, int M, int C, int relu, float* colsum_partial, int dtype, void* stream);
 /* Conv1d(padding="same", padding_mode="reflect", dilation d, odd k) as im2col + GEMM:
  * col[(b,t)][j*Cin + c] = x[b][reflect(t + (j - (k-1)/2) d)][c]; col2im is its exact adjoint (gather, deterministic) */
 int w2v2_im2col_reflect(const void* x, int64_t ldx, void* col, int B, int T, int Cin, int k, int dilation, int dtype,
                         void* stream);
+/* The same over x + x2 (two row-strided operands of one shape, summed tap by tap): the input x_i + y_{i-1} of a Res2Net
+ * chunk (speechbrain Res2NetBlock.forward) without a pass that materialises the sum. */
+int w2v2_im2col_reflect_sum(const void* x, int64_t ldx, const void* x2, int64_t ldx2, void* col, int B, int T, int Cin,
+                            int k, int dilation, int dtype, void* stream);
 int w2v2_col2im_reflect(const void* dcol, void* dx, int64_t lddx, int B, int T, int Cin, int k, int dilation,
                         int accumulate, int dtype, void* stream);
 /* y[m][0..C) = a[m][0..C) + b[m][0..C) over row-strided views (Res2Net cumulative adds); b == NULL: y = a (a strided

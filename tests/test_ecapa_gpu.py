@@ -211,6 +211,60 @@ def test_batchnorm_kernels_vs_torch(dtype, M, C, ld, relu):
     assert torch.equal(running, run0)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_two_operand_forms_of_im2col_and_batchnorm_backward_equal_the_materialised_sum(dtype):
+    """w2v2_im2col_reflect_sum / w2v2_bn_bwd_sum (round 5: the Res2Net chunk input x_i + y_{i-1} and its two-source output
+    gradient are summed by the kernel that reads them) against add_strided followed by the one-operand kernel.  f32:
+    bit-equal.  bf16: the im2col form rounds the same sum once, so it is bit-equal too; the BatchNorm backward adds in
+    f32 what the old path had rounded to bf16 first, so it is compared with the f32 pipeline instead."""
+    from w2v2_speaker_amd import ops
+    dev = DEV
+    B, T, w, C, k, dil = 3, 57, 16, 64, 3, 2
+    M = B * T
+    g = torch.Generator().manual_seed(5)
+    t1 = torch.randn(M, C, generator=g).to(dtype).to(dev)
+    r2 = torch.randn(M, C, generator=g).to(dtype).to(dev)
+    x, x2 = t1[:, 2 * w:3 * w], r2[:, w:2 * w]
+    summed = torch.empty(M, w, dtype=dtype, device=dev)
+    ops.add_strided(x, C, x2, C, summed, w, M, w)
+    col_ref = torch.empty(M, k * w, dtype=dtype, device=dev)
+    col = torch.empty(M, k * w, dtype=dtype, device=dev)
+    ops.im2col_reflect(summed, w, col_ref, B, T, w, k, dil)
+    ops.im2col_reflect(x, C, col, B, T, w, k, dil, x2, C)
+    assert torch.equal(col, col_ref)
+    # BatchNorm backward with dy = d1 + d2
+    a = (torch.randn(M, w, generator=g) * 1.5).to(dtype).to(dev)
+    d1 = torch.randn(M, C, generator=g).to(dtype).to(dev)
+    d2 = torch.randn(M, C, generator=g).to(dtype).to(dev)
+    gamma, beta = (torch.rand(w, generator=g) + 0.5).to(dev), torch.randn(w, generator=g).to(dev)
+    work, mr = ops.bn_workspace(M, w, dev), torch.empty(w, 2, device=dev)
+    y = torch.empty(M, w, dtype=dtype, device=dev)
+    ops.bn_fwd(a, w, work, mr, None, gamma, beta, y, w, M, w, 1e-5, 0.1, True, True)
+
+    def run(two_operands, dt_):
+        da = torch.empty(M, w, dtype=dt_, device=dev)
+        dg, db = torch.empty(w, device=dev), torch.empty(w, device=dev)
+        csp = torch.empty(ops.bn_colsum_rows(M, w), w, device=dev)
+        a_, y1, y2 = a.to(dt_), d1.to(dt_), d2.to(dt_)
+        if two_operands:
+            ops.bn_bwd(y1[:, w:2 * w], C, a_, w, mr, gamma, work, dg, db, da, w, M, w, True, colsum_partial=csp,
+                       dy2=y2[:, 3 * w:4 * w], lddy2=C)
+        else:
+            s_ = torch.empty(M, w, dtype=dt_, device=dev)
+            ops.add_strided(y1[:, w:2 * w], C, y2[:, 3 * w:4 * w], C, s_, w, M, w)
+            ops.bn_bwd(s_, w, a_, w, mr, gamma, work, dg, db, da, w, M, w, True, colsum_partial=csp)
+        return da, dg, db, csp
+
+    got = run(True, dtype)
+    if dtype == torch.float32:
+        for u, v in zip(got, run(False, torch.float32)):
+            assert torch.equal(u, v)
+    else:
+        ref = run(False, torch.float32)                        # (a, d1, d2 hold bf16 values exactly)
+        assert rel_l2(got[0].float().cpu().double(), ref[0].cpu().double()) < 6e-3
+        assert rel_l2(got[1].cpu().double(), ref[1].cpu().double()) < 1e-4 and rel_l2(got[2].cpu().double(), ref[2].cpu().double()) < 1e-4
+
+
 def test_ecapa_full_size_f32_step_every_weight_gradient_and_running_statistics():
     """BASELINE configs[4] at ITS OWN size under -m gpu: C = 1024, 66 utterances x 300 frames, f32 --
     the geometry whose token-long weight gradients take the split-K path with f32 atomics (3072 x 3072 x 19800 eight

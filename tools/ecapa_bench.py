@@ -110,11 +110,13 @@ def bench_ecapa(args, world, rank, dev, dist, emit=True):
     esz = lambda t: t.element_size()
     ft = _FamilyTimer(ops)
     ft.wrap("bn_fwd", "batchnorm", lambda a, lda, work, mr, run, ga, be, y, ldy, M, C, *r: 3 * M * C * esz(a))
-    ft.wrap("bn_bwd", "batchnorm", lambda dy, lddy, a, lda, mr, ga, work, dga, dbe, da, ldda, M, C, *r, **kw: 5 * M * C * esz(a))
+    ft.wrap("bn_bwd", "batchnorm", lambda dy, lddy, a, lda, mr, ga, work, dga, dbe, da, ldda, M, C, *r, **kw:
+            (7 if kw.get("dy2") is not None else 5) * M * C * esz(a))
     ft.wrap("se_scale", "se_gate", lambda x, g_, y, B, T, C: 2 * B * T * C * esz(x))
     ft.wrap("se_bwd_gate", "se_gate", lambda d, x, dg, B, T, C: 2 * B * T * C * esz(x))
     ft.wrap("se_bwd_x", "se_gate", lambda d, g_, ds, dx, B, T, C: 2 * B * T * C * esz(d))
-    ft.wrap("im2col_reflect", "im2col", lambda x, ldx, col, B, T, Cin, k, dil: (1 + k) * B * T * Cin * esz(x))
+    ft.wrap("im2col_reflect", "im2col",
+            lambda x, ldx, col, B, T, Cin, k, dil, x2=None, ldx2=0: ((2 if x2 is not None else 1) + k) * B * T * Cin * esz(x))
     ft.wrap("col2im_reflect", "im2col", lambda dcol, dx, lddx, B, T, Cin, k, dil, acc: (k + 1 + int(acc)) * B * T * Cin * esz(dx))
     ft.wrap("add_strided", "res2net_add", lambda a, lda, b, ldb, y, ldy, M, C: (3 if b is not None else 2) * M * C * esz(a))
 

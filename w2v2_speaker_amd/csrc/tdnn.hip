@@ -171,6 +171,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ a, 
 }
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const T* __restrict__ dy, int64_t lddy,
+                                                             const T* __restrict__ dy2, int64_t lddy2,
                                                              const T* __restrict__ a, int64_t lda,
                                                              const float* __restrict__ mean_rstd,
                                                              float* __restrict__ partial, int M, int C, int relu) {
@@ -191,6 +192,15 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const T* __restrict
         v[u].load(a + mm * lda + cg);
         d[u].load(dy + mm * lddy + cg);
       }
+      if (dy2 != nullptr) {                 // the gradient is dy + dy2 (two Res2Net branches), summed here
+#pragma unroll
+        for (int u = 0; u < BN_UN; ++u) {
+          Vec8<T> w;
+          w.load(dy2 + (int64_t)min(m + u * BN_RL, m1 - 1) * lddy2 + cg);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) d[u].v[e] += w.v[e];
+        }
+      }
 #pragma unroll
       for (int u = 0; u < BN_UN; ++u)
         if (m + u * BN_RL < m1) {
@@ -207,6 +217,7 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const T* __restrict
 }
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dy, int64_t lddy,
+                                                           const T* __restrict__ dy2, int64_t lddy2,
                                                            const T* __restrict__ a, int64_t lda,
                                                            const float* __restrict__ mean_rstd,
                                                            const float* __restrict__ gamma,
@@ -250,6 +261,15 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
       v[u].load(a + mm * lda + cg);
       d[u].load(dy + mm * lddy + cg);
     }
+    if (dy2 != nullptr) {
+#pragma unroll
+      for (int u = 0; u < BN_UN; ++u) {
+        Vec8<T> w;
+        w.load(dy2 + (int64_t)min(m + u * BN_RL, m1 - 1) * lddy2 + cg);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) d[u].v[e] += w.v[e];
+      }
+    }
 #pragma unroll
     for (int u = 0; u < BN_UN; ++u)
       if (m + u * BN_RL < m1) {
@@ -289,8 +309,8 @@ __device__ __forceinline__ int reflect(int p, int Tn) {
 }
 // col[(b,t)][j*Cin + c] = x[b][reflect(t + off_j)][c];   8 channels per thread
 template <typename T>
-__global__ void im2col_reflect_kernel(const T* __restrict__ x, int64_t ldx, T* __restrict__ col, int B, int Tn,
-                                      int Cin, int k, int dil) {
+__global__ void im2col_reflect_kernel(const T* __restrict__ x, int64_t ldx, const T* __restrict__ x2, int64_t ldx2,
+                                      T* __restrict__ col, int B, int Tn, int Cin, int k, int dil) {
   const int nch = Cin >> 3;
   const int64_t total = (int64_t)B * Tn * k * nch;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -302,6 +322,12 @@ __global__ void im2col_reflect_kernel(const T* __restrict__ x, int64_t ldx, T* _
     const int src = reflect(t + (j - (k - 1) / 2) * dil, Tn);
     Vec8<T> v;
     v.load(x + ((int64_t)b * Tn + src) * ldx + ch * 8);
+    if (x2 != nullptr) {                   // taps of x + x2 (Res2Net: chunk input + previous chunk's output), summed here
+      Vec8<T> w;
+      w.load(x2 + ((int64_t)b * Tn + src) * ldx2 + ch * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v.v[e] += w.v[e];
+    }
     v.store(col + ((int64_t)b * Tn + t) * ((int64_t)k * Cin) + (int64_t)j * Cin + ch * 8);
   }
 }
@@ -483,38 +509,66 @@ extern "C" int w2v2_bn_fwd(const void* a, int64_t lda, float* workspace, float* 
   return 0;
 }
 
-extern "C" int w2v2_bn_bwd(const void* dy, int64_t lddy, const void* a, int64_t lda, const float* mean_rstd,
-                           const float* gamma, float* workspace, float* dgamma, float* dbeta, void* da, int64_t ldda,
-                           int M, int C, int relu, float* colsum_partial, int dtype, void* stream) {
+static int bn_bwd_impl(const void* dy, int64_t lddy, const void* dy2, int64_t lddy2, const void* a, int64_t lda,
+                       const float* mean_rstd, const float* gamma, float* workspace, float* dgamma, float* dbeta, void* da,
+                       int64_t ldda, int M, int C, int relu, float* colsum_partial, int dtype, void* stream) {
   W2V2_REQUIRE(dy && a && mean_rstd && gamma && workspace && dgamma && dbeta && da && M > 0 && C > 0 && C % 8 == 0 &&
-                   lda % 8 == 0 && lddy % 8 == 0 && ldda % 8 == 0, "bn_bwd: bad arguments (C and strides multiples of 8)");
+                   lda % 8 == 0 && lddy % 8 == 0 && ldda % 8 == 0 && (dy2 == nullptr || lddy2 % 8 == 0),
+               "bn_bwd: bad arguments (C and strides multiples of 8)");
   const int nblk = (int)cdiv(M, bn_rows_host(C));
   const int arows = bn_arows(M, C);
   const dim3 blk(16, BN_RL), gp((unsigned)cdiv(C, BN_CW), nblk), ga((unsigned)cdiv(C, BN_CW), (unsigned)cdiv(M, arows));
   hipStream_t st = as_stream(stream);
 #define TD_BNB(T_)                                                                                                  \
-  hipLaunchKernelGGL(bn_bwd_partial_kernel<T_>, gp, blk, 0, st, (const T_*)dy, lddy, (const T_*)a, lda, mean_rstd,  \
-                     workspace, M, C, relu);                                                                        \
-  hipLaunchKernelGGL(bn_bwd_apply_kernel<T_>, ga, blk, 0, st, (const T_*)dy, lddy, (const T_*)a, lda, mean_rstd,    \
-                     gamma, workspace, nblk, dgamma, dbeta, (T_*)da, ldda, M, C, relu, 1.0f / (float)M, colsum_partial, arows)
+  hipLaunchKernelGGL(bn_bwd_partial_kernel<T_>, gp, blk, 0, st, (const T_*)dy, lddy, (const T_*)dy2, lddy2,         \
+                     (const T_*)a, lda, mean_rstd, workspace, M, C, relu);                                          \
+  hipLaunchKernelGGL(bn_bwd_apply_kernel<T_>, ga, blk, 0, st, (const T_*)dy, lddy, (const T_*)dy2, lddy2,           \
+                     (const T_*)a, lda, mean_rstd, gamma, workspace, nblk, dgamma, dbeta, (T_*)da, ldda, M, C, relu, \
+                     1.0f / (float)M, colsum_partial, arows)
   W2V2_DISPATCH_ACT(dtype, "bn_bwd", TD_BNB(AT););
 #undef TD_BNB
   W2V2_CHECK_LAUNCH("bn_bwd");
   return 0;
 }
+extern "C" int w2v2_bn_bwd(const void* dy, int64_t lddy, const void* a, int64_t lda, const float* mean_rstd,
+                           const float* gamma, float* workspace, float* dgamma, float* dbeta, void* da, int64_t ldda,
+                           int M, int C, int relu, float* colsum_partial, int dtype, void* stream) {
+  return bn_bwd_impl(dy, lddy, nullptr, 0, a, lda, mean_rstd, gamma, workspace, dgamma, dbeta, da, ldda, M, C, relu,
+                     colsum_partial, dtype, stream);
+}
+// the same with the output gradient given as dy + dy2 (two row-strided operands of one shape; both kernels add them as
+// they read): the Res2Net chunk whose output feeds the next chunk AND the block's concatenation
+extern "C" int w2v2_bn_bwd_sum(const void* dy, int64_t lddy, const void* dy2, int64_t lddy2, const void* a, int64_t lda,
+                               const float* mean_rstd, const float* gamma, float* workspace, float* dgamma, float* dbeta,
+                               void* da, int64_t ldda, int M, int C, int relu, float* colsum_partial, int dtype,
+                               void* stream) {
+  W2V2_REQUIRE(dy2 != nullptr, "bn_bwd_sum: null second operand");
+  return bn_bwd_impl(dy, lddy, dy2, lddy2, a, lda, mean_rstd, gamma, workspace, dgamma, dbeta, da, ldda, M, C, relu,
+                     colsum_partial, dtype, stream);
+}
 
-extern "C" int w2v2_im2col_reflect(const void* x, int64_t ldx, void* col, int B, int T, int Cin, int k, int dilation,
-                                   int dtype, void* stream) {
+static int im2col_reflect_impl(const void* x, int64_t ldx, const void* x2, int64_t ldx2, void* col, int B, int T, int Cin,
+                               int k, int dilation, int dtype, void* stream) {
   W2V2_REQUIRE(x && col && B > 0 && T > 0 && Cin % 8 == 0 && k % 2 == 1 && dilation >= 1 && ldx % 8 == 0 &&
-                   dilation * (k - 1) / 2 < T,
+                   (x2 == nullptr || ldx2 % 8 == 0) && dilation * (k - 1) / 2 < T,
                "im2col_reflect: bad arguments (odd k, Cin %% 8 == 0, padding < T)");
   const int nb = td_blocks((int64_t)B * T * k * (Cin >> 3));
   hipStream_t st = as_stream(stream);
   W2V2_DISPATCH_ACT(dtype, "im2col_reflect",
-    hipLaunchKernelGGL(im2col_reflect_kernel<AT>, dim3(nb), dim3(256), 0, st, (const AT*)x, ldx,
+    hipLaunchKernelGGL(im2col_reflect_kernel<AT>, dim3(nb), dim3(256), 0, st, (const AT*)x, ldx, (const AT*)x2, ldx2,
                            (AT*)col, B, T, Cin, k, dilation););
   W2V2_CHECK_LAUNCH("im2col_reflect");
   return 0;
+}
+extern "C" int w2v2_im2col_reflect(const void* x, int64_t ldx, void* col, int B, int T, int Cin, int k, int dilation,
+                                   int dtype, void* stream) {
+  return im2col_reflect_impl(x, ldx, nullptr, 0, col, B, T, Cin, k, dilation, dtype, stream);
+}
+// the taps of x + x2 (same shape, own row strides): the Res2Net chunk input x_i + y_{i-1} without materialising the sum
+extern "C" int w2v2_im2col_reflect_sum(const void* x, int64_t ldx, const void* x2, int64_t ldx2, void* col, int B, int T,
+                                       int Cin, int k, int dilation, int dtype, void* stream) {
+  W2V2_REQUIRE(x2 != nullptr, "im2col_reflect_sum: null second operand");
+  return im2col_reflect_impl(x, ldx, x2, ldx2, col, B, T, Cin, k, dilation, dtype, stream);
 }
 
 extern "C" int w2v2_col2im_reflect(const void* dcol, void* dx, int64_t lddx, int B, int T, int Cin, int k, int dilation,

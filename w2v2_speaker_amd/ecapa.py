@@ -14,6 +14,8 @@ views of their parent tensors; BatchNorm uses deterministic two-stage batch stat
 """
 from __future__ import annotations
 
+import os
+
 import dataclasses
 import math
 from collections import OrderedDict
@@ -246,9 +248,12 @@ class _Tdnn:
     """TDNNBlock = Conv1d("same", reflect, dilation) -> ReLU -> BatchNorm1d over one [M, Cin] view -> [M, Cout] view."""
 
     def __init__(self, plan: "EcapaPlan", prefix: str, x: torch.Tensor, ldx: int, cin: int, cout: int, k: int, dil: int,
-                 y: torch.Tensor, ldy: int):
+                 y: torch.Tensor, ldy: int, x2: Optional[torch.Tensor] = None, ldx2: int = 0):
+        """x2 (k > 1 only): the block convolves x + x2 -- the im2col pass sums the two while it gathers the taps."""
         st, B, T, dev, adt, f32 = plan.store, plan.B, plan.T, plan.dev, plan.adt, torch.float32
+        assert x2 is None or k > 1, "a second input operand needs the im2col pass (k > 1)"
         self.plan, self.pre, self.x, self.ldx, self.y, self.ldy = plan, FE + prefix, x, ldx, y, ldy
+        self.x2, self.ldx2 = x2, ldx2
         self.cin, self.cout, self.k, self.dil = cin, cout, k, dil
         M, K = B * T, k * cin
         self.M, self.K = M, K
@@ -292,7 +297,7 @@ class _Tdnn:
     def forward(self) -> None:
         st, pl = self.plan.store, self.plan
         if self.k > 1:
-            ops.im2col_reflect(self.x, self.ldx, self.col, pl.B, pl.T, self.cin, self.k, self.dil)
+            ops.im2col_reflect(self.x, self.ldx, self.col, pl.B, pl.T, self.cin, self.k, self.dil, self.x2, self.ldx2)
         self.g_fwd()
         ops.bn_fwd(self.a, self.cout, self.work, self.mean_rstd, self.running, st.p(self.pre + "norm.norm.weight"),
                    st.p(self.pre + "norm.norm.bias"), self.y, self.ldy, self.M, self.cout, BN_EPS, BN_MOMENTUM, True,
@@ -319,14 +324,14 @@ class _Tdnn:
                                  self.plan.store.g(self.pre + "conv.conv.weight"))
 
     def backward(self, dy: torch.Tensor, lddy: int, dx: Optional[torch.Tensor], lddx: int, accumulate: bool,
-                 defer_dw: bool = False) -> None:
+                 defer_dw: bool = False, dy2: Optional[torch.Tensor] = None, lddy2: int = 0) -> None:
         """dy = gradient of the block output (row stride lddy); dx (None: input needs no gradient) receives or, with
         ``accumulate``, is incremented by the input gradient.  Parameter gradients go to the arena; with ``defer_dw``
         (bf16) the owner launches the weight gradients of several blocks in one grouped call afterwards."""
         st, pl = self.plan.store, self.plan
         ops.bn_bwd(dy, lddy, self.a, self.cout, self.mean_rstd, st.p(self.pre + "norm.norm.weight"), self.work,
                    st.g(self.pre + "norm.norm.weight"), st.g(self.pre + "norm.norm.bias"), self.da, self.cout, self.M,
-                   self.cout, True, colsum_partial=None if self.grouped else self.cs_part)
+                   self.cout, True, colsum_partial=None if self.grouped else self.cs_part, dy2=dy2, lddy2=lddy2)
         if not (self.grouped and defer_dw):
             self.weight_grad_single()
         if dx is None:
@@ -398,17 +403,21 @@ class _SERes2Net:
         e = lambda c: plan.buf(M, c)
         self.t1, self.r2, self.t2, self.se_out = e(C), e(C), e(C), e(C)
         self.tdnn1 = _Tdnn(plan, p + "tdnn1.", x, ldx, C, C, 1, 1, self.t1, C)
-        self.sums = [None, None] + [e(w) for _ in range(2, sc)]                  # x_i + y_{i-1}, i >= 2
+        # chunk i >= 2 convolves x_i + y_{i-1}: with k > 1 the im2col pass sums the two slices while it gathers the taps
+        # (no sum tensor, no add launch); k = 1 keeps a materialised sum
+        fuse = cfg.kernel_sizes[idx] > 1
+        self.sums = [None, None] + [None if fuse else e(w) for _ in range(2, sc)]
         self.chunks: List[Optional[_Tdnn]] = [None]
         for i in range(1, sc):
-            src, ld = (_cols(self.t1, w, 2 * w), C) if i == 1 else (self.sums[i], w)
+            x2, ldx2 = (self.r2[:, (i - 1) * w:i * w], C) if (fuse and i >= 2) else (None, 0)
+            src, ld = (_cols(self.t1, i * w, (i + 1) * w), C) if (i == 1 or fuse) else (self.sums[i], w)
             self.chunks.append(_Tdnn(plan, p + f"res2net_block.blocks.{i - 1}.", src, ld, w, w,
-                                     cfg.kernel_sizes[idx], cfg.dilations[idx], self.r2[:, i * w:(i + 1) * w], C))
+                                     cfg.kernel_sizes[idx], cfg.dilations[idx], self.r2[:, i * w:(i + 1) * w], C,
+                                     x2=x2, ldx2=ldx2))
         self.tdnn2 = _Tdnn(plan, p + "tdnn2.", self.r2, C, C, C, 1, 1, self.t2, C)
         self.se = _SEBlock(plan, p + "se_block.", self.t2, self.se_out, C)
         if plan.train:
             self.d_se, self.d_t2, self.d_r2, self.d_t1 = e(C), e(C), e(C), e(C)
-            self.gtmp = e(w)
 
     def blocks(self):
         return [self.tdnn1] + [c for c in self.chunks if c is not None] + [self.tdnn2]
@@ -418,7 +427,7 @@ class _SERes2Net:
         self.tdnn1.forward()
         ops.copy_strided(self.t1, C, self.r2, C, M, w)                             # chunk 0 passes through
         for i in range(1, self.sc):
-            if i >= 2:
+            if i >= 2 and self.sums[i] is not None:
                 ops.add_strided(self.t1[:, i * w:], C, self.r2[:, (i - 1) * w:], C, self.sums[i], w, M, w)
             self.chunks[i].forward()
         self.tdnn2.forward()
@@ -434,12 +443,11 @@ class _SERes2Net:
         self.tdnn2.backward(self.d_t2, C, self.d_r2, C, False, defer_dw=True)
         # Res2Net, last slice first: the gradient of (x_i + y_{i-1}) lands in d_t1[:, i] and is carried to y_{i-1}
         for i in range(sc - 1, 0, -1):
-            if i < sc - 1:
-                ops.add_strided(self.d_r2[:, i * w:], C, self.d_t1[:, (i + 1) * w:], C, self.gtmp, w, M, w)
-                dy, ld = self.gtmp, w
-            else:
-                dy, ld = self.d_r2[:, i * w:], C
-            self.chunks[i].backward(dy, ld, self.d_t1[:, i * w:(i + 1) * w], C, False, defer_dw=True)
+            # chunk i < sc - 1 also feeds chunk i + 1: its output gradient is d_r2[:, i] + d_t1[:, i + 1], which the
+            # BatchNorm backward sums as it reads (no sum tensor, no add launch)
+            dy2, ld2 = (self.d_t1[:, (i + 1) * w:(i + 2) * w], C) if i < sc - 1 else (None, 0)
+            self.chunks[i].backward(self.d_r2[:, i * w:(i + 1) * w], C, self.d_t1[:, i * w:(i + 1) * w], C, False,
+                                    defer_dw=True, dy2=dy2, lddy2=ld2)
         ops.copy_strided(self.d_r2, C, self.d_t1, C, M, w)
         self.tdnn1.backward(self.d_t1, C, dx, lddx, accumulate, defer_dw=True)
         # residual: dx += dout

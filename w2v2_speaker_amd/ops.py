@@ -672,18 +672,30 @@ def bn_colsum_rows(M: int, C: int) -> int:
 
 
 def bn_bwd(dy, lddy: int, a, lda: int, mean_rstd, gamma, work, dgamma, dbeta, da, ldda: int, M: int, C: int,
-           relu: bool, colsum_partial=None) -> None:
-    """colsum_partial [bn_colsum_rows(M, C), C] f32 (optional): written with the per-row-block column sums of da."""
-    _dev(dy, a, mean_rstd, gamma, work, dgamma, dbeta, da, colsum_partial)
-    _lib.check(lib().w2v2_bn_bwd(dy.data_ptr(), lddy, a.data_ptr(), lda, mean_rstd.data_ptr(), gamma.data_ptr(),
-                                 work.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), da.data_ptr(), ldda, M, C,
-                                 int(relu), _p(colsum_partial), dt(a), stream()), "bn_bwd")
+           relu: bool, colsum_partial=None, dy2=None, lddy2: int = 0) -> None:
+    """colsum_partial [bn_colsum_rows(M, C), C] f32 (optional): written with the per-row-block column sums of da.
+    dy2 (optional, same shape as dy, own row stride): the output gradient is dy + dy2."""
+    _dev(dy, a, mean_rstd, gamma, work, dgamma, dbeta, da, colsum_partial, dy2)
+    if dy2 is None:
+        _lib.check(lib().w2v2_bn_bwd(dy.data_ptr(), lddy, a.data_ptr(), lda, mean_rstd.data_ptr(), gamma.data_ptr(),
+                                     work.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), da.data_ptr(), ldda, M, C,
+                                     int(relu), _p(colsum_partial), dt(a), stream()), "bn_bwd")
+    else:
+        _lib.check(lib().w2v2_bn_bwd_sum(dy.data_ptr(), lddy, dy2.data_ptr(), lddy2, a.data_ptr(), lda,
+                                         mean_rstd.data_ptr(), gamma.data_ptr(), work.data_ptr(), dgamma.data_ptr(),
+                                         dbeta.data_ptr(), da.data_ptr(), ldda, M, C, int(relu), _p(colsum_partial),
+                                         dt(a), stream()), "bn_bwd_sum")
 
 
-def im2col_reflect(x, ldx: int, col, B: int, T: int, Cin: int, k: int, dilation: int) -> None:
-    _dev(x, col)
-    _lib.check(lib().w2v2_im2col_reflect(x.data_ptr(), ldx, col.data_ptr(), B, T, Cin, k, dilation, dt(x), stream()),
-               "im2col_reflect")
+def im2col_reflect(x, ldx: int, col, B: int, T: int, Cin: int, k: int, dilation: int, x2=None, ldx2: int = 0) -> None:
+    """x2 (optional, same shape, own row stride): the taps of x + x2."""
+    _dev(x, col, x2)
+    if x2 is None:
+        _lib.check(lib().w2v2_im2col_reflect(x.data_ptr(), ldx, col.data_ptr(), B, T, Cin, k, dilation, dt(x), stream()),
+                   "im2col_reflect")
+    else:
+        _lib.check(lib().w2v2_im2col_reflect_sum(x.data_ptr(), ldx, x2.data_ptr(), ldx2, col.data_ptr(), B, T, Cin, k,
+                                                 dilation, dt(x), stream()), "im2col_reflect_sum")
 
 
 def col2im_reflect(dcol, dx, lddx: int, B: int, T: int, Cin: int, k: int, dilation: int, accumulate: bool) -> None:
