@@ -488,14 +488,18 @@ extern "C" int w2v2_gemm(const w2v2_gemm_desc* d, void* stream) {
   hipStream_t st = as_stream(stream);
 
   if (d->dtype_ab != W2V2_F32) {
-    const bool narrow = d->N <= 64;
+    const bool glds = !a.A.trans && !a.B.trans && a.A.vec_ok && a.B.vec_ok && (d->K % 64 == 0) && d->K >= 64 &&
+                      !g_w2v2_no_glds;
+    // 64-column tiles for N <= 64 -- and, on the LDS-DMA kernel, wherever 128-column tiles would leave more than half of
+    // the CUs without a workgroup (the AAM logits: 66 x 5994 x 1536 is 47 tiles of 128 x 128 on 256 CUs streaming 18 MB
+    // of class weights: 33.6 -> 29.3 us; the register-staged kernel measured 2 us slower with the narrower tile)
+    const bool narrow = d->N <= 64 || (glds && cdiv(d->M, 128) * cdiv(d->N, 128) * split * d->batch * 2 <=
+                                                   (int64_t)w2v2_gemm_device_cus());
     const int BM = 128, BN = narrow ? 64 : 128;
     a.tiles_m = (int)cdiv(d->M, BM); a.tiles_n = (int)cdiv(d->N, BN);
     a.k_per_split = (int)(cdiv(cdiv(d->K, split), 64) * 64);
     if (a.k_per_split == 0) a.k_per_split = 64;
     dim3 grid(a.tiles_m * a.tiles_n, split, d->batch);
-    const bool glds = !a.A.trans && !a.B.trans && a.A.vec_ok && a.B.vec_ok && (d->K % 64 == 0) && d->K >= 64 &&
-                      !g_w2v2_no_glds;
     // 256x128 3-stage kernel for the encoder shapes; the conv stack (N = 512, M ~ 3e5) measures
     // slightly faster on the 128x128 kernel at 2 workgroups per CU
     // (two-term weights exist on this kernel only: such a request takes it whatever the shape)

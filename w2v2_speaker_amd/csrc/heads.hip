@@ -53,10 +53,27 @@ __device__ __forceinline__ float block_reduce(float v, float* sh, bool is_max) {
   return is_max ? fmaxf(fmaxf(a, b), fmaxf(c, d)) : (a + b + c + d);
 }
 
+// the same over NW waves, folded in wave order (fixed order: bitwise reproducible)
+template <int NW>
+__device__ __forceinline__ float block_reduce_n(float v, float* sh, bool is_max) {
+  v = is_max ? wave_max(v) : wave_sum(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) sh[wave] = v;
+  __syncthreads();
+  float r = sh[0];
+#pragma unroll
+  for (int w = 1; w < NW; ++w) r = is_max ? fmaxf(r, sh[w]) : r + sh[w];
+  return r;
+}
+
 // One workgroup per utterance row.  z_c = s*cos_c (c != y), z_y = s*phi(cos_y); loss = lse(z) - z_y.
 // dLoss/dcos_c = s * (softmax_c - [c==y]) / B * (c == y ? dphi/dcos : 1).
+// (1024 threads: the three passes over a row's ~6000 logits are a handful of dependent load rounds on B = 66 workgroups;
+//  with 256 threads they were 24 rounds each and the kernel took 25 us, now 13)
+constexpr int AAM_ROW_THREADS = 1024;
 template <typename T>
-__global__ __launch_bounds__(256) void aam_row_kernel(const float* __restrict__ cosv, const int64_t* __restrict__ label,
+__global__ __launch_bounds__(AAM_ROW_THREADS) void aam_row_kernel(const float* __restrict__ cosv, const int64_t* __restrict__ label,
                                                       float* __restrict__ softmax, float* __restrict__ loss_rows,
                                                       T* __restrict__ dcos_w, T* __restrict__ dcos_x,
                                                       const float* __restrict__ inv_x,
@@ -64,8 +81,9 @@ __global__ __launch_bounds__(256) void aam_row_kernel(const float* __restrict__ 
                                                       float* __restrict__ colprod, int B, int C, int64_t ldc,
                                                       float margin, float scale, const float* __restrict__ loss_scale,
                                                       float* __restrict__ correct_rows, int easy_margin) {
-  __shared__ float sh[4];
-  __shared__ int shi[4];
+  constexpr int NT = AAM_ROW_THREADS, NW = NT / 64;
+  __shared__ float sh[NW];
+  __shared__ int shi[NW];
   const int b = blockIdx.x;
   const int64_t yl = label[b];
   // a label outside [0, C) (data module with more speakers than the head): NaN loss for the row, no gradient, no
@@ -98,12 +116,12 @@ __global__ __launch_bounds__(256) void aam_row_kernel(const float* __restrict__ 
   }
   float mx = -INFINITY;
   int amax = 0;
-  for (int c = threadIdx.x; c < C; c += 256) {
+  for (int c = threadIdx.x; c < C; c += NT) {
     const float z = c == y ? zy : cr[c] * sc;
     if (z > mx) { mx = z; amax = c; }                  // first maximum of this thread's (ascending) columns
   }
   const float mine = mx;
-  mx = block_reduce(mx, sh, true);
+  mx = block_reduce_n<NW>(mx, sh, true);
   if (correct_rows != nullptr) {
     // training accuracy (ref: speaker_recognition_module.py:296-307 torchmetrics.Accuracy on the prediction):
     // arg-max of the softmax = smallest column holding the row maximum
@@ -113,17 +131,21 @@ __global__ __launch_bounds__(256) void aam_row_kernel(const float* __restrict__ 
     __syncthreads();
     if ((threadIdx.x & 63) == 0) shi[threadIdx.x >> 6] = cand;
     __syncthreads();
-    if (threadIdx.x == 0)
-      correct_rows[b] = (!bad_label && min(min(shi[0], shi[1]), min(shi[2], shi[3])) == y) ? 1.0f : 0.0f;
+    if (threadIdx.x == 0) {
+      int best = shi[0];
+#pragma unroll
+      for (int w = 1; w < NW; ++w) best = min(best, shi[w]);
+      correct_rows[b] = (!bad_label && best == y) ? 1.0f : 0.0f;
+    }
   }
   float sum = 0.f;
-  for (int c = threadIdx.x; c < C; c += 256) sum += __expf((c == y ? zy : cr[c] * sc) - mx);
-  sum = block_reduce(sum, sh, false);
+  for (int c = threadIdx.x; c < C; c += NT) sum += __expf((c == y ? zy : cr[c] * sc) - mx);
+  sum = block_reduce_n<NW>(sum, sh, false);
   const float inv = 1.0f / sum;
   if (threadIdx.x == 0) loss_rows[b] = bad_label ? __builtin_nanf("") : (mx + __logf(sum)) - zy;
   const float invB = bad_label ? 0.f : (loss_scale ? loss_scale[0] : 1.0f) / (float)B;
   float rd = 0.f;
-  for (int c = threadIdx.x; c < C; c += 256) {
+  for (int c = threadIdx.x; c < C; c += NT) {
     const float cv = cr[c];
     const float p = __expf((c == y ? zy : cv * sc) - mx) * inv;
     softmax[(int64_t)b * ldc + c] = p;
@@ -140,7 +162,7 @@ __global__ __launch_bounds__(256) void aam_row_kernel(const float* __restrict__ 
     }
   }
   if (rowdot != nullptr) {
-    rd = block_reduce(rd, sh, false);
+    rd = block_reduce_n<NW>(rd, sh, false);
     if (threadIdx.x == 0) rowdot[b] = rd;
   }
 }
@@ -152,7 +174,7 @@ extern "C" int w2v2_aam_softmax_fwd_bwd(const float* cos, const int64_t* label, 
                                         int dtype, void* stream) {
   W2V2_REQUIRE(cos && label && softmax && loss_rows && B > 0 && C > 0 && ldc >= C, "aam_softmax: bad arguments");
   W2V2_DISPATCH_ACT(dtype, "aam_softmax",
-    hipLaunchKernelGGL(aam_row_kernel<AT>, dim3(B), dim3(256), 0, as_stream(stream), cos, label, softmax,
+    hipLaunchKernelGGL(aam_row_kernel<AT>, dim3(B), dim3(AAM_ROW_THREADS), 0, as_stream(stream), cos, label, softmax,
                        loss_rows, (AT*)dcos_w, (AT*)dcos_x, inv_x, inv_w, rowdot, colprod, B, C, ldc, margin,
                        scale, loss_scale, correct_rows, easy_margin););
   W2V2_CHECK_LAUNCH("aam_softmax");
