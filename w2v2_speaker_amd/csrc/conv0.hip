@@ -103,8 +103,11 @@ __device__ __forceinline__ bf16_t c0_lo(float x) { return f32_to_bf16(x - bf16_t
 
 constexpr int C0_CPB = 5;        // 128-frame chunks per workgroup: amortises the weight / scale fragments
 
-template <bool APPLY, typename TO>
-__global__ __launch_bounds__(256, 2) void conv0_mfma_kernel(const float* __restrict__ wav, const float* __restrict__ w,
+// CW = channels per wave: 128 (four waves per workgroup, 213 VGPRs, two waves per SIMD) or 64 (eight waves, half the
+// weight / scale / accumulator registers, four waves per SIMD: the apply pass is ~25 VALU ops per output behind an MFMA and in
+// front of a 650 MB store stream, and needs the waves to overlap them)
+template <bool APPLY, typename TO, int CW = 128>
+__global__ __launch_bounds__(CW == 64 ? 512 : 256, CW == 64 ? 4 : 2) void conv0_mfma_kernel(const float* __restrict__ wav, const float* __restrict__ w,
                                                          float* __restrict__ partial, const float* __restrict__ mr,
                                                          const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, TO* __restrict__ y,
@@ -116,25 +119,28 @@ __global__ __launch_bounds__(256, 2) void conv0_mfma_kernel(const float* __restr
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 15, kq = lane >> 4;           // operand row / 8-wide k slot; as output: frame row r, channel quad kq
   // LDS offsets of this lane's 8 k slots relative to the first sample of its frame (zero slot for the padding)
-  int xoff[8];
+  // (packed two to a register, 0xffff = padding: the 64-channel variant runs at the 128-register limit of four waves per SIMD)
+  uint32_t xoff2[4];
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     const int ki = kq * 8 + e;
-    xoff[e] = ki < k ? ki : ki < 2 * k ? ki - k : ki < 3 * k ? nmax + ki - 2 * k : -1;
+    const int o = ki < k ? ki : ki < 2 * k ? ki - k : ki < 3 * k ? nmax + ki - 2 * k : 0xffff;
+    if (e & 1) xoff2[e >> 1] |= (uint32_t)o << 16; else xoff2[e >> 1] = (uint32_t)o;
   }
   const int chunk0 = blockIdx.x * C0_CPB;
   const int nchunk = (L + C0_FRAMES - 1) / C0_FRAMES;
   const int chunk1 = min(chunk0 + C0_CPB, nchunk);
 
+  constexpr int NU = CW / 64, NJ = 4 * NU, NQ = 16 * NU;
   for (int cw0 = 0; cw0 < C; cw0 += 512) {           // uniform trip count: every wave takes part in the staging
-    const int cw = cw0 + wave * 128;                 // this wave's 128 channels
+    const int cw = cw0 + wave * CW;                  // this wave's CW channels
     const bool active = cw < C;
     // weight fragments: fragment j row rho <-> channel cw + (j >> 2) * 64 + (rho >> 2) * 16 + (j & 3) * 4 + (rho & 3):
     // after the MFMA a lane (frame r, quad kq) holds two runs of 16 consecutive channels, cw + u * 64 + kq * 16 + 0..15
     // (u = 0, 1), and the four kq lanes of a frame cover one whole 128-byte line per run -- see the store below
-    c0_bf16x8 wf[8];
+    c0_bf16x8 wf[NJ];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+    for (int j = 0; j < NJ; ++j) {
       const int ch = active ? cw + (j >> 2) * 64 + (r >> 2) * 16 + (j & 3) * 4 + (r & 3) : 0;
       const float* wp = w + (int64_t)ch * k;
 #pragma unroll
@@ -149,19 +155,22 @@ __global__ __launch_bounds__(256, 2) void conv0_mfma_kernel(const float* __restr
     }
     const int cl = active ? cw + kq * 16 : 0;        // this lane's 32 output channels: cl + (q >> 4) * 64 + (q & 15)
     auto chq = [&](int q) -> int { return cl + (q >> 4) * 64 + (q & 15); };
-    float ga[32], be[32];
+    float ga[NQ], be[NQ];
     if constexpr (APPLY) {
 #pragma unroll
-      for (int q = 0; q < 32; ++q) {
+      for (int q = 0; q < NQ; ++q) {
         const float* st = mr + ((int64_t)b * C + chq(q)) * 2;
         ga[q] = gamma[chq(q)] * st[1];
         be[q] = beta[chq(q)] - st[0] * ga[q];
+        // (four at a time: with all the loads of this block in flight at once the 64-channel variant spills two registers,
+        //  and a kernel that touches scratch at all pays for its set-up on every dispatch)
+        if ((q & 3) == 3) __builtin_amdgcn_sched_barrier(0);
       }
     }
-    float s1[32], s2[32];
+    float s1[NQ], s2[NQ];
     if constexpr (!APPLY) {
 #pragma unroll
-      for (int q = 0; q < 32; ++q) { s1[q] = 0.f; s2[q] = 0.f; }
+      for (int q = 0; q < NQ; ++q) { s1[q] = 0.f; s2[q] = 0.f; }
     }
 #pragma unroll 1
     for (int chunk = chunk0; chunk < chunk1; ++chunk) {
@@ -170,7 +179,7 @@ __global__ __launch_bounds__(256, 2) void conv0_mfma_kernel(const float* __restr
       const int nsamp = (nf - 1) * stride + k;
       const float* src = wav + (int64_t)b * N + (int64_t)l0 * stride;
       __syncthreads();                               // previous chunk fully consumed
-      for (int i = threadIdx.x; i <= nmax; i += 256) {
+      for (int i = threadIdx.x; i <= nmax; i += blockDim.x) {
         const float v = i < nsamp ? src[i] : 0.f;
         if (i < nmax) {
           c0_lds[i] = c0_hi(v);
@@ -183,17 +192,19 @@ __global__ __launch_bounds__(256, 2) void conv0_mfma_kernel(const float* __restr
 #pragma unroll 1
       for (int f0 = 0; f0 < (active ? nf : 0); f0 += 16) {
         // activation fragment: frame f0 + r, k slots kq*8 .. +7; rows past the last frame are exact zeros
-        const int sbase = (f0 + r) * stride;
-        const bool live = f0 + r < nf;
+        // (frames past the end and padding slots index past the image and are clamped onto the zero slot: one v_min per
+        //  element instead of a compare + select with a 64-bit condition each)
+        const int sbase = f0 + r < nf ? (f0 + r) * stride : 0x10000;
         c0_bf16x8 xf;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          const bf16_t v = c0_lds[(live && xoff[e] >= 0) ? sbase + xoff[e] : 2 * nmax];
+          const int xo = (int)((xoff2[e >> 1] >> ((e & 1) * 16)) & 0xffffu);
+          const bf16_t v = c0_lds[min(sbase + xo, 2 * nmax)];
           xf[e] = __builtin_bit_cast(__bf16, v);
         }
-        c0_f32x4 acc[8];
+        c0_f32x4 acc[NJ];
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
+        for (int j = 0; j < NJ; ++j)
           acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf, c0_f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
         if constexpr (APPLY) {
           // full-line stores (common.h): lanes r and r ^ 8 swap one 16-byte half, then every instruction writes
@@ -202,7 +213,7 @@ __global__ __launch_bounds__(256, 2) void conv0_mfma_kernel(const float* __restr
           const int fa = f0 + (r & 7);
           TO* dst = y + ((int64_t)b * L + l0 + fa) * C + cl + (lo ? 0 : 8);
 #pragma unroll
-          for (int u = 0; u < 2; ++u) {
+          for (int u = 0; u < NU; ++u) {
             float v[16];
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
@@ -216,7 +227,7 @@ __global__ __launch_bounds__(256, 2) void conv0_mfma_kernel(const float* __restr
           }
         } else {
 #pragma unroll
-          for (int q = 0; q < 32; ++q) {
+          for (int q = 0; q < NQ; ++q) {
             const float u = acc[q >> 2][q & 3];
             s1[q] += u;
             s2[q] = fmaf(u, u, s2[q]);
@@ -227,7 +238,7 @@ __global__ __launch_bounds__(256, 2) void conv0_mfma_kernel(const float* __restr
     if constexpr (!APPLY) {
       // fold the 16 frame rows (lanes with equal kq) in a fixed butterfly order, then one lane per quad writes
 #pragma unroll
-      for (int q = 0; q < 32; ++q) {
+      for (int q = 0; q < NQ; ++q) {
 #pragma unroll
         for (int o = 1; o < 16; o <<= 1) {
           s1[q] += __shfl_xor(s1[q], o, 64);
@@ -237,7 +248,7 @@ __global__ __launch_bounds__(256, 2) void conv0_mfma_kernel(const float* __restr
       if (r == 0 && active) {
         float* pt = partial + ((int64_t)b * gridDim.x + blockIdx.x) * C * 2;
 #pragma unroll
-        for (int q = 0; q < 32; ++q) {
+        for (int q = 0; q < NQ; ++q) {
           pt[2 * chq(q)] = s1[q];
           pt[2 * chq(q) + 1] = s2[q];
         }
@@ -408,6 +419,10 @@ extern "C" int w2v2_conv0_apply(const float* wav, const float* w, const float* m
     const size_t lds2 = (2 * ((size_t)(C0_FRAMES - 1) * stride + k) + 8) * sizeof(bf16_t);
     dim3 grid2((unsigned)cdiv(cdiv(L, C0_FRAMES), C0_CPB), B);
     W2V2_DISPATCH_16(dtype, "conv0_apply",
+      if (C % 512 == 0)      // eight waves x 64 channels, four waves per SIMD: 238.6 -> 215.2 us at B = 66 (same box)
+        hipLaunchKernelGGL((conv0_mfma_kernel<true, AT, 64>), grid2, dim3(512), lds2, as_stream(stream), wav, w,
+                           (float*)nullptr, mean_rstd, gamma, beta, (AT*)y, N, L, C, k, stride);
+      else
       hipLaunchKernelGGL((conv0_mfma_kernel<true, AT>), grid2, dim3(256), lds2, as_stream(stream), wav, w,
                          (float*)nullptr, mean_rstd, gamma, beta, (AT*)y, N, L, C, k, stride););
   } else W2V2_DISPATCH_ACT(dtype, "conv0_apply",
