@@ -3,9 +3,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from w2v2_speaker_amd import ops, _lib
 dev="cuda"; M,H=66*149,768
-x=torch.randn(M,H,device=dev).bfloat16(); r=torch.randn(M,H,device=dev).bfloat16(); y=torch.empty_like(x)
+x=torch.randn(M,H,device=dev).half(); r=torch.randn(M,H,device=dev).half(); y=torch.empty_like(x)
 g=torch.ones(H,device=dev); b=torch.zeros(H,device=dev); mean=torch.empty(M,device=dev); rstd=torch.empty(M,device=dev)
-dy=torch.randn(M,H,device=dev).bfloat16(); ds=torch.empty_like(x); dr=torch.empty_like(x); dg=torch.zeros(H,device=dev); db=torch.zeros(H,device=dev)
+dy=torch.randn(M,H,device=dev).half(); ds=torch.empty_like(x); dr=torch.empty_like(x); dg=torch.zeros(H,device=dev); db=torch.zeros(H,device=dev)
 def t(fn,reps=50):
     for _ in range(3): fn()
     torch.cuda.synchronize(); e0,e1=torch.cuda.Event(enable_timing=True),torch.cuda.Event(enable_timing=True)

@@ -319,6 +319,100 @@ __global__ __launch_bounds__(256, 3) void ln_bwd16_kernel(const T* __restrict__ 
   }
 }
 
+// The same for H = 256 NC (768: NC = 3, 512: NC = 2): a lane owns NC chunks of FOUR columns (8-byte accesses, lane l of a
+// wave takes columns 256 c + 4 l ..).  With 16-byte chunks a 768-wide row is 96 chunks on 64 lanes: half of the wave idles
+// through the second chunk and still holds its registers (151 VGPRs, three waves per SIMD).  Here every lane does the same
+// work, the column accumulators shrink from 2 x 16 to 2 x 4 NC and the kernel runs at four waves per SIMD.
+constexpr int LN_BWD_BLOCKS_Q = 1024;    // four workgroups per CU
+template <typename T, int NC>
+__global__ __launch_bounds__(256, 4) void ln_bwd16q_kernel(const T* __restrict__ dy, const T* __restrict__ s,
+                                                        const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                        const float* __restrict__ gamma, T* __restrict__ ds,
+                                                        T* __restrict__ d_r, float* __restrict__ partial, int M,
+                                                        float p, uint64_t seed) {
+  static_assert(sizeof(T) == 2, "16-bit activations only");
+  constexpr int H = 256 * NC;
+  __shared__ float red[4][H];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float inv_keep = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
+  float ag[NC][4] = {}, ab[NC][4] = {}, gm[NC][4];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const float4 g = *reinterpret_cast<const float4*>(gamma + 256 * c + 4 * lane);
+    gm[c][0] = g.x; gm[c][1] = g.y; gm[c][2] = g.z; gm[c][3] = g.w;
+  }
+  const int stride = gridDim.x * 4;
+  int row = blockIdx.x * 4 + wave;
+  uint2 rdy[NC], rs_[NC], ndy[NC], ns[NC];
+  float mu = 0.f, rs = 0.f, nmu = 0.f, nrs = 0.f;
+  auto fetch = [&](int r, uint2 (&a)[NC], uint2 (&b)[NC], float& m_, float& r_) {
+    m_ = mean[r];
+    r_ = rstd[r];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int64_t off = (int64_t)r * H + 256 * c + 4 * lane;
+      a[c] = *reinterpret_cast<const uint2*>(dy + off);
+      b[c] = *reinterpret_cast<const uint2*>(s + off);
+    }
+  };
+  if (row < M) fetch(row, rdy, rs_, mu, rs);
+  for (; row < M; row += stride) {
+    const int nrow = row + stride;
+    if (nrow < M) fetch(nrow, ndy, ns, nmu, nrs);
+    float c1 = 0.f, c2 = 0.f;
+    float d[NC][4], xh[NC][4];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      unpack2<T>(rdy[c].x, d[c][0], d[c][1]);
+      unpack2<T>(rdy[c].y, d[c][2], d[c][3]);
+      unpack2<T>(rs_[c].x, xh[c][0], xh[c][1]);
+      unpack2<T>(rs_[c].y, xh[c][2], xh[c][3]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        xh[c][e] = (xh[c][e] - mu) * rs;
+        const float g = d[c][e] * gm[c][e];
+        c1 += g;
+        c2 = fmaf(g, xh[c][e], c2);
+        ag[c][e] = fmaf(d[c][e], xh[c][e], ag[c][e]);
+        ab[c][e] += d[c][e];
+      }
+    }
+    c1 = wave_sum(c1) * (1.0f / (float)H);
+    c2 = wave_sum(c2) * (1.0f / (float)H);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int64_t off = (int64_t)row * H + 256 * c + 4 * lane;
+      float o[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = rs * (d[c][e] * gm[c][e] - c1 - xh[c][e] * c2);
+      *reinterpret_cast<uint2*>(ds + off) = make_uint2(pack2<T>(o[0], o[1]), pack2<T>(o[2], o[3]));
+      if (d_r != nullptr) {
+        float s0 = 1.f, s1 = 1.f, s2 = 1.f, s3 = 1.f;
+        if (p > 0.f) {
+          drop_scale2(seed, (uint64_t)off, p, inv_keep, s0, s1);
+          drop_scale2(seed, (uint64_t)(off + 2), p, inv_keep, s2, s3);
+        }
+        *reinterpret_cast<uint2*>(d_r + off) = make_uint2(pack2<T>(o[0] * s0, o[1] * s1), pack2<T>(o[2] * s2, o[3] * s3));
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) { rdy[c] = ndy[c]; rs_[c] = ns[c]; }
+    mu = nmu;
+    rs = nrs;
+  }
+  if (partial == nullptr) return;
+  for (int pass = 0; pass < 2; ++pass) {
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) red[wave][256 * c + 4 * lane + e] = pass == 0 ? ag[c][e] : ab[c][e];
+    __syncthreads();
+    for (int col = threadIdx.x; col < H; col += 256)
+      partial[((int64_t)blockIdx.x * 2 + pass) * H + col] = red[0][col] + red[1][col] + red[2][col] + red[3][col];
+  }
+}
+
 // fold the per-block column partials in a fixed order (deterministic) and add them to dgamma / dbeta:
 // 32 columns x 32 block lanes per workgroup (round 5: 1024 threads; with 8 lanes a thread walked 96 partial rows and a
 // four-LayerNorm fold took 11.6 us), each lane sums every 32nd block (independent loads, unrolled), then a fixed-order
@@ -378,6 +472,14 @@ __global__ __launch_bounds__(1024) void ln_bwd_finalize_many_kernel(const LnFold
   }
 }
 
+// workgroups of the backward (= partial blocks the fold walks): a function of (M, H) only, so that w2v2_layernorm_bwd_fold
+// agrees with w2v2_layernorm_bwd whatever the dtype -- 1024 where the quad-chunk 16-bit kernel applies (four per CU)
+static bool ln_quad_shape(int H) { return H == 512 || H == 768; }      // (NC = 4 spills at the 128-register cap: H = 1024 keeps the 16-byte kernel)
+static int ln_bwd_nblocks(int M, int H) {
+  const int cap = ln_quad_shape(H) ? LN_BWD_BLOCKS_Q : LN_BWD_BLOCKS;
+  return (int)(cdiv(M, 4) < cap ? cdiv(M, 4) : cap);
+}
+
 extern "C" int w2v2_layernorm_bwd_fold(const w2v2_ln_fold* e, int n, int M, int H, void* stream) {
   W2V2_REQUIRE(e && n >= 0 && n <= 8 && H > 0, "layernorm_bwd_fold: bad arguments (at most 8 entries)");
   if (n == 0 || M <= 0) return 0;
@@ -386,7 +488,7 @@ extern "C" int w2v2_layernorm_bwd_fold(const w2v2_ln_fold* e, int n, int M, int 
     W2V2_REQUIRE(e[i].partial && e[i].dgamma && e[i].dbeta, "layernorm_bwd_fold: null pointer in entry %d", i);
     a.partial[i] = e[i].partial; a.dgamma[i] = e[i].dgamma; a.dbeta[i] = e[i].dbeta;
   }
-  const int nb = (int)(cdiv(M, 4) < LN_BWD_BLOCKS ? cdiv(M, 4) : LN_BWD_BLOCKS);
+  const int nb = ln_bwd_nblocks(M, H);
   hipLaunchKernelGGL(ln_bwd_finalize_many_kernel, dim3((unsigned)cdiv(2 * H, 32), n), dim3(32 * LN_FOLD_LANES), 0, as_stream(stream),
                      a, nb, H);
   W2V2_CHECK_LAUNCH("layernorm_bwd_fold");
@@ -409,7 +511,7 @@ extern "C" int w2v2_layernorm_fwd(const void* x, void* r, const float* gamma, co
   return 0;
 }
 
-extern "C" int w2v2_layernorm_bwd_workspace_floats(int H) { return LN_BWD_BLOCKS * 2 * H; }
+extern "C" int w2v2_layernorm_bwd_workspace_floats(int H) { return (LN_BWD_BLOCKS_Q > LN_BWD_BLOCKS ? LN_BWD_BLOCKS_Q : LN_BWD_BLOCKS) * 2 * H; }
 
 extern "C" int w2v2_layernorm_bwd(const void* dy, const void* s, const float* mean, const float* rstd,
                                   const float* gamma, void* ds, void* d_r, float* dgamma, float* dbeta,
@@ -419,11 +521,21 @@ extern "C" int w2v2_layernorm_bwd(const void* dy, const void* s, const float* me
   W2V2_REQUIRE(H % 8 == 0 && H <= 8 * 64 * LN_MAXC, "layernorm_bwd: H=%d unsupported", H);
   W2V2_REQUIRE((dgamma == nullptr) == (dbeta == nullptr), "layernorm_bwd: dgamma/dbeta must come together");
   if (M <= 0) return 0;
-  const int nb = (int)(cdiv(M, 4) < LN_BWD_BLOCKS ? cdiv(M, 4) : LN_BWD_BLOCKS);
+  const int nb = ln_bwd_nblocks(M, H);
   // dgamma == NULL with a workspace: leave the per-block partials in it for w2v2_layernorm_bwd_fold
   float* partial = workspace;
   static const bool no_prefetch = getenv("W2V2_NO_LN_PREFETCH") != nullptr;       // A/B switch
-  if (dtype == W2V2_F32 || no_prefetch) {
+  static const bool no_quad = getenv("W2V2_LN_NO_QUAD") != nullptr;               // A/B switch
+  if (dtype != W2V2_F32 && !no_prefetch && !no_quad && ln_quad_shape(H) && partial != nullptr) {
+    // 16-bit, H = 768 / 1024, per-block partials: the quad-chunk kernel (every lane busy, four waves per SIMD)
+    W2V2_DISPATCH_16(dtype, "layernorm_bwd",
+      if (H == 768)
+        hipLaunchKernelGGL((ln_bwd16q_kernel<AT, 3>), dim3(nb), dim3(256), 0, as_stream(stream), (const AT*)dy, (const AT*)s,
+                           mean, rstd, gamma, (AT*)ds, (AT*)d_r, partial, M, drop_p, seed);
+      else
+        hipLaunchKernelGGL((ln_bwd16q_kernel<AT, 2>), dim3(nb), dim3(256), 0, as_stream(stream), (const AT*)dy, (const AT*)s,
+                           mean, rstd, gamma, (AT*)ds, (AT*)d_r, partial, M, drop_p, seed););
+  } else if (dtype == W2V2_F32 || no_prefetch) {
     W2V2_DISPATCH_ACT(dtype, "layernorm_bwd",
       hipLaunchKernelGGL(ln_bwd_kernel<AT>, dim3(nb), dim3(256), 0, as_stream(stream), (const AT*)dy,
                          (const AT*)s, mean, rstd, gamma, (AT*)ds, (AT*)d_r, dgamma, dbeta, partial, M, H,
