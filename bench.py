@@ -143,7 +143,22 @@ def eer_leg(store, dev, dtype_name):
         eer, _ = calculate_eer(gt, sc)
         mdc, _ = calculate_mdc(gt, sc)
         del ev
-        return {"hip_" + dtype_name: round(float(eer), 6), "reference": round(float(g["eer"]), 6),
+        # the sharper discriminator: the evaluator's centred + length-normed branch removes the
+        # direction all embeddings share (ref: cosine_distance.py:117-127, speaker_recognition_evaluator.py:162-167),
+        # fitted -- as a reference run would -- on the embeddings THIS engine produced
+        from w2v2_speaker_amd.evaluation.speaker.cosine_distance import CosineDistanceEvaluator, EmbeddingSample, EvaluationPair
+        et = torch.from_numpy(e)
+        smp = [EmbeddingSample(k, v) for k, v in zip(_keys, et)]
+        cev = CosineDistanceEvaluator(True, True, len(smp))
+        cev.fit_parameters([v for v in et], [])
+        csc = np.clip((np.array(cev._compute_prediction_scores([(smp[i], smp[j]) for _, i, j in trials])) + 1) / 2, 0, 1)
+        cres = cev.evaluate([EvaluationPair(bool(s), _keys[i], _keys[j]) for s, i, j in trials], smp)
+        centred = {"hip_" + dtype_name: round(float(cres["eer"]), 6), "reference": round(float(g["eer_cl"]), 6),
+                   "abs_diff": round(abs(float(cres["eer"]) - float(g["eer_cl"])), 6),
+                   "min_dcf_hip": round(float(cres["mdc"]), 5), "min_dcf_reference": round(float(g["mdc_cl"]), 5),
+                   "max_abs_score_diff": float(np.abs(csc - g["scores_cl"]).max()),
+                   "what": "CosineDistanceEvaluator(center_before_scoring=True, length_norm_before_scoring=True) fitted on the 32 embeddings"}
+        return {"hip_" + dtype_name: round(float(eer), 6), "reference": round(float(g["eer"]), 6), "centred": centred,
                 "abs_diff": round(abs(float(eer) - float(g["eer"])), 6),
                 "min_dcf_hip": round(float(mdc), 5), "min_dcf_reference": round(float(g["mdc"]), 5),
                 "trials": len(trials), "target_trials": int(sum(gt)),

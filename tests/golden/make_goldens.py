@@ -449,6 +449,44 @@ def golden_eer(mix=None):
          "eer": res["eer"], "eer_threshold": res["eer_threshold"], "mdc": res["mdc"], "mdc_threshold": res["mdc_threshold"],
          "params": np.array([kw["n_speakers"], kw["utts_per_speaker"], kw["n_samples"], kw["seed"]], dtype=np.int64),
          "mix": np.float64(kw["mix"])}
+    # the evaluator's NON-default branches, again through the reference's own code.
+    # (a) centring (ref speaker_recognition_evaluator.py:154-172 = per-dimension z-score with the statistics of
+    # fit_parameters) with and without length norm, fitted on the 32 reference embeddings themselves;
+    # (b) length norm alone; (c) the non-pooled scoring of 2-D embeddings (ref cosine_distance.py:203-232) on six
+    # seeded [frames, 64] embeddings (15 pairs; frame counts either side of the 50-frame subsample) with
+    # ``random.seed(1234)`` set right before the call.
+    prs = [(samples[i], samples[j]) for _, i, j in trials]
+    for tag, (cen, ln) in {"c": (True, False), "cl": (True, True), "l": (False, True)}.items():
+        ev2 = CosineDistanceEvaluator(cen, ln, 32)
+        ev2.fit_parameters([e for e in emb], [])
+        with contextlib.redirect_stdout(io.StringIO()):
+            r2 = ev2.evaluate(pairs, samples)
+            sc2 = np.clip((np.array(ev2._compute_prediction_scores(prs)) + 1) / 2, 0, 1)
+        g[f"scores_{tag}"] = sc2
+        g[f"eer_{tag}"], g[f"mdc_{tag}"] = r2["eer"], r2["mdc"]
+        g[f"eer_threshold_{tag}"], g[f"mdc_threshold_{tag}"] = r2["eer_threshold"], r2["mdc_threshold"]
+        if cen:
+            g["fit_mean"], g["fit_std"] = ev2.mean, ev2.std
+        t2, n2 = sc2[np.array([t[0] for t in trials]) == 1], sc2[np.array([t[0] for t in trials]) == 0]
+        print(f"  center={cen} length_norm={ln}: eer {r2['eer']:.5f} mdc {r2['mdc']:.4f}; target {t2.mean():.4f}+-{t2.std():.4f} "
+              f"non-target {n2.mean():.4f}+-{n2.std():.4f}")
+    import random as _random
+    frames = [30, 50, 75, 149, 149, 10]                             # below / at / above the 50-frame subsample
+    rng = np.random.default_rng(99)
+    base = rng.standard_normal((3, 64)).astype(np.float32)          # three "speakers": frames scatter round a direction
+    np_emb = [torch.from_numpy((base[i % 3] + 0.7 * rng.standard_normal((f, 64))).astype(np.float32))
+              for i, f in enumerate(frames)]
+    np_samples = [EmbeddingSample(f"np{i}", e) for i, e in enumerate(np_emb)]
+    np_trials = [(int(i % 3 == j % 3), i, j) for i in range(6) for j in range(i + 1, 6)]
+    _random.seed(1234)
+    with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+        np_scores = CosineDistanceEvaluator(True, True, 0)._compute_prediction_scores(   # flags are ignored on this branch
+            [(np_samples[i], np_samples[j]) for _, i, j in np_trials])
+    for i, e in enumerate(np_emb):
+        g[f"nonpooled_emb{i}"] = e
+    g["nonpooled_trials"] = np.array(np_trials, dtype=np.int64)
+    g["nonpooled_scores"] = np.array(np_scores, dtype=np.float64)
+    g["nonpooled_seed"] = np.int64(1234)
     if mix is None:
         np.savez_compressed(os.path.join(OUT, "g12_eer.npz"), **to_np(g))
     tgt = scores[np.array([t[0] for t in trials]) == 1]

@@ -605,3 +605,28 @@ def test_prof_summary_steady_state_window(tmp_path):
     whole = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "prof_summary.py"), str(db), "5"],
                            capture_output=True, text=True, check=True).stdout
     assert "init_copy" in whole
+
+
+def test_rank_agreement_signature_is_exact_in_f32_at_base_size():
+    """the start-up check of CAbiBucketAllReducer.broadcast_parameters all-reduces an f32 signature.
+    With the byte count of wav2vec2-base's replica state (103578496 floats x 4 B, + moments + a loss scale) the former
+    13-bit limbs squared past 2^24 and AGREEING ranks failed; 8-bit limbs keep every summed value exact for <= 258 ranks.
+    Simulated here exactly as the wire does it: f32 vectors summed over the ranks in f32."""
+    from w2v2_speaker_amd.comm import signature_agrees, signature_limbs
+    flat = 103578496
+    for nbytes in (flat * 4 * 3 + 8, flat * 4 * 3 + flat * 2 + 16, (1 << 48) - 1, 0, 255, 256, 65535 * 8191):
+        for world in (2, 4, 8, 64, 258):
+            v = torch.tensor(signature_limbs([27, 3, nbytes]), dtype=torch.float32)
+            acc = torch.zeros_like(v)
+            for _ in range(world):
+                acc = acc + v                                   # f32 accumulation, any order gives the same exact sums
+            assert float(acc.max()) < 2 ** 24
+            assert signature_agrees(acc.tolist(), world), (nbytes, world)
+            # ONE rank off by one byte / one tensor / one counter must be caught
+            for other in ([27, 3, nbytes ^ 1], [28, 3, nbytes], [27, 2, nbytes], [27, 3, nbytes ^ (1 << 40)]):
+                bad = acc - v + torch.tensor(signature_limbs(other), dtype=torch.float32)
+                assert not signature_agrees(bad.tolist(), world), (nbytes, world, other)
+    with pytest.raises(ValueError):
+        signature_limbs([1 << 48])
+    with pytest.raises(ValueError):
+        signature_agrees([0.0] * 36, 259)

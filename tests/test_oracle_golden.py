@@ -159,6 +159,53 @@ def test_eer_trial_set_golden_reference_scores_reproduced_by_the_mirror_and_the_
     assert rel_l2(e.numpy(), emb[rows]) < 1e-4
 
 
+def test_evaluator_mirror_non_default_branches_against_the_reference_evaluator():
+    """VERDICT r5 item 1.  g12_eer.npz also holds the REFERENCE evaluator's results on its non-default branches (ref:
+    cosine_distance.py:84-132,203-232; speaker_recognition_evaluator.py:154-172): centring = per-dimension z-score with
+    the fitted statistics, with / without length norm, length norm alone, and the non-pooled scoring of 2-D embeddings
+    under a seeded ``random``.  The mirror must reproduce every score, EER and minDCF."""
+    import random
+    from w2v2_speaker_amd.data.synthetic import synth_trial_set
+    from w2v2_speaker_amd.evaluation.speaker.cosine_distance import (CosineDistanceEvaluator, EmbeddingSample,
+                                                                     EvaluationPair, center_batch)
+    g = load("g12_eer.npz")
+    _, _, keys, trials = synth_trial_set()
+    emb = T(g["embedding"])
+    pairs = [EvaluationPair(bool(s), keys[i], keys[j]) for s, i, j in trials]
+    samples = [EmbeddingSample(k, e) for k, e in zip(keys, emb)]
+    prs = [(samples[i], samples[j]) for _, i, j in trials]
+    for tag, (cen, ln) in {"c": (True, False), "cl": (True, True), "l": (False, True)}.items():
+        ev = CosineDistanceEvaluator(cen, ln, 32)
+        if cen:
+            with pytest.raises(TypeError):            # the reference dies on ``tensor - None`` when nothing was fitted
+                ev._compute_prediction_scores(prs[:2])
+        ev.fit_parameters([e for e in emb], [])
+        if cen:
+            assert np.array_equal(ev.mean.numpy(), g["fit_mean"]) and np.array_equal(ev.std.numpy(), g["fit_std"])
+        sc = np.clip((np.array(ev._compute_prediction_scores(prs)) + 1) / 2, 0, 1)
+        assert np.abs(sc - g[f"scores_{tag}"]).max() < 1e-7, tag
+        res = ev.evaluate(pairs, samples)
+        for k in ("eer", "mdc", "eer_threshold", "mdc_threshold"):
+            assert abs(res[k] - float(g[f"{k}_{tag}"])) < 1e-6, (tag, k)
+        ev.reset_parameters()
+        assert ev.mean is None and ev.std is None
+    # centring is NOT mean subtraction: on this set the two differ by far more than any tolerance
+    plain = torch.nn.functional.cosine_similarity(emb[0:1] - T(g["fit_mean"]), emb[1:2] - T(g["fit_mean"]))
+    z = torch.nn.functional.cosine_similarity(center_batch(emb[0:1], T(g["fit_mean"]), T(g["fit_std"])),
+                                              center_batch(emb[1:2], T(g["fit_mean"]), T(g["fit_std"])))
+    assert abs(float(plain) - float(z)) > 1e-3
+    assert float(g["eer_c"]) < 0.5 * float(g["eer"])       # the centred scoring is the sharper discriminator
+    with pytest.raises(ValueError):
+        CosineDistanceEvaluator(True, False, 0).fit_parameters([emb[0], emb[1]], [])
+    # non-pooled ([frames, features]) embeddings: seeded subsample of <= 50 frames per side, mean pairwise cosine
+    np_emb = [T(g[f"nonpooled_emb{i}"]) for i in range(6)]
+    np_s = [EmbeddingSample(f"np{i}", e) for i, e in enumerate(np_emb)]
+    random.seed(int(g["nonpooled_seed"]))
+    got = CosineDistanceEvaluator(False, False, 0)._compute_prediction_scores(
+        [(np_s[i], np_s[j]) for _, i, j in g["nonpooled_trials"]])
+    assert np.abs(np.array(got) - g["nonpooled_scores"]).max() < 1e-7
+
+
 def test_evaluation_length_utterance_and_third_weight_seed_goldens():
     """g13_long (one 20 s utterance, T = 999, batch 1: how the reference tests, ref src/main.py:506-514) and g14_seed3
     (weights 4099, 6 x 4 s): two more operating points the oracle is pinned at."""

@@ -269,6 +269,22 @@ def test_eer_on_the_synthetic_trial_set_hip_vs_reference(dtype):
     assert dsc < (1e-6 if f32 else 5e-5), dsc
     assert abs(eer - float(g["eer"])) <= (1e-6 if f32 else 1.0 / 48 + 1e-6), (eer, float(g["eer"]))
     assert abs(mdc - float(g["mdc"])) <= (1e-6 if f32 else 0.05), (mdc, float(g["mdc"]))
+    # the centred (z-scored) + length-normed branch of the evaluator (ref: cosine_distance.py:117-127): the direction all
+    # embeddings share is removed, so an embedding error of 1e-3 is ~15x larger relative to what is scored; fitted on the
+    # HIP embeddings as a reference run would fit on its own.  Scores live in 0.35..0.75 here (reference EER 0.0045).
+    from w2v2_speaker_amd.evaluation.speaker.cosine_distance import CosineDistanceEvaluator, EmbeddingSample, EvaluationPair
+    smp = [EmbeddingSample(k, v) for k, v in zip(keys, e)]
+    cev = CosineDistanceEvaluator(True, True, len(smp))
+    cev.fit_parameters([v for v in e], [])
+    csc = np.clip((np.array(cev._compute_prediction_scores([(smp[i], smp[j]) for _, i, j in trials])) + 1) / 2, 0, 1)
+    cres = cev.evaluate([EvaluationPair(bool(s), keys[i], keys[j]) for s, i, j in trials], smp)
+    cd = float(np.abs(csc - g["scores_cl"]).max())
+    print(f"  centred + length norm: hip EER {cres['eer']:.5f} reference {float(g['eer_cl']):.5f}; minDCF {cres['mdc']:.4f} vs "
+          f"{float(g['mdc_cl']):.4f}; max |score diff| {cd:.2e}")
+    if dtype != torch.bfloat16:
+        assert cd < (2e-5 if f32 else 5e-3), cd
+        assert abs(cres["eer"] - float(g["eer_cl"])) <= (1e-6 if f32 else 1.0 / 48 + 1e-6)
+        assert abs(cres["mdc"] - float(g["mdc_cl"])) <= (1e-6 if f32 else 0.05)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
@@ -784,6 +800,40 @@ def test_gradient_buckets_are_final_when_notified_under_layerdrop(dtype):
             s, e = raw[f"layer{l}"]
             assert float(st.grad[s:e].abs().max()) == 0.0
         assert torch.isfinite(st.grad).all()
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_partial_zero_grad_ranges_are_all_written_by_the_backward(dtype):
+    """ParamStore.zero_grad(skip_layers) leaves the encoder's Linear gradients, the AAM weight and the pos-conv
+    weight-norm pair UN-zeroed because the backward writes (does not accumulate into) them.  Enforce that coupling: poison
+    the whole arena with NaN, run the partial zero, and every backward pattern used with it must leave a finite arena
+    that is bitwise the gradient of a run that zeroed everything first."""
+    import dataclasses
+    from w2v2_speaker_amd.engine import Plan
+    cfg, ocfg = _cfgs("tiny")
+    cfg = dataclasses.replace(cfg, num_hidden_layers=4)
+    ocfg = dataclasses.replace(ocfg, num_hidden_layers=4)
+    st, _ = _store(cfg, ocfg, dtype, "aam", 10)
+    if st.scaler is not None:
+        st.scaler[0] = 256.0
+    wav, label = O.synth_batch(4, 4000, 10, seed=3)
+    wav, label = wav.to(DEV), label.to(DEV)
+    plan = Plan(st, 4, 4000, train=True, reg=_no_reg())
+    assert plan.grouped                                   # the path whose zero_grad is partial
+    for skip in [(), (3,), (0,), (1, 2), (0, 1, 2, 3)]:
+        st.grad.zero_()
+        plan.embed(wav, None, skip)
+        plan.head_forward_backward(label)
+        plan.backward()
+        want = st.grad.clone()
+        st.grad.fill_(float("nan"))
+        st.zero_grad(tuple(skip))
+        plan.embed(wav, None, skip)
+        plan.head_forward_backward(label)
+        plan.backward()
+        torch.cuda.synchronize()
+        assert torch.isfinite(st.grad[:st.n_train]).all(), skip
+        assert torch.equal(st.grad[:st.n_train], want[:st.n_train]), skip
 
 
 def test_large_24_layers_5s_batch32_properties():

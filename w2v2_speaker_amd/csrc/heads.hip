@@ -341,12 +341,10 @@ extern "C" int w2v2_aam_dw(const void* dcos_x, int64_t ldc, const void* emb, con
   hipStream_t st = as_stream(stream);
   W2V2_DISPATCH_ACT(dtype, "aam_dw", {
     const size_t lds = (size_t)ADW_BC * ADW_EC * sizeof(AT) + (size_t)(ADW_BC * ADW_CB + 16 * ADW_CB + ADW_CB) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&aam_dw_kernel<AT>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds);
-      attr_set = true;
-    }
+    // the attribute is per DEVICE (a process may drive more than one): set it on every call that needs it, as posconv.hip does
+    if (lds > 64 * 1024)
+      W2V2_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(&aam_dw_kernel<AT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds) == hipSuccess, "aam_dw: cannot raise the dynamic LDS limit to %zu bytes", lds);
     const int nchunk = (int)cdiv(B, ADW_BC), chunk = (int)cdiv(B, nchunk);
     hipLaunchKernelGGL(aam_dw_kernel<AT>, grid, dim3(256), lds, st, (const AT*)dcos_x, ldc, (const AT*)emb, colprod, W, inv_w,
                        dW, B, Cn, E, chunk);

@@ -2,6 +2,7 @@
 cosine similarity, ``(s+1)/2`` clipped to [0,1] (evaluator.py:81), then EER / minDCF."""
 from __future__ import annotations
 
+import random
 from dataclasses import dataclass
 from typing import List, Tuple, Union
 from warnings import warn
@@ -25,14 +26,51 @@ class EmbeddingSample:
     embedding: Union[torch.Tensor, List[torch.Tensor]]
 
 
+def compute_mean_std_batch(all_tensors: torch.Tensor):
+    """ref: speaker_recognition_evaluator.py:154-159 -- per-dimension mean and UNBIASED std over [NUM_SAMPLES, EMBEDDING_SIZE]."""
+    std, mean = torch.std_mean(all_tensors, dim=0)
+    return mean, std
+
+
+def center_batch(embedding_tensor: torch.Tensor, mean: torch.Tensor, std: torch.Tensor) -> torch.Tensor:
+    """ref: speaker_recognition_evaluator.py:162-167 -- despite the name this is a per-dimension z-score:
+    the reference divides by ``std + 1e-12`` as well as subtracting the mean."""
+    return (embedding_tensor - mean) / (std + 1e-12)
+
+
+def length_norm_batch(embedding_tensor: torch.Tensor) -> torch.Tensor:
+    """ref: speaker_recognition_evaluator.py:170-172."""
+    return torch.nn.functional.normalize(embedding_tensor, dim=1)
+
+
 def compute_cosine_scores(left_samples: torch.Tensor, right_samples: torch.Tensor) -> List[float]:
-    return torch.nn.functional.cosine_similarity(left_samples.float(), right_samples.float(), dim=1) \
+    """ref: cosine_distance.py:235-241 (``torch.nn.CosineSimilarity()``: dim 1, eps 1e-8)."""
+    return torch.nn.functional.cosine_similarity(left_samples, right_samples, dim=1, eps=1e-8) \
         .detach().cpu().numpy().tolist()
 
 
+def compute_non_pooled_cosine_scores(left_tensor: torch.Tensor, right_tensor: torch.Tensor) -> float:
+    """ref: cosine_distance.py:203-232 -- a sample whose embedding is 2-D ([frames, features], the ``NoPooling`` head):
+    at most 50 frames per side, drawn with the GLOBAL ``random`` module (left side first, so a caller that seeds
+    ``random`` sees the reference's draws), and the score is the mean of all pairwise frame cosines.  Element (i, j) of
+    the broadcast below is element ``i * p2 + j`` of the reference's repeat_interleave / repeat pair, so the mean runs
+    over the same values in the same order."""
+    p1, p2 = left_tensor.shape[0], right_tensor.shape[0]
+    left = left_tensor[random.sample(range(p1), min(50, p1)), :]
+    right = right_tensor[random.sample(range(p2), min(50, p2)), :]
+    with torch.no_grad():
+        n1, n2, d = left.shape[0], right.shape[0], left.shape[1]
+        score = torch.nn.functional.cosine_similarity(
+            left[:, None, :].expand(n1, n2, d).reshape(n1 * n2, d),
+            right[None, :, :].expand(n1, n2, d).reshape(n1 * n2, d), dim=1, eps=1e-8)
+    return torch.mean(score).detach().cpu().numpy().tolist()
+
+
 class CosineDistanceEvaluator:
-    """ref: cosine_distance.py:66-201 with the default configuration of the hot path
-    (config/evaluator/cosine_distance.yaml: no centering, no length-norm, max_num_training_samples=0)."""
+    """ref: cosine_distance.py:66-201.  Defaults = config/evaluator/cosine_distance.yaml (no centering, no length
+    norm, max_num_training_samples 0); the non-default branches follow the reference as well: centering is
+    ``(x - mean) / (std + 1e-12)`` with the statistics of ``fit_parameters``, then optional length norm, then the
+    cosine; 2-D embeddings take the non-pooled scoring (no centering / length norm there, as in the reference)."""
 
     def __init__(self, center_before_scoring: bool = False, length_norm_before_scoring: bool = False,
                  max_num_training_samples: int = 0):
@@ -42,27 +80,49 @@ class CosineDistanceEvaluator:
         self.mean = None
         self.std = None
 
+    def _using_parameters(self) -> bool:
+        return self.center_before_scoring
+
     def fit_parameters(self, embedding_tensors: List[torch.Tensor], _label_tensors=None):
-        if not self.center_before_scoring:
+        if not self._using_parameters():
             return
         if len(embedding_tensors) <= 2:
             raise ValueError("mean/std calculation requires more than 2 samples")
-        allt = torch.stack(embedding_tensors, dim=0)
-        self.std, self.mean = torch.std_mean(allt, dim=0)
+        self.mean, self.std = compute_mean_std_batch(torch.stack(embedding_tensors, dim=0))
 
-    def _prep(self, t: torch.Tensor) -> torch.Tensor:
-        if self.center_before_scoring and self.mean is not None:
-            t = t - self.mean
-        if self.length_norm_before_scoring:
-            t = torch.nn.functional.normalize(t, dim=1)
-        return t
+    def reset_parameters(self):
+        """ref: cosine_distance.py:99-104."""
+        if not self._using_parameters():
+            return
+        self.mean = None
+        self.std = None
+
+    def _transform_pairs_to_tensor(self, pairs: List[Tuple[EmbeddingSample, EmbeddingSample]]):
+        """ref: speaker_recognition_evaluator.py:123-137."""
+        return (torch.stack([torch.as_tensor(a.embedding) for a, _ in pairs]),
+                torch.stack([torch.as_tensor(b.embedding) for _, b in pairs]))
 
     def _compute_prediction_scores(self, pairs: List[Tuple[EmbeddingSample, EmbeddingSample]]) -> List[float]:
-        if isinstance(pairs[0][0].embedding, list):     # ref: cosine_distance.py:110-112 (ensemble of layers)
+        first = pairs[0][0].embedding
+        if isinstance(first, list):                     # ref: cosine_distance.py:110-112 (ensemble of layers)
             return self._compute_ensemble_prediction_scores(pairs)
-        left = self._prep(torch.stack([torch.as_tensor(a.embedding).flatten().float().cpu() for a, _ in pairs]))
-        right = self._prep(torch.stack([torch.as_tensor(b.embedding).flatten().float().cpu() for _, b in pairs]))
+        if len(first.shape) == 2:                       # ref: cosine_distance.py:114-116 (non-pooled embeddings)
+            return self._compute_non_pooled_prediction_scored(pairs)
+        left, right = self._transform_pairs_to_tensor(pairs)
+        if self.center_before_scoring:
+            if self.mean is None or self.std is None:   # the reference dies on ``tensor - None`` here; say why
+                raise TypeError("center_before_scoring=True but fit_parameters() has not been called "
+                                "(mean / std are None)")
+            left = center_batch(left, self.mean, self.std)
+            right = center_batch(right, self.mean, self.std)
+        if self.length_norm_before_scoring:
+            left = length_norm_batch(left)
+            right = length_norm_batch(right)
         return compute_cosine_scores(left, right)
+
+    def _compute_non_pooled_prediction_scored(self, pairs: List[Tuple[EmbeddingSample, EmbeddingSample]]) -> List[float]:
+        """ref: cosine_distance.py:187-200 (name kept, typo included: callers may reach for it)."""
+        return [compute_non_pooled_cosine_scores(a.embedding, b.embedding) for a, b in pairs]
 
     def _compute_ensemble_prediction_scores(self, pairs: List[Tuple[EmbeddingSample, EmbeddingSample]]) -> List[float]:
         """ref: cosine_distance.py:134-185 -- every sample carries a LIST of embeddings (one per hidden state,
