@@ -733,6 +733,62 @@ def _attention_dropout_tiled(o, lp, B, heads, d, T, p, seed):
     assert rel_l2(dqkv.float().cpu(), qr.grad) < 2.5e-2
 
 
+@pytest.mark.parametrize("lp", LP16)
+@pytest.mark.parametrize("T", [149, 37, 301, 700])
+def test_fused_attention_two_geometries_agree_and_draw_the_same_mask(lp, T):
+    """Round 6: the attention kernels exist in two geometries (attention.hip: <4 waves, 64-row tiles> and <2 waves, 32-row
+    tiles>, chosen by T; W2V2_ATTN_GEOM forces one, read per call).  Same inputs, dropout on: the two must draw the SAME
+    mask (the stream is indexed by absolute (query, key)) and agree to 16-bit rounding on ctx / LSE / dQKV."""
+    import os
+    o = ops()
+    B, heads, d, p, seed = 2, 3, 64, 0.1, 4242
+    H = heads * d
+    qkv = rnd(B, T, 3 * H, seed=T + 7, scale=1.0)
+    qkv[..., :2 * H] *= 1.5
+    qd = qkv.to(lp).to(DEV)
+    dctx = rnd(B, T, H, seed=T + 8).to(lp).to(DEV)
+    probe = torch.zeros(B, T, 3 * H)
+    n = min(d, T)
+    for h in range(heads):
+        probe[:, :n, 2 * H + h * d:2 * H + h * d + n] = torch.eye(n)
+    probe = probe.to(lp).to(DEV)
+    got = {}
+    old = {k: os.environ.get(k) for k in ("W2V2_ATTN_GEOM", "W2V2_ATTN_IDX64")}
+    try:
+        for geom, idx64 in (("64", True), ("32", False), ("32", True), ("64", False)):
+            os.environ["W2V2_ATTN_GEOM"] = geom
+            os.environ.pop("W2V2_ATTN_IDX64", None)
+            if idx64:
+                os.environ["W2V2_ATTN_IDX64"] = "1"
+            ctx = torch.zeros(B, T, H, dtype=lp, device=DEV)
+            lse = torch.zeros(B * heads * T, device=DEV)
+            o.attention_fwd(probe, ctx, lse, B, T, heads, d, d ** -0.5, p, seed)
+            torch.cuda.synchronize()
+            mask = ctx.float().cpu() > 0
+            o.attention_fwd(qd, ctx, lse, B, T, heads, d, d ** -0.5, p, seed)
+            dqkv = torch.zeros(B, T, 3 * H, dtype=lp, device=DEV)
+            delta = torch.zeros(B * heads * T, device=DEV)
+            o.attention_bwd(qd, ctx, dctx, lse, dqkv, delta, B, T, heads, d, d ** -0.5, p, seed)
+            torch.cuda.synchronize()
+            got[geom, idx64] = (mask, ctx.float().cpu(), lse.cpu(), dqkv.float().cpu(), delta.cpu())
+    finally:
+        for k, v in old.items():
+            os.environ.pop(k, None)
+            if v is not None:
+                os.environ[k] = v
+    # the 32-bit dropout counters are the same bits as the 64-bit ones: everything equal, bit for bit, per geometry
+    for geom in ("64", "32"):
+        for x, y in zip(got[geom, True], got[geom, False]):
+            assert torch.equal(x, y), geom
+    a, b = got["64", True], got["32", False]
+    assert torch.equal(a[0], b[0]) and 0.85 < float(a[0][:, :, :n].float().mean()) < 0.95
+    tol = 3e-3 if lp == torch.float16 else 1.2e-2
+    assert rel_l2(b[1], a[1]) < tol
+    assert float((a[2] - b[2]).abs().max()) < 1e-4
+    assert rel_l2(b[3], a[3]) < 2 * tol
+    assert rel_l2(b[4], a[4]) < tol
+
+
 def test_dropout_stream_statistics():
     """Counter-based dropout (common.h rng_pair): keep rate, independence of the two elements that share one
     32-bit hash, independence of neighbouring hashes, and decorrelation of consecutive seeds."""

@@ -20,8 +20,10 @@ def timeit(fn, reps=50):
     for _ in range(reps): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) * 1e3 / reps
-for p in (0.0, 0.1):
+for geom in os.environ.get("GEOMS", "64,32").split(","):
+  os.environ["W2V2_ATTN_GEOM"] = geom            # read per call by attention.hip
+  for p in (0.0, 0.1):
     f = timeit(lambda: ops.attention_fwd(qkv, ctx, lse, B, T, heads, d, d ** -0.5, p, 1))
     b = timeit(lambda: ops.attention_bwd(qkv, ctx, dctx, lse, dqkv, delta, B, T, heads, d, d ** -0.5, p, 1))
     fl = 4.0 * B * heads * T * T * d
-    print(f"T={T} p={p}: fwd {f:7.1f} us ({fl / f / 1e6:6.1f} TF)   bwd {b:7.1f} us ({2.5 * fl / b / 1e6:6.1f} TF)")
+    print(f"geom {geom} T={T} p={p}: fwd {f:7.1f} us ({fl / f / 1e6:6.1f} TF)   bwd {b:7.1f} us ({2.5 * fl / b / 1e6:6.1f} TF)")

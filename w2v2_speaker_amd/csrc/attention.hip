@@ -36,12 +36,24 @@ __device__ __forceinline__ uint64_t attn_drop_idx(int64_t bh, int q, int key, in
 __device__ __forceinline__ uint64_t attn_row_pair0(int64_t bh, int q, int Tn) {
   return (uint64_t)(bh * Tn + q) * (uint64_t)(((Tn + 1) & ~1) >> 1);
 }
+// The pair index is 64-bit in general; when the whole launch has fewer than 2^32 pairs (B * heads * T * padded T / 2: every
+// training shape) the host picks the 32-bit instantiation: the high word is zero, rng_pair's x = lo ^ key ^ umul24(hi, C)
+// loses its third term and the per-hash 64-bit add becomes one v_add_u32 -- the SAME bits, three VALU slots fewer per hash.
+__device__ __forceinline__ uint32_t rng_pair_i(uint32_t key, uint64_t pair_idx) { return rng_pair(key, pair_idx); }
+__device__ __forceinline__ uint32_t rng_pair_i(uint32_t key, uint32_t pair_idx) {
+  uint32_t x = pair_idx ^ key;
+  x ^= x >> 16; x *= 0x85EBCA6Bu;
+  x ^= x >> 13; x *= 0xC2B2AE35u;
+  x ^= x >> 16;
+  return x;
+}
 // keep-scales of 4 consecutive keys of a query row: two hashes.  row0 = pair index of the row's key k0 (k0 % 4 == 0,
-// lane-dependent), key0_rel = distance of the first of the 4 keys from k0, a wave-uniform multiple of 4 -> one 64-bit add
-__device__ __forceinline__ void attn_drop4_keys(uint32_t k, uint32_t thr, uint64_t row0, int key0_rel, float inv_keep,
+// lane-dependent), key0_rel = distance of the first of the 4 keys from k0, a wave-uniform multiple of 4 -> one add
+template <typename IDX>
+__device__ __forceinline__ void attn_drop4_keys(uint32_t k, uint32_t thr, IDX row0, int key0_rel, float inv_keep,
                                                 float (&ms)[4]) {
-  const uint64_t pi = row0 + (uint64_t)(uint32_t)(key0_rel >> 1);
-  const uint32_t h0 = rng_pair(k, pi), h1 = rng_pair(k, pi + 1);
+  const IDX pi = row0 + (IDX)(uint32_t)(key0_rel >> 1);
+  const uint32_t h0 = rng_pair_i(k, pi), h1 = rng_pair_i(k, (IDX)(pi + 1));
   ms[0] = (h0 & 0xffffu) >= thr ? inv_keep : 0.f;
   ms[1] = (h0 >> 16) >= thr ? inv_keep : 0.f;
   ms[2] = (h1 & 0xffffu) >= thr ? inv_keep : 0.f;
@@ -51,11 +63,12 @@ __device__ __forceinline__ void attn_drop4_keys(uint32_t k, uint32_t thr, uint64
 // of a key pair hash two rows each and swap (one hash serves keys 2j and 2j+1 of a row)
 // col0 = pair index of (query row 0 of this (utterance, head), this lane's key) = attn_drop_idx(bh, 0, key, Tn) >> 1, a
 // per-lane constant; a row adds q * Tp2 (Tp2 = padded row length / 2: 24-bit operands, full-rate multiply)
-__device__ __forceinline__ void attn_drop4_rows(uint32_t k, uint32_t thr, uint64_t col0, uint32_t Tp2, int q0, int odd,
+template <typename IDX>
+__device__ __forceinline__ void attn_drop4_rows(uint32_t k, uint32_t thr, IDX col0, uint32_t Tp2, int q0, int odd,
                                                 float inv_keep, float (&ms)[4]) {
   const uint32_t qa = (uint32_t)(q0 + 2 * odd);
-  const uint32_t h0 = rng_pair(k, col0 + (uint64_t)__umul24(qa, Tp2));
-  const uint32_t h1 = rng_pair(k, col0 + (uint64_t)__umul24(qa + 1u, Tp2));
+  const uint32_t h0 = rng_pair_i(k, (IDX)(col0 + (IDX)__umul24(qa, Tp2)));
+  const uint32_t h1 = rng_pair_i(k, (IDX)(col0 + (IDX)__umul24(qa + 1u, Tp2)));
   const uint32_t p0 = __shfl_xor(h0, 1, 64), p1 = __shfl_xor(h1, 1, 64);
   const uint32_t r0 = odd ? p0 : h0, r1 = odd ? p1 : h1, r2 = odd ? h0 : p0, r3 = odd ? h1 : p1;
   const int sh = odd * 16;
@@ -194,23 +207,34 @@ __device__ __forceinline__ frag8_t lds_frag_tr(const bf16_t* img, const TrOff& t
 // recompute the probabilities from the saved log-sum-exp -- dQ (+ delta) over key tiles, dK / dV over query tiles --
 // with the same per-fragment arithmetic, dropout stream and k-slot mapping as the single-workgroup kernels above.
 // No [B, h, T, T] tensor exists anywhere; work per launch is O(T^2 d), LDS is 32-33 KiB whatever T is.
-constexpr int AT_TILE = 64;
-
+// Two geometries of the same kernels (template parameters NW = waves per workgroup, KT = rows of a streamed tile):
+//   <4, 64>: 64 rows per workgroup, 64-row tiles (rounds 2-5).  At T = 149 a (utterance, head) is three workgroups, the last
+//            one with two idle waves, and 2376 workgroups on 1024 slots (four per CU) are 2.32 lifetimes: the counters of
+//            round 5 (profiles/r05_attention_pmc.txt) had the wave slots ~70 % occupied with the VALU ~90 % busy while resident.
+//   <2, 32>: 32 rows per workgroup, 32-row tiles (round 6).  T = 149 is five workgroups with every wave active and five
+//            tiles with no empty 16-key block; eight workgroups per CU (16 KiB of LDS each) = 3960 items on 2048 slots =
+//            1.93 lifetimes, and the hardware dispatcher back-fills at twice the granularity.  Costs: every tile is loaded
+//            for half as many rows (L2 -> LDS traffic x2, it was not the bound) and the online-softmax bookkeeping of the
+//            forward (running max / rescale) is paid per 32 keys instead of 64.
+// Both stage a tile as 2 x 16 B per thread; the dropout stream is indexed by absolute (query, key), so the two
+// geometries draw the same mask.
 struct TileRegs { uint4 v[2]; };
-// rows row0 .. row0+63 (x 64 elements) of a [*, 64]-column slab with row stride gs -> registers (2 x 16 B per thread)
+// rows row0 .. row0+KT-1 (x 64 elements) of a [*, 64]-column slab with row stride gs -> registers (2 x 16 B per thread)
+template <int NT>
 __device__ __forceinline__ void tile_load(TileRegs& r, const bf16_t* g, int64_t gs, int row0, int n_valid) {
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    const int c = threadIdx.x + 256 * i;
+    const int c = threadIdx.x + NT * i;
     const int row = row0 + (c >> 3), ch = c & 7;
     r.v[i] = make_uint4(0, 0, 0, 0);
     if (row < n_valid) r.v[i] = *reinterpret_cast<const uint4*>(g + (int64_t)row * gs + ch * 8);
   }
 }
+template <int NT>
 __device__ __forceinline__ void tile_store(const TileRegs& r, bf16_t* lds) {
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    const int c = threadIdx.x + 256 * i;
+    const int c = threadIdx.x + NT * i;
     const int row = c >> 3, ch = c & 7;
     *reinterpret_cast<uint4*>(lds + row * 64 + ((ch ^ aswz(row)) << 3)) = r.v[i];
   }
@@ -235,60 +259,62 @@ __device__ __forceinline__ AttnBlock attn_block(int ntile_rows, int heads) {
   return o;
 }
 
-template <typename TE>
-__global__ __launch_bounds__(256, 4) void attn_fwd_tiled_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx,
+template <typename TE, int NW, int KT, typename IDX>
+__global__ __launch_bounds__(64 * NW, 4) void attn_fwd_tiled_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx,
                                                              float* __restrict__ lse, int Tn, int heads_s, float scale,
                                                              float dp, float inv_keep, uint64_t seed) {
+  static_assert(KT * 8 == 2 * 64 * NW, "a tile is staged as two 16-byte chunks per thread");
+  constexpr int NT = 64 * NW, RW = 16 * NW, AT_TILE = KT;
   __shared__ __attribute__((aligned(16))) bf16_t Ks[2][AT_TILE * 64];
   __shared__ __attribute__((aligned(16))) bf16_t Vs[2][AT_TILE * 64];
-  const AttnBlock blk = attn_block((Tn + 63) >> 6, heads_s);
+  const AttnBlock blk = attn_block((Tn + RW - 1) / RW, heads_s);
   const int heads = heads_s < 0 ? -heads_s : heads_s;
   const int b = blk.b, h = blk.h, row_tile = blk.tile;
   const int H = heads * HD;
   const int64_t gs = 3 * (int64_t)H;
   const bf16_t* qb = qkv + (int64_t)b * Tn * gs + h * HD;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
-  const int q = row_tile * 64 + wave * 16 + (lane & 15);
+  const int q = row_tile * RW + wave * 16 + (lane & 15);
   const int64_t bh = (int64_t)b * heads + h;
   frag8_t qf[2];
   reg_frag(qf, qb, gs, q, Tn, lane);
   const TrOff troff = tr_offsets(lane);
   const int ntile = (Tn + AT_TILE - 1) / AT_TILE;
   TileRegs rk, rv;
-  tile_load(rk, qb + H, gs, 0, Tn);
-  tile_load(rv, qb + 2 * H, gs, 0, Tn);
-  tile_store(rk, Ks[0]);
-  tile_store(rv, Vs[0]);
+  tile_load<NT>(rk, qb + H, gs, 0, Tn);
+  tile_load<NT>(rv, qb + 2 * H, gs, 0, Tn);
+  tile_store<NT>(rk, Ks[0]);
+  tile_store<NT>(rv, Vs[0]);
   __syncthreads();
   float m = -INFINITY, l = 0.f;                       // running maximum in the log2 domain
   const float scale2 = scale * 1.4426950408889634f;
   const uint32_t thr = drop_thr16(dp);
   const uint32_t rkey = rng_key(seed);
-  const uint64_t row0 = attn_row_pair0(bh, q, Tn) + (uint64_t)(g * 2);     // + the lane's 4 keys of a 16-key block
+  const IDX row0 = (IDX)(attn_row_pair0(bh, q, Tn) + (uint64_t)(g * 2));     // + the lane's 4 keys of a 16-key block
   f32x4 o[4];
 #pragma unroll
   for (int df = 0; df < 4; ++df) o[df] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const bool active = row_tile * 64 + wave * 16 < Tn;       // wave-uniform: any of this wave's 16 rows valid
+  const bool active = row_tile * RW + wave * 16 < Tn;       // wave-uniform: any of this wave's 16 rows valid
 #pragma unroll 1
   for (int t = 0; t < ntile; ++t) {
     const int cur = t & 1;
     if (t + 1 < ntile) {                              // next tile's loads fly under this tile's arithmetic
-      tile_load(rk, qb + H, gs, (t + 1) * AT_TILE, Tn);
-      tile_load(rv, qb + 2 * H, gs, (t + 1) * AT_TILE, Tn);
+      tile_load<NT>(rk, qb + H, gs, (t + 1) * AT_TILE, Tn);
+      tile_load<NT>(rv, qb + 2 * H, gs, (t + 1) * AT_TILE, Tn);
     }
     // 16-key blocks of this tile that hold a valid key (uniform): the blocks past the end of the sequence are skipped
     // outright -- at T = 149 that is two of the twelve blocks a query tile walks
-    const int nfj = min(4, (Tn - t * AT_TILE + 15) >> 4);
+    const int nfj = min(AT_TILE / 16, (Tn - t * AT_TILE + 15) >> 4);
     if (active) {
       // One body, two instantiations: FULL = a tile with four valid 16-key blocks and no key past T (every tile but the
       // last): straight-line code, no per-block branches, no masks
       auto body = [&](auto full_c, auto drop_c) {
         constexpr bool FULL = decltype(full_c)::value, DROP = decltype(drop_c)::value;
-        float s[4][4];
+        float s[AT_TILE / 16][4];
         float tmax = -INFINITY;
         // scores in the LOG2 domain (scale * log2(e) folded into one multiply, v_exp_f32 is 2^x)
 #pragma unroll
-        for (int fj = 0; fj < 4; ++fj) {
+        for (int fj = 0; fj < AT_TILE / 16; ++fj) {
           if (FULL || fj < nfj) {
             f32x4 acc = mfma16<TE>(lds_frag(Ks[cur], fj * 16, 0, lane), qf[0], f32x4{0.f, 0.f, 0.f, 0.f});
             acc = mfma16<TE>(lds_frag(Ks[cur], fj * 16, 1, lane), qf[1], acc);
@@ -307,7 +333,7 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_tiled_kernel(const bf16_t* __
         m = mn;
         float psum = 0.f;
 #pragma unroll
-        for (int fj = 0; fj < 4; ++fj) {
+        for (int fj = 0; fj < AT_TILE / 16; ++fj) {
           if (FULL || fj < nfj) {
             float ms[4];
             if constexpr (DROP) attn_drop4_keys(rkey, thr, row0, t * AT_TILE + fj * 16, inv_keep, ms);
@@ -326,7 +352,7 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_tiled_kernel(const bf16_t* __
 #pragma unroll
         for (int df = 0; df < 4; ++df) o[df] *= alpha;
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
+        for (int kb = 0; kb < AT_TILE / 32; ++kb) {
           if (FULL || 2 * kb < nfj) {
             const frag8_t pf = pack_frag<TE>(s[2 * kb], s[2 * kb + 1]);
 #pragma unroll
@@ -342,8 +368,8 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_tiled_kernel(const bf16_t* __
       }
     }   // active
     if (t + 1 < ntile) {
-      tile_store(rk, Ks[cur ^ 1]);                    // last read in iteration t-1, behind that iteration's barrier
-      tile_store(rv, Vs[cur ^ 1]);
+      tile_store<NT>(rk, Ks[cur ^ 1]);                    // last read in iteration t-1, behind that iteration's barrier
+      tile_store<NT>(rv, Vs[cur ^ 1]);
     }
     __syncthreads();
   }
@@ -355,17 +381,19 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_tiled_kernel(const bf16_t* __
 }
 
 // dQ (and delta[q] = sum_d dO O) for 64 queries per workgroup, streaming key tiles
-template <typename TE>
-__global__ __launch_bounds__(256, 4) void attn_bwd_dq_tiled_kernel(const bf16_t* __restrict__ qkv,
+template <typename TE, int NW, int KT, typename IDX>
+__global__ __launch_bounds__(64 * NW, 4) void attn_bwd_dq_tiled_kernel(const bf16_t* __restrict__ qkv,
                                                                 const bf16_t* __restrict__ ctx,
                                                                 const bf16_t* __restrict__ dctx,
                                                                 const float* __restrict__ lse,
                                                                 bf16_t* __restrict__ dqkv, float* __restrict__ delta,
                                                                 int Tn, int heads_s, float scale, float dp,
                                                                 float inv_keep, uint64_t seed) {
+  static_assert(KT * 8 == 2 * 64 * NW, "a tile is staged as two 16-byte chunks per thread");
+  constexpr int NT = 64 * NW, RW = 16 * NW, AT_TILE = KT;
   __shared__ __attribute__((aligned(16))) bf16_t Ks[2][AT_TILE * 64];
   __shared__ __attribute__((aligned(16))) bf16_t Vs[2][AT_TILE * 64];
-  const AttnBlock blk = attn_block((Tn + 63) >> 6, heads_s);
+  const AttnBlock blk = attn_block((Tn + RW - 1) / RW, heads_s);
   const int heads = heads_s < 0 ? -heads_s : heads_s;
   const int b = blk.b, h = blk.h, row_tile = blk.tile;
   const int H = heads * HD;
@@ -374,7 +402,7 @@ __global__ __launch_bounds__(256, 4) void attn_bwd_dq_tiled_kernel(const bf16_t*
   const bf16_t* dob = dctx + (int64_t)b * Tn * H + h * HD;
   const bf16_t* ob = ctx + (int64_t)b * Tn * H + h * HD;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
-  const int q = row_tile * 64 + wave * 16 + (lane & 15);
+  const int q = row_tile * RW + wave * 16 + (lane & 15);
   const int64_t bh = (int64_t)b * heads + h;
   frag8_t qf[2], dof[2], of[2];
   reg_frag(qf, qb, gs, q, Tn, lane);
@@ -390,32 +418,32 @@ __global__ __launch_bounds__(256, 4) void attn_bwd_dq_tiled_kernel(const bf16_t*
   // there and would meet a zero K row as inf * 0 after the 16-bit pack.
   const uint32_t thr = drop_thr16(dp);
   const uint32_t rkey = rng_key(seed);
-  const uint64_t row0 = attn_row_pair0(bh, q, Tn) + (uint64_t)(g * 2);     // + the lane's 4 keys of a 16-key block
+  const IDX row0 = (IDX)(attn_row_pair0(bh, q, Tn) + (uint64_t)(g * 2));     // + the lane's 4 keys of a 16-key block
   const float l2 = q < Tn ? lse[bh * Tn + q] * 1.4426950408889634f : 0.f;
   const float scale2 = scale * 1.4426950408889634f;
   const TrOff troff = tr_offsets(lane);
   const int ntile = (Tn + AT_TILE - 1) / AT_TILE;
   TileRegs rk, rv;
-  tile_load(rk, qb + H, gs, 0, Tn);
-  tile_load(rv, qb + 2 * H, gs, 0, Tn);
-  tile_store(rk, Ks[0]);
-  tile_store(rv, Vs[0]);
+  tile_load<NT>(rk, qb + H, gs, 0, Tn);
+  tile_load<NT>(rv, qb + 2 * H, gs, 0, Tn);
+  tile_store<NT>(rk, Ks[0]);
+  tile_store<NT>(rv, Vs[0]);
   __syncthreads();
   f32x4 o[4];
 #pragma unroll
   for (int df = 0; df < 4; ++df) o[df] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const bool active = row_tile * 64 + wave * 16 < Tn;
+  const bool active = row_tile * RW + wave * 16 < Tn;
 #pragma unroll 1
   for (int t = 0; t < ntile; ++t) {
     const int cur = t & 1;
     if (t + 1 < ntile) {
-      tile_load(rk, qb + H, gs, (t + 1) * AT_TILE, Tn);
-      tile_load(rv, qb + 2 * H, gs, (t + 1) * AT_TILE, Tn);
+      tile_load<NT>(rk, qb + H, gs, (t + 1) * AT_TILE, Tn);
+      tile_load<NT>(rv, qb + 2 * H, gs, (t + 1) * AT_TILE, Tn);
     }
-    const int nfj = min(4, (Tn - t * AT_TILE + 15) >> 4);      // 16-key blocks with a valid key (uniform)
+    const int nfj = min(AT_TILE / 16, (Tn - t * AT_TILE + 15) >> 4);      // 16-key blocks with a valid key (uniform)
     if (active)
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
+    for (int kb = 0; kb < AT_TILE / 32; ++kb) {
       if (2 * kb < nfj) {
       float ds2[2][4];
 #pragma unroll
@@ -455,8 +483,8 @@ __global__ __launch_bounds__(256, 4) void attn_bwd_dq_tiled_kernel(const bf16_t*
       }
     }
     if (t + 1 < ntile) {
-      tile_store(rk, Ks[cur ^ 1]);
-      tile_store(rv, Vs[cur ^ 1]);
+      tile_store<NT>(rk, Ks[cur ^ 1]);
+      tile_store<NT>(rv, Vs[cur ^ 1]);
     }
     __syncthreads();
   }
@@ -464,18 +492,20 @@ __global__ __launch_bounds__(256, 4) void attn_bwd_dq_tiled_kernel(const bf16_t*
 }
 
 // dK, dV for 64 keys per workgroup, streaming query tiles (Q, dO, LSE, delta)
-template <typename TE>
-__global__ __launch_bounds__(256, 3) void attn_bwd_kv_tiled_kernel(const bf16_t* __restrict__ qkv,
+template <typename TE, int NW, int KT, typename IDX>
+__global__ __launch_bounds__(64 * NW, 3) void attn_bwd_kv_tiled_kernel(const bf16_t* __restrict__ qkv,
                                                                 const bf16_t* __restrict__ dctx,
                                                                 const float* __restrict__ lse,
                                                                 const float* __restrict__ delta,
                                                                 bf16_t* __restrict__ dqkv, int Tn, int heads_s,
                                                                 float scale, float dp, float inv_keep, uint64_t seed) {
+  static_assert(KT * 8 == 2 * 64 * NW, "a tile is staged as two 16-byte chunks per thread");
+  constexpr int NT = 64 * NW, RW = 16 * NW, AT_TILE = KT;
   __shared__ __attribute__((aligned(16))) bf16_t Qs[2][AT_TILE * 64];
   __shared__ __attribute__((aligned(16))) bf16_t Os[2][AT_TILE * 64];      // dO
   __shared__ __attribute__((aligned(16))) float lse_s[2][AT_TILE];
   __shared__ __attribute__((aligned(16))) float del_s[2][AT_TILE];
-  const AttnBlock blk = attn_block((Tn + 63) >> 6, heads_s);
+  const AttnBlock blk = attn_block((Tn + RW - 1) / RW, heads_s);
   const int heads = heads_s < 0 ? -heads_s : heads_s;
   const int b = blk.b, h = blk.h, row_tile = blk.tile;
   const int H = heads * HD;
@@ -483,7 +513,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_kv_tiled_kernel(const bf16_t*
   const bf16_t* qb = qkv + (int64_t)b * Tn * gs + h * HD;
   const bf16_t* dob = dctx + (int64_t)b * Tn * H + h * HD;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
-  const int key = row_tile * 64 + wave * 16 + (lane & 15);
+  const int key = row_tile * RW + wave * 16 + (lane & 15);
   const int64_t bh = (int64_t)b * heads + h;
   frag8_t kf[2], vf[2];
   reg_frag(kf, qb + H, gs, key, Tn, lane);
@@ -502,33 +532,33 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_kv_tiled_kernel(const bf16_t*
   auto row_store = [&](int buf) {
     if (threadIdx.x < AT_TILE) { lse_s[buf][threadIdx.x] = rl; del_s[buf][threadIdx.x] = rd; }
   };
-  tile_load(rq, qb, gs, 0, Tn);
-  tile_load(ro, dob, H, 0, Tn);
+  tile_load<NT>(rq, qb, gs, 0, Tn);
+  tile_load<NT>(ro, dob, H, 0, Tn);
   row_load(0);
-  tile_store(rq, Qs[0]);
-  tile_store(ro, Os[0]);
+  tile_store<NT>(rq, Qs[0]);
+  tile_store<NT>(ro, Os[0]);
   row_store(0);
   __syncthreads();
   f32x4 dv[4], dk[4];
 #pragma unroll
   for (int df = 0; df < 4; ++df) { dv[df] = f32x4{0.f, 0.f, 0.f, 0.f}; dk[df] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-  const bool active = row_tile * 64 + wave * 16 < Tn;
+  const bool active = row_tile * RW + wave * 16 < Tn;
   const uint32_t rkey = rng_key(seed), thr = drop_thr16(dp);
-  const uint64_t col0 = attn_drop_idx(bh, 0, key, Tn) >> 1;
+  const IDX col0 = (IDX)(attn_drop_idx(bh, 0, key, Tn) >> 1);
   const uint32_t Tp2 = (uint32_t)(((Tn + 1) & ~1) >> 1);
   const float scale2 = scale * 1.4426950408889634f;
 #pragma unroll 1
   for (int t = 0; t < ntile; ++t) {
     const int cur = t & 1;
     if (t + 1 < ntile) {
-      tile_load(rq, qb, gs, (t + 1) * AT_TILE, Tn);
-      tile_load(ro, dob, H, (t + 1) * AT_TILE, Tn);
+      tile_load<NT>(rq, qb, gs, (t + 1) * AT_TILE, Tn);
+      tile_load<NT>(ro, dob, H, (t + 1) * AT_TILE, Tn);
       row_load(t + 1);
     }
-    const int nfq = min(4, (Tn - t * AT_TILE + 15) >> 4);      // 16-query blocks with a valid row (uniform)
+    const int nfq = min(AT_TILE / 16, (Tn - t * AT_TILE + 15) >> 4);      // 16-query blocks with a valid row (uniform)
     if (active)
 #pragma unroll
-    for (int qb2 = 0; qb2 < 2; ++qb2) {
+    for (int qb2 = 0; qb2 < AT_TILE / 32; ++qb2) {
       if (2 * qb2 < nfq) {
       float pt2[2][4], ds2[2][4];
 #pragma unroll
@@ -570,8 +600,8 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_kv_tiled_kernel(const bf16_t*
       }
     }
     if (t + 1 < ntile) {
-      tile_store(rq, Qs[cur ^ 1]);
-      tile_store(ro, Os[cur ^ 1]);
+      tile_store<NT>(rq, Qs[cur ^ 1]);
+      tile_store<NT>(ro, Os[cur ^ 1]);
       row_store(cur ^ 1);
     }
     __syncthreads();
@@ -592,17 +622,45 @@ static int attn_check(const char* nm, int B, int T, int heads, int d, int dtype,
 }
 
 static const bool g_attn_no_remap = getenv("W2V2_ATTN_NO_XCD_REMAP") != nullptr;
+// geometry switch (see the tile helpers): 0 / unset = by sequence length, 64 = force <4, 64>, 32 = force <2, 32>
+// (read on every call, ~0.1 us: a test can compare the two geometries inside one process)
+static int attn_geom_env() { const char* e = getenv("W2V2_ATTN_GEOM"); return e ? atoi(e) : 0; }
+// The small geometry is taken when it pads the sequence to FEWER rows than the large one (T = 149: 160 instead of 192,
+// T = 199: 224 instead of 256) and the sequence is short; where both pad alike (T = 249, 301) the large one wins by its
+// K / V reuse (measured, tools/attn_bench.py: T = 149 fwd 28.1 -> 26.6 us, bwd 71.1 -> 65.5; T = 249 fwd 49.5 -> 53.3).
+// W2V2_ATTN_IDX64 forces the 64-bit dropout counters (tests compare the two index widths).
+constexpr int ATTN_SMALL_GEOM_MAX_T = 512;
+static bool attn_small_geom(int T) {
+  const int g = attn_geom_env();
+  return g == 32 || (g != 64 && T <= ATTN_SMALL_GEOM_MAX_T && ((T + 31) & ~31) < ((T + 63) & ~63));
+}
 
-template <typename TE>
-static int attention_fwd_t(const void* qkv, void* ctx, float* lse, int B, int T, int heads, float scale, float drop_p,
+// true when every pair index of the launch fits 32 bits (see rng_pair_i)
+static bool attn_idx32(int B, int T, int heads) {
+  if (getenv("W2V2_ATTN_IDX64")) return false;
+  return (uint64_t)B * heads * T * (uint64_t)(((T + 1) & ~1) >> 1) < (1ull << 32);
+}
+
+template <typename TE, int NW, int KT, typename IDX>
+static int attention_fwd_g(const void* qkv, void* ctx, float* lse, int B, int T, int heads, float scale, float drop_p,
                            uint64_t seed, void* stream) {
   const float ik = 1.0f / (1.0f - drop_p);
   hipStream_t st = as_stream(stream);
-  dim3 grid((unsigned)(cdiv(T, 64) * heads * B));       // see attn_block
-  hipLaunchKernelGGL((attn_fwd_tiled_kernel<TE>), grid, dim3(256), 0, st, (const bf16_t*)qkv, (bf16_t*)ctx, lse, T,
+  dim3 grid((unsigned)(cdiv(T, 16 * NW) * heads * B));       // see attn_block
+  hipLaunchKernelGGL((attn_fwd_tiled_kernel<TE, NW, KT, IDX>), grid, dim3(64 * NW), 0, st, (const bf16_t*)qkv, (bf16_t*)ctx, lse, T,
                      g_attn_no_remap ? -heads : heads, scale, drop_p, ik, seed);
   W2V2_CHECK_LAUNCH("attention_fwd");
   return 0;
+}
+template <typename TE>
+static int attention_fwd_t(const void* qkv, void* ctx, float* lse, int B, int T, int heads, float scale, float drop_p,
+                           uint64_t seed, void* stream) {
+  const bool i32 = attn_idx32(B, T, heads);
+  if (attn_small_geom(T))
+    return i32 ? attention_fwd_g<TE, 2, 32, uint32_t>(qkv, ctx, lse, B, T, heads, scale, drop_p, seed, stream)
+               : attention_fwd_g<TE, 2, 32, uint64_t>(qkv, ctx, lse, B, T, heads, scale, drop_p, seed, stream);
+  return i32 ? attention_fwd_g<TE, 4, 64, uint32_t>(qkv, ctx, lse, B, T, heads, scale, drop_p, seed, stream)
+             : attention_fwd_g<TE, 4, 64, uint64_t>(qkv, ctx, lse, B, T, heads, scale, drop_p, seed, stream);
 }
 
 extern "C" int w2v2_attention_fwd(const void* qkv, void* ctx, float* lse, int B, int T, int heads, int d, float scale,
@@ -614,20 +672,31 @@ extern "C" int w2v2_attention_fwd(const void* qkv, void* ctx, float* lse, int B,
   return 0;
 }
 
-template <typename TE>
-static int attention_bwd_t(const void* qkv, const void* ctx, const void* dctx, const float* lse, void* dqkv,
+template <typename TE, int NW, int KT, typename IDX>
+static int attention_bwd_g(const void* qkv, const void* ctx, const void* dctx, const float* lse, void* dqkv,
                            float* delta, int B, int T, int heads, float scale, float drop_p, uint64_t seed,
                            void* stream) {
   const float ik = 1.0f / (1.0f - drop_p);
   hipStream_t st = as_stream(stream);
-  dim3 grid((unsigned)(cdiv(T, 64) * heads * B));       // see attn_block
-  hipLaunchKernelGGL((attn_bwd_dq_tiled_kernel<TE>), grid, dim3(256), 0, st, (const bf16_t*)qkv, (const bf16_t*)ctx,
+  dim3 grid((unsigned)(cdiv(T, 16 * NW) * heads * B));       // see attn_block
+  hipLaunchKernelGGL((attn_bwd_dq_tiled_kernel<TE, NW, KT, IDX>), grid, dim3(64 * NW), 0, st, (const bf16_t*)qkv, (const bf16_t*)ctx,
                      (const bf16_t*)dctx, lse, (bf16_t*)dqkv, delta, T, g_attn_no_remap ? -heads : heads, scale, drop_p, ik,
                      seed);
-  hipLaunchKernelGGL((attn_bwd_kv_tiled_kernel<TE>), grid, dim3(256), 0, st, (const bf16_t*)qkv, (const bf16_t*)dctx,
+  hipLaunchKernelGGL((attn_bwd_kv_tiled_kernel<TE, NW, KT, IDX>), grid, dim3(64 * NW), 0, st, (const bf16_t*)qkv, (const bf16_t*)dctx,
                      lse, (const float*)delta, (bf16_t*)dqkv, T, g_attn_no_remap ? -heads : heads, scale, drop_p, ik, seed);
   W2V2_CHECK_LAUNCH("attention_bwd");
   return 0;
+}
+template <typename TE>
+static int attention_bwd_t(const void* qkv, const void* ctx, const void* dctx, const float* lse, void* dqkv,
+                           float* delta, int B, int T, int heads, float scale, float drop_p, uint64_t seed,
+                           void* stream) {
+  const bool i32 = attn_idx32(B, T, heads);
+  if (attn_small_geom(T))
+    return i32 ? attention_bwd_g<TE, 2, 32, uint32_t>(qkv, ctx, dctx, lse, dqkv, delta, B, T, heads, scale, drop_p, seed, stream)
+               : attention_bwd_g<TE, 2, 32, uint64_t>(qkv, ctx, dctx, lse, dqkv, delta, B, T, heads, scale, drop_p, seed, stream);
+  return i32 ? attention_bwd_g<TE, 4, 64, uint32_t>(qkv, ctx, dctx, lse, dqkv, delta, B, T, heads, scale, drop_p, seed, stream)
+             : attention_bwd_g<TE, 4, 64, uint64_t>(qkv, ctx, dctx, lse, dqkv, delta, B, T, heads, scale, drop_p, seed, stream);
 }
 
 extern "C" int w2v2_attention_bwd(const void* qkv, const void* ctx, const void* dctx, const float* lse, void* dqkv,
