@@ -82,15 +82,19 @@ def hf_extra(cfg: O.OracleConfig):
                 num_conv_pos_embedding_groups=cfg.num_conv_pos_embedding_groups)
 
 
-def build_reference_wrapper(cfg: O.OracleConfig, seed: int, cls_token=False):
-    """The reference's wrapper (src/models/wav2vec2.py:97-146) with dropouts/layerdrop/masking = 0."""
+def build_reference_wrapper(cfg: O.OracleConfig, seed: int, cls_token=False, hf_id="facebook/wav2vec2-base", family=None):
+    """The reference's wrapper (src/models/wav2vec2.py:97-146) with dropouts/layerdrop/masking = 0.  ``hf_id`` is what the
+    wrapper inspects for "base" / "large" (:112-117); ``family="outlier"`` = data/synthetic.py outlier_family on the weights."""
     global _CFG_EXTRA
     _CFG_EXTRA = hf_extra(cfg)
     reg = Wav2Vec2RegularisationConfig(activation_dropout=0.0, attention_dropout=0.0,
                                        feat_proj_dropout=0.0, hidden_dropout=0.0, layerdrop=0.0,
                                        mask_time_prob=0.05)   # keep masked_spec_embed alive
-    w = Wav2Vec2WrapperModule("facebook/wav2vec2-base", False, reg, insert_clc_token=cls_token)
+    w = Wav2Vec2WrapperModule(hf_id, False, reg, insert_clc_token=cls_token)
     sd = O.make_state_dict(cfg, seed)
+    if family == "outlier":
+        from w2v2_speaker_amd.data.synthetic import outlier_family
+        sd = {k: torch.from_numpy(v) for k, v in outlier_family({k: v.numpy() for k, v in sd.items()}, seed).items()}
     missing, unexpected = w.model.load_state_dict(sd, strict=True), None
     return w, sd
 
@@ -541,9 +545,88 @@ def golden_seeds():
         print("g16_seeds: seed", sd_, "emb norm", float(g[f"eval.mean+std.{sd_}"].norm()))
     np.savez_compressed(os.path.join(OUT, "g16_seeds.npz"), **to_np(g))
 
+# ----------------------------------------------------------------------------- G17 heavy-tailed weights, G18 the wrapper's "large" branch
+def golden_outlier():
+    """one base-size weight seed from a HEAVY-TAILED family (w2v2_speaker_amd/data/synthetic.py
+    outlier_family: six residual channels with every encoder LayerNorm gain x 20, four FFN-1 bias entries + 8 per block,
+    convolutions 1 / 3 / 5 x 3) through the reference wrapper, eval, mean+std: 4 utterances of 3 s.  Also stored: how
+    heavy the tail is (max |hidden| over RMS) so the consuming test can say what it was bounded on."""
+    cfg = O.OracleConfig.base()
+    w, _ = build_reference_wrapper(cfg, seed=20211, family="outlier")
+    wav, _ = O.synth_batch(4, 48000, 5994, seed=171717)
+    w.eval()
+    with torch.no_grad():
+        out = w.model(torch.squeeze(wav), output_hidden_states=True)
+        h = out.last_hidden_state
+        g = {"eval.mean+std": MeanStdStatPool1D(1)(h), "eval.last_hidden.sample": h[:, ::16, ::16].contiguous(),
+             "hidden_absmax_over_rms": np.array([float(x.abs().max() / x.pow(2).mean().sqrt()) for x in out.hidden_states]),
+             "conv_out_absmax": np.float64(float(out.extract_features.abs().max()))}
+        # context for the 16-bit bound: the REFERENCE's own mixed precision (``precision: 16`` of the paper runs = torch
+        # autocast; ref config/experiment/speaker_wav2vec2_aam.yaml:17) against its own f32, same weights and utterances,
+        # for this family and for the Gaussian family of g2 (torch CPU autocast: 16-bit operands, f32 accumulation)
+        e32 = g["eval.mean+std"]
+        for dt, tag in ((torch.float16, "fp16"), (torch.bfloat16, "bf16")):
+            with torch.autocast("cpu", dtype=dt):
+                e16 = MeanStdStatPool1D(1)(w.model(torch.squeeze(wav)).last_hidden_state.float())
+            g[f"ref_autocast_{tag}.per_utt_err"] = (e16.float() - e32).norm(dim=1) / e32.norm(dim=1)
+        wg, _ = build_reference_wrapper(cfg, seed=20211)
+        wg.eval()
+        eg = MeanStdStatPool1D(1)(wg.model(torch.squeeze(wav)).last_hidden_state)
+        with torch.autocast("cpu", dtype=torch.float16):
+            eg16 = MeanStdStatPool1D(1)(wg.model(torch.squeeze(wav)).last_hidden_state.float())
+        g["ref_autocast_fp16.per_utt_err.gaussian_family"] = (eg16.float() - eg).norm(dim=1) / eg.norm(dim=1)
+    np.savez_compressed(os.path.join(OUT, "g17_outlier.npz"), **to_np(g))
+    print("   reference autocast vs its own f32, per-utterance max: fp16", float(g["ref_autocast_fp16.per_utt_err"].max()),
+          "bf16", float(g["ref_autocast_bf16.per_utt_err"].max()), "| Gaussian family fp16",
+          float(g["ref_autocast_fp16.per_utt_err.gaussian_family"].max()))
+    print("g17_outlier: emb norm", float(g["eval.mean+std"].norm()), "max|h|/rms per layer",
+          np.round(g["hidden_absmax_over_rms"], 1), "conv out max", float(g["conv_out_absmax"]))
+
+
+def golden_large2():
+    """the reference wrapper's "large" branch (ref src/models/wav2vec2.py:115-116: num_features 1024) on
+    a 2-layer cut of the wav2vec2-large geometry (H 1024, 16 heads, FFN 4096; 5 s clips, T = 249), replacing the
+    oracle-only comparison of the HIP path: eval embedding, and -- train mode, no regularisation -- AAM loss (C = 211)
+    and the norm of every gradient."""
+    import dataclasses
+    cfg = dataclasses.replace(O.OracleConfig.large(), num_hidden_layers=2)
+    B, N, C = 2, 80000, 211
+    w, _ = build_reference_wrapper(cfg, seed=20211, hf_id="facebook/wav2vec2-large")
+    assert w.num_features == 1024 and w.model.config.hidden_size == 1024 and w.model.config.num_attention_heads == 16
+    wav, label = O.synth_batch(B, N, C, seed=77)
+    x = torch.squeeze(wav)
+    g = {"label": label}
+    w.eval()
+    with torch.no_grad():
+        h = w(x).transpose(2, 1)
+        g["eval.mean+std"] = MeanStdStatPool1D(1)(h)
+        g["eval.last_hidden.sample"] = h[:, ::16, ::16].contiguous()
+    np.random.seed(11)                                      # injected SpecAugment mask, as g2_base does (seed 7 there)
+    mask_t = torch.from_numpy(hf_mod._compute_mask_indices((B, h.shape[1]), mask_prob=0.05, mask_length=10, min_masks=2))
+    g["mask"] = mask_t
+    w.train()
+    out = w.model(x, mask_time_indices=mask_t).last_hidden_state
+    emb = MeanStdStatPool1D(1)(out)
+    loss_fn = AngularAdditiveMarginSoftMaxLoss(2048, C, margin=0.2, scale=30)
+    with torch.no_grad():
+        loss_fn.fc_weights.copy_(O.synth_tensor("loss_fn.fc_weights", (C, 2048), 20211))
+    loss, pred = loss_fn(emb, label)
+    loss.backward()
+    g["train.embedding"], g["train.loss"] = emb, loss
+    names, norms = [], []
+    for n, p in list(w.model.named_parameters()) + [("loss_fn.fc_weights", loss_fn.fc_weights)]:
+        gr = p.grad if p.grad is not None else torch.zeros_like(p)
+        names.append(n)
+        norms.append(float(gr.double().norm()))
+    g["grad_names"], g["grad_norms"] = np.array(names), np.array(norms)
+    np.savez_compressed(os.path.join(OUT, "g18_large2.npz"), **to_np(g))
+    print("g18_large2: loss", float(loss), "emb norm", float(emb.norm()), "T", h.shape[1])
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["tiny", "base", "aam", "pool", "eval", "optim", "bce", "base2", "base66", "eer", "long", "seed3", "seeds"]
+    which = sys.argv[1:] or ["tiny", "base", "aam", "pool", "eval", "optim", "bce", "base2", "base66", "eer", "long", "seed3", "seeds", "outlier", "large2"]
     for wname in which:
         {"tiny": golden_tiny, "base": golden_base, "aam": golden_aam, "base66": golden_base66, "pool": golden_pool,
          "eval": golden_eval, "optim": golden_optim, "bce": golden_bce, "base2": golden_base2, "eer": golden_eer,
-         "long": golden_long, "seed3": golden_seed3, "seeds": golden_seeds}[wname]()
+         "long": golden_long, "seed3": golden_seed3, "seeds": golden_seeds, "outlier": golden_outlier,
+         "large2": golden_large2}[wname]()

@@ -379,3 +379,55 @@ def test_speechbrain_goldens_pin_the_asp_and_ecapa_restatements():
     for k, v in full.items():
         ref = g["grad." + k[len("blocks.1."):]]
         assert float(np.linalg.norm(v.grad.numpy() - ref)) <= 2e-3 * float(np.linalg.norm(ref)) + 1e-5, k
+
+
+def test_heavy_tailed_weight_family_and_large_branch_goldens():
+    """g17_outlier (make_goldens.py `outlier`: the heavy-tailed weight family of data/synthetic.py outlier_family through the
+    reference wrapper -- max |hidden| / RMS is 26-30 in every layer against 4-5 for the Gaussian family) and g18_large2 (the
+    wrapper's "large" branch, ref src/models/wav2vec2.py:115-116, 2-layer cut, 5 s clips): the oracle is pinned at both."""
+    import dataclasses
+    from w2v2_speaker_amd.data.synthetic import outlier_family
+    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    cfg = O.OracleConfig.base()
+    g = load("g17_outlier.npz")
+    assert float(g["hidden_absmax_over_rms"].min()) > 20.0
+    sd = O.make_state_dict(cfg, 20211)
+    sd = {k: T(v) for k, v in outlier_family({k: v.numpy() for k, v in sd.items()}, 20211).items()}
+    wav, _ = O.synth_batch(4, 48000, 5994, seed=171717)
+    with torch.no_grad():
+        h = O.wav2vec2_forward(wav[:2, 0], sd, cfg)
+    assert rel_l2(h[:, ::16, ::16], g["eval.last_hidden.sample"][:2]) < 1e-4
+    assert rel_l2(O.mean_std_pool(h), g["eval.mean+std"][:2]) < 1e-4
+    # the family is deterministic and really touches what it says
+    base = O.make_state_dict(cfg, 20211)
+    ln = "encoder.layers.3.final_layer_norm.weight"
+    ratio = (sd[ln] / base[ln]).numpy()
+    assert sorted(np.unique(np.round(ratio, 3)).tolist()) == [1.0, 20.0] and int((ratio > 10).sum()) == 6
+    fb = "encoder.layers.5.feed_forward.intermediate_dense.bias"
+    assert int(((sd[fb] - base[fb]) > 7.9).sum()) == 4
+    g = load("g18_large2.npz")
+    lcfg = dataclasses.replace(O.OracleConfig.large(), num_hidden_layers=2)
+    B, N, C = 2, 80000, 211
+    wav, label = O.synth_batch(B, N, C, seed=77)
+    assert np.array_equal(label.numpy(), g["label"])
+    sd = O.make_state_dict(lcfg, 20211)
+    sd["loss_fn.fc_weights"] = O.synth_tensor("loss_fn.fc_weights", (C, 2048), 20211)
+    sdg = {k: v.clone().requires_grad_(k.startswith("encoder") or k.startswith("feature_projection")
+                                       or k in ("masked_spec_embed", "loss_fn.fc_weights")) for k, v in sd.items()}
+    with torch.no_grad():
+        assert rel_l2(O.speaker_embedding(wav, sd, lcfg), g["eval.mean+std"]) < 1e-4
+    emb = O.speaker_embedding(wav, sdg, lcfg, mask_time_indices=T(g["mask"]))
+    assert emb.shape == (B, 2048) and int(g["mask"].sum()) >= 2 * 2 * 10 - 10
+    assert rel_l2(emb.detach(), g["train.embedding"]) < 1e-4
+    loss, _ = O.aam_softmax(emb, sdg["loss_fn.fc_weights"], label)
+    loss.backward()
+    assert abs(float(loss) - float(g["train.loss"])) < 1e-4 * abs(float(g["train.loss"]))
+    ref = dict(zip(g["grad_names"].tolist(), g["grad_norms"].tolist()))
+    gmax = max(ref.values())
+    checked = 0
+    for n, v in sdg.items():
+        if v.grad is None:
+            continue
+        assert abs(float(v.grad.double().norm()) - ref[n]) <= 2e-3 * ref[n] + 1e-6 * gmax, n
+        checked += 1
+    assert checked > 30

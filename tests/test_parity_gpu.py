@@ -342,6 +342,46 @@ def test_five_more_weight_seeds_per_utterance_bound(dtype):
     print(f"five more weight seeds {dtype}: worst utterance rel-L2 {worst:.3e}")
 
 
+# measured on MI355X (profiles/r06_parity.json): the heavy-tailed family is where the 16-bit modes are weakest -- the bound
+# below is what the HIP path is HELD to there; it is reported, not claimed to be 1e-3
+OUTLIER_BOUND = {torch.float32: 1e-4, torch.float16: 4e-3, torch.bfloat16: 6e-2}
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
+def test_heavy_tailed_weight_family_vs_reference_golden(dtype):
+    """every golden up to g16 draws its weights from ONE well-conditioned Gaussian family; the pretrained
+    model is known for outlier channels.  tests/golden/g17_outlier.npz = the REFERENCE on data/synthetic.py outlier_family
+    (six residual channels with every encoder LayerNorm gain x 20, FFN-1 bias entries + 8, convolutions 1 / 3 / 5 x 3: max
+    |hidden| / RMS 26-30 in every layer).  The 16-bit modes must stay FINITE and inside OUTLIER_BOUND per utterance; the
+    measured figure is printed (and recorded in profiles/r06_parity.json)."""
+    from w2v2_speaker_amd.data.synthetic import outlier_family
+    from w2v2_speaker_amd.engine import Plan
+    from w2v2_speaker_amd.params import ParamStore
+    g = load("g17_outlier.npz")
+    cfg, ocfg = _cfgs("base")
+    st = ParamStore(cfg, DEV, dtype, head=None, num_speakers=1)
+    sd = O.make_state_dict(ocfg, 20211)
+    sd = {k: T(v) for k, v in outlier_family({k: v.numpy() for k, v in sd.items()}, 20211).items()}
+    st.load_state_dict(sd)
+    wav, _ = O.synth_batch(4, 48000, 5994, seed=171717)
+    ev = Plan(st, 4, 48000, train=False)
+    e = ev.embed(wav.to(DEV)).float().cpu()
+    torch.cuda.synchronize()
+    assert torch.isfinite(e).all() and torch.isfinite(ev.out.float()).all()
+    ref = T(g["eval.mean+std"])
+    per_utt = (e - ref).norm(dim=1) / ref.norm(dim=1)
+    hid = rel_l2(ev.out[:, ::16, ::16].float().cpu(), g["eval.last_hidden.sample"])
+    print(f"heavy-tailed family {dtype}: embedding per-utterance max {float(per_utt.max()):.3e}, hidden-state sample rel-L2 {hid:.3e}")
+    assert float(per_utt.max()) < OUTLIER_BOUND[dtype], per_utt
+    if dtype != torch.float32:
+        # context: the REFERENCE's own 16-bit autocast against its own f32 on the same weights and utterances (stored by the
+        # golden script: fp16 3.8e-3, bf16 1.5e-2 here; 1.06e-3 fp16 on the Gaussian family, where the HIP path measures 8e-4).
+        # The HIP path's mixed precision must be no worse than the reference's, utterance maximum against utterance maximum.
+        ref16 = float(g["ref_autocast_fp16.per_utt_err" if dtype == torch.float16 else "ref_autocast_bf16.per_utt_err"].max())
+        print(f"   reference autocast {dtype} vs its own f32 on this family: {ref16:.3e}")
+        assert float(per_utt.max()) <= 1.05 * ref16, (float(per_utt.max()), ref16)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
 def test_base_ce_head_1211_vs_reference_golden(dtype):
     """BASELINE configs[0]'s head at its real size: w2v2-base + Linear(1536 -> 1211) + cross-entropy
@@ -550,55 +590,57 @@ def test_paired_input_bce_step_vs_oracle(dtype):
     assert not bad, bad[:8]
 
 
-def test_large_shape_5s_clips_vs_oracle():
+def test_large_shape_5s_clips_vs_reference_golden():
     """BASELINE configs[3] geometry (wav2vec2-large: H=1024, 16 heads, FFN 4096; 5 s clips -> T=249, which takes
-    the T > 160 attention kernels), cut to 2 encoder layers so the CPU oracle finishes in seconds: eval embedding,
-    loss and every trainable gradient norm in the exact-f32 mode; embedding in the bf16 mode."""
+    the 64-row attention geometry), cut to 2 encoder layers, against tests/golden/g18_large2.npz = the REFERENCE wrapper's
+    own "large" branch (ref src/models/wav2vec2.py:115-116; VERDICT r5 item 4b -- this test used to compare with the oracle
+    only): eval embedding, train-mode embedding under the injected SpecAugment mask, AAM loss and every trainable gradient
+    norm in the exact-f32 mode; eval embedding in the 16-bit modes."""
     import dataclasses
     from w2v2_speaker_amd.config import W2V2Config
     from w2v2_speaker_amd.engine import Plan
+    g = load("g18_large2.npz")
     cfg = dataclasses.replace(W2V2Config.from_huggingface_id("facebook/wav2vec2-large"), num_hidden_layers=2)
     ocfg = dataclasses.replace(O.OracleConfig.large(), num_hidden_layers=2)
     B, N, C = 2, 80000, 211
     assert cfg.num_frames(N) == 249
     wav, label = O.synth_batch(B, N, C, seed=77)
-    st, sd = _store(cfg, ocfg, torch.float32, "aam", C)
-    sdg = {k: v.clone().requires_grad_(k.startswith("encoder") or k.startswith("feature_projection")
-                                       or k in ("masked_spec_embed", "loss_fn.fc_weights")) for k, v in sd.items()}
-    torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))
-    emb_ref = O.speaker_embedding(wav, sdg, ocfg)
-    loss_ref, _ = O.aam_softmax(emb_ref, sdg["loss_fn.fc_weights"], label)
-    loss_ref.backward()
+    assert np.array_equal(label.numpy(), g["label"])
+    st, _ = _store(cfg, ocfg, torch.float32, "aam", C)
     ev = Plan(st, B, N, train=False)
     e = ev.embed(wav.to(DEV))
     torch.cuda.synchronize()
-    assert rel_l2(e.cpu(), emb_ref.detach()) < 1e-4
+    assert rel_l2(e.cpu(), g["eval.mean+std"]) < 1e-4
+    assert rel_l2(ev.out[:, ::16, ::16].float().cpu(), g["eval.last_hidden.sample"]) < 1e-4
     del ev
     tr = Plan(st, B, N, train=True, reg=_no_reg())
     st.zero_grad()
-    emb = tr.embed(wav.to(DEV))
+    emb = tr.embed(wav.to(DEV), T(g["mask"]).to(torch.uint8).to(DEV))
     loss, _ = tr.head_forward_backward(label.to(DEV))
     tr.backward()
     torch.cuda.synchronize()
-    assert rel_l2(emb.cpu(), emb_ref.detach()) < 1e-4
-    assert abs(float(loss) - float(loss_ref)) < 1e-4 * abs(float(loss_ref))
-    gmax = max(float(v.grad.norm()) for v in sdg.values() if v.grad is not None)
-    for n, v in sdg.items():
-        if v.grad is None:
-            continue
+    assert rel_l2(emb.cpu(), g["train.embedding"]) < 1e-4
+    assert abs(float(loss) - float(g["train.loss"])) < 1e-4 * abs(float(g["train.loss"]))
+    ref = dict(zip(g["grad_names"].tolist(), g["grad_norms"].tolist()))
+    gmax = max(ref.values())
+    checked = 0
+    for n, want in ref.items():
         name = n if n.startswith("loss_fn") else "wav2vec.model." + n
-        if not st.is_trainable(name):
+        if name not in st.offsets or not st.is_trainable(name):
             continue
-        ref = float(v.grad.double().norm())
         got = float(st.g(name).double().norm())
-        assert abs(got - ref) <= 2e-3 * ref + 1e-6 * gmax, (n, got, ref)
+        assert abs(got - want) <= 2e-3 * want + 1e-6 * gmax, (n, got, want)
+        checked += 1
+    assert checked > 30
     del tr
     for lp, bound in ((torch.bfloat16, 3e-2), (torch.float16, 4e-3)):      # fp16 = the benchmarked mode
         stb, _ = _store(cfg, ocfg, lp, "aam", C)
         evb = Plan(stb, B, N, train=False)
         eb = evb.embed(wav.to(DEV))
         torch.cuda.synchronize()
-        assert rel_l2(eb.cpu(), emb_ref.detach()) < bound, (lp, rel_l2(eb.cpu(), emb_ref.detach()))
+        err = rel_l2(eb.cpu(), g["eval.mean+std"])
+        print(f"large (2-layer cut) {lp}: embedding rel-L2 vs the reference {err:.3e}")
+        assert err < bound, (lp, err)
         del evb, stb
 
 
@@ -832,8 +874,10 @@ def test_partial_zero_grad_ranges_are_all_written_by_the_backward(dtype):
         plan.head_forward_backward(label)
         plan.backward()
         torch.cuda.synchronize()
-        assert torch.isfinite(st.grad[:st.n_train]).all(), skip
-        assert torch.equal(st.grad[:st.n_train], want[:st.n_train]), skip
+        bad = [n for n in st.shapes if st.is_trainable(n) and not torch.isfinite(st.g(n)).all()]
+        assert not bad, (skip, bad)
+        diff = [n for n in st.shapes if st.is_trainable(n) and not torch.equal(st.g(n), want[st.offsets[n]:st.offsets[n] + st.g(n).numel()].view_as(st.g(n)))]
+        assert not diff, (skip, diff)
 
 
 def test_large_24_layers_5s_batch32_properties():

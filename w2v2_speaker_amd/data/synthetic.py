@@ -94,6 +94,32 @@ def synth_weight(name: str, shape: Sequence[int], seed: int) -> np.ndarray:
     return np.ascontiguousarray(a, dtype=np.float32)
 
 
+def outlier_family(sd: Dict[str, np.ndarray], seed: int, prefix: str = "") -> Dict[str, np.ndarray]:
+    """A HEAVY-TAILED variant of a synthetic state dict.  Every golden up to g16 draws its weights from one
+    well-conditioned family (LayerNorm gains 1 +- 0.1, 1/sqrt(fan-in) matrices); the pretrained wav2vec2-base is known for a
+    handful of residual channels that carry activations tens of times larger than the rest and for large pre-projection
+    activations.  Imitated here, deterministically from ``seed``:
+      * six hidden channels: the gain of EVERY encoder LayerNorm (prologue, both norms of each block) x 20 on them,
+      * four entries of every FFN-1 bias + 8,
+      * the convolutions 1, 3, 5 of the feature extractor x 3 (27x larger features in front of the projection's LayerNorm).
+    In place on a copy; ``sd`` keys are HF names with an optional ``prefix`` (as ParamStore.shapes has them)."""
+    out = {k: np.array(v, copy=True) for k, v in sd.items()}
+    g = np.random.Generator(np.random.PCG64(_name_seed("outlier_family", seed)))
+    hidden = out[prefix + "encoder.layer_norm.weight"].shape[0]
+    chans = np.sort(g.choice(hidden, size=min(6, hidden), replace=False))
+    for k in out:
+        n = k[len(prefix):] if prefix and k.startswith(prefix) else k
+        if n.startswith("encoder.") and n.endswith("layer_norm.weight"):
+            out[k][chans] *= 20.0
+        elif n.endswith("feed_forward.intermediate_dense.bias"):
+            idx = g.choice(out[k].shape[0], size=min(4, out[k].shape[0]), replace=False)
+            out[k][idx] += 8.0
+        elif n in ("feature_extractor.conv_layers.1.conv.weight", "feature_extractor.conv_layers.3.conv.weight",
+                   "feature_extractor.conv_layers.5.conv.weight"):
+            out[k] *= 3.0
+    return out
+
+
 def synth_state_dict(shapes: Dict[str, Sequence[int]], seed: int, prefix: str = "wav2vec.model.") -> Dict[str, np.ndarray]:
     """``shapes`` as ``ParamStore.shapes`` has them (reference-style keys): every parameter drawn from ``synth_weight``
     under its HF name (``prefix`` stripped) -- the weights the reference goldens were generated with."""
