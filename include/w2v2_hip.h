@@ -508,6 +508,12 @@ int w2v2_grad_scaler_update(float* state, float growth, float backoff, int growt
 typedef struct w2v2_comm w2v2_comm;
 int w2v2_comm_unique_id(void* id_host_128);
 int w2v2_comm_init(w2v2_comm** comm, const void* id_host_128, int rank, int world, int device);
+/* Loop-back communicator (tests / single-GPU rehearsals; no RCCL involved): stands for rank 0 of a `world`-rank job whose
+ * peers hold bit-identical buffers -- w2v2_allreduce_async multiplies the buffer by `world` on the stream (the SUM of
+ * `world` equal contributions), w2v2_broadcast_async leaves it as it is.  It lets the world > 1 code path of a caller
+ * (bucket order, side stream, 1/world scaling, start-up broadcast) run on a box with one GPU, where RCCL refuses two
+ * ranks per device. */
+int w2v2_comm_init_loopback(w2v2_comm** comm, int world, int device);
 int w2v2_allreduce_async(w2v2_comm* comm, float* buf, int64_t n, void* stream);
 int w2v2_broadcast_async(w2v2_comm* comm, void* buf, int64_t nbytes, int root, void* stream);
 int w2v2_comm_destroy(w2v2_comm* comm);

@@ -191,3 +191,43 @@ def test_c_abi_collective_entry_points_on_rccl():
         outs.append(st.flat[:st.n_train].clone())
     assert torch.equal(outs[0], outs[1])
     comm.destroy()
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_c_abi_reducer_world_n_path_on_a_loopback_communicator(world):
+    """the world > 1 path of CAbiBucketAllReducer without hand-set fields.  w2v2_comm_init_loopback stands
+    for rank 0 of a ``world``-rank job whose peers hold identical buffers (SUM = x world, broadcast = identity): the reducer
+    reports that world, issues every bucket on its side stream, checks the rank-agreement signature, broadcasts the state
+    and the host counters, the trainer scales by 1 / world -- and two training steps end bit-identical to a run with no
+    reducer (x world and x 1/world are exact in f32)."""
+    from w2v2_speaker_amd.comm import CAbiBucketAllReducer, RcclComm
+    from w2v2_speaker_amd.trainer import SpeakerTrainer
+    comm = RcclComm.loopback(world, 0)
+    x = torch.randn(1 << 16, device="cuda")
+    ref = x * world
+    comm.all_reduce_(x)
+    torch.cuda.synchronize()
+    assert torch.equal(x, ref)
+    dev = torch.device("cuda", 0)
+    outs, issued = [], []
+    for use in (False, True):
+        st, plan, sched, wav, label = _setup(dev, 4)
+        red = CAbiBucketAllReducer(st, comm) if use else None
+        tr = SpeakerTrainer(st, plan, sched, reducer=red)
+        if use:
+            assert red.world == world and tr.world == world
+            tr.step = 3
+            st.set_step_counts(5, 4)
+            got = tr.broadcast_state(0, [17])                  # signature all-reduce + state + host counters
+            assert got == [17] and tr.step == 3 and (st.step_head, st.step_body) == (5, 4)
+            tr.step = 0
+            st.set_step_counts(0, 0)
+            orig = red.bucket_ready
+            red.bucket_ready = lambda name: (issued.append(name), orig(name))[1]
+        for _ in range(2):
+            tr.train_step(wav, label)
+        torch.cuda.synchronize()
+        outs.append(st.flat[:st.n_train].clone())
+    assert issued[:1] == ["head"] and "projection" in issued
+    assert torch.isfinite(outs[0]).all() and torch.equal(outs[0], outs[1])
+    comm.destroy()

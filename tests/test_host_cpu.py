@@ -566,6 +566,26 @@ def test_committed_bench_lines_follow_the_contract():
     assert len(pmc["source_hash"]) == 16 and "gemm16_ring_256x128_kernel<_Float16, _Float16>" in pmc["kernels"]
 
 
+def test_committed_ddp_rehearsal_line_carries_the_multi_gpu_fields():
+    """profiles/r06_ddp_rehearsal_line.json = `W2V2_DIST_BACKEND=gloo W2V2_SHARE_GPU=1 bench.py --gpus 2` on a one-GPU box
+    (VERDICT r5 item 8): NOT a scaling measurement (two ranks share one GPU and reduce over gloo) -- it pins the shape of
+    the line the driver will read from an N > 1 run: whole-job value, per-rank records, the self-check of the collective."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    line = json.load(open(os.path.join(root, "profiles", "r06_ddp_rehearsal_line.json")))
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["config"]["parallelism"] == "dp2"
+    assert line["config"]["global_batch"] == 2 * 66
+    assert abs(line["value"] - line["config"]["global_batch"] / (line["ms_per_step"] * 1e-3)) < 0.01 * line["value"]
+    assert abs(line["utt_per_sec_per_gpu"] * 2 - line["value"]) < 0.01 * line["value"]
+    ranks = line["rccl"]["ranks"]
+    assert line["rccl"]["backend"] == "gloo" and [r["rank"] for r in ranks] == [0, 1] and all(r["allreduce_ok"] for r in ranks)
+    d = line["ddp"]
+    for k in ("per_rank_ms_per_step", "per_rank_step_ms_median", "per_rank_solo_ms_per_step"):
+        assert len(d[k]) == 2 and all(v > 0 for v in d[k]), k
+    assert d["rank_spread_ms"] >= 0 and 0 < d["step_time_ratio_vs_solo"] < 1.5
+    assert abs(max(d["per_rank_ms_per_step"]) - line["ms_per_step"]) < 1e-6      # MAX over ranks is what the line reports
+
+
 def test_f32_weight_gradient_split_factor():
     """ecapa.f32_dw_split: few output tiles -> fill the 512 workgroup slots, at most 32 ways; more tiles than half the
     slots -> the factor with the smallest quantisation loss; never fewer than 256 tokens per split."""

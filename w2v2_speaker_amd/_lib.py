@@ -136,6 +136,7 @@ _SIGS = {
     "w2v2_weight_residual": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_vp]),
     "w2v2_comm_unique_id": (c_i32, [c_vp]),
     "w2v2_comm_init": (c_i32, [C.POINTER(c_vp), c_vp, c_i32, c_i32, c_i32]),
+    "w2v2_comm_init_loopback": (c_i32, [C.POINTER(c_vp), c_i32, c_i32]),
     "w2v2_allreduce_async": (c_i32, [c_vp, c_vp, c_i64, c_vp]),
     "w2v2_broadcast_async": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_vp]),
     "w2v2_comm_destroy": (c_i32, [c_vp]),

@@ -26,6 +26,16 @@ class RcclComm:
         buf = C.create_string_buffer(unique_id, 128)
         _lib.check(_lib.load().w2v2_comm_init(C.byref(self._h), buf, rank, world, device), "comm_init")
 
+    @classmethod
+    def loopback(cls, world: int, device: int = 0) -> "RcclComm":
+        """w2v2_comm_init_loopback: rank 0 of a ``world``-rank job whose peers hold identical buffers (SUM all-reduce =
+        x world, broadcast = identity).  Runs the world > 1 path of a reducer on a one-GPU box; no RCCL involved."""
+        self = cls.__new__(cls)
+        self.rank, self.world, self.device = 0, world, device
+        self._h = C.c_void_p()
+        _lib.check(_lib.load().w2v2_comm_init_loopback(C.byref(self._h), world, device), "comm_init_loopback")
+        return self
+
     @staticmethod
     def unique_id() -> bytes:
         buf = C.create_string_buffer(128)

@@ -69,7 +69,13 @@ const char* rccl_err(int rc) { return g_rccl.error_string != nullptr ? g_rccl.er
 struct w2v2_comm {
   Comm comm;
   int rank, world, device;
+  bool loopback;
 };
+
+// loop-back all-reduce: the SUM of `world` bit-identical contributions
+__global__ __launch_bounds__(256) void loopback_scale_kernel(float* __restrict__ buf, int64_t n, float world) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) buf[i] *= world;
+}
 
 extern "C" int w2v2_comm_unique_id(void* id_host_128) {
   W2V2_REQUIRE(id_host_128 != nullptr, "comm_unique_id: null buffer");
@@ -103,7 +109,17 @@ extern "C" int w2v2_comm_init(w2v2_comm** out, const void* id_host_128, int rank
     free(w);
     W2V2_FAIL("comm_init: ncclCommInitRank: %s", rccl_err(rc));
   }
-  w->comm = c; w->rank = rank; w->world = world; w->device = device;
+  w->comm = c; w->rank = rank; w->world = world; w->device = device; w->loopback = false;
+  *out = w;
+  return 0;
+}
+
+extern "C" int w2v2_comm_init_loopback(w2v2_comm** out, int world, int device) {
+  W2V2_REQUIRE(out != nullptr && world >= 1 && device >= 0, "comm_init_loopback: bad arguments (world %d, device %d)", world,
+               device);
+  w2v2_comm* w = (w2v2_comm*)malloc(sizeof(w2v2_comm));
+  if (w == nullptr) W2V2_FAIL("comm_init_loopback: out of memory");
+  w->comm = nullptr; w->rank = 0; w->world = world; w->device = device; w->loopback = true;
   *out = w;
   return 0;
 }
@@ -111,6 +127,15 @@ extern "C" int w2v2_comm_init(w2v2_comm** out, const void* id_host_128, int rank
 extern "C" int w2v2_allreduce_async(w2v2_comm* comm, float* buf, int64_t n, void* stream) {
   W2V2_REQUIRE(comm != nullptr && buf != nullptr && n >= 0, "allreduce_async: bad arguments");
   if (n == 0) return 0;
+  if (comm->loopback) {
+    if (comm->world > 1) {
+      const int64_t blocks = (n + 255) / 256;
+      hipLaunchKernelGGL(loopback_scale_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, as_stream(stream),
+                         buf, n, (float)comm->world);
+      W2V2_CHECK_LAUNCH("allreduce_async (loop-back)");
+    }
+    return 0;
+  }
   const int rc = g_rccl.all_reduce(buf, buf, (size_t)n, /*ncclFloat32*/ 7, /*ncclSum*/ 0, comm->comm, as_stream(stream));
   if (rc != 0) W2V2_FAIL("allreduce_async: ncclAllReduce: %s", rccl_err(rc));
   return 0;
@@ -119,7 +144,7 @@ extern "C" int w2v2_allreduce_async(w2v2_comm* comm, float* buf, int64_t n, void
 extern "C" int w2v2_broadcast_async(w2v2_comm* comm, void* buf, int64_t nbytes, int root, void* stream) {
   W2V2_REQUIRE(comm != nullptr && buf != nullptr && nbytes >= 0 && root >= 0 && root < comm->world,
                "broadcast_async: bad arguments (root %d)", root);
-  if (nbytes == 0) return 0;
+  if (nbytes == 0 || comm->loopback) return 0;
   W2V2_REQUIRE(g_rccl.broadcast != nullptr, "broadcast_async: librccl.so lacks ncclBroadcast");
   const int rc = g_rccl.broadcast(buf, buf, (size_t)nbytes, /*ncclUint8*/ 1, root, comm->comm, as_stream(stream));
   if (rc != 0) W2V2_FAIL("broadcast_async: ncclBroadcast: %s", rccl_err(rc));
@@ -128,7 +153,7 @@ extern "C" int w2v2_broadcast_async(w2v2_comm* comm, void* buf, int64_t nbytes, 
 
 extern "C" int w2v2_comm_destroy(w2v2_comm* comm) {
   if (comm == nullptr) return 0;
-  const int rc = g_rccl.comm_destroy != nullptr ? g_rccl.comm_destroy(comm->comm) : 0;
+  const int rc = (!comm->loopback && g_rccl.comm_destroy != nullptr) ? g_rccl.comm_destroy(comm->comm) : 0;
   free(comm);
   if (rc != 0) W2V2_FAIL("comm_destroy: ncclCommDestroy: %s", rccl_err(rc));
   return 0;
