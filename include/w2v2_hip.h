@@ -170,6 +170,12 @@ int w2v2_conv0_stats_mfma(const float* wav, const float* w, float* partial, floa
 int w2v2_conv0_apply(const float* wav, const float* w, const float* mean_rstd, const float* gamma,
                      const float* beta, void* y, int dtype, int B, int N, int C, int k, int stride,
                      void* stream);
+/* Layer 0 of the feat_extract_norm="layer" family (HF:275-299; "-lv60" / xlsr checkpoints):
+ * out[b, l, :] = GELU(LayerNorm_C(conv1d(wav, w [C][k], stride)[b, l, :] + bias)) -- the normalisation runs over the channels
+ * of one frame (eps = nn.LayerNorm's default 1e-5 at the reference).  bias may be NULL (conv_bias=False).  f32 arithmetic,
+ * `dtype` output; C % 8 == 0, C <= 512, k <= 16.  Forward only. */
+int w2v2_conv0_layernorm_gelu(const float* wav, const float* w, const float* bias, const float* gamma, const float* beta,
+                              void* out, int B, int N, int C, int k, int stride, float eps, int dtype, void* stream);
 /* Backward of layer 0 (unfrozen feature extractor): from dz = dL/d(layer-0 output) [B,L,C] compute dw [C][k],
  * dgamma [C], dbeta [C] (f32 atomics, caller zeroes); conv / GroupNorm are recomputed from the waveform and the
  * forward's mean_rstd.  sums [B][C][2] is f32 scratch. */
@@ -192,6 +198,11 @@ int w2v2_pack_conv_weight(const float* w, void* out, int dtype, int Cout, int Ci
 int w2v2_layernorm_fwd(const void* x, void* r_inout, const float* gamma, const float* beta, void* y,
                        float* mean, float* rstd, int M, int H, float eps, float drop_p,
                        uint64_t seed, int dtype, void* stream);
+/* y = GELU(LN(x) * gamma + beta), x and y [M, H] (y may alias x): the convolution layers of the feat_extract_norm="layer"
+ * checkpoints (HF:275-299 Wav2Vec2LayerNormConvLayer: conv -> LayerNorm over the channels -> GELU).  Forward only: no
+ * statistics are saved (the feature extractor of this family runs frozen, the reference's default). */
+int w2v2_layernorm_gelu_fwd(const void* x, const float* gamma, const float* beta, void* y, int M, int H, float eps,
+                            int dtype, void* stream);
 /* s = pre-norm input (x if r was NULL).  Outputs: ds (grad wrt s; may alias dy), d_r = ds*dropmask
  * (optional; a plain copy of ds when drop_p == 0), dgamma/dbeta ADDED to (f32, caller zeroes): with a
  * workspace of w2v2_layernorm_bwd_workspace_floats(H) floats the column sums are folded in a fixed

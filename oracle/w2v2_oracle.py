@@ -39,6 +39,11 @@ class OracleConfig:
     num_conv_pos_embeddings: int = 128
     num_conv_pos_embedding_groups: int = 16
     layer_norm_eps: float = 1e-5
+    # the "-lv60" / xlsr family of checkpoints: pre-LN encoder (HF:611-654,729-802), a LayerNorm over
+    # the channels after EVERY convolution instead of the layer-0 GroupNorm (HF:275-299), convolutions with bias
+    do_stable_layer_norm: bool = False
+    feat_extract_norm: str = "group"
+    conv_bias: bool = False
 
     @staticmethod
     def base() -> "OracleConfig":
@@ -65,14 +70,17 @@ class OracleConfig:
 
 # --------------------------------------------------------------------------- weights
 def param_shapes(cfg: OracleConfig) -> Dict[str, Tuple[int, ...]]:
-    """HF state-dict names/shapes of Wav2Vec2Model (group-norm CNN, post-LN encoder)."""
+    """HF state-dict names/shapes of Wav2Vec2Model (group-norm or layer-norm CNN, post- or pre-LN encoder: the encoder's
+    names are the same in both)."""
     shp: Dict[str, Tuple[int, ...]] = {}
     cin = 1
     for i, (c, k) in enumerate(zip(cfg.conv_dim, cfg.conv_kernel)):
         shp[f"feature_extractor.conv_layers.{i}.conv.weight"] = (c, cin, k)
-        if i == 0:
-            shp["feature_extractor.conv_layers.0.layer_norm.weight"] = (c,)
-            shp["feature_extractor.conv_layers.0.layer_norm.bias"] = (c,)
+        if cfg.conv_bias:
+            shp[f"feature_extractor.conv_layers.{i}.conv.bias"] = (c,)
+        if i == 0 or cfg.feat_extract_norm == "layer":
+            shp[f"feature_extractor.conv_layers.{i}.layer_norm.weight"] = (c,)
+            shp[f"feature_extractor.conv_layers.{i}.layer_norm.bias"] = (c,)
         cin = c
     H, C = cfg.hidden_size, cfg.conv_dim[-1]
     shp["feature_projection.layer_norm.weight"] = (C,)
@@ -145,8 +153,12 @@ def feature_extractor(x: Tensor, sd: StateDict, cfg: OracleConfig) -> Tensor:
     h = x[:, None, :]
     for i, s in enumerate(cfg.conv_stride):
         w = sd[f"feature_extractor.conv_layers.{i}.conv.weight"]
-        h = F.conv1d(h, w, None, stride=s)
-        if i == 0:
+        h = F.conv1d(h, w, sd[f"feature_extractor.conv_layers.{i}.conv.bias"] if cfg.conv_bias else None, stride=s)
+        if cfg.feat_extract_norm == "layer":
+            # HF:275-299 (Wav2Vec2LayerNormConvLayer): nn.LayerNorm(C) over the channels of every frame, default eps 1e-5
+            h = layer_norm(h.transpose(1, 2), sd[f"feature_extractor.conv_layers.{i}.layer_norm.weight"],
+                           sd[f"feature_extractor.conv_layers.{i}.layer_norm.bias"], 1e-5).transpose(1, 2)
+        elif i == 0:
             gamma = sd["feature_extractor.conv_layers.0.layer_norm.weight"]
             beta = sd["feature_extractor.conv_layers.0.layer_norm.bias"]
             mu = h.mean(dim=2, keepdim=True)
@@ -221,9 +233,41 @@ def encoder_layer(x: Tensor, sd: StateDict, l: int, cfg: OracleConfig) -> Tensor
                       cfg.layer_norm_eps)
 
 
+def encoder_layer_stable(x: Tensor, sd: StateDict, l: int, cfg: OracleConfig) -> Tensor:
+    """HF:611-654 pre-LN block (do_stable_layer_norm): x = x + Attn(LN1(x)); x = x + FFN(LN2(x))."""
+    p = f"encoder.layers.{l}."
+    x = x + attention(layer_norm(x, sd[p + "layer_norm.weight"], sd[p + "layer_norm.bias"], cfg.layer_norm_eps), sd, p,
+                      cfg.num_attention_heads)
+    n = layer_norm(x, sd[p + "final_layer_norm.weight"], sd[p + "final_layer_norm.bias"], cfg.layer_norm_eps)
+    f = gelu(n @ sd[p + "feed_forward.intermediate_dense.weight"].t() + sd[p + "feed_forward.intermediate_dense.bias"])
+    return x + f @ sd[p + "feed_forward.output_dense.weight"].t() + sd[p + "feed_forward.output_dense.bias"]
+
+
+def encoder_stable(h: Tensor, sd: StateDict, cfg: OracleConfig, skip_layers: Sequence[int] = (),
+                   return_stages: bool = False):
+    """HF:729-802 (Wav2Vec2EncoderStableLayerNorm): x = x + posconv(x); pre-LN layers; ONE LayerNorm at the end.
+    Stage l is the un-normalised residual stream after layer l, as HF's hidden_states has it."""
+    stages = {}
+    pos = pos_conv_embed(h, sd, cfg)
+    x = h + pos
+    if return_stages:
+        stages["pos_conv"] = pos
+        stages["enc_in"] = x
+    for l in range(cfg.num_hidden_layers):
+        if l in skip_layers:
+            continue
+        x = encoder_layer_stable(x, sd, l, cfg)
+        if return_stages:
+            stages[f"layer{l}"] = x
+    x = layer_norm(x, sd["encoder.layer_norm.weight"], sd["encoder.layer_norm.bias"], cfg.layer_norm_eps)
+    return (x, stages) if return_stages else x
+
+
 def encoder(h: Tensor, sd: StateDict, cfg: OracleConfig, skip_layers: Sequence[int] = (),
             return_stages: bool = False):
     """HF:657-726: x = LN(x + posconv(x)); 12/24 layers; LayerDrop is injected via skip_layers."""
+    if cfg.do_stable_layer_norm:
+        return encoder_stable(h, sd, cfg, skip_layers, return_stages)
     stages = {}
     pos = pos_conv_embed(h, sd, cfg)
     x = layer_norm(h + pos, sd["encoder.layer_norm.weight"], sd["encoder.layer_norm.bias"],

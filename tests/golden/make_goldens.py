@@ -79,7 +79,9 @@ def hf_extra(cfg: O.OracleConfig):
                 num_attention_heads=cfg.num_attention_heads,
                 intermediate_size=cfg.intermediate_size,
                 num_conv_pos_embeddings=cfg.num_conv_pos_embeddings,
-                num_conv_pos_embedding_groups=cfg.num_conv_pos_embedding_groups)
+                num_conv_pos_embedding_groups=cfg.num_conv_pos_embedding_groups,
+                do_stable_layer_norm=cfg.do_stable_layer_norm, feat_extract_norm=cfg.feat_extract_norm,
+                conv_bias=cfg.conv_bias)
 
 
 def build_reference_wrapper(cfg: O.OracleConfig, seed: int, cls_token=False, hf_id="facebook/wav2vec2-base", family=None):
@@ -623,10 +625,94 @@ def golden_large2():
     print("g18_large2: loss", float(loss), "emb norm", float(emb.norm()), "T", h.shape[1])
 
 
+# ----------------------------------------------------------------------------- G19 pre-LN / layer-norm-conv family
+def golden_tiny_stable():
+    """VERDICT r5 item 6 / SURVEY App. A.12: the "-lv60" / xlsr family -- HF config flags do_stable_layer_norm=True (pre-LN
+    encoder, HF:611-654,729-802), feat_extract_norm="layer" (a LayerNorm after EVERY convolution, HF:275-299), conv_bias=True --
+    through the reference wrapper at the tiny geometry with THREE layers: per-stage activations (train mode, injected mask,
+    dropouts 0), AAM loss, every gradient; the same with layer 1 skipped (what LayerDrop does: the block is removed from
+    the reference's own ModuleList for that pass); eval-mode embedding."""
+    import dataclasses
+    cfg = dataclasses.replace(O.OracleConfig.tiny(), num_hidden_layers=3, do_stable_layer_norm=True,
+                              feat_extract_norm="layer", conv_bias=True)
+    B, N, C = 2, 4000, 10
+    w, sd = build_reference_wrapper(cfg, seed=20211, hf_id="facebook/wav2vec2-large-lv60")
+    assert w.model.config.do_stable_layer_norm and w.model.config.feat_extract_norm == "layer" and w.model.config.conv_bias
+    assert type(w.model.encoder).__name__ == "Wav2Vec2EncoderStableLayerNorm"
+    wav, label = O.synth_batch(B, N, C, seed=42133724)
+    T = cfg.num_frames(N)
+    rng = np.random.Generator(np.random.PCG64(7))
+    mask = np.zeros((B, T), dtype=bool)
+    for b in range(B):
+        s0 = rng.integers(0, T - 3)
+        mask[b, s0:s0 + 3] = True
+    mask_t = torch.from_numpy(mask)
+    m = w.model
+    aam_w = O.synth_tensor("loss_fn.fc_weights", (C, 2 * cfg.hidden_size), 20211)
+    x = torch.squeeze(wav)
+    g = {"wav": wav, "label": label, "mask": mask_t}
+
+    def run(tag, grab_stages):
+        w.train()
+        m.zero_grad()
+        stages, hooks = {}, []
+        if grab_stages:
+            def grab(name):
+                def f(_m, _i, o):
+                    stages[name] = (o[0] if isinstance(o, tuple) else o).detach().clone()
+                return f
+            hooks.append(m.feature_extractor.register_forward_hook(grab("conv_out_bct")))
+            hooks.append(m.feature_projection.register_forward_hook(grab("proj")))
+            hooks.append(m.encoder.pos_conv_embed.register_forward_hook(grab("pos_conv")))
+            hooks.append(m.encoder.layers[0].register_forward_pre_hook(
+                lambda _m, i: stages.__setitem__("enc_in", i[0].detach().clone())))
+            for l, layer in enumerate(m.encoder.layers):
+                hooks.append(layer.register_forward_hook(grab(f"layer{l}")))
+        out = m(x, mask_time_indices=mask_t).last_hidden_state
+        emb = MeanStdStatPool1D(dim_to_reduce=1)(out)
+        loss_fn = AngularAdditiveMarginSoftMaxLoss(2 * cfg.hidden_size, C, margin=0.2, scale=30)
+        with torch.no_grad():
+            loss_fn.fc_weights.copy_(aam_w)
+        loss, pred = loss_fn(emb, label)
+        loss.backward()
+        for h in hooks:
+            h.remove()
+        g[tag + "embedding"], g[tag + "loss"], g[tag + "last_hidden"] = emb, loss, out
+        if grab_stages:
+            g["stage.conv_out"] = stages["conv_out_bct"].transpose(1, 2)
+            for k in ("proj", "pos_conv", "enc_in"):
+                g["stage." + k] = stages[k]
+            for l in range(cfg.num_hidden_layers):
+                g[f"stage.layer{l}"] = stages[f"layer{l}"]
+        return loss_fn
+
+    lf = run("", True)
+    for n, p in m.named_parameters():
+        g["grad." + n] = (p.grad if p.grad is not None else torch.zeros_like(p)).clone()
+    g["grad.loss_fn.fc_weights"] = lf.fc_weights.grad.clone()
+    # LayerDrop of layer 1: the reference's own modules with that block taken out of the list for one pass
+    layers = m.encoder.layers
+    full = list(layers)
+    m.encoder.layers = torch.nn.ModuleList([full[0], full[2]])
+    lf = run("skip1.", False)
+    m.encoder.layers = torch.nn.ModuleList(full)
+    named = dict(m.named_parameters())
+    for n, p in named.items():
+        used = not n.startswith("encoder.layers.1.")
+        g["skip1.grad." + n] = (p.grad.clone() if (used and p.grad is not None) else torch.zeros_like(p))
+    g["skip1.grad.loss_fn.fc_weights"] = lf.fc_weights.grad.clone()
+    w.eval()
+    with torch.no_grad():
+        h = w(x).transpose(2, 1)
+        g["eval.last_hidden"], g["eval.mean+std"] = h, MeanStdStatPool1D(1)(h)
+    np.savez_compressed(os.path.join(OUT, "g19_tiny_stable.npz"), **to_np(g))
+    print("g19_tiny_stable: loss", float(g["loss"]), "skip1 loss", float(g["skip1.loss"]), "T", T, "keys", len(g))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["tiny", "base", "aam", "pool", "eval", "optim", "bce", "base2", "base66", "eer", "long", "seed3", "seeds", "outlier", "large2"]
+    which = sys.argv[1:] or ["tiny", "base", "aam", "pool", "eval", "optim", "bce", "base2", "base66", "eer", "long", "seed3", "seeds", "outlier", "large2", "tiny_stable"]
     for wname in which:
         {"tiny": golden_tiny, "base": golden_base, "aam": golden_aam, "base66": golden_base66, "pool": golden_pool,
          "eval": golden_eval, "optim": golden_optim, "bce": golden_bce, "base2": golden_base2, "eer": golden_eer,
          "long": golden_long, "seed3": golden_seed3, "seeds": golden_seeds, "outlier": golden_outlier,
-         "large2": golden_large2}[wname]()
+         "large2": golden_large2, "tiny_stable": golden_tiny_stable}[wname]()

@@ -650,3 +650,41 @@ def test_rank_agreement_signature_is_exact_in_f32_at_base_size():
         signature_limbs([1 << 48])
     with pytest.raises(ValueError):
         signature_agrees([0.0] * 36, 259)
+
+
+def test_pre_ln_family_parameter_names_order_and_id_table():
+    """The "-lv60" / xlsr family (W2V2Config.do_stable_layer_norm / feat_extract_norm="layer" / conv_bias): the arena holds
+    exactly HF's parameters for those config flags, reference_parameter_order() == HF ``named_parameters()`` order; and
+    from_huggingface_id classifies the ids it knows and RAISES on a 'large' id it cannot classify (VERDICT r5 missing 6)."""
+    import dataclasses
+    import torch
+    from transformers import Wav2Vec2Config, Wav2Vec2Model
+    from w2v2_speaker_amd.config import W2V2Config
+    from w2v2_speaker_amd.params import ParamStore, W2V_PREFIX
+    tiny = dataclasses.replace(W2V2Config.tiny(), do_stable_layer_norm=True, feat_extract_norm="layer", conv_bias=True)
+    hf = Wav2Vec2Model(Wav2Vec2Config(
+        conv_dim=list(tiny.conv_dim), conv_kernel=list(tiny.conv_kernel), conv_stride=list(tiny.conv_stride),
+        hidden_size=tiny.hidden_size, num_hidden_layers=tiny.num_hidden_layers,
+        num_attention_heads=tiny.num_attention_heads, intermediate_size=tiny.intermediate_size,
+        num_conv_pos_embeddings=tiny.num_conv_pos_embeddings,
+        num_conv_pos_embedding_groups=tiny.num_conv_pos_embedding_groups,
+        do_stable_layer_norm=True, feat_extract_norm="layer", conv_bias=True))
+    st = ParamStore(tiny, "cpu", torch.float32, head=None, num_speakers=1)
+    hf_named = [(W2V_PREFIX + n, tuple(p.shape)) for n, p in hf.named_parameters()]
+    assert [n for n in st.reference_parameter_order()] == [n for n, _ in hf_named]
+    assert all(tuple(st.shapes[n]) == s for n, s in hf_named)
+    # the feature extractor of this family is frozen storage like the group-norm one: nothing of it is trainable
+    assert not any(st.is_trainable(n) for n in st.shapes if "feature_extractor" in n)
+    f = W2V2Config.from_huggingface_id
+    for hid in ("facebook/wav2vec2-large-lv60", "facebook/wav2vec2-large-960h-lv60-self", "facebook/wav2vec2-large-xlsr-53",
+                "facebook/wav2vec2-large-robust", "facebook/wav2vec2-large-100k-voxpopuli"):
+        c = f(hid)
+        assert (c.hidden_size, c.num_hidden_layers, c.do_stable_layer_norm, c.feat_extract_norm, c.conv_bias) == \
+            (1024, 24, True, "layer", True), hid
+    for hid in ("facebook/wav2vec2-large", "facebook/wav2vec2-large-960h"):
+        c = f(hid)
+        assert c.hidden_size == 1024 and not c.do_stable_layer_norm and c.feat_extract_norm == "group" and not c.conv_bias
+    assert f("facebook/wav2vec2-base-960h").hidden_size == 768
+    for hid in ("someone/wav2vec2-large-finetuned-xyz", "facebook/hubert-xl"):
+        with pytest.raises(ValueError):
+            f(hid)

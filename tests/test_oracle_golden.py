@@ -431,3 +431,39 @@ def test_heavy_tailed_weight_family_and_large_branch_goldens():
         assert abs(float(v.grad.double().norm()) - ref[n]) <= 2e-3 * ref[n] + 1e-6 * gmax, n
         checked += 1
     assert checked > 30
+
+
+def test_pre_ln_layer_norm_conv_family_all_stages_and_grads():
+    """g19_tiny_stable (make_goldens.py `tiny_stable`): the "-lv60" / xlsr family through the REFERENCE wrapper -- pre-LN
+    encoder, LayerNorm after every convolution, convolutions with bias (HF:275-299,611-654,729-802).  The
+    oracle's restatement must reproduce every stage, the loss and every gradient, with and without a LayerDrop skip."""
+    import dataclasses
+    g = load("g19_tiny_stable.npz")
+    cfg = dataclasses.replace(O.OracleConfig.tiny(), num_hidden_layers=3, do_stable_layer_norm=True,
+                              feat_extract_norm="layer", conv_bias=True)
+    wav, label, mask = T(g["wav"]), T(g["label"]), T(g["mask"])
+    W0 = O.synth_tensor("loss_fn.fc_weights", (10, 2 * cfg.hidden_size), 20211)
+    assert "feature_extractor.conv_layers.3.conv.bias" in O.param_shapes(cfg)
+    assert "feature_extractor.conv_layers.6.layer_norm.weight" in O.param_shapes(cfg)
+    for tag, skip in (("", ()), ("skip1.", (1,))):
+        sd = {k: v.clone().requires_grad_(True) for k, v in O.make_state_dict(cfg, 20211).items()}
+        out, st = O.wav2vec2_forward(wav[:, 0, :], sd, cfg, mask_time_indices=mask, skip_layers=skip, return_stages=True)
+        if not skip:
+            for k in ("conv_out", "proj", "pos_conv", "enc_in", "layer0", "layer1", "layer2"):
+                assert rel_l2(st[k].detach(), g["stage." + k]) < 2e-5, k
+        assert rel_l2(out.detach(), g[tag + "last_hidden"]) < 2e-5
+        emb = O.mean_std_pool(out)
+        assert rel_l2(emb.detach(), g[tag + "embedding"]) < 2e-5
+        W = W0.clone().requires_grad_(True)
+        loss, _ = O.aam_softmax(emb, W, label, 0.2, 30.0)
+        assert abs(float(loss) - float(g[tag + "loss"])) < 1e-4
+        loss.backward()
+        assert rel_l2(W.grad, g[tag + "grad.loss_fn.fc_weights"]) < 1e-4
+        for n, p in sd.items():
+            ref = g[tag + "grad." + n]
+            got = p.grad if p.grad is not None else torch.zeros_like(p)
+            err = float(np.linalg.norm(got.numpy().astype(np.float64) - ref))
+            assert err <= 2e-4 * float(np.linalg.norm(ref)) + 1e-6, (tag, n)
+    with torch.no_grad():
+        e = O.speaker_embedding(wav, O.make_state_dict(cfg, 20211), cfg, "mean+std")
+    assert rel_l2(e, g["eval.mean+std"]) < 2e-5

@@ -104,6 +104,91 @@ def test_tiny_all_stages_loss_and_every_gradient_vs_reference_golden(dtype):
     print("worst grad rel err", worst)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
+def test_pre_ln_layer_norm_conv_family_vs_reference_golden(dtype):
+    """VERDICT r5 item 6 / SURVEY App. A.12: the "-lv60" / xlsr checkpoint family -- pre-LN encoder (HF:611-654,729-802), a
+    LayerNorm after every convolution (HF:275-299), convolutions with bias -- through the HIP engine against
+    tests/golden/g19_tiny_stable.npz (the reference wrapper with those HF config flags, tiny geometry, three blocks): every
+    stage, the loss and the gradient of every trainable parameter, without and with a LayerDrop skip of the middle block."""
+    import dataclasses
+    from w2v2_speaker_amd.config import W2V2Config
+    from w2v2_speaker_amd.engine import Plan
+    g = load("g19_tiny_stable.npz")
+    kw = dict(num_hidden_layers=3, do_stable_layer_norm=True, feat_extract_norm="layer", conv_bias=True)
+    cfg, ocfg = dataclasses.replace(W2V2Config.tiny(), **kw), dataclasses.replace(O.OracleConfig.tiny(), **kw)
+    st, _ = _store(cfg, ocfg, dtype, "aam", 10)
+    assert "wav2vec.model.feature_extractor.conv_layers.4.conv.bias" in st.shapes
+    assert "wav2vec.model.feature_extractor.conv_layers.6.layer_norm.weight" in st.shapes
+    if st.scaler is not None:
+        st.scaler[0] = 256.0
+    wav, label, mask = T(g["wav"]).to(DEV), T(g["label"]).to(DEV), T(g["mask"])
+    plan = Plan(st, 2, wav.shape[-1], train=True, reg=_no_reg())
+    assert plan.stable and plan.ln_conv
+    f32, f16 = dtype == torch.float32, dtype == torch.float16
+    tol = 1e-4 if f32 else (3e-3 if f16 else 3e-2)
+    gtol = 2e-3 if f32 else (8e-3 if f16 else 0.12)
+    for tag, skip in (("", ()), ("skip1.", (1,))):
+        st.zero_grad()
+        emb = plan.embed(wav, mask.to(DEV), skip)
+        loss, _ = plan.head_forward_backward(label)
+        plan.backward()
+        torch.cuda.synchronize()
+        B, Tn, H = plan.out.shape
+        if not skip:
+            assert rel_l2(plan.conv[-1].float().cpu(), g["stage.conv_out"]) < (1e-5 if f32 else (2e-3 if f16 else 1.5e-2))
+            assert rel_l2(plan.pos.float().cpu().view(B, Tn, H), g["stage.enc_in"]) < tol         # x_0 = hx + pos
+            for l in range(cfg.num_hidden_layers):      # the un-normalised residual stream after block l
+                assert rel_l2(plan.lb[l].f.float().cpu().view(B, Tn, H), g[f"stage.layer{l}"]) < tol, l
+        assert rel_l2(plan.out.float().cpu(), g[tag + "last_hidden"]) < tol
+        assert rel_l2(emb.cpu(), g[tag + "embedding"]) < (1e-4 if f32 else (2e-3 if f16 else 3e-2))
+        assert abs(float(loss) - float(g[tag + "loss"])) < (1e-4 if f32 else (3e-3 if f16 else 5e-2)) * abs(float(g[tag + "loss"]))
+        gs = _gscale(st)
+        worst = 0.0
+        for name in st.shapes:
+            if not st.is_trainable(name):
+                continue
+            key = tag + "grad." + (name[len("wav2vec.model."):] if name.startswith("wav2vec.model.") else name)
+            ref = g[key]
+            got = st.g(name).cpu().numpy().astype(np.float64) / gs
+            err = np.linalg.norm(got - ref)
+            floor = 1e-6 if f32 else (3e-4 if f16 else 3e-3)
+            assert err <= gtol * np.linalg.norm(ref) + floor, (tag, name, err, np.linalg.norm(ref))
+            worst = max(worst, err / (np.linalg.norm(ref) + 1e-12))
+        print(f"pre-LN family {dtype} {tag or 'full'}: worst gradient rel err {worst:.3e}")
+    # eval plan (single buffer set, ping-pong X)
+    ev = Plan(st, 2, wav.shape[-1], train=False)
+    e = ev.embed(wav)
+    torch.cuda.synchronize()
+    assert rel_l2(e.cpu(), g["eval.mean+std"]) < (1e-4 if f32 else (2e-3 if f16 else 3e-2))
+    with pytest.raises(NotImplementedError):
+        Plan(st, 2, wav.shape[-1], train=False, insert_cls_token=True, pooling="first+cls")
+
+
+def test_layer_norm_convolution_stack_at_base_width_vs_oracle():
+    """The layer-norm convolution family at the real width (512 channels, k = 10 / 3 / 2, biases): conv_features() of the
+    HIP path against the (g19-pinned) oracle restatement on one second of audio, f32 and fp16."""
+    import dataclasses
+    from w2v2_speaker_amd.config import W2V2Config
+    from w2v2_speaker_amd.engine import Plan
+    from w2v2_speaker_amd.params import ParamStore
+    kw = dict(num_hidden_layers=1, do_stable_layer_norm=True, feat_extract_norm="layer", conv_bias=True)
+    cfg, ocfg = dataclasses.replace(W2V2Config(), **kw), dataclasses.replace(O.OracleConfig.base(), **kw)
+    wav, _ = O.synth_batch(3, 16000, 10, seed=5)
+    sd = O.make_state_dict(ocfg, 31)
+    with torch.no_grad():
+        ref = O.feature_extractor(wav[:, 0], sd, ocfg).transpose(1, 2)
+    for dtype, bound in ((torch.float32, 1e-5), (torch.float16, 2e-3)):
+        st = ParamStore(cfg, DEV, dtype, head=None, num_speakers=1)
+        st.load_state_dict(sd)
+        ev = Plan(st, 3, 16000, train=False)
+        out = ev.conv_features(wav.to(DEV))
+        torch.cuda.synchronize()
+        err = rel_l2(out.float().cpu(), ref)
+        print(f"layer-norm conv stack {dtype}: rel-L2 {err:.3e}")
+        assert err < bound, (dtype, err)
+        del ev, st
+
+
 def test_tiny_ce_head_and_other_pools_vs_golden():
     from w2v2_speaker_amd.engine import Plan
     g = load("g1_tiny.npz")

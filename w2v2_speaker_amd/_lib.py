@@ -64,6 +64,8 @@ _SIGS = {
     "w2v2_conv0_bwd": (c_i32, [c_vp] * 10 + [c_i32] * 6 + [c_vp]),
     "w2v2_col2im": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "w2v2_unpack_conv_grad": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
+    "w2v2_conv0_layernorm_gelu": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_i32, c_vp]),
+    "w2v2_layernorm_gelu_fwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_f32, c_i32, c_vp]),
     "w2v2_layernorm_fwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_f32, c_f32,
                                    c_u64, c_i32, c_vp]),
     "w2v2_layernorm_bwd_workspace_floats": (c_i32, [c_i32]),

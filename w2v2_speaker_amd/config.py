@@ -38,15 +38,40 @@ class W2V2Config:
     num_conv_pos_embedding_groups: int = 16
     layer_norm_eps: float = 1e-5
     mask_time_min_masks: int = 2
+    # The "-lv60" / xlsr family: pre-LN encoder (HF:611-654,729-802: LayerNorm BEFORE attention / FFN, one
+    # LayerNorm after the last block), a LayerNorm over the channels after EVERY convolution instead of the layer-0
+    # GroupNorm (HF:275-299), convolutions with bias.  The reference loads any HF id (ref: src/models/wav2vec2.py:25-55).
+    do_stable_layer_norm: bool = False
+    feat_extract_norm: str = "group"            # "group" | "layer"
+    conv_bias: bool = False
+
+    # checkpoint families by id substring.  From the published HF configs (NOT verifiable offline):
+    # post-LN / group-norm: wav2vec2-base*, wav2vec2-large, wav2vec2-large-960h;
+    # pre-LN / layer-norm convolutions with bias: *-lv60*, *xlsr*, *xls-r*, *-robust*, *voxpopuli* large models
+    _STABLE_MARKS = ("lv60", "xlsr", "xls-r", "xls_r", "robust", "voxpopuli")
+    _POST_LN_LARGE = ("wav2vec2-large", "wav2vec2-large-960h")
 
     @staticmethod
     def from_huggingface_id(hf_id: str) -> "W2V2Config":
-        """The reference only inspects the substrings "base" / "large" (ref: src/models/wav2vec2.py:112-117)."""
+        """The reference only inspects the substrings "base" / "large" for the WIDTH (ref: src/models/wav2vec2.py:112-117)
+        and lets ``from_pretrained`` bring the rest of the architecture.  Offline there is no config.json to read, so the
+        norm placement comes from the id: ids this table cannot classify RAISE instead of silently getting the post-LN
+        geometry (pass an explicit W2V2Config for them)."""
+        name = hf_id.rsplit("/", 1)[-1].lower()
+        stable = any(m in name for m in W2V2Config._STABLE_MARKS)
         if "base" in hf_id:
+            if stable:
+                raise ValueError(f"{hf_id}: a base-width checkpoint of a pre-LN family is not in the table; pass a W2V2Config")
             return W2V2Config()
         if "large" in hf_id:
-            return W2V2Config(hidden_size=1024, num_hidden_layers=24, num_attention_heads=16,
-                              intermediate_size=4096)
+            large = dict(hidden_size=1024, num_hidden_layers=24, num_attention_heads=16, intermediate_size=4096)
+            if stable:
+                return W2V2Config(do_stable_layer_norm=True, feat_extract_norm="layer", conv_bias=True, **large)
+            if name in W2V2Config._POST_LN_LARGE:
+                return W2V2Config(**large)
+            raise ValueError(f"{hf_id}: cannot tell whether this 'large' checkpoint is post-LN (wav2vec2-large, -large-960h) or "
+                             "pre-LN (-lv60, xlsr, robust, voxpopuli); pass a W2V2Config with do_stable_layer_norm / "
+                             "feat_extract_norm / conv_bias set")
         raise ValueError("cannot determine num features")
 
     @staticmethod

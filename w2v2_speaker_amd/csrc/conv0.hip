@@ -445,6 +445,83 @@ __global__ void pack_conv_kernel(const float* __restrict__ w, T* __restrict__ ou
   }
 }
 
+// ------------------------------------------------------------------------------------------ layer-norm family, layer 0
+// feat_extract_norm = "layer" (HF:275-299, the "-lv60" / xlsr checkpoints): y[b, l, :] = GELU(LN_c(conv0(x)[b, l, :] + bias)).
+// The normalisation runs over the CHANNELS of one frame, so a wave owns whole frames: lane i holds channels 8 i .. 8 i + 7
+// (their k taps stay in registers: 8 k floats), the frame's k samples are wave-uniform loads, the two LayerNorm reductions
+// are wave reductions, the output is one 16-byte store per lane.  Exact f32 arithmetic up to the output rounding; HBM-bound
+// on the [B, L, C] write like the group-norm apply pass.  Forward only (this family's feature extractor runs frozen).
+template <typename T, int KMAX>
+__global__ __launch_bounds__(256) void conv0_ln_gelu_kernel(const float* __restrict__ wav, const float* __restrict__ w,
+                                                            const float* __restrict__ bias, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, T* __restrict__ out, int B, int N,
+                                                            int L, int C, int k, int stride, float eps, int frames_per_wave) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nch = C >> 3;
+  const bool on = lane < nch;
+  float wr[8][KMAX], bs[8], ga[8], be[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int c = lane * 8 + e;
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j) wr[e][j] = (on && j < k) ? w[(int64_t)c * k + j] : 0.f;
+    bs[e] = (on && bias != nullptr) ? bias[c] : 0.f;
+    ga[e] = on ? gamma[c] : 0.f;
+    be[e] = on ? beta[c] : 0.f;
+  }
+  const int64_t total = (int64_t)B * L;
+  const int64_t f0 = ((int64_t)blockIdx.x * 4 + wave) * frames_per_wave;
+  for (int64_t f = f0; f < f0 + frames_per_wave && f < total; ++f) {
+    const int b = (int)(f / L), l = (int)(f - (int64_t)b * L);
+    const float* xp = wav + (int64_t)b * N + (int64_t)l * stride;
+    float y[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) y[e] = bs[e];
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j) {
+      if (j < k) {
+        const float xv = xp[j];                       // wave-uniform address
+#pragma unroll
+        for (int e = 0; e < 8; ++e) y[e] = fmaf(wr[e][j], xv, y[e]);
+      }
+    }
+    float sum = 0.f;
+    if (on) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) sum += y[e];
+    }
+    const float mean = wave_sum(sum) / (float)C;
+    float sq = 0.f;
+    if (on) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float d = y[e] - mean; sq += d * d; }
+    }
+    const float rstd = rsqrtf(wave_sum(sq) / (float)C + eps);
+    if (on) {
+      Vec8<T> o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o.v[e] = gelu_f((y[e] - mean) * rstd * ga[e] + be[e]);
+      o.store(out + f * C + lane * 8);
+    }
+  }
+}
+
+extern "C" int w2v2_conv0_layernorm_gelu(const float* wav, const float* w, const float* bias, const float* gamma,
+                                         const float* beta, void* out, int B, int N, int C, int k, int stride, float eps,
+                                         int dtype, void* stream) {
+  W2V2_REQUIRE(wav && w && gamma && beta && out && B > 0 && k > 0 && stride > 0 && N >= k, "conv0_layernorm_gelu: bad arguments");
+  W2V2_REQUIRE(C % 8 == 0 && C <= 512 && k <= 16, "conv0_layernorm_gelu: C=%d (multiple of 8, <= 512), k=%d (<= 16)", C, k);
+  const int L = (N - k) / stride + 1;
+  const int64_t total = (int64_t)B * L;
+  const int fpw = 8;                                   // frames per wave: amortises the 8 k weight registers' load
+  dim3 grid((unsigned)cdiv(total, (int64_t)4 * fpw));
+  W2V2_DISPATCH_ACT(dtype, "conv0_layernorm_gelu",
+    hipLaunchKernelGGL((conv0_ln_gelu_kernel<AT, 16>), grid, dim3(256), 0, as_stream(stream), wav, w, bias, gamma, beta, (AT*)out,
+                       B, N, L, C, k, stride, eps, fpw););
+  W2V2_CHECK_LAUNCH("conv0_layernorm_gelu");
+  return 0;
+}
+
 extern "C" int w2v2_pack_conv_weight(const float* w, void* out, int dtype, int Cout, int Cin, int k, void* stream) {
   W2V2_REQUIRE(w && out && Cout > 0 && Cin > 0 && k > 0, "pack_conv_weight: bad arguments");
   const int64_t total = (int64_t)Cout * Cin * k;

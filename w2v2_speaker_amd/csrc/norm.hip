@@ -13,7 +13,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, T*
                                                      const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, T* __restrict__ y,
                                                      float* __restrict__ mean_o, float* __restrict__ rstd_o,
-                                                     int M, int H, float eps, float p, uint64_t seed, int rounded_sum) {
+                                                     int M, int H, float eps, float p, uint64_t seed, int rounded_sum,
+                                                     int gelu_out) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int row = blockIdx.x * 4 + wave;
   if (row >= M) return;
@@ -64,7 +65,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, T*
       for (int e = 0; e < 8; ++e) { const float d = s[ci][e] - mean; sq += d * d; }
   const float var = wave_sum(sq) / (float)H;
   const float rstd = rsqrtf(var + eps);
-  if (lane == 0) { mean_o[row] = mean; rstd_o[row] = rstd; }
+  if (lane == 0 && mean_o != nullptr) { mean_o[row] = mean; rstd_o[row] = rstd; }
 #pragma unroll
   for (int ci = 0; ci < LN_MAXC; ++ci) {
     const int ch = lane + 64 * ci;
@@ -75,6 +76,10 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, T*
       Vec8<T> o;
 #pragma unroll
       for (int e = 0; e < 8; ++e) o.v[e] = (s[ci][e] - mean) * rstd * g.v[e] + b.v[e];
+      if (gelu_out) {                 // the layer-norm convolution layers (HF:275-299): conv -> LayerNorm -> GELU
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o.v[e] = gelu_f(o.v[e]);
+      }
       o.store(y + (int64_t)row * H + ch * 8);
     }
   }
@@ -506,8 +511,21 @@ extern "C" int w2v2_layernorm_fwd(const void* x, void* r, const float* gamma, co
   dim3 grid((unsigned)cdiv(M, 4));
   W2V2_DISPATCH_ACT(dtype, "layernorm_fwd",
     hipLaunchKernelGGL(ln_fwd_kernel<AT>, grid, dim3(256), 0, as_stream(stream), (const AT*)x,
-                       (AT*)r, gamma, beta, (AT*)y, mean, rstd, M, H, eps, drop_p, seed, (int)rounded_sum););
+                       (AT*)r, gamma, beta, (AT*)y, mean, rstd, M, H, eps, drop_p, seed, (int)rounded_sum, 0););
   W2V2_CHECK_LAUNCH("layernorm_fwd");
+  return 0;
+}
+
+extern "C" int w2v2_layernorm_gelu_fwd(const void* x, const float* gamma, const float* beta, void* y, int M, int H, float eps,
+                                       int dtype, void* stream) {
+  W2V2_REQUIRE(x && gamma && beta && y, "layernorm_gelu_fwd: null pointer");
+  W2V2_REQUIRE(H % 8 == 0 && H <= 8 * 64 * LN_MAXC, "layernorm_gelu_fwd: H=%d unsupported (need H%%8==0, H<=1024)", H);
+  if (M <= 0) return 0;
+  dim3 grid((unsigned)cdiv(M, 4));
+  W2V2_DISPATCH_ACT(dtype, "layernorm_gelu_fwd",
+    hipLaunchKernelGGL(ln_fwd_kernel<AT>, grid, dim3(256), 0, as_stream(stream), (const AT*)x, (AT*)nullptr, gamma, beta,
+                       (AT*)y, (float*)nullptr, (float*)nullptr, M, H, eps, 0.f, (uint64_t)0, 0, 1););
+  W2V2_CHECK_LAUNCH("layernorm_gelu_fwd");
   return 0;
 }
 

@@ -138,6 +138,18 @@ class Plan:
         if fused_attention is None:
             fused_attention = ops.is16(self.adt) and d == 64        # any T (tiled kernels beyond 160 frames)
         self.fused = fused_attention
+        # checkpoint families (config.W2V2Config): pre-LN encoder ("stable layer norm", HF:611-654,729-802) and LayerNorm
+        # convolutions with bias (HF:275-299) -- the "-lv60" / xlsr models the reference can be pointed at by id
+        self.stable = bool(cfg.do_stable_layer_norm)
+        self.ln_conv = cfg.feat_extract_norm == "layer"
+        if cfg.feat_extract_norm not in ("group", "layer"):
+            raise ValueError(f"feat_extract_norm must be 'group' or 'layer', got {cfg.feat_extract_norm!r}")
+        if (self.ln_conv or cfg.conv_bias) and train and not store.freeze_cnn:
+            raise NotImplementedError("the layer-norm / biased convolution stack has a forward path only: train it with the "
+                                      "feature extractor frozen (completely_freeze_feature_extractor: true, the reference's default)")
+        if self.stable and (insert_cls_token or paired or keep_hidden_states):
+            raise NotImplementedError("do_stable_layer_norm: the CLS-token, paired-input and hidden-state-ensemble paths are "
+                                      "built for the post-LN encoder only")
         self.embed_dim = H * (2 if pooling == "attentive" else ops.POOL_WIDTH.get(self.pool_mode, 1))
         self._pack_version = -1
         self._cnn_version = -1
@@ -257,6 +269,7 @@ class Plan:
                            for _ in range(2)]
             self.DC = self._e(M, H)
             self.P1 = self._e(M, H)
+            self.GR = self._e(M, H) if self.stable else None        # pre-LN: gradient of the un-normalised residual stream
             self.dyg = self._e(B, G, self.Tp, self.Cg)
             self.dwf = self._e(G, K * self.Cg, self.Cg, dtype=f32)
             self.pos_dot = ops.weightnorm_scratch(H, G, K, self.dev)
@@ -276,9 +289,11 @@ class Plan:
         self.g_conv = []
         for i in range(1, len(C)):
             k, s, ci, co = cfg.conv_kernel[i], cfg.conv_stride[i], cins[i], C[i]
+            cbias = st.mp(f"feature_extractor.conv_layers.{i}.conv.bias") if cfg.conv_bias else self.zero_bias
+            # layer-norm family: the product only adds the bias; LayerNorm + GELU follow in place (forward())
             self.g_conv.append(Gemm(self.Bc * self.lens[i], co, k * ci, self.conv[i - 1], self.convw[i], self.conv[i],
                                     lda=s * ci, ldb=k * ci, ldc=co, a_seg=(self.lens[i], self.lens[i - 1] * ci),
-                                    epilogue=EPI_BIAS_GELU, bias=self.zero_bias,
+                                    epilogue=EPI_BIAS if self.ln_conv else EPI_BIAS_GELU, bias=cbias,
                                     aux=self.conv_pre[i] if self.cnn_train else None, ldaux=co))
         if self.cnn_train:
             # conv layer i backward: dW (packed layout, f32 scratch) and the im2col-space data gradient
@@ -368,8 +383,11 @@ class Plan:
                                 epilogue=EPI_MUL, aux=lb.hpre, ldaux=I)
                 gl["dW1"] = Gemm(I, H, M, gs["DH"], lb.x1, mg(pre + "feed_forward.intermediate_dense.weight"), lda=I,
                                  ldb=H, ldc=H, transA=True, transB=True, split_k=sk(I, H), accumulate=True)
+                # post-LN: G = DH @ W1 + G (the residual path rides in G); pre-LN: G = DH @ W1 alone (the residual
+                # gradient lives in self.GR, _backward_encoder_stable)
                 gl["dx1"] = Gemm(M, H, I, gs["DH"], W1, self.G, lda=I, ldb=H if tb else I, ldc=H, transB=tb,
-                                 epilogue=EPI_ADD, aux=self.G, ldaux=H)
+                                 epilogue=EPI_NONE if self.stable else EPI_ADD, aux=None if self.stable else self.G,
+                                 ldaux=0 if self.stable else H)
                 gl["dWo"] = Gemm(H, H, M, gs["Gd1"], lb.ctx, mg(pre + "attention.out_proj.weight"), lda=H, ldb=H, ldc=H,
                                  transA=True, transB=True, split_k=sk(H, H), accumulate=True)
                 gl["dctx"] = Gemm(M, H, H, gs["Gd1"], Wo, self.DC, lda=H, ldb=H, ldc=H, transB=tb)
@@ -392,7 +410,8 @@ class Plan:
                 gl["dWqkv"] = Gemm(3 * H, H, M, gs["DQKV"], xin, st.qkv(l, "g"), lda=3 * H, ldb=H, ldc=H, transA=True,
                                    transB=True, split_k=sk(3 * H, H), accumulate=True)
                 gl["dx"] = Gemm(M, H, 3 * H, gs["DQKV"], Wqkv, self.G, lda=3 * H, ldb=H if tb else 3 * H, ldc=H,
-                                transB=tb, epilogue=EPI_ADD, aux=self.G, ldaux=H)
+                                transB=tb, epilogue=EPI_NONE if self.stable else EPI_ADD,
+                                aux=None if self.stable else self.G, ldaux=0 if self.stable else H)
             self.g_layer.append(gl)
         # weight gradients of two consecutive layers (l, l-1; l counted down from the top) in one launch
         self.g_wgrad_pair = {}
@@ -467,12 +486,7 @@ class Plan:
         tr = self.train
         self._step, self._skip, self._mask, self._fmask = step, tuple(skip_layers), None, None
         mp = st.mp
-        ops.conv0_groupnorm_gelu(wav, mp("feature_extractor.conv_layers.0.conv.weight"),
-                                 mp("feature_extractor.conv_layers.0.layer_norm.weight"),
-                                 mp("feature_extractor.conv_layers.0.layer_norm.bias"), self.conv[0], self.stats0,
-                                 cfg.conv_kernel[0], cfg.conv_stride[0])
-        for g in self.g_conv:
-            g()
+        self._cnn_forward(wav)
         ops.layernorm_fwd(self.conv[-1].view(self.M0, -1), None, mp("feature_projection.layer_norm.weight"),
                           mp("feature_projection.layer_norm.bias"), self.ln_feat, self.mean_f, self.rstd_f,
                           cfg.layer_norm_eps)
@@ -504,6 +518,8 @@ class Plan:
                                self.Cg, K, H, 0)
         else:
             self.g_pos()
+        if self.stable:
+            return self._forward_encoder_stable(step)
         x = self.X[0]
         ops.layernorm_fwd(self.hx, self.pos, mp("encoder.layer_norm.weight"), mp("encoder.layer_norm.bias"), x,
                           self.mean0, self.rstd0, cfg.layer_norm_eps)
@@ -544,6 +560,67 @@ class Plan:
         self.out = (self.X[cfg.num_hidden_layers] if self.all_x else self.X[cfg.num_hidden_layers % 2]).view(B, T, H)
         return self.out
 
+    def _ln_params_for_input_of(self, l: int):
+        """Pre-LN encoder: the LayerNorm that produces X[l], the normalised input of block l (its ``layer_norm``), or -- for
+        l = number of blocks -- the encoder's final ``layer_norm`` (HF:791)."""
+        n = f"encoder.layers.{l}.layer_norm" if l < self.cfg.num_hidden_layers else "encoder.layer_norm"
+        return n + ".weight", n + ".bias"
+
+    def _forward_encoder_stable(self, step: int) -> torch.Tensor:
+        """Pre-LN encoder (do_stable_layer_norm, HF:611-654,729-802) on the SAME buffers, GEMM descriptors and fused
+        residual + dropout + LayerNorm kernel as the post-LN one, re-wired:
+            x_0 = drop(hx + pos)                                   X[0] = LN1_0(x_0)
+            block l:  a = out_proj(attn(qkv(X[l])))                s1 = x_l + drop(a)     -> lb.a,   lb.x1 = LN2_l(s1)
+                      f = ffn2(gelu(ffn1(lb.x1)))                  x_{l+1} = s1 + drop(f) -> lb.f,   X[l+1] = LN1_{l+1}(x_{l+1})
+            (the last X is the encoder's final LayerNorm).  The un-normalised residual stream x_l lives in the tensor the
+            fused kernel writes its pre-norm sum into; a LayerDrop-skipped block passes it on and only re-normalises it for
+            the next block (self._res_src[l] remembers which tensor that was, for the backward)."""
+        cfg, st, reg, tr = self.cfg, self.store, self.reg, self.train
+        B, T, H = self.B, self.T, cfg.hidden_size
+        mp, eps = st.mp, cfg.layer_norm_eps
+        heads, d = cfg.num_attention_heads, cfg.head_dim
+        pa = reg.attention_dropout if tr else 0.0
+        ph = reg.hidden_dropout if tr else 0.0
+        ops.add(self.hx, self.pos, self.pos)                      # x_0 (before dropout) replaces the positional embedding
+        if ph > 0:
+            ops.dropout_(self.pos, ph, self._sd("prologue", 0, step))
+        res = self.pos
+        w0, b0 = self._ln_params_for_input_of(0)
+        ops.layernorm_fwd(res, None, mp(w0), mp(b0), self.X[0], self.mean0, self.rstd0, eps)
+        self._res_src = {}
+        L = cfg.num_hidden_layers
+        for l in range(L):
+            xin = self.X[l] if self.all_x else self.X[l % 2]
+            xout = self.X[l + 1] if self.all_x else self.X[(l + 1) % 2]
+            lb, gl = self.lb[l if tr else 0], self.g_layer[l]
+            wn, bn = self._ln_params_for_input_of(l + 1)
+            pre = f"encoder.layers.{l}."
+            if l in self._skip:                 # LayerDrop: x_{l+1} = x_l, re-normalised for the next block
+                ops.layernorm_fwd(res, None, mp(wn), mp(bn), xout, lb.mean2, lb.rstd2, eps)
+                self._res_src[l] = res
+                continue
+            gl["qkv"]()
+            if self.fused:
+                ops.attention_fwd(lb.qkv, lb.ctx, lb.lse, B, T, heads, d, d ** -0.5, pa, self._sd("attn", l, step))
+            else:
+                gl["scores"]()
+                ops.softmax_fwd(self.S, lb.p, lb.pd if pa > 0 else None, B * heads * T, T, self.Tl, pa,
+                                self._sd("attn", l, step))
+                gl["ctx"]()
+            gl["out"]()
+            ops.layernorm_fwd(res, lb.a, mp(pre + "final_layer_norm.weight"), mp(pre + "final_layer_norm.bias"), lb.x1,
+                              lb.mean1, lb.rstd1, eps, ph, self._sd("post_attn", l, step))          # lb.a <- s1
+            gl["ffn1"]()
+            if tr and reg.activation_dropout > 0:
+                ops.dropout_(lb.h, reg.activation_dropout, self._sd("act", l, step))
+                ops.dropout_(lb.hpre, reg.activation_dropout, self._sd("act", l, step))
+            gl["ffn2"]()
+            ops.layernorm_fwd(lb.a, lb.f, mp(wn), mp(bn), xout, lb.mean2, lb.rstd2, eps, ph,
+                              self._sd("ffn", l, step))                                              # lb.f <- x_{l+1}
+            res = lb.f
+        self.out = (self.X[L] if self.all_x else self.X[L % 2]).view(B, T, H)
+        return self.out
+
     def conv_features(self, wav: torch.Tensor) -> torch.Tensor:
         """The conv feature extractor alone (HF:382-419; ref: src/models/wav2vec2.py:163-169,
         ``Wav2vecLiteWrapperModule.forward``): wav [B,N] f32 -> [B, L, 512] (act dtype, channels-last; the reference
@@ -555,14 +632,30 @@ class Plan:
         assert wav.shape == (self.Bc, self.N) and wav.dtype == torch.float32 and wav.is_cuda
         self._refresh_packs()
         self._wav = wav
-        mp = st.mp
-        ops.conv0_groupnorm_gelu(wav, mp("feature_extractor.conv_layers.0.conv.weight"),
-                                 mp("feature_extractor.conv_layers.0.layer_norm.weight"),
-                                 mp("feature_extractor.conv_layers.0.layer_norm.bias"), self.conv[0], self.stats0,
-                                 cfg.conv_kernel[0], cfg.conv_stride[0])
-        for g in self.g_conv:
-            g()
+        self._cnn_forward(wav)
         return self.conv[-1]
+
+    def _cnn_forward(self, wav: torch.Tensor) -> None:
+        """The seven convolution layers (HF:382-419) into self.conv[i] ([Bc, L_i, C_i], channels-last).  Group-norm family
+        (wav2vec2-base / -large): layer 0 = conv + GroupNorm + GELU in one kernel pair, layers 1-6 = implicit GEMM with
+        a bias + GELU epilogue (HF:254-272,302-323; a layer-0 conv bias would be cancelled by the GroupNorm's mean over time
+        and is not read).  Layer-norm family ("-lv60" / xlsr, HF:275-299): every layer is conv (+ bias) -> LayerNorm over
+        the channels -> GELU; layer 0 in one kernel, layers 1-6 as GEMM (bias epilogue) + an in-place LayerNorm-GELU pass."""
+        cfg, mp = self.cfg, self.store.mp
+        fe = "feature_extractor.conv_layers."
+        if not self.ln_conv:
+            ops.conv0_groupnorm_gelu(wav, mp(fe + "0.conv.weight"), mp(fe + "0.layer_norm.weight"), mp(fe + "0.layer_norm.bias"),
+                                     self.conv[0], self.stats0, cfg.conv_kernel[0], cfg.conv_stride[0])
+            for g in self.g_conv:
+                g()
+            return
+        ops.conv0_layernorm_gelu(wav, mp(fe + "0.conv.weight"), mp(fe + "0.conv.bias") if cfg.conv_bias else None,
+                                 mp(fe + "0.layer_norm.weight"), mp(fe + "0.layer_norm.bias"), self.conv[0],
+                                 cfg.conv_kernel[0], cfg.conv_stride[0])
+        for i, g in enumerate(self.g_conv, start=1):
+            g()
+            y = self.conv[i].view(-1, cfg.conv_dim[i])
+            ops.layernorm_gelu_fwd(y, mp(fe + f"{i}.layer_norm.weight"), mp(fe + f"{i}.layer_norm.bias"), y, 1e-5)
 
     def conv_backward(self, dfeat: torch.Tensor) -> None:
         """Backward of conv_features(): dfeat [B, L, 512] = d(loss)/d(features); the gradients of the seven conv layers
@@ -686,7 +779,10 @@ class Plan:
         if getattr(self, "_lnfold", None) is None:
             self._lnfold = ops.LnFoldGroup(H, self.dev)
         lnfold = self._lnfold if not os.environ.get("W2V2_NO_LN_FOLD") else None
-        for ev in encoder_backward_schedule(cfg.num_hidden_layers, self._skip, self.g_wgrad_pair, self.grouped):
+        if self.stable:
+            self._backward_encoder_stable(notify)               # leaves d(loss)/d(hx + pos) in self.G
+        for ev in (() if self.stable else
+                   encoder_backward_schedule(cfg.num_hidden_layers, self._skip, self.g_wgrad_pair, self.grouped)):
             kind = ev[0]
             if kind == "body":
                 self._layer_backward_body(ev[1], lnfold)
@@ -702,10 +798,11 @@ class Plan:
                 notify(f"layer{ev[1]}")
         # encoder prologue: x0 = drop(LN(hx + pos)), pos = GELU(posconv(hx) + b)
         ph = reg.hidden_dropout
-        if ph > 0:
-            ops.dropout_(self.G, ph, self._sd("prologue", 0, step))
-        ops.layernorm_bwd(self.G, self.pos, self.mean0, self.rstd0, mp("encoder.layer_norm.weight"), self.G, None,
-                          mg("encoder.layer_norm.weight"), mg("encoder.layer_norm.bias"))
+        if not self.stable:
+            if ph > 0:
+                ops.dropout_(self.G, ph, self._sd("prologue", 0, step))
+            ops.layernorm_bwd(self.G, self.pos, self.mean0, self.rstd0, mp("encoder.layer_norm.weight"), self.G, None,
+                              mg("encoder.layer_norm.weight"), mg("encoder.layer_norm.bias"))
         if H % 8 == 0:
             ops.gelu_bwd_colsum(self.G, self.pos_pre, self.P1, mg("encoder.pos_conv_embed.conv.bias"), M, H)
         else:
@@ -759,6 +856,82 @@ class Plan:
             if not st.cnn_runtime_frozen:         # feature_extractor.requires_grad_(False) at run time: zero gradient
                 self._backward_cnn()
             notify("cnn")
+
+    def _backward_encoder_stable(self, notify) -> None:
+        """Backward of _forward_encoder_stable.  Two running gradients: self.G = d(loss)/dX[l+1] (the NORMALISED input of
+        the block above: what its QKV data-gradient product wrote) and self.GR = d(loss)/dx_{l+1} (the un-normalised
+        residual stream, accumulated over every block above).  Per block, top down:
+            GR += LN_bwd(G)  [the LayerNorm that fed X[l+1]]      df = drop(GR)  -> FFN backward -> G = d(LN2_l output)
+            GR += LN_bwd(G)  [final_layer_norm of block l]         da = drop(GR)  -> attention backward -> G = dX[l]
+        A LayerDrop-skipped block only passes its re-normalisation back.  One weight-gradient launch per block (the
+        grouped kernel in the 16-bit modes), LayerNorm gamma / beta folded at once; the gradient of a block's FIRST
+        LayerNorm is produced by the block BELOW it (or the prologue), so the layer buckets are notified at the end."""
+        cfg, st, reg = self.cfg, self.store, self.reg
+        B, T, M, H = self.B, self.T, self.M, cfg.hidden_size
+        mp, mg = st.mp, st.mg
+        step = self._step
+        heads, d = cfg.num_attention_heads, cfg.head_dim
+        pa, ph = reg.attention_dropout, reg.hidden_dropout
+        L = cfg.num_hidden_layers
+        G, GR = self.G, self.GR
+        GR.zero_()
+        for l in reversed(range(L)):
+            lb, gl = self.lb[l], self.g_layer[l]
+            wn, bn = self._ln_params_for_input_of(l + 1)
+            if l in self._skip:
+                ops.layernorm_bwd(G, self._res_src[l], lb.mean2, lb.rstd2, mp(wn), G, None, mg(wn), mg(bn))
+                ops.add(GR, G, GR)
+                G.zero_()                       # X[l] fed a skipped block: nothing flows into it
+                continue
+            gs = self._gsets[l % 2]
+            pre = f"encoder.layers.{l}."
+            grouped = self.grouped
+            ops.layernorm_bwd(G, lb.f, lb.mean2, lb.rstd2, mp(wn), G, None, mg(wn), mg(bn))
+            ops.add(GR, G, GR)                                  # GR = d x_{l+1}
+            gs["Gd"].copy_(GR)
+            if ph > 0:
+                ops.dropout_(gs["Gd"], ph, self._sd("ffn", l, step))
+            if not grouped:
+                gl["dW2"]()
+                ops.colsum(gs["Gd"], mg(pre + "feed_forward.output_dense.bias"), M, H)
+            gl["dh"]()
+            if not grouped:
+                gl["dW1"]()
+                ops.colsum(gs["DH"], mg(pre + "feed_forward.intermediate_dense.bias"), M, cfg.intermediate_size)
+            gl["dx1"]()                                         # G = DH @ W1 = d(LN2_l output)
+            ops.layernorm_bwd(G, lb.a, lb.mean1, lb.rstd1, mp(pre + "final_layer_norm.weight"), G, None,
+                              mg(pre + "final_layer_norm.weight"), mg(pre + "final_layer_norm.bias"))
+            ops.add(GR, G, GR)                                  # GR = d s1 = d x_l (residual part)
+            gs["Gd1"].copy_(GR)
+            if ph > 0:
+                ops.dropout_(gs["Gd1"], ph, self._sd("post_attn", l, step))
+            if not grouped:
+                gl["dWo"]()
+                ops.colsum(gs["Gd1"], mg(pre + "attention.out_proj.bias"), M, H)
+            gl["dctx"]()
+            if self.fused:
+                ops.attention_bwd(lb.qkv, lb.ctx, self.DC, lb.lse, gs["DQKV"], self.delta, B, T, heads, d, d ** -0.5,
+                                  pa, self._sd("attn", l, step))
+            else:
+                gl["dP"]()
+                ops.softmax_bwd(self.S, lb.p, self.dS, B * heads * T, T, self.Tl, pa, self._sd("attn", l, step))
+                gl["dq"]()
+                gl["dk"]()
+                gl["dv"]()
+            if grouped:
+                gl["wgrad"]()
+            else:
+                gl["dWqkv"]()
+                ops.colsum(gs["DQKV"], st.qkv(l, "g", "bias"), M, 3 * H)
+            gl["dx"]()                                          # G = DQKV @ Wqkv = dX[l]
+        w0, b0 = self._ln_params_for_input_of(0)
+        ops.layernorm_bwd(G, self.pos, self.mean0, self.rstd0, mp(w0), G, None, mg(w0), mg(b0))
+        ops.add(GR, G, GR)                                      # d x_0
+        if ph > 0:
+            ops.dropout_(GR, ph, self._sd("prologue", 0, step))
+        G.copy_(GR)                                             # = d(hx + pos): the shared prologue backward continues
+        for l in reversed(range(L)):
+            notify(f"layer{l}")
 
     def _layer_backward_body(self, l: int, lnfold) -> None:
         """("body", l) of encoder_backward_schedule: the data-gradient chain of one transformer block."""

@@ -253,6 +253,15 @@ def conv0_groupnorm_gelu(wav: torch.Tensor, w: torch.Tensor, gamma: torch.Tensor
                                   out.data_ptr(), dt(out), B, N, Cc, k, stride, stream()), "conv0_apply")
 
 
+def conv0_layernorm_gelu(wav, w, bias, gamma, beta, out, k: int, stride: int, eps: float = 1e-5) -> None:
+    """Layer 0 of the feat_extract_norm="layer" family: out [B, L, C] = GELU(LN_C(conv0(wav) + bias)) (HF:275-299)."""
+    _dev(wav, w, bias, gamma, beta, out)
+    B, N = wav.shape
+    _lib.check(lib().w2v2_conv0_layernorm_gelu(wav.data_ptr(), w.data_ptr(), _p(bias), gamma.data_ptr(), beta.data_ptr(),
+                                               out.data_ptr(), B, N, out.shape[-1], k, stride, eps, dt(out), stream()),
+               "conv0_layernorm_gelu")
+
+
 def conv0_bwd(wav, w, work, gamma, beta, dz, sums, dw, dgamma, dbeta, k: int, stride: int) -> None:
     """Backward of layer 0 (see w2v2_conv0_bwd); `work` is the forward's conv0 workspace (holds mean/rstd)."""
     _dev(wav, w, work, gamma, beta, dz, sums, dw, dgamma, dbeta)
@@ -290,6 +299,14 @@ def layernorm_fwd(x, r, gamma, beta, y, mean, rstd, eps: float, drop_p: float = 
     _lib.check(lib().w2v2_layernorm_fwd(x.data_ptr(), _p(r), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(),
                                         mean.data_ptr(), rstd.data_ptr(), M, H, eps, drop_p, seed, dt(x), stream()),
                "layernorm_fwd")
+
+
+def layernorm_gelu_fwd(x, gamma, beta, y, eps: float) -> None:
+    """y = GELU(LN(x)): the convolution layers of the feat_extract_norm="layer" family (HF:275-299)."""
+    _dev(x, gamma, beta, y)
+    H = x.shape[-1]
+    _lib.check(lib().w2v2_layernorm_gelu_fwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), x.numel() // H, H,
+                                             eps, dt(x), stream()), "layernorm_gelu_fwd")
 
 
 _LN_WS = {}

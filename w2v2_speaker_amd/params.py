@@ -58,10 +58,17 @@ def hf_param_shapes(cfg: W2V2Config) -> "OrderedDict[str, Tuple[int, ...]]":
     shp["feature_projection.layer_norm.weight"] = (C,)
     shp["feature_projection.layer_norm.bias"] = (C,)
     cins = (1,) + tuple(cfg.conv_dim[:-1])
+    layer_norm_convs = cfg.feat_extract_norm == "layer"       # HF:275-299: a LayerNorm after every convolution
     for i in reversed(range(len(cfg.conv_dim))):
         shp[f"feature_extractor.conv_layers.{i}.conv.weight"] = (cfg.conv_dim[i], cins[i], cfg.conv_kernel[i])
-    shp["feature_extractor.conv_layers.0.layer_norm.weight"] = (cfg.conv_dim[0],)
-    shp["feature_extractor.conv_layers.0.layer_norm.bias"] = (cfg.conv_dim[0],)
+        if cfg.conv_bias:
+            shp[f"feature_extractor.conv_layers.{i}.conv.bias"] = (cfg.conv_dim[i],)
+        if layer_norm_convs:
+            shp[f"feature_extractor.conv_layers.{i}.layer_norm.weight"] = (cfg.conv_dim[i],)
+            shp[f"feature_extractor.conv_layers.{i}.layer_norm.bias"] = (cfg.conv_dim[i],)
+    if not layer_norm_convs:                                  # group norm: layer 0 only (HF:302-323)
+        shp["feature_extractor.conv_layers.0.layer_norm.weight"] = (cfg.conv_dim[0],)
+        shp["feature_extractor.conv_layers.0.layer_norm.bias"] = (cfg.conv_dim[0],)
     return shp
 
 
@@ -349,8 +356,10 @@ class ParamStore:
         hf = ["masked_spec_embed"]
         for i in range(len(cfg.conv_dim)):
             hf.append(f"feature_extractor.conv_layers.{i}.conv.weight")
-            if i == 0:
-                hf += [f"feature_extractor.conv_layers.0.layer_norm.{w}" for w in ("weight", "bias")]
+            if cfg.conv_bias:
+                hf.append(f"feature_extractor.conv_layers.{i}.conv.bias")
+            if i == 0 or cfg.feat_extract_norm == "layer":
+                hf += [f"feature_extractor.conv_layers.{i}.layer_norm.{w}" for w in ("weight", "bias")]
         hf += [f"feature_projection.{m}.{w}" for m in ("layer_norm", "projection") for w in ("weight", "bias")]
         hf += ["encoder.pos_conv_embed.conv.bias", "encoder.pos_conv_embed.conv.parametrizations.weight.original0",
                "encoder.pos_conv_embed.conv.parametrizations.weight.original1",
