@@ -120,6 +120,91 @@ def cpu_baseline(batch=8, n_samples=48000, num_speakers=1211):
                       f"{ncpu} host threads = the fastest of the sweep {sorted(sweep)} ({dt:.2f} s/step)"}
 
 
+def tail_families(trainer, plan, store, wav, label, steps=4):
+    """the NON-GEMM tail of the step against its own rooflines, on the driver line.  After the timed
+    region, `steps` more training steps run with HIP events around every launch of the tail's families (LayerNorm forward /
+    backward, the three attention kernels, Adam, the layer-0 convolution): per family the launches per step, the mean
+    duration, the ALGORITHMIC bytes per launch (operands read once, results written once) and achieved / 8 TB/s.  The
+    attention kernels are VALU-bound, not HBM-bound: their entry also carries the matrix TFLOP/s (fwd 4 T^2 d, bwd 10 T^2 d per
+    head) and the share of computed scores that are real (padding of T to the 16-row / 16-key blocks the geometry walks).
+    The events sit between launches of one stream: a bracket also holds the event records themselves, so the median of 32
+    EMPTY brackets is measured in the same pass and subtracted (both figures are on the line)."""
+    import w2v2_speaker_amd.ops as O_
+    rec, orig = [], {}
+
+    def wrap(name, family, nbytes, extra=None):
+        fn = getattr(O_, name)
+        orig[name] = fn
+
+        def timed(*a, **kw):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = fn(*a, **kw)
+            e1.record()
+            rec.append((family, e0, e1, float(nbytes(*a, **kw)), extra(*a, **kw) if extra else None))
+            return out
+        setattr(O_, name, timed)
+
+    esz = lambda t: t.element_size()
+    wrap("layernorm_fwd", "layernorm_fwd", lambda x, r, g, b, y, *a, **k: x.numel() * esz(x) * (4 if r is not None else 2))
+    wrap("layernorm_bwd", "layernorm_bwd", lambda dy, s_, m, rs, g, ds, d_r, *a, **k: dy.numel() * esz(dy) * (4 if d_r is not None else 3))
+    wrap("attention_fwd", "attention_fwd", lambda qkv, ctx, lse, *a, **k: qkv.numel() * esz(qkv) + ctx.numel() * esz(ctx) + lse.numel() * 4,
+         lambda qkv, ctx, lse, B, T, heads, d, *a, **k: (4.0 * B * heads * T * T * d, T))
+    wrap("attention_bwd", "attention_bwd", lambda qkv, ctx, dctx, lse, dqkv, delta, *a, **k: (2 * qkv.numel() + 2 * ctx.numel()) * esz(qkv) * 1.0 + 3 * lse.numel() * 4,
+         lambda qkv, ctx, dctx, lse, dqkv, delta, B, T, heads, d, *a, **k: (10.0 * B * heads * T * T * d, T))
+    wrap("adam_step", "adam", lambda p_, g_, m, v, pb, n, *a, **k: n * (28.0 + (pb.element_size() if pb is not None else 0)))
+    wrap("conv0_groupnorm_gelu", "conv0", lambda wav_, w, ga, be, y, *a, **k: 2 * wav_.numel() * 4 + y.numel() * esz(y))
+    try:
+        for _ in range(steps):
+            trainer.train_step(wav, label)
+        torch.cuda.synchronize()
+    finally:
+        for n, fn in orig.items():
+            setattr(O_, n, fn)
+    # what a bracket costs by itself: event pairs around NOTHING, between two kernels of the same stream
+    empt = []
+    z = torch.zeros(1 << 20, device=wav.device)
+    for _ in range(32):
+        z.add_(1.0)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        e1.record()
+        empt.append((e0, e1))
+        z.add_(1.0)
+    torch.cuda.synchronize()
+    overhead = float(np.median([a.elapsed_time(b) * 1e3 for a, b in empt]))
+    fam = {}
+    for family, e0, e1, nb, extra in rec:
+        f = fam.setdefault(family, {"us": 0.0, "bytes": 0.0, "n": 0, "flops": 0.0, "T": None})
+        f["us"] += e0.elapsed_time(e1) * 1e3
+        f["bytes"] += nb
+        f["n"] += 1
+        if extra:
+            f["flops"] += extra[0]
+            f["T"] = extra[1]
+    out = []
+    for family, f in sorted(fam.items(), key=lambda kv: -kv[1]["us"]):
+        raw_avg = f["us"] / f["n"]
+        avg = max(raw_avg - overhead, 0.5)               # the kernel's share of the bracket
+        f["us"] = avg * f["n"]
+        gbs = f["bytes"] / f["n"] / (avg * 1e-6) / 1e9
+        e = {"family": family, "bound": "hbm", "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s",
+             "frac": round(gbs / 8000.0, 4), "launches_per_step": round(f["n"] / steps, 2), "avg_us": round(avg, 2),
+             "ms_per_step": round(f["us"] / steps / 1e3, 4), "algorithmic_mb_per_launch": round(f["bytes"] / f["n"] / 1e6, 2),
+             "bracket_us": round(raw_avg, 2), "empty_bracket_us": round(overhead, 2)}
+        if f["flops"]:
+            T = f["T"]
+            pad = -(-T // 32) * 32 if (-(-T // 32) * 32 < -(-T // 64) * 64 and T <= 512) else -(-T // 64) * 64
+            pad16 = -(-T // 16) * 16
+            e.update({"bound_in_practice": "valu (softmax + dropout arithmetic; profiles/r05_attention_pmc.txt)",
+                      "matrix_tflops": round(f["flops"] / f["us"] / 1e6, 1), "matrix_frac_of_2500": round(f["flops"] / f["us"] / 1e6 / 2500.0, 4),
+                      "valid_score_fraction": round(T * T / float(pad16 * pad16), 4),
+                      "rows_padded_to": pad, "note": "fully padded 16-row / 16-key blocks are skipped: computed scores = "
+                                                     f"{pad16} x {pad16} per head for T = {T}"})
+        out.append(e)
+    return out
+
+
 def eer_leg(store, dev, dtype_name):
     """The metric's second half, "eval EER" (SURVEY 8d): the fixed synthetic trial list of
     w2v2_speaker_amd/data/synthetic.py (8 speakers x 4 utterances of 3 s, all 496 pairs) embedded by THIS engine in the
@@ -188,6 +273,7 @@ def parse_args():
                          "(24 layers, H=1024; use --seconds 5 --batch 32); ecapa = configs[4] (ECAPA-TDNN on 300 x 40 "
                          "filterbank frames, HBM-roofline entry)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-families", action="store_true", help="skip the tail-family pass (4 extra steps with HIP events, after the timed region)")
     ap.add_argument("--no-eer", action="store_true", help="skip the eval-EER leg (32 synthetic utterances, after the timed region)")
     ap.add_argument("--no-also", action="store_true",
                     help="skip the short legs reported under `also` (bf16 mode + BASELINE configs[2], [3], [4])")
@@ -310,7 +396,7 @@ def run(args):
                                            layerdrop=0.0, mask_time_prob=0.0)
     plan = Plan(store, args.batch, n_samples, train=True, reg=reg, seed=7 + rank, pooling=args.pooling,
                 insert_cls_token=args.pooling == "first+cls")
-    total = args.steps + args.warmup + 1
+    total = args.steps + args.warmup + 1 + 8          # + the tail-family pass behind the timed region (tail_families)
     trainer = SpeakerTrainer(store, plan, OneCycle(max_lr=5e-5, total_steps=max(total, 10)),
                              layerdrop_seed=1234 + rank, mask_seed=7 + rank)
     wav, label = synth_batch(args.batch, n_samples, args.speakers, seed=42133724 + rank, device=dev)
@@ -484,6 +570,11 @@ def run(args):
             out["roofline"] = entry(*ranked[0])
             if len(ranked) > 1:
                 out["roofline_second_kernel"] = entry(*ranked[1])
+        if world == 1 and not args.no_families and not os.environ.get("W2V2_BENCH_NO_FAMILY_PASS"):
+            try:
+                out["roofline_families"] = tail_families(trainer, plan, store, wav, label)
+            except Exception as ex:          # a side leg must never cost the headline line
+                out["roofline_families"] = {"error": repr(ex)}
         if world == 1 and args.model == "base" and args.pooling == "mean+std" and not args.no_eer:
             out["eer"] = eer_leg(store, dev, args.dtype)
         if world == 1 and args.dtype == "f16" and args.model == "base" and not args.no_also:
