@@ -789,6 +789,43 @@ def test_fused_attention_two_geometries_agree_and_draw_the_same_mask(lp, T):
     assert rel_l2(b[4], a[4]) < tol
 
 
+@pytest.mark.parametrize("lp", LP16)
+@pytest.mark.parametrize("T", [149, 33, 160, 97])
+def test_attention_dkdv_lds_dma_tile_loads_bit_equal_to_register_staging(lp, T):
+    """Round 6: in the 32-row geometry the dK / dV kernel takes its Q / dO tiles by LDS-DMA (no staging registers: 126
+    VGPRs, four waves per SIMD instead of three).  The DMA cannot zero-fill the rows past T -- they arrive as copies of
+    the last row and are silenced through lse = +inf -- so the result must be BIT-equal to the register-staged kernel
+    (W2V2_ATTN_KV_NO_DMA=1, read per call), ragged tiles included."""
+    import os
+    o = ops()
+    B, heads, d, p, seed = 3, 2, 64, 0.1, 77
+    H = heads * d
+    qd = (rnd(B, T, 3 * H, seed=T + 1, scale=1.2)).to(lp).to(DEV)
+    dctx = rnd(B, T, H, seed=T + 2).to(lp).to(DEV)
+    ctx = torch.zeros(B, T, H, dtype=lp, device=DEV)
+    lse = torch.zeros(B * heads * T, device=DEV)
+    outs = []
+    old = {k: os.environ.get(k) for k in ("W2V2_ATTN_GEOM", "W2V2_ATTN_KV_NO_DMA")}
+    try:
+        os.environ["W2V2_ATTN_GEOM"] = "32"
+        o.attention_fwd(qd, ctx, lse, B, T, heads, d, d ** -0.5, p, seed)
+        for no_dma in (True, False):
+            os.environ.pop("W2V2_ATTN_KV_NO_DMA", None)
+            if no_dma:
+                os.environ["W2V2_ATTN_KV_NO_DMA"] = "1"
+            dqkv = torch.full((B, T, 3 * H), float("nan"), dtype=lp, device=DEV)
+            delta = torch.zeros(B * heads * T, device=DEV)
+            o.attention_bwd(qd, ctx, dctx, lse, dqkv, delta, B, T, heads, d, d ** -0.5, p, seed)
+            torch.cuda.synchronize()
+            outs.append(dqkv.clone())
+    finally:
+        for k, v in old.items():
+            os.environ.pop(k, None)
+            if v is not None:
+                os.environ[k] = v
+    assert torch.isfinite(outs[0].float()).all() and torch.equal(outs[0], outs[1])
+
+
 def test_dropout_stream_statistics():
     """Counter-based dropout (common.h rng_pair): keep rate, independence of the two elements that share one
     32-bit hash, independence of neighbouring hashes, and decorrelation of consecutive seeds."""

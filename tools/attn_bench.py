@@ -20,8 +20,10 @@ def timeit(fn, reps=50):
     for _ in range(reps): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) * 1e3 / reps
-for geom in os.environ.get("GEOMS", "64,32").split(","):
-  os.environ["W2V2_ATTN_GEOM"] = geom            # read per call by attention.hip
+for geom in os.environ.get("GEOMS", "64,32,32nodma").split(","):
+  os.environ["W2V2_ATTN_GEOM"] = geom[:2]        # read per call by attention.hip
+  os.environ.pop("W2V2_ATTN_KV_NO_DMA", None)
+  if geom.endswith("nodma"): os.environ["W2V2_ATTN_KV_NO_DMA"] = "1"
   for p in (0.0, 0.1):
     f = timeit(lambda: ops.attention_fwd(qkv, ctx, lse, B, T, heads, d, d ** -0.5, p, 1))
     b = timeit(lambda: ops.attention_bwd(qkv, ctx, dctx, lse, dqkv, delta, B, T, heads, d, d ** -0.5, p, 1))

@@ -240,6 +240,25 @@ __device__ __forceinline__ void tile_store(const TileRegs& r, bf16_t* lds) {
   }
 }
 
+// The same tile straight from global memory into LDS (global_load_lds_dwordx4: no staging registers).  A wave-instruction
+// moves 64 x 16 B = 8 rows of the image; lane l lands at chunk (l & 7) of row 8 p + (l >> 3), so the XOR swizzle is
+// applied on the SOURCE side (the lane fetches chunk (l & 7) ^ aswz(row)).  The DMA cannot write zeros: rows past
+// n_valid are CLAMPED onto the last valid row (finite data) and the caller makes their contribution vanish
+// (dK / dV kernel: lse = +inf for those query rows -> p = 0).  KT / (8 NW) instructions per wave and operand.
+typedef __attribute__((address_space(1))) const void attn_gvoid_t;
+typedef __attribute__((address_space(3))) void attn_lvoid_t;
+template <int NW, int KT>
+__device__ __forceinline__ void tile_dma(const bf16_t* g, int64_t gs, int row0, int n_valid, bf16_t* lds, int wave, int lane) {
+#pragma unroll
+  for (int i = 0; i < KT / (8 * NW); ++i) {
+    const int piece = wave * (KT / (8 * NW)) + i;
+    const int row = piece * 8 + (lane >> 3);
+    const int src_row = min(row0 + row, n_valid - 1);
+    const int ch = (lane & 7) ^ aswz(row);
+    __builtin_amdgcn_global_load_lds((attn_gvoid_t*)(g + (int64_t)src_row * gs + ch * 8), (attn_lvoid_t*)(lds + piece * 8 * 64), 16, 0, 0);
+  }
+}
+
 // Workgroup -> (row tile, head, utterance).  The grid is ONE-dimensional and the index is remapped so that every XCD
 // (workgroup id % 8) owns a contiguous run of logical indices: the ceil(T / 64) row tiles of one (utterance, head) --
 // which all stream the SAME K / V (forward, dQ) or Q / dO (dK, dV) rows -- then sit on the same XCD at the same time and
@@ -492,8 +511,8 @@ __global__ __launch_bounds__(64 * NW, 4) void attn_bwd_dq_tiled_kernel(const bf1
 }
 
 // dK, dV for 64 keys per workgroup, streaming query tiles (Q, dO, LSE, delta)
-template <typename TE, int NW, int KT, typename IDX>
-__global__ __launch_bounds__(64 * NW, 3) void attn_bwd_kv_tiled_kernel(const bf16_t* __restrict__ qkv,
+template <typename TE, int NW, int KT, typename IDX, bool DMA>
+__global__ __launch_bounds__(64 * NW, DMA ? 4 : 3) void attn_bwd_kv_tiled_kernel(const bf16_t* __restrict__ qkv,
                                                                 const bf16_t* __restrict__ dctx,
                                                                 const float* __restrict__ lse,
                                                                 const float* __restrict__ delta,
@@ -522,22 +541,31 @@ __global__ __launch_bounds__(64 * NW, 3) void attn_bwd_kv_tiled_kernel(const bf1
   const int ntile = (Tn + AT_TILE - 1) / AT_TILE;
   TileRegs rq, ro;
   float rl = 0.f, rd = 0.f;
+  // (DMA: query rows past T arrive as copies of row T - 1; +inf in the log2-domain LSE makes their p exactly 0)
   auto row_load = [&](int t) {
     if (threadIdx.x < AT_TILE) {
       const int r = t * AT_TILE + threadIdx.x;
-      rl = r < Tn ? lse[bh * Tn + r] * 1.4426950408889634f : 0.f;
+      rl = r < Tn ? lse[bh * Tn + r] * 1.4426950408889634f : (DMA ? INFINITY : 0.f);
       rd = r < Tn ? delta[bh * Tn + r] : 0.f;
     }
   };
   auto row_store = [&](int buf) {
     if (threadIdx.x < AT_TILE) { lse_s[buf][threadIdx.x] = rl; del_s[buf][threadIdx.x] = rd; }
   };
-  tile_load<NT>(rq, qb, gs, 0, Tn);
-  tile_load<NT>(ro, dob, H, 0, Tn);
-  row_load(0);
-  tile_store<NT>(rq, Qs[0]);
-  tile_store<NT>(ro, Os[0]);
-  row_store(0);
+  if constexpr (DMA) {
+    tile_dma<NW, KT>(qb, gs, 0, Tn, Qs[0], wave, lane);
+    tile_dma<NW, KT>(dob, H, 0, Tn, Os[0], wave, lane);
+    row_load(0);
+    row_store(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  } else {
+    tile_load<NT>(rq, qb, gs, 0, Tn);
+    tile_load<NT>(ro, dob, H, 0, Tn);
+    row_load(0);
+    tile_store<NT>(rq, Qs[0]);
+    tile_store<NT>(ro, Os[0]);
+    row_store(0);
+  }
   __syncthreads();
   f32x4 dv[4], dk[4];
 #pragma unroll
@@ -551,8 +579,13 @@ __global__ __launch_bounds__(64 * NW, 3) void attn_bwd_kv_tiled_kernel(const bf1
   for (int t = 0; t < ntile; ++t) {
     const int cur = t & 1;
     if (t + 1 < ntile) {
-      tile_load<NT>(rq, qb, gs, (t + 1) * AT_TILE, Tn);
-      tile_load<NT>(ro, dob, H, (t + 1) * AT_TILE, Tn);
+      if constexpr (DMA) {        // buffer cur ^ 1 was last read in iteration t - 1, behind that iteration's barrier
+        tile_dma<NW, KT>(qb, gs, (t + 1) * AT_TILE, Tn, Qs[cur ^ 1], wave, lane);
+        tile_dma<NW, KT>(dob, H, (t + 1) * AT_TILE, Tn, Os[cur ^ 1], wave, lane);
+      } else {
+        tile_load<NT>(rq, qb, gs, (t + 1) * AT_TILE, Tn);
+        tile_load<NT>(ro, dob, H, (t + 1) * AT_TILE, Tn);
+      }
       row_load(t + 1);
     }
     const int nfq = min(AT_TILE / 16, (Tn - t * AT_TILE + 15) >> 4);      // 16-query blocks with a valid row (uniform)
@@ -600,9 +633,12 @@ __global__ __launch_bounds__(64 * NW, 3) void attn_bwd_kv_tiled_kernel(const bf1
       }
     }
     if (t + 1 < ntile) {
-      tile_store<NT>(rq, Qs[cur ^ 1]);
-      tile_store<NT>(ro, Os[cur ^ 1]);
+      if constexpr (!DMA) {
+        tile_store<NT>(rq, Qs[cur ^ 1]);
+        tile_store<NT>(ro, Os[cur ^ 1]);
+      }
       row_store(cur ^ 1);
+      if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
   }
@@ -682,8 +718,15 @@ static int attention_bwd_g(const void* qkv, const void* ctx, const void* dctx, c
   hipLaunchKernelGGL((attn_bwd_dq_tiled_kernel<TE, NW, KT, IDX>), grid, dim3(64 * NW), 0, st, (const bf16_t*)qkv, (const bf16_t*)ctx,
                      (const bf16_t*)dctx, lse, (bf16_t*)dqkv, delta, T, g_attn_no_remap ? -heads : heads, scale, drop_p, ik,
                      seed);
-  hipLaunchKernelGGL((attn_bwd_kv_tiled_kernel<TE, NW, KT, IDX>), grid, dim3(64 * NW), 0, st, (const bf16_t*)qkv, (const bf16_t*)dctx,
-                     lse, (const float*)delta, (bf16_t*)dqkv, T, g_attn_no_remap ? -heads : heads, scale, drop_p, ik, seed);
+  // dK / dV with LDS-DMA tile loads (no staging registers: 128 VGPRs, four waves per SIMD); W2V2_ATTN_KV_NO_DMA: A/B switch
+  if (NW == 2 && getenv("W2V2_ATTN_KV_NO_DMA") == nullptr)
+    hipLaunchKernelGGL((attn_bwd_kv_tiled_kernel<TE, NW, KT, IDX, NW == 2>), grid, dim3(64 * NW), 0, st, (const bf16_t*)qkv,
+                       (const bf16_t*)dctx, lse, (const float*)delta, (bf16_t*)dqkv, T, g_attn_no_remap ? -heads : heads, scale,
+                       drop_p, ik, seed);
+  else
+    hipLaunchKernelGGL((attn_bwd_kv_tiled_kernel<TE, NW, KT, IDX, false>), grid, dim3(64 * NW), 0, st, (const bf16_t*)qkv,
+                       (const bf16_t*)dctx, lse, (const float*)delta, (bf16_t*)dqkv, T, g_attn_no_remap ? -heads : heads, scale,
+                       drop_p, ik, seed);
   W2V2_CHECK_LAUNCH("attention_bwd");
   return 0;
 }
