@@ -1,6 +1,6 @@
 #!/bin/bash
 # copy the evidence tools/profile_round.sh left in gpurun_out/ into profiles/ under the names the docs and tests cite
-TAG=${1:-r05}
+TAG=${1:-r06}
 G=gpurun_out; P=profiles
 cp $G/${TAG}_bench_line.json $P/${TAG}_bench_line.json
 cp $G/${TAG}_kernel_stats.txt $P/${TAG}_bench_b66_kernel_stats.txt

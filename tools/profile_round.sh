@@ -4,7 +4,7 @@
 # Usage: bash tools/profile_round.sh <tag> [ecapa]
 #   -> gpurun_out/<tag>_{kernel_stats.txt,pmc_counters.json,bench_line.json}   (with `ecapa`: <tag>_ecapa_*, configs[4])
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 MODEL=""
 if [ "${2:-}" = "ecapa" ]; then TAG=${TAG}_ecapa; MODEL="--model ecapa"; fi
 OUT=$PWD/gpurun_out
