@@ -566,6 +566,36 @@ def test_committed_bench_lines_follow_the_contract():
     assert len(pmc["source_hash"]) == 16 and "gemm16_ring_256x128_kernel<_Float16, _Float16>" in pmc["kernels"]
 
 
+def test_round6_bench_line_carries_the_tail_families_and_the_centred_eer():
+    """profiles/r06_bench_line.json (tools/round_final.sh r06 on an MI355X): besides the contract fields, the non-GEMM tail
+    against the HBM roofline (`roofline_families`) and the EER leg's centred figure next to the plain one
+    (item 1), both equal to the reference's on the committed line."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    line = json.load(open(os.path.join(root, "profiles", "r06_bench_line.json")))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in line, k
+    assert line["n_gpus"] == 1 and line["dtype"] == "f16" and line["vs_baseline"] is None
+    assert abs(line["value"] - 66 / (line["ms_per_step"] * 1e-3)) < 0.01 * line["value"]
+    r = line["roofline"]
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["pmc_stale"] is False
+    assert r["pmc_source"] == "profiles/r06_pmc_counters.json"
+    fam = {e["family"]: e for e in line["roofline_families"]}
+    assert {"layernorm_fwd", "layernorm_bwd", "attention_fwd", "attention_bwd", "adam", "conv0"} <= set(fam)
+    for e in fam.values():
+        assert e["bound"] == "hbm" and e["peak"] == 8000.0 and e["unit"] == "GB/s"
+        assert abs(e["frac"] - e["achieved"] / 8000.0) < 1e-3 and e["avg_us"] > 0 and e["bracket_us"] >= e["avg_us"]
+    a = fam["attention_fwd"]
+    assert a["rows_padded_to"] == 160 and abs(a["valid_score_fraction"] - 149 * 149 / 160.0 ** 2) < 1e-3 and a["matrix_tflops"] > 100
+    assert 10.0 < fam["layernorm_fwd"]["launches_per_step"] < 30 and fam["adam"]["launches_per_step"] == 1.0
+    e = line["eer"]
+    assert e["hip_f16"] == e["reference"] and e["centred"]["hip_f16"] == e["centred"]["reference"]
+    assert e["centred"]["reference"] < 0.5 * e["reference"] and e["centred"]["max_abs_score_diff"] < 5e-3
+    c = line["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0
+
+
 def test_committed_ddp_rehearsal_line_carries_the_multi_gpu_fields():
     """profiles/r06_ddp_rehearsal_line.json = `W2V2_DIST_BACKEND=gloo W2V2_SHARE_GPU=1 bench.py --gpus 2` on a one-GPU box
     (VERDICT r5 item 8): NOT a scaling measurement (two ranks share one GPU and reduce over gloo) -- it pins the shape of
