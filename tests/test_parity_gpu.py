@@ -852,6 +852,78 @@ def test_regularised_training_step_runs_layerdrop_masks_dropout():
         assert torch.isfinite(st.flat).all()
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+def test_pre_ln_family_regularised_training_steps_and_dropout_backward(dtype):
+    """The pre-LN / layer-norm-convolution family under the THROUGHPUT configuration (dropouts, LayerDrop, SpecAugment): three
+    trainer steps are finite, LayerDrop-skipped blocks get exactly-zero Linear gradients while their neighbours do not, the
+    loss falls on a fixed batch; and (exact-f32 mode) the backward with every dropout site active agrees with central
+    differences of the forward along a random direction -- the keep decisions are a pure function of (seed, step, site,
+    element), so the loss is a deterministic function of the weights."""
+    import dataclasses
+    from w2v2_speaker_amd.config import W2V2Config, Wav2Vec2RegularisationConfig
+    from w2v2_speaker_amd.engine import Plan
+    from w2v2_speaker_amd.optim.schedule import OneCycle
+    from w2v2_speaker_amd.trainer import SpeakerTrainer
+    kw = dict(num_hidden_layers=3, do_stable_layer_norm=True, feat_extract_norm="layer", conv_bias=True)
+    cfg, ocfg = dataclasses.replace(W2V2Config.tiny(), **kw), dataclasses.replace(O.OracleConfig.tiny(), **kw)
+    st, _ = _store(cfg, ocfg, dtype, "aam", 10)
+    if st.scaler is not None:
+        st.scaler[0] = 256.0      # B = 4: d loss / d cos is 16x the workload's; the default scale overflows fp16 here
+    wav, label = O.synth_batch(4, 8000, 10, seed=3)
+    wav, label = wav.to(DEV), label.to(DEV)
+    reg = Wav2Vec2RegularisationConfig(mask_time_length=3, activation_dropout=0.1)
+    plan = Plan(st, 4, 8000, train=True, reg=reg)
+    tr = SpeakerTrainer(st, plan, OneCycle(2e-3, 10))
+    loss, _ = tr.train_step(wav, label, skip_layers=(1,))
+    torch.cuda.synchronize()
+    assert np.isfinite(float(loss))
+    assert float(st.mg("encoder.layers.1.feed_forward.output_dense.weight").abs().max()) == 0.0
+    assert float(st.mg("encoder.layers.1.attention.out_proj.weight").abs().max()) == 0.0
+    assert float(st.mg("encoder.layers.0.feed_forward.output_dense.weight").abs().max()) > 0.0
+    assert float(st.mg("encoder.layers.2.layer_norm.weight").abs().max()) > 0.0       # produced by the skipped block's re-normalisation
+    assert float(st.mg("masked_spec_embed").abs().max()) > 0.0
+    losses = [float(loss)]
+    for _ in range(4):
+        l2, _ = tr.train_step(wav, label, skip_layers=())
+        losses.append(float(l2))
+    assert all(np.isfinite(losses)) and torch.isfinite(st.flat).all()
+    if st.scaler is not None:
+        assert int(st.scaler[3]) == 0                      # no step was skipped for an overflow
+    if dtype != torch.float32:
+        return
+    # directional derivative with all dropout sites on (fixed step -> fixed masks), f32
+    st2, _ = _store(cfg, ocfg, torch.float32, "aam", 10)
+    plan2 = Plan(st2, 4, 8000, train=True, reg=dataclasses.replace(reg, layerdrop=0.0, mask_time_prob=0.0))
+
+    def loss_at():
+        plan2.embed(wav, None, (), 5)
+        l, _ = plan2.head_forward_backward(label)
+        return float(l.double())
+    st2.zero_grad()
+    plan2.embed(wav, None, (), 5)
+    plan2.head_forward_backward(label)
+    plan2.backward()
+    torch.cuda.synchronize()
+    gen = torch.Generator().manual_seed(9)
+    names = [n for n in st2.shapes if st2.is_trainable(n) and n.startswith("wav2vec.model.encoder.layers.")]
+    for name in (names[3], names[17], "wav2vec.model.encoder.layer_norm.weight", "wav2vec.model.encoder.layers.0.layer_norm.weight"):
+        d = torch.randn(st2.shapes[name], generator=gen).to(DEV)
+        d /= d.norm()
+        ana = float((st2.g(name).double() * d.double()).sum())
+        base = st2.p(name).clone()
+        eps = 2e-2
+        st2.p(name).copy_(base + eps * d)
+        st2.sync_lowp()
+        lp = loss_at()
+        st2.p(name).copy_(base - eps * d)
+        st2.sync_lowp()
+        lm = loss_at()
+        st2.p(name).copy_(base)
+        st2.sync_lowp()
+        num = (lp - lm) / (2 * eps)
+        assert abs(num - ana) <= 3e-2 * max(abs(ana), abs(num)) + 2e-4, (name, num, ana)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_unfrozen_cnn_every_gradient_vs_reference_golden(dtype):
     """completely_freeze_feature_extractor=False: gradients of ALL parameters, incl. the 7 conv layers and the
