@@ -164,6 +164,58 @@ def test_pre_ln_layer_norm_conv_family_vs_reference_golden(dtype):
         Plan(st, 2, wav.shape[-1], train=False, insert_cls_token=True, pooling="first+cls")
 
 
+def test_large_lv60_geometry_cut_vs_oracle():
+    """`W2V2Config.from_huggingface_id("facebook/wav2vec2-large-lv60")` (H = 1024, 16 heads, FFN 4096, pre-LN, layer-norm
+    convolutions with bias) cut to 2 blocks, 2 s clips: eval embedding, train-mode loss and every trainable gradient norm of
+    the HIP path (exact-f32 mode) against the oracle restatement that g19_tiny_stable pins; eval embedding in fp16 / bf16."""
+    import dataclasses
+    from w2v2_speaker_amd.config import W2V2Config
+    from w2v2_speaker_amd.engine import Plan
+    cfg = dataclasses.replace(W2V2Config.from_huggingface_id("facebook/wav2vec2-large-lv60"), num_hidden_layers=2)
+    ocfg = dataclasses.replace(O.OracleConfig.large(), num_hidden_layers=2, do_stable_layer_norm=True,
+                               feat_extract_norm="layer", conv_bias=True)
+    assert cfg.do_stable_layer_norm and cfg.feat_extract_norm == "layer" and cfg.conv_bias and cfg.hidden_size == 1024
+    B, N, C = 2, 32000, 101
+    wav, label = O.synth_batch(B, N, C, seed=78)
+    st, sd = _store(cfg, ocfg, torch.float32, "aam", C)
+    sdg = {k: v.clone().requires_grad_(k.startswith("encoder") or k.startswith("feature_projection")
+                                       or k in ("masked_spec_embed", "loss_fn.fc_weights")) for k, v in sd.items()}
+    torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))
+    emb_ref = O.speaker_embedding(wav, sdg, ocfg)
+    loss_ref, _ = O.aam_softmax(emb_ref, sdg["loss_fn.fc_weights"], label)
+    loss_ref.backward()
+    tr = Plan(st, B, N, train=True, reg=_no_reg())
+    st.zero_grad()
+    emb = tr.embed(wav.to(DEV))
+    loss, _ = tr.head_forward_backward(label.to(DEV))
+    tr.backward()
+    torch.cuda.synchronize()
+    assert rel_l2(emb.cpu(), emb_ref.detach()) < 1e-4
+    assert abs(float(loss) - float(loss_ref)) < 1e-4 * abs(float(loss_ref))
+    gmax = max(float(v.grad.norm()) for v in sdg.values() if v.grad is not None)
+    checked = 0
+    for n, v in sdg.items():
+        if v.grad is None:
+            continue
+        name = n if n.startswith("loss_fn") else "wav2vec.model." + n
+        if not st.is_trainable(name):
+            continue
+        ref, got = float(v.grad.double().norm()), float(st.g(name).double().norm())
+        assert abs(got - ref) <= 2e-3 * ref + 1e-6 * gmax, (n, got, ref)
+        checked += 1
+    assert checked > 30
+    del tr
+    for lp, bound in ((torch.float16, 4e-3), (torch.bfloat16, 3e-2)):
+        stb, _ = _store(cfg, ocfg, lp, "aam", C)
+        evb = Plan(stb, B, N, train=False)
+        eb = evb.embed(wav.to(DEV))
+        torch.cuda.synchronize()
+        err = rel_l2(eb.cpu(), emb_ref.detach())
+        print(f"large-lv60 geometry (2-block cut) {lp}: embedding rel-L2 vs the oracle {err:.3e}")
+        assert err < bound, (lp, err)
+        del evb, stb
+
+
 def test_layer_norm_convolution_stack_at_base_width_vs_oracle():
     """The layer-norm convolution family at the real width (512 channels, k = 10 / 3 / 2, biases): conv_features() of the
     HIP path against the (g19-pinned) oracle restatement on one second of audio, f32 and fp16."""
