@@ -217,10 +217,14 @@ def test_broadcast_parameters_two_ranks_gloo():
     assert all(ok and refused for _, ok, refused in res), res
 
 
-def _check_schedule(L, skip, pair_uppers, members):
+def _check_schedule(L, skip, pair_uppers, members, group=2):
     """Invariants of engine.encoder_backward_schedule against the bucketing of trainer.BucketAllReducer."""
     from w2v2_speaker_amd.engine import encoder_backward_schedule
-    ev = encoder_backward_schedule(L, skip, pair_uppers)
+    ev = encoder_backward_schedule(L, skip, pair_uppers, True, group)
+    if group > 2:        # members of one launch never share a scratch set (l % group), and a launch has at most `group` of them
+        for e in ev:
+            if e[0] == "wgrad":
+                assert len(e[1]) <= group and len({l % group for l in e[1]}) == len(e[1]), e
     last_write, parked, notified = {}, [], []
     for i, e in enumerate(ev):
         if e[0] == "body":
@@ -281,6 +285,8 @@ def test_backward_schedule_notifies_every_bucket_after_its_last_writer():
             for skip in pats:
                 _check_schedule(L, set(skip), pair_uppers, members)
                 _check_schedule(L, set(skip), [], members)            # W2V2_NO_WGRAD_PAIRS
+                _check_schedule(L, set(skip), pair_uppers, members, group=4)      # wav2vec2-large: groups of four
+                _check_schedule(L, set(skip), pair_uppers, members, group=3)
 
 
 def test_eval_metrics_and_evaluator_match_reference_golden():

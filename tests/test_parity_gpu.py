@@ -1054,6 +1054,60 @@ def test_gradient_buckets_are_final_when_notified_under_layerdrop(dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_weight_gradient_groups_of_four_bit_equal_to_pairs_and_final_when_notified(dtype):
+    """Round 6: the grouped weight-gradient launch may cover FOUR consecutive blocks (chosen for wav2vec2-large, where four
+    fill the chip's rounds of 256 x 256 tiles and two do not; forced here with W2V2_WGRAD_GROUP on an 8-block tiny model).
+    Same gradients bit for bit as with pairs -- the kernel writes each tile from its own K loop whatever the grouping --
+    under LayerDrop patterns that close groups early, and every bucket is final when it is notified."""
+    import dataclasses
+    from w2v2_speaker_amd.engine import Plan
+    cfg, ocfg = _cfgs("tiny")
+    cfg = dataclasses.replace(cfg, num_hidden_layers=8)
+    ocfg = dataclasses.replace(ocfg, num_hidden_layers=8)
+    st, _ = _store(cfg, ocfg, dtype, "aam", 10)
+    if st.scaler is not None:
+        st.scaler[0] = 256.0
+    wav, label = O.synth_batch(4, 4000, 10, seed=3)
+    wav, label = wav.to(DEV), label.to(DEV)
+    raw = {n: (s, e) for n, s, e in st.grad_buckets()}
+    old = os.environ.get("W2V2_WGRAD_GROUP")
+    plans = {}
+    try:
+        for k in ("2", "4"):
+            os.environ["W2V2_WGRAD_GROUP"] = k
+            plans[k] = Plan(st, 4, 4000, train=True, reg=_no_reg())
+            assert plans[k].wg_group == int(k) and len(plans[k]._gsets) == max(2, int(k))
+    finally:
+        if old is None:
+            os.environ.pop("W2V2_WGRAD_GROUP", None)
+        else:
+            os.environ["W2V2_WGRAD_GROUP"] = old
+    for skip in [(), (7,), (5,), (4, 3), (0,), (6, 2), (7, 6, 5, 4), (1, 3, 5, 7), (0, 1, 2, 3, 4, 5, 6, 7)]:
+        got = {}
+        for k, plan in plans.items():
+            st.zero_grad()
+            plan.embed(wav, None, skip)
+            plan.head_forward_backward(label)
+            snaps, order = [], []
+
+            def rec(name):
+                order.append(name)
+                if name in raw:
+                    s_, e_ = raw[name]
+                    snaps.append((name, s_, e_, st.grad[s_:e_].clone()))
+            plan.backward(on_bucket_ready=rec)
+            torch.cuda.synchronize()
+            assert order == ["head"] + [f"layer{l}" for l in range(7, -1, -1)] + ["prologue", "projection"], order
+            for name, s_, e_, snap in snaps:
+                assert torch.equal(snap, st.grad[s_:e_]), (k, skip, name)
+            got[k] = st.grad.clone()
+        assert torch.isfinite(got["4"][:st.n_train]).all()
+        bad = [n for n in st.shapes if st.is_trainable(n) and not torch.equal(
+            got["2"][st.offsets[n]:st.offsets[n] + st.g(n).numel()], got["4"][st.offsets[n]:st.offsets[n] + st.g(n).numel()])]
+        assert not bad, (skip, bad[:5])
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 def test_partial_zero_grad_ranges_are_all_written_by_the_backward(dtype):
     """ParamStore.zero_grad(skip_layers) leaves the encoder's Linear gradients, the AAM weight and the pos-conv
     weight-norm pair UN-zeroed because the backward writes (does not accumulate into) them.  Enforce that coupling: poison

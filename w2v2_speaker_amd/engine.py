@@ -40,7 +40,8 @@ def _tiles(n: int, t: int = 128) -> int:
     return (n + t - 1) // t
 
 
-def encoder_backward_schedule(num_layers: int, skip: Sequence[int], pair_uppers: Sequence[int], grouped: bool = True):
+def encoder_backward_schedule(num_layers: int, skip: Sequence[int], pair_uppers: Sequence[int], grouped: bool = True,
+                              group: int = 2):
     """Order of the encoder part of one backward pass, as plain data (no device work): a list of events
         ("body", l)        data-gradient chain of layer l up to and including the attention backward; its LayerNorm
                            gamma/beta partials are parked in the fold group; without the grouped weight-gradient
@@ -53,6 +54,29 @@ def encoder_backward_schedule(num_layers: int, skip: Sequence[int], pair_uppers:
     `pair_uppers` = upper layers of the weight-gradient pairs (Plan.g_wgrad_pair); `skip` = this step's LayerDrop
     decisions.  Plan.backward executes exactly this list; tests/test_host_cpu.py checks its invariants (every bucket
     is notified once, in descending order, after its last writer) for every skip pattern."""
+    if grouped and group > 2:
+        # Groups of `group` consecutive layers counted down from the top (round 6: wav2vec2-large, whose 192 tiles of
+        # 256 x 256 per layer fill 256 CUs badly in ones -- 0.75 -- and in pairs -- 1.5 rounds -- but well in fours: 3.0).
+        # A layer's dY buffers live in scratch set l % group, so the members of a group never share a set.  A LayerDrop
+        # skip closes the open group early (as it does for pairs); buckets are still notified once, in descending order,
+        # after their last writer.
+        ev, held, Ltop, skip = [], [], num_layers - 1, set(skip)
+        for l in reversed(range(num_layers)):
+            if l in skip:
+                if held:
+                    ev += [("wgrad", tuple(held)), ("fold",)] + [("notify", h) for h in held]
+                    held = []
+                ev.append(("notify", l))
+                continue
+            ev.append(("body", l))
+            held.append(l)
+            if (Ltop - l) % group == group - 1 or l == 0:
+                ev += [("wgrad", tuple(held)), ("dx", l), ("fold",)] + [("notify", h) for h in held]
+                held = []
+            else:
+                ev.append(("dx", l))
+        assert not held
+        return ev
     ev, held, Ltop, skip, pair_uppers = [], None, num_layers - 1, set(skip), set(pair_uppers)
     for l in reversed(range(num_layers)):
         upper = grouped and (Ltop - l) % 2 == 0 and l > 0 and l in pair_uppers      # l pairs with l - 1
@@ -157,6 +181,35 @@ class Plan:
         self.grouped = False
         self._alloc()
         self._build_gemms()
+
+    def _wgrad_group_size(self) -> int:
+        """How many consecutive blocks share one grouped weight-gradient launch: 2 (pairs, since round 3) unless FOUR fill
+        the chip's rounds of 256 x 256 tiles strictly better (wav2vec2-large: 192 tiles per block -> pairs 384 = 1.5
+        rounds, fours 768 = 3.0).  W2V2_WGRAD_GROUP forces 1 / 2 / 4 (tests, A/B)."""
+        env = os.environ.get("W2V2_WGRAD_GROUP")
+        if env:
+            return max(1, min(4, int(env)))
+        cfg = self.cfg
+        H, I = cfg.hidden_size, cfg.intermediate_size
+        c = lambda n: -(-n // 256)
+        tiles = c(H) * c(I) * 2 + c(H) * c(H) + c(3 * H) * c(H)
+        ncu = torch.cuda.get_device_properties(self.dev).multi_processor_count if self.dev.type == "cuda" else 256
+        cost = {k: -(-k * tiles // ncu) / k for k in (2, 4)}
+        return 4 if (cfg.num_hidden_layers >= 4 and cost[4] < cost[2] - 1e-9) else 2
+
+    def _wgrad_for(self, layers):
+        """The grouped weight-gradient launch covering `layers` (a tuple from encoder_backward_schedule): prebuilt for
+        single blocks and for the regular pairs, built on first use (and kept) for every other subset."""
+        if len(layers) == 1:
+            return self.g_layer[layers[0]]["wgrad"]
+        if len(layers) == 2 and layers[0] in self.g_wgrad_pair and layers[1] == layers[0] - 1:
+            return self.g_wgrad_pair[layers[0]]
+        if layers not in self._wgrad_cache:
+            probs = []
+            for l in layers:
+                probs += self.g_layer[l]["wgrad_problems"]
+            self._wgrad_cache[layers] = WgradGroup(probs, self.M, (self.M + 63) // 64 * 64)
+        return self._wgrad_cache[layers]
 
     # ------------------------------------------------------------------------------------------ buffers
     def _e(self, *shape, dtype=None) -> torch.Tensor:
@@ -265,8 +318,9 @@ class Plan:
             # Gd1 = da (attention residual branch), DH, DQKV.  TWO sets, used by alternating layers: the grouped
             # weight-gradient launch then covers a PAIR of layers (8 problems = 216 tiles of 256x256, one full round
             # of the chip instead of two 216-tile rounds of 256x128), see _build_gemms / backward.
+            self.wg_group = self._wgrad_group_size()
             self._gsets = [dict(Gd=self._ep(M, H), Gd1=self._ep(M, H), DH=self._ep(M, I), DQKV=self._ep(M, 3 * H))
-                           for _ in range(2)]
+                           for _ in range(max(2, self.wg_group))]
             self.DC = self._e(M, H)
             self.P1 = self._e(M, H)
             self.GR = self._e(M, H) if self.stable else None        # pre-LN: gradient of the un-normalised residual stream
@@ -357,7 +411,7 @@ class Plan:
                 Wqkv = st.qkv(l, "w")
                 # data-gradient products: with the pre-transposed bf16 weight copies they are plain
                 # K-contiguous GEMMs (LDS-DMA kernel); the f32 parity mode reads W as a K-major operand
-                gs = self._gsets[l % 2]
+                gs = self._gsets[l % len(self._gsets)]
                 tb = st.flat_lp_t is None
                 if not tb:
                     W2, W1, Wo = (st.wt("wav2vec.model." + pre + "feed_forward.output_dense.weight"),
@@ -415,6 +469,7 @@ class Plan:
             self.g_layer.append(gl)
         # weight gradients of two consecutive layers (l, l-1; l counted down from the top) in one launch
         self.g_wgrad_pair = {}
+        self._wgrad_cache = {}
         if self.train and getattr(self, "grouped", False) and not os.environ.get("W2V2_NO_WGRAD_PAIRS"):
             Mp = (M + 63) // 64 * 64
             for l in range(L - 1, 0, -2):
@@ -782,13 +837,14 @@ class Plan:
         if self.stable:
             self._backward_encoder_stable(notify)               # leaves d(loss)/d(hx + pos) in self.G
         for ev in (() if self.stable else
-                   encoder_backward_schedule(cfg.num_hidden_layers, self._skip, self.g_wgrad_pair, self.grouped)):
+                   encoder_backward_schedule(cfg.num_hidden_layers, self._skip, self.g_wgrad_pair, self.grouped,
+                                             1 if os.environ.get("W2V2_NO_WGRAD_PAIRS") else getattr(self, "wg_group", 2))):
             kind = ev[0]
             if kind == "body":
                 self._layer_backward_body(ev[1], lnfold)
             elif kind == "wgrad":
                 layers = ev[1]
-                (self.g_wgrad_pair[layers[0]] if len(layers) == 2 else self.g_layer[layers[0]]["wgrad"])()
+                self._wgrad_for(tuple(layers))()
             elif kind == "dx":
                 self.g_layer[ev[1]]["dx"]()                     # G = DQKV @ Wqkv + G
             elif kind == "fold":
@@ -883,7 +939,7 @@ class Plan:
                 ops.add(GR, G, GR)
                 G.zero_()                       # X[l] fed a skipped block: nothing flows into it
                 continue
-            gs = self._gsets[l % 2]
+            gs = self._gsets[l % len(self._gsets)]
             pre = f"encoder.layers.{l}."
             grouped = self.grouped
             ops.layernorm_bwd(G, lb.f, lb.mean2, lb.rstd2, mp(wn), G, None, mg(wn), mg(bn))
@@ -942,7 +998,7 @@ class Plan:
         heads, d = cfg.num_attention_heads, cfg.head_dim
         pa, ph = reg.attention_dropout, reg.hidden_dropout
         lb, gl = self.lb[l], self.g_layer[l]
-        gs = self._gsets[l % 2]
+        gs = self._gsets[l % len(self._gsets)]
         pre = f"encoder.layers.{l}."
         grouped = self.grouped
         # x2 = LN2(x1 + drop(f)):  G <- ds2 (residual path), Gd <- df = ds2 * dropmask
