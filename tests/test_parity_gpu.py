@@ -1076,7 +1076,7 @@ def test_weight_gradient_groups_of_four_bit_equal_to_pairs_and_final_when_notifi
         for k in ("2", "4"):
             os.environ["W2V2_WGRAD_GROUP"] = k
             plans[k] = Plan(st, 4, 4000, train=True, reg=_no_reg())
-            assert plans[k].wg_group == int(k) and len(plans[k]._gsets) == max(2, int(k))
+            assert plans[k].wg_group == int(k) and len(plans[k]._gsets) == (8 if int(k) > 2 else 2)
     finally:
         if old is None:
             os.environ.pop("W2V2_WGRAD_GROUP", None)

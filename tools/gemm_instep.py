@@ -38,14 +38,17 @@ def run(seq_path, steps=6, warmup=3, dtype="f16"):
     from w2v2_speaker_amd.trainer import SpeakerTrainer
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(0)
-    cfg = W2V2Config.from_huggingface_id("facebook/wav2vec2-base")
+    # INSTEP_MODEL=large INSTEP_BATCH=32 INSTEP_SAMPLES=80000: BASELINE configs[3]'s per-GPU share instead of configs[1]
+    model = os.environ.get("INSTEP_MODEL", "base")
+    nb, ns = int(os.environ.get("INSTEP_BATCH", "66")), int(os.environ.get("INSTEP_SAMPLES", "48000"))
+    cfg = W2V2Config.from_huggingface_id("facebook/wav2vec2-" + model)
     adt = {"bf16": torch.bfloat16, "f16": torch.float16}[dtype]
     store = ParamStore(cfg, dev, adt, head="aam", num_speakers=5994, freeze_cnn=True)
     store.init_weights(seed=20211)
-    plan = Plan(store, 66, 48000, train=True, reg=Wav2Vec2RegularisationConfig(), seed=7)
+    plan = Plan(store, nb, ns, train=True, reg=Wav2Vec2RegularisationConfig(), seed=7)
     trainer = SpeakerTrainer(store, plan, OneCycle(max_lr=5e-5, total_steps=max(steps + warmup + 1, 10)),
                              layerdrop_seed=1234, mask_seed=7)
-    wav, label = synth_batch(66, 48000, 5994, seed=42133724, device=dev)
+    wav, label = synth_batch(nb, ns, 5994, seed=42133724, device=dev)
     ops.Gemm._log = []
     marks = []
     for i in range(warmup + steps):

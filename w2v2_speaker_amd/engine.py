@@ -55,27 +55,31 @@ def encoder_backward_schedule(num_layers: int, skip: Sequence[int], pair_uppers:
     decisions.  Plan.backward executes exactly this list; tests/test_host_cpu.py checks its invariants (every bucket
     is notified once, in descending order, after its last writer) for every skip pattern."""
     if grouped and group > 2:
-        # Groups of `group` consecutive layers counted down from the top (round 6: wav2vec2-large, whose 192 tiles of
+        # Groups of `group` NON-SKIPPED layers, counted down from the top (round 6: wav2vec2-large, whose 192 tiles of
         # 256 x 256 per layer fill 256 CUs badly in ones -- 0.75 -- and in pairs -- 1.5 rounds -- but well in fours: 3.0).
-        # A layer's dY buffers live in scratch set l % group, so the members of a group never share a set.  A LayerDrop
-        # skip closes the open group early (as it does for pairs); buckets are still notified once, in descending order,
-        # after their last writer.
-        ev, held, Ltop, skip = [], [], num_layers - 1, set(skip)
+        # Every layer has its OWN dY scratch set in this mode (3.5 GB of the 288 at wav2vec2-large), so a group may span
+        # LayerDrop-skipped layers and its launch may come after the data-gradient products of its last member.  Buckets
+        # are notified once, in descending order, after their last writer: a skipped layer inside an open group waits for
+        # the group's launch.
+        ev, held, skip, pending_top = [], [], set(skip), num_layers - 1
+
+        def flush(down_to):
+            nonlocal held, pending_top
+            if held:
+                ev.extend([("wgrad", tuple(held)), ("fold",)])
+            ev.extend(("notify", h) for h in range(pending_top, down_to - 1, -1))
+            held, pending_top = [], down_to - 1
         for l in reversed(range(num_layers)):
             if l in skip:
-                if held:
-                    ev += [("wgrad", tuple(held)), ("fold",)] + [("notify", h) for h in held]
-                    held = []
-                ev.append(("notify", l))
+                if not held:
+                    flush(l)                      # nothing open: the zero-gradient bucket is final at once
                 continue
             ev.append(("body", l))
             held.append(l)
-            if (Ltop - l) % group == group - 1 or l == 0:
-                ev += [("wgrad", tuple(held)), ("dx", l), ("fold",)] + [("notify", h) for h in held]
-                held = []
-            else:
-                ev.append(("dx", l))
-        assert not held
+            ev.append(("dx", l))
+            if len(held) == group:
+                flush(l)
+        flush(0)
         return ev
     ev, held, Ltop, skip, pair_uppers = [], None, num_layers - 1, set(skip), set(pair_uppers)
     for l in reversed(range(num_layers)):
@@ -205,6 +209,8 @@ class Plan:
         if len(layers) == 2 and layers[0] in self.g_wgrad_pair and layers[1] == layers[0] - 1:
             return self.g_wgrad_pair[layers[0]]
         if layers not in self._wgrad_cache:
+            if len(self._wgrad_cache) >= 256:          # LayerDrop patterns: bounded (descriptors only, a few KB each)
+                self._wgrad_cache.clear()
             probs = []
             for l in layers:
                 probs += self.g_layer[l]["wgrad_problems"]
@@ -318,9 +324,11 @@ class Plan:
             # Gd1 = da (attention residual branch), DH, DQKV.  TWO sets, used by alternating layers: the grouped
             # weight-gradient launch then covers a PAIR of layers (8 problems = 216 tiles of 256x256, one full round
             # of the chip instead of two 216-tile rounds of 256x128), see _build_gemms / backward.
+            # two alternating sets for single / paired launches; groups of four get one set PER LAYER (they may span
+            # LayerDrop-skipped layers: encoder_backward_schedule)
             self.wg_group = self._wgrad_group_size()
             self._gsets = [dict(Gd=self._ep(M, H), Gd1=self._ep(M, H), DH=self._ep(M, I), DQKV=self._ep(M, 3 * H))
-                           for _ in range(max(2, self.wg_group))]
+                           for _ in range(cfg.num_hidden_layers if self.wg_group > 2 else 2)]
             self.DC = self._e(M, H)
             self.P1 = self._e(M, H)
             self.GR = self._e(M, H) if self.stable else None        # pre-LN: gradient of the un-normalised residual stream
