@@ -52,13 +52,17 @@ class Recorder:
 def main():
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(0)
-    cfg = W2V2Config.from_huggingface_id("facebook/wav2vec2-base")
+    # TAIL_MODEL=large TAIL_BATCH=32 TAIL_SAMPLES=80000: BASELINE configs[3]'s per-GPU share (W2V2_WGRAD_GROUP=2 / 4 to compare)
+    model = os.environ.get("TAIL_MODEL", "base")
+    nb, ns = int(os.environ.get("TAIL_BATCH", "66")), int(os.environ.get("TAIL_SAMPLES", "48000"))
+    cfg = W2V2Config.from_huggingface_id("facebook/wav2vec2-" + model)
     store = ParamStore(cfg, dev, torch.float16, head="aam", num_speakers=5994, freeze_cnn=True)
     store.init_weights(seed=20211)
-    plan = Plan(store, 66, 48000, train=True, reg=Wav2Vec2RegularisationConfig(), seed=7)
+    plan = Plan(store, nb, ns, train=True, reg=Wav2Vec2RegularisationConfig(), seed=7)
+    print(f"# model {model}, {nb} utterances of {ns} samples per GPU, weight-gradient groups of {getattr(plan, 'wg_group', 2)}")
     rec = Recorder()
     tr = SpeakerTrainer(store, plan, OneCycle(max_lr=5e-5, total_steps=100), reducer=rec)
-    wav, label = synth_batch(66, 48000, 5994, seed=42133724, device=dev)
+    wav, label = synth_batch(nb, ns, 5994, seed=42133724, device=dev)
     for _ in range(5):
         tr.train_step(wav, label, skip_layers=())
     torch.cuda.synchronize()
