@@ -1189,16 +1189,17 @@ def test_transpose_many_vector_and_scalar_paths(lp):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("B,T", [(3, 149), (2, 301), (5, 37), (1, 160), (2, 161)])
+@pytest.mark.parametrize("Cg", [48, 64])
+@pytest.mark.parametrize("B,T", [(3, 149), (2, 301), (5, 37), (1, 160), (2, 161), (2, 249)])
 @pytest.mark.parametrize("lp", LP16)
-def test_posconv_direct_convolution_bit_equal_to_implicit_gemm(B, T, lp):
+def test_posconv_direct_convolution_bit_equal_to_implicit_gemm(B, T, lp, Cg):
     """csrc/posconv_direct.hip (image of one (utterance, group) resident in LDS, weights streamed): forward (bias + GELU,
     pre-activation saved) and data-gradient (+ aux, in place) modes at the w2v2-base geometry (16 groups x 48 channels,
     128 taps) against (a) an f64 grouped convolution and (b) the implicit GEMM of w2v2_gemm over the SAME operands --
     bit for bit (same k order per accumulator).  T = 301 / 161: two frame blocks per utterance; T = 37: shorter than
     the kernel's halo."""
     o = ops()
-    G, Cg, K = 16, 48, 128
+    G, K = 16, 128               # Cg = 48: w2v2-base (H = 768); Cg = 64: wav2vec2-large (H = 1024; swizzled image rows, round 6)
     H, Tp, M = G * Cg, T + K - 1, B * T
     g = torch.Generator(device="cpu").manual_seed(B * 1000 + T)
     x = (torch.randn(B, T, H, generator=g)).to(lp)

@@ -21,19 +21,30 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((address_space(1))) const void gvoid_t;
 typedef __attribute__((address_space(3))) void lvoid_t;
 
-constexpr int PD_CG = 48;                      // channels per group
 constexpr int PD_MB = 160;                     // frames per workgroup (ten 16-row fragments)
-constexpr int PD_IMG_BYTES = 27 * 1024;        // (160 + 127) rows x 96 B = 27552 -> 27 DMA pieces of 1 KiB
-constexpr int PD_BSTAGE = PD_CG * 64 * 2;      // one K tile of the weights: [48][64] 16-bit = 6 KiB
-constexpr int PD_LDS = PD_IMG_BYTES + 3 * PD_BSTAGE;
+// Two geometries (template parameter CG = channels per group): 48 (w2v2-base, H = 768 / 16 groups) and 64 (wav2vec2-large,
+// H = 1024 / 16 groups; round 6).  CG = 64: a frame row of the image is exactly one 128-byte line = one 64-wide K tile (one
+// tap), so the A fragments of K tile kt are chunks of row (frame + kt); rows 128 B apart would put the sixteen rows of a
+// fragment read on two bank groups, so the 16-byte chunks of a row are XOR-swizzled like a GEMM stage -- applied on the
+// SOURCE side of the image DMA and again on the read (the swizzle of row + kt changes with the K tile: two VALU per tile).
+template <int CG> struct PdGeom {
+  static constexpr int ROWB = CG * 2;                                        // bytes per frame row of the image
+  static constexpr int IMG_PIECES = ((PD_MB + 127) * ROWB + 1023) / 1024;    // 1 KiB DMA pieces: 27 / 36
+  static constexpr int IMG_BYTES = IMG_PIECES * 1024;
+  static constexpr int BSTAGE = CG * 64 * 2;                                 // one K tile of the weights: [CG][64] 16-bit
+  static constexpr int LDS = IMG_BYTES + 3 * BSTAGE;
+  static constexpr int NJ = CG / 16;                                         // channel fragments
+};
 
 __device__ __forceinline__ int pd_swz(int row) { return ((row ^ (row >> 1)) & 3) | (row & 4); }   // gemm_common.h swz()
 
-template <typename TE, int MODE>   // MODE 0: bias + GELU (aux = pre-activation, may be NULL); 1: + aux
+template <typename TE, int MODE, int CG>   // MODE 0: bias + GELU (aux = pre-activation, may be NULL); 1: + aux
 __global__ __launch_bounds__(256) void posconv_direct_kernel(const bf16_t* __restrict__ xg, const bf16_t* __restrict__ w,
                                                              bf16_t* __restrict__ out, bf16_t* __restrict__ aux,
                                                              const float* __restrict__ bias, int B, int Tn, int G,
                                                              int K, int64_t ldc, int mblocks, int64_t xg_elems) {
+  using GEO = PdGeom<CG>;
+  constexpr int PD_CG = CG, PD_IMG_BYTES = GEO::IMG_BYTES, PD_BSTAGE = GEO::BSTAGE, NJ = GEO::NJ, ROWB = GEO::ROWB;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -48,8 +59,14 @@ __global__ __launch_bounds__(256) void posconv_direct_kernel(const bf16_t* __res
   // outputs that are never stored)
   {
     const int64_t base = (((int64_t)b * G + g) * Tp + t0) * PD_CG;
-    for (int p = wave; p < 27; p += 4) {
-      int64_t off = base + p * 512 + lane * 8;
+    for (int p = wave; p < GEO::IMG_PIECES; p += 4) {
+      int64_t off;
+      if constexpr (CG == 64) {                   // 8 rows x 8 chunks per piece; the lane lands at chunk (lane & 7) of its row
+        const int row = p * 8 + (lane >> 3);
+        off = base + (int64_t)row * 64 + (((lane & 7) ^ pd_swz(row)) << 3);
+      } else {
+        off = base + p * 512 + lane * 8;
+      }
       off = off < xg_elems - 8 ? off : xg_elems - 8;
       __builtin_amdgcn_global_load_lds((gvoid_t*)(xg + off), (lvoid_t*)(smem + p * 1024), 16, 0, 0);
     }
@@ -64,8 +81,9 @@ __global__ __launch_bounds__(256) void posconv_direct_kernel(const bf16_t* __res
     const int row = (wave * 2 + j) * 8 + r8;
     boff[j] = (row < PD_CG ? row : PD_CG - 1) * (K * PD_CG) + ((c8 ^ pd_swz(row)) << 3);
   }
+  const bool loader = wave * 16 < PD_CG;         // waves 0..2 (48 channels) / 0..3 (64) issue two 8-row pieces per stage
   auto issue = [&](int kt) {
-    if (wave < 3) {
+    if (loader) {
       char* dst = smem + PD_IMG_BYTES + (kt % 3) * PD_BSTAGE + (wave * 2) * 1024;
 #pragma unroll
       for (int j = 0; j < 2; ++j)
@@ -78,18 +96,18 @@ __global__ __launch_bounds__(256) void posconv_direct_kernel(const bf16_t* __res
   const int fr = lane & 15, kg = lane >> 4;
   const int nmf = (wave < 2) ? 3 : 2;            // frame fragments of this wave: w, w + 4, (w + 8)
   // A: byte offset of (frame 16 i + fr, k chunk kg) in the image; B: fragment j, row 16 j + fr
-  const int aoff = fr * 96 + kg * 16;
+  const int aoff = fr * ROWB + kg * 16;
   const int sw = pd_swz(fr);
-  f32x4 acc[3][3];
+  f32x4 acc[3][NJ];
 #pragma unroll
   for (int i = 0; i < 3; ++i)
 #pragma unroll
-    for (int j = 0; j < 3; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
 #pragma unroll 1
   for (int kt = 0; kt < nk; ++kt) {
     // stage kt (and, the first time, the image) landed: at most the pieces of stage kt + 1 stay in flight
-    if (wave < 3) {
+    if (loader) {
       if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else {
@@ -100,19 +118,24 @@ __global__ __launch_bounds__(256) void posconv_direct_kernel(const bf16_t* __res
     const char* bs = smem + PD_IMG_BYTES + (kt % 3) * PD_BSTAGE;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-      frag8_t bf[3], af[3];
+      frag8_t bf[NJ], af[3];
 #pragma unroll
-      for (int j = 0; j < 3; ++j)
+      for (int j = 0; j < NJ; ++j)
         bf[j] = *reinterpret_cast<const frag8_t*>(bs + (j * 16 + fr) * 128 + (((kk * 4 + kg) ^ sw) << 4));
 #pragma unroll
       for (int i = 0; i < 3; ++i)
-        if (i < nmf)
-          af[i] = *reinterpret_cast<const frag8_t*>(smem + (wave + 4 * i) * (16 * 96) + aoff + kt * 128 + kk * 64);
+        if (i < nmf) {
+          if constexpr (CG == 64)       // row (frame + kt) of the image, logical chunk kk * 4 + kg, swizzled by that row
+            af[i] = *reinterpret_cast<const frag8_t*>(smem + ((wave + 4 * i) * 16 + fr + kt) * 128 +
+                                                      (((kk * 4 + kg) ^ pd_swz(fr + kt)) << 4));
+          else
+            af[i] = *reinterpret_cast<const frag8_t*>(smem + (wave + 4 * i) * (16 * 96) + aoff + kt * 128 + kk * 64);
+        }
 #pragma unroll
       for (int i = 0; i < 3; ++i)
         if (i < nmf) {
 #pragma unroll
-          for (int j = 0; j < 3; ++j) acc[i][j] = mfma16<TE>(bf[j], af[i], acc[i][j]);
+          for (int j = 0; j < NJ; ++j) acc[i][j] = mfma16<TE>(bf[j], af[i], acc[i][j]);
         }
     }
   }
@@ -127,9 +150,9 @@ __global__ __launch_bounds__(256) void posconv_direct_kernel(const bf16_t* __res
     const int t = t0 + (wave + 4 * i) * 16 + fr;
     const bool valid = t < Tn;                       // (the same for the two lanes of a pair: it depends on fr only)
     const int64_t rowoff = ((int64_t)b * Tn + (valid ? t : 0)) * ldc + g * PD_CG;
-    uint2 ow[3], pw[3];
+    uint2 ow[NJ], pw[NJ];
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
+    for (int j = 0; j < NJ; ++j) {
       const int n = j * 16 + kg * 4;
       float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
       if constexpr (MODE == 0) {
@@ -151,14 +174,23 @@ __global__ __launch_bounds__(256) void posconv_direct_kernel(const bf16_t* __res
       ow[j].x = pack2<TE>(v[0], v[1]);
       ow[j].y = pack2<TE>(v[2], v[3]);
     }
-    auto store48 = [&](bf16_t* dst, const uint2 (&w)[3]) {
+    auto store48 = [&](bf16_t* dst, const uint2 (&w)[NJ]) {
       const auto sx = __builtin_amdgcn_permlane16_swap(w[0].x, w[1].x, false, false);
       const auto sy = __builtin_amdgcn_permlane16_swap(w[0].y, w[1].y, false, false);
-      const auto tx = __builtin_amdgcn_permlane16_swap(w[2].x, 0u, false, false);
-      const auto ty = __builtin_amdgcn_permlane16_swap(w[2].y, 0u, false, false);
-      if (valid) {
-        store16_wt(dst + rowoff + (odd ? 16 : 0) + (kg & 2) * 4, make_uint4(sx[0], sy[0], sx[1], sy[1]));
-        if (!odd) store16_wt(dst + rowoff + 32 + (kg & 2) * 4, make_uint4(tx[0], ty[0], tx[1], ty[1]));
+      if constexpr (NJ == 4) {          // 64 channels: two block pairs, every lane stores one 16-byte piece of each
+        const auto tx = __builtin_amdgcn_permlane16_swap(w[2].x, w[3].x, false, false);
+        const auto ty = __builtin_amdgcn_permlane16_swap(w[2].y, w[3].y, false, false);
+        if (valid) {
+          store16_wt(dst + rowoff + (odd ? 16 : 0) + (kg & 2) * 4, make_uint4(sx[0], sy[0], sx[1], sy[1]));
+          store16_wt(dst + rowoff + 32 + (odd ? 16 : 0) + (kg & 2) * 4, make_uint4(tx[0], ty[0], tx[1], ty[1]));
+        }
+      } else {
+        const auto tx = __builtin_amdgcn_permlane16_swap(w[2].x, 0u, false, false);
+        const auto ty = __builtin_amdgcn_permlane16_swap(w[2].y, 0u, false, false);
+        if (valid) {
+          store16_wt(dst + rowoff + (odd ? 16 : 0) + (kg & 2) * 4, make_uint4(sx[0], sy[0], sx[1], sy[1]));
+          if (!odd) store16_wt(dst + rowoff + 32 + (kg & 2) * 4, make_uint4(tx[0], ty[0], tx[1], ty[1]));
+        }
       }
     };
     if constexpr (MODE == 0) {
@@ -171,8 +203,8 @@ __global__ __launch_bounds__(256) void posconv_direct_kernel(const bf16_t* __res
 extern "C" int w2v2_posconv_direct(const void* xg, const void* w, void* out, void* aux, const float* bias, int B, int T,
                                    int G, int Cg, int K, int64_t ldc, int mode, int dtype, void* stream) {
   W2V2_REQUIRE(xg && w && out && B > 0 && T > 0 && G > 0 && K > 0, "posconv_direct: bad arguments");
-  W2V2_REQUIRE(Cg == PD_CG && K == 128, "posconv_direct: built for 48 channels per group and 128 taps (w2v2-base); got "
-               "Cg=%d K=%d -- use the implicit GEMM", Cg, K);
+  W2V2_REQUIRE((Cg == 48 || Cg == 64) && K == 128, "posconv_direct: built for 48 (w2v2-base) or 64 (wav2vec2-large) channels "
+               "per group and 128 taps; got Cg=%d K=%d -- use the implicit GEMM", Cg, K);
   W2V2_REQUIRE(mode == 0 ? bias != nullptr : (mode == 1 && aux != nullptr), "posconv_direct: mode 0 needs bias, mode 1 aux");
   W2V2_REQUIRE(ldc % 8 == 0 && ldc >= G * Cg, "posconv_direct: ldc must be a multiple of 8 and >= G * Cg");
   W2V2_REQUIRE(((uintptr_t)xg | (uintptr_t)w | (uintptr_t)out | (uintptr_t)aux) % 16 == 0,
@@ -183,19 +215,21 @@ extern "C" int w2v2_posconv_direct(const void* xg, const void* w, void* out, voi
   W2V2_REQUIRE(xg_elems >= 8, "posconv_direct: input too small");
   dim3 grid((unsigned)(B * G * mblocks));
   hipStream_t st = as_stream(stream);
-#define PD_LAUNCH(TE_, MODE_)                                                                                        \
+#define PD_LAUNCH(TE_, MODE_, CG_)                                                                                  \
   do {                                                                                                               \
-    static bool attr_set = false;                                                                                    \
-    if (!attr_set) {                                                                                                 \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&posconv_direct_kernel<TE_, MODE_>),                    \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, PD_LDS);                                 \
-      attr_set = true;                                                                                               \
-    }                                                                                                                \
-    hipLaunchKernelGGL((posconv_direct_kernel<TE_, MODE_>), grid, dim3(256), PD_LDS, st, (const bf16_t*)xg,           \
-                       (const bf16_t*)w, (bf16_t*)out, (bf16_t*)aux, bias, B, T, G, K, ldc, mblocks, xg_elems);       \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&posconv_direct_kernel<TE_, MODE_, CG_>),                 \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, PdGeom<CG_>::LDS);                          \
+    hipLaunchKernelGGL((posconv_direct_kernel<TE_, MODE_, CG_>), grid, dim3(256), PdGeom<CG_>::LDS, st,               \
+                       (const bf16_t*)xg, (const bf16_t*)w, (bf16_t*)out, (bf16_t*)aux, bias, B, T, G, K, ldc, mblocks, \
+                       xg_elems);                                                                                    \
   } while (0)
-  if (dtype == W2V2_BF16) { if (mode == 0) PD_LAUNCH(bf16_t, 0); else PD_LAUNCH(bf16_t, 1); }
-  else { if (mode == 0) PD_LAUNCH(f16_t, 0); else PD_LAUNCH(f16_t, 1); }
+#define PD_LAUNCH_T(TE_)                                                                                             \
+  do {                                                                                                               \
+    if (Cg == 48) { if (mode == 0) PD_LAUNCH(TE_, 0, 48); else PD_LAUNCH(TE_, 1, 48); }                               \
+    else { if (mode == 0) PD_LAUNCH(TE_, 0, 64); else PD_LAUNCH(TE_, 1, 64); }                                       \
+  } while (0)
+  if (dtype == W2V2_BF16) PD_LAUNCH_T(bf16_t); else PD_LAUNCH_T(f16_t);
+#undef PD_LAUNCH_T
 #undef PD_LAUNCH
   W2V2_CHECK_LAUNCH("posconv_direct");
   return 0;

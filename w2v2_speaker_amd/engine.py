@@ -261,9 +261,9 @@ class Plan:
         self.hx = self._e(M, H) if (self.cls or self.paired) else self.h0       # encoder input
         G, K = cfg.num_conv_pos_embedding_groups, cfg.num_conv_pos_embeddings
         self.Cg, self.Tp = H // G, T + K - 1
-        # the direct convolution kernel is built for the w2v2-base geometry (48 channels per group, 128 taps); everything
-        # else (wav2vec2-large: 64 channels per group; the exact-f32 mode) runs the implicit GEMM
-        self.pos_direct = (ops.is16(self.adt) and self.Cg == 48 and K == 128 and not os.environ.get("W2V2_NO_POSCONV_DIRECT"))
+        # the direct convolution kernel is built for 48 (w2v2-base) and 64 (wav2vec2-large, round 6) channels per group at
+        # 128 taps; everything else (the tiny test geometry, the exact-f32 mode) runs the implicit GEMM
+        self.pos_direct = (ops.is16(self.adt) and self.Cg in (48, 64) and K == 128 and not os.environ.get("W2V2_NO_POSCONV_DIRECT"))
         self.xg = self._e(B, G, self.Tp, self.Cg)
         self.posw_f, self.posw_b = self._e(G, self.Cg, K * self.Cg), self._e(G, self.Cg, K * self.Cg)
         self.pos_sumsq = ops.weightnorm_scratch(H, G, K, self.dev)
