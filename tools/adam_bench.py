@@ -5,7 +5,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from w2v2_speaker_amd import ops
-n = 99_400_000 // 64 * 64
+n = int(os.environ.get("ADAM_N", "99400000")) // 64 * 64
 dev = "cuda"
 p, g = torch.randn(n, device=dev), torch.randn(n, device=dev) * 1e-3
 m, v = torch.zeros(n, device=dev), torch.zeros(n, device=dev)

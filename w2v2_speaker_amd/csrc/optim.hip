@@ -182,7 +182,10 @@ extern "C" int w2v2_adam_step(float* p, const float* g, float* m, float* v, void
   // A/B knobs (tools): W2V2_ADAM_U = vectors per thread and pass (1, 2, 4), W2V2_ADAM_BLOCKS = grid cap
   static const int env_u_raw = getenv("W2V2_ADAM_U") ? atoi(getenv("W2V2_ADAM_U")) : 2;   // 2: 495 vs 549 us over the 99.4 M-parameter arena
   static const int env_u = env_u_raw >= 4 ? 4 : (env_u_raw >= 2 ? 2 : 1);
-  static const int env_nb = getenv("W2V2_ADAM_BLOCKS") ? atoi(getenv("W2V2_ADAM_BLOCKS")) : 8192;
+  // grid cap: none by default (round 6).  The 8192-block cap of round 3 made every thread walk 6 (w2v2-base) to 20
+  // (wav2vec2-large) strides of the arena; one pass of one or two vectors per thread measures 456 vs 561 us over the base
+  // arena (6.5 vs 5.3 TB/s, tools/adam_sweep.sh, profiles/r06_adam_sweep.txt) and -0.7 % of the step (ABAB x 4).
+  static const int env_nb = getenv("W2V2_ADAM_BLOCKS") ? atoi(getenv("W2V2_ADAM_BLOCKS")) : (1 << 20);
   int64_t nb = cdiv(n >> 2, 256 * env_u);
   if (nb > env_nb) nb = env_nb;
   if (nb < 1) nb = 1;
