@@ -123,9 +123,14 @@ int w2v2_tune_gemm_kernel(int family);
  * phase issued between its MFMAs, bit 6 / 7 plain / write-through epilogue stores.  Variants with bits 0-3 compute
  * garbage by design.  Returns the previous setting; 0 = the product kernel. */
 int w2v2_tune_gemm_debug(int bits);
-/* Tools only: force the block tile of the exact-f32 MFMA GEMM (csrc/gemm_f32.hip) -- 0 = the library's choice (largest
- * tile whose grid fills the chip), 1 = 128x128, 2 = 64x128, 3 = 128x64, 4 = 64x64.  Returns the previous setting. */
+/* Tools only: force the kernel / block tile of the exact-f32 MFMA GEMM -- 0 = the library's choice; 1..4 = the
+ * register-staged kernel (csrc/gemm_f32.hip) on 128x128 / 64x128 / 128x64 / 64x64; 11..15 = the LDS-DMA kernel
+ * (csrc/gemm_f32_dma.hip) on (32 fi) x 128 tiles, fi = tile - 10; + 100 = the same with XCD-contiguous tile order.  A product the LDS-DMA kernel cannot take (segmented or
+ * unaligned operands, K % 4 != 0, M or N <= 64) ignores codes >= 11.  Returns the previous setting. */
 int w2v2_tune_gemm_f32_tile(int tile);
+/* Tools / tests: which kernel the LAST exact-f32 product ran on -- 0 = register-staged, else 10 fi + stages of the
+ * LDS-DMA kernel (e.g. 52 = 160 x 128 tiles, two-stage ring). */
+int w2v2_gemm_f32_last_kernel(void);
 
 /* Grouped weight-gradient GEMM (the backward of HF:520-526,544,565-572 nn.Linear weights/biases):
  *   dW_p[o][i] = sum_t dY_p[t][o] * X_p[t][i]      dbias_p[o] = sum_t dY_p[t][o]   (dbias may be NULL)

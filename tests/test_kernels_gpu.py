@@ -327,6 +327,32 @@ def test_gemm_f32_exact(ta, tb):
         _gemm_case(o, M, N, K, ta, tb, torch.float32, torch.float32)
 
 
+@pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, False), (True, True)])
+@pytest.mark.parametrize("code", [11, 12, 13, 14, 15, 115, 0])
+def test_gemm_f32_lds_dma_tiles(ta, tb, code):
+    """csrc/gemm_f32_dma.hip: every tile height (32 fi rows, fi = 1..5), XCD-contiguous order, all four
+    operand layouts; ragged M / N (zero-source lanes), K tails inside a tile and inside a split, split-K atomics, the
+    epilogues of the ECAPA step.  Tolerance 2e-5 relative l2 against f64 (as test_gemm_f32_exact)."""
+    from w2v2_speaker_amd import _lib
+    o, lib = ops(), _lib.load()
+    old = lib.w2v2_tune_gemm_f32_tile(code)
+    try:
+        for (M, N, K) in [(200, 136, 160), (328, 260, 100), (160, 128, 64), (1000, 384, 36), (68, 5996, 192)]:
+            _gemm_case(o, M, N, K, ta, tb, torch.float32, torch.float32)
+            want = None if code == 0 else (code % 100 - 10) * 10 + 2
+            got = lib.w2v2_gemm_f32_last_kernel()
+            assert got == want if want is not None else got > 0, (code, got)
+        for epi in ("bias", "add", "bias_gelu", "mul"):
+            _gemm_case(o, 200, 136, 160, ta, tb, torch.float32, torch.float32, epi)
+        _gemm_case(o, 192, 160, 2000, ta, tb, torch.float32, torch.float32, "none", split=5)
+        _gemm_case(o, 192, 160, 2000, ta, tb, torch.float32, torch.float32, "bias", split=3)
+        assert lib.w2v2_gemm_f32_last_kernel() > 0
+        _gemm_case(o, 149, 70, 33, ta, tb, torch.float32, torch.float32)          # K % 4 != 0: the register-staged kernel
+        assert lib.w2v2_gemm_f32_last_kernel() == 0
+    finally:
+        lib.w2v2_tune_gemm_f32_tile(old)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 def test_gemm_batched_heads_and_implicit_conv(dtype):
     o = ops()

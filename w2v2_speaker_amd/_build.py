@@ -11,7 +11,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libw2v2hip.so")
-SOURCES = ["api.hip", "gemm.hip", "gemm_ring.hip", "gemm_phased.hip", "gemm_f32.hip", "wgrad.hip", "wgrad_phased.hip", "norm.hip", "elementwise.hip", "conv0.hip", "posconv.hip", "posconv_direct.hip", "posconv_wgrad.hip",
+SOURCES = ["api.hip", "gemm.hip", "gemm_ring.hip", "gemm_phased.hip", "gemm_f32.hip", "gemm_f32_dma.hip", "wgrad.hip", "wgrad_phased.hip", "norm.hip", "elementwise.hip", "conv0.hip", "posconv.hip", "posconv_direct.hip", "posconv_wgrad.hip",
            "softmax.hip", "attention.hip", "pool.hip", "asp.hip", "tdnn.hip", "skinny.hip", "heads.hip", "optim.hip", "comm.hip"]
 HEADERS = ["common.h", "gemm_common.h", "wgrad_common.h"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]

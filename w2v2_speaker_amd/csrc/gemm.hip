@@ -481,6 +481,7 @@ extern "C" int w2v2_gemm(const w2v2_gemm_desc* d, void* stream) {
   a.defer_ok = 0;
   a.wt_stores = 1;
   a.late_dma = 0;
+  a.xcd_tiles = 0;
   const int cal = d->dtype_c == W2V2_F32 ? 4 : 8;     // elements per 16 bytes
   a.c_vec_ok = aligned16(d->C) && (d->ldc % cal == 0) && (d->c_stride0 % cal == 0) && (d->c_stride1 % cal == 0);
   a.aux_vec_ok = d->aux && aligned16(d->aux) && (d->ldaux % cal == 0) && (d->aux_stride0 % cal == 0) &&

@@ -45,6 +45,7 @@ struct GemmArgs {
   // two-term weights (w2v2_hip.h): tiles with n0 >= n_ext_from run k_ext more K steps against B + b_lo_off
   int k_ext, n_ext_from;
   int64_t b_lo_off;
+  int xcd_tiles;   // gemm_f32_dma: 1 = every XCD takes a contiguous run of tiles (set by w2v2_launch_gemm_f32)
 };
 
 __device__ __forceinline__ int64_t outer_off(const OpDev& o, int64_t idx) {
@@ -545,3 +546,5 @@ void w2v2_launch_ring_256x128(const GemmArgs& a, int dtype_ab, int dtype_c, int 
 void w2v2_launch_phased_256x256(const GemmArgs& a, int dtype_ab, int dtype_c, int M, int N, int batch, hipStream_t st);
 // gemm_f32.hip: exact-f32 products (f32 operands, f32 C); split = split-K factor (atomics), chooses its own tile
 void w2v2_launch_gemm_f32(GemmArgs a, int M, int N, int K, int split, int batch, hipStream_t st);
+// gemm_f32_dma.hip: the LDS-DMA variant, (32 fi) x 128 tiles, nst-stage ring; the caller has checked eligibility
+void w2v2_launch_gemm_f32_dma(const GemmArgs& a, int M, int N, int split, int batch, int fi, int nst, hipStream_t st);

@@ -272,10 +272,16 @@ static void launch_f32_layout(const GemmArgs& a, int M, int N, int split, int ba
   else launch_f32<true, true, BM, BN>(a, M, N, split, batch, st);
 }
 
-static int g_f32_tile_force = 0;      // tools: 0 = the choice below, 1 = 128x128, 2 = 64x128, 3 = 128x64, 4 = 64x64
+// tools: 0 = the choice below; 1..4 = the register-staged kernel on 128x128 / 64x128 / 128x64 / 64x64; 11..15 = the LDS-DMA
+// kernel (gemm_f32_dma.hip) on (32 fi) x 128 tiles, fi = t - 10; + 100: the same with XCD-contiguous tiles (+ 200, 400, 800:
+// timing-only variants without the loop's DMA / barrier / vmcnt wait).  An ineligible product ignores a DMA code.
+static int g_f32_tile_force = 0;
+static int g_f32_last_kernel = 0;
+extern "C" int w2v2_gemm_f32_last_kernel(void) { return g_f32_last_kernel; }
 extern "C" int w2v2_tune_gemm_f32_tile(int t) {
   const int old = g_f32_tile_force;
-  if (t >= 0 && t <= 4) g_f32_tile_force = t;
+  const int b = t % 100;
+  if (t >= 0 && t < 1600 && ((b >= 0 && b <= 4) || (b >= 11 && b <= 15))) g_f32_tile_force = t;
   return old;
 }
 
@@ -292,6 +298,42 @@ void w2v2_launch_gemm_f32(GemmArgs a, int M, int N, int K, int split, int batch,
   //   * else 64 x 64: skinny and short-K products (N = 128 Res2Net convolutions, K = 128 .. 200) are bound by the
   //     global-load latency of a 12-trip K loop, which only more resident workgroups hide (41.7 -> 30.6 us).
   const int64_t cus = w2v2_gemm_device_cus();
+  // LDS-DMA kernel (gemm_f32_dma.hip): plain 16-byte aligned operands whose every 16-byte piece is whole
+  static const bool no_dma = [] { const char* e = getenv("W2V2_F32_NO_DMA"); return e && e[0] != '0'; }();
+  const bool dma_ok = !no_dma && a.A.vec_ok && a.B.vec_ok && a.A.seg_len <= 0 && a.B.seg_len <= 0 && K % 4 == 0 &&
+                      (!a.A.trans || M % 4 == 0) && (!a.B.trans || N % 4 == 0) && M > 64 && N > 64;
+  if (dma_ok) {
+    const int force = g_f32_tile_force % 100;
+    int fi = 0;
+    const int nst = 2;
+    if (force >= 11 && force <= 15) fi = force - 10;
+    else if (force == 0) {
+      // Rows per tile.  The matrix pipes of a CU are shared by its resident workgroups, so what a grid quantises over is
+      // TILES PER CU, not workgroup slots: cost = ceil(tiles / CUs) x (fi + 0.6), the 0.6 standing for a tile's
+      // prologue + epilogue.  A lone workgroup on a CU cannot hide its own barriers and fragment reads (x 1.35).  Short
+      // K ranges (<= 16 K tiles) are bound by the latency of the first tiles, which only more resident workgroups hide:
+      // fi = 1 (40 KiB of LDS, four per CU).  From every product of the ECAPA step on every fi
+      // (tools/f32_dma_sweep.sh, profiles/r06_f32_dma_sweep.txt).
+      const int64_t kper = cdiv(K, split);
+      if (kper <= 512) fi = 1;
+      else {
+        double best = 1e30;
+        for (int f = 1; f <= 5; ++f) {
+          const int64_t w = cdiv(M, 32 * f) * cdiv(N, 128) * (int64_t)split * batch;
+          const int64_t per_cu = cdiv(w, cus);
+          const double cost = (double)per_cu * (f + 0.6) * (per_cu == 1 ? 1.35 : 1.0);
+          if (cost <= best) { best = cost; fi = f; }
+        }
+      }
+    }
+    if (fi > 0) {
+      a.xcd_tiles = g_f32_tile_force / 100;       // bit 0: XCD-contiguous tiles; bits 1, 2: debug variants (tools)
+      g_f32_last_kernel = 10 * fi + nst;
+      w2v2_launch_gemm_f32_dma(a, M, N, split, batch, fi, nst, st);
+      return;
+    }
+  }
+  g_f32_last_kernel = 0;
   auto wgs = [&](int bm, int bn) { return cdiv(M, bm) * cdiv(N, bn) * (int64_t)split * batch; };
   auto fits = [&](int bm, int bn, int per_cu) {
     const double exact = (double)wgs(bm, bn) / (double)(per_cu * cus);
