@@ -27,6 +27,28 @@ extern thread_local char g_w2v2_err[512];
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// ---------------------------------------------------------------- LDS-DMA piece (global_load_lds_dwordx4)
+// 16 bytes per lane from `src` (per lane) to LDS at lds + 16 * lane (`lds`: wave-uniform pointer into __shared__ memory).
+// Inline assembly instead of __builtin_amdgcn_global_load_lds ON PURPOSE: the compiler's waitcnt pass treats an LDS read
+// behind the builtin as possibly aliasing the piece and puts its own `s_waitcnt vmcnt(0)` in front of the first ds_read
+// that follows (round 6, found in the ISA of gemm_f32_dma.hip; the same wait stood at the top of the steady-state K loop
+// of the phased and ring GEMMs, behind their own counted `vmcnt(8)` / `vmcnt(6)`): every K tile then waits for ALL
+// pieces in flight, which is exactly what the counted waits of a multi-stage ring are there to avoid.  A kernel that uses
+// this helper must order every piece against its readers itself (s_waitcnt vmcnt(n) + barrier) -- __syncthreads() does
+// NOT wait for these pieces -- and must not use the builtin as well (the compiler does not know M0 changed here).
+__device__ __forceinline__ void w2v2_dma16(const void* src, void* lds) {
+  const uint32_t l = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(l), "v"(src) : "memory");
+}
+
+// `s_waitcnt vmcnt(0)` as an instruction the COMPILER sees (the builtin, not inline assembly).  Its waitcnt pass does not
+// read the counted waits the kernels write in assembly: with vector-memory operations of its own still pending at a K
+// loop's header (the previous tile's epilogue in a persistent kernel, the kernel-argument-dependent loads of the
+// prologue) it guards the first register it overwrites INSIDE the loop with its own vmcnt(0) -- executed in every
+// iteration, where it also waits for every LDS-DMA piece in flight.  One visible full wait in front of the loop (behind
+// the prologue's pieces, which it also waits for) leaves the pass nothing to guard.
+__device__ __forceinline__ void w2v2_vmcnt0_visible() { __builtin_amdgcn_s_waitcnt(0x0F70); }   // vmcnt 0, expcnt 7, lgkmcnt 15
+
 // ---------------------------------------------------------------- bf16 storage type
 typedef uint16_t bf16_t;
 

@@ -120,8 +120,7 @@ __global__ __launch_bounds__(512) void gemm16_phased_256x256_kernel(const GemmAr
       bf16_t* base = smem + (kt & 1) * BUF + (isa ? 0 : BM * 64);
 #pragma unroll
       for (int j = 0; j < 2; ++j)
-        __builtin_amdgcn_global_load_lds((gvoid_t*)((isa ? Ab : Bb) + (soff[q][j] + kt * 64)),
-                                         (lvoid_t*)(base + piece_row(q, j) * 64), 16, 0, 0);
+        w2v2_dma16(((isa ? Ab : Bb) + (soff[q][j] + kt * 64)), (base + piece_row(q, j) * 64));
     };
     f32x4 acc[FM][FN];
 #pragma unroll
@@ -132,7 +131,7 @@ __global__ __launch_bounds__(512) void gemm16_phased_256x256_kernel(const GemmAr
     // ---- prologue: K tile 0 entirely, QA0 / QB0 of K tile 1 (issue order = consumption order)
     issue(0, 0); issue(1, 0); issue(2, 0); issue(3, 0);
     if (nk > 1) { issue(0, 1); issue(1, 1); }
-    wait_quarters(2 + (nk > 1 ? 2 : 0));             // QA0(0), QB0(0) landed (this wave's pieces)
+    w2v2_vmcnt0_visible();                           // QA0(0), QB0(0) landed (this wave's pieces; all six quarters: common.h)
     __builtin_amdgcn_s_barrier();                    // ... everyone's
     if (wr == 1) __builtin_amdgcn_s_barrier();       // group 1 runs one barrier behind from here on
 
@@ -156,8 +155,7 @@ __global__ __launch_bounds__(512) void gemm16_phased_256x256_kernel(const GemmAr
     auto issue1 = [&](int q, int kt, int j) {
       const bool isa = q == 0 || q == 3;
       bf16_t* base = smem + (kt & 1) * BUF + (isa ? 0 : BM * 64);
-      __builtin_amdgcn_global_load_lds((gvoid_t*)((isa ? Ab : Bb) + (soff[q][j] + kt * 64)),
-                                       (lvoid_t*)(base + piece_row(q, j) * 64), 16, 0, 0);
+      w2v2_dma16(((isa ? Ab : Bb) + (soff[q][j] + kt * 64)), (base + piece_row(q, j) * 64));
     };
     // 16 MFMAs of a phase: acc rows io.., columns jo.., fragments bsel; with DMA_IN_MFMA the two pieces of quarter q of K
     // tile kq go out behind the 4th and the 12th MFMA

@@ -117,10 +117,10 @@ __global__ __launch_bounds__(512) void gemm16_ring_256x128_kernel(const GemmArgs
     const int64_t kb = koff_b(kt);
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-      __builtin_amdgcn_global_load_lds((gvoid_t*)(ap[j] + ka), (lvoid_t*)(ad + j * 8 * 64), 16, 0, 0);
+      w2v2_dma16((ap[j] + ka), (ad + j * 8 * 64));
 #pragma unroll
     for (int j = 0; j < 2; ++j)
-      __builtin_amdgcn_global_load_lds((gvoid_t*)(bp[j] + kb), (lvoid_t*)(bd + j * 8 * 64), 16, 0, 0);
+      w2v2_dma16((bp[j] + kb), (bd + j * 8 * 64));
   };
   const int frow = lane & 15, fk = lane >> 4;
   // per-lane fragment offsets (elements) for k-step 0 / 1; everything else is a compile-time constant
@@ -135,11 +135,9 @@ __global__ __launch_bounds__(512) void gemm16_ring_256x128_kernel(const GemmArgs
   // piece p of the 6 DMA pieces of one stage: A0..A3, B0, B1
   auto stage_piece = [&](bf16_t* base, int kt, int p) {
     if (p < 4)
-      __builtin_amdgcn_global_load_lds((gvoid_t*)(ap[p] + koff_a(kt)), (lvoid_t*)(base + (wave * 4 + p) * 8 * 64), 16,
-                                       0, 0);
+      w2v2_dma16((ap[p] + koff_a(kt)), (base + (wave * 4 + p) * 8 * 64));
     else
-      __builtin_amdgcn_global_load_lds((gvoid_t*)(bp[p - 4] + koff_b(kt)),
-                                       (lvoid_t*)(base + BM * 64 + (wave * 2 + p - 4) * 8 * 64), 16, 0, 0);
+      w2v2_dma16((bp[p - 4] + koff_b(kt)), (base + BM * 64 + (wave * 2 + p - 4) * 8 * 64));
   };
   // multiply stage `base`; when kload >= 0 the DMA pieces of K tile kload go to `nxt`, spread over the MFMA groups
   // (issued back to back behind the barrier they keep both waves of a SIMD in the queue-limited DMA issue)
@@ -187,6 +185,7 @@ __global__ __launch_bounds__(512) void gemm16_ring_256x128_kernel(const GemmArgs
   __builtin_amdgcn_s_barrier();          // every wave has finished reading the previous tile's stages
   if (nk > 0) stage(s0, 0);
   if (nk > 1) stage(s1, 1);
+  w2v2_vmcnt0_visible();                 // both prologue tiles in (common.h: keeps the compiler's own vmcnt(0) out of the loop)
   int kt = 0;
   if (pending) {
     if (nk >= 3) {                                         // one peeled rotation of the ring carries the stores
