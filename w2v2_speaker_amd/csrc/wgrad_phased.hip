@@ -127,14 +127,14 @@ __global__ __launch_bounds__(512) void wgrad_grouped_phased_kernel(const WgArgs 
     const bf16_t* base = isa ? pa + kt * astep : pb + kt * bstep;
 #pragma unroll
     for (int j = 0; j < 2; ++j)
-      w2v2_dma16((base + soff[q][j]), (dst + j * 4 * 256));
+      __builtin_amdgcn_global_load_lds((gvoid_t*)(base + soff[q][j]), (lvoid_t*)(dst + j * 4 * 256), 16, 0, 0);
   };
   auto issue1 = [&](int q, int kt, int j) {          // one piece of it
     const bool isa = q == 0 || q == 3;
     const int region = q == 0 ? 0 : (q == 3 ? 1 : (q == 1 ? 2 : 3));
     char* dst = smem_raw + (kt & 1) * BUFB + region * QB + (8 * wave) * 256;
     const bf16_t* base = isa ? pa + kt * astep : pb + kt * bstep;
-    w2v2_dma16((base + soff[q][j]), (dst + j * 4 * 256));
+    __builtin_amdgcn_global_load_lds((gvoid_t*)(base + soff[q][j]), (lvoid_t*)(dst + j * 4 * 256), 16, 0, 0);
   };
   // read-segment part of a phase's quarter / the part that goes between the MFMAs (behind MFMA number `after`)
   auto issue_early = [&](int q, int kt) {
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(512) void wgrad_grouped_phased_kernel(const WgArgs 
   // ---- prologue: K tile 0 entirely, QA0 / QB0 of K tile 1 (issue order = consumption order)
   issue(0, 0); issue(1, 0); issue(2, 0); issue(3, 0);
   if (nk > 1) { issue(0, 1); issue(1, 1); }
-  w2v2_vmcnt0_visible();                             // QA0(0), QB0(0) landed (this wave's pieces; all six quarters: common.h)
+  wgp_wait_quarters(2 + (nk > 1 ? 2 : 0));           // QA0(0), QB0(0) landed (this wave's pieces)
   __builtin_amdgcn_s_barrier();                      // ... everyone's
   if (wr == 1) __builtin_amdgcn_s_barrier();         // group 1 runs one barrier behind from here on
 
