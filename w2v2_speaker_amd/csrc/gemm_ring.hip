@@ -182,10 +182,10 @@ __global__ __launch_bounds__(512) void gemm16_ring_256x128_kernel(const GemmArgs
     compute(cur, nxt, kt + 2 < nk ? kt + 2 : -1);                  \
     ++kt;                                                          \
   }
+  w2v2_vmcnt0_visible();                 // (common.h: keeps the compiler's own vmcnt(0) out of the loop; nothing of this wave's is in flight here but the previous tile's epilogue loads / non-deferred stores)
   __builtin_amdgcn_s_barrier();          // every wave has finished reading the previous tile's stages
   if (nk > 0) stage(s0, 0);
   if (nk > 1) stage(s1, 1);
-  w2v2_vmcnt0_visible();                 // both prologue tiles in (common.h: keeps the compiler's own vmcnt(0) out of the loop)
   int kt = 0;
   if (pending) {
     if (nk >= 3) {                                         // one peeled rotation of the ring carries the stores
