@@ -37,7 +37,7 @@ static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 // this helper must order every piece against its readers itself (s_waitcnt vmcnt(n) + barrier) -- __syncthreads() does
 // NOT wait for these pieces -- and must not use the builtin as well (the compiler does not know M0 changed here).
 __device__ __forceinline__ void w2v2_dma16(const void* src, void* lds) {
-  const uint32_t l = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
+  const uint32_t l = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds);
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(l), "v"(src) : "memory");
 }
 
