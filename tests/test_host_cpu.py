@@ -723,3 +723,21 @@ def test_pre_ln_family_parameter_names_order_and_id_table():
     for hid in ("someone/wav2vec2-large-finetuned-xyz", "facebook/hubert-xl"):
         with pytest.raises(ValueError):
             f(hid)
+
+
+def test_no_compiler_vmcnt_inside_the_k_loops_of_the_lds_dma_gemms():
+    """Round 6: the compiler's waitcnt pass had its own `s_waitcnt vmcnt(0)` at the top of the steady-state K loop of the ring and
+    the phased GEMM (behind their counted waits written in assembly) -- every K tile waited for every LDS-DMA piece in flight.
+    tools/loop_waits.sh lists the waits that are NOT inside an inline-assembly block with the loop they sit in; the K loops
+    (depth 2, inside the persistent tile loop) must have none.  Cross-compiles two files (about a minute), no GPU."""
+    import shutil
+    import subprocess
+    if not os.path.exists("/opt/rocm/bin/hipcc") and shutil.which("hipcc") is None:
+        pytest.skip("no hipcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for src, pat in (("gemm_ring.hip", "IDF16_DF16_E"), ("gemm_phased.hip", "IDF16_DF16_Li0E")):
+        out = subprocess.run(["bash", os.path.join(root, "tools", "loop_waits.sh"), src, pat], capture_output=True, text=True,
+                             timeout=600).stdout
+        assert "_Z" in out, (src, out[-400:])                   # the kernel was found and compiled
+        inner = [l for l in out.splitlines() if "Depth=2" in l or "Depth=3" in l]
+        assert not inner, (src, inner[:4])
