@@ -112,7 +112,8 @@ int w2v2_gemm(const w2v2_gemm_desc* d, void* stream);
 int w2v2_gemm_timed(const w2v2_gemm_desc* d, void* stream, int slot);
 int w2v2_timer_read(int first_slot, int n, float* ms_out);
 /* The kernel family w2v2_gemm sends this descriptor to, from a dry run of the dispatch itself (nothing is launched):
- * 4 = phased 256x256, 2 = 256x128 ring, 1 = 128-row LDS-DMA, 3 = register-staged, 9 = exact f32; < 0 = rejected. */
+ * 4 = phased 256x256, 2 = 256x128 ring, 1 = 128-row LDS-DMA, 3 = register-staged, 9 = exact f32 (register-staged,
+ * csrc/gemm_f32.hip), 10 = exact f32 with LDS-DMA staging (csrc/gemm_f32_dma.hip); < 0 = rejected. */
 int w2v2_gemm_kernel_of(const w2v2_gemm_desc* d);
 /* Tuning hook (tools/gemm_shapes.py, not used by the training path): force the tile family of plain K-contiguous
  * 16-bit products -- 0 = the library's own dispatch, 1 = 128x128, 2 = 256x128 ring, 3 = 256x256x32 ring,

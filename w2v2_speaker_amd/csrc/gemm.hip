@@ -587,7 +587,7 @@ extern "C" int w2v2_gemm(const w2v2_gemm_desc* d, void* stream) {
       return aligned16(o.ptr) && (o.ld % 4 == 0) && (o.seg_stride % 4 == 0) && (o.stride0 % 4 == 0) && (o.stride1 % 4 == 0);
     };
     a.A.vec_ok = vec4(d->A); a.B.vec_ok = vec4(d->B);
-    g_gemm_family = 9;
+    g_gemm_family = w2v2_gemm_f32_dma_rows(a, d->M, d->N, d->K, split, d->batch) > 0 ? 10 : 9;   // 10: gemm_f32_dma.hip
     if (g_gemm_dry) return 0;
     w2v2_launch_gemm_f32(a, d->M, d->N, d->K, split, d->batch, st);       // gemm_f32.hip
   }

@@ -546,5 +546,6 @@ void w2v2_launch_ring_256x128(const GemmArgs& a, int dtype_ab, int dtype_c, int 
 void w2v2_launch_phased_256x256(const GemmArgs& a, int dtype_ab, int dtype_c, int M, int N, int batch, hipStream_t st);
 // gemm_f32.hip: exact-f32 products (f32 operands, f32 C); split = split-K factor (atomics), chooses its own tile
 void w2v2_launch_gemm_f32(GemmArgs a, int M, int N, int K, int split, int batch, hipStream_t st);
+int w2v2_gemm_f32_dma_rows(const GemmArgs& a, int M, int N, int K, int split, int batch);   // gemm_f32.hip: 0 = register-staged
 // gemm_f32_dma.hip: the LDS-DMA variant, (32 fi) x 128 tiles, nst-stage ring; the caller has checked eligibility
 void w2v2_launch_gemm_f32_dma(const GemmArgs& a, int M, int N, int split, int batch, int fi, int nst, hipStream_t st);

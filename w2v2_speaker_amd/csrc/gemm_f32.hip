@@ -285,6 +285,37 @@ extern "C" int w2v2_tune_gemm_f32_tile(int t) {
   return old;
 }
 
+// Which kernel an exact-f32 product runs on: 0 = the register-staged kernel below, else the tile height fi (rows = 32 fi)
+// of the LDS-DMA kernel (gemm_f32_dma.hip).  Also asked by w2v2_gemm's dry run (w2v2_gemm_kernel_of: family 10 instead of 9).
+int w2v2_gemm_f32_dma_rows(const GemmArgs& a, int M, int N, int K, int split, int batch) {
+  // plain 16-byte aligned operands whose every 16-byte piece is whole
+  static const bool no_dma = [] { const char* e = getenv("W2V2_F32_NO_DMA"); return e && e[0] != '0'; }();
+  const bool dma_ok = !no_dma && a.A.vec_ok && a.B.vec_ok && a.A.seg_len <= 0 && a.B.seg_len <= 0 && K % 4 == 0 &&
+                      (!a.A.trans || M % 4 == 0) && (!a.B.trans || N % 4 == 0) && M > 64 && N > 64;
+  if (!dma_ok) return 0;
+  const int force = g_f32_tile_force % 100;
+  if (force >= 11 && force <= 15) return force - 10;
+  if (force != 0) return 0;
+  // Rows per tile.  The matrix pipes of a CU are shared by its resident workgroups, so what a grid quantises over is
+  // TILES PER CU, not workgroup slots: cost = ceil(tiles / CUs) x (fi + 0.6), the 0.6 standing for a tile's
+  // prologue + epilogue.  A lone workgroup on a CU cannot hide its own barriers and fragment reads (x 1.35).  Short
+  // K ranges (<= 16 K tiles) are bound by the latency of the first tiles, which only more resident workgroups hide:
+  // fi = 1 (40 KiB of LDS, four per CU).  From every product of the ECAPA step on every fi
+  // (tools/f32_dma_sweep.sh, profiles/r06_f32_dma_sweep.txt).
+  const int64_t cus = w2v2_gemm_device_cus();
+  const int64_t kper = cdiv(K, split);
+  if (kper <= 512) return 1;
+  int fi = 1;
+  double best = 1e30;
+  for (int f = 1; f <= 5; ++f) {
+    const int64_t w = cdiv(M, 32 * f) * cdiv(N, 128) * (int64_t)split * batch;
+    const int64_t per_cu = cdiv(w, cus);
+    const double cost = (double)per_cu * (f + 0.6) * (per_cu == 1 ? 1.35 : 1.0);
+    if (cost <= best) { best = cost; fi = f; }
+  }
+  return fi;
+}
+
 void w2v2_launch_gemm_f32(GemmArgs a, int M, int N, int K, int split, int batch, hipStream_t st) {
   a.k_per_split = (int)(cdiv(cdiv(K, split), 32) * 32);
   if (a.k_per_split == 0) a.k_per_split = 32;
@@ -298,40 +329,12 @@ void w2v2_launch_gemm_f32(GemmArgs a, int M, int N, int K, int split, int batch,
   //   * else 64 x 64: skinny and short-K products (N = 128 Res2Net convolutions, K = 128 .. 200) are bound by the
   //     global-load latency of a 12-trip K loop, which only more resident workgroups hide (41.7 -> 30.6 us).
   const int64_t cus = w2v2_gemm_device_cus();
-  // LDS-DMA kernel (gemm_f32_dma.hip): plain 16-byte aligned operands whose every 16-byte piece is whole
-  static const bool no_dma = [] { const char* e = getenv("W2V2_F32_NO_DMA"); return e && e[0] != '0'; }();
-  const bool dma_ok = !no_dma && a.A.vec_ok && a.B.vec_ok && a.A.seg_len <= 0 && a.B.seg_len <= 0 && K % 4 == 0 &&
-                      (!a.A.trans || M % 4 == 0) && (!a.B.trans || N % 4 == 0) && M > 64 && N > 64;
-  if (dma_ok) {
-    const int force = g_f32_tile_force % 100;
-    int fi = 0;
-    const int nst = 2;
-    if (force >= 11 && force <= 15) fi = force - 10;
-    else if (force == 0) {
-      // Rows per tile.  The matrix pipes of a CU are shared by its resident workgroups, so what a grid quantises over is
-      // TILES PER CU, not workgroup slots: cost = ceil(tiles / CUs) x (fi + 0.6), the 0.6 standing for a tile's
-      // prologue + epilogue.  A lone workgroup on a CU cannot hide its own barriers and fragment reads (x 1.35).  Short
-      // K ranges (<= 16 K tiles) are bound by the latency of the first tiles, which only more resident workgroups hide:
-      // fi = 1 (40 KiB of LDS, four per CU).  From every product of the ECAPA step on every fi
-      // (tools/f32_dma_sweep.sh, profiles/r06_f32_dma_sweep.txt).
-      const int64_t kper = cdiv(K, split);
-      if (kper <= 512) fi = 1;
-      else {
-        double best = 1e30;
-        for (int f = 1; f <= 5; ++f) {
-          const int64_t w = cdiv(M, 32 * f) * cdiv(N, 128) * (int64_t)split * batch;
-          const int64_t per_cu = cdiv(w, cus);
-          const double cost = (double)per_cu * (f + 0.6) * (per_cu == 1 ? 1.35 : 1.0);
-          if (cost <= best) { best = cost; fi = f; }
-        }
-      }
-    }
-    if (fi > 0) {
-      a.xcd_tiles = g_f32_tile_force / 100;       // bit 0: XCD-contiguous tiles; bits 1, 2: debug variants (tools)
-      g_f32_last_kernel = 10 * fi + nst;
-      w2v2_launch_gemm_f32_dma(a, M, N, split, batch, fi, nst, st);
-      return;
-    }
+  const int fi = w2v2_gemm_f32_dma_rows(a, M, N, K, split, batch);
+  if (fi > 0) {
+    a.xcd_tiles = g_f32_tile_force / 100;         // bit 0: XCD-contiguous tiles; bits 1-3: timing-only variants (tools)
+    g_f32_last_kernel = 10 * fi + 2;
+    w2v2_launch_gemm_f32_dma(a, M, N, split, batch, fi, 2, st);
+    return;
   }
   g_f32_last_kernel = 0;
   auto wgs = [&](int bm, int bn) { return cdiv(M, bm) * cdiv(N, bn) * (int64_t)split * batch; };

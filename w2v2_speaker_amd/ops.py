@@ -116,7 +116,8 @@ class Gemm:
         # the Python mirror of its heuristics could disagree with an env-tuned or differently sized device)
         fam = lib().w2v2_gemm_kernel_of(self._ref)
         self.kernel_name = {4: "gemm16_phased_256x256_kernel", 2: "gemm16_ring_256x128_kernel", 1: "gemm16_dma_128_kernel",
-                            3: "gemm16_regstage_kernel", 9: "gemm_f32_mfma_kernel"}.get(fam, "gemm16_regstage_kernel" if lp
+                            3: "gemm16_regstage_kernel", 9: "gemm_f32_mfma_kernel",
+                            10: "gemm_f32_dma_kernel"}.get(fam, "gemm16_regstage_kernel" if lp
                                                                                        else "gemm_f32_mfma_kernel")
 
     _prof = None
