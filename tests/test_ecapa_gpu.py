@@ -166,10 +166,12 @@ def test_skinny_linear_kernels_vs_torch(B, N, K, act):
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("M,C,ld,relu", [(9900, 128, 1024, True), (3300, 1024, 1024, True), (66, 6144, 6144, False),
-                                          (257, 8, 8, True), (130, 200, 208, False)])
+                                          (257, 8, 8, True), (130, 200, 208, False),
+                                          (2050, 3072, 3072, False), (1501, 1024, 1280, True), (1100, 1536, 1536, True)])
 def test_batchnorm_kernels_vs_torch(dtype, M, C, ld, relu):
     """csrc/tdnn.hip BatchNorm (partial sums + fold/apply) on a row-strided [M, C] view against torch BatchNorm1d
-    in f64: output, running statistics, input gradient, dgamma / dbeta; then the evaluation mode."""
+    in f64: output, running statistics, input gradient, dgamma / dbeta; then the evaluation mode.  C >= 1024 with
+    M >= 1024 runs the whole-row apply kernels behind a finalize launch (round 6), the rest the 128-channel strip kernels."""
     from w2v2_speaker_amd import ops
     dev = "cuda"
     g = torch.Generator().manual_seed(M + C)
@@ -255,6 +257,26 @@ def test_two_operand_forms_of_im2col_and_batchnorm_backward_equal_the_materialis
             ops.bn_bwd(s_, w, a_, w, mr, gamma, work, dg, db, da, w, M, w, True, colsum_partial=csp)
         return da, dg, db, csp
 
+    if dtype == torch.float32:          # the same two-operand form on the whole-row kernels (C >= 1024, M >= 1024)
+        Mw, Cw = 1200, 1024
+        aw = torch.randn(Mw, Cw, generator=g).to(dev)
+        e1, e2 = torch.randn(Mw, Cw, generator=g).to(dev), torch.randn(Mw, Cw, generator=g).to(dev)
+        gw, bw = (torch.rand(Cw, generator=g) + 0.5).to(dev), torch.randn(Cw, generator=g).to(dev)
+        workw, mrw = ops.bn_workspace(Mw, Cw, dev), torch.empty(Cw, 2, device=dev)
+        yw = torch.empty(Mw, Cw, device=dev)
+        ops.bn_fwd(aw, Cw, workw, mrw, None, gw, bw, yw, Cw, Mw, Cw, 1e-5, 0.1, True, True)
+        outs = []
+        for two in (True, False):
+            daw = torch.empty(Mw, Cw, device=dev)
+            dgw, dbw = torch.empty(Cw, device=dev), torch.empty(Cw, device=dev)
+            cw = torch.empty(ops.bn_colsum_rows(Mw, Cw), Cw, device=dev)
+            if two:
+                ops.bn_bwd(e1, Cw, aw, Cw, mrw, gw, workw, dgw, dbw, daw, Cw, Mw, Cw, True, colsum_partial=cw, dy2=e2, lddy2=Cw)
+            else:
+                ops.bn_bwd(e1 + e2, Cw, aw, Cw, mrw, gw, workw, dgw, dbw, daw, Cw, Mw, Cw, True, colsum_partial=cw)
+            outs.append((daw, dgw, dbw, cw))
+        for u, v in zip(*outs):
+            assert torch.equal(u, v)
     got = run(True, dtype)
     if dtype == torch.float32:
         for u, v in zip(got, run(False, torch.float32)):

@@ -48,4 +48,10 @@ for name, C, ld in (("128-ch slice of 1024", 128, 1024), ("1024 wide", 1024, 102
     f = timed(lambda: o.bn_fwd(a, ld, work, mr, running, gamma, beta, y, ld, M, C, 1e-5, 0.1, True, True))
     b = timed(lambda: o.bn_bwd(dy, ld, a, ld, mr, gamma, work, dg, db, da, ld, M, C, True, cs))
     t = M * C * 4 / 1e3          # KB -> us * GB/s
-    print(f"{name:28s} {f:12.1f} {3 * t / f / 1e3:18.0f} {b:13.1f} {5 * t / b / 1e3:18.0f}")
+    ev = timed(lambda: o.bn_fwd(a, ld, work, mr, running + 1.0, gamma, beta, y, ld, M, C, 1e-5, 0.1, True, False))
+    print(f"{name + ': eval apply only':28s} {ev:12.1f} {2 * t / ev:18.0f}    (one kernel, 2 x tensor, no statistics fold)")
+    if C == ld:                   # what the part streams, cold, on the same tensors: a device copy (2 x tensor) and a + dy -> y (3 x)
+        cp = timed(lambda: y.copy_(a))
+        ad = timed(lambda: torch.add(a, dy, out=y))
+        print(f"{name + ': copy / add':28s} {cp:12.1f} {2 * t / cp:18.0f} {ad:13.1f} {3 * t / ad:18.0f}")
+    print(f"{name:28s} {f:12.1f} {3 * t / f:18.0f} {b:13.1f} {5 * t / b:18.0f}")
