@@ -168,12 +168,24 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, in
           for (int e = 0; e < 8; ++e) acc[e] += v[u].v[e];
       }
     }
+    if constexpr (VEC == 4) {          // f32: one 16-byte load per thread (8 columns per thread = two half-used requests)
+      for (; m + 7 * step < M; m += 8 * step) {
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(x + (int64_t)(m + u * step) * ld + col);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { acc[0] += v[u].x; acc[1] += v[u].y; acc[2] += v[u].z; acc[3] += v[u].w; }
+      }
+    }
     for (; m < M; m += step) {
       if constexpr (VEC == 8) {
         Vec8<T> v;
         v.load(x + (int64_t)m * ld + col);
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[e] += v.v[e];
+      } else if constexpr (VEC == 4) {
+        const float4 v = *reinterpret_cast<const float4*>(x + (int64_t)m * ld + col);
+        acc[0] += v.x; acc[1] += v.y; acc[2] += v.z; acc[3] += v.w;
       } else {
         acc[0] += to_f32<T>(x[(int64_t)m * ld + col]);
       }
@@ -195,14 +207,17 @@ extern "C" int w2v2_colsum(const void* x, int64_t ld, float* out, int M, int N, 
   W2V2_REQUIRE(x && out && M >= 0 && N > 0 && ld >= N, "colsum: bad arguments");
   if (M == 0) return 0;
   const bool vec = (N % 8 == 0) && (ld % 8 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
-  const int VECW = vec ? 8 : 1;
+  const int VECW = vec ? (dtype == W2V2_F32 ? 4 : 8) : 1;
   int gy = (int)cdiv(M, 4 * 64);
   if (gy > 64) gy = 64;
   if (gy < 1) gy = 1;
   dim3 grid((unsigned)cdiv(N, 64 * VECW), gy), block(64, 4);
   hipStream_t st = as_stream(stream);
   W2V2_DISPATCH_ACT(dtype, "colsum", {
-    if (vec) hipLaunchKernelGGL((colsum_kernel<AT, 8>), grid, block, 0, st, (const AT*)x, ld, out, M, N);
+    if (vec) {
+      if constexpr (sizeof(AT) == 4) hipLaunchKernelGGL((colsum_kernel<float, 4>), grid, block, 0, st, (const float*)x, ld, out, M, N);
+      else hipLaunchKernelGGL((colsum_kernel<AT, 8>), grid, block, 0, st, (const AT*)x, ld, out, M, N);
+    }
     else hipLaunchKernelGGL((colsum_kernel<AT, 1>), grid, block, 0, st, (const AT*)x, ld, out, M, N);
   });
   W2V2_CHECK_LAUNCH("colsum");
