@@ -129,6 +129,10 @@ int w2v2_tune_gemm_debug(int bits);
  * (csrc/gemm_f32_dma.hip) on (32 fi) x 128 tiles, fi = tile - 10; + 100 = the same with XCD-contiguous tile order.  A product the LDS-DMA kernel cannot take (segmented or
  * unaligned operands, K % 4 != 0, M or N <= 64) ignores codes >= 11.  Returns the previous setting. */
 int w2v2_tune_gemm_f32_tile(int tile);
+/* Tools only: time-attribution variants of the 256x128 ring GEMM's K loop (results are garbage) -- bit 0 no LDS-DMA pieces in
+ * the steady-state loop, 1 no barrier, 2 no vmcnt wait, 3 no fragment reads.  Returns the previous setting; 0 = the product
+ * kernel. */
+int w2v2_tune_gemm_ring_debug(int bits);
 /* Tools / tests: which kernel the LAST exact-f32 product ran on -- 0 = register-staged, else 10 fi + stages of the
  * LDS-DMA kernel (e.g. 52 = 160 x 128 tiles, two-stage ring). */
 int w2v2_gemm_f32_last_kernel(void);

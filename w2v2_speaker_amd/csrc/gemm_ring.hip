@@ -16,7 +16,7 @@ template <int S> __device__ __forceinline__ void wait_vmcnt() {
   else static_assert(S == 0 || S == 4 || S == 6 || S == 8, "unsupported count");
 }
 
-template <typename TE, typename TC>
+template <typename TE, typename TC, bool DBG = false>
 __global__ __launch_bounds__(512) void gemm16_ring_256x128_kernel(const GemmArgs g) {
   constexpr int BM = 256, BN = 128, FM = 4, FN = 4;
   constexpr int STAGE = (BM + BN) * 64;           // elements per stage (A then B)
@@ -141,7 +141,11 @@ __global__ __launch_bounds__(512) void gemm16_ring_256x128_kernel(const GemmArgs
   };
   // multiply stage `base`; when kload >= 0 the DMA pieces of K tile kload go to `nxt`, spread over the MFMA groups
   // (issued back to back behind the barrier they keep both waves of a SIMD in the queue-limited DMA issue)
+  // tools only (w2v2_tune_gemm_ring_debug, carried in g.late_dma for ring launches; results are garbage):
+  //   1 = no DMA pieces in the steady-state loop, 2 = no barrier in the loop, 4 = no vmcnt wait in the loop, 8 = no fragment reads
+  const int dbg = DBG ? g.late_dma : 0;
   auto compute = [&](const bf16_t* base, bf16_t* nxt, int kload) {
+    if (dbg & 1) kload = -1;
     const bf16_t* a0 = base + aoff + lo0;
     const bf16_t* a1 = base + aoff + lo1;
     const bf16_t* b0 = base + boff + lb0;
@@ -149,10 +153,17 @@ __global__ __launch_bounds__(512) void gemm16_ring_256x128_kernel(const GemmArgs
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       frag8_t af[FM], bfr[FN];
+      if (DBG && (dbg & 8)) {                      // registers as they are (no load, nothing kept live for it)
 #pragma unroll
-      for (int i = 0; i < FM; ++i) af[i] = *reinterpret_cast<const frag8_t*>((kk ? a1 : a0) + i * 16 * 64);
+        for (int i = 0; i < FM; ++i) asm volatile("" : "=v"(af[i]));
 #pragma unroll
-      for (int j = 0; j < FN; ++j) bfr[j] = *reinterpret_cast<const frag8_t*>((kk ? b1 : b0) + j * 4 * 64);
+        for (int j = 0; j < FN; ++j) asm volatile("" : "=v"(bfr[j]));
+      } else {
+#pragma unroll
+        for (int i = 0; i < FM; ++i) af[i] = *reinterpret_cast<const frag8_t*>((kk ? a1 : a0) + i * 16 * 64);
+#pragma unroll
+        for (int j = 0; j < FN; ++j) bfr[j] = *reinterpret_cast<const frag8_t*>((kk ? b1 : b0) + j * 4 * 64);
+      }
 #pragma unroll
       for (int i = 0; i < FM; ++i) {
 #pragma unroll
@@ -177,8 +188,8 @@ __global__ __launch_bounds__(512) void gemm16_ring_256x128_kernel(const GemmArgs
   // one ring step: tile kt is in `cur`; tile kt+2 goes to `nxt` (which held tile kt-1)
 #define W2V2_RING_STEP(cur, nxt)                                   \
   {                                                                \
-    if (kt + 1 < nk) wait_vmcnt<6>(); else wait_vmcnt<0>();        \
-    __builtin_amdgcn_s_barrier();                                  \
+    if (!(dbg & 4)) { if (kt + 1 < nk) wait_vmcnt<6>(); else wait_vmcnt<0>(); }   \
+    if (!(dbg & 2)) __builtin_amdgcn_s_barrier();                  \
     compute(cur, nxt, kt + 2 < nk ? kt + 2 : -1);                  \
     ++kt;                                                          \
   }
@@ -246,12 +257,12 @@ __global__ __launch_bounds__(512) void gemm16_ring_256x128_kernel(const GemmArgs
   if (pending) flush(std::integral_constant<int, 0>{}, std::integral_constant<int, 8>{});
 }
 
-template <typename TE, typename TC>
-static void launch_ring(GemmArgs a, int M, int N, int batch, bool persistent, hipStream_t st) {
+template <typename TE, typename TC, bool DBG>
+static void launch_ring_v(GemmArgs a, int M, int N, int batch, bool persistent, hipStream_t st) {
   constexpr size_t lds = (size_t)3 * (256 + 128) * 64 * sizeof(bf16_t);   // 144 KiB
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm16_ring_256x128_kernel<TE, TC>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm16_ring_256x128_kernel<TE, TC, DBG>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
@@ -260,11 +271,25 @@ static void launch_ring(GemmArgs a, int M, int N, int batch, bool persistent, hi
   const int ncu = persistent ? w2v2_gemm_device_cus() : (1 << 30);
   const int tiles = a.tiles_m * a.tiles_n;
   dim3 grid(tiles < ncu ? tiles : ncu, 1, batch);
-  W2V2_LAUNCH_MAYBE_TIMED((gemm16_ring_256x128_kernel<TE, TC>), grid, dim3(512), lds, st, a);
+  W2V2_LAUNCH_MAYBE_TIMED((gemm16_ring_256x128_kernel<TE, TC, DBG>), grid, dim3(512), lds, st, a);
+}
+template <typename TE, typename TC>
+static void launch_ring(GemmArgs a, int M, int N, int batch, bool persistent, hipStream_t st) {
+  if (a.late_dma != 0 && sizeof(TC) == 2 && sizeof(TE) == 2 && std::is_same<TE, f16_t>::value)
+    launch_ring_v<f16_t, f16_t, true>(a, M, N, batch, persistent, st);      // tools: attribution variants, fp16 in / fp16 out only
+  else launch_ring_v<TE, TC, false>(a, M, N, batch, persistent, st);
 }
 
-void w2v2_launch_ring_256x128(const GemmArgs& a, int dtype_ab, int dtype_c, int M, int N, int batch, bool persistent,
+static int g_ring_dbg = 0;            // tools only: time-attribution variants of the ring kernel's K loop (garbage results)
+extern "C" int w2v2_tune_gemm_ring_debug(int bits) {
+  const int old = g_ring_dbg;
+  g_ring_dbg = bits & 31;          // bit 4: the attribution kernel with nothing removed (its own baseline)
+  return old;
+}
+void w2v2_launch_ring_256x128(const GemmArgs& a_in, int dtype_ab, int dtype_c, int M, int N, int batch, bool persistent,
                               hipStream_t st) {
+  GemmArgs a = a_in;
+  a.late_dma = g_ring_dbg;
   if (dtype_ab == W2V2_BF16) {
     if (dtype_c == W2V2_F32) launch_ring<bf16_t, float>(a, M, N, batch, persistent, st);
     else launch_ring<bf16_t, bf16_t>(a, M, N, batch, persistent, st);
