@@ -735,7 +735,7 @@ def test_no_compiler_vmcnt_inside_the_k_loops_of_the_lds_dma_gemms():
     if not os.path.exists("/opt/rocm/bin/hipcc") and shutil.which("hipcc") is None:
         pytest.skip("no hipcc")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for src, pat in (("gemm_ring.hip", "IDF16_DF16_E"), ("gemm_phased.hip", "IDF16_DF16_Li0E")):
+    for src, pat in (("gemm_ring.hip", "IDF16_DF16_Lb0E"), ("gemm_phased.hip", "IDF16_DF16_Li0E")):
         out = subprocess.run(["bash", os.path.join(root, "tools", "loop_waits.sh"), src, pat], capture_output=True, text=True,
                              timeout=600).stdout
         assert "_Z" in out, (src, out[-400:])                   # the kernel was found and compiled

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Compiler-inserted `s_waitcnt vmcnt(n)` (i.e. those NOT inside an inline-assembly block) of the kernels matching <regex> in one
 # .hip file, with the loop / block they sit in -- a wait at the header of a K loop is executed in every iteration and also waits for
-# every LDS-DMA piece in flight.   bash tools/loop_waits.sh gemm_ring.hip "IDF16_DF16_E"
+# every LDS-DMA piece in flight.   bash tools/loop_waits.sh gemm_ring.hip "IDF16_DF16_Lb0E"
 f=$1; pat=${2:-.}
 root=$(dirname "$(dirname "$(realpath "$0")")")
 cd /tmp && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -I$root/include -I$root/w2v2_speaker_amd/csrc --cuda-device-only -S $root/w2v2_speaker_amd/csrc/$f -o /tmp/lw.s 2>/dev/null
