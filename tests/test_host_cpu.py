@@ -517,7 +517,7 @@ def test_hot_kernels_use_no_scratch(tmp_path):
     lib = tmp_path / "lib.so"
     shutil.copy(_build.LIB, lib)
     subprocess.run([objdump, "--offloading", str(lib)], cwd=tmp_path, capture_output=True, check=True)
-    allowed = re.compile(r"gemm16_ring_256x256_kernel|gemm16_ring_256x128_kernelI\w+fEv|ln_bwd_kernelIfE|gemm_f32_kernel")
+    allowed = re.compile(r"gemm16_ring_256x256_kernel|gemm16_ring_256x128_kernelI\w+fLb0EEv|ln_bwd_kernelIfE|gemm_f32_kernel")
     spills, seen = [], 0
     for f in tmp_path.glob("lib.so.*gfx950"):
         notes = subprocess.run([readelf, "--notes", str(f)], capture_output=True, text=True, check=True).stdout
