@@ -248,8 +248,11 @@ class _Tdnn:
     """TDNNBlock = Conv1d("same", reflect, dilation) -> ReLU -> BatchNorm1d over one [M, Cin] view -> [M, Cout] view."""
 
     def __init__(self, plan: "EcapaPlan", prefix: str, x: torch.Tensor, ldx: int, cin: int, cout: int, k: int, dil: int,
-                 y: torch.Tensor, ldy: int, x2: Optional[torch.Tensor] = None, ldx2: int = 0):
-        """x2 (k > 1 only): the block convolves x + x2 -- the im2col pass sums the two while it gathers the taps."""
+                 y: torch.Tensor, ldy: int, x2: Optional[torch.Tensor] = None, ldx2: int = 0,
+                 shared: Optional[dict] = None):
+        """x2 (k > 1 only): the block convolves x + x2 -- the im2col pass sums the two while it gathers the taps.
+        shared (exact-f32 training, Res2Net chunks): {"col", "da", "dwp"} views into the owner's [chunks, ...] arrays -- the
+        owner then computes the weight gradients of all its chunks in ONE batched product (_SERes2Net.backward)."""
         st, B, T, dev, adt, f32 = plan.store, plan.B, plan.T, plan.dev, plan.adt, torch.float32
         assert x2 is None or k > 1, "a second input operand needs the im2col pass (k > 1)"
         self.plan, self.pre, self.x, self.ldx, self.y, self.ldy = plan, FE + prefix, x, ldx, y, ldy
@@ -258,7 +261,8 @@ class _Tdnn:
         M, K = B * T, k * cin
         self.M, self.K = M, K
         self.wp, self.wpt = plan.weight_pair(cout, K)                          # packed [cout][tap][cin] operand (+ its transpose)
-        self.col = plan.buf(M, K) if k > 1 else None
+        self.shared = shared
+        self.col = (shared["col"] if shared else plan.buf(M, K)) if k > 1 else None
         self.a = torch.empty(M, cout, dtype=adt, device=dev)                   # pre-activation (saved)
         self.mean_rstd = torch.empty(cout, 2, dtype=f32, device=dev)
         self.running = st.running(self.pre + "norm.norm.weight")            # shared BatchNorm1d buffers (store)
@@ -267,9 +271,9 @@ class _Tdnn:
         self.g_fwd = Gemm(M, cout, K, A, self.wp, self.a, lda=lda, ldb=K, ldc=cout, epilogue=EPI_BIAS,
                           bias=st.p(self.pre + "conv.conv.bias"))
         if plan.train:
-            self.da = plan.buf(M, cout)
+            self.da = shared["da"] if shared else plan.buf(M, cout)
             self.cs_part = torch.empty(ops.bn_colsum_rows(M, cout), cout, dtype=f32, device=dev)   # bias-gradient partials
-            self.dwp = torch.zeros(cout, K, dtype=f32, device=dev) if k > 1 else None
+            self.dwp = (shared["dwp"] if shared else torch.zeros(cout, K, dtype=f32, device=dev)) if k > 1 else None
             dW = self.dwp if k > 1 else st.g(self.pre + "conv.conv.weight").view(cout, cin)
             # bf16: weight + bias gradient through the grouped, atomic-free wgrad kernels (K-major operands: da and the
             # conv input / im2col buffer, both zero-padded to a multiple of 64 rows), launched per group by the owner
@@ -332,7 +336,7 @@ class _Tdnn:
         ops.bn_bwd(dy, lddy, self.a, self.cout, self.mean_rstd, st.p(self.pre + "norm.norm.weight"), self.work,
                    st.g(self.pre + "norm.norm.weight"), st.g(self.pre + "norm.norm.bias"), self.da, self.cout, self.M,
                    self.cout, True, colsum_partial=None if self.grouped else self.cs_part, dy2=dy2, lddy2=lddy2)
-        if not (self.grouped and defer_dw):
+        if not ((self.grouped or self.shared) and defer_dw):
             self.weight_grad_single()
         if dx is None:
             return
@@ -408,12 +412,34 @@ class _SERes2Net:
         fuse = cfg.kernel_sizes[idx] > 1
         self.sums = [None, None] + [None if fuse else e(w) for _ in range(2, sc)]
         self.chunks: List[Optional[_Tdnn]] = [None]
+        # exact-f32 training: the sc - 1 chunk convolutions share one [chunks, M, .] array per operand, so that their weight
+        # gradients -- 3-tile outputs over 19800 tokens, 30 us each as separate split-K launches -- are ONE batched product
+        kk = cfg.kernel_sizes[idx]
+        self.batched = bool(plan.train and not ops.is16(adt) and kk > 1 and sc > 2 and
+                            not os.environ.get("W2V2_ECAPA_NO_BATCHED_DW"))
+        if self.batched:
+            n, Mp, Kc = sc - 1, (M + 63) // 64 * 64, kk * w
+            self._col_all = torch.zeros(n, Mp, Kc, dtype=adt, device=dev)
+            self._da_all = torch.zeros(n, Mp, w, dtype=adt, device=dev)
+            self._dwp_all = torch.zeros(n, w, Kc, dtype=torch.float32, device=dev)
         for i in range(1, sc):
             x2, ldx2 = (self.r2[:, (i - 1) * w:i * w], C) if (fuse and i >= 2) else (None, 0)
             src, ld = (_cols(self.t1, i * w, (i + 1) * w), C) if (i == 1 or fuse) else (self.sums[i], w)
+            shared = ({"col": self._col_all[i - 1, :M], "da": self._da_all[i - 1, :M], "dwp": self._dwp_all[i - 1]}
+                      if self.batched else None)
             self.chunks.append(_Tdnn(plan, p + f"res2net_block.blocks.{i - 1}.", src, ld, w, w,
                                      cfg.kernel_sizes[idx], cfg.dilations[idx], self.r2[:, i * w:(i + 1) * w], C,
-                                     x2=x2, ldx2=ldx2))
+                                     x2=x2, ldx2=ldx2, shared=shared))
+        if self.batched:
+            n, Mp, Kc = sc - 1, (M + 63) // 64 * 64, kk * w
+            # split-K so that the batch fills the 512 workgroup slots once (7 chunks x 3 tiles x 24: measured best of 4 .. 32,
+            # 23.66 -> 23.3 ms/step; W2V2_ECAPA_BDW_SPLIT overrides)
+            tiles = -(-w // 128) * -(-Kc // 128)
+            split = int(os.environ.get("W2V2_ECAPA_BDW_SPLIT", "0")) or max(1, min(32, 512 // (n * tiles)))
+            self._dw_ztab = torch.tensor([[0, n * w * Kc]], dtype=torch.int64, device=dev)
+            self._g_dw_all = Gemm(w, Kc, M, self._da_all, self._col_all, self._dwp_all, lda=w, ldb=Kc, ldc=Kc, transA=True,
+                                  transB=True, batch=n, a_strides=(Mp * w, 0), b_strides=(Mp * Kc, 0),
+                                  c_strides=(w * Kc, 0), split_k=split, accumulate=True)
         self.tdnn2 = _Tdnn(plan, p + "tdnn2.", self.r2, C, C, C, 1, 1, self.t2, C)
         self.se = _SEBlock(plan, p + "se_block.", self.t2, self.se_out, C)
         if plan.train:
@@ -448,6 +474,13 @@ class _SERes2Net:
             dy2, ld2 = (self.d_t1[:, (i + 1) * w:(i + 2) * w], C) if i < sc - 1 else (None, 0)
             self.chunks[i].backward(self.d_r2[:, i * w:(i + 1) * w], C, self.d_t1[:, i * w:(i + 1) * w], C, False,
                                     defer_dw=True, dy2=dy2, lddy2=ld2)
+        if self.batched:            # the chunks' weight gradients: one zeroing, one batched split-K product, then per chunk the
+            st = self.plan.store    # bias fold (BatchNorm backward's row-block partials) and the unpack into the arena
+            ops.zero_ranges(self._dwp_all.view(-1), self._dw_ztab, blocks_per_range=64)
+            self._g_dw_all()
+            for c in self.chunks[1:]:
+                ops.colsum(c.cs_part, st.g(c.pre + "conv.conv.bias"), c.cs_part.shape[0], c.cout)
+                c.finish_weight_grad()
         ops.copy_strided(self.d_r2, C, self.d_t1, C, M, w)
         self.tdnn1.backward(self.d_t1, C, dx, lddx, accumulate, defer_dw=True)
         # residual: dx += dout
