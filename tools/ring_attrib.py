@@ -2,7 +2,7 @@
 """Time attribution of the 256x128 ring GEMM (the dominant kernel of the step): the products of one transformer block that run on
 it, stand-alone, with parts of the K loop compiled out by w2v2_tune_gemm_ring_debug (garbage results, timing only):
     16 the attribution kernel with nothing removed (its own baseline)   + 1 no LDS-DMA pieces in the
-    steady-state loop   + 2 no barrier   + 4 no vmcnt wait   + 8 no fragment reads (combinations add); 0 = the product kernel
+    steady-state loop   + 2 no barrier   + 4 no vmcnt wait   + 8 no fragment reads   + 32 no epilogue (combinations add); 0 = the product kernel
 Median of ROUNDS interleaved rounds of 5 launches.   python3 tools/ring_attrib.py"""
 import os
 import statistics
@@ -16,8 +16,8 @@ lib = _lib.load()
 dev = "cuda"
 M = 66 * 149
 shapes = [("out-proj (single term)", M, 768, 768), ("QKV (single term)", M, 2304, 768), ("FFN2 / dX1", M, 768, 3072),
-          ("dX (K = 2304)", M, 768, 2304)]
-codes = [int(c) for c in os.environ.get("CODES", "0 16 17 18 20 24 25 30 31").split()]
+          ("dX (K = 2304)", M, 768, 2304), ("one K tile (N = 768)", M, 768, 64), ("two K tiles (N = 768)", M, 768, 128)]
+codes = [int(c) for c in os.environ.get("CODES", "0 16 17 18 20 24 25 30 31 48 63").split()]
 rounds = int(os.environ.get("ROUNDS", "5"))
 print(f"{'product':24s} {'M':>5} {'N':>5} {'K':>5} " + " ".join(f"{c:>7d}" for c in codes) + "   us (median); code 31 = bare MFMA loop + prologue + epilogue")
 for name, m, n, k in shapes:

@@ -232,6 +232,7 @@ __global__ __launch_bounds__(512) void gemm16_ring_256x128_kernel(const GemmArgs
   // Register epilogue: thanks to the permuted B rows a lane holds, for each of its four rows, 16 consecutive
   // output columns (32 B of bf16): bias / GELU / residual are applied in registers and stored as 2 x 16 B per lane,
   // four lanes covering 128 contiguous bytes of a row -- no LDS round trip and no barrier after the main loop.
+  if (DBG && (dbg & 32)) { if (g.M > 0) { asm volatile("" :: "v"(acc[0][0]), "v"(acc[3][3])); continue; } }   // (tools: no epilogue)
   TC* Cz = reinterpret_cast<TC*>(g.C) + z0 * g.c_s0 + z1 * g.c_s1;
   TC* auxz = g.aux ? reinterpret_cast<TC*>(g.aux) + z0 * g.aux_s0 + z1 * g.aux_s1 : nullptr;
   const float* bias = g.bias ? g.bias + z1 * g.bias_s1 : nullptr;
@@ -283,7 +284,7 @@ static void launch_ring(GemmArgs a, int M, int N, int batch, bool persistent, hi
 static int g_ring_dbg = 0;            // tools only: time-attribution variants of the ring kernel's K loop (garbage results)
 extern "C" int w2v2_tune_gemm_ring_debug(int bits) {
   const int old = g_ring_dbg;
-  g_ring_dbg = bits & 31;          // bit 4: the attribution kernel with nothing removed (its own baseline)
+  g_ring_dbg = bits & 63;          // bit 4: the attribution kernel with nothing removed (its own baseline); bit 5: no epilogue
   return old;
 }
 void w2v2_launch_ring_256x128(const GemmArgs& a_in, int dtype_ab, int dtype_c, int M, int N, int batch, bool persistent,
