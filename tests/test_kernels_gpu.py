@@ -359,6 +359,34 @@ def test_gemm_f32_lds_dma_tiles(ta, tb, code):
         lib.w2v2_tune_gemm_f32_tile(old)
 
 
+def test_lds_dma_gemms_bit_stable_over_repeated_launches():
+    """The LDS-DMA pieces of the ring / phased / f32 GEMMs are inline assembly the compiler does not order (round 6: its own
+    conservative vmcnt(0) in the K loops was the price of the builtin) -- a missing counted wait would be an intermittent
+    difference between launches on the same operands.  40 launches per product against the first, bit for bit; the same
+    check with 400 launches per product is tools/gemm_race_check.py (profiles/r06_gemm_race_check.txt)."""
+    o = ops()
+    M = 66 * 149
+    for (m, n, k, dt, name) in [(M, 768, 768, torch.float16, "gemm16_ring_256x128_kernel"),
+                                (M, 3072, 768, torch.float16, "gemm16_phased_256x256_kernel"),
+                                (M, 768, 3072, torch.float16, "gemm16_ring_256x128_kernel"),
+                                (19800, 1024, 1024, torch.float32, "gemm_f32_dma_kernel"),
+                                (4004, 260, 100, torch.float32, "gemm_f32_dma_kernel")]:
+        A, Bm = rnd(m, k, seed=m + k, scale=0.2).to(dt).to(DEV), rnd(n, k, seed=n + k, scale=0.2).to(dt).to(DEV)
+        bias = rnd(n, seed=n).to(DEV)
+        C = torch.zeros(m, n, dtype=dt, device=DEV)
+        gm = o.Gemm(m, n, k, A, Bm, C, lda=k, ldb=k, ldc=n, epilogue=o.EPI_BIAS, bias=bias)
+        assert gm.kernel_name == name
+        gm()
+        ref = C.clone()
+        tol = 5e-3 if dt == torch.float16 else 1e-5
+        assert float((ref.float() - (A.float() @ Bm.float().t() + bias)).abs().max()) < tol * max(1.0, k ** 0.5 / 8)
+        for r in range(40):
+            C.zero_()
+            gm()
+            if r % 8 == 7:
+                assert torch.equal(C, ref), (name, m, n, k, r)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 def test_gemm_batched_heads_and_implicit_conv(dtype):
     o = ops()
