@@ -265,12 +265,16 @@ __global__ __launch_bounds__(256) void gemm16_dma_128_kernel(const GemmArgs g) {
   auto stage = [&](int buf, int kt) {
     bf16_t* ad = As + buf * BM * 64 + wave * NA * 8 * 64;
     bf16_t* bd = Bs + buf * BN * 64 + wave * NB * 8 * 64;
+    // (inline-assembly pieces, common.h: behind the builtin the compiler put `s_waitcnt vmcnt(0)` in front of the first fragment
+    // read of the tile being multiplied -- the tile just issued was waited for before anything overlapped it)
 #pragma unroll
-    for (int j = 0; j < NA; ++j)
-      __builtin_amdgcn_global_load_lds((gvoid_t*)(ap[j] + kt * 64), (lvoid_t*)(ad + j * 8 * 64), 16, 0, 0);
+    for (int j = 0; j < NA; ++j) w2v2_dma16(ap[j] + kt * 64, ad + j * 8 * 64);
 #pragma unroll
-    for (int j = 0; j < NB; ++j)
-      __builtin_amdgcn_global_load_lds((gvoid_t*)(bp[j] + kt * 64), (lvoid_t*)(bd + j * 8 * 64), 16, 0, 0);
+    for (int j = 0; j < NB; ++j) w2v2_dma16(bp[j] + kt * 64, bd + j * 8 * 64);
+  };
+  auto landed = [&]() {                           // this wave's pieces are in; the barrier then makes every wave's visible
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
   };
   const int frow = lane & 15, fk = lane >> 4;
   auto compute = [&](int buf) {
@@ -298,15 +302,16 @@ __global__ __launch_bounds__(256) void gemm16_dma_128_kernel(const GemmArgs g) {
   };
 
   if (nk > 0) stage(0, 0);
+  w2v2_vmcnt0_visible();                          // (common.h: nothing of the compiler's own left to guard inside the loop)
   __syncthreads();
   for (int kt = 0; kt < nk; kt += 2) {
     if (kt + 1 < nk) stage(1, kt + 1);
     compute(0);
-    __syncthreads();
+    landed();
     if (kt + 1 < nk) {
       if (kt + 2 < nk) stage(0, kt + 2);
       compute(1);
-      __syncthreads();
+      landed();
     }
   }
 
