@@ -334,6 +334,8 @@ def test_gemm_f32_lds_dma_tiles(ta, tb, code):
     operand layouts; ragged M / N (zero-source lanes), K tails inside a tile and inside a split, split-K atomics, the
     epilogues of the ECAPA step.  Tolerance 2e-5 relative l2 against f64 (as test_gemm_f32_exact)."""
     from w2v2_speaker_amd import _lib
+    if os.environ.get("W2V2_F32_NO_DMA"):
+        pytest.skip("W2V2_F32_NO_DMA sends every f32 product to the register-staged kernel")
     o, lib = ops(), _lib.load()
     old = lib.w2v2_tune_gemm_f32_tile(code)
     try:
@@ -375,7 +377,8 @@ def test_lds_dma_gemms_bit_stable_over_repeated_launches():
         bias = rnd(n, seed=n).to(DEV)
         C = torch.zeros(m, n, dtype=dt, device=DEV)
         gm = o.Gemm(m, n, k, A, Bm, C, lda=k, ldb=k, ldc=n, epilogue=o.EPI_BIAS, bias=bias)
-        assert gm.kernel_name == name
+        if not any(os.environ.get(e) for e in ("W2V2_NO_GEMM_PH", "W2V2_NO_GLDS3", "W2V2_NO_GLDS", "W2V2_F32_NO_DMA", "W2V2_G3N")):
+            assert gm.kernel_name == name            # (the A/B switches of the library move products between kernels)
         gm()
         ref = C.clone()
         tol = 5e-3 if dt == torch.float16 else 1e-5
